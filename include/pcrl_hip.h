@@ -1,0 +1,191 @@
+/*
+ * pcrl_hip.h -- C ABI of libpcrl_hip.so: the MI355X (gfx950) native operator layer of the
+ * PCRLv2 3D pre-training hot path.
+ *
+ * The reference (RL4M/PCRLv2) has no FFI of its own: its operator boundary is torch.nn /
+ * autograd.  Each entry point below replaces the ATen operator that the cited
+ * reference line dispatches.  Paths are relative to the reference repository.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch types.  All pointers are DEVICE pointers.
+ *   - Activations are NDHWC ("channels last 3d"): element (n,d,h,w,c) at (((n*D+d)*H+h)*W+w)*C+c.
+ *     `dtype` selects the activation / packed-weight storage type: PCRL_F32 or PCRL_BF16.
+ *     Accumulation, statistics, 1-channel maps, head tensors, gradients of parameters and the
+ *     parameters themselves ("*_ref" pointers, reference layout) are always float32.
+ *   - Every call is asynchronous on `stream`; nothing synchronises, allocates or frees.
+ *     The caller owns all memory, including workspaces (sizes from the *_ws_bytes helpers).
+ *   - Returns 0 on success, a negative PCRL_E* code on failure; pcrl_last_error() returns a
+ *     thread-local message.  Nothing throws across the ABI.  Re-entrant: no mutable globals.
+ *   - Reductions are deterministic (two-stage, fixed order; no floating-point atomics).
+ */
+#ifndef PCRL_HIP_H
+#define PCRL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pcrl_stream_t; /* hipStream_t */
+
+enum { PCRL_F32 = 0, PCRL_BF16 = 1 };
+enum { PCRL_ACT_NONE = 0, PCRL_ACT_RELU = 1, PCRL_ACT_SIGMOID = 2 };
+enum { PCRL_OK = 0, PCRL_EINVAL = -1, PCRL_ELAUNCH = -2, PCRL_EWORKSPACE = -3 };
+
+#define PCRL_CONV_BM 128 /* rows (voxels) per conv tile == rows per BN-statistics partial */
+
+const char* pcrl_version(void);
+const char* pcrl_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Weight packing (once per optimizer step).  Reference layouts: Conv3d weight [Co][Ci][3][3][3]
+ * (models/pcrlv2_model_3d.py:9), ConvTranspose3d weight [Ci][Co][2][2][2] (:52).
+ *   conv3 : w_fwd[co][t][ci]           (t = kd*9+kh*3+kw)         -- B^T operand of the forward GEMM
+ *           w_dgrad[ci][26-t][co]                                   -- B^T operand of the data-gradient GEMM
+ *   convT : w_fwd[t][co][ci]           (t = i*4+j*2+k)
+ *           w_dgrad[ci][t][co]
+ * Either output pointer may be NULL. */
+int pcrl_pack_conv3_weight(const float* w_ref, void* w_fwd, void* w_dgrad, int Co, int Ci, int dtype, pcrl_stream_t stream);
+int pcrl_pack_convt_weight(const float* w_ref, void* w_fwd, void* w_dgrad, int Ci, int Co, int dtype, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * 3x3x3 convolution, pad 1, stride 1 -- aten::convolution at pcrlv2_model_3d.py:9,33 (LUConv.conv1).
+ * Implicit GEMM on MFMA: M = N*D*H*W voxels, N = Co, K = 27*Ci.  Ci % 32 == 0, Co % 32 == 0.
+ *   y[m][co] = bias[co] + sum_{t,ci} x[m+delta_t][ci] * wp[co][t][ci]      (zero outside the volume)
+ * `stats_partial` (optional): [ceil(M/128)][Co][2] float; row r receives (sum y, sum y^2) of tile r, taken
+ * from the fp32 accumulators, for the training-mode BatchNorm that follows (:12,33).
+ * The data gradient (aten::convolution_backward, input half) is the same call with wp = w_dgrad,
+ * Ci/Co exchanged, bias = NULL, stats_partial = NULL. */
+int pcrl_conv3d_k3_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial,
+                       int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
+
+/* Weight gradient (aten::convolution_backward, weight half).  dw_ref[co][ci][27] float32, reference layout.
+ * Split-K over voxels with a fixed-order second pass.  ws: pcrl_conv3d_k3_wgrad_ws_bytes(). */
+size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co);
+int pcrl_conv3d_k3_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes,
+                         int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
+
+/* First layer, Ci == 1 (pcrlv2_model_3d.py:101 -> down_tr64.ops.0, K = 27: HBM-bound, no MFMA).
+ * x: float32 scalar field [M]; w_ref [Co][1][27] float32; y: dtype [M][Co]; Co % 8 == 0, Co <= 64. */
+int pcrl_conv3d_k3_c1_fwd(const float* x, const float* w_ref, const float* bias, void* y, float* stats_partial,
+                          int N, int D, int H, int W, int Co, int dtype, pcrl_stream_t stream);
+size_t pcrl_conv3d_k3_c1_wgrad_ws_bytes(int N, int D, int H, int W, int Co);
+int pcrl_conv3d_k3_c1_wgrad(const float* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes,
+                            int N, int D, int H, int W, int Co, int dtype, pcrl_stream_t stream);
+
+/* Convolutions with ONE output channel: deep-supervision head conv3x3x3 C->1 (pcrlv2_model_3d.py:60,71)
+ * and OutputTransition.final_conv 1x1x1 64->1 (:78).  taps = 27 or 1.  y, dy: float32 [M].
+ * w_ref: [1][C][taps] float32.  `stats_partial`: [ceil(M/1024)][1][2] or NULL.
+ * dgrad: dx[m][c] (+)= sum_t dy[m-delta_t] * w[c][t]; accumulate != 0 adds into dx. */
+int pcrl_conv3d_to1_fwd(const void* x, const float* w_ref, const float* bias, float* y, float* stats_partial,
+                        int N, int D, int H, int W, int C, int taps, int dtype, pcrl_stream_t stream);
+int pcrl_conv3d_to1_dgrad(const float* dy, const float* w_ref, void* dx, int accumulate,
+                          int N, int D, int H, int W, int C, int taps, int dtype, pcrl_stream_t stream);
+size_t pcrl_conv3d_to1_wgrad_ws_bytes(int N, int D, int H, int W, int C, int taps);
+int pcrl_conv3d_to1_wgrad(const void* x, const float* dy, float* dw_ref, float* db, void* ws, size_t ws_bytes,
+                          int N, int D, int H, int W, int C, int taps, int dtype, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * ConvTranspose3d kernel 2 stride 2 -- aten::convolution (transposed) at pcrlv2_model_3d.py:52,64.
+ * N,D,H,W are the INPUT dims; the output is [N][2D][2H][2W][Co].  Eight independent GEMMs with a
+ * scatter store (fwd) / one K = 8*Co gather GEMM (dgrad).  Ci % 32 == 0, Co % 32 == 0. */
+int pcrl_convt3d_k2s2_fwd(const void* x, const void* wp_fwd, const float* bias, void* y,
+                          int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
+int pcrl_convt3d_k2s2_dgrad(const void* dy, const void* wp_dgrad, void* dx,
+                            int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
+size_t pcrl_convt3d_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co);
+int pcrl_convt3d_k2s2_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes,
+                            int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
+
+/* Per-channel column sum of a [M][C] activation (bias gradients): out[c] = sum_m v[m][c].
+ * ws: pcrl_colsum_ws_bytes(M, C). */
+size_t pcrl_colsum_ws_bytes(int64_t M, int C);
+int pcrl_colsum(const void* v, float* out, void* ws, size_t ws_bytes, int64_t M, int C, int dtype, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Training-mode BatchNorm3d + activation -- aten::native_batch_norm(+_backward), relu_, sigmoid
+ * at pcrlv2_model_3d.py:12,21,27,33.  Statistics arrive as per-tile partials from the conv epilogue.
+ *   finalize : mean, biased var over `count` elements per channel (fp64 fixed-order reduction);
+ *              running_mean/var updated in place (momentum, unbiased var), num_batches_tracked is the
+ *              caller's; emits mean, rstd and the fused apply coefficients scale = gamma*rstd,
+ *              shift = beta - mean*scale.
+ *   apply    : a = act(scale[c]*y + shift[c])
+ *   bwd      : dz = da*act'(z);  reduce -> partial (sum dz, sum dz*xhat) per 1024-row tile;
+ *              bwd_finalize -> dgamma, dbeta and coefficients k1,kB,kA;  bwd_apply: dy = k1*dz + kB*y + kA. */
+int pcrl_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps,
+                     float* mean, float* rstd, float* scale, float* shift, pcrl_stream_t stream);
+int pcrl_bn_act_apply(const void* y, void* a, const float* scale, const float* shift,
+                      int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
+int64_t pcrl_bn_bwd_partial_rows(int64_t M);
+int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, const float* shift,
+                           const float* mean, const float* rstd, float* partial,
+                           int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
+int pcrl_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* mean,
+                         const float* rstd, float* dgamma, float* dbeta, float* k1, float* kB, float* kA,
+                         pcrl_stream_t stream);
+int pcrl_bn_act_bwd_apply(const void* da, const void* y, void* dy, const float* scale, const float* shift,
+                          const float* k1, const float* kB, const float* kA,
+                          int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MaxPool3d(2) -- aten::max_pool3d_with_indices(+backward) at pcrlv2_model_3d.py:100,115-117.
+ * N,D,H,W are the INPUT dims (even).  Backward recomputes the argmax from the saved input
+ * (first maximum in d,h,w scan order takes the gradient, like ATen). */
+int pcrl_maxpool3d_2_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, pcrl_stream_t stream);
+int pcrl_maxpool3d_2_bwd(const void* x, const void* dy, void* dx, int N, int D, int H, int W, int C, int dtype, pcrl_stream_t stream);
+
+/* Global average pool -- aten::adaptive_avg_pool3d -> (1,1,1) at pcrlv2_model_3d.py:67.
+ * fwd: g[n][c] = mean_s a[n][s][c] (float32 out).  bwd: da[n][s][c] (+)= dg[n][c]/S. */
+size_t pcrl_gap_ws_bytes(int N, int64_t S, int C);
+int pcrl_gap_fwd(const void* a, float* g, void* ws, size_t ws_bytes, int N, int64_t S, int C, int dtype, pcrl_stream_t stream);
+int pcrl_gap_bwd(const float* dg, void* da, int accumulate, int N, int64_t S, int C, int dtype, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Projection / predictor heads on [rows][C] float32 -- BatchNorm1d, Linear, ReLU at
+ * pcrlv2_model_3d.py:55-59,69-70.  Tiny (latency-bound) kernels. */
+int pcrl_bn1d_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                  float momentum, float eps, float* mean, float* rstd, int rows, int C, int relu, pcrl_stream_t stream);
+int pcrl_bn1d_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* mean, const float* rstd,
+                  float* dx, float* dgamma, float* dbeta, int rows, int C, int relu, pcrl_stream_t stream);
+int pcrl_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int Cin, int Cout, pcrl_stream_t stream);
+int pcrl_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                    int rows, int Cin, int Cout, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Trilinear upsampling of 1-channel float32 maps, align_corners=False, integer scale --
+ * aten::upsample_trilinear3d(+backward) at pcrlv2_model_3d.py:125-126.  N,D,H,W: INPUT dims. */
+int pcrl_upsample_trilinear_fwd(const float* x, float* y, int N, int D, int H, int W, int scale, pcrl_stream_t stream);
+int pcrl_upsample_trilinear_bwd(const float* dy, float* dx, int N, int D, int H, int W, int scale, pcrl_stream_t stream);
+
+/* Elementwise sigmoid on float32 maps (OutputTransition, pcrlv2_model_3d.py:79,82) and its backward
+ * dpre = dout * out * (1 - out). */
+int pcrl_sigmoid_fwd(const float* x, float* y, int64_t n, pcrl_stream_t stream);
+int pcrl_sigmoid_bwd(const float* dout, const float* out, float* dpre, int64_t n, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Losses -- aten::mse_loss (train_3d.py:56,135,137) and aten::cosine_similarity(dim=1, eps=1e-8).mean()
+ * (train_3d.py:57,90-91).  ws: pcrl_reduce_ws_bytes(n). */
+size_t pcrl_reduce_ws_bytes(int64_t n);
+int pcrl_mse_fwd(const float* p, const float* gt, float* loss, void* ws, size_t ws_bytes, int64_t n, pcrl_stream_t stream);
+int pcrl_mse_bwd(const float* p, const float* gt, const float* dloss, float* dp, int64_t n, pcrl_stream_t stream);
+/* out[0] = mean_r cos(x_r, y_r); saved[r][3] = (dot, |x|, |y|).  bwd: gradient w.r.t. x only (y is detached). */
+int pcrl_cosine_mean_fwd(const float* x, const float* y, float* out, float* saved, int rows, int C, float eps, pcrl_stream_t stream);
+int pcrl_cosine_mean_bwd(const float* x, const float* y, const float* saved, const float* dout, float* dx,
+                         int rows, int C, float eps, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * torch.optim.SGD (momentum, weight decay, dampening 0, no nesterov) over a flat parameter arena --
+ * train_3d.py:48-51,151.  `offsets`: int64[ntensors+1] element offsets of each tensor in the arena;
+ * `flags`: int32[ntensors], bit0 = tensor has a gradient this step (others are skipped, like
+ * params whose .grad is None), bit1 = momentum buffer already initialised (else buf = g).
+ * g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
+int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
+                  int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCRL_HIP_H */

@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference, and pin the oracle against it.
+
+Runs only in the authoring container (needs /root/reference, which never travels to the
+GPU box).  What it does:
+  1. imports the reference's `models/pcrlv2_model_3d.py` by file path (torch-only), and
+     `train_3d.cos_loss` / `utils.adjust_learning_rate` behind stub modules for the
+     reference's absent third-party imports (segmentation_models_pytorch, apex, PIL);
+  2. loads the closed-form state of `pcrlv2_oracle.fill_state` into the reference model,
+     runs it in float64 with oneDNN off on `fill_batch` inputs, restating
+     train_3d.py:109-151 around the imported model + imported cos_loss (the loop itself has
+     hard .cuda() calls and cannot run here);
+  3. asserts the functional oracle reproduces the reference (outputs, losses, every
+     gradient, BN buffers, 2 SGD steps) to float64 round-off;
+  4. writes compact fixtures: scalars, full [b,C] features, and for big tensors the L2 norm
+     plus entries sampled at hashed indices (`sample_idx`).
+
+Usage:  python oracle/make_golden.py
+"""
+import importlib.util
+import os
+import random
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import pcrlv2_oracle as O  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def sample_idx(n: int, k: int, seed: int) -> np.ndarray:
+    """k deterministic indices into a flat tensor of n elements (shared with the tests)."""
+    if n <= k:
+        return np.arange(n, dtype=np.int64)
+    u = (O._hash_uniform(k, seed) + 1.0) * 0.5
+    return np.minimum((u * n).astype(np.int64), n - 1)
+
+
+def summarize(t: torch.Tensor, k: int = 64, seed: int = 3):
+    f = t.detach().double().reshape(-1).numpy()
+    return dict(l2=np.float64(np.sqrt((f * f).sum())), mean=np.float64(f.mean()),
+                samples=f[sample_idx(f.size, k, seed)].copy())
+
+
+def _stub_modules():
+    smp = types.ModuleType("segmentation_models_pytorch")
+    base = types.ModuleType("segmentation_models_pytorch.base")
+    mods = types.ModuleType("segmentation_models_pytorch.base.modules")
+    init = types.ModuleType("segmentation_models_pytorch.base.initialization")
+    init.initialize_decoder = lambda m: None
+    init.initialize_head = lambda m: None
+    smp.base, base.modules, base.initialization = base, mods, init
+    smp.Unet = object
+    for n, m in (("segmentation_models_pytorch", smp), ("segmentation_models_pytorch.base", base),
+                 ("segmentation_models_pytorch.base.modules", mods),
+                 ("segmentation_models_pytorch.base.initialization", init)):
+        sys.modules.setdefault(n, m)
+    if "PIL" not in sys.modules:
+        try:
+            import PIL  # noqa: F401
+        except ImportError:
+            pil = types.ModuleType("PIL")
+            pil.ImageFilter = types.ModuleType("PIL.ImageFilter")
+            sys.modules["PIL"] = pil
+            sys.modules["PIL.ImageFilter"] = pil.ImageFilter
+
+
+def load_reference():
+    spec = importlib.util.spec_from_file_location("ref_model3d", os.path.join(REF, "models", "pcrlv2_model_3d.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _stub_modules()
+    sys.path.insert(0, REF)
+    try:
+        import train_3d as ref_train  # reference module (its `models` package resolves to the stubs + real 3D file)
+        import utils as ref_utils
+    finally:
+        sys.path.remove(REF)
+    return mod, ref_train, ref_utils
+
+
+def reference_step(model, ref_train, batch, epoch, criterion, cosine):
+    """train_3d.py:113-138 around the imported model and imported cos_loss (CPU, no .cuda())."""
+    import math
+    input1, input2, gt, _gt2, local_views = batch
+    bsz = input1.size(0)
+    mask1, dec1, mid1 = model(input1)
+    _mask2, dec2, _ = model(input2)
+    loss2, index2 = ref_train.cos_loss(cosine, dec1, dec2)
+    local_loss = 0.0
+    local_input = torch.cat(local_views, dim=0)
+    _, lout, _ = model(local_input, local=True)
+    lout = [torch.stack(t) for t in lout]
+    for i in range(len(local_views)):
+        tmp = [t[:, bsz * i: bsz * (i + 1)] for t in lout]
+        l1, _ = ref_train.cos_loss(cosine, dec1, tmp)
+        l2, _ = ref_train.cos_loss(cosine, dec2, tmp)
+        local_loss += l1
+        local_loss += l2
+    local_loss = local_loss / (2 * len(local_views))
+    loss1 = criterion(mask1, gt)
+    beta = 0.5 * (1. + math.cos(math.pi * epoch / 240))
+    loss4 = beta * criterion(mid1[index2], gt)
+    loss = loss1 + loss2 + loss4 + local_loss
+    return dict(loss=loss, loss1=loss1, loss2=loss2, loss4=loss4, local_loss=local_loss, index2=index2,
+                mask1=mask1, dec1=dec1, mid1=mid1)
+
+
+def close(a, b, tol, what):
+    a, b = a.detach().double(), b.detach().double()
+    err = (a - b).abs().max().item()
+    ref = max(b.abs().max().item(), 1e-30)
+    assert err <= tol * max(ref, 1.0), f"oracle != reference for {what}: max|d|={err:.3e} (ref max {ref:.3e})"
+    return err
+
+
+def make_case(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=3, base_lr=1e-3, epochs=240, seed=0):
+    torch.set_num_threads(8)
+    dt = torch.float64
+    st0 = O.fill_state(dt)
+    batches = [O.fill_batch(b, dhw, dtype=dt, seed=7 + 100 * s) for s in range(nsteps)]
+
+    # ---------------- reference ----------------
+    model = refmod.PCRLv23d().double()
+    missing = model.load_state_dict(st0, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert list(model.state_dict().keys()) == list(st0.keys()), "state_dict order differs from oracle layout"
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=1e-4)
+
+    class A:  # args stand-in for utils.adjust_learning_rate
+        pass
+    A.lr, A.epochs = base_lr, epochs
+    ref_utils.adjust_learning_rate(epoch, A, opt)
+    assert abs(opt.param_groups[0]["lr"] - O.lr_at(epoch, base_lr, epochs)) < 1e-18
+    criterion, cosine = torch.nn.MSELoss(), torch.nn.CosineSimilarity()
+    random.seed(seed)
+    ref_log, ref_first, ref_first_grads = [], None, None
+    with torch.backends.mkldnn.flags(enabled=False):
+        for s in range(nsteps):
+            r = reference_step(model, ref_train, batches[s], epoch, criterion, cosine)
+            opt.zero_grad()
+            r["loss"].backward()
+            if s == 0:
+                ref_first = r
+                ref_first_grads = {k: (None if p.grad is None else p.grad.detach().clone())
+                                   for k, p in model.named_parameters()}
+                ref_bufs1 = {k: v.detach().clone() for k, v in model.state_dict().items() if O.is_buffer(k)}
+            opt.step()
+            ref_log.append({k: float(r[k].detach()) for k in ("loss", "loss1", "loss2", "loss4", "local_loss")} | {"index2": r["index2"]})
+    ref_final = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    # ---------------- oracle, checked against the reference ----------------
+    with torch.backends.mkldnn.flags(enabled=False):
+        st_fin, mom, log, g0 = O.train_steps(st0, batches, epoch, base_lr, epochs, seed)
+        rng = random.Random(seed)
+        nb = {}
+        o0 = O.step_losses(st0, batches[0], epoch, rng, nb)
+    worst = 0.0
+    for k in ("loss", "loss1", "loss2", "loss4", "local_loss"):
+        for s in range(nsteps):
+            assert abs(log[s][k] - ref_log[s][k]) < 1e-10, (k, s, log[s][k], ref_log[s][k])
+    assert [l["index2"] for l in log] == [l["index2"] for l in ref_log]
+    worst = max(worst, close(o0["mask1"], ref_first["mask1"], 1e-10, "out"))
+    for i in range(3):
+        worst = max(worst, close(o0["dec1"][i][0], ref_first["dec1"][i][0], 1e-9, f"pro{i}"))
+        worst = max(worst, close(o0["dec1"][i][1], ref_first["dec1"][i][1], 1e-9, f"pre{i}"))
+        worst = max(worst, close(o0["mid1"][i], ref_first["mid1"][i], 1e-10, f"mid{i}"))
+    for k, g in ref_first_grads.items():
+        assert (g is None) == (g0[k] is None), f"grad None-ness differs for {k}"
+        if g is not None:
+            tol = 1e-9 * g.abs().max().item() + 1e-11  # zero-gradient params carry ~1e-15 noise
+            assert (g - g0[k]).abs().max().item() <= tol, f"grad {k}"
+    for k, v in ref_bufs1.items():
+        close(nb[k].double() if nb[k].dtype != torch.int64 else nb[k].double(), v.double(), 1e-10, k)
+    for k, v in ref_final.items():
+        close(st_fin[k].double(), v.double(), 1e-9, "final " + k)
+    print(f"[{tag}] oracle == reference (worst fwd |d| {worst:.2e}); losses {ref_log}")
+
+    # ---------------- fixtures ----------------
+    fx = OrderedDict()
+    fx["meta/b"], fx["meta/dhw"], fx["meta/nsteps"] = np.int64(b), np.array(dhw), np.int64(nsteps)
+    fx["meta/epoch"], fx["meta/base_lr"], fx["meta/epochs"], fx["meta/seed"] = np.int64(epoch), np.float64(base_lr), np.int64(epochs), np.int64(seed)
+    fx["meta/lr"] = np.float64(opt.param_groups[0]["lr"])
+    for s, l in enumerate(ref_log):
+        for k, v in l.items():
+            fx[f"step{s}/{k}"] = np.float64(v)
+    r = ref_first
+    for k, v in summarize(r["mask1"], 256).items():
+        fx[f"fwd/out/{k}"] = v
+    for i in range(3):
+        fx[f"fwd/pro{i}"] = r["dec1"][i][0].detach().numpy().copy()
+        fx[f"fwd/pre{i}"] = r["dec1"][i][1].detach().numpy().copy()
+        for k, v in summarize(r["mid1"][i], 256).items():
+            fx[f"fwd/mid{i}/{k}"] = v
+    for name, g in ref_first_grads.items():
+        if g is None:
+            fx[f"grad/{name}/none"] = np.int64(1)
+            continue
+        for k, v in summarize(g, 64).items():
+            fx[f"grad/{name}/{k}"] = v
+    for name, v in ref_bufs1.items():
+        fx[f"buf1/{name}"] = v.double().numpy().copy()
+    for name, v in ref_final.items():
+        if O.is_buffer(name):
+            continue
+        for k, vv in summarize(v, 64).items():
+            fx[f"final/{name}/{k}"] = vv
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, f"{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{tag}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB, {len(fx)} arrays)")
+
+
+def main():
+    if not os.path.isdir(REF):
+        sys.exit("reference not present: fixtures can only be regenerated in the authoring container")
+    refmod, ref_train, ref_utils = load_reference()
+    make_case("c_small_b4_32x32x16", 4, (32, 32, 16), 2, refmod, ref_train, ref_utils)
+    make_case("c_luna_b2_64x64x32", 2, (64, 64, 32), 1, refmod, ref_train, ref_utils)
+    # LR schedule vector (utils.py:101-114) for epochs 0..240 at lr=1e-3
+    class A:
+        lr, epochs = 1e-3, 240
+
+    class Opt:
+        param_groups = [dict(lr=0.0)]
+    lrs = []
+    for e in range(0, 241):
+        ref_utils.adjust_learning_rate(e, A, Opt)
+        lrs.append(Opt.param_groups[0]["lr"])
+    np.savez_compressed(os.path.join(OUT, "lr_schedule.npz"), lr=np.array(lrs))
+    # state_dict key/shape manifest from the real model
+    m = refmod.PCRLv23d()
+    with open(os.path.join(OUT, "state_dict_manifest.txt"), "w") as f:
+        for k, v in m.state_dict().items():
+            f.write(f"{k} {tuple(v.shape)} {str(v.dtype).replace('torch.', '')}\n")
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,322 @@
+// Implicit-GEMM convolution on MFMA for gfx950: 3x3x3 conv forward / data-gradient and the
+// 2x2x2-stride-2 transposed conv (forward scatter GEMMs, data-gradient gather GEMM).
+//
+// Replaces aten::convolution / convolution_backward(input) dispatched from
+// models/pcrlv2_model_3d.py:9,33 (LUConv.conv1) and :52,64 (UpTransition.up_conv).
+//
+// GEMM view: rows = voxels (M = N*D*H*W), cols = output channels, K = taps * channels.
+// Activations are NDHWC so one (voxel, tap) contributes a CONTIGUOUS channel vector: the A tile
+// of a K-step (one tap, 32 channels) is 128 rows x 64 B (bf16), fetched with 16-byte loads whose
+// address is `row + tap_delta` -- the 27 shifted re-reads of a voxel hit L1/L2, HBM sees each
+// activation once.  Weights are pre-packed K-contiguous ([co][tap][ci]) so both MFMA operands are
+// plain 16-byte LDS reads.  Tile 128 x BN (BN = 32/64/128), 4 waves as 2(M) x 2(N), each wave
+// 64 x BN/2 = 4 x FN fragments of v_mfma_f32_16x16x32_bf16 (bf16) or 8 x v_mfma_f32_16x16x4_f32
+// (exact fp32 parity mode).  LDS tiles are double-buffered, register-staged (the halo needs
+// zero-fill, which an LDS-DMA cannot do) and XOR-swizzled in 16-byte slots so a 16-lane fragment
+// read covers all 64 banks.
+//
+// Epilogue: + bias, store, and per-tile per-channel (sum, sum of squares) from the fp32
+// accumulators for the training-mode BatchNorm that follows every conv (no atomics: one partial
+// row per tile, reduced in fixed order by bn_finalize).
+#include "common.h"
+
+namespace {
+
+enum { GEOM_CONV3 = 0, GEOM_UP2_FWD = 1, GEOM_UP2_DGRAD = 2 };
+
+struct IgemmParams {
+  const void* x;      // A source rows [*][K]
+  const void* w;      // packed weights [z][Nc][taps][K]
+  const float* bias;  // [Nc] or null
+  void* y;            // output rows [*][Nc]
+  float* stats;       // [gridDim.x][Nc][2] or null
+  Dims g;             // index space of the GEMM rows
+  int64_t M;
+  int K;              // channels per tap
+  int Nc;             // output channels
+  int taps;           // taps accumulated inside one GEMM (27, 1 or 8)
+};
+
+template <typename T> struct Tile {  // [rows][32] of T, 16-byte slots XOR-swizzled by row
+  static constexpr int ROWB = 32 * (int)sizeof(T);
+  static constexpr int SLOTS = ROWB / 16;
+  static constexpr int RPB = 256 / ROWB;
+  static __device__ __forceinline__ int off(int row, int slot) {
+    return row * ROWB + (((slot ^ (row / RPB)) & (SLOTS - 1)) << 4);
+  }
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  using Frag = bf16x8;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int g) {
+    return *reinterpret_cast<const bf16x8*>(tile + Tile<bf16>::off(row, g));
+  }
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  struct Frag { f32x4 lo, hi; };
+  // lane group g holds k = 8g..8g+7 of the 32-wide K-step; MFMA sub-step e consumes element e of every
+  // lane (the k <-> (g,e) assignment is the same for A and B, so the sum over k is unchanged).
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int g) {
+    Frag f;
+    f.lo = *reinterpret_cast<const f32x4*>(tile + Tile<float>::off(row, 2 * g));
+    f.hi = *reinterpret_cast<const f32x4*>(tile + Tile<float>::off(row, 2 * g + 1));
+    return f;
+  }
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[e], b.lo[e], c, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[e], b.hi[e], c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN, int GEOM>
+__global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
+  constexpr int BM = PCRL_CONV_BM;
+  using TL = Tile<T>;
+  using MM = Mma<T>;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int SLOTS = TL::SLOTS;
+  constexpr int RPP = 256 / SLOTS;  // tile rows staged per pass of the 256 threads
+  constexpr int AP = BM / RPP;
+  constexpr int BP = (BN + RPP - 1) / RPP;
+  constexpr int FM = 4, FN = BN / 32;
+  constexpr int A_BYTES = BM * TL::ROWB, B_BYTES = BN * TL::ROWB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;
+  char* Bs = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int z = blockIdx.z;
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.w);
+  const Dims g = p.g;
+  const int K = p.K;
+
+  const int slot = tid % SLOTS, rowp = tid / SLOTS;
+
+  // ---- per-thread A rows: base row in the source and tap validity ----
+  int64_t abase[AP];
+  uint32_t amask[AP];
+#pragma unroll
+  for (int ps = 0; ps < AP; ++ps) {
+    const int64_t m = m0 + ps * RPP + rowp;
+    abase[ps] = 0;
+    amask[ps] = 0;
+    if (m < p.M) {
+      int n, d, h, w;
+      decode_voxel(m, g, n, d, h, w);
+      if (GEOM == GEOM_CONV3) {
+        abase[ps] = m;
+        amask[ps] = tap_mask27(d, h, w, g);
+      } else if (GEOM == GEOM_UP2_FWD) {
+        abase[ps] = m;
+        amask[ps] = 1u;
+      } else {
+        abase[ps] = up2_row(n, d, h, w, 0, g);
+        amask[ps] = 0xFFu;
+      }
+    }
+  }
+  // ---- per-thread B rows ----
+  int64_t boff[BP];
+  bool bok[BP];
+#pragma unroll
+  for (int ps = 0; ps < BP; ++ps) {
+    const int brow = ps * RPP + rowp;
+    bok[ps] = brow < BN;
+    boff[ps] = ((int64_t)(z * p.Nc + n0 + (bok[ps] ? brow : 0)) * p.taps) * K + slot * VEC;
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunk = K / 32;
+  const int S = p.taps * nchunk;
+  uint4 ra[AP], rb[BP];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+#define IGEMM_LOAD(t_, c_)                                                                              \
+  do {                                                                                                  \
+    int64_t delta_;                                                                                     \
+    if (GEOM == GEOM_CONV3) delta_ = tap_delta27((t_), g);                                              \
+    else if (GEOM == GEOM_UP2_DGRAD)                                                                    \
+      delta_ = ((int64_t)((t_) >> 2) * (2 * g.H) + (((t_) >> 1) & 1)) * (2 * g.W) + ((t_)&1);           \
+    else delta_ = 0;                                                                                    \
+    _Pragma("unroll") for (int ps = 0; ps < AP; ++ps) {                                                 \
+      const bool ok_ = (amask[ps] >> (t_)) & 1u;                                                        \
+      ra[ps] = ok_ ? *reinterpret_cast<const uint4*>(X + (abase[ps] + delta_) * K + (c_)*32 + slot * VEC) \
+                   : zero4;                                                                             \
+    }                                                                                                   \
+    _Pragma("unroll") for (int ps = 0; ps < BP; ++ps) {                                                 \
+      if (bok[ps]) rb[ps] = *reinterpret_cast<const uint4*>(Wp + boff[ps] + (int64_t)(t_)*K + (c_)*32); \
+    }                                                                                                   \
+  } while (0)
+
+#define IGEMM_STORE(buf_)                                                                               \
+  do {                                                                                                  \
+    _Pragma("unroll") for (int ps = 0; ps < AP; ++ps)                                                   \
+      *reinterpret_cast<uint4*>(As + (buf_)*A_BYTES + TL::off(ps * RPP + rowp, slot)) = ra[ps];         \
+    _Pragma("unroll") for (int ps = 0; ps < BP; ++ps) {                                                 \
+      if (bok[ps]) *reinterpret_cast<uint4*>(Bs + (buf_)*B_BYTES + TL::off(ps * RPP + rowp, slot)) = rb[ps]; \
+    }                                                                                                   \
+  } while (0)
+
+  IGEMM_LOAD(0, 0);
+  IGEMM_STORE(0);
+  __syncthreads();
+
+  int t = 0, c = 0;
+  for (int s = 0; s < S; ++s) {
+    const int cur = s & 1;
+    int tn = t, cn = c + 1;
+    if (cn == nchunk) { cn = 0; tn = t + 1; }
+    const bool more = (s + 1 < S);
+    if (more) IGEMM_LOAD(tn, cn);
+
+    {
+      const char* a = As + cur * A_BYTES;
+      const char* b = Bs + cur * B_BYTES;
+      typename MM::Frag fa[FM], fb[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) fa[i] = MM::read(a, wm * 64 + i * 16 + lr, lg);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) fb[j] = MM::read(b, wn * (BN / 2) + j * 16 + lr, lg);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) MM::mma(fa[i], fb[j], acc[i][j]);
+    }
+
+    if (more) IGEMM_STORE(cur ^ 1);
+    __syncthreads();
+    t = tn;
+    c = cn;
+  }
+#undef IGEMM_LOAD
+#undef IGEMM_STORE
+
+  // ---- epilogue: bias, store, BN statistics ----
+  T* __restrict__ Y = reinterpret_cast<T*>(p.y);
+  float s1[FN], s2[FN], bv[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+    bv[j] = p.bias ? p.bias[n0 + wn * (BN / 2) + j * 16 + lr] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + wm * 64 + i * 16 + lg * 4 + r;
+      if (m < p.M) {
+        int64_t orow = m;
+        if (GEOM == GEOM_UP2_FWD) {
+          int n, d, h, w;
+          decode_voxel(m, g, n, d, h, w);
+          orow = up2_row(n, d, h, w, z, g);
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const float v = acc[i][j][r] + bv[j];
+          Y[orow * p.Nc + n0 + wn * (BN / 2) + j * 16 + lr] = from_f<T>(v);
+          s1[j] += v;
+          s2[j] += v * v;
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][FN][16][2]; all LDS reads finished at the last barrier
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float a = s1[j], b = s2[j];
+      a += __shfl_xor(a, 16, 64);
+      b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (lg == 0) {
+        red[((wid * FN + j) * 16 + lr) * 2 + 0] = a;
+        red[((wid * FN + j) * 16 + lr) * 2 + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      const int wn_ = tid / (BN / 2), within = tid % (BN / 2);
+      const int j = within / 16, l = within % 16;
+      const float* r0 = red + (((0 * 2 + wn_) * FN + j) * 16 + l) * 2;
+      const float* r1 = red + (((1 * 2 + wn_) * FN + j) * 16 + l) * 2;
+      float* o = p.stats + ((int64_t)blockIdx.x * p.Nc + n0 + tid) * 2;
+      o[0] = r0[0] + r1[0];
+      o[1] = r0[1] + r1[1];
+    }
+  }
+}
+
+template <typename T, int BN, int GEOM>
+int launch_igemm(const IgemmParams& p, int zdim, hipStream_t stream) {
+  using TL = Tile<T>;
+  const size_t lds = 2 * (size_t)(PCRL_CONV_BM + BN) * TL::ROWB;
+  dim3 grid((unsigned)((p.M + PCRL_CONV_BM - 1) / PCRL_CONV_BM), (unsigned)(p.Nc / BN), (unsigned)zdim);
+  hipLaunchKernelGGL((igemm_kernel<T, BN, GEOM>), grid, dim3(256), lds, stream, p);
+  return pcrl_check_launch("igemm");
+}
+
+template <typename T, int GEOM> int dispatch_bn(const IgemmParams& p, int zdim, hipStream_t stream) {
+  if (p.Nc % 128 == 0) return launch_igemm<T, 128, GEOM>(p, zdim, stream);
+  if (p.Nc % 64 == 0) return launch_igemm<T, 64, GEOM>(p, zdim, stream);
+  return launch_igemm<T, 32, GEOM>(p, zdim, stream);
+}
+
+template <int GEOM> int dispatch(const IgemmParams& p, int zdim, int dtype, hipStream_t stream) {
+  if (dtype == PCRL_BF16) return dispatch_bn<bf16, GEOM>(p, zdim, stream);
+  if (dtype == PCRL_F32) return dispatch_bn<float, GEOM>(p, zdim, stream);
+  return pcrl_fail(PCRL_EINVAL, "igemm: bad dtype %d", dtype);
+}
+
+int check_dims(const char* what, int N, int D, int H, int W, int Ci, int Co) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return pcrl_fail(PCRL_EINVAL, "%s: bad dims %d %d %d %d", what, N, D, H, W);
+  if (Ci % 32 != 0 || Co % 32 != 0 || Ci <= 0 || Co <= 0)
+    return pcrl_fail(PCRL_EINVAL, "%s: channels must be positive multiples of 32 (Ci=%d Co=%d)", what, Ci, Co);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pcrl_conv3d_k3_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial,
+                                  int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  if (int e = check_dims("conv3d_k3_fwd", N, D, H, W, Ci, Co)) return e;
+  PCRL_REQUIRE(x && wp && y, "conv3d_k3_fwd: null pointer");
+  IgemmParams p{x, wp, bias, y, stats_partial, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 27};
+  return dispatch<GEOM_CONV3>(p, 1, dtype, as_stream(stream));
+}
+
+extern "C" int pcrl_convt3d_k2s2_fwd(const void* x, const void* wp_fwd, const float* bias, void* y,
+                                     int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  if (int e = check_dims("convt3d_k2s2_fwd", N, D, H, W, Ci, Co)) return e;
+  PCRL_REQUIRE(x && wp_fwd && y, "convt3d_k2s2_fwd: null pointer");
+  IgemmParams p{x, wp_fwd, bias, y, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 1};
+  return dispatch<GEOM_UP2_FWD>(p, 8, dtype, as_stream(stream));
+}
+
+extern "C" int pcrl_convt3d_k2s2_dgrad(const void* dy, const void* wp_dgrad, void* dx,
+                                       int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  if (int e = check_dims("convt3d_k2s2_dgrad", N, D, H, W, Ci, Co)) return e;
+  PCRL_REQUIRE(dy && wp_dgrad && dx, "convt3d_k2s2_dgrad: null pointer");
+  // rows = input voxels, K per tap = Co (channels of dy), output channels = Ci
+  IgemmParams p{dy, wp_dgrad, nullptr, dx, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Co, Ci, 8};
+  return dispatch<GEOM_UP2_DGRAD>(p, 1, dtype, as_stream(stream));
+}

@@ -1,0 +1,302 @@
+// Weight-gradient GEMMs on MFMA for gfx950 (split-K over voxels, deterministic second pass).
+//
+// Replaces the weight half of aten::convolution_backward for models/pcrlv2_model_3d.py:9,33
+// (3x3x3 conv) and :52,64 (ConvTranspose3d k2 s2).  Per tap t:
+//     P_t[i][j] = sum_m U[m][i] * V[g(m,t)][j]
+//   conv3 : U = dy (i = co), V = x  (j = ci), g(m,t) = m + delta_t (zero outside the volume)
+//   convT : U = x  (i = ci), V = dy (j = co), g(m,t) = row of tap t in the 2x-upsampled volume
+// and the result is written in the reference layout [i][j][t].
+//
+// The reduction index m is the ROW index of both NDHWC operands, while an MFMA operand wants 8
+// consecutive k per lane.  bf16: tiles are staged in their natural [voxel][channel] layout and the
+// fragments are fetched with ds_read_b64_tr_b16 (gfx950 transpose read), two per fragment;
+// a scalar-read fallback (`tr = 0`) is kept for validation.  fp32: v_mfma_f32_16x16x4_f32 takes one
+// float per lane, so the natural layout is read directly.
+//
+// Block = 64(i) x 64(j) result tile of ONE tap and ONE voxel split; 4 waves as 2x2, each 32x32
+// (2x2 fragments); K-step = 32 voxels, double-buffered register-staged LDS tiles.
+#include "common.h"
+
+namespace {
+
+enum { WG_CONV3 = 0, WG_UP2 = 1 };
+
+struct WgradParams {
+  const void* u;  // [M][Cu]
+  const void* v;  // [rows][Cv]
+  float* ws;      // [splits][taps][Cu][Cv]
+  Dims g;         // index space of m (output voxels for conv3, input voxels for convT)
+  int64_t M;
+  int Cu, Cv, taps;
+  int64_t chunk;  // voxels per split, multiple of 32
+};
+
+// 32-byte quad swizzle of a 64-channel bf16 row (4 quads of 16 channels): spreads the 8 rows a
+// 32-lane group of a transpose-read touches over all 64 banks.
+__device__ __forceinline__ int quad_sw(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+template <typename T> struct WTile;
+template <> struct WTile<bf16> {
+  static constexpr int ROWB = 128;  // 64 ch * 2 B
+  static __device__ __forceinline__ int off(int row, int col) {  // byte offset of channel `col`
+    return row * ROWB + ((((col >> 4) ^ quad_sw(row)) & 3) << 5) + ((col & 15) << 1);
+  }
+};
+template <> struct WTile<float> {
+  static constexpr int ROWB = 256;
+  static __device__ __forceinline__ int off(int row, int col) { return row * ROWB + (col << 2); }
+};
+
+template <typename T, bool TR> struct WFrag;
+template <> struct WFrag<float, false> {
+  struct Frag { float v[8]; };
+  // lane (c = lane&15, g = lane>>4) takes voxels k = 8g..8g+7 of channel cbase+c
+  static __device__ __forceinline__ Frag read(const char* tile, int cbase, int lane) {
+    Frag f;
+    const int c = cbase + (lane & 15), g = lane >> 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f.v[e] = *reinterpret_cast<const float*>(tile + WTile<float>::off(8 * g + e, c));
+    return f;
+  }
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[e], b.v[e], c, 0, 0, 0);
+  }
+};
+template <> struct WFrag<bf16, false> {
+  using Frag = bf16x8;
+  static __device__ __forceinline__ Frag read(const char* tile, int cbase, int lane) {
+    Frag f;
+    const int c = cbase + (lane & 15), g = lane >> 4;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = *reinterpret_cast<const bf16*>(tile + WTile<bf16>::off(8 * g + e, c));
+    return f;
+  }
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct WFrag<bf16, true> {
+  using Frag = bf16x8;
+  // ds_read_b64_tr_b16: within each 16-lane group, result lane l element j comes from source lane
+  // 4j + (l&15)/4, element l&3.  Source lane s therefore points at voxel row (s&15)>>2 of the 4-row group,
+  // channels 4*(s&3)..+3; lane l receives channel (l&15) of 4 consecutive voxels.  Two reads give the lane
+  // voxels 8g..8g+7 of its channel -- the canonical A/B fragment of v_mfma_f32_16x16x32_bf16.
+  static __device__ __forceinline__ Frag read(const char* tile, int cbase, int lane) {
+    const int g = lane >> 4, jr = (lane & 15) >> 2, cq = lane & 3;
+    const int row0 = 8 * g + jr;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const char* p0 = tile + WTile<bf16>::off(row0, cbase + 4 * cq);
+    const char* p1 = tile + WTile<bf16>::off(row0 + 4, cbase + 4 * cq);
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    union { struct { s16x4 a, b; } s; bf16x8 f; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.f;
+  }
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T, int GEOM, bool TR>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
+  using WT = WTile<T>;
+  using WF = WFrag<T, TR>;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int CPR = WT::ROWB / 16;  // 16-byte chunks per tile row: 8 / 16
+  constexpr int RPP = 256 / CPR;      // rows per pass: 32 / 16
+  constexpr int NP = 32 / RPP;        // passes: 1 / 2
+  constexpr int TILE_BYTES = 32 * WT::ROWB;
+
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // U[2], V[2]
+  char* Us = smem;
+  char* Vs = smem + 2 * TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wi = wid >> 1, wj = wid & 1;
+  const int ntj = (p.Cv + 63) / 64;
+  const int i0 = (blockIdx.x / ntj) * 64, j0 = (blockIdx.x % ntj) * 64;
+  const int t = blockIdx.y;
+  const int64_t mbeg = (int64_t)blockIdx.z * p.chunk;
+  const int64_t mend = (mbeg + p.chunk < p.M) ? (mbeg + p.chunk) : p.M;
+  const T* __restrict__ U = reinterpret_cast<const T*>(p.u);
+  const T* __restrict__ V = reinterpret_cast<const T*>(p.v);
+  const Dims g = p.g;
+
+  const int chunk16 = tid % CPR, rowp = tid / CPR;
+  const int ucol = chunk16 * VEC;                 // channel offset of this thread's 16 bytes in the tile
+  const bool u_ok = (i0 + ucol) < p.Cu;           // Cu, Cv are multiples of 32; a 64-wide tile may hang over
+  const bool v_ok = (j0 + ucol) < p.Cv;
+  const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+  const int64_t delta = (GEOM == WG_CONV3) ? tap_delta27(t, g) : 0;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ru[NP], rv[NP];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+#define WG_LOAD(ms_)                                                                            \
+  do {                                                                                          \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                         \
+      const int64_t m = (ms_) + ps * RPP + rowp;                                                \
+      ru[ps] = zero4;                                                                           \
+      rv[ps] = zero4;                                                                           \
+      if (m < mend) {                                                                           \
+        if (u_ok) ru[ps] = *reinterpret_cast<const uint4*>(U + m * p.Cu + i0 + ucol);           \
+        int n, d, h, w;                                                                         \
+        decode_voxel(m, g, n, d, h, w);                                                         \
+        if (GEOM == WG_CONV3) {                                                                 \
+          const bool ok = (unsigned)(d + kd - 1) < (unsigned)g.D && (unsigned)(h + kh - 1) < (unsigned)g.H && \
+                          (unsigned)(w + kw - 1) < (unsigned)g.W;                               \
+          if (ok && v_ok) rv[ps] = *reinterpret_cast<const uint4*>(V + (m + delta) * p.Cv + j0 + ucol); \
+        } else {                                                                                \
+          if (v_ok) rv[ps] = *reinterpret_cast<const uint4*>(V + up2_row(n, d, h, w, t, g) * p.Cv + j0 + ucol); \
+        }                                                                                       \
+      }                                                                                         \
+    }                                                                                           \
+  } while (0)
+
+#define WG_STORE(buf_)                                                                          \
+  do {                                                                                          \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                         \
+      const int row = ps * RPP + rowp;                                                          \
+      *reinterpret_cast<uint4*>(Us + (buf_)*TILE_BYTES + WT::off(row, ucol)) = ru[ps];          \
+      *reinterpret_cast<uint4*>(Vs + (buf_)*TILE_BYTES + WT::off(row, ucol)) = rv[ps];          \
+    }                                                                                           \
+  } while (0)
+
+  const int64_t nsteps = (mend > mbeg) ? (mend - mbeg + 31) / 32 : 0;
+  if (nsteps > 0) {
+    WG_LOAD(mbeg);
+    WG_STORE(0);
+  }
+  __syncthreads();
+  for (int64_t s = 0; s < nsteps; ++s) {
+    const int cur = (int)(s & 1);
+    const bool more = (s + 1 < nsteps);
+    if (more) WG_LOAD(mbeg + (s + 1) * 32);
+    {
+      const char* ut = Us + cur * TILE_BYTES;
+      const char* vt = Vs + cur * TILE_BYTES;
+      typename WF::Frag fa[2], fb[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = WF::read(ut, wi * 32 + a * 16, lane);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fb[b] = WF::read(vt, wj * 32 + b * 16, lane);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) WF::mma(fa[a], fb[b], acc[a][b]);
+    }
+    if (more) WG_STORE(cur ^ 1);
+    __syncthreads();
+  }
+#undef WG_LOAD
+#undef WG_STORE
+
+  float* __restrict__ out = p.ws + ((int64_t)blockIdx.z * p.taps + t) * (int64_t)p.Cu * p.Cv;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = i0 + wi * 32 + a * 16 + (lane >> 4) * 4 + r;
+        const int j = j0 + wj * 32 + b * 16 + (lane & 15);
+        if (i < p.Cu && j < p.Cv) out[(int64_t)i * p.Cv + j] = acc[a][b][r];
+      }
+}
+
+// Second pass: out_ref[i][j][t] = sum_z ws[z][t][i][j], fixed order.
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                           int splits, int taps, int Cu, int Cv) {
+  const int64_t per = (int64_t)Cu * Cv;
+  const int64_t total = per * taps;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    // idx enumerates [t][i][j] (coalesced reads); write transposed
+    const int t = (int)(idx / per);
+    const int64_t ij = idx % per;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[((int64_t)z * taps + t) * per + ij];
+    out[ij * taps + t] = s;
+  }
+}
+
+struct SplitPlan {
+  int splits;
+  int64_t chunk;
+};
+SplitPlan plan_splits(int64_t M, int Cu, int Cv, int taps) {
+  const int64_t tiles = (int64_t)((Cu + 63) / 64) * ((Cv + 63) / 64) * taps;
+  const int64_t steps = (M + 31) / 32;
+  int64_t splits = 2048 / tiles;
+  if (splits < 1) splits = 1;
+  const int64_t max_splits = (steps + 7) / 8;  // at least 8 K-steps per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int64_t steps_per = (steps + splits - 1) / splits;
+  splits = (steps + steps_per - 1) / steps_per;
+  return SplitPlan{(int)splits, steps_per * 32};
+}
+
+int g_wgrad_tr = 1;  // bf16 fragment fetch: 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
+
+template <int GEOM>
+int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_bytes, Dims g, int Cu, int Cv, int taps,
+              int dtype, hipStream_t stream) {
+  const int64_t M = (int64_t)g.N * g.D * g.H * g.W;
+  const SplitPlan sp = plan_splits(M, Cu, Cv, taps);
+  const size_t need = (size_t)sp.splits * taps * Cu * Cv * sizeof(float);
+  if (ws_bytes < need || !ws) return pcrl_fail(PCRL_EWORKSPACE, "wgrad: workspace %zu < %zu", ws_bytes, need);
+  WgradParams p{u, v, (float*)ws, g, M, Cu, Cv, taps, sp.chunk};
+  dim3 grid((unsigned)(((Cu + 63) / 64) * ((Cv + 63) / 64)), (unsigned)taps, (unsigned)sp.splits);
+  if (dtype == PCRL_BF16) {
+    if (g_wgrad_tr) hipLaunchKernelGGL((wgrad_kernel<bf16, GEOM, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16, GEOM, false>), grid, dim3(256), 0, stream, p);
+  } else if (dtype == PCRL_F32) {
+    hipLaunchKernelGGL((wgrad_kernel<float, GEOM, false>), grid, dim3(256), 0, stream, p);
+  } else {
+    return pcrl_fail(PCRL_EINVAL, "wgrad: bad dtype %d", dtype);
+  }
+  if (int e = pcrl_check_launch("wgrad")) return e;
+  const int64_t total = (int64_t)Cu * Cv * taps;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, dw_ref, sp.splits, taps, Cu, Cv);
+  return pcrl_check_launch("wgrad_reduce");
+}
+
+}  // namespace
+
+// Test hook (not part of the drop-in surface): select the bf16 fragment-fetch path.
+extern "C" void pcrl_debug_set_wgrad_tr(int on) { g_wgrad_tr = on; }
+
+extern "C" size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
+  const SplitPlan sp = plan_splits((int64_t)N * D * H * W, Co, Ci, 27);
+  return (size_t)sp.splits * 27 * Co * Ci * sizeof(float);
+}
+
+extern "C" int pcrl_conv3d_k3_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes,
+                                    int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && dy && dw_ref, "conv3d_k3_wgrad: null pointer");
+  PCRL_REQUIRE(Ci > 0 && Co > 0 && Ci % 32 == 0 && Co % 32 == 0, "conv3d_k3_wgrad: channels must be multiples of 32 (Ci=%d Co=%d)", Ci, Co);
+  return run_wgrad<WG_CONV3>(dy, x, dw_ref, ws, ws_bytes, Dims{N, D, H, W}, Co, Ci, 27, dtype, as_stream(stream));
+}
+
+extern "C" size_t pcrl_convt3d_k2s2_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
+  const SplitPlan sp = plan_splits((int64_t)N * D * H * W, Ci, Co, 8);
+  return (size_t)sp.splits * 8 * Co * Ci * sizeof(float);
+}
+
+extern "C" int pcrl_convt3d_k2s2_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes,
+                                       int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && dy && dw_ref, "convt3d_k2s2_wgrad: null pointer");
+  PCRL_REQUIRE(Ci > 0 && Co > 0 && Ci % 32 == 0 && Co % 32 == 0, "convt3d_k2s2_wgrad: channels must be multiples of 32 (Ci=%d Co=%d)", Ci, Co);
+  return run_wgrad<WG_UP2>(x, dy, dw_ref, ws, ws_bytes, Dims{N, D, H, W}, Ci, Co, 8, dtype, as_stream(stream));
+}
