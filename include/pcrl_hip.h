@@ -78,10 +78,11 @@ int pcrl_conv3d_k3_c1_wgrad(const float* x, const void* dy, float* dw_ref, void*
 /* Convolutions with ONE output channel: deep-supervision head conv3x3x3 C->1 (pcrlv2_model_3d.py:60,71)
  * and OutputTransition.final_conv 1x1x1 64->1 (:78).  taps = 27 or 1.  y, dy: float32 [M].
  * w_ref: [1][C][taps] float32.  `stats_partial`: [ceil(M/1024)][1][2] or NULL.
- * dgrad: dx[m][c] (+)= sum_t dy[m-delta_t] * w[c][t]; accumulate != 0 adds into dx. */
+ * dgrad: dx[m][c] = add_src[m][c] + sum_t dy[m-delta_t] * w[c][t]; add_src may be NULL (zero), dx itself
+ * (in-place accumulation) or another tensor of the same shape (an upstream gradient to fold in). */
 int pcrl_conv3d_to1_fwd(const void* x, const float* w_ref, const float* bias, float* y, float* stats_partial,
                         int N, int D, int H, int W, int C, int taps, int dtype, pcrl_stream_t stream);
-int pcrl_conv3d_to1_dgrad(const float* dy, const float* w_ref, void* dx, int accumulate,
+int pcrl_conv3d_to1_dgrad(const float* dy, const float* w_ref, const void* add_src, void* dx,
                           int N, int D, int H, int W, int C, int taps, int dtype, pcrl_stream_t stream);
 size_t pcrl_conv3d_to1_wgrad_ws_bytes(int N, int D, int H, int W, int C, int taps);
 int pcrl_conv3d_to1_wgrad(const void* x, const float* dy, float* dw_ref, float* db, void* ws, size_t ws_bytes,
@@ -138,10 +139,11 @@ int pcrl_maxpool3d_2_fwd(const void* x, void* y, int N, int D, int H, int W, int
 int pcrl_maxpool3d_2_bwd(const void* x, const void* dy, void* dx, int N, int D, int H, int W, int C, int dtype, pcrl_stream_t stream);
 
 /* Global average pool -- aten::adaptive_avg_pool3d -> (1,1,1) at pcrlv2_model_3d.py:67.
- * fwd: g[n][c] = mean_s a[n][s][c] (float32 out).  bwd: da[n][s][c] (+)= dg[n][c]/S. */
+ * fwd: g[n][c] = mean_s a[n][s][c] (float32 out).  bwd: da[n][s][c] = add_src[n][s][c] + dg[n][c]/S
+ * (add_src: NULL, da itself, or another tensor, as for pcrl_conv3d_to1_dgrad). */
 size_t pcrl_gap_ws_bytes(int N, int64_t S, int C);
 int pcrl_gap_fwd(const void* a, float* g, void* ws, size_t ws_bytes, int N, int64_t S, int C, int dtype, pcrl_stream_t stream);
-int pcrl_gap_bwd(const float* dg, void* da, int accumulate, int N, int64_t S, int C, int dtype, pcrl_stream_t stream);
+int pcrl_gap_bwd(const float* dg, const void* add_src, void* da, int N, int64_t S, int C, int dtype, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Projection / predictor heads on [rows][C] float32 -- BatchNorm1d, Linear, ReLU at

@@ -1,0 +1,136 @@
+"""ctypes binding of libpcrl_hip.so.
+
+Signatures are parsed from include/pcrl_hip.h (the single source of truth for the C ABI), so every
+declared entry point is bound with exact argument types, and a missing symbol is an import-time
+error.  There is NO fallback: if the library is absent or a call fails, a RuntimeError is raised
+(the product path never routes through PyTorch eager ops or the CPU oracle).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import threading
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_PKG), "include", "pcrl_hip.h")
+LIBPATH = os.path.join(_PKG, "lib", "libpcrl_hip.so")
+
+PCRL_F32, PCRL_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+CONV_BM = 128
+
+_CTYPES = {
+    "int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
+    "double": ctypes.c_double, "pcrl_stream_t": ctypes.c_void_p,
+}
+_RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}
+
+
+def parse_header(path: str = HEADER):
+    """-> {name: (return type string, [(arg type string, arg name), ...])} for every prototype."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"(const char\*|int64_t|size_t|int)\s+(pcrl_\w+)\s*\(([^;{]*?)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        lst = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                lst.append((mm.group(1).strip(), mm.group(2)))
+        protos[name] = (ret, lst)
+    return protos
+
+
+def _ctype_of(t: str):
+    if "*" in t:
+        return ctypes.c_void_p
+    return _CTYPES[t]
+
+
+class PcrlError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIBPATH):
+            raise PcrlError(
+                f"{LIBPATH} not found: the HIP extension is not built (run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `python -m pcrlv2_amd.build`).  pcrlv2_amd has no CPU / eager fallback.")
+        self.cdll = ctypes.CDLL(LIBPATH)
+        self.protos = parse_header()
+        self.fn = {}
+        for name, (ret, args) in self.protos.items():
+            try:
+                f = getattr(self.cdll, name)
+            except AttributeError as e:
+                raise PcrlError(f"libpcrl_hip.so does not export {name} declared in pcrl_hip.h") from e
+            f.restype = _RET[ret]
+            f.argtypes = [_ctype_of(t) for t, _ in args]
+            self.fn[name] = (f, ret, args)
+        self.debug_set_wgrad_tr = self.cdll.pcrl_debug_set_wgrad_tr
+        self.debug_set_wgrad_tr.argtypes = [ctypes.c_int]
+        self.debug_set_wgrad_tr.restype = None
+
+    def version(self) -> str:
+        return self.fn["pcrl_version"][0]().decode()
+
+    def last_error(self) -> str:
+        return self.fn["pcrl_last_error"][0]().decode()
+
+    def call(self, name: str, *args):
+        """Call an `int pcrl_*` entry point; tensors -> device pointers, None -> NULL; raises on error."""
+        f, ret, protos = self.fn[name]
+        if len(args) != len(protos):
+            raise TypeError(f"{name}: expected {len(protos)} arguments, got {len(args)}")
+        conv = []
+        for a, (t, an) in zip(args, protos):
+            if "*" in t:
+                if a is None:
+                    conv.append(None)
+                elif isinstance(a, torch.Tensor):
+                    if not a.is_cuda:
+                        raise PcrlError(f"{name}: argument `{an}` is a {a.device} tensor; libpcrl_hip needs device memory (no CPU fallback)")
+                    conv.append(a.data_ptr())
+                else:
+                    conv.append(int(a))
+            elif t == "pcrl_stream_t":
+                conv.append(a)
+            elif t in ("float", "double"):
+                conv.append(float(a))
+            else:
+                conv.append(int(a))
+        r = f(*conv)
+        if ret == "int" and r != 0:
+            raise PcrlError(f"{name} failed ({r}): {self.last_error()}")
+        return r
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> _Lib:
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                _lib = _Lib()
+    return _lib
+
+
+def stream_handle() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return PCRL_F32
+    if dt == torch.bfloat16:
+        return PCRL_BF16
+    raise PcrlError(f"unsupported activation dtype {dt} (float32 or bfloat16)")

@@ -1,0 +1,22 @@
+"""Global knobs of the MI355X engine."""
+import os
+
+import torch
+
+_DTYPES = {"fp32": torch.float32, "float32": torch.float32, "f32": torch.float32,
+           "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+_default = _DTYPES[os.environ.get("PCRL_DTYPE", "fp32").lower()]
+
+
+def default_compute_dtype() -> torch.dtype:
+    """Activation / MFMA-operand dtype for newly built models: float32 (exact-parity mode, the reference's
+    default precision) unless PCRL_DTYPE=bf16 or `set_default_compute_dtype` says otherwise.  The training
+    entry point maps the reference's `--amp` switch (apex O1 fp16 there) to bfloat16."""
+    return _default
+
+
+def set_default_compute_dtype(dt):
+    global _default
+    _default = _DTYPES[dt.lower()] if isinstance(dt, str) else dt
+    if _default not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"compute dtype must be float32 or bfloat16, got {dt}")

@@ -184,10 +184,10 @@ __global__ void __launch_bounds__(256) to1_fwd_kernel(const T* __restrict__ x, c
   }
 }
 
-// C -> 1 data gradient: dx[m][c] (+)= sum_t dy[m - delta_t] * w[c][t].  One 16-byte channel vector per thread.
+// C -> 1 data gradient: dx[m][c] = add[m][c] + sum_t dy[m - delta_t] * w[c][t].  One 16-byte channel vector per thread.
 template <typename T>
 __global__ void __launch_bounds__(256) to1_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w_ref,
-                                                        T* __restrict__ dx, int accumulate, Dims g, int64_t M, int C, int taps) {
+                                                        const T* add, T* dx, Dims g, int64_t M, int C, int taps) {
   constexpr int VEC = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* wl = sm;  // [taps][C]
@@ -224,8 +224,8 @@ __global__ void __launch_bounds__(256) to1_dgrad_kernel(const float* __restrict_
     }
     T* o = dx + m * C + cv * VEC;
     Vec16<T> ov;
-    if (accumulate) {
-      const Vec16<T> old = ld16(o);
+    if (add) {
+      const Vec16<T> old = ld16(add + m * C + cv * VEC);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) ov.v[j] = from_f<T>(to_f(old.v[j]) + acc[j]);
     } else {
@@ -375,7 +375,7 @@ extern "C" int pcrl_conv3d_to1_fwd(const void* x, const float* w_ref, const floa
   return pcrl_check_launch("to1_fwd");
 }
 
-extern "C" int pcrl_conv3d_to1_dgrad(const float* dy, const float* w_ref, void* dx, int accumulate,
+extern "C" int pcrl_conv3d_to1_dgrad(const float* dy, const float* w_ref, const void* add_src, void* dx,
                                      int N, int D, int H, int W, int C, int taps, int dtype, pcrl_stream_t stream) {
   if (int e = to1_check("conv3d_to1_dgrad", C, taps, dtype)) return e;
   PCRL_REQUIRE(dy && w_ref && dx, "conv3d_to1_dgrad: null pointer");
@@ -387,9 +387,9 @@ extern "C" int pcrl_conv3d_to1_dgrad(const float* dy, const float* w_ref, void* 
   if (blocks > 8192) blocks = 8192;
   const size_t lds = (size_t)taps * C * sizeof(float);
   if (dtype == PCRL_BF16)
-    hipLaunchKernelGGL(to1_dgrad_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), dy, w_ref, (bf16*)dx, accumulate, g, M, C, taps);
+    hipLaunchKernelGGL(to1_dgrad_kernel<bf16>, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), dy, w_ref, (const bf16*)add_src, (bf16*)dx, g, M, C, taps);
   else
-    hipLaunchKernelGGL(to1_dgrad_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), dy, w_ref, (float*)dx, accumulate, g, M, C, taps);
+    hipLaunchKernelGGL(to1_dgrad_kernel<float>, dim3((unsigned)blocks), dim3(256), lds, as_stream(stream), dy, w_ref, (const float*)add_src, (float*)dx, g, M, C, taps);
   return pcrl_check_launch("to1_dgrad");
 }
 

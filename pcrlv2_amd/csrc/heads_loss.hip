@@ -1,0 +1,440 @@
+// Latency-bound tail of the step: projection/predictor heads on [rows][C] float32 (BatchNorm1d, Linear, ReLU;
+// models/pcrlv2_model_3d.py:55-59,69-70), trilinear upsampling of the 1-channel deep-supervision maps (:125-126),
+// sigmoid (:79,82), MSE and cosine losses (train_3d.py:56-57,86-92,135-137), the fused SGD update
+// (train_3d.py:48-51,151) and the once-per-step weight packing for the MFMA convolutions.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm1d (training mode) on [rows][C]: one thread per channel, fp64 statistics.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn1d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* running_mean, float* running_var,
+                                                       float momentum, float eps, float* mean, float* rstd, int rows, int C, int relu) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0;
+  for (int r = 0; r < rows; ++r) s1 += (double)x[(int64_t)r * C + c];
+  const double mu = s1 / rows;
+  double s2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    const double d = (double)x[(int64_t)r * C + c] - mu;
+    s2 += d * d;
+  }
+  const double var = s2 / rows;
+  const double rs = 1.0 / sqrt(var + (double)eps);
+  mean[c] = (float)mu;
+  rstd[c] = (float)rs;
+  const float g = gamma[c], b = beta[c];
+  for (int r = 0; r < rows; ++r) {
+    float v = (float)(((double)x[(int64_t)r * C + c] - mu) * rs) * g + b;
+    if (relu && v < 0.f) v = 0.f;
+    y[(int64_t)r * C + c] = v;
+  }
+  if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+  if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * (rows > 1 ? var * rows / (rows - 1.0) : var));
+}
+
+__global__ void __launch_bounds__(256) bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float* __restrict__ dx, float* dgamma, float* dbeta,
+                                                       int rows, int C, int relu) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double mu = mean[c], rs = rstd[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    const int64_t i = (int64_t)r * C + c;
+    const double dz = (relu && y[i] <= 0.f) ? 0.0 : (double)dy[i];
+    s1 += dz;
+    s2 += dz * ((double)x[i] - mu) * rs;
+  }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+  const double g1 = (double)gamma[c] * rs;
+  for (int r = 0; r < rows; ++r) {
+    const int64_t i = (int64_t)r * C + c;
+    const double dz = (relu && y[i] <= 0.f) ? 0.0 : (double)dy[i];
+    const double xh = ((double)x[i] - mu) * rs;
+    dx[i] = (float)(g1 * (dz - s1 / rows - xh * s2 / rows));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Linear: y = x W^T + b.  One wave per output element row-block would be overkill: rows <= a few hundred,
+// C <= 512.  One thread per output, K-loop over contiguous weights rows.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                         float* __restrict__ y, int rows, int Cin, int Cout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * Cout) return;
+  const int r = i / Cout, o = i % Cout;
+  const float* xr = x + (int64_t)r * Cin;
+  const float* wr = w + (int64_t)o * Cin;
+  float acc = 0.f;
+  for (int k = 0; k < Cin; ++k) acc = fmaf(xr[k], wr[k], acc);
+  y[i] = acc + (b ? b[o] : 0.f);
+}
+__global__ void __launch_bounds__(256) linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                        int rows, int Cin, int Cout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * Cin) return;
+  const int r = i / Cin, k = i % Cin;
+  float acc = 0.f;
+  for (int o = 0; o < Cout; ++o) acc = fmaf(dy[(int64_t)r * Cout + o], w[(int64_t)o * Cin + k], acc);
+  dx[i] = acc;
+}
+__global__ void __launch_bounds__(256) linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                        float* __restrict__ db, int rows, int Cin, int Cout) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < Cout * Cin) {
+    const int o = i / Cin, k = i % Cin;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc = fmaf(dy[(int64_t)r * Cout + o], x[(int64_t)r * Cin + k], acc);
+    dw[i] = acc;
+  }
+  if (db && i < Cout) {
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += dy[(int64_t)r * Cout + i];
+    db[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trilinear upsample, align_corners=False, integer scale s: src = (dst + 0.5)/s - 0.5, clamped at 0;
+// i0 = floor(src), i1 = min(i0+1, n-1), lambda = src - i0  (ATen area_pixel_compute_source_index).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tri_src(int o, int n_in, float inv_s, int& i0, int& i1, float& l1) {
+  float src = ((float)o + 0.5f) * inv_s - 0.5f;
+  if (src < 0.f) src = 0.f;
+  i0 = (int)src;
+  if (i0 > n_in - 1) i0 = n_in - 1;
+  i1 = i0 + ((i0 < n_in - 1) ? 1 : 0);
+  l1 = src - (float)i0;
+}
+
+__global__ void __launch_bounds__(256) tri_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, Dims g, int s, int64_t total) {
+  const Dims go{g.N, g.D * s, g.H * s, g.W * s};
+  const float inv = 1.f / (float)s;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int n, d, h, w;
+    decode_voxel(i, go, n, d, h, w);
+    int d0, d1, h0, h1, w0, w1;
+    float ld, lh, lw;
+    tri_src(d, g.D, inv, d0, d1, ld);
+    tri_src(h, g.H, inv, h0, h1, lh);
+    tri_src(w, g.W, inv, w0, w1, lw);
+    const float* b = x + (int64_t)n * g.D * g.H * g.W;
+#define X_(dd, hh, ww) b[((int64_t)(dd)*g.H + (hh)) * g.W + (ww)]
+    const float v = (1.f - ld) * ((1.f - lh) * ((1.f - lw) * X_(d0, h0, w0) + lw * X_(d0, h0, w1)) +
+                                  lh * ((1.f - lw) * X_(d0, h1, w0) + lw * X_(d0, h1, w1))) +
+                    ld * ((1.f - lh) * ((1.f - lw) * X_(d1, h0, w0) + lw * X_(d1, h0, w1)) +
+                          lh * ((1.f - lw) * X_(d1, h1, w0) + lw * X_(d1, h1, w1)));
+#undef X_
+    y[i] = v;
+  }
+}
+
+// Backward as a gather: input voxel i collects from every output voxel whose stencil touches it.
+// Per dimension at most 3*s-1 < 16 candidate outputs (s <= 4 keeps the weight tables in registers).
+constexpr int TRI_MAXW = 16;
+__device__ __forceinline__ int tri_weights(int i, int n_in, int s, float inv_s, int& obeg, float* wts) {
+  int lo = s * (i - 1);
+  if (lo < 0) lo = 0;
+  int hi = s * (i + 2) - 1;
+  const int n_out = n_in * s;
+  if (hi > n_out - 1) hi = n_out - 1;
+  obeg = lo;
+  int cnt = hi - lo + 1;
+  if (cnt > TRI_MAXW) cnt = TRI_MAXW;
+  for (int k = 0; k < cnt; ++k) {
+    int i0, i1;
+    float l1;
+    tri_src(lo + k, n_in, inv_s, i0, i1, l1);
+    float wgt = 0.f;
+    if (i0 == i) wgt += 1.f - l1;
+    if (i1 == i) wgt += l1;
+    wts[k] = wgt;
+  }
+  return cnt;
+}
+
+__global__ void __launch_bounds__(256) tri_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, Dims g, int s, int64_t total) {
+  const float inv = 1.f / (float)s;
+  const int Do = g.D * s, Ho = g.H * s, Wo = g.W * s;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int n, d, h, w;
+    decode_voxel(i, g, n, d, h, w);
+    float wd[TRI_MAXW], wh[TRI_MAXW], ww[TRI_MAXW];
+    int od, oh, ow;
+    const int nd = tri_weights(d, g.D, s, inv, od, wd);
+    const int nh = tri_weights(h, g.H, s, inv, oh, wh);
+    const int nw = tri_weights(w, g.W, s, inv, ow, ww);
+    const float* b = dy + (int64_t)n * Do * Ho * Wo;
+    float acc = 0.f;
+    for (int a = 0; a < nd; ++a) {
+      if (wd[a] == 0.f) continue;
+      for (int c = 0; c < nh; ++c) {
+        if (wh[c] == 0.f) continue;
+        const float wdh = wd[a] * wh[c];
+        const float* row = b + ((int64_t)(od + a) * Ho + (oh + c)) * Wo + ow;
+        float r = 0.f;
+        for (int e = 0; e < nw; ++e) r += ww[e] * row[e];
+        acc += wdh * r;
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sigmoid / MSE / cosine
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sigmoid_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = 1.f / (1.f + expf(-x[i]));
+}
+__global__ void __launch_bounds__(256) sigmoid_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                          float* __restrict__ dpre, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = out[i];
+    dpre[i] = dout[i] * a * (1.f - a);
+  }
+}
+
+constexpr int RED_CHUNK = 4096;  // elements per first-stage block
+__global__ void __launch_bounds__(256) mse_partial_kernel(const float* __restrict__ p, const float* __restrict__ gt, double* __restrict__ ws, int64_t n) {
+  __shared__ double red[4];
+  const int64_t beg = (int64_t)blockIdx.x * RED_CHUNK;
+  const int64_t end = (beg + RED_CHUNK < n) ? beg + RED_CHUNK : n;
+  double s = 0.0;
+  for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+    const float d = p[i] - gt[i];
+    s += (double)(d * d);
+  }
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) mse_finish_kernel(const double* __restrict__ ws, float* __restrict__ loss, int blocks, double inv_n) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < blocks; i += 256) s += ws[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) loss[0] = (float)(s * inv_n);
+}
+__global__ void __launch_bounds__(256) mse_bwd_kernel(const float* __restrict__ p, const float* __restrict__ gt, const float* __restrict__ dloss,
+                                                      float* __restrict__ dp, int64_t n, float two_over_n) {
+  const float g = dloss[0] * two_over_n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dp[i] = g * (p[i] - gt[i]);
+}
+
+// One block; one wave per row (round-robin): dot, |x|, |y| by wave-shuffle reduction; mean over rows in fp64.
+__global__ void __launch_bounds__(256) cosine_fwd_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                                                         float* __restrict__ saved, int rows, int C, float eps) {
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double part = 0.0;
+  for (int r = wid; r < rows; r += 4) {
+    float dot = 0.f, xx = 0.f, yy = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float a = x[(int64_t)r * C + c], b = y[(int64_t)r * C + c];
+      dot += a * b;
+      xx += a * a;
+      yy += b * b;
+    }
+    dot = wave_sum(dot);
+    xx = wave_sum(xx);
+    yy = wave_sum(yy);
+    const float nx = sqrtf(xx), ny = sqrtf(yy);
+    if (lane == 0) {
+      saved[r * 3 + 0] = dot;
+      saved[r * 3 + 1] = nx;
+      saved[r * 3 + 2] = ny;
+      part += (double)(dot / (fmaxf(nx, eps) * fmaxf(ny, eps)));
+    }
+  }
+  __syncthreads();
+  if (lane == 0) red[wid] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (float)((red[0] + red[1] + red[2] + red[3]) / rows);
+}
+// d/dx [x.y / (max(|x|,eps) max(|y|,eps))] = y/(nx' ny') - (x.y) x / (nx'^3 ny')   (second term only where |x| > eps)
+__global__ void __launch_bounds__(256) cosine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ saved,
+                                                         const float* __restrict__ dout, float* __restrict__ dx, int rows, int C, float eps) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * C) return;
+  const int r = i / C;
+  const float dot = saved[r * 3], nx = saved[r * 3 + 1], ny = saved[r * 3 + 2];
+  const float nxc = fmaxf(nx, eps), nyc = fmaxf(ny, eps);
+  const float g = dout[0] / (float)rows;
+  float v = y[i] / (nxc * nyc);
+  if (nx > eps) v -= dot * x[i] / (nxc * nxc * nxc * nyc);
+  dx[i] = g * v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SGD over a flat arena; per-tensor flags looked up by binary search on the offsets table.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                  const int64_t* __restrict__ offsets, const int32_t* __restrict__ flags, int ntensors,
+                                                  int64_t total, float lr, float momentum, float wd, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int lo = 0, hi = ntensors;  // find t with offsets[t] <= i < offsets[t+1]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int f = flags[lo];
+    if (!(f & 1)) continue;
+    const float pv = p[i];
+    const float gv = g[i] * gscale + wd * pv;
+    const float b = (f & 2) ? momentum * buf[i] + gv : gv;
+    buf[i] = b;
+    p[i] = pv - lr * b;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight packing
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) pack_conv3_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Co, int Ci) {
+  const int64_t total = (int64_t)Co * Ci * 27;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // i enumerates the reference layout [co][ci][t]
+    const int t = (int)(i % 27);
+    const int ci = (int)((i / 27) % Ci);
+    const int co = (int)(i / (27 * (int64_t)Ci));
+    const T v = from_f<T>(w[i]);
+    if (wf) wf[((int64_t)co * 27 + t) * Ci + ci] = v;
+    if (wd) wd[((int64_t)ci * 27 + (26 - t)) * Co + co] = v;
+  }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) pack_convt_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int Ci, int Co) {
+  const int64_t total = (int64_t)Ci * Co * 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    // reference layout [ci][co][t]
+    const int t = (int)(i % 8);
+    const int co = (int)((i / 8) % Co);
+    const int ci = (int)(i / (8 * (int64_t)Co));
+    const T v = from_f<T>(w[i]);
+    if (wf) wf[((int64_t)t * Co + co) * Ci + ci] = v;
+    if (wd) wd[((int64_t)ci * 8 + t) * Co + co] = v;
+  }
+}
+
+inline unsigned grid_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int pcrl_bn1d_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                             float momentum, float eps, float* mean, float* rstd, int rows, int C, int relu, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && y && gamma && beta && mean && rstd, "bn1d_fwd: null pointer");
+  PCRL_REQUIRE(rows > 1, "bn1d_fwd: Expected more than 1 value per channel when training, got rows=%d", rows);
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), x, y, gamma, beta, running_mean, running_var,
+                     momentum, eps, mean, rstd, rows, C, relu);
+  return pcrl_check_launch("bn1d_fwd");
+}
+extern "C" int pcrl_bn1d_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* mean, const float* rstd,
+                             float* dx, float* dgamma, float* dbeta, int rows, int C, int relu, pcrl_stream_t stream) {
+  PCRL_REQUIRE(dy && x && y && gamma && mean && rstd && dx && dgamma && dbeta, "bn1d_bwd: null pointer");
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), dy, x, y, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, relu);
+  return pcrl_check_launch("bn1d_bwd");
+}
+extern "C" int pcrl_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int Cin, int Cout, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && w && y && rows > 0 && Cin > 0 && Cout > 0, "linear_fwd: bad arguments");
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((rows * Cout + 255) / 256), dim3(256), 0, as_stream(stream), x, w, b, y, rows, Cin, Cout);
+  return pcrl_check_launch("linear_fwd");
+}
+extern "C" int pcrl_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                               int rows, int Cin, int Cout, pcrl_stream_t stream) {
+  PCRL_REQUIRE(dy && x && w && dx && dw, "linear_bwd: null pointer");
+  hipLaunchKernelGGL(linear_dx_kernel, dim3((rows * Cin + 255) / 256), dim3(256), 0, as_stream(stream), dy, w, dx, rows, Cin, Cout);
+  if (int e = pcrl_check_launch("linear_dx")) return e;
+  hipLaunchKernelGGL(linear_dw_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, as_stream(stream), dy, x, dw, db, rows, Cin, Cout);
+  return pcrl_check_launch("linear_dw");
+}
+
+extern "C" int pcrl_upsample_trilinear_fwd(const float* x, float* y, int N, int D, int H, int W, int scale, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && y && scale >= 1 && scale <= 4, "upsample_trilinear_fwd: scale must be 1..4 (got %d)", scale);
+  const int64_t total = (int64_t)N * D * H * W * scale * scale * scale;
+  hipLaunchKernelGGL(tri_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, Dims{N, D, H, W}, scale, total);
+  return pcrl_check_launch("tri_fwd");
+}
+extern "C" int pcrl_upsample_trilinear_bwd(const float* dy, float* dx, int N, int D, int H, int W, int scale, pcrl_stream_t stream) {
+  PCRL_REQUIRE(dy && dx && scale >= 1 && scale <= 4, "upsample_trilinear_bwd: scale must be 1..4 (got %d)", scale);
+  const int64_t total = (int64_t)N * D * H * W;
+  hipLaunchKernelGGL(tri_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dx, Dims{N, D, H, W}, scale, total);
+  return pcrl_check_launch("tri_bwd");
+}
+
+extern "C" int pcrl_sigmoid_fwd(const float* x, float* y, int64_t n, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && y, "sigmoid_fwd: null pointer");
+  hipLaunchKernelGGL(sigmoid_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), x, y, n);
+  return pcrl_check_launch("sigmoid_fwd");
+}
+extern "C" int pcrl_sigmoid_bwd(const float* dout, const float* out, float* dpre, int64_t n, pcrl_stream_t stream) {
+  PCRL_REQUIRE(dout && out && dpre, "sigmoid_bwd: null pointer");
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), dout, out, dpre, n);
+  return pcrl_check_launch("sigmoid_bwd");
+}
+
+extern "C" size_t pcrl_reduce_ws_bytes(int64_t n) { return (size_t)((n + RED_CHUNK - 1) / RED_CHUNK) * sizeof(double); }
+
+extern "C" int pcrl_mse_fwd(const float* p, const float* gt, float* loss, void* ws, size_t ws_bytes, int64_t n, pcrl_stream_t stream) {
+  PCRL_REQUIRE(p && gt && loss && n > 0, "mse_fwd: bad arguments");
+  if (!ws || ws_bytes < pcrl_reduce_ws_bytes(n)) return pcrl_fail(PCRL_EWORKSPACE, "mse_fwd: workspace too small");
+  const int blocks = (int)((n + RED_CHUNK - 1) / RED_CHUNK);
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), p, gt, (double*)ws, n);
+  if (int e = pcrl_check_launch("mse_partial")) return e;
+  hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const double*)ws, loss, blocks, 1.0 / (double)n);
+  return pcrl_check_launch("mse_finish");
+}
+extern "C" int pcrl_mse_bwd(const float* p, const float* gt, const float* dloss, float* dp, int64_t n, pcrl_stream_t stream) {
+  PCRL_REQUIRE(p && gt && dloss && dp && n > 0, "mse_bwd: bad arguments");
+  hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, as_stream(stream), p, gt, dloss, dp, n, (float)(2.0 / (double)n));
+  return pcrl_check_launch("mse_bwd");
+}
+
+extern "C" int pcrl_cosine_mean_fwd(const float* x, const float* y, float* out, float* saved, int rows, int C, float eps, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && y && out && saved && rows > 0 && C > 0, "cosine_mean_fwd: bad arguments");
+  hipLaunchKernelGGL(cosine_fwd_kernel, dim3(1), dim3(256), 0, as_stream(stream), x, y, out, saved, rows, C, eps);
+  return pcrl_check_launch("cosine_fwd");
+}
+extern "C" int pcrl_cosine_mean_bwd(const float* x, const float* y, const float* saved, const float* dout, float* dx,
+                                    int rows, int C, float eps, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && y && saved && dout && dx, "cosine_mean_bwd: null pointer");
+  hipLaunchKernelGGL(cosine_bwd_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, as_stream(stream), x, y, saved, dout, dx, rows, C, eps);
+  return pcrl_check_launch("cosine_bwd");
+}
+
+extern "C" int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
+                             int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream) {
+  PCRL_REQUIRE(p && g && buf && offsets && flags && ntensors > 0 && total > 0, "sgd_step: bad arguments");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), p, g, buf, offsets, flags, ntensors, total, lr, momentum,
+                     weight_decay, grad_scale);
+  return pcrl_check_launch("sgd");
+}
+
+extern "C" int pcrl_pack_conv3_weight(const float* w_ref, void* w_fwd, void* w_dgrad, int Co, int Ci, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(w_ref && Co > 0 && Ci > 0, "pack_conv3_weight: bad arguments");
+  const int64_t total = (int64_t)Co * Ci * 27;
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(pack_conv3_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w_ref, (bf16*)w_fwd, (bf16*)w_dgrad, Co, Ci);
+  else if (dtype == PCRL_F32) hipLaunchKernelGGL(pack_conv3_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w_ref, (float*)w_fwd, (float*)w_dgrad, Co, Ci);
+  else return pcrl_fail(PCRL_EINVAL, "pack_conv3_weight: bad dtype %d", dtype);
+  return pcrl_check_launch("pack_conv3");
+}
+extern "C" int pcrl_pack_convt_weight(const float* w_ref, void* w_fwd, void* w_dgrad, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(w_ref && Co > 0 && Ci > 0, "pack_convt_weight: bad arguments");
+  const int64_t total = (int64_t)Co * Ci * 8;
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(pack_convt_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w_ref, (bf16*)w_fwd, (bf16*)w_dgrad, Ci, Co);
+  else if (dtype == PCRL_F32) hipLaunchKernelGGL(pack_convt_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), w_ref, (float*)w_fwd, (float*)w_dgrad, Ci, Co);
+  else return pcrl_fail(PCRL_EINVAL, "pack_convt_weight: bad dtype %d", dtype);
+  return pcrl_check_launch("pack_convt");
+}

@@ -1,0 +1,496 @@
+// HBM-bound NDHWC kernels: training-mode BatchNorm3d (+ReLU / sigmoid) forward & backward, MaxPool3d(2),
+// global average pool, per-channel column sums.  All accesses are 16-byte channel vectors; every
+// reduction is two-stage with a fixed order (no atomics), second stage in fp64.
+//
+// Replaces aten::native_batch_norm(+_backward), relu_/threshold_backward, sigmoid(+_backward)
+// (models/pcrlv2_model_3d.py:12,21,27,33), max_pool3d_with_indices(+backward) (:100,115-117) and
+// adaptive_avg_pool3d(+backward) (:67).
+#include "common.h"
+
+namespace {
+
+constexpr int TILE_ROWS = 1024;  // rows per first-stage partial
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf(-z)); }
+
+template <int ACT> __device__ __forceinline__ float act_fwd(float z) {
+  if (ACT == PCRL_ACT_RELU) return z > 0.f ? z : 0.f;
+  if (ACT == PCRL_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
+  return z;
+}
+template <int ACT> __device__ __forceinline__ float act_bwd(float z, float da) {
+  if (ACT == PCRL_ACT_RELU) return z > 0.f ? da : 0.f;
+  if (ACT == PCRL_ACT_SIGMOID) {
+    const float a = 1.f / (1.f + expf(-z));
+    return da * a * (1.f - a);
+  }
+  return da;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Statistics finalize: one block per channel.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum, float eps,
+                                                          float* mean, float* rstd, float* scale, float* shift) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    s1 += (double)partial[((int64_t)r * C + c) * 2 + 0];
+    s2 += (double)partial[((int64_t)r * C + c) * 2 + 1];
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) {
+    const double mu = s1 / count;
+    double var = s2 / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double rs = 1.0 / sqrt(var + (double)eps);
+    mean[c] = (float)mu;
+    rstd[c] = (float)rs;
+    const double sc = (double)gamma[c] * rs;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - mu * sc);
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    if (running_var) {
+      const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, float* dgamma, float* dbeta,
+                                                              float* k1, float* kB, float* kA) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    s1 += (double)partial[((int64_t)r * C + c) * 2 + 0];
+    s2 += (double)partial[((int64_t)r * C + c) * 2 + 1];
+  }
+  s1 = block_sum_256(s1, red);
+  s2 = block_sum_256(s2, red);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+    const double g1 = (double)gamma[c] * (double)rstd[c];
+    const double b = -g1 * (double)rstd[c] * s2 / count;
+    k1[c] = (float)g1;
+    kB[c] = (float)b;
+    kA[c] = (float)(-g1 * s1 / count - b * (double)mean[c]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Elementwise apply (forward and backward).  C % VEC == 0, or C == 1.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_apply_kernel(const T* __restrict__ y, T* __restrict__ a, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int64_t nvec, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (C == 1) ? 0 : (int)((i * VEC) % C);
+    const Vec16<T> v = ld16(y + i * VEC);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = (C == 1) ? 0 : c0 + j;
+      o.v[j] = from_f<T>(act_fwd<ACT>(scale[c] * to_f(v.v[j]) + shift[c]));
+    }
+    st16(a + i * VEC, o);
+  }
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ da, const T* __restrict__ y, T* __restrict__ dy,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ k1, const float* __restrict__ kB,
+                                                           const float* __restrict__ kA, int64_t nvec, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (C == 1) ? 0 : (int)((i * VEC) % C);
+    const Vec16<T> g = ld16(da + i * VEC);
+    const Vec16<T> v = ld16(y + i * VEC);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = (C == 1) ? 0 : c0 + j;
+      const float yv = to_f(v.v[j]);
+      const float dz = act_bwd<ACT>(scale[c] * yv + shift[c], to_f(g.v[j]));
+      o.v[j] = from_f<T>(k1[c] * dz + kB[c] * yv + kA[c]);
+    }
+    st16(dy + i * VEC, o);
+  }
+}
+
+// First-stage reduction of the backward: per 1024-row tile, per channel: (sum dz, sum dz*xhat).
+// Thread = (channel vector, row slot); LDS combine over row slots.  nvec = C/VEC divides 256.
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ y,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ partial, int64_t M, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C'][2], C' = max(C, VEC)
+  const int tid = threadIdx.x;
+  const int nvec = (C == 1) ? 1 : C / VEC;
+  const int cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
+  // C == 1: a "row" is VEC consecutive voxels of the single channel
+  const int64_t rows_total = (C == 1) ? M / VEC : M;
+  const int tile = (C == 1) ? TILE_ROWS / VEC : TILE_ROWS;
+  const int64_t rbeg = (int64_t)blockIdx.x * tile;
+  const int64_t rend = (rbeg + tile < rows_total) ? rbeg + tile : rows_total;
+  float s1[VEC], s2[VEC], sc[VEC], sh[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int c = (C == 1) ? 0 : cv * VEC + j;
+    s1[j] = 0.f; s2[j] = 0.f;
+    sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
+  }
+  for (int64_t r = rbeg + slot; r < rend; r += nslots) {
+    const int64_t off = (r * nvec + cv) * VEC;
+    const Vec16<T> g = ld16(da + off);
+    const Vec16<T> v = ld16(y + off);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float yv = to_f(v.v[j]);
+      const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], to_f(g.v[j]));
+      s1[j] += dz;
+      s2[j] += dz * (yv - mu[j]) * rs[j];
+    }
+  }
+  const int Cp = nvec * VEC;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sm[(slot * Cp + cv * VEC + j) * 2 + 0] = s1[j];
+    sm[(slot * Cp + cv * VEC + j) * 2 + 1] = s2[j];
+  }
+  __syncthreads();
+  if (C == 1) {
+    if (tid == 0) {
+      float a = 0.f, b = 0.f;
+      for (int s = 0; s < nslots; ++s)
+        for (int j = 0; j < VEC; ++j) { a += sm[(s * Cp + j) * 2]; b += sm[(s * Cp + j) * 2 + 1]; }
+      partial[(int64_t)blockIdx.x * 2 + 0] = a;
+      partial[(int64_t)blockIdx.x * 2 + 1] = b;
+    }
+  } else {
+    for (int c = tid; c < C; c += 256) {
+      float a = 0.f, b = 0.f;
+      for (int s = 0; s < nslots; ++s) { a += sm[(s * Cp + c) * 2]; b += sm[(s * Cp + c) * 2 + 1]; }
+      partial[((int64_t)blockIdx.x * C + c) * 2 + 0] = a;
+      partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums over row tiles (used by colsum and the global average pool).
+//   ws[(blockIdx.y * gridDim.x + blockIdx.x) * C + c] = sum over the tile's rows of v[n=blockIdx.y][row][c]
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) coltile_sum_kernel(const T* __restrict__ v, float* __restrict__ ws, int64_t rows_per_n, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C]
+  const int tid = threadIdx.x;
+  const int nvec = C / VEC;
+  const int cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
+  const T* base = v + (int64_t)blockIdx.y * rows_per_n * C;
+  const int64_t rbeg = (int64_t)blockIdx.x * TILE_ROWS;
+  const int64_t rend = (rbeg + TILE_ROWS < rows_per_n) ? rbeg + TILE_ROWS : rows_per_n;
+  float s[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+  for (int64_t r = rbeg + slot; r < rend; r += nslots) {
+    const Vec16<T> x = ld16(base + (r * nvec + cv) * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] += to_f(x.v[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sm[slot * C + cv * VEC + j] = s[j];
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f;
+    for (int q = 0; q < nslots; ++q) a += sm[q * C + c];
+    ws[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * C + c] = a;
+  }
+}
+
+// out[n][c] = scale * sum_t ws[n][t][c]
+__global__ void __launch_bounds__(256) coltile_finish_kernel(const float* __restrict__ ws, float* __restrict__ out, int tiles, int C,
+                                                             int N, double scale) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i % C;
+  double s = 0.0;
+  for (int t = 0; t < tiles; ++t) s += (double)ws[((int64_t)n * tiles + t) * C + c];
+  out[i] = (float)(s * scale);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gap_bwd_kernel(const float* __restrict__ dg, const T* add, T* da, int64_t S,
+                                                      int C, int64_t nvec_total, float inv_s) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nvec = C / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec_total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % nvec);
+    const int64_t n = (i / nvec) / S;
+    const float* gr = dg + n * C + cv * VEC;
+    Vec16<T> o;
+    if (add) {
+      const Vec16<T> old = ld16(add + i * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(to_f(old.v[j]) + gr[j] * inv_s);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(gr[j] * inv_s);
+    }
+    st16(da + i * VEC, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MaxPool3d(2): thread = (output voxel, channel vector)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, Dims g, int C, int64_t total) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nvec = C / VEC;
+  const Dims go{g.N, g.D / 2, g.H / 2, g.W / 2};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % nvec);
+    int n, d, h, w;
+    decode_voxel(i / nvec, go, n, d, h, w);
+    float m[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int64_t row = (((int64_t)n * g.D + 2 * d + (t >> 2)) * g.H + 2 * h + ((t >> 1) & 1)) * g.W + 2 * w + (t & 1);
+      const Vec16<T> v = ld16(x + row * C + cv * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float f = to_f(v.v[j]);
+        if (f > m[j] || f != f) m[j] = f;
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(m[j]);
+    st16(y + i * VEC, o);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, Dims g,
+                                                          int C, int64_t total) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nvec = C / VEC;
+  const Dims go{g.N, g.D / 2, g.H / 2, g.W / 2};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cv = (int)(i % nvec);
+    int n, d, h, w;
+    decode_voxel(i / nvec, go, n, d, h, w);
+    float m[VEC];
+    int arg[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { m[j] = -INFINITY; arg[j] = 0; }
+    int64_t rows[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      rows[t] = (((int64_t)n * g.D + 2 * d + (t >> 2)) * g.H + 2 * h + ((t >> 1) & 1)) * g.W + 2 * w + (t & 1);
+      const Vec16<T> v = ld16(x + rows[t] * C + cv * VEC);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float f = to_f(v.v[j]);
+        if (f > m[j] || f != f) { m[j] = f; arg[j] = t; }  // strict '>' keeps the FIRST maximum in scan order
+      }
+    }
+    const Vec16<T> gy = ld16(dy + i * VEC);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o.v[j] = (arg[j] == t) ? gy.v[j] : from_f<T>(0.f);
+      st16(dx + rows[t] * C + cv * VEC, o);
+    }
+  }
+}
+
+inline unsigned grid_for(int64_t work_items) {
+  int64_t b = (work_items + 255) / 256;
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+int check_vec(const char* what, int C, int dtype, bool allow_c1) {
+  if (dtype != PCRL_F32 && dtype != PCRL_BF16) return pcrl_fail(PCRL_EINVAL, "%s: bad dtype %d", what, dtype);
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  if (C == 1 && allow_c1 && dtype == PCRL_F32) return 0;
+  if (C <= 0 || C % vec != 0) return pcrl_fail(PCRL_EINVAL, "%s: C=%d must be a multiple of %d", what, C, vec);
+  return 0;
+}
+int check_tilevec(const char* what, int C, int dtype, bool allow_c1) {
+  if (int e = check_vec(what, C, dtype, allow_c1)) return e;
+  if (C == 1) return 0;
+  const int nvec = C / (dtype == PCRL_BF16 ? 8 : 4);
+  if (nvec > 256 || 256 % nvec != 0) return pcrl_fail(PCRL_EINVAL, "%s: C=%d: channel vectors (%d) must divide 256", what, C, nvec);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int pcrl_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps,
+                                float* mean, float* rstd, float* scale, float* shift, pcrl_stream_t stream) {
+  PCRL_REQUIRE(partial && gamma && beta && mean && rstd && scale && shift, "bn_finalize: null pointer");
+  PCRL_REQUIRE(rows > 0 && C > 0 && count > 0, "bn_finalize: bad sizes rows=%d C=%d", rows, C);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial, rows, C, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
+  return pcrl_check_launch("bn_finalize");
+}
+
+#define DISPATCH_ACT_T(KERNEL, GRID, LDS, ...)                                                                                   \
+  do {                                                                                                                           \
+    if (act == PCRL_ACT_RELU) hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_RELU>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__); \
+    else if (act == PCRL_ACT_SIGMOID) hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_SIGMOID>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_NONE>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__);                    \
+  } while (0)
+
+extern "C" int pcrl_bn_act_apply(const void* y, void* a, const float* scale, const float* shift,
+                                 int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+  if (int e = check_vec("bn_act_apply", C, dtype, true)) return e;
+  PCRL_REQUIRE(y && a && scale && shift, "bn_act_apply: null pointer");
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  PCRL_REQUIRE((M * C) % vec == 0, "bn_act_apply: M*C must be a multiple of %d", vec);
+  const int64_t nvec = M * C / vec;
+  const dim3 grid(grid_for(nvec));
+  if (dtype == PCRL_BF16) {
+    using T = bf16;
+    DISPATCH_ACT_T(bn_apply_kernel, grid, 0, (const T*)y, (T*)a, scale, shift, nvec, C);
+  } else {
+    using T = float;
+    DISPATCH_ACT_T(bn_apply_kernel, grid, 0, (const T*)y, (T*)a, scale, shift, nvec, C);
+  }
+  return pcrl_check_launch("bn_act_apply");
+}
+
+extern "C" int64_t pcrl_bn_bwd_partial_rows(int64_t M) { return (M + TILE_ROWS - 1) / TILE_ROWS; }
+
+extern "C" int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, const float* shift,
+                                      const float* mean, const float* rstd, float* partial,
+                                      int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+  if (int e = check_tilevec("bn_act_bwd_reduce", C, dtype, true)) return e;
+  PCRL_REQUIRE(da && y && scale && shift && mean && rstd && partial, "bn_act_bwd_reduce: null pointer");
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  PCRL_REQUIRE(C != 1 || M % vec == 0, "bn_act_bwd_reduce: M must be a multiple of %d for C == 1", vec);
+  const dim3 grid((unsigned)pcrl_bn_bwd_partial_rows(M));
+  const int nvec = C == 1 ? 1 : C / vec;
+  const size_t lds = (size_t)(256 / nvec) * (nvec * vec) * 2 * sizeof(float);
+  if (dtype == PCRL_BF16) {
+    using T = bf16;
+    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C);
+  } else {
+    using T = float;
+    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C);
+  }
+  return pcrl_check_launch("bn_act_bwd_reduce");
+}
+
+extern "C" int pcrl_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* mean,
+                                    const float* rstd, float* dgamma, float* dbeta, float* k1, float* kB, float* kA,
+                                    pcrl_stream_t stream) {
+  PCRL_REQUIRE(partial && gamma && mean && rstd && dgamma && dbeta && k1 && kB && kA, "bn_bwd_finalize: null pointer");
+  PCRL_REQUIRE(rows > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad sizes rows=%d C=%d", rows, C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), partial, rows, C, count, gamma, mean, rstd,
+                     dgamma, dbeta, k1, kB, kA);
+  return pcrl_check_launch("bn_bwd_finalize");
+}
+
+extern "C" int pcrl_bn_act_bwd_apply(const void* da, const void* y, void* dy, const float* scale, const float* shift,
+                                     const float* k1, const float* kB, const float* kA,
+                                     int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+  if (int e = check_vec("bn_act_bwd_apply", C, dtype, true)) return e;
+  PCRL_REQUIRE(da && y && dy && scale && shift && k1 && kB && kA, "bn_act_bwd_apply: null pointer");
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  PCRL_REQUIRE((M * C) % vec == 0, "bn_act_bwd_apply: M*C must be a multiple of %d", vec);
+  const int64_t nvec = M * C / vec;
+  const dim3 grid(grid_for(nvec));
+  if (dtype == PCRL_BF16) {
+    using T = bf16;
+    DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
+  } else {
+    using T = float;
+    DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
+  }
+  return pcrl_check_launch("bn_act_bwd_apply");
+}
+
+extern "C" int pcrl_maxpool3d_2_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, pcrl_stream_t stream) {
+  if (int e = check_vec("maxpool3d_2_fwd", C, dtype, false)) return e;
+  PCRL_REQUIRE(x && y, "maxpool3d_2_fwd: null pointer");
+  PCRL_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && D > 0 && H > 0 && W > 0, "maxpool3d_2_fwd: dims must be even (%d %d %d)", D, H, W);
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vec);
+  const Dims g{N, D, H, W};
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const bf16*)x, (bf16*)y, g, C, total);
+  else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, g, C, total);
+  return pcrl_check_launch("maxpool_fwd");
+}
+
+extern "C" int pcrl_maxpool3d_2_bwd(const void* x, const void* dy, void* dx, int N, int D, int H, int W, int C, int dtype, pcrl_stream_t stream) {
+  if (int e = check_vec("maxpool3d_2_bwd", C, dtype, false)) return e;
+  PCRL_REQUIRE(x && dy && dx, "maxpool3d_2_bwd: null pointer");
+  PCRL_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && D > 0 && H > 0 && W > 0, "maxpool3d_2_bwd: dims must be even (%d %d %d)", D, H, W);
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vec);
+  const Dims g{N, D, H, W};
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const bf16*)x, (const bf16*)dy, (bf16*)dx, g, C, total);
+  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (float*)dx, g, C, total);
+  return pcrl_check_launch("maxpool_bwd");
+}
+
+extern "C" size_t pcrl_colsum_ws_bytes(int64_t M, int C) { return (size_t)((M + TILE_ROWS - 1) / TILE_ROWS) * C * sizeof(float); }
+
+static int coltile_launch(const void* v, float* out, void* ws, size_t ws_bytes, int N, int64_t S, int C, int dtype, double scale,
+                          hipStream_t stream, const char* what) {
+  if (int e = check_tilevec(what, C, dtype, false)) return e;
+  const int64_t tiles = (S + TILE_ROWS - 1) / TILE_ROWS;
+  const size_t need = (size_t)N * tiles * C * sizeof(float);
+  if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "%s: workspace %zu < %zu", what, ws_bytes, need);
+  const size_t lds = (size_t)(256 / (C / (dtype == PCRL_BF16 ? 8 : 4))) * C * sizeof(float);
+  const dim3 grid((unsigned)tiles, (unsigned)N);
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(coltile_sum_kernel<bf16>, grid, dim3(256), lds, stream, (const bf16*)v, (float*)ws, S, C);
+  else hipLaunchKernelGGL(coltile_sum_kernel<float>, grid, dim3(256), lds, stream, (const float*)v, (float*)ws, S, C);
+  if (int e = pcrl_check_launch(what)) return e;
+  hipLaunchKernelGGL(coltile_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, out, (int)tiles, C, N, scale);
+  return pcrl_check_launch(what);
+}
+
+extern "C" int pcrl_colsum(const void* v, float* out, void* ws, size_t ws_bytes, int64_t M, int C, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(v && out, "colsum: null pointer");
+  return coltile_launch(v, out, ws, ws_bytes, 1, M, C, dtype, 1.0, as_stream(stream), "colsum");
+}
+
+extern "C" size_t pcrl_gap_ws_bytes(int N, int64_t S, int C) { return (size_t)N * ((S + TILE_ROWS - 1) / TILE_ROWS) * C * sizeof(float); }
+
+extern "C" int pcrl_gap_fwd(const void* a, float* g, void* ws, size_t ws_bytes, int N, int64_t S, int C, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(a && g && N > 0 && S > 0, "gap_fwd: bad arguments");
+  return coltile_launch(a, g, ws, ws_bytes, N, S, C, dtype, 1.0 / (double)S, as_stream(stream), "gap_fwd");
+}
+
+extern "C" int pcrl_gap_bwd(const float* dg, const void* add_src, void* da, int N, int64_t S, int C, int dtype, pcrl_stream_t stream) {
+  if (int e = check_vec("gap_bwd", C, dtype, false)) return e;
+  PCRL_REQUIRE(dg && da && N > 0 && S > 0, "gap_bwd: bad arguments");
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  const int64_t nvt = (int64_t)N * S * (C / vec);
+  const float inv = (float)(1.0 / (double)S);
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(gap_bwd_kernel<bf16>, dim3(grid_for(nvt)), dim3(256), 0, as_stream(stream), dg, (const bf16*)add_src, (bf16*)da, S, C, nvt, inv);
+  else hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for(nvt)), dim3(256), 0, as_stream(stream), dg, (const float*)add_src, (float*)da, S, C, nvt, inv);
+  return pcrl_check_launch("gap_bwd");
+}

@@ -1,0 +1,208 @@
+"""autograd.Function wrappers: the drop-in boundary towards torch's autograd engine.
+
+One Function per reference stage so every gradient fan-out inside a stage (UpTransition feeds the
+next stage, the pooled projection head and the deep-supervision head from the same tensor) is
+combined by our own kernels instead of autograd's adds.  Unused outputs arrive as None
+(`set_materialize_grads(False)`) and whole branches are skipped, which reproduces what the
+reference's autograd does for the never-used `mask2` / view-2 deep-supervision heads.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+from ._lib import ACT_RELU, ACT_SIGMOID
+
+
+def _act_grad(g, dtype):
+    return ops.to_act(g, dtype)
+
+
+class LUConvFn(Function):
+    """act(bn1(conv1(x)))  --  models/pcrlv2_model_3d.py:32-34."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, mod):
+        dt = mod.compute_dtype
+        a, sv = ops.luconv_forward(x, w, b, gamma, beta, mod.bn1.running_mean, mod.bn1.running_var, mod._packed, mod._act, dt)
+        mod._count_batch()
+        ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
+        ctx.wref, ctx.gref = w, gamma
+        ctx.set_materialize_grads(False)
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        if da is None:
+            return (None,) * 6
+        sv = ctx.sv
+        da = da.contiguous() if sv.kind == "to1" else _act_grad(da, ctx.dt)
+        dx, dw, db, dg, dbeta = ops.luconv_backward(sv, da, ctx.wref, ctx.gref, ctx.mod._packed, ctx.dt,
+                                                    need_dx=ctx.needs_input_grad[0] and sv.kind != "c1")
+        return dx, dw, db, dg, dbeta, None
+
+
+class MaxPoolFn(Function):
+    """nn.MaxPool3d(2)  --  models/pcrlv2_model_3d.py:100,115-117."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.x, ctx.dt = x, dt
+        ctx.set_materialize_grads(False)
+        return ops.maxpool_forward(x, dt)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None
+        return ops.maxpool_backward(ctx.x, _act_grad(dy, ctx.dt), ctx.dt), None
+
+
+class UpStageFn(Function):
+    """UpTransition.forward  --  models/pcrlv2_model_3d.py:62-72.
+
+    inputs : x, up_w, up_b, [w,b,gamma,beta] of ops.0, ops.1, bn.(gamma,beta), ph0.(w,b), ph1.(gamma,beta),
+             ph3.(w,b), [w,b,gamma,beta] of deep_supervision_head, module
+    outputs: x_out (activation), x_pro [N,C], x_pre [N,C], x_mask [N,1,D,H,W] float32
+    """
+
+    @staticmethod
+    def forward(ctx, x, up_w, up_b, w0, b0, g0, be0, w1, b1, g1, be1, bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b,
+                dw_, db_, dg_, dbe_, mod):
+        dt = mod.compute_dtype
+        x = ops.to_act(x, dt)
+        up = ops.convt_forward(x, up_w, up_b, mod._packed_up, dt)
+        l0, l1, ld = mod.ops[0], mod.ops[1], mod.deep_supervision_head
+        a0, sv0 = ops.luconv_forward(up, w0, b0, g0, be0, l0.bn1.running_mean, l0.bn1.running_var, l0._packed, ACT_RELU, dt)
+        a1, sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, l1.bn1.running_mean, l1.bn1.running_var, l1._packed, ACT_RELU, dt)
+        g = ops.gap_forward(a1, dt)
+        x_pro, m_pro, r_pro = ops.bn1d_forward(g, bn_g, bn_b, mod.bn.running_mean, mod.bn.running_var, relu=False)
+        h0 = ops.linear_forward(x_pro, p0_w, p0_b)
+        ph1 = mod.predictor_head[1]
+        h1, m_h, r_h = ops.bn1d_forward(h0, p1_g, p1_b, ph1.running_mean, ph1.running_var, relu=True)
+        x_pre = ops.linear_forward(h1, p3_w, p3_b)
+        x_mask, svd = ops.luconv_forward(a1, dw_, db_, dg_, dbe_, ld.bn1.running_mean, ld.bn1.running_var, ld._packed, ACT_SIGMOID, dt)
+        for m in (l0, l1, ld):
+            m._count_batch()
+        mod._count_batch_heads()
+        ctx.mod, ctx.dt = mod, dt
+        ctx.x, ctx.sv0, ctx.sv1, ctx.svd, ctx.a1 = x, sv0, sv1, svd, a1
+        ctx.heads = (g, x_pro, m_pro, r_pro, h0, h1, m_h, r_h)
+        ctx.params = (up_w, w0, g0, w1, g1, bn_g, p0_w, p1_g, p3_w, dw_, dg_)
+        ctx.set_materialize_grads(False)
+        return a1, x_pro, x_pre, x_mask
+
+    @staticmethod
+    def backward(ctx, d_out, d_pro, d_pre, d_mask):
+        n_in = 24
+        if d_out is None and d_pro is None and d_pre is None and d_mask is None:
+            return (None,) * n_in
+        mod, dt = ctx.mod, ctx.dt
+        up_w, w0, g0, w1, g1, bn_g, p0_w, p1_g, p3_w, dsw, dsg = ctx.params
+        g, x_pro, m_pro, r_pro, h0, h1, m_h, r_h = ctx.heads
+        l0, l1, ld = mod.ops[0], mod.ops[1], mod.deep_supervision_head
+        grads = [None] * n_in
+
+        # ---- gradient w.r.t. a1 (output of ops.1): up to three sources, combined by our kernels ----
+        d_a1 = _act_grad(d_out, dt) if d_out is not None else None
+        # predictor / projection heads (train: pcrlv2_model_3d.py:55-59,69-70)
+        if d_pre is not None or d_pro is not None:
+            d_xpro = d_pro.contiguous() if d_pro is not None else None
+            if d_pre is not None:
+                d_h1, g_p3w, g_p3b = ops.linear_backward(d_pre, h1, p3_w)
+                d_h0, g_p1g, g_p1b = ops.bn1d_backward(d_h1, h0, h1, p1_g, m_h, r_h, relu=True)
+                d_xp, g_p0w, g_p0b = ops.linear_backward(d_h0, x_pro, p0_w)
+                d_xpro = d_xp if d_xpro is None else d_xpro + d_xp   # [N,C] float32: a few KB
+                grads[13], grads[14], grads[15], grads[16], grads[17], grads[18] = g_p0w, g_p0b, g_p1g, g_p1b, g_p3w, g_p3b
+            d_g, g_bng, g_bnb = ops.bn1d_backward(d_xpro, g, x_pro, bn_g, m_pro, r_pro, relu=False)
+            grads[11], grads[12] = g_bng, g_bnb
+            d_a1 = ops.gap_backward(d_g, ctx.a1, d_a1, dt)
+        # deep-supervision head (pcrlv2_model_3d.py:60,71)
+        if d_mask is not None:
+            dx_ds, g_dw, g_db, g_dg, g_dbe = ops.luconv_backward(ctx.svd, d_mask, dsw, dsg, ld._packed, dt, need_dx=True, dx_add=d_a1)
+            d_a1 = dx_ds
+            grads[19], grads[20], grads[21], grads[22] = g_dw, g_db, g_dg, g_dbe
+        # ---- ops.1, ops.0 ----
+        d_a0, gw1, gb1, gg1, gbe1 = ops.luconv_backward(ctx.sv1, d_a1, w1, g1, l1._packed, dt, need_dx=True)
+        grads[7], grads[8], grads[9], grads[10] = gw1, gb1, gg1, gbe1
+        d_up, gw0, gb0, gg0, gbe0 = ops.luconv_backward(ctx.sv0, d_a0, w0, g0, l0._packed, dt, need_dx=True)
+        grads[3], grads[4], grads[5], grads[6] = gw0, gb0, gg0, gbe0
+        # ---- up_conv ----
+        dx, g_upw, g_upb = ops.convt_backward(ctx.x, d_up, up_w, mod._packed_up, dt, need_dx=ctx.needs_input_grad[0])
+        grads[0], grads[1], grads[2] = dx, g_upw, g_upb
+        return tuple(grads)
+
+
+class OutFn(Function):
+    """OutputTransition.forward: sigmoid(final_conv(x))  --  models/pcrlv2_model_3d.py:81-83."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, mod):
+        dt = mod.compute_dtype
+        x = ops.to_act(x, dt)
+        out = ops.conv1x1_to1_forward(x, w, b, dt)
+        ctx.x, ctx.out, ctx.w, ctx.dt = x, out, w, dt
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if dout is None:
+            return None, None, None, None
+        dx, dw, db = ops.conv1x1_to1_backward(ctx.x, ctx.out, dout, ctx.w, ctx.dt, need_dx=ctx.needs_input_grad[0])
+        return dx, dw, db, None
+
+
+class TrilinearFn(Function):
+    """F.interpolate(x, scale_factor=s, mode='trilinear')  --  models/pcrlv2_model_3d.py:125-126."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.shape, ctx.scale = tuple(x.shape), scale
+        ctx.set_materialize_grads(False)
+        return ops.upsample_forward(x, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None
+        return ops.upsample_backward(dy, ctx.shape, ctx.scale), None
+
+
+class MSELossFn(Function):
+    """nn.MSELoss()(p, gt)  --  train_3d.py:56,135,137."""
+
+    @staticmethod
+    def forward(ctx, p, gt):
+        p, gt = p.contiguous().float(), gt.contiguous().float()
+        ctx.p, ctx.gt = p, gt
+        return ops.mse_forward(p, gt)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        return ops.mse_backward(ctx.p, ctx.gt, dloss), None
+
+
+class CosineMeanFn(Function):
+    """nn.CosineSimilarity(dim=1, eps=1e-8)(x, y.detach()).mean()  --  train_3d.py:57,90-91.
+    Gradient flows to x only (the reference always detaches the second operand)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.contiguous().float(), y.contiguous().float()
+        out, saved = ops.cosine_mean_forward(x, y)
+        ctx.x, ctx.y, ctx.saved = x, y, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.cosine_mean_backward(ctx.x, ctx.y, ctx.saved, dout), None
+
+
+def mse_loss(p, gt):
+    return MSELossFn.apply(p, gt)
+
+
+def cosine_mean(x, y_detached):
+    return CosineMeanFn.apply(x, y_detached.detach())

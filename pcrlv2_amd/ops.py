@@ -1,0 +1,403 @@
+"""Host-side functional layer over libpcrl_hip.so (plain functions on device tensors, no autograd).
+
+Tensor conventions (see include/pcrl_hip.h):
+  * activations: torch tensors of logical shape [N, C, D, H, W] whose MEMORY is NDHWC (torch's
+    channels_last_3d), dtype float32 or bfloat16 -- `new_act` / `dims` below;
+  * 1-channel maps, head tensors [rows, C], parameters and their gradients: contiguous float32.
+Every function launches on torch's current stream and returns immediately.
+"""
+from __future__ import annotations
+
+import torch
+
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_BM, PcrlError, dtype_code, lib, stream_handle
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+# ----------------------------------------------------------------------------------------------
+# memory helpers
+# ----------------------------------------------------------------------------------------------
+_ws_cache: dict = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Grow-only scratch arena per device; safe to share because all calls are stream-ordered."""
+    key = (device.type, device.index)
+    t = _ws_cache.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = t
+    return t
+
+
+def new_act(N, D, H, W, C, dtype, device) -> torch.Tensor:
+    return torch.empty((N, D, H, W, C), dtype=dtype, device=device).permute(0, 4, 1, 2, 3)
+
+
+def dims(t: torch.Tensor):
+    """(N, D, H, W, C) of an NDHWC-memory activation; raises if the memory layout is not NDHWC."""
+    if t.dim() != 5:
+        raise PcrlError(f"expected a 5-D activation, got shape {tuple(t.shape)}")
+    N, C, D, H, W = t.shape
+    if not t.permute(0, 2, 3, 4, 1).is_contiguous():
+        raise PcrlError("activation is not NDHWC (channels_last_3d) contiguous")
+    return N, D, H, W, C
+
+
+def to_act(x: torch.Tensor, dtype) -> torch.Tensor:
+    """API-boundary glue: any [N,C,D,H,W] tensor -> NDHWC memory in `dtype` (no-op when already so)."""
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    if not x.permute(0, 2, 3, 4, 1).is_contiguous():
+        x = x.permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)
+    return x
+
+
+def _f32(n, device):
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
+# ----------------------------------------------------------------------------------------------
+# weight packing (cached per parameter version)
+# ----------------------------------------------------------------------------------------------
+_weights_epoch = 0
+
+
+def bump_weights_epoch():
+    """Called by optimizers that update parameters outside torch's version counter."""
+    global _weights_epoch
+    _weights_epoch += 1
+
+
+class PackedWeights:
+    """Packed (K-contiguous, activation-dtype) copies of one conv / transposed-conv weight."""
+
+    def __init__(self, kind: str):
+        self.kind = kind  # 'conv3' | 'convt'
+        self.key = None
+        self.fwd = None
+        self.dgrad = None
+
+    def get(self, w: torch.Tensor, dtype):
+        key = (_weights_epoch, w._version, w.data_ptr(), dtype)
+        if key != self.key:
+            L, s = lib(), stream_handle()
+            self.fwd = torch.empty(w.numel(), dtype=dtype, device=w.device)
+            self.dgrad = torch.empty(w.numel(), dtype=dtype, device=w.device)
+            if self.kind == "conv3":
+                Co, Ci = w.shape[0], w.shape[1]
+                L.call("pcrl_pack_conv3_weight", w.detach(), self.fwd, self.dgrad, Co, Ci, dtype_code(dtype), s)
+            else:
+                Ci, Co = w.shape[0], w.shape[1]
+                L.call("pcrl_pack_convt_weight", w.detach(), self.fwd, self.dgrad, Ci, Co, dtype_code(dtype), s)
+            self.key = key
+        return self.fwd, self.dgrad
+
+
+# ----------------------------------------------------------------------------------------------
+# BatchNorm(+activation) on conv outputs
+# ----------------------------------------------------------------------------------------------
+def bn_finalize(partial, rows, C, count, gamma, beta, running_mean, running_var):
+    dev = partial.device
+    coef = _f32(4 * C, dev)
+    mean, rstd, scale, shift = coef[:C], coef[C:2 * C], coef[2 * C:3 * C], coef[3 * C:]
+    lib().call("pcrl_bn_finalize", partial, rows, C, float(count), gamma, beta, running_mean, running_var,
+               BN_MOMENTUM, BN_EPS, mean, rstd, scale, shift, stream_handle())
+    return mean, rstd, scale, shift
+
+
+def bn_act_apply(y, scale, shift, M, C, act, dtype, out=None):
+    a = torch.empty_like(y) if out is None else out
+    lib().call("pcrl_bn_act_apply", y, a, scale, shift, M, C, act, dtype_code(dtype), stream_handle())
+    return a
+
+
+def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype):
+    """-> (dy, dgamma, dbeta): gradient w.r.t. the pre-normalisation tensor and the affine parameters."""
+    L, s, dev = lib(), stream_handle(), y.device
+    rows = L.call("pcrl_bn_bwd_partial_rows", M)
+    partial = _f32(rows * C * 2, dev)
+    L.call("pcrl_bn_act_bwd_reduce", da, y, scale, shift, mean, rstd, partial, M, C, act, dtype_code(dtype), s)
+    out = _f32(5 * C, dev)
+    dgamma, dbeta, k1, kB, kA = (out[i * C:(i + 1) * C] for i in range(5))
+    L.call("pcrl_bn_bwd_finalize", partial, rows, C, float(M), gamma, mean, rstd, dgamma, dbeta, k1, kB, kA, s)
+    dy = torch.empty_like(y)
+    L.call("pcrl_bn_act_bwd_apply", da, y, dy, scale, shift, k1, kB, kA, M, C, act, dtype_code(dtype), s)
+    return dy, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------------------------
+# LUConv = conv3x3x3 + BatchNorm3d(train) + activation      (models/pcrlv2_model_3d.py:6-34)
+# ----------------------------------------------------------------------------------------------
+class LUConvSaved:
+    __slots__ = ("kind", "x", "y", "mean", "rstd", "scale", "shift", "geom", "act")
+
+
+def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, packed: PackedWeights, act: int, dtype):
+    """x: activation (or float32 [N,1,D,H,W] for the first layer).  Returns (a, saved)."""
+    L, s, dev = lib(), stream_handle(), x.device
+    Co, Ci = conv_w.shape[0], conv_w.shape[1]
+    sv = LUConvSaved()
+    sv.act = act
+    if Co == 1:  # deep-supervision head: C -> 1, float32 map out
+        N, D, H, W, C = dims(x)
+        if C != Ci:
+            raise PcrlError(f"LUConv: input has {C} channels, weight expects {Ci}")
+        M = N * D * H * W
+        rows = (M + 1023) // 1024
+        y = _f32(M, dev)
+        partial = _f32(rows * 2, dev)
+        L.call("pcrl_conv3d_to1_fwd", x, conv_w.detach(), conv_b.detach(), y, partial, N, D, H, W, C, 27, dtype_code(dtype), s)
+        mean, rstd, scale, shift = bn_finalize(partial, rows, 1, M, gamma.detach(), beta.detach(), running_mean, running_var)
+        a = bn_act_apply(y, scale, shift, M, 1, act, torch.float32).view(N, 1, D, H, W)
+        sv.kind = "to1"
+    elif Ci == 1:  # first layer: 1 -> Co on a float32 scalar field
+        if x.dtype != torch.float32 or not x.is_contiguous() or x.shape[1] != 1:
+            raise PcrlError("first-layer input must be a contiguous float32 [N,1,D,H,W] tensor")
+        N, _, D, H, W = x.shape
+        M = N * D * H * W
+        rows = (M + CONV_BM - 1) // CONV_BM
+        y = new_act(N, D, H, W, Co, dtype, dev)
+        partial = _f32(rows * Co * 2, dev)
+        L.call("pcrl_conv3d_k3_c1_fwd", x, conv_w.detach(), conv_b.detach(), y, partial, N, D, H, W, Co, dtype_code(dtype), s)
+        mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var)
+        a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
+        sv.kind = "c1"
+    else:
+        N, D, H, W, C = dims(x)
+        if C != Ci:
+            raise PcrlError(f"LUConv: input has {C} channels, weight expects {Ci}")
+        if x.dtype != dtype:
+            raise PcrlError(f"LUConv: activation dtype {x.dtype} != compute dtype {dtype}")
+        M = N * D * H * W
+        rows = (M + CONV_BM - 1) // CONV_BM
+        wf, _ = packed.get(conv_w, dtype)
+        y = new_act(N, D, H, W, Co, dtype, dev)
+        partial = _f32(rows * Co * 2, dev)
+        L.call("pcrl_conv3d_k3_fwd", x, wf, conv_b.detach(), y, partial, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+        mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var)
+        a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
+        sv.kind = "gemm"
+    sv.x, sv.y, sv.mean, sv.rstd, sv.scale, sv.shift = x, y, mean, rstd, scale, shift
+    sv.geom = (N, D, H, W, Ci, Co)
+    return a, sv
+
+
+def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, dtype, need_dx=True, dx_add=None):
+    """-> (dx | None, dw, db, dgamma, dbeta).  `dx_add`: optional activation folded into dx (to1 kind only).
+
+    db is exactly zero: a bias that is followed by a batch-statistics normalisation has an identically
+    zero gradient (the reference's autograd yields round-off noise ~1e-8 there).
+    """
+    L, s = lib(), stream_handle()
+    N, D, H, W, Ci, Co = sv.geom
+    M = N * D * H * W
+    dev = sv.y.device
+    dw = torch.empty_like(conv_w, dtype=torch.float32, memory_format=torch.contiguous_format)
+    db = torch.zeros(Co, dtype=torch.float32, device=dev)
+    if sv.kind == "to1":
+        da = da.contiguous()
+        dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, 1, sv.act, torch.float32)
+        nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, Ci, 27)
+        dbias_unused = _f32(1, dev)
+        L.call("pcrl_conv3d_to1_wgrad", sv.x, dy, dw, dbias_unused, workspace(nb, dev), nb, N, D, H, W, Ci, 27, dtype_code(dtype), s)
+        dx = None
+        if need_dx:
+            dx = new_act(N, D, H, W, Ci, dtype, dev)
+            L.call("pcrl_conv3d_to1_dgrad", dy, conv_w.detach(), dx_add, dx, N, D, H, W, Ci, 27, dtype_code(dtype), s)
+        return dx, dw, db, dgamma, dbeta
+    dims(da)
+    dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype)
+    if sv.kind == "c1":
+        nb = L.call("pcrl_conv3d_k3_c1_wgrad_ws_bytes", N, D, H, W, Co)
+        L.call("pcrl_conv3d_k3_c1_wgrad", sv.x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Co, dtype_code(dtype), s)
+        return None, dw, db, dgamma, dbeta
+    nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
+    L.call("pcrl_conv3d_k3_wgrad", sv.x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    dx = None
+    if need_dx:
+        _, wd = packed.get(conv_w, dtype)
+        dx = new_act(N, D, H, W, Ci, dtype, dev)
+        L.call("pcrl_conv3d_k3_fwd", dy, wd, None, dx, None, N, D, H, W, Co, Ci, dtype_code(dtype), s)
+    return dx, dw, db, dgamma, dbeta
+
+
+# ----------------------------------------------------------------------------------------------
+# MaxPool3d(2), ConvTranspose3d(k2,s2), global average pool
+# ----------------------------------------------------------------------------------------------
+def maxpool_forward(x, dtype):
+    N, D, H, W, C = dims(x)
+    y = new_act(N, D // 2, H // 2, W // 2, C, dtype, x.device)
+    lib().call("pcrl_maxpool3d_2_fwd", x, y, N, D, H, W, C, dtype_code(dtype), stream_handle())
+    return y
+
+
+def maxpool_backward(x, dy, dtype):
+    N, D, H, W, C = dims(x)
+    dims(dy)
+    dx = torch.empty_like(x)
+    lib().call("pcrl_maxpool3d_2_bwd", x, dy, dx, N, D, H, W, C, dtype_code(dtype), stream_handle())
+    return dx
+
+
+def convt_forward(x, w, b, packed: PackedWeights, dtype):
+    N, D, H, W, Ci = dims(x)
+    Co = w.shape[1]
+    wf, _ = packed.get(w, dtype)
+    y = new_act(N, 2 * D, 2 * H, 2 * W, Co, dtype, x.device)
+    lib().call("pcrl_convt3d_k2s2_fwd", x, wf, b.detach(), y, N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
+    return y
+
+
+def convt_backward(x, dy, w, packed: PackedWeights, dtype, need_dx=True):
+    """-> (dx | None, dw [Ci,Co,2,2,2], db [Co])."""
+    L, s, dev = lib(), stream_handle(), x.device
+    N, D, H, W, Ci = dims(x)
+    Co = w.shape[1]
+    dims(dy)
+    dw = torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format)
+    nb = L.call("pcrl_convt3d_k2s2_wgrad_ws_bytes", N, D, H, W, Ci, Co)
+    L.call("pcrl_convt3d_k2s2_wgrad", x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    Mo = N * D * H * W * 8
+    db = _f32(Co, dev)
+    nb2 = L.call("pcrl_colsum_ws_bytes", Mo, Co)
+    L.call("pcrl_colsum", dy, db, workspace(nb2, dev), nb2, Mo, Co, dtype_code(dtype), s)
+    dx = None
+    if need_dx:
+        _, wd = packed.get(w, dtype)
+        dx = new_act(N, D, H, W, Ci, dtype, dev)
+        L.call("pcrl_convt3d_k2s2_dgrad", dy, wd, dx, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    return dx, dw, db
+
+
+def gap_forward(a, dtype):
+    N, D, H, W, C = dims(a)
+    S = D * H * W
+    g = _f32(N * C, a.device).view(N, C)
+    L = lib()
+    nb = L.call("pcrl_gap_ws_bytes", N, S, C)
+    L.call("pcrl_gap_fwd", a, g, workspace(nb, a.device), nb, N, S, C, dtype_code(dtype), stream_handle())
+    return g
+
+
+def gap_backward(dg, like, add_src, dtype):
+    """da = add_src + dg/S broadcast over the volume (add_src may be None)."""
+    N, D, H, W, C = dims(like)
+    da = torch.empty_like(like)
+    lib().call("pcrl_gap_bwd", dg.contiguous(), add_src, da, N, D * H * W, C, dtype_code(dtype), stream_handle())
+    return da
+
+
+# ----------------------------------------------------------------------------------------------
+# heads: BatchNorm1d / Linear on [rows, C] float32
+# ----------------------------------------------------------------------------------------------
+def bn1d_forward(x, gamma, beta, running_mean, running_var, relu: bool):
+    rows, C = x.shape
+    y = torch.empty_like(x)
+    st = _f32(2 * C, x.device)
+    lib().call("pcrl_bn1d_fwd", x, y, gamma.detach(), beta.detach(), running_mean, running_var, BN_MOMENTUM, BN_EPS,
+               st[:C], st[C:], rows, C, int(relu), stream_handle())
+    return y, st[:C], st[C:]
+
+
+def bn1d_backward(dy, x, y, gamma, mean, rstd, relu: bool):
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    g = _f32(2 * C, x.device)
+    lib().call("pcrl_bn1d_bwd", dy.contiguous(), x, y, gamma.detach(), mean, rstd, dx, g[:C], g[C:], rows, C, int(relu), stream_handle())
+    return dx, g[:C], g[C:]
+
+
+def linear_forward(x, w, b):
+    rows, Cin = x.shape
+    Cout = w.shape[0]
+    y = _f32(rows * Cout, x.device).view(rows, Cout)
+    lib().call("pcrl_linear_fwd", x, w.detach(), b.detach(), y, rows, Cin, Cout, stream_handle())
+    return y
+
+
+def linear_backward(dy, x, w):
+    rows, Cin = x.shape
+    Cout = w.shape[0]
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w, dtype=torch.float32)
+    db = _f32(Cout, x.device)
+    lib().call("pcrl_linear_bwd", dy.contiguous(), x, w.detach(), dx, dw, db, rows, Cin, Cout, stream_handle())
+    return dx, dw, db
+
+
+# ----------------------------------------------------------------------------------------------
+# 1-channel map ops and losses
+# ----------------------------------------------------------------------------------------------
+def upsample_forward(x, scale: int):
+    N, _, D, H, W = x.shape
+    y = torch.empty((N, 1, D * scale, H * scale, W * scale), dtype=torch.float32, device=x.device)
+    lib().call("pcrl_upsample_trilinear_fwd", x.contiguous(), y, N, D, H, W, scale, stream_handle())
+    return y
+
+
+def upsample_backward(dy, in_shape, scale: int):
+    N, _, D, H, W = in_shape
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dy.device)
+    lib().call("pcrl_upsample_trilinear_bwd", dy.contiguous(), dx, N, D, H, W, scale, stream_handle())
+    return dx
+
+
+def conv1x1_to1_forward(x, w, b, dtype):
+    """OutputTransition: sigmoid(conv1x1x1(x)) -> (out [N,1,D,H,W] float32)."""
+    L, s = lib(), stream_handle()
+    N, D, H, W, C = dims(x)
+    M = N * D * H * W
+    pre = _f32(M, x.device)
+    L.call("pcrl_conv3d_to1_fwd", x, w.detach(), b.detach(), pre, None, N, D, H, W, C, 1, dtype_code(dtype), s)
+    out = torch.empty((N, 1, D, H, W), dtype=torch.float32, device=x.device)
+    L.call("pcrl_sigmoid_fwd", pre, out, M, s)
+    return out
+
+
+def conv1x1_to1_backward(x, out, dout, w, dtype, need_dx=True):
+    L, s, dev = lib(), stream_handle(), x.device
+    N, D, H, W, C = dims(x)
+    M = N * D * H * W
+    dpre = _f32(M, dev)
+    L.call("pcrl_sigmoid_bwd", dout.contiguous(), out, dpre, M, s)
+    dw = torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format)
+    db = _f32(1, dev)
+    nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, C, 1)
+    L.call("pcrl_conv3d_to1_wgrad", x, dpre, dw, db, workspace(nb, dev), nb, N, D, H, W, C, 1, dtype_code(dtype), s)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        L.call("pcrl_conv3d_to1_dgrad", dpre, w.detach(), None, dx, N, D, H, W, C, 1, dtype_code(dtype), s)
+    return dx, dw, db
+
+
+def mse_forward(p, gt):
+    L = lib()
+    n = p.numel()
+    loss = _f32(1, p.device)
+    nb = L.call("pcrl_reduce_ws_bytes", n)
+    L.call("pcrl_mse_fwd", p, gt, loss, workspace(nb, p.device), nb, n, stream_handle())
+    return loss.view(())
+
+
+def mse_backward(p, gt, dloss):
+    dp = torch.empty_like(p)
+    lib().call("pcrl_mse_bwd", p, gt, dloss.contiguous().view(1), dp, p.numel(), stream_handle())
+    return dp
+
+
+def cosine_mean_forward(x, y, eps=1e-8):
+    rows, C = x.shape
+    out = _f32(1, x.device)
+    saved = _f32(rows * 3, x.device)
+    lib().call("pcrl_cosine_mean_fwd", x, y, out, saved, rows, C, eps, stream_handle())
+    return out.view(()), saved
+
+
+def cosine_mean_backward(x, y, saved, dout, eps=1e-8):
+    rows, C = x.shape
+    dx = torch.empty_like(x)
+    lib().call("pcrl_cosine_mean_bwd", x, y, saved, dout.contiguous().view(1), dx, rows, C, eps, stream_handle())
+    return dx

@@ -1,0 +1,96 @@
+"""Fused SGD over a flat parameter arena -- torch.optim.SGD as configured at train_3d.py:48-51
+(momentum, weight decay on every parameter, dampening 0, no nesterov), one kernel launch per step.
+
+`FusedSGD` subclasses torch.optim.SGD so `param_groups` (what utils.adjust_learning_rate edits) and
+the checkpoint's `optimizer.state_dict()` layout ('momentum_buffer' per parameter) stay those of the
+reference.  Parameters are re-homed into one contiguous float32 arena (values preserved; the
+nn.Parameter objects stay the same), momentum buffers into a second arena, and gradients are
+gathered into a third (which is also the buffer the data-parallel all-reduce works on).
+Parameters whose .grad is None are skipped, like torch.optim.SGD does after zero_grad(set_to_none=True).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import lib, stream_handle
+
+
+class FusedSGD(torch.optim.SGD):
+    def __init__(self, params, lr=1e-3, momentum=0.0, weight_decay=0.0, **kw):
+        # the reference's argparse leaves --momentum / --weight_decay as strings when given on the CLI
+        super().__init__(params, lr=float(lr), momentum=float(momentum), weight_decay=float(weight_decay), **kw)
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedSGD supports a single param group (the reference uses one)")
+        g = self.param_groups[0]
+        if g["dampening"] != 0 or g["nesterov"] or g.get("maximize", False):
+            raise ValueError("FusedSGD implements dampening=0, nesterov=False, maximize=False")
+        self._plist = [p for p in g["params"]]
+        dev = self._plist[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FusedSGD needs parameters on the GPU (no CPU fallback)")
+        sizes = [p.numel() for p in self._plist]
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        self._offsets_host = offs
+        self._total = offs[-1]
+        self.flat_p = torch.empty(self._total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(self._total, dtype=torch.float32, device=dev)
+        self.flat_buf = torch.zeros(self._total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o, n in zip(self._plist, offs, sizes):
+                if p.dtype != torch.float32:
+                    raise ValueError("FusedSGD: parameters must be float32")
+                self.flat_p[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + n].view(p.shape)
+        self._offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._gviews = [self.flat_g[o:o + n].view(p.shape) for p, o, n in zip(self._plist, offs, sizes)]
+        self._initialised = [False] * len(self._plist)
+        self._flag_cache = {}
+        self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
+        self.pre_step = None           # optional callable(self, has_grad) -> None, run after the gradient gather
+        ops.bump_weights_epoch()
+
+    # ------------------------------------------------------------------
+    def gather_grads(self):
+        """Copy the per-parameter gradients into the flat arena; returns the has-grad list."""
+        has = [p.grad is not None for p in self._plist]
+        dst = [v for v, h in zip(self._gviews, has) if h]
+        src = [p.grad for p, h in zip(self._plist, has) if h]
+        if dst:
+            torch._foreach_copy_(dst, src)
+        return has
+
+    def _flags(self, has):
+        key = (tuple(has), tuple(self._initialised))
+        t = self._flag_cache.get(key)
+        if t is None:
+            vals = [(1 if h else 0) | (2 if i else 0) for h, i in zip(has, self._initialised)]
+            t = torch.tensor(vals, dtype=torch.int32, device=self.flat_p.device)
+            if len(self._flag_cache) > 64:
+                self._flag_cache.clear()
+            self._flag_cache[key] = t
+        return t
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        g = self.param_groups[0]
+        has = self.gather_grads()
+        if self.pre_step is not None:
+            has = self.pre_step(self, has) or has
+        flags = self._flags(has)
+        lib().call("pcrl_sgd_step", self.flat_p, self.flat_g, self.flat_buf, self._offsets, flags, len(self._plist),
+                   self._total, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(self.grad_scale),
+                   stream_handle())
+        for i, (p, h) in enumerate(zip(self._plist, has)):
+            if h and not self._initialised[i]:
+                self._initialised[i] = True
+                o, n = self._offsets_host[i], p.numel()
+                self.state[p]["momentum_buffer"] = self.flat_buf[o:o + n].view(p.shape)
+        ops.bump_weights_epoch()
+        return loss

@@ -1,0 +1,99 @@
+"""CPU: the oracle (oracle/pcrlv2_oracle.py) against the golden vectors generated from the REAL reference
+(oracle/make_golden.py).  This is what pins the oracle; the GPU tests then compare the HIP path with both."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import pcrlv2_oracle as O
+from make_golden import sample_idx
+
+
+def _load(golden_dir, tag):
+    return np.load(os.path.join(golden_dir, tag + ".npz"))
+
+
+def _samples(t, k, seed=3):
+    f = t.detach().double().reshape(-1).numpy()
+    return f[sample_idx(f.size, k, seed)]
+
+
+@pytest.fixture(scope="module")
+def small(golden_dir):
+    fx = _load(golden_dir, "c_small_b4_32x32x16")
+    b, dhw, nsteps = int(fx["meta/b"]), tuple(int(v) for v in fx["meta/dhw"]), int(fx["meta/nsteps"])
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    st0 = O.fill_state(torch.float64)
+    batches = [O.fill_batch(b, dhw, dtype=torch.float64, seed=7 + 100 * s) for s in range(nsteps)]
+    with torch.backends.mkldnn.flags(enabled=False):
+        st, mom, log, g0 = O.train_steps(st0, batches, int(fx["meta/epoch"]), float(fx["meta/base_lr"]), int(fx["meta/epochs"]), int(fx["meta/seed"]))
+        rng = random.Random(int(fx["meta/seed"]))
+        nb = {}
+        fwd = O.step_losses(st0, batches[0], int(fx["meta/epoch"]), rng, nb)
+    return fx, st, log, g0, fwd, nb
+
+
+def test_layout_matches_reference_manifest(golden_dir):
+    lines = [l.split(" ", 1) for l in open(os.path.join(golden_dir, "state_dict_manifest.txt")).read().strip().splitlines()]
+    lay = O.state_layout()
+    assert [k for k, _ in lines] == list(lay.keys())
+    for (k, rest), shape in zip(lines, lay.values()):
+        assert rest.startswith(str(tuple(shape))), (k, rest, shape)
+    n_params = sum(int(np.prod(s)) if s else 1 for k, s in lay.items() if not O.is_buffer(k))
+    assert n_params == 17111434
+
+
+def test_losses_match_reference(small):
+    fx, st, log, g0, fwd, nb = small
+    for s, l in enumerate(log):
+        for k in ("loss", "loss1", "loss2", "loss4", "local_loss"):
+            assert abs(l[k] - float(fx[f"step{s}/{k}"])) < 1e-10, (s, k)
+        assert l["index2"] == int(fx[f"step{s}/index2"])
+
+
+def test_forward_matches_reference(small):
+    fx, st, log, g0, fwd, nb = small
+    np.testing.assert_allclose(_samples(fwd["mask1"], 256), fx["fwd/out/samples"], rtol=0, atol=1e-10)
+    for i in range(3):
+        np.testing.assert_allclose(fwd["dec1"][i][0].detach().numpy(), fx[f"fwd/pro{i}"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(fwd["dec1"][i][1].detach().numpy(), fx[f"fwd/pre{i}"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(_samples(fwd["mid1"][i], 256), fx[f"fwd/mid{i}/samples"], rtol=0, atol=1e-10)
+
+
+def test_gradients_match_reference(small):
+    fx, st, log, g0, fwd, nb = small
+    n_none = 0
+    for name, g in g0.items():
+        if g is None:
+            assert f"grad/{name}/none" in fx.files
+            n_none += 1
+            continue
+        l2 = float(fx[f"grad/{name}/l2"])
+        np.testing.assert_allclose(_samples(g, 64), fx[f"grad/{name}/samples"], rtol=1e-8, atol=1e-9 * max(l2, 1e-3))
+    assert n_none == 8  # the two deep-supervision heads not selected by index2 (4 tensors each), SURVEY Q3
+
+
+def test_state_after_two_steps_matches_reference(small):
+    fx, st, log, g0, fwd, nb = small
+    for name, v in st.items():
+        if O.is_buffer(name):
+            continue
+        np.testing.assert_allclose(_samples(v, 64), fx[f"final/{name}/samples"], rtol=1e-9, atol=1e-11)
+    for name, v in nb.items():
+        np.testing.assert_allclose(v.double().numpy(), fx[f"buf1/{name}"], rtol=1e-9, atol=1e-11)
+
+
+def test_lr_schedule(golden_dir):
+    lrs = np.load(os.path.join(golden_dir, "lr_schedule.npz"))["lr"]
+    mine = np.array([O.lr_at(e, 1e-3, 240) for e in range(241)])
+    np.testing.assert_allclose(mine, lrs, rtol=0, atol=1e-18)
+    assert mine[-1] < 1e-18 and mine[0] == 1e-3
+
+
+def test_cosine_similarity_semantics():
+    x = torch.tensor([[3.0, 4.0], [0.0, 0.0]], dtype=torch.float64)
+    y = torch.tensor([[4.0, 3.0], [1.0, 0.0]], dtype=torch.float64)
+    ref = torch.nn.CosineSimilarity()(x, y)
+    np.testing.assert_allclose(O.cosine_similarity(x, y).numpy(), ref.numpy(), atol=1e-15)
