@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its named configuration.
+
+  metric   : 3D crops/sec of the full PCRLv2 pre-training step (2 global 64x64x32 views + 6 local 16^3 views per crop,
+             forward + backward + SGD), b = 32 crops per GPU, synthetic data resident in HBM, bf16 activations / MFMA
+             operands with fp32 accumulation (BASELINE config C2; C3 with --gpus N, weak scaling).
+  step     : one pass of train_3d.train_step over one batch.
+  roofline : the dominant kernel (bf16 implicit-GEMM 3x3x3 convolution, forward + data-gradient launches): algorithmic
+             FLOPs (2*M*27*Ci*Co per launch) / launch duration measured with HIP events on the launch stream, against
+             the dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).
+  cpu_baseline : the CPU oracle (a port of the reference step, oracle/pcrlv2_oracle.py) timed on this box's host cores on
+             a bounded sample (b=2), rank 0, N=1 only.
+
+Launch: python bench.py [--gpus 1 --steps K --warmup W]   or, for N>1,
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA ~2.5 PF dense"
+FLOP_PER_CROP = 1.2707e12   # fwd+bwd of one crop (2 global + 6 local views), SURVEY 8(d) [torch flop counter on the reference]
+
+
+def conv_key(name, args):
+    """Classify an igemm launch like the kernel template does and return its algorithmic FLOPs."""
+    # pcrl_conv3d_k3_fwd(x, wp, bias, y, stats, N, D, H, W, Ci, Co, dtype, stream)
+    N, D, H, W, Ci, Co, dt = args[5:12]
+    bn = 128 if Co % 128 == 0 else (64 if Co % 64 == 0 else 32)
+    key = "igemm_kernel<%s,%d,conv3>" % ("bf16" if dt == 1 else "f32", bn)
+    return key, 2.0 * N * D * H * W * 27 * Ci * Co
+
+
+def wgrad_key(name, args):
+    # pcrl_conv3d_k3_wgrad(x, dy, dw, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)
+    N, D, H, W, Ci, Co, dt = args[5:12]
+    return "wgrad_kernel<%s,conv3>" % ("bf16" if dt == 1 else "f32"), 2.0 * N * D * H * W * 27 * Ci * Co
+
+
+def keyfn(name, args):
+    return conv_key(name, args) if name == "pcrl_conv3d_k3_fwd" else wgrad_key(name, args)
+
+
+def synthetic_batch(b, dhw, local, device, seed):
+    """x1 ~ N(0,1), x2 = x1 + 0.1 N(0,1) (correlated views), gt ~ U(0,1), 6 local N(0,1) crops."""
+    g = torch.Generator().manual_seed(seed)
+    D, H, W = dhw
+    x1 = torch.randn(b, 1, D, H, W, generator=g)
+    x2 = x1 + 0.1 * torch.randn(b, 1, D, H, W, generator=g)
+    gt = torch.rand(b, 1, D, H, W, generator=g)
+    loc = [torch.randn(b, 1, local, local, local, generator=g) for _ in range(6)]
+    to = lambda t: t.to(device)
+    return to(x1), to(x2), to(gt), None, [to(t) for t in loc]
+
+
+def cpu_baseline(b=2, budget_s=25.0, threads=None):
+    """Time the oracle port of the reference step on the host cores (fp32, default oneDNN) on a BOUNDED sample:
+    one warm-up step at 32x32x16, then full-size (64x64x32) b=2 steps until ~budget_s of CPU work is spent (>= 1 step).
+    Threads: min(32, cores) -- with all 256 hardware threads of the GPU box a b=2 step is >10x SLOWER (oversubscribed
+    oneDNN / ATen threading on a tiny batch; measured 279 s/step), so that is not a fair baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pcrlv2_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(threads or min(32, cores))
+    st = O.fill_state(torch.float32)
+    O.train_steps(st, [O.fill_batch(b, (32, 32, 16), local=16, dtype=torch.float32, seed=3)])   # warm-up
+    steps, t0 = 0, time.time()
+    while True:
+        O.train_steps(st, [O.fill_batch(b, (64, 64, 32), local=16, dtype=torch.float32, seed=7 + steps)])
+        steps += 1
+        dt = time.time() - t0
+        if dt + dt / steps > budget_s or steps >= 4:
+            break
+    return {"value": round(b * steps / dt, 4), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle port of train_3d.py:109-151 (oracle/pcrlv2_oracle.py), fp32 oneDNN, b={b}, 64x64x32 + 6x16^3, "
+                      f"{steps} timed step(s) in {dt:.1f} s on {torch.get_num_threads()} of {cores} host threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--b", type=int, default=32, help="crops per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dhw", default="64,64,32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from pcrlv2_amd import _lib, ddp
+    from pcrlv2_amd.models import PCRLv23d
+    from pcrlv2_amd.optim import FusedSGD
+    from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank = 0, 0
+    if world > 1:
+        rank, world, local_rank = ddp.init_process_group_from_env("nccl")
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dhw = tuple(int(v) for v in args.dhw.split(","))
+
+    torch.manual_seed(0)
+    random.seed(0)          # same scale draws on every rank (see ddp.DataParallel)
+    model = PCRLv23d().to(dev).train()
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    dp = ddp.DataParallel(model, opt) if world > 1 else None  # noqa: F841
+    crit, cosine = MSELoss(), CosineSimilarityMean()
+    batch = synthetic_batch(args.b, dhw, 16, dev, 1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(model, opt, batch, 0, crit, cosine, guard=False)
+    L = _lib.lib()
+    prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_wgrad"}, keyfn)
+    barrier()
+    L.profiler = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = train_step(model, opt, batch, 0, crit, cosine, guard=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.profiler = None
+    loss = float(out[0])
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank != 0:
+        return
+    res = prof.results()
+    detail = {}
+    for k, (n, ms, work) in sorted(res.items()):
+        detail[k] = {"launches": n, "avg_ms": round(ms / n, 4), "tflops": round(work / (ms * 1e-3) / 1e12, 1)}
+    conv = {k: v for k, v in res.items() if k.startswith("igemm")}
+    dom = max(conv, key=lambda k: conv[k][1])
+    n, ms, work = conv[dom]
+    achieved = work / (ms * 1e-3) / 1e12
+    crops = world * args.b * args.steps / elapsed
+    line = {
+        "metric": "3D crops/sec (64x64x32, b=32) pretrain step", "value": round(crops, 2), "unit": "crops/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"C2: PCRLv23d pre-train step, {dhw[0]}x{dhw[1]}x{dhw[2]} global views x2 + 6 local 16^3, "
+                               f"b={args.b}/GPU, fwd+bwd+SGD", "global_batch": world * args.b, "parallelism": f"dp{world}"},
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
+                     "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
+                     "avg_launch_ms": round(ms / n, 4), "launches": n, "traffic": None},
+        "step_mfma_frac": round(FLOP_PER_CROP * args.b * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "kernels": detail, "final_loss": round(loss, 5),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,7 @@ class _Lib:
             f.restype = _RET[ret]
             f.argtypes = [_ctype_of(t) for t, _ in args]
             self.fn[name] = (f, ret, args)
+        self.profiler = None
         self.debug_set_wgrad_tr = self.cdll.pcrl_debug_set_wgrad_tr
         self.debug_set_wgrad_tr.argtypes = [ctypes.c_int]
         self.debug_set_wgrad_tr.restype = None
@@ -105,10 +106,42 @@ class _Lib:
                 conv.append(float(a))
             else:
                 conv.append(int(a))
-        r = f(*conv)
+        if self.profiler is not None and name in self.profiler.watch:
+            r = self.profiler.timed(name, args, f, conv)
+        else:
+            r = f(*conv)
         if ret == "int" and r != 0:
             raise PcrlError(f"{name} failed ({r}): {self.last_error()}")
         return r
+
+
+class EventProfiler:
+    """Times selected entry points with HIP events recorded on the launch stream (torch's current stream, which is
+    the stream every pcrl_* call is given).  `keyfn(name, args) -> (key, work)` classifies a launch and returns its
+    algorithmic work (flops or bytes); results: {key: [launches, total_ms, total_work]}."""
+
+    def __init__(self, watch, keyfn):
+        self.watch, self.keyfn = set(watch), keyfn
+        self.pending = []
+
+    def timed(self, name, args, f, conv):
+        key, work = self.keyfn(name, args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = f(*conv)
+        e1.record()
+        self.pending.append((key, work, e0, e1))
+        return r
+
+    def results(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, work, e0, e1 in self.pending:
+            rec = out.setdefault(key, [0, 0.0, 0.0])
+            rec[0] += 1
+            rec[1] += e0.elapsed_time(e1)
+            rec[2] += work
+        return out
 
 
 _lib = None

@@ -1,0 +1,363 @@
+"""GPU parity of every kernel family, called through the C ABI (pcrlv2_amd.ops -> libpcrl_hip.so), against a plain
+PyTorch float64 CPU computation of the same operator.
+
+Tolerances: float32 mode -- 2e-5 * max|ref| (accumulation-order noise of an exact-fp32 MFMA chain);
+bfloat16 mode -- operands are pre-rounded to bf16 on both sides, so what remains is fp32 accumulation order plus ONE
+bf16 rounding of the stored result: 1e-2 * max|ref| (bf16 has 8 mantissa bits: 2^-8 = 3.9e-3 relative).
+Reductions that stay in float32 on both sides (weight gradients, statistics) use the tight bound in both modes.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from pcrlv2_amd import ops  # noqa: E402
+from pcrlv2_amd._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_BM, dtype_code, lib, stream_handle  # noqa: E402
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def q(t, dt):
+    """round a float64 CPU tensor to the activation dtype and back (what the kernel sees)"""
+    return t.to(dt).double()
+
+
+def act_dev(t, dt):
+    """float64 NCDHW CPU tensor -> NDHWC device activation in dt"""
+    return ops.to_act(t.to(dt).to(DEV), dt)
+
+
+def back(t):
+    return t.detach().double().cpu().contiguous()
+
+
+def check(got, ref, dt, what, out_rounded=True, f32_tol=2e-5, bf_tol=1e-2):
+    got, ref = back(got) if torch.is_tensor(got) and got.is_cuda else got.double(), ref.double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(ref.abs().max().item(), 1e-6)
+    tol = (bf_tol if (dt == torch.bfloat16 and out_rounded) else f32_tol) * scale
+    err = (got - ref).abs().max().item()
+    assert err <= tol, f"{what} [{dt}]: max|d|={err:.3e} > tol {tol:.3e} (ref max {scale:.3e})"
+    return err
+
+
+SHAPES3 = [  # N, D, H, W, Ci, Co   (M deliberately not a multiple of 128 in the first rows)
+    (3, 6, 5, 7, 32, 64), (2, 4, 4, 4, 64, 32), (1, 8, 8, 4, 64, 128), (2, 2, 2, 2, 128, 256), (1, 16, 8, 8, 32, 64),
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", SHAPES3)
+def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
+    N, D, H, W, Ci, Co = shape
+    L, s = lib(), stream_handle()
+    x, w, b = rnd(N, Ci, D, H, W, seed=1), rnd(Co, Ci, 3, 3, 3, seed=2, scale=0.1), rnd(Co, seed=3)
+    xq, wq = q(x, dt), q(w, dt)
+    ref = F.conv3d(xq, wq, b, padding=1)
+    pk = ops.PackedWeights("conv3")
+    wdev = w.float().to(DEV)
+    wf, wd = pk.get(wdev, dt)
+    xa = act_dev(x, dt)
+    M = N * D * H * W
+    rows = (M + CONV_BM - 1) // CONV_BM
+    y = ops.new_act(N, D, H, W, Co, dt, DEV)
+    part = torch.zeros(rows * Co * 2, dtype=torch.float32, device=DEV)
+    L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y, part, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    check(y, ref, dt, "conv3 fwd")
+    st = back(part).view(rows, Co, 2).sum(0)
+    check(st[:, 0], ref.sum(dim=(0, 2, 3, 4)), dt, "conv3 stats sum", out_rounded=False, f32_tol=1e-4)
+    check(st[:, 1], (ref * ref).sum(dim=(0, 2, 3, 4)), dt, "conv3 stats sumsq", out_rounded=False, f32_tol=1e-4)
+    # data gradient == conv with flipped / transposed weights
+    dy = rnd(N, Co, D, H, W, seed=4)
+    dyq = q(dy, dt)
+    xr = xq.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    F.conv3d(xr, wr, None, padding=1).backward(dyq)
+    dya = act_dev(dy, dt)
+    dx = ops.new_act(N, D, H, W, Ci, dt, DEV)
+    L.call("pcrl_conv3d_k3_fwd", dya, wd, None, dx, None, N, D, H, W, Co, Ci, dtype_code(dt), s)
+    check(dx, xr.grad, dt, "conv3 dgrad")
+    # weight gradient (float32 out in both modes): both bf16 fragment-fetch paths
+    nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
+    for tr in ((1, 0) if dt == torch.bfloat16 else (1,)):
+        L.debug_set_wgrad_tr(tr)
+        dw = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float32, device=DEV)
+        L.call("pcrl_conv3d_k3_wgrad", xa, dya, dw, ops.workspace(nb, xa.device), nb, N, D, H, W, Ci, Co, dtype_code(dt), s)
+        check(dw, wr.grad, dt, f"conv3 wgrad tr={tr}", out_rounded=False, f32_tol=3e-5)
+    L.debug_set_wgrad_tr(1)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 3, 4, 5, 64, 64), (1, 4, 4, 2, 128, 128), (3, 2, 2, 2, 32, 32)])
+def test_convt_k2s2(shape, dt):
+    N, D, H, W, Ci, Co = shape
+    x, w, b = rnd(N, Ci, D, H, W, seed=1), rnd(Ci, Co, 2, 2, 2, seed=2, scale=0.2), rnd(Co, seed=3)
+    xq, wq = q(x, dt).requires_grad_(True), q(w, dt).requires_grad_(True)
+    bq = b.clone().requires_grad_(True)
+    ref = F.conv_transpose3d(xq, wq, bq, stride=2)
+    dy = rnd(N, Co, 2 * D, 2 * H, 2 * W, seed=5)
+    ref.backward(q(dy, dt))
+    pk = ops.PackedWeights("convt")
+    wdev, bdev = w.float().to(DEV), b.float().to(DEV)
+    xa = act_dev(x, dt)
+    y = ops.convt_forward(xa, wdev, bdev, pk, dt)
+    check(y, ref, dt, "convT fwd")
+    dx, dw, db = ops.convt_backward(xa, act_dev(dy, dt), wdev, pk, dt)
+    check(dx, xq.grad, dt, "convT dgrad")
+    check(dw, wq.grad, dt, "convT wgrad", out_rounded=False, f32_tol=3e-5)
+    check(db, bq.grad, dt, "convT bias grad", out_rounded=False, f32_tol=3e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_first_layer_c1(dt):
+    N, D, H, W, Co = 3, 6, 5, 7, 32
+    L, s = lib(), stream_handle()
+    x, w, b = rnd(N, 1, D, H, W, seed=1), rnd(Co, 1, 3, 3, 3, seed=2), rnd(Co, seed=3)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv3d(x, wr, b, padding=1)
+    M = N * D * H * W
+    rows = (M + CONV_BM - 1) // CONV_BM
+    y = ops.new_act(N, D, H, W, Co, dt, DEV)
+    part = torch.zeros(rows * Co * 2, dtype=torch.float32, device=DEV)
+    xd = x.float().to(DEV)
+    L.call("pcrl_conv3d_k3_c1_fwd", xd, w.float().to(DEV), b.float().to(DEV), y, part, N, D, H, W, Co, dtype_code(dt), s)
+    check(y, ref, dt, "c1 fwd")
+    st = back(part).view(rows, Co, 2).sum(0)
+    check(st[:, 0], ref.detach().sum(dim=(0, 2, 3, 4)), dt, "c1 stats", out_rounded=False, f32_tol=1e-4)
+    dy = rnd(N, Co, D, H, W, seed=4)
+    ref.backward(q(dy, dt))
+    nb = L.call("pcrl_conv3d_k3_c1_wgrad_ws_bytes", N, D, H, W, Co)
+    dw = torch.zeros(Co, 1, 3, 3, 3, dtype=torch.float32, device=DEV)
+    L.call("pcrl_conv3d_k3_c1_wgrad", xd, act_dev(dy, dt), dw, ops.workspace(nb, xd.device), nb, N, D, H, W, Co, dtype_code(dt), s)
+    check(dw, wr.grad, dt, "c1 wgrad", out_rounded=False, f32_tol=3e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("C,taps", [(64, 27), (128, 27), (256, 27), (64, 1)])
+def test_conv_to_one_channel(C, taps, dt):
+    N, D, H, W = 2, 5, 6, 4
+    L, s = lib(), stream_handle()
+    k = 3 if taps == 27 else 1
+    x, w, b = rnd(N, C, D, H, W, seed=1), rnd(1, C, k, k, k, seed=2, scale=0.2), rnd(1, seed=3)
+    xq = q(x, dt).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref = F.conv3d(xq, wr, br, padding=k // 2)
+    M = N * D * H * W
+    xa = act_dev(x, dt)
+    y = torch.zeros(M, dtype=torch.float32, device=DEV)
+    part = torch.zeros(((M + 1023) // 1024) * 2, dtype=torch.float32, device=DEV)
+    wdev, bdev = w.float().to(DEV), b.float().to(DEV)
+    L.call("pcrl_conv3d_to1_fwd", xa, wdev, bdev, y, part, N, D, H, W, C, taps, dtype_code(dt), s)
+    check(y.view(N, 1, D, H, W), ref, dt, "to1 fwd", out_rounded=False)
+    st = back(part).view(-1, 2).sum(0)
+    assert abs(st[0].item() - ref.sum().item()) <= 1e-4 * max(1.0, ref.abs().sum().item())
+    dy = rnd(N, 1, D, H, W, seed=4)
+    ref.backward(dy)
+    dyd = dy.float().to(DEV).contiguous()
+    add = rnd(N, C, D, H, W, seed=6)
+    adda = act_dev(add, dt)
+    dx = ops.new_act(N, D, H, W, C, dt, DEV)
+    L.call("pcrl_conv3d_to1_dgrad", dyd, wdev, adda, dx, N, D, H, W, C, taps, dtype_code(dt), s)
+    check(dx, xq.grad + q(add, dt), dt, "to1 dgrad (+add_src)")
+    L.call("pcrl_conv3d_to1_dgrad", dyd, wdev, None, dx, N, D, H, W, C, taps, dtype_code(dt), s)
+    check(dx, xq.grad, dt, "to1 dgrad")
+    nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, C, taps)
+    dw = torch.zeros_like(wdev)
+    db = torch.zeros(1, dtype=torch.float32, device=DEV)
+    L.call("pcrl_conv3d_to1_wgrad", xa, dyd, dw, db, ops.workspace(nb, xa.device), nb, N, D, H, W, C, taps, dtype_code(dt), s)
+    check(dw, wr.grad, dt, "to1 wgrad", out_rounded=False, f32_tol=3e-5)
+    check(db, br.grad, dt, "to1 bias grad", out_rounded=False, f32_tol=3e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("act", [ACT_RELU, ACT_NONE])
+@pytest.mark.parametrize("shape", [(3, 6, 5, 7, 32), (2, 4, 4, 4, 512)])
+def test_batchnorm_act(shape, act, dt):
+    """luconv-style BN: statistics from partials, apply, backward (vs torch batch_norm autograd)."""
+    N, D, H, W, C = shape
+    M = N * D * H * W
+    y = rnd(N, C, D, H, W, seed=1, scale=2.0) + rnd(1, C, 1, 1, 1, seed=9)
+    gamma, beta = 1 + 0.3 * rnd(C, seed=2), 0.3 * rnd(C, seed=3)
+    yq = q(y, dt).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    z = F.batch_norm(yq, rm, rv, gr, br, training=True, momentum=0.1, eps=1e-5)
+    a = torch.relu(z) if act == ACT_RELU else z
+    da = rnd(N, C, D, H, W, seed=4)
+    a.backward(q(da, dt))
+    # device: partial statistics as the conv epilogue would emit them (computed here from the rounded tensor)
+    ya = act_dev(y, dt)
+    flat = back(ya).permute(0, 2, 3, 4, 1).reshape(M, C)
+    rows = (M + CONV_BM - 1) // CONV_BM
+    pad = torch.zeros(rows * CONV_BM - M, C, dtype=torch.float64)
+    fp = torch.cat([flat, pad]).view(rows, CONV_BM, C)
+    part = torch.stack([fp.sum(1), (fp * fp).sum(1)], dim=-1).float().to(DEV).contiguous()
+    g32, b32 = gamma.float().to(DEV), beta.float().to(DEV)
+    rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    mean, rstd, scale, shift = ops.bn_finalize(part.view(-1), rows, C, M, g32, b32, rmd, rvd)
+    check(rmd, rm, dt, "running_mean", out_rounded=False, f32_tol=1e-5)
+    check(rvd, rv, dt, "running_var", out_rounded=False, f32_tol=1e-5)
+    out = ops.bn_act_apply(ya, scale, shift, M, C, act, dt)
+    check(out, a.detach(), dt, "bn apply")
+    dy, dg, dbeta = ops.bn_act_backward(act_dev(da, dt), ya, g32, mean, rstd, scale, shift, M, C, act, dt)
+    check(dy, yq.grad, dt, "bn bwd dx")
+    check(dg, gr.grad, dt, "bn dgamma", out_rounded=False, f32_tol=1e-4)
+    check(dbeta, br.grad, dt, "bn dbeta", out_rounded=False, f32_tol=1e-4)
+
+
+def test_batchnorm_one_channel_sigmoid():
+    N, D, H, W = 2, 8, 8, 4
+    M = N * D * H * W
+    y = rnd(N, 1, D, H, W, seed=1, scale=2.0) + 0.3
+    yr = y.clone().requires_grad_(True)
+    g, b = torch.tensor([1.2], dtype=torch.float64, requires_grad=True), torch.tensor([-0.1], dtype=torch.float64, requires_grad=True)
+    a = torch.sigmoid(F.batch_norm(yr, None, None, g, b, training=True, eps=1e-5))
+    da = rnd(N, 1, D, H, W, seed=2)
+    a.backward(da)
+    yd = y.float().to(DEV).view(-1)
+    part = torch.stack([yd.double().sum(), (yd.double() ** 2).sum()]).float().view(1, 2).contiguous()
+    mean, rstd, scale, shift = ops.bn_finalize(part.view(-1), 1, 1, M, g.detach().float().to(DEV), b.detach().float().to(DEV), None, None)
+    out = ops.bn_act_apply(yd, scale, shift, M, 1, ACT_SIGMOID, torch.float32)
+    check(out.view(N, 1, D, H, W), a.detach(), torch.float32, "bn1 sigmoid apply")
+    dy, dg, dbeta = ops.bn_act_backward(da.float().to(DEV).view(-1), yd, g.detach().float().to(DEV), mean, rstd, scale, shift, M, 1, ACT_SIGMOID, torch.float32)
+    check(dy.view(N, 1, D, H, W), yr.grad, torch.float32, "bn1 sigmoid bwd", f32_tol=1e-4)
+    check(dg, g.grad, torch.float32, "bn1 dgamma", f32_tol=1e-4)
+    check(dbeta, b.grad, torch.float32, "bn1 dbeta", f32_tol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_maxpool_with_ties(dt):
+    N, C, D, H, W = 2, 64, 4, 6, 4
+    x = torch.round(rnd(N, C, D, H, W, seed=1) * 2) / 2  # few distinct values -> many ties
+    xr = x.clone().requires_grad_(True)
+    ref = F.max_pool3d(xr, 2)
+    dy = rnd(N, C, D // 2, H // 2, W // 2, seed=2)
+    ref.backward(q(dy, dt))
+    xa = act_dev(x, dt)
+    y = ops.maxpool_forward(xa, dt)
+    check(y, ref.detach(), dt, "maxpool fwd", bf_tol=1e-6)
+    dx = ops.maxpool_backward(xa, act_dev(dy, dt), dt)
+    check(dx, xr.grad, dt, "maxpool bwd (first max takes the gradient)", bf_tol=1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gap_and_colsum(dt):
+    N, C, D, H, W = 3, 128, 12, 10, 9  # S = 1080 > one 1024-row tile
+    x = rnd(N, C, D, H, W, seed=1)
+    xa = act_dev(x, dt)
+    g = ops.gap_forward(xa, dt)
+    check(g, q(x, dt).mean(dim=(2, 3, 4)), dt, "gap fwd", out_rounded=False)
+    dg = rnd(N, C, seed=2)
+    add = rnd(N, C, D, H, W, seed=3)
+    da = ops.gap_backward(dg.float().to(DEV), xa, act_dev(add, dt), dt)
+    check(da, q(add, dt) + (dg / (D * H * W)).view(N, C, 1, 1, 1), dt, "gap bwd + add_src")
+    da = ops.gap_backward(dg.float().to(DEV), xa, None, dt)
+    check(da, (dg / (D * H * W)).view(N, C, 1, 1, 1).expand(N, C, D, H, W), dt, "gap bwd")
+    L = lib()
+    M = N * D * H * W
+    nb = L.call("pcrl_colsum_ws_bytes", M, C)
+    out = torch.zeros(C, dtype=torch.float32, device=DEV)
+    L.call("pcrl_colsum", xa, out, ops.workspace(nb, xa.device), nb, M, C, dtype_code(dt), stream_handle())
+    check(out, q(x, dt).sum(dim=(0, 2, 3, 4)), dt, "colsum", out_rounded=False)
+
+
+@pytest.mark.parametrize("rows,C", [(4, 64), (32, 256), (24, 128)])
+def test_heads_bn1d_linear(rows, C):
+    dt = torch.float32
+    x = rnd(rows, C, seed=1).requires_grad_(True)
+    g, b = (1 + 0.2 * rnd(C, seed=2)).requires_grad_(True), (0.2 * rnd(C, seed=3)).requires_grad_(True)
+    for relu in (False, True):
+        for t in (x, g, b):
+            t.grad = None
+        rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+        z = F.batch_norm(x, rm, rv, g, b, training=True, momentum=0.1, eps=1e-5)
+        y = torch.relu(z) if relu else z
+        dy = rnd(rows, C, seed=4)
+        y.backward(dy)
+        rmd, rvd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        xd = x.detach().float().to(DEV)
+        yd, mean, rstd = ops.bn1d_forward(xd, g.detach().float().to(DEV), b.detach().float().to(DEV), rmd, rvd, relu)
+        check(yd, y.detach(), dt, "bn1d fwd", f32_tol=1e-5)
+        check(rvd, rv, dt, "bn1d running_var", f32_tol=1e-5)
+        check(rmd, rm, dt, "bn1d running_mean", f32_tol=1e-5)
+        dx, dg, db = ops.bn1d_backward(dy.float().to(DEV), xd, yd, g.detach().float().to(DEV), mean, rstd, relu)
+        check(dx, x.grad, dt, "bn1d bwd", f32_tol=2e-4)
+        check(dg, g.grad, dt, "bn1d dgamma", f32_tol=1e-4)
+        check(db, b.grad, dt, "bn1d dbeta", f32_tol=1e-4)
+    w, bias = rnd(2 * C, C, seed=5, scale=0.1).requires_grad_(True), rnd(2 * C, seed=6).requires_grad_(True)
+    x.grad = None
+    yl = F.linear(x, w, bias)
+    dyl = rnd(rows, 2 * C, seed=7)
+    yl.backward(dyl)
+    xd, wd, bd = x.detach().float().to(DEV), w.detach().float().to(DEV), bias.detach().float().to(DEV)
+    check(ops.linear_forward(xd, wd, bd), yl.detach(), dt, "linear fwd")
+    dx, dw, db = ops.linear_backward(dyl.float().to(DEV), xd, wd)
+    check(dx, x.grad, dt, "linear dx")
+    check(dw, w.grad, dt, "linear dw")
+    check(db, bias.grad, dt, "linear db")
+    with pytest.raises(RuntimeError, match="more than 1 value per channel"):
+        ops.bn1d_forward(xd[:1].contiguous(), wd[0].contiguous(), wd[1].contiguous(), None, None, False)
+
+
+@pytest.mark.parametrize("scale", [2, 4])
+def test_trilinear(scale):
+    N, D, H, W = 2, 4, 6, 3
+    x = rnd(N, 1, D, H, W, seed=1).requires_grad_(True)
+    ref = F.interpolate(x, scale_factor=scale, mode="trilinear")
+    dy = rnd(*ref.shape, seed=2)
+    ref.backward(dy)
+    y = ops.upsample_forward(x.detach().float().to(DEV), scale)
+    check(y, ref.detach(), torch.float32, "trilinear fwd")
+    dx = ops.upsample_backward(dy.float().to(DEV), tuple(x.shape), scale)
+    check(dx, x.grad, torch.float32, "trilinear bwd")
+    probe = ops.upsample_forward(torch.arange(4, dtype=torch.float32, device=DEV).view(1, 1, 1, 1, 4), 2)
+    np.testing.assert_allclose(back(probe)[0, 0, 0, 0].numpy(), [0, .25, .75, 1.25, 1.75, 2.25, 2.75, 3], atol=1e-6)
+
+
+def test_losses_and_sigmoid():
+    p, gt = torch.sigmoid(rnd(2, 1, 8, 8, 9, seed=1)).requires_grad_(True), rnd(2, 1, 8, 8, 9, seed=2).abs()
+    ref = F.mse_loss(p, gt)
+    ref.backward(torch.tensor(0.7, dtype=torch.float64))
+    pd, gd = p.detach().float().to(DEV), gt.float().to(DEV)
+    check(ops.mse_forward(pd, gd).view(1), ref.detach().view(1), torch.float32, "mse fwd")
+    check(ops.mse_backward(pd, gd, torch.tensor(0.7, device=DEV)), p.grad, torch.float32, "mse bwd")
+    for rows, C in ((4, 64), (32, 256)):
+        x, y = rnd(rows, C, seed=3).requires_grad_(True), rnd(rows, C, seed=4)
+        c = torch.nn.CosineSimilarity()(x, y).mean()
+        c.backward(torch.tensor(-0.5, dtype=torch.float64))
+        xd, yd = x.detach().float().to(DEV), y.float().to(DEV)
+        out, saved = ops.cosine_mean_forward(xd, yd)
+        check(out.view(1), c.detach().view(1), torch.float32, "cosine fwd")
+        check(ops.cosine_mean_backward(xd, yd, saved, torch.tensor(-0.5, device=DEV)), x.grad, torch.float32, "cosine bwd")
+
+
+def test_fused_sgd_matches_torch_sgd():
+    from pcrlv2_amd.optim import FusedSGD
+    torch.manual_seed(0)
+    shapes = [(32, 1, 3, 3, 3), (32,), (7,), (64, 32, 3, 3, 3), (5, 3)]
+    ref_p = [torch.randn(s, dtype=torch.float64, requires_grad=True) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().float().to(DEV)) for p in ref_p]
+    ref = torch.optim.SGD(ref_p, lr=0.05, momentum=0.9, weight_decay=1e-2)
+    mine = FusedSGD(my_p, lr=0.05, momentum="0.9", weight_decay="1e-2")   # strings, like the reference CLI can pass
+    for step in range(4):
+        for i, (a, b) in enumerate(zip(ref_p, my_p)):
+            if i == 2 and step in (0, 2):   # parameter without a gradient in some steps (deep-supervision heads)
+                a.grad, b.grad = None, None
+                continue
+            g = torch.randn(a.shape, dtype=torch.float64)
+            a.grad, b.grad = g, g.float().to(DEV)
+        ref.step()
+        mine.step()
+    for a, b in zip(ref_p, my_p):
+        check(b.detach(), a.detach(), torch.float32, "sgd param")
+    sd = mine.state_dict()
+    assert set(sd["state"][0].keys()) == {"momentum_buffer"} and sd["param_groups"][0]["momentum"] == 0.9
