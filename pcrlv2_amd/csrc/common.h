@@ -12,6 +12,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte staging register
+
+// By-VALUE zero-select of a staged 16-byte vector.  (`cond ? arr[i] : zero` on lvalues is a select between ADDRESSES and
+// forces the staging array into scratch memory.)
+__device__ __forceinline__ u32x4 keep_if(bool ok, u32x4 v) {
+  const unsigned m = ok ? 0xFFFFFFFFu : 0u;
+  return u32x4{v.x & m, v.y & m, v.z & m, v.w & m};
+}
 
 // ---- error reporting (thread-local, never throws across the ABI) ----------------------
 int pcrl_fail(int code, const char* fmt, ...);

@@ -138,27 +138,36 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 ru[NP], rv[NP];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  u32x4 ru[NP], rv[NP];
 
+  // Unconditional loads from clamped (always valid) addresses; validity is applied at the LDS store (a load under a
+  // per-lane condition is wrapped by hipcc in a branch + `s_waitcnt vmcnt(0)`, serialising the K-step).
+  const int ucol_u = u_ok ? ucol : 0, ucol_v = v_ok ? ucol : 0;
+  uint32_t uokb = 0, vokb = 0;
 #define WG_LOAD(ms_)                                                                            \
   do {                                                                                          \
+    uokb = 0;                                                                                   \
+    vokb = 0;                                                                                   \
     _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                         \
-      const int64_t m = (ms_) + ps * RPP + rowp;                                                \
-      ru[ps] = zero4;                                                                           \
-      rv[ps] = zero4;                                                                           \
-      if (m < mend) {                                                                           \
-        if (u_ok) ru[ps] = *reinterpret_cast<const uint4*>(U + m * p.Cu + i0 + ucol);           \
-        int n, d, h, w;                                                                         \
-        decode_voxel(m, g, n, d, h, w);                                                         \
-        if (GEOM == WG_CONV3) {                                                                 \
-          const bool ok = (unsigned)(d + kd - 1) < (unsigned)g.D && (unsigned)(h + kh - 1) < (unsigned)g.H && \
-                          (unsigned)(w + kw - 1) < (unsigned)g.W;                               \
-          if (ok && v_ok) rv[ps] = *reinterpret_cast<const uint4*>(V + (m + delta) * p.Cv + j0 + ucol); \
-        } else {                                                                                \
-          if (v_ok) rv[ps] = *reinterpret_cast<const uint4*>(V + up2_row(n, d, h, w, t, g) * p.Cv + j0 + ucol); \
-        }                                                                                       \
+      const int64_t m_ = (ms_) + ps * RPP + rowp;                                               \
+      const bool live = m_ < mend;                                                              \
+      const int64_t m = live ? m_ : mbeg;                                                       \
+      ru[ps] = *reinterpret_cast<const u32x4*>(U + m * p.Cu + i0 + ucol_u);                     \
+      int n, d, h, w;                                                                           \
+      decode_voxel(m, g, n, d, h, w);                                                           \
+      bool ok = live;                                                                           \
+      int64_t vrow;                                                                             \
+      if (GEOM == WG_CONV3) {                                                                   \
+        const bool in = (unsigned)(d + kd - 1) < (unsigned)g.D && (unsigned)(h + kh - 1) < (unsigned)g.H && \
+                        (unsigned)(w + kw - 1) < (unsigned)g.W;                                 \
+        ok = ok && in;                                                                          \
+        vrow = in ? m + delta : m;                                                              \
+      } else {                                                                                  \
+        vrow = up2_row(n, d, h, w, t, g);                                                       \
       }                                                                                         \
+      rv[ps] = *reinterpret_cast<const u32x4*>(V + vrow * p.Cv + j0 + ucol_v);                  \
+      uokb |= (uint32_t)(live && u_ok) << ps;                                                   \
+      vokb |= (uint32_t)(ok && v_ok) << ps;                                                     \
     }                                                                                           \
   } while (0)
 
@@ -166,8 +175,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   do {                                                                                          \
     _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                         \
       const int row = ps * RPP + rowp;                                                          \
-      *reinterpret_cast<uint4*>(Us + (buf_)*TILE_BYTES + WT::off(row, ucol)) = ru[ps];          \
-      *reinterpret_cast<uint4*>(Vs + (buf_)*TILE_BYTES + WT::off(row, ucol)) = rv[ps];          \
+      *reinterpret_cast<u32x4*>(Us + (buf_)*TILE_BYTES + WT::off(row, ucol)) = keep_if((uokb >> ps) & 1u, ru[ps]);  \
+      *reinterpret_cast<u32x4*>(Vs + (buf_)*TILE_BYTES + WT::off(row, ucol)) = keep_if((vokb >> ps) & 1u, rv[ps]);  \
     }                                                                                           \
   } while (0)
 
@@ -177,10 +186,12 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     WG_STORE(0);
   }
   __syncthreads();
+  // straight-line body: the last iteration stages a duplicate of its own step into the idle buffer (see conv_igemm.hip)
   for (int64_t s = 0; s < nsteps; ++s) {
     const int cur = (int)(s & 1);
-    const bool more = (s + 1 < nsteps);
-    if (more) WG_LOAD(mbeg + (s + 1) * 32);
+    const int64_t sn = (s + 1 < nsteps) ? s + 1 : s;
+    WG_LOAD(mbeg + sn * 32);
+    __builtin_amdgcn_sched_barrier(0);
     {
       const char* ut = Us + cur * TILE_BYTES;
       const char* vt = Vs + cur * TILE_BYTES;
@@ -194,7 +205,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) WF::mma(fa[a], fb[b], acc[a][b]);
     }
-    if (more) WG_STORE(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    WG_STORE(cur ^ 1);
     __syncthreads();
   }
 #undef WG_LOAD
