@@ -1,10 +1,11 @@
 // HBM/L2-bound convolutions with ONE input or ONE output channel (no MFMA: K or N of the GEMM is 1).
 //
-//   c1_fwd / c1_wgrad : first layer, Conv3d(1 -> Co, 3x3x3)   models/pcrlv2_model_3d.py:101 (down_tr64.ops.0)
-//   to1_fwd / to1_dgrad / to1_wgrad : Conv3d(C -> 1), 27 taps (deep_supervision_head.conv1, :60,71) or
+//   c1_fwd            : first layer, Conv3d(1 -> Co, 3x3x3)   models/pcrlv2_model_3d.py:101 (down_tr64.ops.0)
+//   to1_fwd / to1_dgrad : Conv3d(C -> 1), 27 taps (deep_supervision_head.conv1, :60,71) or
 //                                     1 tap (OutputTransition.final_conv, :78)
 // Scalar fields (x of the first layer, y/dy of the heads) are float32 [M]; C-channel tensors are NDHWC
-// in the activation dtype, accessed as 16-byte channel vectors.
+// in the activation dtype, accessed as 16-byte channel vectors.  The weight gradients of these layers are MFMA GEMMs
+// (conv_wgrad.hip, via an im2col of the scalar operand).
 #include "common.h"
 
 namespace {
@@ -74,51 +75,6 @@ __global__ void c1_fwd_kernel(const float* __restrict__ x, const float* __restri
       stats[((int64_t)blockIdx.x * Co + tid) * 2 + 1] = s2;
     }
   }
-}
-
-// First layer weight gradient: dw[c][t] = sum_m dy[m][c] * x[m+delta_t].  Thread = (channel, tap group of 8);
-// block = 2048 voxels; partials ws[block][Co*27] reduced in fixed order.
-constexpr int C1W_VOX = 2048;
-template <typename T>
-__global__ void __launch_bounds__(256) c1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
-                                                       float* __restrict__ ws, Dims g, int64_t M, int Co) {
-  const int tid = threadIdx.x;
-  const int c = tid % Co, tg = tid / Co;
-  const int ngroups = 256 / Co;  // Co in {16,32,64} -> 16, 8, 4 tap groups
-  float acc[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  const int64_t mbeg = (int64_t)blockIdx.x * C1W_VOX;
-  const int64_t mend = (mbeg + C1W_VOX < M) ? mbeg + C1W_VOX : M;
-  for (int64_t m = mbeg; m < mend; ++m) {
-    int n, d, h, w;
-    decode_voxel(m, g, n, d, h, w);
-    const float dv = to_f(dy[m * Co + c]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int t = tg + j * ngroups;
-      if (t < 27) {
-        const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
-        if (tap_ok(d, h, w, kd, kh, kw, g)) acc[j] += dv * x[m + ((int64_t)kd * g.H + kh) * g.W + kw];
-      }
-    }
-  }
-  float* o = ws + (int64_t)blockIdx.x * Co * 27;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int t = tg + j * ngroups;
-    if (t < 27) o[c * 27 + t] = acc[j];
-  }
-}
-
-// out[i] = sum_r ws[r*stride + i], i < n: fixed-order fp64 accumulation.
-__global__ void __launch_bounds__(256) rows_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int rows, int n,
-                                                          int64_t stride) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)ws[(int64_t)r * stride + i];
-  out[i] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -236,68 +192,6 @@ __global__ void __launch_bounds__(256) to1_dgrad_kernel(const float* __restrict_
   }
 }
 
-// C -> 1 weight gradient: dw[c][t] = sum_m dy[m] * x[m+delta_t][c];  db = sum_m dy[m].
-// Thread = (channel vector, tap group); block = 1024 voxels; partials ws[block][taps*C + 1].
-template <typename T>
-__global__ void __launch_bounds__(256) to1_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy,
-                                                        float* __restrict__ ws, Dims g, int64_t M, int C, int taps) {
-  constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int TPT = 8;  // max taps per thread
-  __shared__ float red[4];
-  const int tid = threadIdx.x;
-  const int nvec = C / VEC;         // <= 64 vectors handled per pass of the block
-  const int cvs = nvec < 256 ? nvec : 256;
-  const int ngroups = 256 / cvs;    // tap groups
-  const int cv0 = tid % cvs, tg = tid / cvs;
-  const int64_t mbeg = (int64_t)blockIdx.x * TO1_VOX;
-  const int64_t mend = (mbeg + TO1_VOX < M) ? mbeg + TO1_VOX : M;
-  float* o = ws + (int64_t)blockIdx.x * ((int64_t)taps * C + 1);
-  for (int cv = cv0; cv < nvec; cv += cvs) {
-    float acc[TPT][VEC];
-#pragma unroll
-    for (int a = 0; a < TPT; ++a)
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[a][j] = 0.f;
-    if (tg < ngroups) {
-      for (int64_t m = mbeg; m < mend; ++m) {
-        const float dv = dy[m];
-        int n, d, h, w;
-        decode_voxel(m, g, n, d, h, w);
-#pragma unroll
-        for (int a = 0; a < TPT; ++a) {
-          const int t = tg + a * ngroups;
-          if (t < taps) {
-            int64_t src = m;
-            bool ok = true;
-            if (taps == 27) {
-              const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
-              ok = tap_ok(d, h, w, kd, kh, kw, g);
-              src = m + ((int64_t)kd * g.H + kh) * g.W + kw;
-            }
-            if (ok) {
-              const Vec16<T> xv = ld16(x + src * C + cv * VEC);
-#pragma unroll
-              for (int j = 0; j < VEC; ++j) acc[a][j] += dv * to_f(xv.v[j]);
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < TPT; ++a) {
-        const int t = tg + a * ngroups;
-        if (t < taps) {
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) o[(int64_t)(cv * VEC + j) * taps + t] = acc[a][j];
-        }
-      }
-    }
-  }
-  float s = 0.f;
-  for (int64_t m = mbeg + tid; m < mend; m += 256) s += dy[m];
-  s = block_sum_256(s, red);
-  if (tid == 0) o[(int64_t)taps * C] = s;
-}
-
 int pow2_floor(int v) {
   int p = 1;
   while (p * 2 <= v) p *= 2;
@@ -321,32 +215,6 @@ extern "C" int pcrl_conv3d_k3_c1_fwd(const float* x, const float* w_ref, const f
   else
     return pcrl_fail(PCRL_EINVAL, "conv3d_k3_c1_fwd: bad dtype %d", dtype);
   return pcrl_check_launch("c1_fwd");
-}
-
-extern "C" size_t pcrl_conv3d_k3_c1_wgrad_ws_bytes(int N, int D, int H, int W, int Co) {
-  const int64_t M = (int64_t)N * D * H * W;
-  return (size_t)((M + C1W_VOX - 1) / C1W_VOX) * Co * 27 * sizeof(float);
-}
-
-extern "C" int pcrl_conv3d_k3_c1_wgrad(const float* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes,
-                                       int N, int D, int H, int W, int Co, int dtype, pcrl_stream_t stream) {
-  PCRL_REQUIRE(x && dy && dw_ref, "conv3d_k3_c1_wgrad: null pointer");
-  PCRL_REQUIRE(Co == 16 || Co == 32 || Co == 64, "conv3d_k3_c1_wgrad: Co must be 16, 32 or 64 (got %d)", Co);
-  const size_t need = pcrl_conv3d_k3_c1_wgrad_ws_bytes(N, D, H, W, Co);
-  if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_k3_c1_wgrad: workspace %zu < %zu", ws_bytes, need);
-  const Dims g{N, D, H, W};
-  const int64_t M = (int64_t)N * D * H * W;
-  const unsigned blocks = (unsigned)((M + C1W_VOX - 1) / C1W_VOX);
-  if (dtype == PCRL_BF16)
-    hipLaunchKernelGGL(c1_wgrad_kernel<bf16>, dim3(blocks), dim3(256), 0, as_stream(stream), x, (const bf16*)dy, (float*)ws, g, M, Co);
-  else if (dtype == PCRL_F32)
-    hipLaunchKernelGGL(c1_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), x, (const float*)dy, (float*)ws, g, M, Co);
-  else
-    return pcrl_fail(PCRL_EINVAL, "conv3d_k3_c1_wgrad: bad dtype %d", dtype);
-  if (int e = pcrl_check_launch("c1_wgrad")) return e;
-  const int n = Co * 27;
-  hipLaunchKernelGGL(rows_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), (const float*)ws, dw_ref, (int)blocks, n, (int64_t)n);
-  return pcrl_check_launch("c1_wgrad_reduce");
 }
 
 static int to1_check(const char* what, int C, int taps, int dtype) {
@@ -393,34 +261,3 @@ extern "C" int pcrl_conv3d_to1_dgrad(const float* dy, const float* w_ref, const 
   return pcrl_check_launch("to1_dgrad");
 }
 
-extern "C" size_t pcrl_conv3d_to1_wgrad_ws_bytes(int N, int D, int H, int W, int C, int taps) {
-  const int64_t M = (int64_t)N * D * H * W;
-  return (size_t)((M + TO1_VOX - 1) / TO1_VOX) * ((size_t)taps * C + 1) * sizeof(float);
-}
-
-extern "C" int pcrl_conv3d_to1_wgrad(const void* x, const float* dy, float* dw_ref, float* db, void* ws, size_t ws_bytes,
-                                     int N, int D, int H, int W, int C, int taps, int dtype, pcrl_stream_t stream) {
-  if (int e = to1_check("conv3d_to1_wgrad", C, taps, dtype)) return e;
-  PCRL_REQUIRE(x && dy && dw_ref && db, "conv3d_to1_wgrad: null pointer");
-  const size_t need = pcrl_conv3d_to1_wgrad_ws_bytes(N, D, H, W, C, taps);
-  if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_to1_wgrad: workspace %zu < %zu", ws_bytes, need);
-  const Dims g{N, D, H, W};
-  const int64_t M = (int64_t)N * D * H * W;
-  const unsigned blocks = (unsigned)((M + TO1_VOX - 1) / TO1_VOX);
-  const int vec = dtype == PCRL_BF16 ? 8 : 4;
-  const int nvec = C / vec;
-  const int cvs = nvec < 256 ? nvec : 256;
-  if (256 % cvs != 0 || (taps + (256 / cvs) - 1) / (256 / cvs) > 8)
-    return pcrl_fail(PCRL_EINVAL, "conv3d_to1_wgrad: unsupported C=%d (vectors per voxel %d)", C, nvec);
-  if (dtype == PCRL_BF16)
-    hipLaunchKernelGGL(to1_wgrad_kernel<bf16>, dim3(blocks), dim3(256), 0, as_stream(stream), (const bf16*)x, dy, (float*)ws, g, M, C, taps);
-  else
-    hipLaunchKernelGGL(to1_wgrad_kernel<float>, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)x, dy, (float*)ws, g, M, C, taps);
-  if (int e = pcrl_check_launch("to1_wgrad")) return e;
-  // partial row = [taps*C] weight sums followed by 1 bias sum
-  const int n = taps * C;
-  hipLaunchKernelGGL(rows_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), (const float*)ws, dw_ref, (int)blocks, n, (int64_t)n + 1);
-  if (int e = pcrl_check_launch("to1_wgrad_reduce")) return e;
-  hipLaunchKernelGGL(rows_reduce_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const float*)ws + n, db, (int)blocks, 1, (int64_t)n + 1);
-  return pcrl_check_launch("to1_wgrad_reduce_b");
-}

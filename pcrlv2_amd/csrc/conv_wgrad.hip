@@ -19,7 +19,7 @@
 
 namespace {
 
-enum { WG_CONV3 = 0, WG_UP2 = 1 };
+enum { WG_CONV3 = 0, WG_UP2 = 1, WG_PLAIN = 2 };  // PLAIN: V is indexed by m directly (taps == 1)
 
 struct WgradParams {
   const void* u;  // [M][Cu]
@@ -162,8 +162,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
                         (unsigned)(w + kw - 1) < (unsigned)g.W;                                 \
         ok = ok && in;                                                                          \
         vrow = in ? m + delta : m;                                                              \
-      } else {                                                                                  \
+      } else if (GEOM == WG_UP2) {                                                              \
         vrow = up2_row(n, d, h, w, t, g);                                                       \
+      } else {                                                                                  \
+        vrow = m;                                                                               \
       }                                                                                         \
       rv[ps] = *reinterpret_cast<const u32x4*>(V + vrow * p.Cv + j0 + ucol_v);                  \
       uokb |= (uint32_t)(live && u_ok) << ps;                                                   \
@@ -225,19 +227,69 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       }
 }
 
-// Second pass: out_ref[i][j][t] = sum_z ws[z][t][i][j], fixed order.
+// Second pass: out_ref[i][j][t] = sum_z ws[z][t][i][j] for j < Cv_out (padding columns dropped), fixed order.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                           int splits, int taps, int Cu, int Cv) {
+                                                           int splits, int taps, int Cu, int Cv, int Cv_out) {
   const int64_t per = (int64_t)Cu * Cv;
   const int64_t total = per * taps;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     // idx enumerates [t][i][j] (coalesced reads); write transposed
     const int t = (int)(idx / per);
     const int64_t ij = idx % per;
-    float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[((int64_t)z * taps + t) * per + ij];
-    out[ij * taps + t] = s;
+    const int i = (int)(ij / Cv), j = (int)(ij % Cv);
+    if (j >= Cv_out) continue;
+    double s = 0.0;
+    for (int z = 0; z < splits; ++z) s += (double)ws[((int64_t)z * taps + t) * per + ij];
+    out[((int64_t)i * Cv_out + j) * taps + t] = (float)s;
   }
+}
+
+// im2col of a float32 scalar field for the 1-channel convolutions: out[m][t] = s[m + delta_t] (0 outside the volume),
+// t < 27 (flip: delta of tap 26-t), columns 27..31 zero.  taps == 1: out[m][0] = s[m].
+template <typename T>
+__global__ void __launch_bounds__(256) im2col27_kernel(const float* __restrict__ s, T* __restrict__ out, Dims g, int64_t M, int taps,
+                                                       int flip) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int NV = 32 / VEC;
+  const int64_t total = M * NV;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t m = idx / NV;
+    const int v0 = (int)(idx % NV) * VEC;
+    int n, d, h, w;
+    decode_voxel(m, g, n, d, h, w);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int col = v0 + j;
+      float val = 0.f;
+      if (taps == 1) {
+        if (col == 0) val = s[m];
+      } else if (col < 27) {
+        const int t = flip ? 26 - col : col;
+        const int kd = t / 9 - 1, kh = (t / 3) % 3 - 1, kw = t % 3 - 1;
+        if ((unsigned)(d + kd) < (unsigned)g.D && (unsigned)(h + kh) < (unsigned)g.H && (unsigned)(w + kw) < (unsigned)g.W)
+          val = s[m + ((int64_t)kd * g.H + kh) * g.W + kw];
+      }
+      o.v[j] = from_f<T>(val);
+    }
+    st16(out + m * 32 + v0, o);
+  }
+}
+
+// deterministic two-stage sum of a float32 vector (bias gradient of the 1-output-channel convolutions)
+__global__ void __launch_bounds__(256) vecsum_partial_kernel(const float* __restrict__ v, double* __restrict__ ws, int64_t n) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += (double)v[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) vecsum_finish_kernel(const double* __restrict__ ws, float* __restrict__ out, int blocks) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < blocks; i += 256) s += ws[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) out[0] = (float)s;
 }
 
 struct SplitPlan {
@@ -261,7 +313,8 @@ int g_wgrad_tr = 1;  // bf16 fragment fetch: 1 = ds_read_b64_tr_b16, 0 = scalar 
 
 template <int GEOM>
 int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_bytes, Dims g, int Cu, int Cv, int taps,
-              int dtype, hipStream_t stream) {
+              int dtype, hipStream_t stream, int Cv_out = -1) {
+  if (Cv_out < 0) Cv_out = Cv;
   const int64_t M = (int64_t)g.N * g.D * g.H * g.W;
   const SplitPlan sp = plan_splits(M, Cu, Cv, taps);
   const size_t need = (size_t)sp.splits * taps * Cu * Cv * sizeof(float);
@@ -280,7 +333,7 @@ int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_b
   const int64_t total = (int64_t)Cu * Cv * taps;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, dw_ref, sp.splits, taps, Cu, Cv);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, dw_ref, sp.splits, taps, Cu, Cv, Cv_out);
   return pcrl_check_launch("wgrad_reduce");
 }
 
@@ -311,4 +364,72 @@ extern "C" int pcrl_convt3d_k2s2_wgrad(const void* x, const void* dy, float* dw_
   PCRL_REQUIRE(x && dy && dw_ref, "convt3d_k2s2_wgrad: null pointer");
   PCRL_REQUIRE(Ci > 0 && Co > 0 && Ci % 32 == 0 && Co % 32 == 0, "convt3d_k2s2_wgrad: channels must be multiples of 32 (Ci=%d Co=%d)", Ci, Co);
   return run_wgrad<WG_UP2>(x, dy, dw_ref, ws, ws_bytes, Dims{N, D, H, W}, Ci, Co, 8, dtype, as_stream(stream));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradients of the 1-channel convolutions as plain MFMA GEMMs over voxels, via an im2col of the SCALAR operand
+// (32 columns: 27 taps + padding), which costs one extra HBM pass over a 32-channel tensor:
+//   first layer  (1 -> Co): dw[c][t] = sum_m dy[m][c] * x[m+delta_t]      = (dy^T . im2col(x))[c][t]
+//   heads        (C -> 1) : dw[c][t] = sum_m x[m][c]  * dy[m-delta_t]     = (x^T  . im2col_flipped(dy))[c][t];  db = sum dy
+// Workspace layout: [ im2col: M*32 elements of dtype ][ 8 KiB of fp64 partials ][ split-K partials ].
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+size_t plain_ws_bytes(int64_t M, int Cu, int dtype_size) {
+  const SplitPlan sp = plan_splits(M, Cu, 32, 1);
+  return (size_t)M * 32 * dtype_size + 8192 + (size_t)sp.splits * Cu * 32 * sizeof(float);
+}
+int im2col_launch(const float* s, void* out, Dims g, int64_t M, int taps, int flip, int dtype, hipStream_t stream) {
+  int64_t blocks = (M * (dtype == PCRL_BF16 ? 4 : 8) + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(im2col27_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, s, (bf16*)out, g, M, taps, flip);
+  else hipLaunchKernelGGL(im2col27_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, s, (float*)out, g, M, taps, flip);
+  return pcrl_check_launch("im2col27");
+}
+}  // namespace
+
+extern "C" size_t pcrl_conv3d_k3_c1_wgrad_ws_bytes(int N, int D, int H, int W, int Co) {
+  return plain_ws_bytes((int64_t)N * D * H * W, Co, 4);
+}
+
+extern "C" int pcrl_conv3d_k3_c1_wgrad(const float* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes,
+                                       int N, int D, int H, int W, int Co, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && dy && dw_ref, "conv3d_k3_c1_wgrad: null pointer");
+  PCRL_REQUIRE(dtype == PCRL_BF16 || dtype == PCRL_F32, "conv3d_k3_c1_wgrad: bad dtype %d", dtype);
+  PCRL_REQUIRE(Co > 0 && Co % 8 == 0, "conv3d_k3_c1_wgrad: Co must be a multiple of 8 (got %d)", Co);
+  const int64_t M = (int64_t)N * D * H * W;
+  const int esz = dtype == PCRL_BF16 ? 2 : 4;
+  if (!ws || ws_bytes < plain_ws_bytes(M, Co, esz)) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_k3_c1_wgrad: workspace too small");
+  const Dims g{N, D, H, W};
+  char* col = (char*)ws;
+  char* part = col + (size_t)M * 32 * esz + 8192;
+  if (int e = im2col_launch(x, col, g, M, 27, 0, dtype, as_stream(stream))) return e;
+  return run_wgrad<WG_PLAIN>(dy, col, dw_ref, part, ws_bytes - (size_t)(part - col), g, Co, 32, 1, dtype, as_stream(stream), 27);
+}
+
+extern "C" size_t pcrl_conv3d_to1_wgrad_ws_bytes(int N, int D, int H, int W, int C, int taps) {
+  (void)taps;
+  return plain_ws_bytes((int64_t)N * D * H * W, C, 4);
+}
+
+extern "C" int pcrl_conv3d_to1_wgrad(const void* x, const float* dy, float* dw_ref, float* db, void* ws, size_t ws_bytes,
+                                     int N, int D, int H, int W, int C, int taps, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && dy && dw_ref && db, "conv3d_to1_wgrad: null pointer");
+  PCRL_REQUIRE(dtype == PCRL_BF16 || dtype == PCRL_F32, "conv3d_to1_wgrad: bad dtype %d", dtype);
+  PCRL_REQUIRE(taps == 27 || taps == 1, "conv3d_to1_wgrad: taps must be 27 or 1 (got %d)", taps);
+  PCRL_REQUIRE(C > 0 && C % 8 == 0, "conv3d_to1_wgrad: C must be a multiple of 8 (got %d)", C);
+  const int64_t M = (int64_t)N * D * H * W;
+  const int esz = dtype == PCRL_BF16 ? 2 : 4;
+  if (!ws || ws_bytes < plain_ws_bytes(M, C, esz)) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_to1_wgrad: workspace too small");
+  const Dims g{N, D, H, W};
+  char* col = (char*)ws;
+  double* red = (double*)(col + (size_t)M * 32 * esz);
+  char* part = (char*)red + 8192;
+  if (int e = im2col_launch(dy, col, g, M, taps, 1, dtype, as_stream(stream))) return e;
+  if (int e = run_wgrad<WG_PLAIN>(x, col, dw_ref, part, ws_bytes - (size_t)(part - col), g, C, 32, 1, dtype, as_stream(stream), taps)) return e;
+  int blocks = (int)((M + 4095) / 4096);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(vecsum_partial_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, red, M);
+  if (int e = pcrl_check_launch("vecsum_partial")) return e;
+  hipLaunchKernelGGL(vecsum_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const double*)red, db, blocks);
+  return pcrl_check_launch("vecsum_finish");
 }

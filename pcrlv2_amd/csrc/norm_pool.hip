@@ -127,6 +127,59 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// Fast variants for C % VEC == 0 with (C/VEC) dividing 256: a thread owns ONE channel vector for its whole life, so the
+// per-channel coefficients are loaded once into registers and the streaming loop touches only the activations (the generic
+// kernels above re-load 2-5 coefficients per ELEMENT, which bounds them by VMEM issue at ~1.2 TB/s instead of HBM).
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_apply_rc_kernel(const T* __restrict__ y, T* __restrict__ a, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int64_t M, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nvec = C / VEC, cv = threadIdx.x % nvec, slot = threadIdx.x / nvec, nslots = 256 / nvec;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sc[j] = scale[cv * VEC + j]; sh[j] = shift[cv * VEC + j]; }
+  const int64_t stride = (int64_t)gridDim.x * nslots;
+#pragma unroll 4
+  for (int64_t r = (int64_t)blockIdx.x * nslots + slot; r < M; r += stride) {
+    const int64_t off = (r * nvec + cv) * VEC;
+    const Vec16<T> v = ld16(y + off);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(act_fwd<ACT>(sc[j] * to_f(v.v[j]) + sh[j]));
+    st16(a + off, o);
+  }
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_apply_rc_kernel(const T* __restrict__ da, const T* __restrict__ y, T* __restrict__ dy,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ k1, const float* __restrict__ kB,
+                                                              const float* __restrict__ kA, int64_t M, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nvec = C / VEC, cv = threadIdx.x % nvec, slot = threadIdx.x / nvec, nslots = 256 / nvec;
+  float sc[VEC], sh[VEC], c1[VEC], cB[VEC], cA[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int c = cv * VEC + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; c1[j] = k1[c]; cB[j] = kB[c]; cA[j] = kA[c];
+  }
+  const int64_t stride = (int64_t)gridDim.x * nslots;
+#pragma unroll 4
+  for (int64_t r = (int64_t)blockIdx.x * nslots + slot; r < M; r += stride) {
+    const int64_t off = (r * nvec + cv) * VEC;
+    const Vec16<T> g = ld16(da + off);
+    const Vec16<T> v = ld16(y + off);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float yv = to_f(v.v[j]);
+      const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], to_f(g.v[j]));
+      o.v[j] = from_f<T>(c1[j] * dz + cB[j] * yv + cA[j]);
+    }
+    st16(dy + off, o);
+  }
+}
+
 // First-stage reduction of the backward: per 1024-row tile, per channel: (sum dz, sum dz*xhat).
 // Thread = (channel vector, row slot); LDS combine over row slots.  nvec = C/VEC divides 256.
 template <typename T, int ACT>
@@ -220,15 +273,23 @@ __global__ void __launch_bounds__(256) coltile_sum_kernel(const T* __restrict__ 
   }
 }
 
-// out[n][c] = scale * sum_t ws[n][t][c]
+// out[n][c] = scale * sum_t ws[n][t][c].  Block = 32 channels x 8 tile slices (fp64 partials, LDS combine, fixed order).
 __global__ void __launch_bounds__(256) coltile_finish_kernel(const float* __restrict__ ws, float* __restrict__ out, int tiles, int C,
                                                              int N, double scale) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N * C) return;
-  const int n = i / C, c = i % C;
+  __shared__ double sm[8][33];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, n = blockIdx.y;
   double s = 0.0;
-  for (int t = 0; t < tiles; ++t) s += (double)ws[((int64_t)n * tiles + t) * C + c];
-  out[i] = (float)(s * scale);
+  if (c < C)
+    for (int t = sl; t < tiles; t += 8) s += (double)ws[((int64_t)n * tiles + t) * C + c];
+  sm[sl][cl] = s;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    double a = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a += sm[q][cl];
+    out[(int64_t)n * C + c] = (float)(a * scale);
+  }
 }
 
 template <typename T>
@@ -328,6 +389,15 @@ inline unsigned grid_for(int64_t work_items) {
   return (unsigned)b;
 }
 
+// grid for the register-cached streaming kernels: enough blocks to fill the chip (8 per CU), never more rows than exist
+inline unsigned rc_grid(int64_t M, int nvec) {
+  const int nslots = (nvec > 0 && nvec <= 256) ? 256 / nvec : 1;
+  int64_t b = (M + nslots - 1) / nslots;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
 int check_vec(const char* what, int C, int dtype, bool allow_c1) {
   if (dtype != PCRL_F32 && dtype != PCRL_BF16) return pcrl_fail(PCRL_EINVAL, "%s: bad dtype %d", what, dtype);
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
@@ -370,12 +440,16 @@ extern "C" int pcrl_bn_act_apply(const void* y, void* a, const float* scale, con
   PCRL_REQUIRE((M * C) % vec == 0, "bn_act_apply: M*C must be a multiple of %d", vec);
   const int64_t nvec = M * C / vec;
   const dim3 grid(grid_for(nvec));
+  const bool rc = C % vec == 0 && (C / vec) <= 256 && 256 % (C / vec) == 0;
+  const dim3 grid_rc(rc_grid(M, C / (C % vec == 0 ? vec : 1)));
   if (dtype == PCRL_BF16) {
     using T = bf16;
-    DISPATCH_ACT_T(bn_apply_kernel, grid, 0, (const T*)y, (T*)a, scale, shift, nvec, C);
+    if (rc) DISPATCH_ACT_T(bn_apply_rc_kernel, grid_rc, 0, (const T*)y, (T*)a, scale, shift, M, C);
+    else DISPATCH_ACT_T(bn_apply_kernel, grid, 0, (const T*)y, (T*)a, scale, shift, nvec, C);
   } else {
     using T = float;
-    DISPATCH_ACT_T(bn_apply_kernel, grid, 0, (const T*)y, (T*)a, scale, shift, nvec, C);
+    if (rc) DISPATCH_ACT_T(bn_apply_rc_kernel, grid_rc, 0, (const T*)y, (T*)a, scale, shift, M, C);
+    else DISPATCH_ACT_T(bn_apply_kernel, grid, 0, (const T*)y, (T*)a, scale, shift, nvec, C);
   }
   return pcrl_check_launch("bn_act_apply");
 }
@@ -421,12 +495,16 @@ extern "C" int pcrl_bn_act_bwd_apply(const void* da, const void* y, void* dy, co
   PCRL_REQUIRE((M * C) % vec == 0, "bn_act_bwd_apply: M*C must be a multiple of %d", vec);
   const int64_t nvec = M * C / vec;
   const dim3 grid(grid_for(nvec));
+  const bool rc = C % vec == 0 && (C / vec) <= 256 && 256 % (C / vec) == 0;
+  const dim3 grid_rc(rc_grid(M, C / (C % vec == 0 ? vec : 1)));
   if (dtype == PCRL_BF16) {
     using T = bf16;
-    DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
+    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C);
+    else DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
   } else {
     using T = float;
-    DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
+    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C);
+    else DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
   }
   return pcrl_check_launch("bn_act_bwd_apply");
 }
@@ -468,7 +546,7 @@ static int coltile_launch(const void* v, float* out, void* ws, size_t ws_bytes, 
   if (dtype == PCRL_BF16) hipLaunchKernelGGL(coltile_sum_kernel<bf16>, grid, dim3(256), lds, stream, (const bf16*)v, (float*)ws, S, C);
   else hipLaunchKernelGGL(coltile_sum_kernel<float>, grid, dim3(256), lds, stream, (const float*)v, (float*)ws, S, C);
   if (int e = pcrl_check_launch(what)) return e;
-  hipLaunchKernelGGL(coltile_finish_kernel, dim3((N * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, out, (int)tiles, C, N, scale);
+  hipLaunchKernelGGL(coltile_finish_kernel, dim3((C + 31) / 32, N), dim3(256), 0, stream, (const float*)ws, out, (int)tiles, C, N, scale);
   return pcrl_check_launch(what);
 }
 

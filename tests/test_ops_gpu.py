@@ -133,7 +133,8 @@ def test_first_layer_c1(dt):
     st = back(part).view(rows, Co, 2).sum(0)
     check(st[:, 0], ref.detach().sum(dim=(0, 2, 3, 4)), dt, "c1 stats", out_rounded=False, f32_tol=1e-4)
     dy = rnd(N, Co, D, H, W, seed=4)
-    ref.backward(q(dy, dt))
+    # the weight gradient is an MFMA GEMM whose operands (dy and the im2col of x) are stored in the activation dtype
+    F.conv3d(q(x, dt), wr, b, padding=1).backward(q(dy, dt))
     nb = L.call("pcrl_conv3d_k3_c1_wgrad_ws_bytes", N, D, H, W, Co)
     dw = torch.zeros(Co, 1, 3, 3, 3, dtype=torch.float32, device=DEV)
     L.call("pcrl_conv3d_k3_c1_wgrad", xd, act_dev(dy, dt), dw, ops.workspace(nb, xd.device), nb, N, D, H, W, Co, dtype_code(dt), s)
@@ -162,14 +163,18 @@ def test_conv_to_one_channel(C, taps, dt):
     assert abs(st[0].item() - ref.sum().item()) <= 1e-4 * max(1.0, ref.abs().sum().item())
     dy = rnd(N, 1, D, H, W, seed=4)
     ref.backward(dy)
+    gx = xq.grad.clone()
+    # weight gradient: MFMA GEMM on x and the im2col of dy, both stored in the activation dtype
+    wr.grad = None
+    F.conv3d(xq.detach(), wr, None, padding=k // 2).backward(q(dy, dt))
     dyd = dy.float().to(DEV).contiguous()
     add = rnd(N, C, D, H, W, seed=6)
     adda = act_dev(add, dt)
     dx = ops.new_act(N, D, H, W, C, dt, DEV)
     L.call("pcrl_conv3d_to1_dgrad", dyd, wdev, adda, dx, N, D, H, W, C, taps, dtype_code(dt), s)
-    check(dx, xq.grad + q(add, dt), dt, "to1 dgrad (+add_src)")
+    check(dx, gx + q(add, dt), dt, "to1 dgrad (+add_src)")
     L.call("pcrl_conv3d_to1_dgrad", dyd, wdev, None, dx, N, D, H, W, C, taps, dtype_code(dt), s)
-    check(dx, xq.grad, dt, "to1 dgrad")
+    check(dx, gx, dt, "to1 dgrad")
     nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, C, taps)
     dw = torch.zeros_like(wdev)
     db = torch.zeros(1, dtype=torch.float32, device=DEV)
