@@ -5,7 +5,7 @@
              forward + backward + SGD), b = 32 crops per GPU, synthetic data resident in HBM, bf16 activations / MFMA
              operands with fp32 accumulation (BASELINE config C2; C3 with --gpus N, weak scaling).
   step     : one pass of train_3d.train_step over one batch.
-  roofline : the dominant kernel (bf16 implicit-GEMM 3x3x3 convolution, forward + data-gradient launches): algorithmic
+  roofline : the dominant kernel (bf16 LDS-halo implicit-GEMM 3x3x3 convolution, forward + data-gradient launches): algorithmic
              FLOPs (2*M*27*Ci*Co per launch) / launch duration measured with HIP events on the launch stream, against
              the dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).
   cpu_baseline : the CPU oracle (a port of the reference step, oracle/pcrlv2_oracle.py) timed on this box's host cores on
@@ -33,18 +33,26 @@ FLOP_PER_CROP = 1.2707e12   # fwd+bwd of one crop (2 global + 6 local views), SU
 
 
 def conv_key(name, args):
-    """Classify an igemm launch like the kernel template does and return its algorithmic FLOPs."""
+    """Classify a pcrl_conv3d_k3_fwd launch the way the library's dispatcher does (conv_igemm.hip / conv_brick.hip) and
+    return its algorithmic FLOPs (2 * voxels * 27 * Ci * Co)."""
     # pcrl_conv3d_k3_fwd(x, wp, bias, y, stats, N, D, H, W, Ci, Co, dtype, stream)
     N, D, H, W, Ci, Co, dt = args[5:12]
-    bn = 128 if Co % 128 == 0 else (64 if Co % 64 == 0 else 32)
-    key = "igemm_kernel<%s,%d,conv3>" % ("bf16" if dt == 1 else "f32", bn)
+    if dt == 1 and D % 4 == 0 and H % 8 == 0 and W % 8 == 0 and Co % 64 == 0:
+        key = "brick_conv_kernel"
+    else:
+        bn = 128 if Co % 128 == 0 else (64 if Co % 64 == 0 else 32)
+        key = "igemm_kernel<%s,%d,conv3>" % ("bf16" if dt == 1 else "f32", bn)
     return key, 2.0 * N * D * H * W * 27 * Ci * Co
 
 
 def wgrad_key(name, args):
     # pcrl_conv3d_k3_wgrad(x, dy, dw, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)
     N, D, H, W, Ci, Co, dt = args[5:12]
-    return "wgrad_kernel<%s,conv3>" % ("bf16" if dt == 1 else "f32"), 2.0 * N * D * H * W * 27 * Ci * Co
+    if dt == 1 and D % 2 == 0 and H % 8 == 0 and W % 8 == 0 and Co % 64 == 0:
+        key = "wgrad_brick_kernel(+reduce)"
+    else:
+        key = "wgrad_kernel<%s,conv3>(+reduce)" % ("bf16" if dt == 1 else "f32")
+    return key, 2.0 * N * D * H * W * 27 * Ci * Co
 
 
 def keyfn(name, args):
@@ -151,7 +159,7 @@ def main():
     detail = {}
     for k, (n, ms, work) in sorted(res.items()):
         detail[k] = {"launches": n, "avg_ms": round(ms / n, 4), "tflops": round(work / (ms * 1e-3) / 1e12, 1)}
-    conv = {k: v for k, v in res.items() if k.startswith("igemm")}
+    conv = {k: v for k, v in res.items() if k.startswith(("igemm", "brick"))}
     dom = max(conv, key=lambda k: conv[k][1])
     n, ms, work = conv[dom]
     achieved = work / (ms * 1e-3) / 1e12

@@ -54,10 +54,14 @@ int pcrl_pack_convt_weight(const float* w_ref, void* w_fwd, void* w_dgrad, int C
  * 3x3x3 convolution, pad 1, stride 1 -- aten::convolution at pcrlv2_model_3d.py:9,33 (LUConv.conv1).
  * Implicit GEMM on MFMA: M = N*D*H*W voxels, N = Co, K = 27*Ci.  Ci % 32 == 0, Co % 32 == 0.
  *   y[m][co] = bias[co] + sum_{t,ci} x[m+delta_t][ci] * wp[co][t][ci]      (zero outside the volume)
- * `stats_partial` (optional): [ceil(M/128)][Co][2] float; row r receives (sum y, sum y^2) of tile r, taken
- * from the fp32 accumulators, for the training-mode BatchNorm that follows (:12,33).
+ * `stats_partial` (optional): [pcrl_conv3d_k3_stats_rows(...)][Co][2] float; row r receives (sum y, sum y^2) of
+ * output tile r, taken from the fp32 accumulators, for the training-mode BatchNorm that follows (:12,33).
+ * Two kernels sit behind this entry point: an LDS-halo "brick" kernel (bf16, D%4 == 0, H%8 == 0, W%8 == 0, Co%64 == 0:
+ * 4x8x8-voxel tiles) and a gather kernel (any shape, both dtypes: 128-voxel tiles); the helper tells which tiling
+ * the given shape gets.
  * The data gradient (aten::convolution_backward, input half) is the same call with wp = w_dgrad,
  * Ci/Co exchanged, bias = NULL, stats_partial = NULL. */
+int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype);
 int pcrl_conv3d_k3_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial,
                        int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
 

@@ -77,6 +77,12 @@ class _Lib:
         self.debug_set_wgrad_tr = self.cdll.pcrl_debug_set_wgrad_tr
         self.debug_set_wgrad_tr.argtypes = [ctypes.c_int]
         self.debug_set_wgrad_tr.restype = None
+        self.debug_set_wgrad_impl = self.cdll.pcrl_debug_set_wgrad_impl
+        self.debug_set_wgrad_impl.argtypes = [ctypes.c_int]
+        self.debug_set_wgrad_impl.restype = None
+        self.debug_set_conv_impl = self.cdll.pcrl_debug_set_conv_impl
+        self.debug_set_conv_impl.argtypes = [ctypes.c_int]
+        self.debug_set_conv_impl.restype = None
 
     def version(self) -> str:
         return self.fn["pcrl_version"][0]().decode()

@@ -311,10 +311,26 @@ int check_dims(const char* what, int N, int D, int H, int W, int Ci, int Co) {
 
 }  // namespace
 
+// LDS-halo brick kernel (conv_brick.hip)
+bool pcrl_brick_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);
+int64_t pcrl_brick_conv_rows(int N, int D, int H, int W);
+int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
+                           int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
+
+static int g_conv_impl = 0;  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
+extern "C" void pcrl_debug_set_conv_impl(int impl) { g_conv_impl = impl; }
+
+extern "C" int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  if (g_conv_impl == 0 && pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype)) return pcrl_brick_conv_rows(N, D, H, W);
+  return ((int64_t)N * D * H * W + PCRL_CONV_BM - 1) / PCRL_CONV_BM;
+}
+
 extern "C" int pcrl_conv3d_k3_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial,
                                   int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_dims("conv3d_k3_fwd", N, D, H, W, Ci, Co)) return e;
   PCRL_REQUIRE(x && wp && y, "conv3d_k3_fwd: null pointer");
+  if (g_conv_impl == 0 && pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype))
+    return pcrl_brick_conv_launch(x, wp, bias, y, stats_partial, N, D, H, W, Ci, Co, as_stream(stream));
   IgemmParams p{x, wp, bias, y, stats_partial, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 27};
   return dispatch<GEOM_CONV3>(p, 1, dtype, as_stream(stream));
 }

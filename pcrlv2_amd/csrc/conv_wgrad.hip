@@ -342,15 +342,39 @@ int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_b
 // Test hook (not part of the drop-in surface): select the bf16 fragment-fetch path.
 extern "C" void pcrl_debug_set_wgrad_tr(int on) { g_wgrad_tr = on; }
 
+// LDS-halo brick kernel (wgrad_brick.hip)
+bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);
+int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co);
+int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
+
+static int g_wgrad_impl = 0;  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
+extern "C" void pcrl_debug_set_wgrad_impl(int impl) { g_wgrad_impl = impl; }
+
 extern "C" size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
   const SplitPlan sp = plan_splits((int64_t)N * D * H * W, Co, Ci, 27);
-  return (size_t)sp.splits * 27 * Co * Ci * sizeof(float);
+  size_t a = (size_t)sp.splits * 27 * Co * Ci * sizeof(float);
+  if (pcrl_wgrad_brick_eligible(N, D, H, W, Ci, Co, PCRL_BF16)) {
+    const size_t b = (size_t)pcrl_wgrad_brick_splits(N, D, H, W, Ci, Co) * 27 * Co * Ci * sizeof(float);
+    if (b > a) a = b;
+  }
+  return a;
 }
 
 extern "C" int pcrl_conv3d_k3_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes,
                                     int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   PCRL_REQUIRE(x && dy && dw_ref, "conv3d_k3_wgrad: null pointer");
   PCRL_REQUIRE(Ci > 0 && Co > 0 && Ci % 32 == 0 && Co % 32 == 0, "conv3d_k3_wgrad: channels must be multiples of 32 (Ci=%d Co=%d)", Ci, Co);
+  if (g_wgrad_impl == 0 && pcrl_wgrad_brick_eligible(N, D, H, W, Ci, Co, dtype)) {
+    const int splits = pcrl_wgrad_brick_splits(N, D, H, W, Ci, Co);
+    const size_t need = (size_t)splits * 27 * Co * Ci * sizeof(float);
+    if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_k3_wgrad: workspace %zu < %zu", ws_bytes, need);
+    if (int e = pcrl_wgrad_brick_launch(x, dy, (float*)ws, N, D, H, W, Ci, Co, as_stream(stream))) return e;
+    const int64_t total = (int64_t)Co * Ci * 27;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)ws, dw_ref, splits, 27, Co, Ci, Ci);
+    return pcrl_check_launch("wgrad_reduce");
+  }
   return run_wgrad<WG_CONV3>(dy, x, dw_ref, ws, ws_bytes, Dims{N, D, H, W}, Co, Ci, 27, dtype, as_stream(stream));
 }
 

@@ -1,0 +1,215 @@
+// LDS-halo ("brick") weight-gradient kernel for the 3x3x3 convolution, bf16, gfx950 -- the throughput path of
+// pcrl_conv3d_k3_wgrad for volumes with D % 2 == 0, H % 8 == 0, W % 8 == 0 and Co % 64 == 0.
+//
+// Replaces the weight half of aten::convolution_backward for LUConv.conv1 (models/pcrlv2_model_3d.py:9,33).
+//
+//   dW[co][ci][t] = sum_m dy[m][co] * x[m + delta_t][ci]
+//
+// The gather kernel (conv_wgrad.hip) re-reads both operand tiles from L2 for each of the 27 taps (8 KB per 64 MFMA
+// cycles: L2-bandwidth bound, ~240 TF).  Here a block owns a 64(co) x 64(ci) tile of ONE kd plane (9 taps) and walks
+// over bricks of 2 x 8 x 8 = 128 voxels: per brick it stages dy[128][64] and the x halo for that kd
+// ([2][10][12-padded] rows x 64 ch, zero outside the volume) in LDS ONCE and runs all 9 (kh,kw) taps from it.
+// Operands are fetched with ds_read_b64_tr_b16 (the reduction index is the row index of both NDHWC tensors).
+// Each wave owns all 64 co x 16 ci of the 9 taps (36 accumulator fragments): the dy fragments are read once per
+// 32-voxel K-chunk and reused by 9 taps, the x fragment of a tap feeds 4 MFMAs -> 13 KB of LDS reads per 36 MFMAs.
+// The next brick is prefetched into registers while the current one is multiplied.  Split-K over brick ranges; the
+// partial slabs are reduced in fixed order by the same second pass as the gather kernel.
+#include "common.h"
+
+namespace {
+
+constexpr int BD = 2, BH = 8, BW = 8;
+constexpr int BV = BD * BH * BW;          // 128 voxels per brick
+constexpr int XH = BH + 2, XW = 12;       // halo extents (w padded 10 -> 12 for conflict-free transpose reads)
+constexpr int XROWS = BD * XH * XW;       // 240
+constexpr int DY_BYTES = BV * 128;        // 16 KiB
+constexpr int X_BYTES = XROWS * 128;      // 30 KiB
+constexpr int DYP = BV * 8 / 256;         // dy 16-byte pieces per thread (4)
+constexpr int XP = (XROWS * 8 + 255) / 256;  // x pieces per thread (8: 1920 pieces)
+
+struct WBrickParams {
+  const bf16* dy;   // [M][Cu]
+  const bf16* x;    // [M][Cv]
+  float* ws;        // [splits][27][Cu][Cv]
+  int N, D, H, W;
+  int Cu, Cv;
+  int nbricks, per_split;
+};
+
+__device__ __forceinline__ int dy_off(int v, int col) {   // 128-byte rows, 32-byte quads XOR-swizzled (see conv_wgrad.hip)
+  const int key = ((v >> 1) & 1) | (((v >> 3) & 1) << 1);
+  return v * 128 + ((((col >> 4) ^ key) & 3) << 5) + ((col & 15) << 1);
+}
+__device__ __forceinline__ int x_off(int row, int col) {  // rows R0+{0..3} and R0+12+{0..3} of one read -> distinct quads
+  return row * 128 + ((((col >> 4) ^ (row >> 1)) & 3) << 5) + ((col & 15) << 1);
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
+  union { struct { s16x4 a, b; } s; bf16x8 f; } u;
+  u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+  u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+  return u.f;
+}
+
+__global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* dys = smem;
+  char* xs = smem + DY_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lg = lane >> 4, jr = (lane & 15) >> 2, cq = lane & 3;
+  const int ntj = p.Cv / 64 > 0 ? (p.Cv + 63) / 64 : 1;
+  const int kd = blockIdx.y % 3;
+  const int tile = blockIdx.y / 3;
+  const int i0 = (tile / ntj) * 64, j0 = (tile % ntj) * 64;
+  const int b_beg = blockIdx.x * p.per_split;
+  const int b_end = min(b_beg + p.per_split, p.nbricks);
+  const int bw = p.W / BW, bh = p.H / BH, bd = p.D / BD;
+
+  f32x4 acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging roles: dy piece q = tid + 256*i -> voxel q>>3, 16-byte piece q&7 ; x piece likewise over 240 halo rows
+  const int pc = tid & 7;
+  const bool jcol_ok = (j0 + pc * 8) < p.Cv;       // Cv is a multiple of 32: a 64-wide tile may hang over
+  const int xcol = jcol_ok ? j0 + pc * 8 : 0;
+  u32x4 rdy[DYP], rx[XP];
+  uint32_t xvalid = 0;
+
+#define WB_LOAD(b_)                                                                                          \
+  do {                                                                                                       \
+    int t_ = (b_);                                                                                           \
+    const int w0 = (t_ % bw) * BW; t_ /= bw;                                                                 \
+    const int h0 = (t_ % bh) * BH; t_ /= bh;                                                                 \
+    const int d0 = (t_ % bd) * BD; t_ /= bd;                                                                 \
+    const int n = t_;                                                                                        \
+    const int64_t base0 = (((int64_t)n * p.D + d0) * p.H + h0) * p.W + w0;                                   \
+    _Pragma("unroll") for (int i = 0; i < DYP; ++i) {                                                        \
+      const int v = (tid >> 3) + 32 * i;                                                                     \
+      const int64_t row = base0 + ((int64_t)(v >> 6) * p.H + ((v >> 3) & 7)) * p.W + (v & 7);                \
+      rdy[i] = *reinterpret_cast<const u32x4*>(p.dy + row * p.Cu + i0 + pc * 8);                             \
+    }                                                                                                        \
+    xvalid = 0;                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                         \
+      const int r = (tid >> 3) + 32 * i;                                                                     \
+      const int hd = r / (XH * XW), hh = (r / XW) % XH, hw = r % XW;                                         \
+      const int d = d0 + hd + kd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                      \
+      const bool ok = r < XROWS && hw < BW + 2 && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && \
+                      (unsigned)w < (unsigned)p.W;                                                           \
+      const int64_t row = ok ? (((int64_t)n * p.D + d) * p.H + h) * p.W + w : base0;                         \
+      rx[i] = *reinterpret_cast<const u32x4*>(p.x + row * p.Cv + xcol);                                      \
+      xvalid |= (uint32_t)(ok && jcol_ok) << i;                                                              \
+    }                                                                                                        \
+  } while (0)
+
+#define WB_STORE()                                                                                           \
+  do {                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < DYP; ++i)                                                          \
+      *reinterpret_cast<u32x4*>(dys + dy_off((tid >> 3) + 32 * i, pc * 8)) = rdy[i];                         \
+    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                         \
+      const int r = (tid >> 3) + 32 * i;                                                                     \
+      if (r < XROWS) *reinterpret_cast<u32x4*>(xs + x_off(r, pc * 8)) = keep_if((xvalid >> i) & 1u, rx[i]);  \
+    }                                                                                                        \
+  } while (0)
+
+  if (b_beg < b_end) {
+    WB_LOAD(b_beg);
+    WB_STORE();
+  }
+  __syncthreads();
+
+  for (int b = b_beg; b < b_end; ++b) {
+    const int bn = (b + 1 < b_end) ? b + 1 : b;
+    WB_LOAD(bn);
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+      // lane's voxels of this K-chunk: v = 32*kc + 8*lg + 4*q + jr   (q = 0,1 = the two transpose reads)
+      const int vrow = 32 * kc + 8 * lg + jr;
+      bf16x8 fa[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+        fa[f] = tr_frag(dys + dy_off(vrow, f * 16 + 4 * cq), dys + dy_off(vrow + 4, f * 16 + 4 * cq));
+      // halo row of voxel (vd, vh, vw) at tap (kh, kw): (vd*XH + vh + kh)*XW + vw + kw
+      const int vd = kc >> 1, vh = (kc & 1) * 4 + lg;
+      const int xrow0 = (vd * XH + vh) * XW + jr;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int r0 = xrow0 + kh * XW + kw;
+          const bf16x8 fb = tr_frag(xs + x_off(r0, wid * 16 + 4 * cq), xs + x_off(r0 + 4, wid * 16 + 4 * cq));
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
+            acc[kh * 3 + kw][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f], fb, acc[kh * 3 + kw][f], 0, 0, 0);
+        }
+      }
+    }
+
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();   // all waves have finished reading this brick
+    WB_STORE();
+    __syncthreads();
+  }
+#undef WB_LOAD
+#undef WB_STORE
+
+  // D[i][j]: lane holds i = 16 f + 4 lg + r, j = lane & 15
+  float* out = p.ws + (int64_t)blockIdx.x * 27 * p.Cu * p.Cv;
+  const int j = j0 + wid * 16 + (lane & 15);
+  if (j < p.Cv) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float* ot = out + (int64_t)(kd * 9 + t) * p.Cu * p.Cv;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[(int64_t)(i0 + f * 16 + lg * 4 + r) * p.Cv + j] = acc[t][f][r];
+    }
+  }
+}
+
+struct BrickSplit {
+  int splits, per_split;
+};
+BrickSplit plan(int nbricks, int Cu, int Cv) {
+  const int tiles = (Cu / 64) * ((Cv + 63) / 64) * 3;
+  int splits = 1024 / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > nbricks / 4) splits = nbricks / 4;   // at least 4 bricks per block
+  if (splits < 1) splits = 1;
+  const int per = (nbricks + splits - 1) / splits;
+  splits = (nbricks + per - 1) / per;
+  return BrickSplit{splits, per};
+}
+
+}  // namespace
+
+// ---- internal interface used by conv_wgrad.hip ---------------------------------------------------------------------
+bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return dtype == PCRL_BF16 && D % BD == 0 && H % BH == 0 && W % BW == 0 && Co % 64 == 0 && Ci % 32 == 0 &&
+         (int64_t)N * D * H * W / BV < (1 << 30);
+}
+int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co) {
+  return plan((int)((int64_t)N * D * H * W / BV), Co, Ci).splits;
+}
+int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co,
+                            hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds = DY_BYTES + X_BYTES;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int nbricks = (int)((int64_t)N * D * H * W / BV);
+  const BrickSplit sp = plan(nbricks, Co, Ci);
+  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split};
+  dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64) * 3));
+  hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(256), lds, stream, p);
+  return pcrl_check_launch("wgrad_brick");
+}

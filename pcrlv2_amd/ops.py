@@ -171,7 +171,7 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         if x.dtype != dtype:
             raise PcrlError(f"LUConv: activation dtype {x.dtype} != compute dtype {dtype}")
         M = N * D * H * W
-        rows = (M + CONV_BM - 1) // CONV_BM
+        rows = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Ci, Co, dtype_code(dtype))
         wf, _ = packed.get(conv_w, dtype)
         y = new_act(N, D, H, W, Co, dtype, dev)
         partial = _f32(rows * Co * 2, dev)

@@ -51,6 +51,8 @@ def check(got, ref, dt, what, out_rounded=True, f32_tol=2e-5, bf_tol=1e-2):
 
 SHAPES3 = [  # N, D, H, W, Ci, Co   (M deliberately not a multiple of 128 in the first rows)
     (3, 6, 5, 7, 32, 64), (2, 4, 4, 4, 64, 32), (1, 8, 8, 4, 64, 128), (2, 2, 2, 2, 128, 256), (1, 16, 8, 8, 32, 64),
+    # shapes served by the LDS-halo brick kernel in bf16 (D%4 == H%8 == W%8 == 0): edge bricks in every direction
+    (2, 8, 16, 8, 64, 64), (1, 4, 8, 16, 96, 128), (3, 4, 8, 8, 32, 64), (1, 12, 24, 16, 64, 64), (2, 2, 8, 8, 128, 64),
 ]
 
 
@@ -67,7 +69,7 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
     wf, wd = pk.get(wdev, dt)
     xa = act_dev(x, dt)
     M = N * D * H * W
-    rows = (M + CONV_BM - 1) // CONV_BM
+    rows = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Ci, Co, dtype_code(dt))
     y = ops.new_act(N, D, H, W, Co, dt, DEV)
     part = torch.zeros(rows * Co * 2, dtype=torch.float32, device=DEV)
     L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y, part, N, D, H, W, Ci, Co, dtype_code(dt), s)
@@ -87,12 +89,23 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
     check(dx, xr.grad, dt, "conv3 dgrad")
     # weight gradient (float32 out in both modes): both bf16 fragment-fetch paths
     nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
-    for tr in ((1, 0) if dt == torch.bfloat16 else (1,)):
+    # impl 0 = auto (LDS-halo brick kernel where eligible), 1 = gather kernel; tr = bf16 fragment fetch of the gather kernel
+    for impl, tr in (((0, 1), (1, 1), (1, 0)) if dt == torch.bfloat16 else ((0, 1),)):
+        L.debug_set_wgrad_impl(impl)
         L.debug_set_wgrad_tr(tr)
         dw = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float32, device=DEV)
         L.call("pcrl_conv3d_k3_wgrad", xa, dya, dw, ops.workspace(nb, xa.device), nb, N, D, H, W, Ci, Co, dtype_code(dt), s)
-        check(dw, wr.grad, dt, f"conv3 wgrad tr={tr}", out_rounded=False, f32_tol=3e-5)
+        check(dw, wr.grad, dt, f"conv3 wgrad impl={impl} tr={tr}", out_rounded=False, f32_tol=3e-5)
     L.debug_set_wgrad_tr(1)
+    L.debug_set_wgrad_impl(0)
+    # the gather forward kernel on the same shape (impl 1), in case impl 0 took the brick kernel above
+    L.debug_set_conv_impl(1)
+    rows1 = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Ci, Co, dtype_code(dt))
+    part1 = torch.zeros(rows1 * Co * 2, dtype=torch.float32, device=DEV)
+    L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y, part1, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    L.debug_set_conv_impl(0)
+    check(y, ref, dt, "conv3 fwd (gather kernel)")
+    check(back(part1).view(rows1, Co, 2).sum(0)[:, 0], ref.sum(dim=(0, 2, 3, 4)), dt, "conv3 stats (gather)", out_rounded=False, f32_tol=1e-4)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

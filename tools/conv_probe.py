@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Per-layer A/B probe of the convolution kernels (within one process, interleaved rounds, HIP-event timing).
+
+    python tools/conv_probe.py [--b 32] [--rounds 5] [--what fwd,wgrad] [--layers up64.0,...]
+
+Prints, per layer shape of PCRLv23d at batch b: time and TFLOP/s of
+  fwd   : pcrl_conv3d_k3_fwd  with impl 0 (auto: LDS-halo brick kernel where eligible) vs impl 1 (gather kernel)
+  wgrad : pcrl_conv3d_k3_wgrad
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from pcrlv2_amd import ops  # noqa: E402
+from pcrlv2_amd._lib import dtype_code, lib, stream_handle  # noqa: E402
+
+LAYERS = [  # name, Ci, Co, (D, H, W) for 64x64x32 inputs
+    ("down64.1", 32, 64, (64, 64, 32)), ("down128.0", 64, 64, (32, 32, 16)), ("down128.1", 64, 128, (32, 32, 16)),
+    ("down256.0", 128, 128, (16, 16, 8)), ("down256.1", 128, 256, (16, 16, 8)), ("down512.0", 256, 256, (8, 8, 4)),
+    ("down512.1", 256, 512, (8, 8, 4)), ("up256.0", 512, 256, (16, 16, 8)), ("up256.1", 256, 256, (16, 16, 8)),
+    ("up128.0", 256, 128, (32, 32, 16)), ("up128.1", 128, 128, (32, 32, 16)), ("up64.0", 128, 64, (64, 64, 32)),
+    ("up64.1", 64, 64, (64, 64, 32)),
+]
+
+
+def timed(fn, rounds):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--b", type=int, default=32)
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--what", default="fwd,dgrad,wgrad")
+    ap.add_argument("--layers", default="")
+    ap.add_argument("--impls", default="0,1")
+    args = ap.parse_args()
+    L, dev, dt = lib(), torch.device("cuda"), torch.bfloat16
+    what = args.what.split(",")
+    sel = set(args.layers.split(",")) if args.layers else None
+    impls = [int(v) for v in args.impls.split(",")]
+    tot = {}
+    for name, Ci, Co, (D, H, W) in LAYERS:
+        if sel and name not in sel:
+            continue
+        N = args.b
+        M = N * D * H * W
+        flops = 2.0 * M * 27 * Ci * Co
+        x = ops.new_act(N, D, H, W, Ci, dt, dev).normal_()
+        dy = ops.new_act(N, D, H, W, Co, dt, dev).normal_()
+        w = torch.randn(Co, Ci, 3, 3, 3, device=dev) * 0.05
+        wf, wd = ops.PackedWeights("conv3").get(w, dt)
+        y = ops.new_act(N, D, H, W, Co, dt, dev)
+        dx = ops.new_act(N, D, H, W, Ci, dt, dev)
+        st = torch.empty(((M + 127) // 128) * max(Ci, Co) * 2, dtype=torch.float32, device=dev)
+        s = stream_handle()
+        line = f"{name:10s} Ci={Ci:3d} Co={Co:3d} {D}x{H}x{W} M={M:8d} {flops / 1e9:8.1f} GF |"
+        for kind in what:
+            if kind in ("fwd", "dgrad"):
+                for impl in impls:
+                    L.debug_set_conv_impl(impl)
+                    if kind == "fwd":
+                        fn = lambda: L.call("pcrl_conv3d_k3_fwd", x, wf, None, y, st, N, D, H, W, Ci, Co, dtype_code(dt), s)
+                    else:
+                        fn = lambda: L.call("pcrl_conv3d_k3_fwd", dy, wd, None, dx, None, N, D, H, W, Co, Ci, dtype_code(dt), s)
+                    med, mn = timed(fn, args.rounds)
+                    line += f" {kind}[{impl}] {med:7.3f} ms {flops / med / 1e9:6.0f} TF |"
+                    tot[(kind, impl)] = tot.get((kind, impl), 0.0) + med
+                L.debug_set_conv_impl(0)
+            elif kind == "wgrad":
+                nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
+                ws = ops.workspace(nb, dev)
+                dw = torch.empty_like(w)
+                fn = lambda: L.call("pcrl_conv3d_k3_wgrad", x, dy, dw, ws, nb, N, D, H, W, Ci, Co, dtype_code(dt), s)
+                for impl in impls:
+                    L.debug_set_wgrad_impl(impl)
+                    med, mn = timed(fn, args.rounds)
+                    line += f" wgrad[{impl}] {med:7.3f} ms {flops / med / 1e9:6.0f} TF |"
+                    tot[("wgrad", impl)] = tot.get(("wgrad", impl), 0.0) + med
+                L.debug_set_wgrad_impl(0)
+        print(line, flush=True)
+    print("totals (ms, one pass over the listed layers):", {f"{k[0]}[{k[1]}]": round(v, 2) for k, v in tot.items()})
+
+
+if __name__ == "__main__":
+    main()
