@@ -11,22 +11,25 @@
 // 16-byte LDS reads (A: halo row of the lane's voxel + tap offset; B: weight row), 8 x 2 fragments of
 // v_mfma_f32_16x16x32_bf16 per wave and tap, three taps (one kw row) per barrier.
 //
-// Block = 256 threads = 4 waves as 2 (voxels) x 2 (channels): wave tile 128 voxels x 32 output channels.
-// LDS: halo 600 x 64 B = 37.5 KiB (single buffer; the next chunk is prefetched into registers during the last tap row)
-//      + weights 2 x (3 taps x 64 x 64 B) = 24 KiB  -> two blocks per CU.
+// Block = 256 threads = 4 waves; wave tile = 64 voxels x all 64 output channels (4 A + 4 B fragment reads per 16 MFMAs).
+// LDS: halo 960 rows (w pitch padded to 16, bank-conflict-free for every tap offset) x 64 B = 60 KiB, single buffer --
+//      the next chunk is prefetched into registers during the last tap row -- + one weight stage (3 taps x 64 x 64 B =
+//      12 KiB, next stage prefetched into registers) -> 72 KiB, two blocks per CU.
 #include "common.h"
 
 namespace {
 
 constexpr int TD = 4, TH = 8, TW = 8;
 constexpr int BRICK = TD * TH * TW;                    // 256 voxels
-constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;   // halo extents
-constexpr int HROWS = HD * HH * HW;                    // 600
+constexpr int HD = TD + 2, HH = TH + 2, HWU = TW + 2;  // halo extents (used)
+constexpr int HW = 16;                                 // halo row pitch in w: padded 10 -> 16, see hoff_h()
+constexpr int HROWS_USED = HD * HH * HWU;              // 600 rows are loaded
+constexpr int HROWS = HD * HH * HW;                    // 960 rows of LDS
 constexpr int BN = 64;
-constexpr int HPIECES = HROWS * 4;                     // 16-byte pieces of one 32-channel halo chunk
+constexpr int HPIECES = HROWS_USED * 4;                // 16-byte pieces of one 32-channel halo chunk
 constexpr int HPT = (HPIECES + 255) / 256;             // pieces per thread (10)
-constexpr int HALO_BYTES = HROWS * 64;
-constexpr int WT_BYTES = 3 * BN * 64;                  // one weight stage: 3 taps
+constexpr int HALO_BYTES = HROWS * 64;                 // 60 KiB
+constexpr int WT_BYTES = 3 * BN * 64;                  // one weight stage: 3 taps, 12 KiB
 
 struct BrickParams {
   const bf16* x;
@@ -38,10 +41,19 @@ struct BrickParams {
   int K, Nc;
 };
 
-// same slot swizzle as conv_igemm.hip's Tile<bf16> (64-byte rows, keys f = [0,2,3,1] per row quad)
-__device__ __forceinline__ int hoff(int row, int slot) {
+// Weight tile [64 co][32 k]: a fragment read takes 16 CONSECUTIVE rows -> same swizzle as conv_igemm.hip's Tile<bf16>.
+__device__ __forceinline__ int hoff_w(int row, int slot) {
   const int key = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
   return row * 64 + ((slot ^ key) << 4);
+}
+// Halo rows (64 B each).  An A-fragment read of tap (kd,kh,kw) takes rows R + (lr & 7) + HW * (lr >> 3) for ARBITRARY R
+// (R moves with the tap), slot lr >> 4.  gfx950 serves ds_read_b128 in 16-lane groups {0-3,12-15,20-27}, ... so one
+// group mixes rows R+0..3 and R+HW+4..7 at slot s with rows R+4..7 and R+HW+0..3 at slot s^1.  Exhaustive search over
+// row pitches and XOR keys (period <= 8 in row>>1..3): with the natural pitch HW = 10 every key leaves >= 2-way
+// conflicts on most reads (measured: SQ_LDS_BANK_CONFLICT = 55 % of SQ_LDS_IDX_ACTIVE); pitch 16 with
+// key = 2 * ((row >> 2) & 1) is conflict-free for every R.
+__device__ __forceinline__ int hoff_h(int row, int slot) {
+  return row * 64 + ((slot ^ (((row >> 2) & 1) << 1)) << 4);
 }
 
 __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p) {
@@ -49,8 +61,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   char* halo = smem;
   char* wbuf = smem + HALO_BYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;   // wave = 64 voxels x all 64 output channels
   const int lr = lane & 15, lg = lane >> 4;
   const int K = p.K, nchunk = K / 32;
   const int n0 = blockIdx.y * BN;
@@ -63,37 +74,38 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   const int d0 = (b % bd) * TD; b /= bd;
   const int n = b;
 
-  // ---- halo pieces of this thread: global row (clamped to a valid one) + validity ----
-  int grow[HPT];
+  // ---- halo pieces of this thread: global row (clamped to a valid one), LDS offset, validity ----
+  int grow[HPT], hdst[HPT];
   uint32_t hvalid = 0;
 #pragma unroll
   for (int i = 0; i < HPT; ++i) {
     const int pc = tid + 256 * i;
     const int row = pc >> 2;
-    const int hd = row / (HH * HW), hh = (row / HW) % HH, hw = row % HW;
+    const int hd = row / (HH * HWU), hh = (row / HWU) % HH, hw = row % HWU;
     const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
     const bool ok = pc < HPIECES && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
     grow[i] = ok ? ((n * p.D + d) * p.H + h) * p.W + w : ((n * p.D + d0) * p.H + h0) * p.W + w0;
+    hdst[i] = hoff_h((hd * HH + hh) * HW + hw, pc & 3);
     hvalid |= (uint32_t)ok << i;
   }
   const int hslot = tid & 3;
 
   // ---- A-fragment base rows in the halo (tap offset added per tap) ----
-  int abase[8];
+  int abase[4];
 #pragma unroll
-  for (int fm = 0; fm < 8; ++fm) {
-    const int v = wm * 128 + fm * 16 + lr;
+  for (int fm = 0; fm < 4; ++fm) {
+    const int v = wid * 64 + fm * 16 + lr;
     abase[fm] = ((v >> 6) * HH + ((v >> 3) & 7)) * HW + (v & 7);
   }
   // ---- weight staging: 3 pieces per thread (tap kw = 0,1,2 of the current (kd,kh)), row co = tid>>2, slot tid&3 ----
   const bf16* wrow = p.w + ((int64_t)(n0 + (tid >> 2)) * 27) * K + (tid & 3) * 8;
-  const int wdst = hoff(tid >> 2, tid & 3);   // within one tap tile [64][32]
+  const int wdst = hoff_w(tid >> 2, tid & 3);   // within one tap tile [64][32]
 
-  f32x4 acc[8][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 rh[HPT], rw[3];
 
@@ -105,8 +117,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #define STORE_HALO()                                                                                      \
   do {                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < HPT; ++i) {                                                     \
-      const int pc = tid + 256 * i;                                                                       \
-      if (pc < HPIECES) *reinterpret_cast<u32x4*>(halo + hoff(pc >> 2, pc & 3)) = keep_if((hvalid >> i) & 1u, rh[i]); \
+      if (tid + 256 * i < HPIECES) *reinterpret_cast<u32x4*>(halo + hdst[i]) = keep_if((hvalid >> i) & 1u, rh[i]); \
     }                                                                                                     \
   } while (0)
 #define LOAD_W(c_, s9_)                                                                                   \
@@ -114,22 +125,21 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
     _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                         \
       rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)((s9_)*3 + j) * K + (c_)*32);               \
   } while (0)
-#define STORE_W(buf_)                                                                                     \
+#define STORE_W()                                                                                         \
   do {                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                         \
-      *reinterpret_cast<u32x4*>(wbuf + (buf_)*WT_BYTES + j * (BN * 64) + wdst) = rw[j];                   \
+      *reinterpret_cast<u32x4*>(wbuf + j * (BN * 64) + wdst) = rw[j];                                     \
   } while (0)
 
   LOAD_HALO(0);
   LOAD_W(0, 0);
   STORE_HALO();
-  STORE_W(0);
+  STORE_W();
   __syncthreads();
 
-  int cur = 0;
   for (int c = 0; c < nchunk; ++c) {
     for (int s9 = 0; s9 < 9; ++s9) {
-      // next weight stage (wraps into the next chunk; the very last one re-loads itself)
+      // prefetch the next weight stage into registers (wraps into the next chunk; the very last one re-loads itself)
       int cn = c, sn = s9 + 1;
       if (sn == 9) { sn = 0; cn = c + 1; }
       const bool last = (cn == nchunk);
@@ -143,26 +153,23 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
       const int tapoff = (kd * HH + kh) * HW;
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        const char* wt = wbuf + cur * WT_BYTES + kw * (BN * 64);
-        bf16x8 fb[2];
+        const char* wt = wbuf + kw * (BN * 64);
+        bf16x8 fb[4], fa[4];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wt + hoff(wn * 32 + j * 16 + lr, lg));
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wt + hoff_w(j * 16 + lr, lg));
 #pragma unroll
-        for (int fm = 0; fm < 8; ++fm) {
-          const bf16x8 fa = *reinterpret_cast<const bf16x8*>(halo + hoff(abase[fm] + tapoff + kw, lg));
+        for (int fm = 0; fm < 4; ++fm) fa[fm] = *reinterpret_cast<const bf16x8*>(halo + hoff_h(abase[fm] + tapoff + kw, lg));
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[fm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[fm][j], 0, 0, 0);
-        }
+        for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[fm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[fm], fb[j], acc[fm][j], 0, 0, 0);
       }
 
       __builtin_amdgcn_sched_barrier(0);
-      STORE_W(cur ^ 1);
-      if (halo_next) {
-        __syncthreads();   // every wave has finished reading this chunk's halo
-        STORE_HALO();
-      }
+      __syncthreads();   // every wave has finished reading this weight stage (and, on the last tap row, the halo)
+      STORE_W();
+      if (halo_next) STORE_HALO();
       __syncthreads();
-      cur ^= 1;
     }
   }
 #undef LOAD_HALO
@@ -171,50 +178,53 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #undef STORE_W
 
   // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick) ----
-  float s1[2], s2[2], bv[2];
+  float s1[4], s2[4], bv[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < 4; ++j) {
     s1[j] = 0.f;
     s2[j] = 0.f;
-    bv[j] = p.bias ? p.bias[n0 + wn * 32 + j * 16 + lr] : 0.f;
+    bv[j] = p.bias ? p.bias[n0 + j * 16 + lr] : 0.f;
   }
 #pragma unroll
-  for (int fm = 0; fm < 8; ++fm) {
+  for (int fm = 0; fm < 4; ++fm) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int v = wm * 128 + fm * 16 + lg * 4 + r;
+      const int v = wid * 64 + fm * 16 + lg * 4 + r;
       const int64_t row = (((int64_t)n * p.D + d0 + (v >> 6)) * p.H + h0 + ((v >> 3) & 7)) * p.W + w0 + (v & 7);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < 4; ++j) {
         const float val = acc[fm][j][r] + bv[j];
-        p.y[row * p.Nc + n0 + wn * 32 + j * 16 + lr] = (bf16)val;
+        p.y[row * p.Nc + n0 + j * 16 + lr] = (bf16)val;
         s1[j] += val;
         s2[j] += val * val;
       }
     }
   }
   if (p.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][16][2]; the loop ended with a barrier
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][64 ch][2]; the loop ended with a barrier
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < 4; ++j) {
       float a = s1[j], c2 = s2[j];
       a += __shfl_xor(a, 16, 64);
       c2 += __shfl_xor(c2, 16, 64);
       a += __shfl_xor(a, 32, 64);
       c2 += __shfl_xor(c2, 32, 64);
       if (lg == 0) {
-        red[((wid * 2 + j) * 16 + lr) * 2 + 0] = a;
-        red[((wid * 2 + j) * 16 + lr) * 2 + 1] = c2;
+        red[(wid * 64 + j * 16 + lr) * 2 + 0] = a;
+        red[(wid * 64 + j * 16 + lr) * 2 + 1] = c2;
       }
     }
     __syncthreads();
     if (tid < BN) {
-      const int wn_ = tid >> 5, j = (tid >> 4) & 1, l = tid & 15;
-      const float* r0 = red + (((0 * 2 + wn_) * 2 + j) * 16 + l) * 2;
-      const float* r1 = red + (((1 * 2 + wn_) * 2 + j) * 16 + l) * 2;
+      float a = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a += red[(q * 64 + tid) * 2 + 0];
+        c2 += red[(q * 64 + tid) * 2 + 1];
+      }
       float* o = p.stats + ((int64_t)blockIdx.x * p.Nc + n0 + tid) * 2;
-      o[0] = r0[0] + r1[0];
-      o[1] = r0[1] + r1[1];
+      o[0] = a;
+      o[1] = c2;
     }
   }
 }
@@ -231,7 +241,7 @@ int64_t pcrl_brick_conv_rows(int N, int D, int H, int W) { return (int64_t)N * (
 int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                            int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
   static bool attr_set = false;
-  const size_t lds = HALO_BYTES + 2 * WT_BYTES;
+  const size_t lds = HALO_BYTES + WT_BYTES;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
