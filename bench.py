@@ -141,12 +141,18 @@ def main():
     prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_wgrad"}, keyfn)
     barrier()
     L.profiler = prof
+    ms0 = torch.cuda.memory_stats(dev)
+    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_marks[0].record()
+    for i in range(args.steps):
         out = train_step(model, opt, batch, 0, crit, cosine, guard=False)
+        step_marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     L.profiler = None
+    ms1 = torch.cuda.memory_stats(dev)
+    per_step = [round(step_marks[i].elapsed_time(step_marks[i + 1]), 1) for i in range(args.steps)]
     loss = float(out[0])
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -175,6 +181,10 @@ def main():
                      "avg_launch_ms": round(ms / n, 4), "launches": n, "traffic": None},
         "step_mfma_frac": round(FLOP_PER_CROP * args.b * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4),
         "kernels": detail, "final_loss": round(loss, 5),
+        "diag": {"gpu_ms_per_step": per_step,
+                 "device_mallocs_in_timed_region": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+                 "alloc_retries": ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
+                 "reserved_GB": round(ms1.get("reserved_bytes.all.peak", 0) / 2**30, 1)},
     }
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()

@@ -87,8 +87,12 @@ class UpStageFn(Function):
             m._count_batch()
         mod._count_batch_heads()
         ctx.mod, ctx.dt = mod, dt
-        ctx.x, ctx.sv0, ctx.sv1, ctx.svd, ctx.a1 = x, sv0, sv1, svd, a1
-        ctx.heads = (g, x_pro, m_pro, r_pro, h0, h1, m_h, r_h)
+        svd.x = None   # = a1, an OUTPUT of this Function: re-attached from saved_tensors in backward (see below)
+        ctx.x, ctx.sv0, ctx.sv1, ctx.svd = x, sv0, sv1, svd
+        # OUTPUTS needed in backward go through save_for_backward: stashing an output on ctx directly makes a reference
+        # cycle (output -> grad_fn -> ctx -> output) that only the cyclic GC frees -- tens of GB of activations linger.
+        ctx.save_for_backward(a1, x_pro)
+        ctx.heads = (g, m_pro, r_pro, h0, h1, m_h, r_h)   # intermediates (no grad_fn): safe on ctx
         ctx.params = (up_w, w0, g0, w1, g1, bn_g, p0_w, p1_g, p3_w, dw_, dg_)
         ctx.set_materialize_grads(False)
         return a1, x_pro, x_pre, x_mask
@@ -100,7 +104,9 @@ class UpStageFn(Function):
             return (None,) * n_in
         mod, dt = ctx.mod, ctx.dt
         up_w, w0, g0, w1, g1, bn_g, p0_w, p1_g, p3_w, dsw, dsg = ctx.params
-        g, x_pro, m_pro, r_pro, h0, h1, m_h, r_h = ctx.heads
+        a1, x_pro = ctx.saved_tensors
+        ctx.svd.x = a1
+        g, m_pro, r_pro, h0, h1, m_h, r_h = ctx.heads
         l0, l1, ld = mod.ops[0], mod.ops[1], mod.deep_supervision_head
         grads = [None] * n_in
 
@@ -117,7 +123,7 @@ class UpStageFn(Function):
                 grads[13], grads[14], grads[15], grads[16], grads[17], grads[18] = g_p0w, g_p0b, g_p1g, g_p1b, g_p3w, g_p3b
             d_g, g_bng, g_bnb = ops.bn1d_backward(d_xpro, g, x_pro, bn_g, m_pro, r_pro, relu=False)
             grads[11], grads[12] = g_bng, g_bnb
-            d_a1 = ops.gap_backward(d_g, ctx.a1, d_a1, dt)
+            d_a1 = ops.gap_backward(d_g, a1, d_a1, dt)
         # deep-supervision head (pcrlv2_model_3d.py:60,71)
         if d_mask is not None:
             dx_ds, g_dw, g_db, g_dg, g_dbe = ops.luconv_backward(ctx.svd, d_mask, dsw, dsg, ld._packed, dt, need_dx=True, dx_add=d_a1)
@@ -131,6 +137,7 @@ class UpStageFn(Function):
         # ---- up_conv ----
         dx, g_upw, g_upb = ops.convt_backward(ctx.x, d_up, up_w, mod._packed_up, dt, need_dx=ctx.needs_input_grad[0])
         grads[0], grads[1], grads[2] = dx, g_upw, g_upb
+        ctx.svd.x = None
         return tuple(grads)
 
 
@@ -142,7 +149,8 @@ class OutFn(Function):
         dt = mod.compute_dtype
         x = ops.to_act(x, dt)
         out = ops.conv1x1_to1_forward(x, w, b, dt)
-        ctx.x, ctx.out, ctx.w, ctx.dt = x, out, w, dt
+        ctx.x, ctx.w, ctx.dt = x, w, dt
+        ctx.save_for_backward(out)   # an output: never stash it on ctx directly (reference cycle)
         ctx.set_materialize_grads(False)
         return out
 
@@ -150,7 +158,7 @@ class OutFn(Function):
     def backward(ctx, dout):
         if dout is None:
             return None, None, None, None
-        dx, dw, db = ops.conv1x1_to1_backward(ctx.x, ctx.out, dout, ctx.w, ctx.dt, need_dx=ctx.needs_input_grad[0])
+        dx, dw, db = ops.conv1x1_to1_backward(ctx.x, ctx.saved_tensors[0], dout, ctx.w, ctx.dt, need_dx=ctx.needs_input_grad[0])
         return dx, dw, db, None
 
 
