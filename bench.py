@@ -139,6 +139,10 @@ def main():
         train_step(model, opt, batch, 0, crit, cosine, guard=False)
     L = _lib.lib()
     prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_wgrad"}, keyfn)
+    import gc
+    gc.collect()
+    if os.environ.get("PCRL_BENCH_NOGC", "0") == "1":
+        gc.disable()
     barrier()
     L.profiler = prof
     ms0 = torch.cuda.memory_stats(dev)

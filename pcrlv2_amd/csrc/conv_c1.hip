@@ -192,6 +192,48 @@ __global__ void __launch_bounds__(256) to1_dgrad_kernel(const float* __restrict_
   }
 }
 
+// wt[t][c] = w_ref[c][t] (t < 27), zero rows 27..31: the B^T operand of the pointwise product.
+template <typename T>
+__global__ void __launch_bounds__(256) pack_to1_kernel(const float* __restrict__ w_ref, T* __restrict__ wt, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 32 * C) return;
+  const int t = i / C, c = i % C;
+  wt[i] = from_f<T>(t < 27 ? w_ref[c * 27 + t] : 0.f);
+}
+
+// y[m] = bias + sum_t z[t][m + delta_t] over the taps whose neighbour lies inside the volume; z is plane-major, so every
+// tap is one coalesced read.  1024 voxels per block = one BatchNorm partial row.
+__global__ void __launch_bounds__(256) shift_sum27_kernel(const float* __restrict__ z, const float* __restrict__ bias,
+                                                          float* __restrict__ y, float* __restrict__ stats, Dims g, int64_t M) {
+  __shared__ float red[4];
+  const float b0 = bias ? bias[0] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int64_t m = (int64_t)blockIdx.x * TO1_VOX + it * 256 + threadIdx.x;
+    if (m < M) {
+      int n, d, h, w;
+      decode_voxel(m, g, n, d, h, w);
+      const uint32_t mask = tap_mask27(d, h, w, g);
+      float acc = b0;
+#pragma unroll
+      for (int t = 0; t < 27; ++t)
+        if ((mask >> t) & 1u) acc += z[(int64_t)t * M + m + tap_delta27(t, g)];
+      y[m] = acc;
+      s1 += acc;
+      s2 += acc * acc;
+    }
+  }
+  if (stats) {
+    const float a = block_sum_256(s1, red);
+    const float c = block_sum_256(s2, red);
+    if (threadIdx.x == 0) {
+      stats[(int64_t)blockIdx.x * 2 + 0] = a;
+      stats[(int64_t)blockIdx.x * 2 + 1] = c;
+    }
+  }
+}
+
 int pow2_floor(int v) {
   int p = 1;
   while (p * 2 <= v) p *= 2;
@@ -225,12 +267,33 @@ static int to1_check(const char* what, int C, int taps, int dtype) {
   return 0;
 }
 
+int pcrl_pointwise_planes_launch(const void* x, const void* wt, float* z, int64_t M, int C, int dtype, hipStream_t stream);
+
+extern "C" size_t pcrl_conv3d_to1_fwd_ws_bytes(int N, int D, int H, int W, int C, int taps) {
+  if (taps != 27 || C % 32 != 0) return 0;
+  return (size_t)32 * C * 4 + (size_t)32 * N * D * H * W * sizeof(float);
+}
+
 extern "C" int pcrl_conv3d_to1_fwd(const void* x, const float* w_ref, const float* bias, float* y, float* stats_partial,
-                                   int N, int D, int H, int W, int C, int taps, int dtype, pcrl_stream_t stream) {
+                                   void* ws, size_t ws_bytes, int N, int D, int H, int W, int C, int taps, int dtype,
+                                   pcrl_stream_t stream) {
   if (int e = to1_check("conv3d_to1_fwd", C, taps, dtype)) return e;
   PCRL_REQUIRE(x && w_ref && y, "conv3d_to1_fwd: null pointer");
   const Dims g{N, D, H, W};
   const int64_t M = (int64_t)N * D * H * W;
+  if (taps == 27 && C % 32 == 0 && M % 4 == 0 && ws && ws_bytes >= pcrl_conv3d_to1_fwd_ws_bytes(N, D, H, W, C, taps)) {
+    // Two passes instead of a 27-fold gather of x through L2: (1) pointwise MFMA product z[t][m] = sum_c x[m][c] w[c][t]
+    // (x is read ONCE), (2) shifted sum of the 27 float32 planes.
+    char* wt = (char*)ws;
+    float* z = (float*)(wt + (size_t)32 * C * 4);
+    if (dtype == PCRL_BF16) hipLaunchKernelGGL(pack_to1_kernel<bf16>, dim3((32 * C + 255) / 256), dim3(256), 0, as_stream(stream), w_ref, (bf16*)wt, C);
+    else hipLaunchKernelGGL(pack_to1_kernel<float>, dim3((32 * C + 255) / 256), dim3(256), 0, as_stream(stream), w_ref, (float*)wt, C);
+    if (int e = pcrl_check_launch("pack_to1")) return e;
+    if (int e = pcrl_pointwise_planes_launch(x, wt, z, M, C, dtype, as_stream(stream))) return e;
+    hipLaunchKernelGGL(shift_sum27_kernel, dim3((unsigned)((M + TO1_VOX - 1) / TO1_VOX)), dim3(256), 0, as_stream(stream),
+                       (const float*)z, bias, y, stats_partial, g, M);
+    return pcrl_check_launch("shift_sum27");
+  }
   const unsigned blocks = (unsigned)((M + TO1_VOX - 1) / TO1_VOX);
   const size_t lds = (size_t)taps * C * sizeof(float);
   const int vec = dtype == PCRL_BF16 ? 8 : 4;

@@ -80,7 +80,10 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int BN, int GEOM>
+// PLANES: epilogue variant for the 1-output-channel convolutions (conv_c1.hip): the GEMM columns are the 27 taps of a
+// pointwise product z[t][m] = sum_c x[m][c] w[c][t]; the tile is written as float32, PLANE-major (z[col * M + m]), so the
+// shifted-sum pass that follows reads every plane contiguously.  No bias, no statistics.
+template <typename T, int BN, int GEOM, bool PLANES = false>
 __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   constexpr int BM = PCRL_CONV_BM;
   using TL = Tile<T>;
@@ -223,6 +226,26 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #undef IGEMM_LOAD
 #undef IGEMM_STORE
 
+  if (PLANES) {
+    float* __restrict__ Z = reinterpret_cast<float*>(p.y);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int64_t m = m0 + wm * 64 + i * 16 + lg * 4;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * (BN / 2) + j * 16 + lr;
+        float* dst = Z + (int64_t)col * p.M + m;
+        if (m + 3 < p.M) {
+          *reinterpret_cast<f32x4*>(dst) = acc[i][j];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (m + r < p.M) dst[r] = acc[i][j][r];
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: bias, store, BN statistics ----
   T* __restrict__ Y = reinterpret_cast<T*>(p.y);
   float s1[FN], s2[FN], bv[FN];
@@ -350,4 +373,20 @@ extern "C" int pcrl_convt3d_k2s2_dgrad(const void* dy, const void* wp_dgrad, voi
   // rows = input voxels, K per tap = Co (channels of dy), output channels = Ci
   IgemmParams p{dy, wp_dgrad, nullptr, dx, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Co, Ci, 8};
   return dispatch<GEOM_UP2_DGRAD>(p, 1, dtype, as_stream(stream));
+}
+
+// Pointwise product for the C -> 1 convolutions (conv_c1.hip): z[t][m] = sum_c x[m][c] * wt[t][c], t < 32 (27 taps + zero
+// padding), float32 plane-major output.  wt: [32][C] in `dtype`.  C % 32 == 0.
+int pcrl_pointwise_planes_launch(const void* x, const void* wt, float* z, int64_t M, int C, int dtype, hipStream_t stream) {
+  IgemmParams p{x, wt, nullptr, z, nullptr, Dims{1, 1, 1, 1}, M, C, 32, 1};
+  p.g = Dims{(int)1, 1, 1, (int)(M > 0x7fffffff ? 0x7fffffff : M)};
+  const unsigned gx = (unsigned)((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
+  if (dtype == PCRL_BF16) {
+    const size_t lds = 2 * (size_t)(PCRL_CONV_BM + 32) * Tile<bf16>::ROWB;
+    hipLaunchKernelGGL((igemm_kernel<bf16, 32, GEOM_UP2_FWD, true>), dim3(gx, 1, 1), dim3(256), lds, stream, p);
+  } else {
+    const size_t lds = 2 * (size_t)(PCRL_CONV_BM + 32) * Tile<float>::ROWB;
+    hipLaunchKernelGGL((igemm_kernel<float, 32, GEOM_UP2_FWD, true>), dim3(gx, 1, 1), dim3(256), lds, stream, p);
+  }
+  return pcrl_check_launch("pointwise_planes");
 }

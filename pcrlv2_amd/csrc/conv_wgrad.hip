@@ -228,19 +228,19 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 }
 
 // Second pass: out_ref[i][j][t] = sum_z ws[z][t][i][j] for j < Cv_out (padding columns dropped), fixed order.
+// One thread per OUTPUT element (coalesced 4-byte writes; the reads of a wave cover `taps` planes of contiguous ij runs).
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                            int splits, int taps, int Cu, int Cv, int Cv_out) {
   const int64_t per = (int64_t)Cu * Cv;
-  const int64_t total = per * taps;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    // idx enumerates [t][i][j] (coalesced reads); write transposed
-    const int t = (int)(idx / per);
-    const int64_t ij = idx % per;
-    const int i = (int)(ij / Cv), j = (int)(ij % Cv);
-    if (j >= Cv_out) continue;
+  const int64_t total = (int64_t)Cu * Cv_out * taps;
+  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+    const int t = (int)(o % taps);
+    const int64_t ij_out = o / taps;
+    const int i = (int)(ij_out / Cv_out), j = (int)(ij_out % Cv_out);
+    const float* src = ws + (int64_t)t * per + (int64_t)i * Cv + j;
     double s = 0.0;
-    for (int z = 0; z < splits; ++z) s += (double)ws[((int64_t)z * taps + t) * per + ij];
-    out[((int64_t)i * Cv_out + j) * taps + t] = (float)s;
+    for (int z = 0; z < splits; ++z) s += (double)src[(int64_t)z * taps * per];
+    out[o] = (float)s;
   }
 }
 

@@ -7,53 +7,61 @@
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// BatchNorm1d (training mode) on [rows][C]: one thread per channel, fp64 statistics.
+// BatchNorm1d (training mode) on [rows][C]: one WAVE per channel (lanes stride over the rows, fp64 wave reductions).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bn1d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* running_mean, float* running_var,
                                                        float momentum, float eps, float* mean, float* rstd, int rows, int C, int relu) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   double s1 = 0.0;
-  for (int r = 0; r < rows; ++r) s1 += (double)x[(int64_t)r * C + c];
-  const double mu = s1 / rows;
+  for (int r = lane; r < rows; r += 64) s1 += (double)x[(int64_t)r * C + c];
+  const double mu = wave_sum(s1) / rows;
   double s2 = 0.0;
-  for (int r = 0; r < rows; ++r) {
+  for (int r = lane; r < rows; r += 64) {
     const double d = (double)x[(int64_t)r * C + c] - mu;
     s2 += d * d;
   }
-  const double var = s2 / rows;
+  const double var = wave_sum(s2) / rows;
   const double rs = 1.0 / sqrt(var + (double)eps);
-  mean[c] = (float)mu;
-  rstd[c] = (float)rs;
   const float g = gamma[c], b = beta[c];
-  for (int r = 0; r < rows; ++r) {
+  for (int r = lane; r < rows; r += 64) {
     float v = (float)(((double)x[(int64_t)r * C + c] - mu) * rs) * g + b;
     if (relu && v < 0.f) v = 0.f;
     y[(int64_t)r * C + c] = v;
   }
-  if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
-  if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * (rows > 1 ? var * rows / (rows - 1.0) : var));
+  if (lane == 0) {
+    mean[c] = (float)mu;
+    rstd[c] = (float)rs;
+    if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mu);
+    if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * (rows > 1 ? var * rows / (rows - 1.0) : var));
+  }
 }
 
 __global__ void __launch_bounds__(256) bn1d_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ y,
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, float* __restrict__ dx, float* dgamma, float* dbeta,
                                                        int rows, int C, int relu) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
   const double mu = mean[c], rs = rstd[c];
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < rows; ++r) {
+  for (int r = lane; r < rows; r += 64) {
     const int64_t i = (int64_t)r * C + c;
     const double dz = (relu && y[i] <= 0.f) ? 0.0 : (double)dy[i];
     s1 += dz;
     s2 += dz * ((double)x[i] - mu) * rs;
   }
-  dbeta[c] = (float)s1;
-  dgamma[c] = (float)s2;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    dbeta[c] = (float)s1;
+    dgamma[c] = (float)s2;
+  }
   const double g1 = (double)gamma[c] * rs;
-  for (int r = 0; r < rows; ++r) {
+  for (int r = lane; r < rows; r += 64) {
     const int64_t i = (int64_t)r * C + c;
     const double dz = (relu && y[i] <= 0.f) ? 0.0 : (double)dy[i];
     const double xh = ((double)x[i] - mu) * rs;
@@ -62,43 +70,52 @@ __global__ void __launch_bounds__(256) bn1d_bwd_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// Linear: y = x W^T + b.  One wave per output element row-block would be overkill: rows <= a few hundred,
-// C <= 512.  One thread per output, K-loop over contiguous weights rows.
+// Linear layers of the heads: one small LDS-tiled SGEMM, C[m][n] = sum_k A(m,k) * B(k,n) (+ bias[n]), operands addressed
+// through (row, col) strides so the three products of a Linear (y = x W^T, dx = dy W, dW = dy^T x) share the kernel.
+// 16x16 threads, 32x32 tile, K chunks of 16.  Sizes here: M, N, K <= 512.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
-                                                         float* __restrict__ y, int rows, int Cin, int Cout) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * Cout) return;
-  const int r = i / Cout, o = i % Cout;
-  const float* xr = x + (int64_t)r * Cin;
-  const float* wr = w + (int64_t)o * Cin;
-  float acc = 0.f;
-  for (int k = 0; k < Cin; ++k) acc = fmaf(xr[k], wr[k], acc);
-  y[i] = acc + (b ? b[o] : 0.f);
-}
-__global__ void __launch_bounds__(256) linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
-                                                        int rows, int Cin, int Cout) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * Cin) return;
-  const int r = i / Cin, k = i % Cin;
-  float acc = 0.f;
-  for (int o = 0; o < Cout; ++o) acc = fmaf(dy[(int64_t)r * Cout + o], w[(int64_t)o * Cin + k], acc);
-  dx[i] = acc;
-}
-__global__ void __launch_bounds__(256) linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
-                                                        float* __restrict__ db, int rows, int Cin, int Cout) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < Cout * Cin) {
-    const int o = i / Cin, k = i % Cin;
-    float acc = 0.f;
-    for (int r = 0; r < rows; ++r) acc = fmaf(dy[(int64_t)r * Cout + o], x[(int64_t)r * Cin + k], acc);
-    dw[i] = acc;
+__global__ void __launch_bounds__(256) sgemm_small_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
+                                                          const float* __restrict__ B, int64_t sbk, int64_t sbn,
+                                                          const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K) {
+  __shared__ float As[16][33], Bs[16][33];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {   // 256 threads load 16x32 of A and of B, two elements each
+      const int idx = threadIdx.x + 256 * h, kk = idx >> 5, mm = idx & 31;
+      const int m = m0 + mm, n = n0 + mm, k = k0 + kk;
+      As[kk][mm] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
+      Bs[kk][mm] = (n < N && k < K) ? B[k * sbk + n * sbn] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float a0 = As[kk][ty], a1 = As[kk][ty + 16], b0 = Bs[kk][tx], b1 = Bs[kk][tx + 16];
+      acc[0][0] = fmaf(a0, b0, acc[0][0]);
+      acc[0][1] = fmaf(a0, b1, acc[0][1]);
+      acc[1][0] = fmaf(a1, b0, acc[1][0]);
+      acc[1][1] = fmaf(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
   }
-  if (db && i < Cout) {
-    float acc = 0.f;
-    for (int r = 0; r < rows; ++r) acc += dy[(int64_t)r * Cout + i];
-    db[i] = acc;
-  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+      if (m < M && n < N) Cm[(int64_t)m * N + n] = acc[i][j] + (bias ? bias[n] : 0.f);
+    }
+}
+__global__ void __launch_bounds__(256) colsum_small_kernel(const float* __restrict__ v, float* __restrict__ out, int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = lane; r < rows; r += 64) s += v[(int64_t)r * C + c];
+  s = wave_sum(s);
+  if (lane == 0) out[c] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -337,28 +354,39 @@ extern "C" int pcrl_bn1d_fwd(const float* x, float* y, const float* gamma, const
                              float momentum, float eps, float* mean, float* rstd, int rows, int C, int relu, pcrl_stream_t stream) {
   PCRL_REQUIRE(x && y && gamma && beta && mean && rstd, "bn1d_fwd: null pointer");
   PCRL_REQUIRE(rows > 1, "bn1d_fwd: Expected more than 1 value per channel when training, got rows=%d", rows);
-  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), x, y, gamma, beta, running_mean, running_var,
+  hipLaunchKernelGGL(bn1d_fwd_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), x, y, gamma, beta, running_mean, running_var,
                      momentum, eps, mean, rstd, rows, C, relu);
   return pcrl_check_launch("bn1d_fwd");
 }
 extern "C" int pcrl_bn1d_bwd(const float* dy, const float* x, const float* y, const float* gamma, const float* mean, const float* rstd,
                              float* dx, float* dgamma, float* dbeta, int rows, int C, int relu, pcrl_stream_t stream) {
   PCRL_REQUIRE(dy && x && y && gamma && mean && rstd && dx && dgamma && dbeta, "bn1d_bwd: null pointer");
-  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), dy, x, y, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, relu);
+  hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), dy, x, y, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, relu);
   return pcrl_check_launch("bn1d_bwd");
 }
 extern "C" int pcrl_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int Cin, int Cout, pcrl_stream_t stream) {
   PCRL_REQUIRE(x && w && y && rows > 0 && Cin > 0 && Cout > 0, "linear_fwd: bad arguments");
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3((rows * Cout + 255) / 256), dim3(256), 0, as_stream(stream), x, w, b, y, rows, Cin, Cout);
+  // y[r][o] = sum_k x[r][k] * w[o][k] + b[o]
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3((Cout + 31) / 32, (rows + 31) / 32), dim3(256), 0, as_stream(stream),
+                     x, (int64_t)Cin, (int64_t)1, w, (int64_t)1, (int64_t)Cin, b, y, rows, Cout, Cin);
   return pcrl_check_launch("linear_fwd");
 }
 extern "C" int pcrl_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
                                int rows, int Cin, int Cout, pcrl_stream_t stream) {
   PCRL_REQUIRE(dy && x && w && dx && dw, "linear_bwd: null pointer");
-  hipLaunchKernelGGL(linear_dx_kernel, dim3((rows * Cin + 255) / 256), dim3(256), 0, as_stream(stream), dy, w, dx, rows, Cin, Cout);
+  // dx[r][k] = sum_o dy[r][o] * w[o][k]
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3((Cin + 31) / 32, (rows + 31) / 32), dim3(256), 0, as_stream(stream),
+                     dy, (int64_t)Cout, (int64_t)1, w, (int64_t)Cin, (int64_t)1, (const float*)nullptr, dx, rows, Cin, Cout);
   if (int e = pcrl_check_launch("linear_dx")) return e;
-  hipLaunchKernelGGL(linear_dw_kernel, dim3((Cout * Cin + 255) / 256), dim3(256), 0, as_stream(stream), dy, x, dw, db, rows, Cin, Cout);
-  return pcrl_check_launch("linear_dw");
+  // dw[o][k] = sum_r dy[r][o] * x[r][k]
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32), dim3(256), 0, as_stream(stream),
+                     dy, (int64_t)1, (int64_t)Cout, x, (int64_t)Cin, (int64_t)1, (const float*)nullptr, dw, Cout, Cin, rows);
+  if (int e = pcrl_check_launch("linear_dw")) return e;
+  if (db) {
+    hipLaunchKernelGGL(colsum_small_kernel, dim3((Cout + 3) / 4), dim3(256), 0, as_stream(stream), dy, db, rows, Cout);
+    return pcrl_check_launch("linear_db");
+  }
+  return PCRL_OK;
 }
 
 extern "C" int pcrl_upsample_trilinear_fwd(const float* x, float* y, int N, int D, int H, int W, int scale, pcrl_stream_t stream) {

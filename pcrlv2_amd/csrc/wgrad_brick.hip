@@ -179,7 +179,7 @@ struct BrickSplit {
 };
 BrickSplit plan(int nbricks, int Cu, int Cv) {
   const int tiles = (Cu / 64) * ((Cv + 63) / 64) * 3;
-  int splits = 1024 / tiles;
+  int splits = 768 / tiles;   // ~3 blocks per CU in flight; fewer splits = smaller partial slabs for the second pass
   if (splits < 1) splits = 1;
   if (splits > nbricks / 4) splits = nbricks / 4;   // at least 4 bricks per block
   if (splits < 1) splits = 1;

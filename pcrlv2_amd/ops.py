@@ -148,7 +148,9 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         rows = (M + 1023) // 1024
         y = _f32(M, dev)
         partial = _f32(rows * 2, dev)
-        L.call("pcrl_conv3d_to1_fwd", x, conv_w.detach(), conv_b.detach(), y, partial, N, D, H, W, C, 27, dtype_code(dtype), s)
+        nb = L.call("pcrl_conv3d_to1_fwd_ws_bytes", N, D, H, W, C, 27)
+        L.call("pcrl_conv3d_to1_fwd", x, conv_w.detach(), conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb,
+               N, D, H, W, C, 27, dtype_code(dtype), s)
         mean, rstd, scale, shift = bn_finalize(partial, rows, 1, M, gamma.detach(), beta.detach(), running_mean, running_var)
         a = bn_act_apply(y, scale, shift, M, 1, act, torch.float32).view(N, 1, D, H, W)
         sv.kind = "to1"
@@ -350,7 +352,7 @@ def conv1x1_to1_forward(x, w, b, dtype):
     N, D, H, W, C = dims(x)
     M = N * D * H * W
     pre = _f32(M, x.device)
-    L.call("pcrl_conv3d_to1_fwd", x, w.detach(), b.detach(), pre, None, N, D, H, W, C, 1, dtype_code(dtype), s)
+    L.call("pcrl_conv3d_to1_fwd", x, w.detach(), b.detach(), pre, None, None, 0, N, D, H, W, C, 1, dtype_code(dtype), s)
     out = torch.empty((N, 1, D, H, W), dtype=torch.float32, device=x.device)
     L.call("pcrl_sigmoid_fwd", pre, out, M, s)
     return out

@@ -170,10 +170,22 @@ def test_conv_to_one_channel(C, taps, dt):
     y = torch.zeros(M, dtype=torch.float32, device=DEV)
     part = torch.zeros(((M + 1023) // 1024) * 2, dtype=torch.float32, device=DEV)
     wdev, bdev = w.float().to(DEV), b.float().to(DEV)
-    L.call("pcrl_conv3d_to1_fwd", xa, wdev, bdev, y, part, N, D, H, W, C, taps, dtype_code(dt), s)
-    check(y.view(N, 1, D, H, W), ref, dt, "to1 fwd", out_rounded=False)
+    # direct gather kernel (no workspace) and the two-pass pointwise-GEMM + shifted-sum path (27 taps, with workspace)
+    L.call("pcrl_conv3d_to1_fwd", xa, wdev, bdev, y, part, None, 0, N, D, H, W, C, taps, dtype_code(dt), s)
+    check(y.view(N, 1, D, H, W), ref, dt, "to1 fwd (gather)", out_rounded=False)
     st = back(part).view(-1, 2).sum(0)
     assert abs(st[0].item() - ref.sum().item()) <= 1e-4 * max(1.0, ref.abs().sum().item())
+    nbf = L.call("pcrl_conv3d_to1_fwd_ws_bytes", N, D, H, W, C, taps)
+    if nbf:
+        y.zero_()
+        part.zero_()
+        L.call("pcrl_conv3d_to1_fwd", xa, wdev, bdev, y, part, ops.workspace(nbf, xa.device), nbf, N, D, H, W, C, taps, dtype_code(dt), s)
+        # bf16: the tap weights are MFMA operands here (rounded to bf16)
+        ref2 = F.conv3d(xq.detach(), q(w, dt), b, padding=k // 2) if dt == torch.bfloat16 else ref
+        check(y.view(N, 1, D, H, W), ref2, dt, "to1 fwd (pointwise GEMM + shifted sum)", out_rounded=False)
+        st = back(part).view(-1, 2).sum(0)
+        assert abs(st[0].item() - ref2.sum().item()) <= 1e-4 * max(1.0, ref2.abs().sum().item())
+        assert abs(st[1].item() - (ref2 * ref2).sum().item()) <= 1e-4 * max(1.0, (ref2 * ref2).sum().item())
     dy = rnd(N, 1, D, H, W, seed=4)
     ref.backward(dy)
     gx = xq.grad.clone()
