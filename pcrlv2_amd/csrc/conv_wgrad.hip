@@ -227,21 +227,44 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       }
 }
 
-// Second pass: out_ref[i][j][t] = sum_z ws[z][t][i][j] for j < Cv_out (padding columns dropped), fixed order.
-// One thread per OUTPUT element (coalesced 4-byte writes; the reads of a wave cover `taps` planes of contiguous ij runs).
+// Second pass: out_ref[i][j][t] = sum_z ws[z][t][i][j] for j < Cv_out (padding columns dropped), fixed order over z.
+// Block = 32 consecutive (i,j) x all taps: a thread sums a few (t, ij) pairs over z with 128-byte coalesced reads, the
+// [t][ij] -> [ij][t] transposition goes through LDS, the stores are one contiguous run.  Requires Cv_out % 32 == 0 or
+// a tail guard (handled); taps <= 27.
+constexpr int RED_IJ = 16;
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                            int splits, int taps, int Cu, int Cv, int Cv_out) {
+  __shared__ float tile[RED_IJ * 27];
   const int64_t per = (int64_t)Cu * Cv;
-  const int64_t total = (int64_t)Cu * Cv_out * taps;
-  for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
-    const int t = (int)(o % taps);
-    const int64_t ij_out = o / taps;
-    const int i = (int)(ij_out / Cv_out), j = (int)(ij_out % Cv_out);
-    const float* src = ws + (int64_t)t * per + (int64_t)i * Cv + j;
-    double s = 0.0;
-    for (int z = 0; z < splits; ++z) s += (double)src[(int64_t)z * taps * per];
-    out[o] = (float)s;
+  const int64_t n_out = (int64_t)Cu * Cv_out;
+  const int64_t ij0 = (int64_t)blockIdx.x * RED_IJ;
+  const int npairs = taps * RED_IJ;
+  for (int q = threadIdx.x; q < npairs; q += 256) {
+    const int t = q / RED_IJ, l = q % RED_IJ;
+    const int64_t ij = ij0 + l;
+    float s = 0.f;
+    if (ij < n_out) {
+      const int i = (int)(ij / Cv_out), j = (int)(ij % Cv_out);
+      const float* src = ws + (int64_t)t * per + (int64_t)i * Cv + j;
+      const int64_t zs = (int64_t)taps * per;
+      // four independent partial sums (a fixed tree, so still deterministic) keep 4+ loads in flight per thread
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int z = 0;
+      for (; z + 3 < splits; z += 4) {
+        a0 += (double)src[(z + 0) * zs];
+        a1 += (double)src[(z + 1) * zs];
+        a2 += (double)src[(z + 2) * zs];
+        a3 += (double)src[(z + 3) * zs];
+      }
+      for (; z < splits; ++z) a0 += (double)src[z * zs];
+      s = (float)((a0 + a1) + (a2 + a3));
+    }
+    tile[l * taps + t] = s;
   }
+  __syncthreads();
+  const int64_t base = ij0 * taps, lim = n_out * taps;
+  for (int k = threadIdx.x; k < npairs; k += 256)
+    if (base + k < lim) out[base + k] = tile[k];
 }
 
 // im2col of a float32 scalar field for the 1-channel convolutions: out[m][t] = s[m + delta_t] (0 outside the volume),
@@ -330,9 +353,7 @@ int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_b
     return pcrl_fail(PCRL_EINVAL, "wgrad: bad dtype %d", dtype);
   }
   if (int e = pcrl_check_launch("wgrad")) return e;
-  const int64_t total = (int64_t)Cu * Cv * taps;
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 4096) blocks = 4096;
+  const int blocks = (int)(((int64_t)Cu * Cv_out + RED_IJ - 1) / RED_IJ);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, dw_ref, sp.splits, taps, Cu, Cv, Cv_out);
   return pcrl_check_launch("wgrad_reduce");
 }
@@ -369,9 +390,7 @@ extern "C" int pcrl_conv3d_k3_wgrad(const void* x, const void* dy, float* dw_ref
     const size_t need = (size_t)splits * 27 * Co * Ci * sizeof(float);
     if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_k3_wgrad: workspace %zu < %zu", ws_bytes, need);
     if (int e = pcrl_wgrad_brick_launch(x, dy, (float*)ws, N, D, H, W, Ci, Co, as_stream(stream))) return e;
-    const int64_t total = (int64_t)Co * Ci * 27;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
+    const int blocks = (int)(((int64_t)Co * Ci + RED_IJ - 1) / RED_IJ);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)ws, dw_ref, splits, 27, Co, Ci, Ci);
     return pcrl_check_launch("wgrad_reduce");
   }

@@ -127,29 +127,37 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
     WB_LOAD(bn);
     __builtin_amdgcn_sched_barrier(0);
 
+    // 36 steps = 4 K-chunks x 9 taps, fully unrolled and SOFTWARE-PIPELINED: the x fragment of step s+1 (and the dy
+    // fragments of the next K-chunk) are fetched before the MFMAs of step s.  With one wave per SIMD nothing else hides
+    // the LDS latency: the naive order (read, wait, 4 MFMAs) ran the matrix pipe at ~40 % inside this phase.
+    // lane's voxels of K-chunk kc: v = 32*kc + 8*lg + 4*q + jr (q = 0,1 = the two transpose reads);
+    // halo row of voxel (vd, vh, vw) at tap (kh, kw): (vd*XH + vh + kh)*XW + vw + kw.
+#define WB_A(kc_, f_) tr_frag(dys + dy_off(32 * (kc_) + 8 * lg + jr, (f_)*16 + 4 * cq), dys + dy_off(32 * (kc_) + 8 * lg + jr + 4, (f_)*16 + 4 * cq))
+#define WB_XROW(kc_, t_) ((((kc_) >> 1) * XH + ((kc_)&1) * 4 + lg + (t_) / 3) * XW + jr + (t_) % 3)
+#define WB_B(kc_, t_) tr_frag(xs + x_off(WB_XROW(kc_, t_), wid * 16 + 4 * cq), xs + x_off(WB_XROW(kc_, t_) + 4, wid * 16 + 4 * cq))
+    bf16x8 fa[4], fan[4], fb, fbn;
 #pragma unroll
-    for (int kc = 0; kc < 4; ++kc) {
-      // lane's voxels of this K-chunk: v = 32*kc + 8*lg + 4*q + jr   (q = 0,1 = the two transpose reads)
-      const int vrow = 32 * kc + 8 * lg + jr;
-      bf16x8 fa[4];
+    for (int f = 0; f < 4; ++f) fa[f] = WB_A(0, f);
+    fb = WB_B(0, 0);
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
-        fa[f] = tr_frag(dys + dy_off(vrow, f * 16 + 4 * cq), dys + dy_off(vrow + 4, f * 16 + 4 * cq));
-      // halo row of voxel (vd, vh, vw) at tap (kh, kw): (vd*XH + vh + kh)*XW + vw + kw
-      const int vd = kc >> 1, vh = (kc & 1) * 4 + lg;
-      const int xrow0 = (vd * XH + vh) * XW + jr;
+    for (int st = 0; st < 36; ++st) {
+      const int kc = st / 9, t = st % 9;
+      if (st + 1 < 36) fbn = WB_B((st + 1) / 9, (st + 1) % 9);
+      if (t == 5 && kc < 3) {
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh) {
+        for (int f = 0; f < 4; ++f) fan[f] = WB_A(kc + 1, f);
+      }
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int r0 = xrow0 + kh * XW + kw;
-          const bf16x8 fb = tr_frag(xs + x_off(r0, wid * 16 + 4 * cq), xs + x_off(r0 + 4, wid * 16 + 4 * cq));
+      for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f], fb, acc[t][f], 0, 0, 0);
+      fb = fbn;
+      if (t == 8 && kc < 3) {
 #pragma unroll
-          for (int f = 0; f < 4; ++f)
-            acc[kh * 3 + kw][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f], fb, acc[kh * 3 + kw][f], 0, 0, 0);
-        }
+        for (int f = 0; f < 4; ++f) fa[f] = fan[f];
       }
     }
+#undef WB_A
+#undef WB_XROW
+#undef WB_B
 
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();   // all waves have finished reading this brick
@@ -181,7 +189,7 @@ BrickSplit plan(int nbricks, int Cu, int Cv) {
   const int tiles = (Cu / 64) * ((Cv + 63) / 64) * 3;
   int splits = 768 / tiles;   // ~3 blocks per CU in flight; fewer splits = smaller partial slabs for the second pass
   if (splits < 1) splits = 1;
-  if (splits > nbricks / 4) splits = nbricks / 4;   // at least 4 bricks per block
+  if (splits > nbricks / 16) splits = nbricks / 16;   // at least 16 bricks per block (bounds the partial slabs)
   if (splits < 1) splits = 1;
   const int per = (nbricks + splits - 1) / splits;
   splits = (nbricks + per - 1) / per;
