@@ -25,11 +25,10 @@ constexpr int HD = TD + 2, HH = TH + 2, HWU = TW + 2;  // halo extents (used)
 constexpr int HW = 16;                                 // halo row pitch in w: padded 10 -> 16, see hoff_h()
 constexpr int HROWS_USED = HD * HH * HWU;              // 600 rows are loaded
 constexpr int HROWS = HD * HH * HW;                    // 960 rows of LDS
-constexpr int BN = 64;
 constexpr int HPIECES = HROWS_USED * 4;                // 16-byte pieces of one 32-channel halo chunk
 constexpr int HPT = (HPIECES + 255) / 256;             // pieces per thread (10)
 constexpr int HALO_BYTES = HROWS * 64;                 // 60 KiB
-constexpr int WT_BYTES = 3 * BN * 64;                  // one weight stage: 3 taps, 12 KiB
+// one weight stage: 3 taps x BN rows x 64 B (12 KiB for BN = 64)
 
 struct BrickParams {
   const bf16* x;
@@ -56,7 +55,10 @@ __device__ __forceinline__ int hoff_h(int row, int slot) {
   return row * 64 + ((slot ^ (((row >> 2) & 1) << 1)) << 4);
 }
 
+template <int BN>   // output channels per block: 64, or 32 for the Co = 32 data gradient (wave tile 64 voxels x BN)
 __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p) {
+  constexpr int FN = BN / 16;
+  constexpr int WT_BYTES = 3 * BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* wbuf = smem + HALO_BYTES;
@@ -98,14 +100,15 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
     abase[fm] = ((v >> 6) * HH + ((v >> 3) & 7)) * HW + (v & 7);
   }
   // ---- weight staging: 3 pieces per thread (tap kw = 0,1,2 of the current (kd,kh)), row co = tid>>2, slot tid&3 ----
-  const bf16* wrow = p.w + ((int64_t)(n0 + (tid >> 2)) * 27) * K + (tid & 3) * 8;
+  const bool wthread = (tid >> 2) < BN;   // BN = 32: only the first 128 threads stage weights
+  const bf16* wrow = p.w + ((int64_t)(n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8;
   const int wdst = hoff_w(tid >> 2, tid & 3);   // within one tap tile [64][32]
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][FN];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   u32x4 rh[HPT], rw[3];
 
@@ -127,8 +130,10 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   } while (0)
 #define STORE_W()                                                                                         \
   do {                                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                         \
-      *reinterpret_cast<u32x4*>(wbuf + j * (BN * 64) + wdst) = rw[j];                                     \
+    if (wthread) {                                                                                        \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                       \
+        *reinterpret_cast<u32x4*>(wbuf + j * (BN * 64) + wdst) = rw[j];                                   \
+    }                                                                                                     \
   } while (0)
 
   LOAD_HALO(0);
@@ -154,15 +159,15 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const char* wt = wbuf + kw * (BN * 64);
-        bf16x8 fb[4], fa[4];
+        bf16x8 fb[FN], fa[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wt + hoff_w(j * 16 + lr, lg));
+        for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wt + hoff_w(j * 16 + lr, lg));
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) fa[fm] = *reinterpret_cast<const bf16x8*>(halo + hoff_h(abase[fm] + tapoff + kw, lg));
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[fm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[fm], fb[j], acc[fm][j], 0, 0, 0);
+          for (int j = 0; j < FN; ++j) acc[fm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[fm], fb[j], acc[fm][j], 0, 0, 0);
       }
 
       __builtin_amdgcn_sched_barrier(0);
@@ -178,9 +183,9 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #undef STORE_W
 
   // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick) ----
-  float s1[4], s2[4], bv[4];
+  float s1[FN], s2[FN], bv[FN];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < FN; ++j) {
     s1[j] = 0.f;
     s2[j] = 0.f;
     bv[j] = p.bias ? p.bias[n0 + j * 16 + lr] : 0.f;
@@ -192,7 +197,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
       const int v = wid * 64 + fm * 16 + lg * 4 + r;
       const int64_t row = (((int64_t)n * p.D + d0 + (v >> 6)) * p.H + h0 + ((v >> 3) & 7)) * p.W + w0 + (v & 7);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < FN; ++j) {
         const float val = acc[fm][j][r] + bv[j];
         p.y[row * p.Nc + n0 + j * 16 + lr] = (bf16)val;
         s1[j] += val;
@@ -203,7 +208,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   if (p.stats) {
     float* red = reinterpret_cast<float*>(smem);  // [4 waves][64 ch][2]; the loop ended with a barrier
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < FN; ++j) {
       float a = s1[j], c2 = s2[j];
       a += __shfl_xor(a, 16, 64);
       c2 += __shfl_xor(c2, 16, 64);
@@ -233,7 +238,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 
 // ---- internal interface used by conv_igemm.hip's dispatcher -------------------------------------------------------
 bool pcrl_brick_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  return dtype == PCRL_BF16 && D % TD == 0 && H % TH == 0 && W % TW == 0 && Ci % 32 == 0 && Co % BN == 0 &&
+  return dtype == PCRL_BF16 && D % TD == 0 && H % TH == 0 && W % TW == 0 && Ci % 32 == 0 && Co % 32 == 0 &&
          (int64_t)N * D * H * W < (int64_t)1 << 31;
 }
 int64_t pcrl_brick_conv_rows(int N, int D, int H, int W) { return (int64_t)N * (D / TD) * (H / TH) * (W / TW); }
@@ -241,13 +246,14 @@ int64_t pcrl_brick_conv_rows(int N, int D, int H, int W) { return (int64_t)N * (
 int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                            int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
   static bool attr_set = false;
-  const size_t lds = HALO_BYTES + WT_BYTES;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 32 * 64);
     attr_set = true;
   }
   BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co};
-  dim3 grid((unsigned)pcrl_brick_conv_rows(N, D, H, W), (unsigned)(Co / BN));
-  hipLaunchKernelGGL(brick_conv_kernel, grid, dim3(256), lds, stream, p);
+  const unsigned bricks = (unsigned)pcrl_brick_conv_rows(N, D, H, W);
+  if (Co % 64 == 0) hipLaunchKernelGGL(brick_conv_kernel<64>, dim3(bricks, Co / 64), dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
+  else hipLaunchKernelGGL(brick_conv_kernel<32>, dim3(bricks, Co / 32), dim3(256), HALO_BYTES + 3 * 32 * 64, stream, p);
   return pcrl_check_launch("brick_conv");
 }
