@@ -174,6 +174,17 @@ def main():
     n, ms, work = conv[dom]
     achieved = work / (ms * 1e-3) / 1e12
     crops = world * args.b * args.steps / elapsed
+    # HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected separately
+    # with rocprofv3 --pmc and summarised by tools/summarize_profiles.py); null if no summary for this kernel is committed.
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+            d = json.load(open(f))
+            if dom in d:
+                traffic, traffic_src = round(d[dom]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
+    except Exception:
+        pass
     line = {
         "metric": "3D crops/sec (64x64x32, b=32) pretrain step", "value": round(crops, 2), "unit": "crops/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -182,7 +193,8 @@ def main():
                                f"b={args.b}/GPU, fwd+bwd+SGD", "global_batch": world * args.b, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
                      "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
-                     "avg_launch_ms": round(ms / n, 4), "launches": n, "traffic": None},
+                     "avg_launch_ms": round(ms / n, 4), "launches": n, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
+                     "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(work / n)},
         "step_mfma_frac": round(FLOP_PER_CROP * args.b * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4),
         "kernels": detail, "final_loss": round(loss, 5),
         "diag": {"gpu_ms_per_step": per_step,

@@ -63,7 +63,7 @@ class BucketedAllReduce:
 
     def reduce(self):
         """SUM all-reduce of the flat gradient arena, bucket by bucket (last parameters first)."""
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             return
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
@@ -81,38 +81,137 @@ class BucketedAllReduce:
 
 
 class DataParallel:
-    """Ties a FusedSGD optimizer to the process group: parameter broadcast at start, gradient SUM
-    all-reduce + 1/world scaling inside optimizer.step()."""
+    """Ties a FusedSGD-style optimizer to the process group: parameter/buffer broadcast at start; per step a SUM
+    all-reduce of the flat gradient arena with 1/world folded into the SGD kernel.
 
-    def __init__(self, model: torch.nn.Module, optimizer, group=None, bucket_mb: float = 24.0, strict_flags: bool = False):
+    Overlap with backward.  A step runs three forwards (view 1, view 2, local views) that share all parameters, and
+    autograd replays them in reverse creation order: local, view 2, view 1.  A parameter's gradient is therefore FINAL
+    once the stage of the FIRST forward of the step (pass 0) has run its backward.  The stage Functions set
+    `param._pcrl_final = True` in that case (pcrlv2_amd.functions.mark_final); a post-accumulate-grad hook then marks the
+    parameter ready, and as soon as every parameter of a bucket is ready the bucket's gradients are gathered into the flat
+    arena and its all-reduce is launched on the side stream -- while the rest of backward (earlier layers) is still
+    running.  Whatever is not final by then (parameters without a pass-0 gradient, e.g. the unused deep-supervision
+    heads) is swept up in optimizer.step().  `overlap=False` (or PCRL_DDP_OVERLAP=0) does everything in optimizer.step().
+    """
+
+    def __init__(self, model: torch.nn.Module, optimizer, group=None, bucket_mb: float = 24.0, strict_flags: bool = False,
+                 overlap=None, force_collectives: bool = False):
         self.model, self.opt, self.group = model, optimizer, group
         self.strict_flags = strict_flags
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.reducer = BucketedAllReduce(optimizer.flat_g, [p.numel() for p in optimizer._plist], group, bucket_mb)
+        self._active = self.world > 1 or (force_collectives and dist.is_initialized())   # 1-rank groups: test hook only
+        sizes = [p.numel() for p in optimizer._plist]
+        self.reducer = BucketedAllReduce(optimizer.flat_g, sizes, group, bucket_mb)
+        self.overlap = (os.environ.get("PCRL_DDP_OVERLAP", "1") == "1") if overlap is None else overlap
         optimizer.grad_scale = 1.0 / self.world
         optimizer.pre_step = self._pre_step
+        # bucket bookkeeping: which parameters live in which bucket
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        self._bucket_params = []
+        for (b, e) in self.reducer.buckets:
+            self._bucket_params.append([i for i in range(len(sizes)) if offs[i] >= b and offs[i + 1] <= e])
+        self._param_bucket = {}
+        for bi, idxs in enumerate(self._bucket_params):
+            for i in idxs:
+                self._param_bucket[i] = bi
+        self._reset_step()
+        self._hooks = []
+        if self._active and self.overlap:
+            for i, p in enumerate(optimizer._plist):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.broadcast_state()
 
+    # ------------------------------------------------------------------
+    def _reset_step(self):
+        self._ready = [0] * len(self.reducer.buckets)
+        self._launched = [False] * len(self.reducer.buckets)
+        self._gathered = [False] * len(self.opt._plist)
+        self._works = []
+        self._late = False
+
+    def _make_hook(self, i):
+        def hook(p):
+            if self._gathered[i]:
+                self._late = True      # a gradient arrived after its bucket was sent: redo the reduction in step()
+                return
+            if getattr(p, "_pcrl_final", False) and not self._gathered[i]:
+                p._pcrl_final = False
+                self._gathered[i] = True
+                bi = self._param_bucket[i]
+                self._ready[bi] += 1
+                if self._ready[bi] == len(self._bucket_params[bi]) and not self._launched[bi]:
+                    self._launch_bucket(bi)
+        return hook
+
+    def _launch_bucket(self, bi):
+        """Gather the bucket's gradients into the flat arena (zeros for parameters without one) and start its all-reduce."""
+        opt = self.opt
+        idxs = self._bucket_params[bi]
+        have = [i for i in idxs if opt._plist[i].grad is not None]
+        miss = [i for i in idxs if opt._plist[i].grad is None]
+        if have:
+            torch._foreach_copy_([opt._gviews[i] for i in have], [opt._plist[i].grad for i in have])
+        if miss:
+            torch._foreach_zero_([opt._gviews[i] for i in miss])
+        for i in idxs:
+            self._gathered[i] = True
+        self._launched[bi] = True
+        b, e = self.reducer.buckets[bi]
+        seg = opt.flat_g[b:e]
+        cs = self.reducer.comm_stream
+        if cs is not None:
+            cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def broadcast_state(self):
-        if self.world == 1:
+        if not self._active:
             return
         dist.broadcast(self.opt.flat_p, src=0, group=self.group)
         for b in self.model.buffers():
             dist.broadcast(b, src=0, group=self.group)
 
     def _pre_step(self, opt, has):
-        if self.world == 1:
+        """Runs inside optimizer.step() INSTEAD of the optimizer's own gradient gather (returns the has-grad list)."""
+        has = [p.grad is not None for p in opt._plist]
+        if not self._active:
+            opt.gather_grads()
             return has
-        # Slots of parameters without a gradient this step hold stale data: zero them so they add nothing.
-        missing = [v for v, h in zip(opt._gviews, has) if not h]
-        if missing:
-            torch._foreach_zero_(missing)
         if self.strict_flags:
-            # A parameter is updated if ANY rank produced a gradient for it.  All ranks draw the loss scales
-            # from identically seeded `random` streams (train_3d.seed_everything), so the pattern is the same
-            # everywhere and this exchange (which costs a device sync) is a debug check, off by default.
+            # A parameter is updated if ANY rank produced a gradient for it.  All ranks draw the loss scales from
+            # identically seeded `random` streams (train_3d.seed_everything), so the pattern is the same everywhere and
+            # this exchange (which costs a device sync) is a debug check, off by default.
             flags = torch.tensor([1 if h else 0 for h in has], dtype=torch.int32, device=opt.flat_g.device)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
             has = [bool(v) for v in flags.tolist()]
-        self.reducer.reduce()
+        if self._late:
+            # should not happen (pass-0 backward runs last); stay correct anyway: wait, then gather + reduce everything again
+            for w in self._works:
+                w.wait()
+            if self.reducer.comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.reducer.comm_stream)
+            self._works, self._launched = [], [False] * len(self.reducer.buckets)
+            if not getattr(self, "_warned_late", False):
+                print("[pcrlv2_amd.ddp] warning: late gradient accumulation detected; falling back to a full post-backward all-reduce")
+                self._warned_late = True
+        for bi in range(len(self.reducer.buckets)):      # buckets are ordered last-parameters-first
+            if not self._launched[bi]:
+                self._launch_bucket(bi)
+        cs = self.reducer.comm_stream
+        if cs is not None:
+            with torch.cuda.stream(cs):
+                for w in self._works:
+                    w.wait()
+            torch.cuda.current_stream().wait_stream(cs)
+        else:
+            for w in self._works:
+                w.wait()
+        for p in opt._plist:
+            if hasattr(p, "_pcrl_final"):
+                p._pcrl_final = False
+        self._reset_step()
         return has

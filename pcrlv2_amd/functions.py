@@ -19,6 +19,13 @@ def _act_grad(g, dtype):
     return ops.to_act(g, dtype)
 
 
+def mark_final(ctx, params):
+    """Backward of a stage that ran in the FIRST forward of the step: nothing will add to these gradients any more."""
+    if getattr(ctx, "pass_idx", 1) == 0:
+        for p in params:
+            p._pcrl_final = True
+
+
 class LUConvFn(Function):
     """act(bn1(conv1(x)))  --  models/pcrlv2_model_3d.py:32-34."""
 
@@ -29,6 +36,8 @@ class LUConvFn(Function):
         mod._count_batch()
         ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
         ctx.wref, ctx.gref = w, gamma
+        ctx.pass_idx = getattr(mod, "_pass_idx", 1)
+        ctx.plist = (w, b, gamma, beta)
         ctx.set_materialize_grads(False)
         return a
 
@@ -40,6 +49,7 @@ class LUConvFn(Function):
         da = da.contiguous() if sv.kind == "to1" else _act_grad(da, ctx.dt)
         dx, dw, db, dg, dbeta = ops.luconv_backward(sv, da, ctx.wref, ctx.gref, ctx.mod._packed, ctx.dt,
                                                     need_dx=ctx.needs_input_grad[0] and sv.kind != "c1")
+        mark_final(ctx, ctx.plist)
         return dx, dw, db, dg, dbeta, None
 
 
@@ -94,6 +104,8 @@ class UpStageFn(Function):
         ctx.save_for_backward(a1, x_pro)
         ctx.heads = (g, m_pro, r_pro, h0, h1, m_h, r_h)   # intermediates (no grad_fn): safe on ctx
         ctx.params = (up_w, w0, g0, w1, g1, bn_g, p0_w, p1_g, p3_w, dw_, dg_)
+        ctx.pass_idx = getattr(mod, "_pass_idx", 1)
+        ctx.plist = (up_w, up_b, w0, b0, g0, be0, w1, b1, g1, be1, bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b, dw_, db_, dg_, dbe_)
         ctx.set_materialize_grads(False)
         return a1, x_pro, x_pre, x_mask
 
@@ -138,6 +150,7 @@ class UpStageFn(Function):
         dx, g_upw, g_upb = ops.convt_backward(ctx.x, d_up, up_w, mod._packed_up, dt, need_dx=ctx.needs_input_grad[0])
         grads[0], grads[1], grads[2] = dx, g_upw, g_upb
         ctx.svd.x = None
+        mark_final(ctx, ctx.plist)
         return tuple(grads)
 
 
@@ -150,6 +163,8 @@ class OutFn(Function):
         x = ops.to_act(x, dt)
         out = ops.conv1x1_to1_forward(x, w, b, dt)
         ctx.x, ctx.w, ctx.dt = x, w, dt
+        ctx.pass_idx = getattr(mod, "_pass_idx", 1)
+        ctx.plist = (w, b)
         ctx.save_for_backward(out)   # an output: never stash it on ctx directly (reference cycle)
         ctx.set_materialize_grads(False)
         return out
@@ -159,6 +174,7 @@ class OutFn(Function):
         if dout is None:
             return None, None, None, None
         dx, dw, db = ops.conv1x1_to1_backward(ctx.x, ctx.saved_tensors[0], dout, ctx.w, ctx.dt, need_dx=ctx.needs_input_grad[0])
+        mark_final(ctx, ctx.plist)
         return dx, dw, db, None
 
 

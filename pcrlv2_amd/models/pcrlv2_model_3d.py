@@ -191,6 +191,11 @@ class PCRLv23d(nn.Module):
             if isinstance(m, _Counted):
                 m.flush_counters()
 
+    def _stage_modules(self):
+        if not hasattr(self, "_stages"):
+            object.__setattr__(self, "_stages", [m for m in self.modules() if isinstance(m, (LUConv, UpTransition, OutputTransition))])
+        return self._stages
+
     def state_dict(self, *args, **kwargs):
         self.flush_counters()
         return super().state_dict(*args, **kwargs)
@@ -201,6 +206,9 @@ class PCRLv23d(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
         b = x.shape[0]
+        pass_idx = ops.next_pass()          # 0 = first forward since the last optimizer step (its backward runs last)
+        for m in self._stage_modules():
+            m._pass_idx = pass_idx
         self.skip_out64 = self.down_tr64(x)
         self.skip_out128 = self.down_tr128(self.maxpool(self.skip_out64))
         self.skip_out256 = self.down_tr256(self.maxpool(self.skip_out128))

@@ -70,6 +70,25 @@ def bump_weights_epoch():
     _weights_epoch += 1
 
 
+# ----------------------------------------------------------------------------------------------
+# forward-pass index within one optimizer step (0 = first forward after optimizer.step(): its backward runs LAST, so the
+# parameter gradients it produces are final -- used by ddp.DataParallel to start all-reduces during backward)
+# ----------------------------------------------------------------------------------------------
+_pass_index = 0
+
+
+def begin_step():
+    global _pass_index
+    _pass_index = 0
+
+
+def next_pass() -> int:
+    global _pass_index
+    i = _pass_index
+    _pass_index += 1
+    return i
+
+
 class PackedWeights:
     """Packed (K-contiguous, activation-dtype) copies of one conv / transposed-conv weight."""
 

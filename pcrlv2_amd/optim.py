@@ -49,7 +49,7 @@ class FusedSGD(torch.optim.SGD):
         self._initialised = [False] * len(self._plist)
         self._flag_cache = {}
         self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
-        self.pre_step = None           # optional callable(self, has_grad) -> None, run after the gradient gather
+        self.pre_step = None           # optional callable(self, None) -> has-grad list: replaces the gradient gather (ddp.DataParallel)
         ops.bump_weights_epoch()
 
     # ------------------------------------------------------------------
@@ -80,9 +80,10 @@ class FusedSGD(torch.optim.SGD):
             with torch.enable_grad():
                 loss = closure()
         g = self.param_groups[0]
-        has = self.gather_grads()
         if self.pre_step is not None:
-            has = self.pre_step(self, has) or has
+            has = self.pre_step(self, None)       # the data-parallel wrapper gathers (bucket by bucket) and all-reduces
+        else:
+            has = self.gather_grads()
         flags = self._flags(has)
         lib().call("pcrl_sgd_step", self.flat_p, self.flat_g, self.flat_buf, self._offsets, flags, len(self._plist),
                    self._total, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(self.grad_scale),
@@ -93,4 +94,5 @@ class FusedSGD(torch.optim.SGD):
                 o, n = self._offsets_host[i], p.numel()
                 self.state[p]["momentum_buffer"] = self.flat_buf[o:o + n].view(p.shape)
         ops.bump_weights_epoch()
+        ops.begin_step()
         return loss

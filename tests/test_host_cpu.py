@@ -128,3 +128,57 @@ def test_bucketed_allreduce_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("OK" in o for o in outs)
+
+
+DP_WORKER = r'''
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pcrlv2_amd.ddp import DataParallel, init_process_group_from_env
+rank, world, _ = init_process_group_from_env("gloo")
+torch.manual_seed(0)
+shapes = [(300,), (7, 5), (2000,), (3,), (64, 8)]
+params = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+sizes = [p.numel() for p in params]
+offs = [0]
+for n in sizes: offs.append(offs[-1] + n)
+flat_g = torch.full((offs[-1],), 123.0)                    # stale garbage that must not leak into the result
+opt = types.SimpleNamespace(_plist=params, flat_g=flat_g, flat_p=torch.cat([p.detach().reshape(-1) for p in params]).clone(),
+                            _gviews=[flat_g[o:o + n].view(p.shape) for p, o, n in zip(params, offs, sizes)], grad_scale=1.0, pre_step=None)
+opt.gather_grads = lambda: None
+model = torch.nn.Module()
+dp = DataParallel(model, opt, bucket_mb=0.004, overlap=True)     # ~1000 floats per bucket -> several buckets
+assert opt.grad_scale == 1.0 / world and len(dp.reducer.buckets) >= 3
+for step in range(2):
+    # parameter 3 has no gradient at all (unused head); parameter 1 gets a gradient only from a non-final pass
+    x = [torch.full(s, float(rank + 1 + step)) for s in shapes]
+    for p in params: p.grad = None
+    # "pass 1" (not final) for params 0,1,2,4
+    loss = sum((p * xi).sum() for i, (p, xi) in enumerate(zip(params, x)) if i != 3)
+    loss.backward()
+    # "pass 0" (final) for params 0,2,4: mark, then accumulate again
+    for i in (0, 2, 4): params[i]._pcrl_final = True
+    loss = sum((p * xi).sum() for i, (p, xi) in enumerate(zip(params, x)) if i in (0, 2, 4))
+    loss.backward()
+    has = dp._pre_step(opt, None)
+    assert has == [True, True, True, False, True], has
+    tot = sum(r + 1 + step for r in range(world))
+    for i, v in enumerate(opt._gviews):
+        mult = {0: 2, 1: 1, 2: 2, 3: 0, 4: 2}[i]
+        assert torch.allclose(v, torch.full_like(v, float(mult * tot))), (step, i, v.flatten()[:3], mult * tot)
+    assert not dp._late
+dist.barrier()
+print("OK", rank)
+'''
+
+
+def test_data_parallel_overlap_logic_gloo_world2(tmp_path):
+    """ddp.DataParallel (bucket readiness via final-pass marks, zero-fill of grad-less parameters, sweep in step())
+    with 2 gloo ranks on CPU and a stand-in optimizer."""
+    script = tmp_path / "dp.py"
+    script.write_text(DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs)

@@ -332,3 +332,42 @@ def test_full_size_step_properties_bf16():
         results.append((vals, opt.flat_p.clone()))
     assert results[0][0] == results[1][0], "losses differ between identical runs (non-deterministic reduction?)"
     assert torch.equal(results[0][1], results[1][1]), "parameters differ between identical runs"
+
+
+def test_data_parallel_wrapper_on_one_rank_rccl_group():
+    """ddp.DataParallel on a 1-rank RCCL group: the hook-driven bucket launches (final-pass marks set by the stage
+    Functions during view 1's backward), the side stream and the collectives run for real; with world = 1 the result must
+    be bit-identical to the plain step.  (Multi-GPU runs are the driver's; the N>1 logic is covered with gloo on CPU.)"""
+    import torch.distributed as dist
+    from pcrlv2_amd import ddp
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    b, dhw = 4, (32, 32, 16)
+    batches = [O.fill_batch(b, dhw, dtype=torch.float32, seed=50 + s) for s in range(2)]
+    finals = []
+    for wrap in (False, True):
+        model = build(torch.bfloat16)
+        opt = FusedSGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+        launched_in_backward = []
+        if wrap:
+            dp = ddp.DataParallel(model, opt, bucket_mb=8.0, overlap=True, force_collectives=True)
+            assert len(dp.reducer.buckets) >= 4
+            orig = dp._pre_step
+
+            def spy(o, h, dp=dp, orig=orig):
+                launched_in_backward.append(sum(dp._launched))
+                return orig(o, h)
+            opt.pre_step = spy
+        random.seed(1)
+        for batch in batches:
+            train_step(model, opt, batch, 0, MSELoss(), CosineSimilarityMean())
+        torch.cuda.synchronize()
+        finals.append(opt.flat_p.clone())
+        if wrap:
+            assert not dp._late
+            assert all(n >= 1 for n in launched_in_backward), f"no bucket was launched during backward: {launched_in_backward}"
+            print("buckets launched before optimizer.step():", launched_in_backward, "of", len(dp.reducer.buckets))
+    assert torch.equal(finals[0], finals[1])
+    dist.destroy_process_group()
