@@ -219,12 +219,51 @@ def make_case(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=3, base_l
     print(f"[{tag}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB, {len(fx)} arrays)")
 
 
+def make_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, base_lr=1e-3, epochs=240, seed=5):
+    """Loss curve of the REAL reference (float64, oneDNN off) over `nsteps` SGD steps on correlated synthetic views:
+    the fixture behind the "loss curve within 1e-3" test (SURVEY App. C scopes what can be asserted)."""
+    torch.set_num_threads(8)
+    dt = torch.float64
+    st0 = O.fill_state(dt)
+    batches = [O.fill_batch(b, dhw, dtype=dt, seed=900 + s) for s in range(nsteps)]
+    model = refmod.PCRLv23d().double()
+    model.load_state_dict(st0, strict=True)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=1e-4)
+
+    class A:
+        pass
+    A.lr, A.epochs = base_lr, epochs
+    ref_utils.adjust_learning_rate(epoch, A, opt)
+    criterion, cosine = torch.nn.MSELoss(), torch.nn.CosineSimilarity()
+    random.seed(seed)
+    rows = []
+    with torch.backends.mkldnn.flags(enabled=False):
+        for s in range(nsteps):
+            r = reference_step(model, ref_train, batches[s], epoch, criterion, cosine)
+            opt.zero_grad()
+            r["loss"].backward()
+            opt.step()
+            rows.append([float(r[k].detach()) for k in ("loss", "loss1", "loss2", "loss4", "local_loss")] + [float(r["index2"])])
+            print(f"[{tag}] step {s}: {rows[-1]}")
+    # the oracle must follow the same curve (it is what runs where the reference cannot travel)
+    with torch.backends.mkldnn.flags(enabled=False):
+        _, _, log, _ = O.train_steps(st0, batches, epoch, base_lr, epochs, seed)
+    for s in range(nsteps):
+        for i, k in enumerate(("loss", "loss1", "loss2", "loss4", "local_loss")):
+            assert abs(log[s][k] - rows[s][i]) < 1e-9, (s, k, log[s][k], rows[s][i])
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), curve=np.array(rows), b=np.int64(b), dhw=np.array(dhw), nsteps=np.int64(nsteps),
+                        epoch=np.int64(epoch), base_lr=np.float64(base_lr), seed=np.int64(seed), batch_seed0=np.int64(900))
+    print(f"[{tag}] wrote fixture; oracle == reference over {nsteps} steps")
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be regenerated in the authoring container")
     refmod, ref_train, ref_utils = load_reference()
     make_case("c_small_b4_32x32x16", 4, (32, 32, 16), 2, refmod, ref_train, ref_utils)
     make_case("c_luna_b2_64x64x32", 2, (64, 64, 32), 1, refmod, ref_train, ref_utils)
+    make_curve("curve_b8_32x32x16_12steps", 8, (32, 32, 16), 12, refmod, ref_train, ref_utils)
     # LR schedule vector (utils.py:101-114) for epochs 0..240 at lr=1e-3
     class A:
         lr, epochs = 1e-3, 240

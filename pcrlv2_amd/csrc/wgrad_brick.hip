@@ -128,28 +128,30 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
     __builtin_amdgcn_sched_barrier(0);
 
     // 36 steps = 4 K-chunks x 9 taps, fully unrolled and SOFTWARE-PIPELINED: the x fragment of step s+1 (and the dy
-    // fragments of the next K-chunk) are fetched before the MFMAs of step s.  With one wave per SIMD nothing else hides
+    // fragments of the next K-chunk) are fetched two steps before the MFMAs that use them.  With one wave per SIMD nothing else hides
     // the LDS latency: the naive order (read, wait, 4 MFMAs) ran the matrix pipe at ~40 % inside this phase.
     // lane's voxels of K-chunk kc: v = 32*kc + 8*lg + 4*q + jr (q = 0,1 = the two transpose reads);
     // halo row of voxel (vd, vh, vw) at tap (kh, kw): (vd*XH + vh + kh)*XW + vw + kw.
 #define WB_A(kc_, f_) tr_frag(dys + dy_off(32 * (kc_) + 8 * lg + jr, (f_)*16 + 4 * cq), dys + dy_off(32 * (kc_) + 8 * lg + jr + 4, (f_)*16 + 4 * cq))
 #define WB_XROW(kc_, t_) ((((kc_) >> 1) * XH + ((kc_)&1) * 4 + lg + (t_) / 3) * XW + jr + (t_) % 3)
 #define WB_B(kc_, t_) tr_frag(xs + x_off(WB_XROW(kc_, t_), wid * 16 + 4 * cq), xs + x_off(WB_XROW(kc_, t_) + 4, wid * 16 + 4 * cq))
-    bf16x8 fa[4], fan[4], fb, fbn;
+    bf16x8 fa[4], fan[4], fbr[3];   // fbr: 3-deep ring, the x fragment is fetched TWO steps (8 MFMAs, ~130 cycles) ahead of its use
 #pragma unroll
     for (int f = 0; f < 4; ++f) fa[f] = WB_A(0, f);
-    fb = WB_B(0, 0);
+    fbr[0] = WB_B(0, 0);
+    fbr[1] = WB_B(0, 1);
 #pragma unroll
     for (int st = 0; st < 36; ++st) {
       const int kc = st / 9, t = st % 9;
-      if (st + 1 < 36) fbn = WB_B((st + 1) / 9, (st + 1) % 9);
-      if (t == 5 && kc < 3) {
+      if (st + 2 < 36) fbr[(st + 2) % 3] = WB_B((st + 2) / 9, (st + 2) % 9);
+      if (t == 4 && kc < 3) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) fan[f] = WB_A(kc + 1, f);
       }
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this step's MFMAs (hipcc sinks them next to their use otherwise)
 #pragma unroll
-      for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f], fb, acc[t][f], 0, 0, 0);
-      fb = fbn;
+      for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f], fbr[st % 3], acc[t][f], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
       if (t == 8 && kc < 3) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) fa[f] = fan[f];
