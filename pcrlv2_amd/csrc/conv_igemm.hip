@@ -154,13 +154,15 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 
   const int nchunk = K / 32;
   const int S = p.taps * nchunk;
-  u32x4 ra[AP], rb[BP];
-  uint32_t aok = 0;  // validity bits of the staged A rows (applied when they are written to LDS)
+  // Two staging register sets: the loads of K-step s+2 are issued while step s is multiplied and step s+1 waits in the
+  // other set, so a load has two MFMA phases to land.
+  u32x4 raA[AP], rbA[BP], raB[AP], rbB[BP];
+  uint32_t aokA = 0, aokB = 0;
   // NOTE: global loads are UNCONDITIONAL (invalid taps re-read the row's own, always valid, base row and are zeroed at
   // the LDS store).  A load under a per-lane condition makes hipcc wrap it in a branch with `s_waitcnt vmcnt(0)`, which
-  // serialises every load of the K-step ahead of the MFMAs (measured: 185 TF -> see profiles/).
+  // serialises every load of the K-step ahead of the MFMAs (measured: 185 TF -> 655 TF, see profiles/).
 
-#define IGEMM_LOAD(t_, c_)                                                                              \
+#define IGEMM_LOAD(t_, c_, ra, rb, aok)                                                                 \
   do {                                                                                                  \
     int64_t delta_;                                                                                     \
     if (GEOM == GEOM_CONV3) delta_ = tap_delta27((t_), g);                                              \
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       rb[ps] = *reinterpret_cast<const u32x4*>(Wp + boff[ps] + (int64_t)(t_)*K + (c_)*32);              \
   } while (0)
 
-#define IGEMM_STORE(buf_)                                                                               \
+#define IGEMM_STORE(buf_, ra, rb, aok)                                                                  \
   do {                                                                                                  \
     _Pragma("unroll") for (int ps = 0; ps < AP; ++ps)                                                   \
       *reinterpret_cast<u32x4*>(As + (buf_)*A_BYTES + TL::off(ps * RPP + rowp, slot)) =                 \
@@ -188,41 +190,56 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     }                                                                                                   \
   } while (0)
 
-  IGEMM_LOAD(0, 0);
-  IGEMM_STORE(0);
+#define IGEMM_COMPUTE(cur_)                                                                             \
+  do {                                                                                                  \
+    const char* a = As + (cur_)*A_BYTES;                                                                \
+    const char* b = Bs + (cur_)*B_BYTES;                                                                \
+    typename MM::Frag fa[FM], fb[FN];                                                                   \
+    _Pragma("unroll") for (int i = 0; i < FM; ++i) fa[i] = MM::read(a, wm * 64 + i * 16 + lr, lg);      \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) fb[j] = MM::read(b, wn * (BN / 2) + j * 16 + lr, lg); \
+    _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                      \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j) MM::mma(fa[i], fb[j], acc[i][j]);                  \
+  } while (0)
+
+  // step -> (tap, chunk), clamped to the last step (the tail re-loads a valid step; its data is never used)
+#define STEP_TC(s_, t_, c_)                                                                             \
+  do {                                                                                                  \
+    const int ss_ = (s_) < S ? (s_) : S - 1;                                                            \
+    t_ = ss_ / nchunk;                                                                                  \
+    c_ = ss_ - t_ * nchunk;                                                                             \
+  } while (0)
+
+  int t0_, c0_;
+  STEP_TC(0, t0_, c0_);
+  IGEMM_LOAD(t0_, c0_, raA, rbA, aokA);
+  IGEMM_STORE(0, raA, rbA, aokA);
+  STEP_TC(1, t0_, c0_);
+  IGEMM_LOAD(t0_, c0_, raA, rbA, aokA);      // set A holds step 1
   __syncthreads();
 
-  // Straight-line loop body (no conditionals around the staging registers: under an `if` hipcc demotes the ra/rb arrays
-  // to scratch memory).  The last iteration stages a harmless duplicate of its own step into the idle buffer.
-  int t = 0, c = 0;
-  for (int s = 0; s < S; ++s) {
-    const int cur = s & 1;
-    int tn = t, cn = c + 1;
-    if (cn == nchunk) { cn = 0; tn = t + 1; }
-    if (s + 1 == S) { tn = t; cn = c; }
-    IGEMM_LOAD(tn, cn);
-    __builtin_amdgcn_sched_barrier(0);  // loads stay in flight across the MFMA phase: no consumer may move above this line
-
-    {
-      const char* a = As + cur * A_BYTES;
-      const char* b = Bs + cur * B_BYTES;
-      typename MM::Frag fa[FM], fb[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) fa[i] = MM::read(a, wm * 64 + i * 16 + lr, lg);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) fb[j] = MM::read(b, wn * (BN / 2) + j * 16 + lr, lg);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) MM::mma(fa[i], fb[j], acc[i][j]);
-    }
-
+  // Straight-line loop body, unrolled by two so that the register sets alternate statically.
+  for (int s = 0; s < S; s += 2) {
+    int tn, cn;
+    // ---- even step s: compute buffer 0; set A (step s+1) -> buffer 1; set B <- step s+2
+    STEP_TC(s + 2, tn, cn);
+    IGEMM_LOAD(tn, cn, raB, rbB, aokB);
     __builtin_amdgcn_sched_barrier(0);
-    IGEMM_STORE(cur ^ 1);
+    IGEMM_COMPUTE(0);
+    __builtin_amdgcn_sched_barrier(0);
+    IGEMM_STORE(1, raA, rbA, aokA);
     __syncthreads();
-    t = tn;
-    c = cn;
+    if (s + 1 >= S) break;
+    // ---- odd step s+1: compute buffer 1; set B (step s+2) -> buffer 0; set A <- step s+3
+    STEP_TC(s + 3, tn, cn);
+    IGEMM_LOAD(tn, cn, raA, rbA, aokA);
+    __builtin_amdgcn_sched_barrier(0);
+    IGEMM_COMPUTE(1);
+    __builtin_amdgcn_sched_barrier(0);
+    IGEMM_STORE(0, raB, rbB, aokB);
+    __syncthreads();
   }
+#undef IGEMM_COMPUTE
+#undef STEP_TC
 #undef IGEMM_LOAD
 #undef IGEMM_STORE
 
