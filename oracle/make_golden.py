@@ -257,10 +257,27 @@ def make_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, base_
     print(f"[{tag}] wrote fixture; oracle == reference over {nsteps} steps")
 
 
+def make_init(tag, refmod, seed=7):
+    """Freshly constructed reference model under torch.manual_seed(seed): per-tensor sum, |sum| and leading entries.
+    A drop-in model class must consume the RNG in the same order to start from the same point (models/pcrlv2_model_3d.py:85-104)."""
+    torch.manual_seed(seed)
+    m = refmod.PCRLv23d()
+    fx = OrderedDict()
+    fx["meta/seed"] = np.int64(seed)
+    for k, v in m.state_dict().items():
+        f = v.detach().double().reshape(-1).numpy()
+        fx[f"{k}/sum"], fx[f"{k}/abs"], fx[f"{k}/head"] = np.float64(f.sum()), np.float64(np.abs(f).sum()), f[:4].copy()
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **fx)
+    print(f"[{tag}] {len(m.state_dict())} tensors")
+
+
 def main():
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be regenerated in the authoring container")
     refmod, ref_train, ref_utils = load_reference()
+    make_init("init_seed7", refmod)
+    if "--init-only" in sys.argv:
+        return
     make_case("c_small_b4_32x32x16", 4, (32, 32, 16), 2, refmod, ref_train, ref_utils)
     make_case("c_luna_b2_64x64x32", 2, (64, 64, 32), 1, refmod, ref_train, ref_utils)
     make_curve("curve_b8_32x32x16_12steps", 8, (32, 32, 16), 12, refmod, ref_train, ref_utils)

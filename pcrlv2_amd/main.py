@@ -18,26 +18,36 @@ import warnings
 warnings.filterwarnings('ignore')
 
 
+# flag, default, type (None = store_true), help -- the reference's flags (main.py:22-39) with their defaults
+_FLAGS = (
+    ("data", "/data1/luchixiang/LUNA16/processed", str, "dataset directory, or 'synthetic'"),
+    ("model", "pcrlv2", str, "model family"),
+    ("phase", "pretask", str, "pretask | finetune | scratch"),
+    ("b", 16, int, "batch size PER PROCESS"),
+    ("epochs", 100, int, "last epoch index (inclusive)"),
+    ("lr", 1e-3, float, "initial learning rate"),
+    ("output", "./model_genesis_pretrain", str, "checkpoint directory"),
+    ("n", "luna", str, "dataset name (goes into the checkpoint file name)"),
+    ("d", 3, int, "2 or 3 dimensional model"),
+    ("workers", 4, int, "loader workers"),
+    ("gpus", "0,1,2,3", str, "visible device ids, comma separated"),
+    ("ratio", 0.8, float, "fraction of the data used for pre-training"),
+    ("momentum", 0.9, float, "SGD momentum"),
+    ("weight_decay", 1e-4, float, "SGD weight decay"),
+    ("seed", 42, int, "python/torch seed"),
+    ("amp", False, None, "bfloat16 activations and MFMA operands"),
+    ("steps_per_epoch", 16, int, "only with --data synthetic"),
+)
+
+
 def build_parser():
-    parser = argparse.ArgumentParser(description='Self Training benchmark')
-    parser.add_argument('--data', metavar='DIR', default='/data1/luchixiang/LUNA16/processed', help='path to dataset')
-    parser.add_argument('--model', metavar='MODEL', default='pcrlv2', help='choose the model')
-    parser.add_argument('--phase', default='pretask', type=str, help='pretask or finetune or train from scratch')
-    parser.add_argument('--b', default=16, type=int, help='batch size (per process)')
-    parser.add_argument('--epochs', default=100, type=int, help='epochs to train')
-    parser.add_argument('--lr', default=1e-3, type=float, help='learning rate')
-    parser.add_argument('--output', default='./model_genesis_pretrain', type=str, help='output path')
-    parser.add_argument('--n', default='luna', type=str, help='dataset to use')
-    parser.add_argument('--d', default=3, type=int, help='3d or 2d to run')
-    parser.add_argument('--workers', default=4, type=int, help='num of workers')
-    parser.add_argument('--gpus', default='0,1,2,3', type=str, help='gpu indexs')
-    parser.add_argument('--ratio', default=0.8, type=float, help='ratio of data used for pretraining')
-    parser.add_argument('--momentum', default=0.9, type=float)
-    parser.add_argument('--weight_decay', default=1e-4, type=float)
-    parser.add_argument('--seed', default=42, type=int)
-    parser.add_argument('--amp', action='store_true', default=False)
-    parser.add_argument('--steps_per_epoch', default=16, type=int, help='only with --data synthetic')
-    return parser
+    ap = argparse.ArgumentParser(description="PCRLv2 pre-training on MI355X")
+    for name, default, kind, text in _FLAGS:
+        if kind is None:
+            ap.add_argument("--" + name, action="store_true", default=default, help=text)
+        else:
+            ap.add_argument("--" + name, default=default, type=kind, help=text)
+    return ap
 
 
 class SyntheticLunaLoader:

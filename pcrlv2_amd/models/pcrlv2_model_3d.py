@@ -1,15 +1,13 @@
 """PCRLv23d on the MI355X engine -- drop-in for the reference's models/pcrlv2_model_3d.py.
 
-Same classes, constructor arguments, forward signatures, return tuples, attribute names and
-state_dict (169 entries); the compute goes through libpcrl_hip.so (hand-written
-gfx950 kernels) via `pcrlv2_amd.functions`.  The torch.nn layers instantiated below are PARAMETER
-CONTAINERS only: they give the reference's parameter names, shapes and default initialisation (so
-the same `torch.manual_seed` yields the same initial weights as the reference); their forward()
-is never called.  There is no CPU / eager fallback: calling the model on non-GPU tensors raises.
+Same public classes, constructor arguments, forward signatures, return tuples, attribute names and state_dict
+(169 entries in the same order); the arithmetic runs in libpcrl_hip.so (hand-written gfx950 kernels)
+through `pcrlv2_amd.functions`.  torch.nn layers appear here ONLY as parameter containers: they provide the reference's
+parameter names / shapes / default initialisation (so an identical `torch.manual_seed` yields identical initial
+weights); their forward() is never called.  There is no CPU / eager fallback: non-GPU inputs raise.
 
-Not supported (raises NotImplementedError at construction): norm in {'gn','in'} and act in
-{'prelu','elu'} -- the reference accepts these strings but never instantiates them ('gn' crashes
-in the reference itself); in_channels != 1 and n_class != 1.
+Unsupported on purpose (NotImplementedError at construction): norm in {'gn','in'} and act in {'prelu','elu'} -- accepted
+as strings by the reference but never instantiated ('gn' crashes there) -- in_channels != 1, n_class != 1.
 """
 from __future__ import annotations
 
@@ -19,14 +17,17 @@ import torch.nn as nn
 from .. import config, functions as Fn, ops
 from .._lib import ACT_RELU, ACT_SIGMOID
 
+_ACTS = {"relu": ACT_RELU, "sigmoid": ACT_SIGMOID}
+_NO_KERNEL_ACTS = ("prelu", "elu")
+_NO_KERNEL_NORMS = ("gn", "in")
+
 
 class _Counted:
-    """Lazy `num_batches_tracked` bookkeeping: the counter buffers are bumped on the host and written
-    to the device tensors only when somebody looks (state_dict / flush), not once per forward."""
+    """`num_batches_tracked` bookkeeping done lazily: bumped on the host per forward, written to the device buffers
+    only when somebody looks (state_dict / flush_counters)."""
 
     def _init_counter(self, bns):
-        self._bns = bns
-        self._pending = 0
+        self._bns, self._pending = bns, 0
 
     def _count_batch(self):
         self._pending += 1
@@ -39,66 +40,52 @@ class _Counted:
 
 
 class LUConv(nn.Module, _Counted):
-    """reference: models/pcrlv2_model_3d.py:6-34"""
+    """conv3x3x3(pad 1, bias) -> BatchNorm3d(batch statistics) -> activation      [reference :6-34]"""
 
     def __init__(self, in_chan, out_chan, act, norm):
-        super(LUConv, self).__init__()
-        self.conv1 = nn.Conv3d(in_chan, out_chan, kernel_size=3, padding=1)
-        if norm == 'bn':
-            self.bn1 = nn.BatchNorm3d(num_features=out_chan, momentum=0.1, affine=True)
-        elif norm in ('gn', 'in'):
-            raise NotImplementedError("normalization type {} has no gfx950 kernel (reference default and only "
-                                      "working configuration is 'bn')".format(norm))
-        else:
+        super().__init__()
+        if norm in _NO_KERNEL_NORMS:
+            raise NotImplementedError(f"normalization type {norm} has no gfx950 kernel ('bn' is the reference default and its only working setting)")
+        if norm != "bn":
             raise ValueError('normalization type {} is not supported'.format(norm))
-        if act == 'relu':
-            self._act = ACT_RELU
-        elif act == 'sigmoid':
-            self._act = ACT_SIGMOID
-        elif act in ('prelu', 'elu'):
-            raise NotImplementedError("activation type {} has no gfx950 kernel".format(act))
-        else:
+        if act in _NO_KERNEL_ACTS:
+            raise NotImplementedError(f"activation type {act} has no gfx950 kernel")
+        if act not in _ACTS:
             raise ValueError('activation type {} is not supported'.format(act))
+        self.conv1 = nn.Conv3d(in_chan, out_chan, 3, padding=1)               # container: weight [Co,Ci,3,3,3], bias [Co]
+        self.bn1 = nn.BatchNorm3d(out_chan, momentum=ops.BN_MOMENTUM)          # container: affine + running statistics
+        self._act = _ACTS[act]
         self.compute_dtype = config.default_compute_dtype()
         self._packed = ops.PackedWeights("conv3")
         self._init_counter([self.bn1])
 
     def forward(self, x):
-        if self.conv1.in_channels == 1:
-            x = x.float().contiguous()
-        else:
-            x = ops.to_act(x, self.compute_dtype)
-        return Fn.LUConvFn.apply(x, self.conv1.weight, self.conv1.bias, self.bn1.weight, self.bn1.bias, self)
+        x = x.float().contiguous() if self.conv1.in_channels == 1 else ops.to_act(x, self.compute_dtype)
+        c, n = self.conv1, self.bn1
+        return Fn.LUConvFn.apply(x, c.weight, c.bias, n.weight, n.bias, self)
 
 
 def _make_nConv(in_channel, depth, act, norm, double_chnnel=False):
-    """reference: models/pcrlv2_model_3d.py:37-45"""
-    if double_chnnel:
-        layer1 = LUConv(in_channel, 32 * (2 ** (depth + 1)), act, norm)
-        layer2 = LUConv(32 * (2 ** (depth + 1)), 32 * (2 ** (depth + 1)), act, norm)
-    else:
-        layer1 = LUConv(in_channel, 32 * (2 ** depth), act, norm)
-        layer2 = LUConv(32 * (2 ** depth), 32 * (2 ** depth) * 2, act, norm)
-    return nn.Sequential(layer1, layer2)
+    """Two LUConvs.  Encoder stage d: in -> 32*2^d -> 64*2^d; decoder stage (double_chnnel): in -> 64*2^d -> 64*2^d   [:37-45]"""
+    wide = 64 << depth
+    mid = wide if double_chnnel else wide // 2
+    return nn.Sequential(LUConv(in_channel, mid, act, norm), LUConv(mid, wide, act, norm))
 
 
 class UpTransition(nn.Module, _Counted):
-    """reference: models/pcrlv2_model_3d.py:48-72"""
+    """ConvTranspose3d(k2,s2) -> two LUConvs -> {global-average projection head, predictor MLP, deep-supervision map}   [:48-72]"""
 
     def __init__(self, inChans, outChans, depth, act, norm):
-        super(UpTransition, self).__init__()
-        self.depth = depth
-        self.up_conv = nn.ConvTranspose3d(inChans, outChans, kernel_size=2, stride=2)
-        self.ops = _make_nConv(outChans, depth, act, norm, double_chnnel=True)
-        channels = 32 * (2 ** depth) * 2
-        self.bn = nn.BatchNorm1d(channels)
-        self.predictor_head = nn.Sequential(nn.Linear(channels, 2 * channels),
-                                            nn.BatchNorm1d(2 * channels),
-                                            nn.ReLU(inplace=True),
-                                            nn.Linear(2 * channels, channels))
-        self.deep_supervision_head = LUConv(channels, 1, 'sigmoid', norm)
-        if act != 'relu':
+        super().__init__()
+        if act != "relu":
             raise NotImplementedError("UpTransition is implemented for act='relu' (the reference default)")
+        c = 64 << depth
+        self.depth = depth
+        self.up_conv = nn.ConvTranspose3d(inChans, outChans, 2, stride=2)
+        self.ops = _make_nConv(outChans, depth, act, norm, double_chnnel=True)
+        self.bn = nn.BatchNorm1d(c)
+        self.predictor_head = nn.Sequential(nn.Linear(c, 2 * c), nn.BatchNorm1d(2 * c), nn.ReLU(inplace=True), nn.Linear(2 * c, c))
+        self.deep_supervision_head = LUConv(c, 1, "sigmoid", norm)
         self.compute_dtype = config.default_compute_dtype()
         self._packed_up = ops.PackedWeights("convt")
         self._init_counter([self.bn, self.predictor_head[1]])
@@ -106,25 +93,26 @@ class UpTransition(nn.Module, _Counted):
     def _count_batch_heads(self):
         self._count_batch()
 
+    def _stage_params(self):
+        lu = lambda m: (m.conv1.weight, m.conv1.bias, m.bn1.weight, m.bn1.bias)
+        ph = self.predictor_head
+        return ((self.up_conv.weight, self.up_conv.bias) + lu(self.ops[0]) + lu(self.ops[1]) + (self.bn.weight, self.bn.bias)
+                + (ph[0].weight, ph[0].bias, ph[1].weight, ph[1].bias, ph[3].weight, ph[3].bias) + lu(self.deep_supervision_head))
+
     def forward(self, x):
-        l0, l1, ld, ph = self.ops[0], self.ops[1], self.deep_supervision_head, self.predictor_head
-        return Fn.UpStageFn.apply(
-            x, self.up_conv.weight, self.up_conv.bias,
-            l0.conv1.weight, l0.conv1.bias, l0.bn1.weight, l0.bn1.bias,
-            l1.conv1.weight, l1.conv1.bias, l1.bn1.weight, l1.bn1.bias,
-            self.bn.weight, self.bn.bias, ph[0].weight, ph[0].bias, ph[1].weight, ph[1].bias, ph[3].weight, ph[3].bias,
-            ld.conv1.weight, ld.conv1.bias, ld.bn1.weight, ld.bn1.bias, self)
+        """-> (x, x_pro, x_pre, x_mask)"""
+        return Fn.UpStageFn.apply(x, *self._stage_params(), self)
 
 
 class OutputTransition(nn.Module):
-    """reference: models/pcrlv2_model_3d.py:75-83"""
+    """sigmoid(conv1x1x1)   [:75-83]"""
 
     def __init__(self, inChans, n_labels):
-        super(OutputTransition, self).__init__()
-        self.final_conv = nn.Conv3d(inChans, n_labels, kernel_size=1)
-        self.sigmoid = nn.Sigmoid()
+        super().__init__()
         if n_labels != 1:
-            raise NotImplementedError("n_class != 1 has no gfx950 kernel (the pre-training path uses n_class=1)")
+            raise NotImplementedError("n_class != 1 has no gfx950 kernel (pre-training uses n_class=1)")
+        self.final_conv = nn.Conv3d(inChans, n_labels, 1)
+        self.sigmoid = nn.Sigmoid()   # kept for attribute parity; the sigmoid is fused into the kernel path
         self.compute_dtype = config.default_compute_dtype()
 
     def forward(self, x):
@@ -132,10 +120,10 @@ class OutputTransition(nn.Module):
 
 
 class DownTransition(nn.Module):
-    """reference: models/pcrlv2_model_3d.py:86-92"""
+    """encoder stage   [:86-92]"""
 
     def __init__(self, in_channel, depth, act, norm):
-        super(DownTransition, self).__init__()
+        super().__init__()
         self.ops = _make_nConv(in_channel, depth, act, norm)
 
     def forward(self, x):
@@ -143,42 +131,44 @@ class DownTransition(nn.Module):
 
 
 class _MaxPool3d2(nn.MaxPool3d):
-    """`self.maxpool` of the reference (:100); forward goes to the gfx950 kernel."""
+    """`self.maxpool` of the reference (:100) routed to the gfx950 kernel."""
 
     def __init__(self):
         super().__init__(2)
         self.compute_dtype = config.default_compute_dtype()
 
     def forward(self, x):
-        dt = self.compute_dtype
-        return Fn.MaxPoolFn.apply(ops.to_act(x, dt), dt)
+        return Fn.MaxPoolFn.apply(ops.to_act(x, self.compute_dtype), self.compute_dtype)
+
+
+_ENCODER = (("down_tr64", None, 0), ("down_tr128", 64, 1), ("down_tr256", 128, 2), ("down_tr512", 256, 3))   # name, Cin, depth
+_DECODER = (("up_tr256", 512, 2), ("up_tr128", 256, 1), ("up_tr64", 128, 0))                                  # name, C, depth
+_SKIPS = ("skip_out64", "skip_out128", "skip_out256", "out512")                                               # attributes stashed by forward (:114-117)
+_UPSAMPLE = (4, 2, 1)                                                                                         # trilinear factors of the three masks (:125-127)
 
 
 class PCRLv23d(nn.Module):
     """reference: models/pcrlv2_model_3d.py:95-133"""
 
     def __init__(self, n_class=1, act='relu', norm='bn', in_channels=1, low_dim=128, student=False):
-        super(PCRLv23d, self).__init__()
+        super().__init__()
         if in_channels != 1:
             raise NotImplementedError("in_channels != 1 has no gfx950 first-layer kernel (LUNA volumes are 1-channel)")
         self.compute_dtype = config.default_compute_dtype()
+        # registration order == the reference's, so state_dict() enumerates the same 169 keys in the same order
         self.maxpool = _MaxPool3d2()
-        self.down_tr64 = DownTransition(in_channels, 0, act, norm)
-        self.down_tr128 = DownTransition(64, 1, act, norm)
-        self.down_tr256 = DownTransition(128, 2, act, norm)
-        self.down_tr512 = DownTransition(256, 3, act, norm)
-        self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1))  # unused, kept like the reference (:105)
-        self.up_tr256 = UpTransition(512, 512, 2, act, norm)
-        self.up_tr128 = UpTransition(256, 256, 1, act, norm)
-        self.up_tr64 = UpTransition(128, 128, 0, act, norm)
+        for name, cin, depth in _ENCODER:
+            setattr(self, name, DownTransition(in_channels if cin is None else cin, depth, act, norm))
+        self.avg_pool = nn.AdaptiveAvgPool3d((1, 1, 1))     # unused in the reference too (:105)
+        for name, c, depth in _DECODER:
+            setattr(self, name, UpTransition(c, c, depth, act, norm))
         self.out_tr = OutputTransition(64, n_class)
-        self.sigmoid = nn.Sigmoid()                       # unused, kept like the reference (:110)
+        self.sigmoid = nn.Sigmoid()                         # unused in the reference too (:110)
 
     # ---- engine controls (not in the reference) ----
     def set_compute_dtype(self, dt):
         """float32 (exact parity mode) or bfloat16 (MFMA throughput mode) for activations / packed weights."""
-        if isinstance(dt, str):
-            dt = {"fp32": torch.float32, "bf16": torch.bfloat16}[dt]
+        dt = {"fp32": torch.float32, "bf16": torch.bfloat16}.get(dt, dt) if isinstance(dt, str) else dt
         if dt not in (torch.float32, torch.bfloat16):
             raise ValueError("compute dtype must be float32 or bfloat16")
         for m in self.modules():
@@ -201,29 +191,22 @@ class PCRLv23d(nn.Module):
         return super().state_dict(*args, **kwargs)
 
     def forward(self, x, local=False):
+        """-> (out [b,1,D,H,W], [[pro, pre] x 3 scales], [mask x 3] or [] when local)"""
         if not self.training:
             raise NotImplementedError("PCRLv23d on the MI355X engine implements the pre-training (train-mode) path only")
         if not x.is_cuda:
             raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
-        b = x.shape[0]
         pass_idx = ops.next_pass()          # 0 = first forward since the last optimizer step (its backward runs last)
         for m in self._stage_modules():
             m._pass_idx = pass_idx
-        self.skip_out64 = self.down_tr64(x)
-        self.skip_out128 = self.down_tr128(self.maxpool(self.skip_out64))
-        self.skip_out256 = self.down_tr256(self.maxpool(self.skip_out128))
-        self.out512 = self.down_tr512(self.maxpool(self.skip_out256))
-        middle_masks = []
-        middle_features = []
-        out_up_256, pro_256, pre_256, middle_masks_256 = self.up_tr256(self.out512)
-        out_up_128, pro_128, pre_128, middle_masks_128 = self.up_tr128(out_up_256)
-        out_up_64, pro_64, pre_64, middle_masks_64 = self.up_tr64(out_up_128)
-        if not local:
-            middle_masks.append(Fn.TrilinearFn.apply(middle_masks_256, 4))
-            middle_masks.append(Fn.TrilinearFn.apply(middle_masks_128, 2))
-            middle_masks.append(middle_masks_64)
-        middle_features.append([pro_256, pre_256])
-        middle_features.append([pro_128, pre_128])
-        middle_features.append([pro_64, pre_64])
-        out = self.out_tr(out_up_64)
-        return out, middle_features, middle_masks
+        h = x
+        for i, ((name, _, _), attr) in enumerate(zip(_ENCODER, _SKIPS)):
+            h = getattr(self, name)(h if i == 0 else self.maxpool(h))
+            setattr(self, attr, h)          # the reference keeps these alive as attributes; the skips are never consumed (D6)
+        middle_features, middle_masks = [], []
+        for (name, _, _), factor in zip(_DECODER, _UPSAMPLE):
+            h, pro, pre, mask = getattr(self, name)(h)
+            middle_features.append([pro, pre])
+            if not local:
+                middle_masks.append(mask if factor == 1 else Fn.TrilinearFn.apply(mask, factor))
+        return self.out_tr(h), middle_features, middle_masks

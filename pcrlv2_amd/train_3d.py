@@ -1,19 +1,18 @@
 """3D pre-training loop on the MI355X engine -- drop-in for the reference's train_3d.py.
 
-Same entry point `train_pcrlv2_3d(args, data_loader, out_channel=3)`, same `cos_loss`, same loss
+Same entry point `train_pcrlv2_3d(args, data_loader, out_channel=3)`, same `cos_loss(cosine, output1, output2)`, same loss
 assembly, LR schedule, log line, checkpoint dict and file name.  Differences, all deliberate:
 
-  * compute: PCRLv23d runs on hand-written gfx950 kernels (pcrlv2_amd.models); losses and SGD too;
-  * `--amp` (apex O1 fp16 in the reference, train_3d.py:52-53) selects bfloat16 activations / MFMA operands
-    with float32 accumulation, statistics and master weights; no loss scaling is needed with bf16;
-  * `nn.DataParallel` (train_3d.py:54) is replaced by one process per GPU + RCCL all-reduce
-    (`pcrlv2_amd.ddp`): launch with torchrun, or plain `python main.py ...` for one GPU.  `--b` is the
-    PER-PROCESS batch here (the reference splits a global batch over replicas);
-  * meters hold device scalars and are read only when the log line is printed, so a step does not
-    synchronise the GPU (the reference calls .item() twice and cuda.synchronize() every iteration);
-  * the divergence guard (train_3d.py:140-142) is evaluated as `epoch > 10 and loss > 1000` so the
-    device->host read happens only when the reference would act on it;
-  * `--seed`, ignored by the reference, seeds python `random` (scale draws) and torch.
+  * compute: PCRLv23d, the losses and SGD run on hand-written gfx950 kernels (pcrlv2_amd.models / functions / optim);
+  * `--amp` (apex O1 fp16 in the reference, train_3d.py:52-53) selects bfloat16 activations / MFMA operands with float32
+    accumulation, statistics and master weights; bf16 needs no loss scaling;
+  * `nn.DataParallel` (train_3d.py:54) -> one process per GPU + RCCL all-reduce (`pcrlv2_amd.ddp`): launch under torchrun,
+    or plain `python main.py ...` for one GPU.  `--b` is the PER-PROCESS batch (the reference splits a global batch);
+  * meters hold device scalars and are read only when the log line is printed: a step does not synchronise the GPU
+    (the reference calls .item() twice and cuda.synchronize() every iteration);
+  * the divergence guard (train_3d.py:140-142) is evaluated as `epoch > 10 and loss > 1000`, so the device->host read
+    happens only when the reference would act on it;
+  * `--seed`, ignored by the reference, seeds python `random` (the scale draws) and torch.
 """
 from __future__ import print_function
 
@@ -31,39 +30,39 @@ from .models import PCRLv23d
 from .optim import FusedSGD
 from .utils import AverageMeter, adjust_learning_rate
 
+BETA_PERIOD = 240   # train_3d.py:136 hard-codes 240 (not args.epochs) in the deep-supervision weight; reproduced (Q2)
+
 
 class MSELoss:
-    """criterion of train_3d.py:56 on the fused sigmoid-map MSE kernel."""
+    """`criterion` of train_3d.py:56: mean squared error on the fused reduction kernel."""
 
     def cuda(self):
         return self
 
-    def __call__(self, p, gt):
-        return mse_loss(p, gt)
+    def __call__(self, pred, target):
+        return mse_loss(pred, target)
 
 
 class CosineSimilarityMean:
-    """train_3d.py:57's nn.CosineSimilarity(), fused with the `.mean()` every call site applies."""
+    """train_3d.py:57's nn.CosineSimilarity(), fused with the `.mean()` that every call site applies to it."""
     returns_mean = True
 
     def cuda(self):
         return self
 
-    def __call__(self, x, y):
-        return cosine_mean(x, y)
+    def __call__(self, a, b):
+        return cosine_mean(a, b)
 
 
 def cos_loss(cosine, output1, output2):
-    """reference: train_3d.py:86-92 (one scale per call, drawn from python's global `random`)."""
-    index = random.randint(0, len(output1) - 1)
-    sample1 = output1[index]
-    sample2 = output2[index]
-    if getattr(cosine, "returns_mean", False):
-        c12, c21 = cosine(sample1[1], sample2[0].detach()), cosine(sample2[1], sample1[0].detach())
-    else:
-        c12, c21 = cosine(sample1[1], sample2[0].detach()).mean(), cosine(sample2[1], sample1[0].detach()).mean()
-    loss = -(c12 + c21) * 0.5
-    return loss, index
+    """Symmetric negative cosine similarity between predictor and (stop-gradient) projection on ONE scale drawn from
+    python's global `random` -- train_3d.py:86-92.  output*[k] = [projection, prediction] of scale k."""
+    k = random.randint(0, len(output1) - 1)
+    (pro_a, pre_a), (pro_b, pre_b) = output1[k], output2[k]
+    sim_ab, sim_ba = cosine(pre_a, pro_b.detach()), cosine(pre_b, pro_a.detach())
+    if not getattr(cosine, "returns_mean", False):      # a plain nn.CosineSimilarity was passed in
+        sim_ab, sim_ba = sim_ab.mean(), sim_ba.mean()
+    return -(sim_ab + sim_ba) * 0.5, k
 
 
 def seed_everything(seed):
@@ -71,115 +70,111 @@ def seed_everything(seed):
     torch.manual_seed(seed)
 
 
-def train_step(model, optimizer, batch, epoch, criterion, cosine, guard=True):
-    """One iteration of train_3d.py:113-151.  Returns (loss, loss1, loss2, loss4, local_loss) as device
-    scalars, or None if the divergence guard skipped the step."""
-    input1, input2, gt, _gt2, local_views = batch
-    bsz = input1.size(0)
-    x1 = input1.float().cuda(non_blocking=True)
-    x2 = input2.float().cuda(non_blocking=True)
-    gt = gt.float().cuda(non_blocking=True)
-    mask1, decoder_outputs1, middle_masks1 = model(x1)
-    mask2, decoder_outputs2, _ = model(x2)
-    loss2, index2 = cos_loss(cosine, decoder_outputs1, decoder_outputs2)
-    local_loss = 0.0
-    local_input = torch.cat([v.float().cuda(non_blocking=True) for v in local_views], dim=0)
-    _, local_views_outputs, _ = model(local_input, local=True)
-    local_views_outputs = [torch.stack(t) for t in local_views_outputs]
+def _to_gpu(t):
+    return t.float().cuda(non_blocking=True)
+
+
+def step_losses(model, batch, epoch, criterion, cosine):
+    """Forward half of one iteration (train_3d.py:113-138): three forwards, 13 cosine terms, two restoration terms.
+    Returns (total, restoration, global-cosine, deep-supervision, local-cosine) as device scalars."""
+    view1, view2, target, _unused_gt2, local_views = batch              # gt2 is never used by the reference either (Q3)
+    n = view1.size(0)
+    target = _to_gpu(target)
+    out1, feats1, masks1 = model(_to_gpu(view1))
+    _out2, feats2, _ = model(_to_gpu(view2))                            # mask2 / its deep-supervision maps stay unused (Q3)
+    l_global, scale = cos_loss(cosine, feats1, feats2)
+    _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
+    stacked = [torch.stack(pair) for pair in feats_loc]                 # [2, 6n, C] per scale
+    l_local = 0.0
     for i in range(len(local_views)):
-        local_views_outputs_tmp = [t[:, bsz * i: bsz * (i + 1)] for t in local_views_outputs]
-        loss_local_1, _ = cos_loss(cosine, decoder_outputs1, local_views_outputs_tmp)
-        loss_local_2, _ = cos_loss(cosine, decoder_outputs2, local_views_outputs_tmp)
-        local_loss += loss_local_1
-        local_loss += loss_local_2
-    local_loss = local_loss / (2 * len(local_views))
-    loss1 = criterion(mask1, gt)
-    beta = 0.5 * (1. + math.cos(math.pi * epoch / 240))
-    loss4 = beta * criterion(middle_masks1[index2], gt)
-    loss = loss1 + loss2 + loss4 + local_loss
-    if guard and epoch > 10 and loss > 1000:
+        crop_i = [s[:, n * i: n * (i + 1)] for s in stacked]
+        l_local = l_local + cos_loss(cosine, feats1, crop_i)[0]
+        l_local = l_local + cos_loss(cosine, feats2, crop_i)[0]
+    l_local = l_local / (2 * len(local_views))
+    l_restore = criterion(out1, target)
+    beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
+    l_deep = beta * criterion(masks1[scale], target)                    # the scale drawn by the FIRST cos_loss call
+    return l_restore + l_global + l_deep + l_local, l_restore, l_global, l_deep, l_local
+
+
+def train_step(model, optimizer, batch, epoch, criterion, cosine, guard=True):
+    """One iteration of train_3d.py:113-151.  Returns (loss, loss1, loss2, loss4, local_loss) as detached device
+    scalars, or None when the divergence guard skipped the update."""
+    losses = step_losses(model, batch, epoch, criterion, cosine)
+    if guard and epoch > 10 and losses[0] > 1000:
         print('skip the step')
         return None
     optimizer.zero_grad()
-    loss.backward()
+    losses[0].backward()
     optimizer.step()
-    return loss.detach(), loss1.detach(), loss2.detach(), loss4.detach(), local_loss.detach()
+    return tuple(l.detach() for l in losses)
+
+
+def _checkpoint_name(args, epoch):
+    return os.path.join(args.output, "{}_{}_{}_{}_{}.pt".format(args.model, args.n, args.phase, args.ratio, epoch))
 
 
 def train_pcrlv2_3d(args, data_loader, out_channel=3):
-    train_loader = data_loader['train']
     distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
     rank = 0
     if distributed:
-        rank, _, local = _ddp.init_process_group_from_env()
-        torch.cuda.set_device(local)
+        rank, _, local_rank = _ddp.init_process_group_from_env()
+        torch.cuda.set_device(local_rank)
     seed_everything(getattr(args, "seed", 42))
-    model = PCRLv23d()
-    model = model.cuda()
+    model = PCRLv23d().cuda()
     if getattr(args, "amp", False):
         model.set_compute_dtype(torch.bfloat16)
     optimizer = FusedSGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
-    dp = _ddp.DataParallel(model, optimizer) if distributed else None  # noqa: F841  (hooks into optimizer.step)
+    if distributed:
+        _ddp.DataParallel(model, optimizer)          # hooks itself into optimizer.step()
+    criterion, cosine = MSELoss().cuda(), CosineSimilarityMean().cuda()
+    chatty = rank == 0
 
-    criterion = MSELoss().cuda()
-    cosine = CosineSimilarityMean().cuda()
-
-    for epoch in range(0, args.epochs + 1):
+    for epoch in range(0, args.epochs + 1):          # inclusive upper bound, like the reference (Q1): lr reaches 0 in the last epoch
         adjust_learning_rate(epoch, args, optimizer)
-        if rank == 0:
+        if chatty:
             print("==> training...")
-        time1 = time.time()
-        loss, prob = train_pcrlv2_inner(args, epoch, train_loader, model, optimizer, criterion, cosine, verbose=(rank == 0))
-        time2 = time.time()
-        if rank == 0:
-            print('epoch {}, total time {:.2f}'.format(epoch, time2 - time1))
-        if rank == 0 and (epoch % 100 == 0 or epoch == 240):
-            print('==> Saving...')
-            state = {'opt': args, 'state_dict': model.state_dict(),
-                     'optimizer': optimizer.state_dict(), 'epoch': epoch}
-            save_file = os.path.join(args.output,
-                                     args.model + "_" + args.n + '_' + args.phase + '_' + str(
-                                         args.ratio) + '_' + str(epoch) + '.pt')
-            torch.save(state, save_file)
-            del state
+        t_start = time.time()
+        train_pcrlv2_inner(args, epoch, data_loader['train'], model, optimizer, criterion, cosine, verbose=chatty)
+        if chatty:
+            print('epoch {}, total time {:.2f}'.format(epoch, time.time() - t_start))
+            if epoch % 100 == 0 or epoch == 240:     # checkpoint cadence and layout of train_3d.py:71-82
+                print('==> Saving...')
+                torch.save({'opt': args, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
+                           _checkpoint_name(args, epoch))
         torch.cuda.empty_cache()
     return model
 
 
 def train_pcrlv2_inner(args, epoch, train_loader, model, optimizer, criterion, cosine, verbose=True):
-    """one epoch -- reference: train_3d.py:95-173"""
+    """One epoch (train_3d.py:95-173).  Returns (mean restoration loss, mean local loss)."""
     model.train()
-    batch_time = AverageMeter()
-    data_time = AverageMeter()
-    loss_meter = AverageMeter()
-    mg_loss_meter = AverageMeter()
-    prob_meter = AverageMeter()
-
-    end = time.time()
-    for idx, batch in enumerate(train_loader):
-        data_time.update(time.time() - end)
-        bsz = batch[0].size(0)
+    meters = {k: AverageMeter() for k in ("bt", "dt", "cos", "mg", "local")}
+    tick = time.time()
+    for it, batch in enumerate(train_loader, start=1):
+        meters["dt"].update(time.time() - tick)
         out = train_step(model, optimizer, batch, epoch, criterion, cosine)
         if out is None:
             continue
-        _, loss1, loss2, _, local_loss = out
-        mg_loss_meter.update(loss1, bsz)
-        loss_meter.update(loss2, bsz)
-        prob_meter.update(local_loss, bsz)
-        if (idx + 1) % 10 == 0:
+        n = batch[0].size(0)
+        meters["mg"].update(out[1], n)
+        meters["cos"].update(out[2], n)
+        meters["local"].update(out[4], n)
+        log_now = it % 10 == 0
+        if log_now:
             torch.cuda.synchronize()
-        batch_time.update(time.time() - end)
-        end = time.time()
-        if verbose and (idx + 1) % 10 == 0:
-            f = float
+        meters["bt"].update(time.time() - tick)
+        tick = time.time()
+        if log_now and verbose:
+            m = meters
             print('Train: [{0}][{1}/{2}]\t'
                   'BT {3:.3f} ({4:.3f})\t'
                   'DT {5:.3f} ({6:.3f})\t'
                   'cos_loss {7:.3f} ({8:.3f})\t'
                   'mg loss {9:.3f} ({10:.3f})\t'
                   'local loss {11:.3f} ({12:.3f})'.format(
-                      epoch, idx + 1, len(train_loader), batch_time.val, batch_time.avg, data_time.val, data_time.avg,
-                      f(loss_meter.val), f(loss_meter.avg), f(mg_loss_meter.val), f(mg_loss_meter.avg),
-                      f(prob_meter.val), f(prob_meter.avg)))
+                      epoch, it, len(train_loader), m["bt"].val, m["bt"].avg, m["dt"].val, m["dt"].avg,
+                      float(m["cos"].val), float(m["cos"].avg), float(m["mg"].val), float(m["mg"].avg),
+                      float(m["local"].val), float(m["local"].avg)))
             sys.stdout.flush()
-    return (float(mg_loss_meter.avg), float(prob_meter.avg))
+    return float(meters["mg"].avg), float(meters["local"].avg)

@@ -182,3 +182,19 @@ def test_data_parallel_overlap_logic_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("OK" in o for o in outs)
+
+
+def test_model_init_matches_reference_under_seed():
+    """Constructing PCRLv23d consumes the torch RNG in the reference's order: same seed => the reference's initial weights
+    (golden from the real reference class, oracle/make_golden.py:make_init)."""
+    import numpy as np
+    import torch
+    from pcrlv2_amd.models import PCRLv23d
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "init_seed7.npz"))
+    torch.manual_seed(int(fx["meta/seed"]))
+    sd = PCRLv23d().state_dict()
+    assert len(sd) == (len(fx.files) - 1) // 3
+    for k, v in sd.items():
+        f = v.detach().double().reshape(-1).numpy()
+        assert f.sum() == fx[k + "/sum"] and np.abs(f).sum() == fx[k + "/abs"], k
+        assert np.array_equal(f[:4], fx[k + "/head"]), k
