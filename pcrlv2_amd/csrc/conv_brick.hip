@@ -25,8 +25,8 @@ constexpr int HD = TD + 2, HH = TH + 2, HWU = TW + 2;  // halo extents (used)
 constexpr int HW = 16;                                 // halo row pitch in w: padded 10 -> 16, see hoff_h()
 constexpr int HROWS_USED = HD * HH * HWU;              // 600 rows are loaded
 constexpr int HROWS = HD * HH * HW;                    // 960 rows of LDS
-constexpr int HPIECES = HROWS_USED * 4;                // 16-byte pieces of one 32-channel halo chunk
-constexpr int HPT = (HPIECES + 255) / 256;             // pieces per thread (10)
+constexpr int HLT = 240;                               // threads that stage the halo: 6 lines x 40 pieces per round
+constexpr int HPT = HD * HH / 6;                       // rounds = pieces per thread (10)
 constexpr int HALO_BYTES = HROWS * 64;                 // 60 KiB
 // one weight stage: 3 taps x BN rows x 64 B (12 KiB for BN = 64)
 
@@ -76,31 +76,26 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   const int d0 = (b % bd) * TD; b /= bd;
   const int n = b;
 
-  // ---- halo pieces of this thread: global row (clamped to a valid one), LDS offset, validity ----
-  int grow[HPT], hdst[HPT];
+  // ---- halo pieces of this thread: 240 threads x 10 rounds; a round covers 6 (d,h) lines of 10 rows x 4 pieces, so the
+  //      LDS offset of round i is the offset of round 0 + i * 6 lines (an immediate).  Global row clamped to a valid one.
+  const int htid = tid < HLT ? tid : tid - HLT;   // the last 16 threads repeat the first 16 (same address, same data)
+  const int hq = htid % 40, hl0 = htid / 40;
+  const int hslot = hq & 3;
+  int grow[HPT];
   uint32_t hvalid = 0;
 #pragma unroll
   for (int i = 0; i < HPT; ++i) {
-    const int pc = tid + 256 * i;
-    const int row = pc >> 2;
-    const int hd = row / (HH * HWU), hh = (row / HWU) % HH, hw = row % HWU;
+    const int line = hl0 + 6 * i;
+    const int hd = line / HH, hh = line % HH, hw = hq >> 2;
     const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
-    const bool ok = pc < HPIECES && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+    const bool ok = (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
     grow[i] = ok ? ((n * p.D + d) * p.H + h) * p.W + w : ((n * p.D + d0) * p.H + h0) * p.W + w0;
-    hdst[i] = hoff_h((hd * HH + hh) * HW + hw, pc & 3);
     hvalid |= (uint32_t)ok << i;
   }
-  const int hslot = tid & 3;
+  const int hdst0 = hoff_h(hl0 * HW + (hq >> 2), hslot);   // + i * 6 * HW * 64
 
-  // ---- A-fragment base rows in the halo (tap offset added per tap) ----
-  int abase[4];
-#pragma unroll
-  for (int fm = 0; fm < 4; ++fm) {
-    const int v = wid * 64 + fm * 16 + lr;
-    abase[fm] = ((v >> 6) * HH + ((v >> 3) & 7)) * HW + (v & 7);
-  }
   // ---- weight staging: 3 pieces per thread (tap kw = 0,1,2 of the current (kd,kh)), row co = tid>>2, slot tid&3 ----
-  const bool wthread = (tid >> 2) < BN;   // BN = 32: only the first 128 threads stage weights
+  const bool wthread = BN == 64 || (tid >> 2) < BN;   // BN = 32: only the first 128 threads stage weights
   const bf16* wrow = p.w + ((int64_t)(n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8;
   const int wdst = hoff_w(tid >> 2, tid & 3);   // within one tap tile [64][32]
 
@@ -120,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #define STORE_HALO()                                                                                      \
   do {                                                                                                    \
     _Pragma("unroll") for (int i = 0; i < HPT; ++i) {                                                     \
-      if (tid + 256 * i < HPIECES) *reinterpret_cast<u32x4*>(halo + hdst[i]) = keep_if((hvalid >> i) & 1u, rh[i]); \
+      *reinterpret_cast<u32x4*>(halo + hdst0 + i * (6 * HW * 64)) = keep_if((hvalid >> i) & 1u, rh[i]);       \
     }                                                                                                     \
   } while (0)
 #define LOAD_W(c_, s9_)                                                                                   \
@@ -136,47 +131,110 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
     }                                                                                                     \
   } while (0)
 
+  // Fragment addressing.  The wave's 64 voxels are one d-plane of the brick: voxel row of fragment fm = abase + fm * 32,
+  // so the swizzle key of a halo read depends only on (lr & 7) + kw (tap offsets in kd, kh are multiples of the pitch):
+  // three byte offsets per lane (one per kw), the (kd,kh) offset is a block-uniform add, fm is an immediate.
+  int akw[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) akw[kw] = hoff_h((wid * HH + (lr >> 3)) * HW + (lr & 7) + kw, lg);
+  const int bofs = hoff_w(lr, lg);   // weight row j * 16 + lr: same key for every j -> + j * 1024
+
+  // Two fragment sets in ping-pong: the reads of tap t+1 are issued before the MFMAs of tap t.
+  bf16x8 fa[2][4], fb[2][FN];
+#define LOADF(B_, aoff_, wt_)                                                                             \
+  do {                                                                                                    \
+    fa[B_][0] = *reinterpret_cast<const bf16x8*>(halo + (aoff_));                                         \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                        \
+      fb[B_][j] = *reinterpret_cast<const bf16x8*>((wt_) + bofs + j * 1024);                              \
+    _Pragma("unroll") for (int fm = 1; fm < 4; ++fm)                                                      \
+      fa[B_][fm] = *reinterpret_cast<const bf16x8*>(halo + (aoff_) + fm * (2 * HW * 64));                 \
+  } while (0)
+// scheduling pipelines: n x { m MFMA, 1 LDS read }  /  n x { m MFMA, 1 LDS write }
+#define PIPE_READS(n_, m_)                                                                                \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < (n_); ++q) {                                                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, (m_), 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+    }                                                                                                     \
+  } while (0)
+#define PIPE_WRITES(n_, m_)                                                                               \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int q = 0; q < (n_); ++q) {                                                    \
+      __builtin_amdgcn_sched_group_barrier(0x008, (m_), 0);                                               \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                  \
+    }                                                                                                     \
+  } while (0)
+#define MFMA_ROWS(B_, F0_, F1_)                                                                           \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int fm = (F0_); fm < (F1_); ++fm)                                              \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                      \
+        acc[fm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[B_][fm], fb[B_][j], acc[fm][j], 0, 0, 0); \
+  } while (0)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+  // One stage = the three kw taps of one (kd,kh) of one 32-channel chunk.  P = fragment set that holds tap kw = 0 on
+  // entry.  Both barriers of the stage sit between halves of tap kw = 2's MFMAs, whose operands are already in
+  // registers: the weight (and, once per chunk, halo) stores and the first reads of the next stage run under them.
+  int c = 0, s9 = 0;
+#define STAGE(P_)                                                                                         \
+  do {                                                                                                    \
+    int cn = c, sn = s9 + 1;                                                                              \
+    if (sn == 9) { sn = 0; cn = c + 1; }                                                                  \
+    const bool last = (cn == nchunk);                                                                     \
+    if (last) { cn = c; sn = s9; }                                                                        \
+    LOAD_W(cn, sn);                                                                                       \
+    const bool halo_next = (s9 == 8) && !last; /* block-uniform */                                        \
+    if (halo_next) LOAD_HALO(c + 1);                                                                      \
+    const int tap64 = ((s9 / 3) * HH + (s9 % 3)) * (HW * 64);                                             \
+    const int ntap64 = ((sn / 3) * HH + (sn % 3)) * (HW * 64);                                            \
+    LOADF((P_) ^ 1, akw[1] + tap64, wbuf + 1 * (BN * 64));                                                \
+    MFMA_ROWS(P_, 0, 4);                                                                                  \
+    PIPE_READS(4 + FN, 16 / (4 + FN));                                                                    \
+    SB();                                                                                                 \
+    LOADF(P_, akw[2] + tap64, wbuf + 2 * (BN * 64));                                                      \
+    MFMA_ROWS((P_) ^ 1, 0, 4);                                                                            \
+    PIPE_READS(4 + FN, 16 / (4 + FN));                                                                    \
+    SB();                                                                                                 \
+    __syncthreads(); /* every wave holds its kw = 2 fragments: weight stage (and halo) may be replaced */ \
+    STORE_W();                                                                                            \
+    if (halo_next) {                                                                                      \
+      STORE_HALO();                                                                                       \
+      MFMA_ROWS(P_, 0, 2);                                                                                \
+      PIPE_WRITES(2 * FN, 1);                                                                             \
+    } else {                                                                                              \
+      MFMA_ROWS(P_, 0, 2);                                                                                \
+      PIPE_WRITES(3, 2);                                                                                  \
+    }                                                                                                     \
+    SB();                                                                                                 \
+    __syncthreads();                                                                                      \
+    LOADF((P_) ^ 1, akw[0] + ntap64, wbuf);                                                               \
+    MFMA_ROWS(P_, 2, 4);                                                                                  \
+    PIPE_READS(4 + FN, 1);                                                                                \
+    SB();                                                                                                 \
+    c = cn;                                                                                               \
+    s9 = sn;                                                                                              \
+  } while (0)
+
   LOAD_HALO(0);
   LOAD_W(0, 0);
   STORE_HALO();
   STORE_W();
   __syncthreads();
+  LOADF(0, akw[0], wbuf);
 
-  for (int c = 0; c < nchunk; ++c) {
-    for (int s9 = 0; s9 < 9; ++s9) {
-      // prefetch the next weight stage into registers (wraps into the next chunk; the very last one re-loads itself)
-      int cn = c, sn = s9 + 1;
-      if (sn == 9) { sn = 0; cn = c + 1; }
-      const bool last = (cn == nchunk);
-      if (last) { cn = c; sn = s9; }
-      LOAD_W(cn, sn);
-      const bool halo_next = (s9 == 8) && !last;   // block-uniform
-      if (halo_next) LOAD_HALO(c + 1);
-      __builtin_amdgcn_sched_barrier(0);
-
-      const int kd = s9 / 3, kh = s9 % 3;
-      const int tapoff = (kd * HH + kh) * HW;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const char* wt = wbuf + kw * (BN * 64);
-        bf16x8 fb[FN], fa[4];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(wt + hoff_w(j * 16 + lr, lg));
-#pragma unroll
-        for (int fm = 0; fm < 4; ++fm) fa[fm] = *reinterpret_cast<const bf16x8*>(halo + hoff_h(abase[fm] + tapoff + kw, lg));
-#pragma unroll
-        for (int fm = 0; fm < 4; ++fm)
-#pragma unroll
-          for (int j = 0; j < FN; ++j) acc[fm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[fm], fb[j], acc[fm][j], 0, 0, 0);
-      }
-
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();   // every wave has finished reading this weight stage (and, on the last tap row, the halo)
-      STORE_W();
-      if (halo_next) STORE_HALO();
-      __syncthreads();
-    }
+  const int nstage = 9 * nchunk;
+  for (int S = 0; S + 1 < nstage; S += 2) {
+    STAGE(0);
+    STAGE(1);
   }
+  if (nstage & 1) STAGE(0);
+  __syncthreads();   // the epilogue reuses the LDS
+#undef STAGE
+#undef SB
+#undef MFMA_ROWS
+#undef LOADF
+#undef PIPE_READS
+#undef PIPE_WRITES
 #undef LOAD_HALO
 #undef STORE_HALO
 #undef LOAD_W
