@@ -357,6 +357,9 @@ int64_t pcrl_brick_conv_rows(int N, int D, int H, int W);
 int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                            int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
 
+bool pcrl_convt_up2_eligible(int Ci, int Co, int dtype);   // conv_up2.hip
+int pcrl_convt_up2_launch(const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Ci, int Co,
+                          hipStream_t stream);
 static int g_conv_impl = 0;  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
 extern "C" void pcrl_debug_set_conv_impl(int impl) { g_conv_impl = impl; }
 
@@ -379,6 +382,8 @@ extern "C" int pcrl_convt3d_k2s2_fwd(const void* x, const void* wp_fwd, const fl
                                      int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_dims("convt3d_k2s2_fwd", N, D, H, W, Ci, Co)) return e;
   PCRL_REQUIRE(x && wp_fwd && y, "convt3d_k2s2_fwd: null pointer");
+  if (g_conv_impl == 0 && pcrl_convt_up2_eligible(Ci, Co, dtype))
+    return pcrl_convt_up2_launch(x, wp_fwd, bias, y, N, D, H, W, Ci, Co, as_stream(stream));
   IgemmParams p{x, wp_fwd, bias, y, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 1};
   return dispatch<GEOM_UP2_FWD>(p, 8, dtype, as_stream(stream));
 }

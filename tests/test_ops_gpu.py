@@ -109,7 +109,7 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 3, 4, 5, 64, 64), (1, 4, 4, 2, 128, 128), (3, 2, 2, 2, 32, 32)])
+@pytest.mark.parametrize("shape", [(2, 3, 4, 5, 64, 64), (1, 4, 4, 2, 128, 128), (3, 2, 2, 2, 32, 32), (2, 5, 4, 4, 256, 128), (1, 3, 4, 4, 512, 64)])
 def test_convt_k2s2(shape, dt):
     N, D, H, W, Ci, Co = shape
     x, w, b = rnd(N, Ci, D, H, W, seed=1), rnd(Ci, Co, 2, 2, 2, seed=2, scale=0.2), rnd(Co, seed=3)
