@@ -186,7 +186,7 @@ template <typename T, int ACT>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ y,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ partial, int64_t M, int C) {
+                                                            float* __restrict__ partial, int64_t M, int C, int tile_rows) {
   constexpr int VEC = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C'][2], C' = max(C, VEC)
   const int tid = threadIdx.x;
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
   const int cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
   // C == 1: a "row" is VEC consecutive voxels of the single channel
   const int64_t rows_total = (C == 1) ? M / VEC : M;
-  const int tile = (C == 1) ? TILE_ROWS / VEC : TILE_ROWS;
+  const int tile = (C == 1) ? tile_rows / VEC : tile_rows;
   const int64_t rbeg = (int64_t)blockIdx.x * tile;
   const int64_t rend = (rbeg + tile < rows_total) ? rbeg + tile : rows_total;
   float s1[VEC], s2[VEC], sc[VEC], sh[VEC], mu[VEC], rs[VEC];
@@ -204,7 +204,27 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
     s1[j] = 0.f; s2[j] = 0.f;
     sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
   }
-  for (int64_t r = rbeg + slot; r < rend; r += nslots) {
+  // four rows in flight per thread (eight 16-byte loads): the tile is streamed once and nothing else hides HBM latency
+  int64_t r = rbeg + slot;
+  for (; r + 3 * (int64_t)nslots < rend; r += 4 * (int64_t)nslots) {
+    Vec16<T> g[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t off = ((r + u * (int64_t)nslots) * nvec + cv) * VEC;
+      g[u] = ld16(da + off);
+      v[u] = ld16(y + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float yv = to_f(v[u].v[j]);
+        const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], to_f(g[u].v[j]));
+        s1[j] += dz;
+        s2[j] += dz * (yv - mu[j]) * rs[j];
+      }
+  }
+  for (; r < rend; r += nslots) {
     const int64_t off = (r * nvec + cv) * VEC;
     const Vec16<T> g = ld16(da + off);
     const Vec16<T> v = ld16(y + off);
@@ -454,7 +474,17 @@ extern "C" int pcrl_bn_act_apply(const void* y, void* a, const float* scale, con
   return pcrl_check_launch("bn_act_apply");
 }
 
-extern "C" int64_t pcrl_bn_bwd_partial_rows(int64_t M) { return (M + TILE_ROWS - 1) / TILE_ROWS; }
+// Rows per first-stage partial of the BatchNorm backward: 1024 for the big volumes, fewer for small ones so that the
+// reduction still spreads over >= ~1000 blocks (M = 65536 used to run on 64 of the 256 CUs).
+static int bn_bwd_tile_rows(int64_t M) {
+  int t = TILE_ROWS;
+  while (t > 32 && M / t < 1024) t >>= 1;
+  return t;
+}
+extern "C" int64_t pcrl_bn_bwd_partial_rows(int64_t M) {
+  const int t = bn_bwd_tile_rows(M);
+  return (M + t - 1) / t;
+}
 
 extern "C" int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, const float* shift,
                                       const float* mean, const float* rstd, float* partial,
@@ -468,10 +498,10 @@ extern "C" int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float
   const size_t lds = (size_t)(256 / nvec) * (nvec * vec) * 2 * sizeof(float);
   if (dtype == PCRL_BF16) {
     using T = bf16;
-    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C);
+    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M));
   } else {
     using T = float;
-    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C);
+    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M));
   }
   return pcrl_check_launch("bn_act_bwd_reduce");
 }
