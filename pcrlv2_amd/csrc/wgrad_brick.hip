@@ -73,10 +73,32 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
 #pragma unroll
     for (int f = 0; f < 4; ++f) acc[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging roles: dy piece q = tid + 256*i -> voxel q>>3, 16-byte piece q&7 ; x piece likewise over 240 halo rows
+  // staging roles: dy piece q = tid + 256*i -> voxel q>>3, 16-byte piece q&7 ; x piece likewise over 240 halo rows.
+  // Address generation is kept off the critical path: a brick's pieces sit at FIXED byte offsets from the brick's first
+  // halo voxel, computed once per thread; per brick only a block-uniform 64-bit base pointer, a 6-bit boundary mask and
+  // one select per piece remain.  (The first version decoded every piece per brick with 64-bit multiplies under divergent
+  // branches: 2400 of the 6200 cycles a brick took, with the matrix pipe idle -- one wave per SIMD.)
   const int pc = tid & 7;
   const bool jcol_ok = (j0 + pc * 8) < p.Cv;       // Cv is a multiple of 32: a 64-wide tile may hang over
   const int xcol = jcol_ok ? j0 + pc * 8 : 0;
+  uint32_t dyoff[DYP], xoff[XP];   // byte offsets from the brick bases
+  uint32_t xedge[XP];              // which faces of the halo the piece's row lies on (bit: d-,d+,h-,h+,w-,w+); bit 6 = not a halo row
+#pragma unroll
+  for (int i = 0; i < DYP; ++i) {
+    const int v = (tid >> 3) + 32 * i;
+    dyoff[i] = (uint32_t)((((v >> 6) * p.H + ((v >> 3) & 7)) * p.W + (v & 7)) * p.Cu + pc * 8) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int r = (tid >> 3) + 32 * i;
+    const int hd = r / (XH * XW), hh = (r / XW) % XH, hw = r % XW;
+    const bool row_ok = r < XROWS && hw < BW + 2;
+    xoff[i] = row_ok ? (uint32_t)(((hd * p.H + hh) * p.W + hw) * p.Cv + xcol) * 2u : 0u;
+    xedge[i] = (hd == 0 ? 1u : 0u) | (hd == BD - 1 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == XH - 1 ? 8u : 0u) | (hw == 0 ? 16u : 0u) |
+               (hw == BW + 1 ? 32u : 0u) | (row_ok && jcol_ok ? 0u : 64u);
+  }
+  // a halo row that is inside the volume for every brick: (hd = 1 for kd = 0, else 0 ; hh = 1 ; hw = 1)
+  const uint32_t xsafe = (uint32_t)((((kd == 0 ? 1 : 0) * p.H + 1) * p.W + 1) * p.Cv + xcol) * 2u;
   u32x4 rdy[DYP], rx[XP];
   uint32_t xvalid = 0;
 
@@ -88,21 +110,18 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
     const int d0 = (t_ % bd) * BD; t_ /= bd;                                                                 \
     const int n = t_;                                                                                        \
     const int64_t base0 = (((int64_t)n * p.D + d0) * p.H + h0) * p.W + w0;                                   \
-    _Pragma("unroll") for (int i = 0; i < DYP; ++i) {                                                        \
-      const int v = (tid >> 3) + 32 * i;                                                                     \
-      const int64_t row = base0 + ((int64_t)(v >> 6) * p.H + ((v >> 3) & 7)) * p.W + (v & 7);                \
-      rdy[i] = *reinterpret_cast<const u32x4*>(p.dy + row * p.Cu + i0 + pc * 8);                             \
-    }                                                                                                        \
+    const char* dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                               \
+    /* first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
+    const char* xb = reinterpret_cast<const char*>(p.x + (base0 + ((int64_t)(kd - 1) * p.H - 1) * p.W - 1) * p.Cv); \
+    /* faces of this brick's halo that stick out of the volume (BD = 2: the d faces are the two planes) */    \
+    const uint32_t out = (d0 + kd - 1 < 0 ? 1u : 0u) | (d0 + kd - 1 + BD - 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |   \
+                         (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u; \
+    _Pragma("unroll") for (int i = 0; i < DYP; ++i) rdy[i] = *reinterpret_cast<const u32x4*>(dyb + dyoff[i]); \
     xvalid = 0;                                                                                              \
     _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                         \
-      const int r = (tid >> 3) + 32 * i;                                                                     \
-      const int hd = r / (XH * XW), hh = (r / XW) % XH, hw = r % XW;                                         \
-      const int d = d0 + hd + kd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                      \
-      const bool ok = r < XROWS && hw < BW + 2 && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && \
-                      (unsigned)w < (unsigned)p.W;                                                           \
-      const int64_t row = ok ? (((int64_t)n * p.D + d) * p.H + h) * p.W + w : base0;                         \
-      rx[i] = *reinterpret_cast<const u32x4*>(p.x + row * p.Cv + xcol);                                      \
-      xvalid |= (uint32_t)(ok && jcol_ok) << i;                                                              \
+      const bool ok = (xedge[i] & out) == 0;                                                                 \
+      rx[i] = *reinterpret_cast<const u32x4*>(xb + (ok ? xoff[i] : xsafe));                                  \
+      xvalid |= (uint32_t)ok << i;                                                                           \
     }                                                                                                        \
   } while (0)
 
@@ -115,6 +134,17 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
       if (r < XROWS) *reinterpret_cast<u32x4*>(xs + x_off(r, pc * 8)) = keep_if((xvalid >> i) & 1u, rx[i]);  \
     }                                                                                                        \
   } while (0)
+
+  // lane parts of the fragment addresses (see the brick loop)
+  int abase[4], xbase[6];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) abase[f] = dy_off(8 * lg + jr, f * 16 + 4 * cq);
+#pragma unroll
+  for (int ci = 0; ci < 6; ++ci) {
+    const int c = ci < 3 ? ci : ci + 1;   // R mod 8 is one of 0,1,2,4,5,6 (R = 12 a + b, b < 3)
+    const int lrow = lg * XW + jr, col = wid * 16 + 4 * cq;
+    xbase[ci] = lrow * 128 + ((((col >> 4) ^ ((c + lrow) >> 1)) & 3) << 5) + ((col & 15) << 1);
+  }
 
   if (b_beg < b_end) {
     WB_LOAD(b_beg);
@@ -132,12 +162,17 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
     // the LDS latency: the naive order (read, wait, 4 MFMAs) ran the matrix pipe at ~40 % inside this phase.
     // lane's voxels of K-chunk kc: v = 32*kc + 8*lg + 4*q + jr (q = 0,1 = the two transpose reads);
     // halo row of voxel (vd, vh, vw) at tap (kh, kw): (vd*XH + vh + kh)*XW + vw + kw.
-#define WB_A(kc_, f_) tr_frag(dys + dy_off(32 * (kc_) + 8 * lg + jr, (f_)*16 + 4 * cq), dys + dy_off(32 * (kc_) + 8 * lg + jr + 4, (f_)*16 + 4 * cq))
-#define WB_XROW(kc_, t_) ((((kc_) >> 1) * XH + ((kc_)&1) * 4 + lg + (t_) / 3) * XW + jr + (t_) % 3)
-#define WB_B(kc_, t_) tr_frag(xs + x_off(WB_XROW(kc_, t_), wid * 16 + 4 * cq), xs + x_off(WB_XROW(kc_, t_) + 4, wid * 16 + 4 * cq))
-    bf16x8 fa[4], fan[4], fbr[3];   // fbr: 3-deep ring, the x fragment is fetched TWO steps (8 MFMAs, ~130 cycles) ahead of its use
+    // Fragment addresses without per-read arithmetic: a read's row = (block-uniform, compile-time) R + the lane's row, and
+    // the XOR swizzle only looks at row bits 1-2 (x) / voxel bits 1,3 (dy).  So the lane part -- including the swizzle for
+    // each residue of R mod 8 -- is precomputed (abase[4], xbase[6], before the brick loop) and R * 128 goes into the
+    // instruction's immediate offset.  One wave per SIMD issues in order: every VALU saved here is an issue slot for an MFMA.
+#define WB_A(kc_, f_) tr_frag(dys + abase[f_] + (kc_)*4096, dys + abase[f_] + (kc_)*4096 + 512)
+#define WB_XR(kc_, t_) ((((kc_) >> 1) * XH + ((kc_)&1) * 4 + (t_) / 3) * XW + (t_) % 3)
+#define WB_XADDR(r_) (xs + xbase[((r_)&7) < 3 ? ((r_)&7) : ((r_)&7) - 1] + (r_)*128)
+#define WB_B(kc_, t_) tr_frag(WB_XADDR(WB_XR(kc_, t_)), WB_XADDR(WB_XR(kc_, t_) + 4))
+    bf16x8 fa[2][4], fbr[3];   // fbr: 3-deep ring, the x fragment is fetched TWO steps (8 MFMAs, ~130 cycles) ahead of its use
 #pragma unroll
-    for (int f = 0; f < 4; ++f) fa[f] = WB_A(0, f);
+    for (int f = 0; f < 4; ++f) fa[0][f] = WB_A(0, f);
     fbr[0] = WB_B(0, 0);
     fbr[1] = WB_B(0, 1);
 #pragma unroll
@@ -146,19 +181,16 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
       if (st + 2 < 36) fbr[(st + 2) % 3] = WB_B((st + 2) / 9, (st + 2) % 9);
       if (t == 4 && kc < 3) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) fan[f] = WB_A(kc + 1, f);
+        for (int f = 0; f < 4; ++f) fa[(kc + 1) & 1][f] = WB_A(kc + 1, f);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this step's MFMAs (hipcc sinks them next to their use otherwise)
 #pragma unroll
-      for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[f], fbr[st % 3], acc[t][f], 0, 0, 0);
+      for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st % 3], acc[t][f], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (t == 8 && kc < 3) {
-#pragma unroll
-        for (int f = 0; f < 4; ++f) fa[f] = fan[f];
-      }
     }
 #undef WB_A
-#undef WB_XROW
+#undef WB_XR
+#undef WB_XADDR
 #undef WB_B
 
     __builtin_amdgcn_sched_barrier(0);
