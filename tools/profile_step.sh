@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence kept under profiles/: kernel stats + three PMC passes of the default bench command.
+#   gpurun -- 'tools/profile_step.sh <tag>'   then   python tools/summarize_profiles.py <tag> ... (see that file)
+TAG=${1:-prof}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/stats -- $B > $R/gpurun_out/$TAG.stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$TAG/fetch -- $B > $R/gpurun_out/$TAG.fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$TAG/write -- $B > $R/gpurun_out/$TAG.write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/$TAG/sq -- $B > $R/gpurun_out/$TAG.sq.log 2>&1
+find $R/gpurun_out/$TAG -name "*.csv" | grep -v agent_info | xargs ls -la | awk '{print $5, $9}'
+# the counter CSVs hold one row per dispatch and counter: keep only the two big kernels (the merge-back limit is 64 MiB)
+for d in fetch write sq; do
+  f=$(find $R/gpurun_out/$TAG/$d -name "*counter_collection.csv")
+  head -1 $f > $R/gpurun_out/$TAG/$d.csv
+  grep "brick_conv_kernel\|wgrad_brick_kernel" $f >> $R/gpurun_out/$TAG/$d.csv
+  rm -f $f $(find $R/gpurun_out/$TAG/$d -name "*kernel_trace.csv")
+done
