@@ -35,13 +35,13 @@ FLOP_PER_CROP = 1.2707e12   # fwd+bwd of one crop (2 global + 6 local views), SU
 def conv_key(name, args):
     """Classify a pcrl_conv3d_k3_fwd launch the way the library's dispatcher does (conv_igemm.hip / conv_brick.hip) and
     return its algorithmic FLOPs (2 * voxels * 27 * Ci * Co)."""
-    # pcrl_conv3d_k3_fwd(x, wp, bias, y, stats, N, D, H, W, Ci, Co, dtype, stream)
-    N, D, H, W, Ci, Co, dt = args[5:12]
+    # pcrl_conv3d_k3_fwd_ws(x, wp, bias, y, stats, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)   [_fwd: without ws, ws_bytes]
+    N, D, H, W, Ci, Co, dt = args[7:14] if name == "pcrl_conv3d_k3_fwd_ws" else args[5:12]
     if dt == 1 and D % 4 == 0 and H % 8 == 0 and W % 8 == 0 and Co % 32 == 0:
         key = "brick_conv_kernel"
     else:
         bn = 128 if Co % 128 == 0 else (64 if Co % 64 == 0 else 32)
-        key = "igemm_kernel<%s,%d,conv3>" % ("bf16" if dt == 1 else "f32", bn)
+        key = "igemm_kernel<%s,%d,conv3>(+split-K finish)" % ("bf16" if dt == 1 else "f32", bn)
     return key, 2.0 * N * D * H * W * 27 * Ci * Co
 
 
@@ -56,7 +56,7 @@ def wgrad_key(name, args):
 
 
 def keyfn(name, args):
-    return conv_key(name, args) if name == "pcrl_conv3d_k3_fwd" else wgrad_key(name, args)
+    return conv_key(name, args) if name.startswith("pcrl_conv3d_k3_fwd") else wgrad_key(name, args)
 
 
 def synthetic_batch(b, dhw, local, device, seed):
@@ -138,7 +138,7 @@ def main():
     for _ in range(args.warmup):
         train_step(model, opt, batch, 0, crit, cosine, guard=False)
     L = _lib.lib()
-    prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_wgrad"}, keyfn)
+    prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad"}, keyfn)
     import gc
     gc.collect()
     if os.environ.get("PCRL_BENCH_NOGC", "0") == "1":

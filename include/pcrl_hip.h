@@ -64,6 +64,14 @@ int pcrl_pack_convt_weight(const float* w_ref, void* w_fwd, void* w_dgrad, int C
 int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype);
 int pcrl_conv3d_k3_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial,
                        int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
+/* Same operation with a caller-provided workspace: volumes too small to fill the chip with 128-voxel tiles (the 8x8x4 bottleneck
+ * level at b=32; the 4^3 / 2^3 levels of the 16^3 local views, train_3d.py:118-121) are then split along K = 27 taps x Ci/32
+ * into float partial sums in `ws`, combined in fixed order by a second pass that also adds the bias, rounds and emits
+ * `stats_partial` (same layout and row count as the one-pass kernel).  `pcrl_conv3d_k3_fwd_ws_bytes` returns the size needed
+ * (0: the shape is not split; `ws` may then be NULL). */
+int64_t pcrl_conv3d_k3_fwd_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype);
+int pcrl_conv3d_k3_fwd_ws(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, void* ws, int64_t ws_bytes,
+                          int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
 
 /* Weight gradient (aten::convolution_backward, weight half).  dw_ref[co][ci][27] float32, reference layout.
  * Split-K over voxels with a fixed-order second pass.  ws: pcrl_conv3d_k3_wgrad_ws_bytes(). */
@@ -129,6 +137,7 @@ int pcrl_bn_finalize(const float* partial, int rows, int C, double count, const 
                      float* mean, float* rstd, float* scale, float* shift, pcrl_stream_t stream);
 int pcrl_bn_act_apply(const void* y, void* a, const float* scale, const float* shift,
                       int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
+/* rows of `partial` for bwd_reduce: ceil(M / tile), tile = 1024 rows for M >= 2^20, halved down to 32 for smaller M */
 int64_t pcrl_bn_bwd_partial_rows(int64_t M);
 int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, const float* shift,
                            const float* mean, const float* rstd, float* partial,

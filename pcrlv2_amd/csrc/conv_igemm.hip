@@ -35,6 +35,8 @@ struct IgemmParams {
   int K;              // channels per tap
   int Nc;             // output channels
   int taps;           // taps accumulated inside one GEMM (27, 1 or 8)
+  float* ws;          // split-K (GEOM_CONV3 only): [gridDim.z][M][Nc] float partial sums, or null
+  int steps_per_split;
 };
 
 // [rows][32] of T, 16-byte slots XOR-swizzled by row.  ds_read_b128 on gfx950 is serviced in four NON-contiguous 16-lane
@@ -105,7 +107,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   const int lr = lane & 15, lg = lane >> 4;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int z = blockIdx.z;
+  const int z = (GEOM == GEOM_CONV3) ? 0 : blockIdx.z;   // convT forward: tap; conv3: blockIdx.z = K split
   const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ Wp = reinterpret_cast<const T*>(p.w);
   const Dims g = p.g;
@@ -153,7 +155,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = K / 32;
-  const int S = p.taps * nchunk;
+  const int s_off = (GEOM == GEOM_CONV3 && p.ws) ? blockIdx.z * p.steps_per_split : 0;   // first K-step of this split
+  const int S = (GEOM == GEOM_CONV3 && p.ws) ? min(p.steps_per_split, p.taps * nchunk - s_off) : p.taps * nchunk;
   // Two staging register sets: the loads of K-step s+2 are issued while step s is multiplied and step s+1 waits in the
   // other set, so a load has two MFMA phases to land.
   u32x4 raA[AP], rbA[BP], raB[AP], rbB[BP];
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   // step -> (tap, chunk), clamped to the last step (the tail re-loads a valid step; its data is never used)
 #define STEP_TC(s_, t_, c_)                                                                             \
   do {                                                                                                  \
-    const int ss_ = (s_) < S ? (s_) : S - 1;                                                            \
+    const int ss_ = s_off + ((s_) < S ? (s_) : S - 1);                                                  \
     t_ = ss_ / nchunk;                                                                                  \
     c_ = ss_ - t_ * nchunk;                                                                             \
   } while (0)
@@ -261,6 +264,20 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         }
       }
     }
+    return;
+  }
+  if (GEOM == GEOM_CONV3 && p.ws) {   // split-K: raw float partial sums; bias, rounding and statistics happen in the finish pass
+    float* __restrict__ Z = p.ws + (int64_t)blockIdx.z * p.M * p.Nc;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + wm * 64 + i * 16 + lg * 4 + r;
+        if (m < p.M) {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) Z[m * p.Nc + n0 + wn * (BN / 2) + j * 16 + lr] = acc[i][j][r];
+        }
+      }
     return;
   }
   // ---- epilogue: bias, store, BN statistics ----
@@ -349,6 +366,67 @@ int check_dims(const char* what, int N, int D, int H, int W, int Ci, int Co) {
   return 0;
 }
 
+// Second pass of the split-K convolution: y = bias + sum over splits, rounded to T; (sum, sum^2) per 128-row tile and channel
+// from the float sums, in the layout of the one-pass epilogue.  Thread = 4 consecutive channels x a row group.
+template <typename T>
+__global__ void __launch_bounds__(256) igemm_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                                  T* __restrict__ y, float* __restrict__ stats, int64_t M, int Nc,
+                                                                  int splits) {
+  __shared__ float red[256 * 8];
+  const int ncg = Nc / 4, cg = threadIdx.x % ncg, rg = threadIdx.x / ncg, nrg = 256 / ncg;
+  const int64_t m0 = (int64_t)blockIdx.x * PCRL_CONV_BM;
+  f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + cg * 4);
+  f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  for (int r = rg; r < PCRL_CONV_BM; r += nrg) {
+    const int64_t m = m0 + r;
+    if (m >= M) break;
+    f32x4 v = bv;
+    for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)z * M + m) * Nc + cg * 4);
+    T* dst = y + m * Nc + cg * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = from_f<T>(v[q]);
+    s1 += v;
+    s2 += v * v;
+  }
+  if (stats) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      red[(threadIdx.x * 4 + q) * 2 + 0] = s1[q];
+      red[(threadIdx.x * 4 + q) * 2 + 1] = s2[q];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Nc; c += 256) {
+      float a = 0.f, b = 0.f;
+      for (int g = 0; g < nrg; ++g) {
+        const int t = g * ncg + c / 4;
+        a += red[(t * 4 + (c & 3)) * 2 + 0];
+        b += red[(t * 4 + (c & 3)) * 2 + 1];
+      }
+      stats[((int64_t)blockIdx.x * Nc + c) * 2 + 0] = a;
+      stats[((int64_t)blockIdx.x * Nc + c) * 2 + 1] = b;
+    }
+  }
+}
+
+// Split-K plan of the gather kernel for a 3x3x3 convolution: volumes too small to fill the chip with 128-row tiles
+// (8x8x4 crops at b=32: 128 blocks of 216 K-steps) are cut along K = 27 taps x Ci/32 chunks.
+struct SplitPlan {
+  int splits, steps_per_split;
+};
+static SplitPlan splitk_plan(int64_t M, int Ci, int Co) {
+  const int bn = Co % 128 == 0 ? 128 : (Co % 64 == 0 ? 64 : 32);
+  const int64_t blocks = ((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM) * (Co / bn);
+  const int steps = 27 * (Ci / 32);
+  const bool shape_ok = (Co / 4) <= 256 && 256 % (Co / 4) == 0;
+  if (blocks >= 256 || !shape_ok) return SplitPlan{1, steps};
+  int splits = (int)((640 + blocks - 1) / blocks);
+  if (splits > steps / 8) splits = steps / 8;   // at least 8 K-steps per split
+  if (splits < 2) return SplitPlan{1, steps};
+  const int per = (steps + splits - 1) / splits;
+  return SplitPlan{(steps + per - 1) / per, per};
+}
+
 }  // namespace
 
 // LDS-halo brick kernel (conv_brick.hip)
@@ -368,14 +446,46 @@ extern "C" int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci,
   return ((int64_t)N * D * H * W + PCRL_CONV_BM - 1) / PCRL_CONV_BM;
 }
 
-extern "C" int pcrl_conv3d_k3_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial,
-                                  int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+static int conv3d_k3_fwd_impl(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, void* ws, int64_t ws_bytes,
+                             int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_dims("conv3d_k3_fwd", N, D, H, W, Ci, Co)) return e;
   PCRL_REQUIRE(x && wp && y, "conv3d_k3_fwd: null pointer");
   if (g_conv_impl == 0 && pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype))
     return pcrl_brick_conv_launch(x, wp, bias, y, stats_partial, N, D, H, W, Ci, Co, as_stream(stream));
-  IgemmParams p{x, wp, bias, y, stats_partial, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 27};
+  const int64_t M = (int64_t)N * D * H * W;
+  IgemmParams p{x, wp, bias, y, stats_partial, Dims{N, D, H, W}, M, Ci, Co, 27, nullptr, 0};
+  const SplitPlan sp = splitk_plan(M, Ci, Co);
+  if (ws && sp.splits > 1 && g_conv_impl != 2) {
+    PCRL_REQUIRE(ws_bytes >= (int64_t)sp.splits * M * Co * 4, "conv3d_k3_fwd: workspace too small (%lld bytes)", (long long)ws_bytes);
+    p.ws = static_cast<float*>(ws);
+    p.steps_per_split = sp.steps_per_split;
+    if (int e = dispatch<GEOM_CONV3>(p, sp.splits, dtype, as_stream(stream))) return e;
+    const dim3 grid((unsigned)((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM));
+    if (dtype == PCRL_BF16)
+      hipLaunchKernelGGL(igemm_splitk_finish_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), p.ws, bias, (bf16*)y, stats_partial, M, Co, sp.splits);
+    else
+      hipLaunchKernelGGL(igemm_splitk_finish_kernel<float>, grid, dim3(256), 0, as_stream(stream), p.ws, bias, (float*)y, stats_partial, M, Co, sp.splits);
+    return pcrl_check_launch("conv3d_k3_fwd (split-K finish)");
+  }
   return dispatch<GEOM_CONV3>(p, 1, dtype, as_stream(stream));
+}
+
+extern "C" int pcrl_conv3d_k3_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial,
+                                  int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  return conv3d_k3_fwd_impl(x, wp, bias, y, stats_partial, nullptr, 0, N, D, H, W, Ci, Co, dtype, stream);
+}
+
+extern "C" int64_t pcrl_conv3d_k3_fwd_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 32 != 0 || Co % 32 != 0) return 0;
+  if (g_conv_impl == 0 && pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype)) return 0;
+  const int64_t M = (int64_t)N * D * H * W;
+  const SplitPlan sp = splitk_plan(M, Ci, Co);
+  return sp.splits > 1 ? (int64_t)sp.splits * M * Co * 4 : 0;
+}
+
+extern "C" int pcrl_conv3d_k3_fwd_ws(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, void* ws,
+                                     int64_t ws_bytes, int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  return conv3d_k3_fwd_impl(x, wp, bias, y, stats_partial, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream);
 }
 
 extern "C" int pcrl_convt3d_k2s2_fwd(const void* x, const void* wp_fwd, const float* bias, void* y,
@@ -384,7 +494,7 @@ extern "C" int pcrl_convt3d_k2s2_fwd(const void* x, const void* wp_fwd, const fl
   PCRL_REQUIRE(x && wp_fwd && y, "convt3d_k2s2_fwd: null pointer");
   if (g_conv_impl == 0 && pcrl_convt_up2_eligible(Ci, Co, dtype))
     return pcrl_convt_up2_launch(x, wp_fwd, bias, y, N, D, H, W, Ci, Co, as_stream(stream));
-  IgemmParams p{x, wp_fwd, bias, y, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 1};
+  IgemmParams p{x, wp_fwd, bias, y, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 1, nullptr, 0};
   return dispatch<GEOM_UP2_FWD>(p, 8, dtype, as_stream(stream));
 }
 
@@ -393,7 +503,7 @@ extern "C" int pcrl_convt3d_k2s2_dgrad(const void* dy, const void* wp_dgrad, voi
   if (int e = check_dims("convt3d_k2s2_dgrad", N, D, H, W, Ci, Co)) return e;
   PCRL_REQUIRE(dy && wp_dgrad && dx, "convt3d_k2s2_dgrad: null pointer");
   // rows = input voxels, K per tap = Co (channels of dy), output channels = Ci
-  IgemmParams p{dy, wp_dgrad, nullptr, dx, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Co, Ci, 8};
+  IgemmParams p{dy, wp_dgrad, nullptr, dx, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Co, Ci, 8, nullptr, 0};
   return dispatch<GEOM_UP2_DGRAD>(p, 1, dtype, as_stream(stream));
 }
 

@@ -196,7 +196,9 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         wf, _ = packed.get(conv_w, dtype)
         y = new_act(N, D, H, W, Co, dtype, dev)
         partial = _f32(rows * Co * 2, dev)
-        L.call("pcrl_conv3d_k3_fwd", x, wf, conv_b.detach(), y, partial, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+        nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
+        L.call("pcrl_conv3d_k3_fwd_ws", x, wf, conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb, N, D, H, W, Ci, Co,
+               dtype_code(dtype), s)
         mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var)
         a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
         sv.kind = "gemm"
@@ -240,7 +242,8 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
     if need_dx:
         _, wd = packed.get(conv_w, dtype)
         dx = new_act(N, D, H, W, Ci, dtype, dev)
-        L.call("pcrl_conv3d_k3_fwd", dy, wd, None, dx, None, N, D, H, W, Co, Ci, dtype_code(dtype), s)
+        nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Co, Ci, dtype_code(dtype))
+        L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, None, workspace(nb, dev) if nb else None, nb, N, D, H, W, Co, Ci, dtype_code(dtype), s)
     return dx, dw, db, dgamma, dbeta
 
 

@@ -27,7 +27,10 @@ def test_library_exports_every_declared_symbol():
     assert "gfx950" in L.version()
     # workspace-size helpers are pure host functions: callable without a GPU
     assert L.call("pcrl_conv3d_k3_wgrad_ws_bytes", 2, 16, 16, 16, 64, 64) > 0
-    assert L.call("pcrl_bn_bwd_partial_rows", 5000) == 5
+    assert L.call("pcrl_bn_bwd_partial_rows", 1 << 22) == 4096      # 1024-row tiles on the big volumes
+    assert L.call("pcrl_bn_bwd_partial_rows", 5000) == 157          # 32-row tiles: small volumes still spread over the chip
+    assert L.call("pcrl_conv3d_k3_fwd_ws_bytes", 32, 8, 8, 4, 256, 256, 1) > 0   # 8x8x4 bottleneck level: split-K
+    assert L.call("pcrl_conv3d_k3_fwd_ws_bytes", 32, 64, 64, 32, 64, 64, 1) == 0
 
 
 def test_error_path_reports_message():

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from pcrlv2_amd import ops  # noqa: E402
-from pcrlv2_amd._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_BM, dtype_code, lib, stream_handle  # noqa: E402
+from pcrlv2_amd._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_BM, PcrlError, dtype_code, lib, stream_handle  # noqa: E402
 
 DEV = "cuda"
 DTYPES = [torch.float32, torch.bfloat16]
@@ -106,6 +106,37 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
     L.debug_set_conv_impl(0)
     check(y, ref, dt, "conv3 fwd (gather kernel)")
     check(back(part1).view(rows1, Co, 2).sum(0)[:, 0], ref.sum(dim=(0, 2, 3, 4)), dt, "conv3 stats (gather)", out_rounded=False, f32_tol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(4, 8, 8, 4, 64, 128), (3, 2, 2, 2, 96, 64), (2, 4, 4, 4, 256, 32)])
+def test_conv3d_small_volume_split_k(shape, dt):
+    """pcrl_conv3d_k3_fwd_ws: the K-split gather path of small volumes (8x8x4 bottleneck, 4^3 / 2^3 local-view levels) must give
+    the one-pass result: output, bias, and the BatchNorm partial statistics (same row count)."""
+    N, D, H, W, Ci, Co = shape
+    L, s = lib(), stream_handle()
+    x, w, b = rnd(N, Ci, D, H, W, seed=11), rnd(Co, Ci, 3, 3, 3, seed=12, scale=0.1), rnd(Co, seed=13)
+    ref = F.conv3d(q(x, dt), q(w, dt), b, padding=1)
+    wf, _ = ops.PackedWeights("conv3").get(w.float().to(DEV), dt)
+    xa = act_dev(x, dt)
+    rows = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Ci, Co, dtype_code(dt))
+    nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dt))
+    assert nb > 0, "these shapes are expected to take the split-K path"
+    y = ops.new_act(N, D, H, W, Co, dt, DEV)
+    part = torch.zeros(rows * Co * 2, dtype=torch.float32, device=DEV)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    L.call("pcrl_conv3d_k3_fwd_ws", xa, wf, b.float().to(DEV), y, part, ws, nb, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    check(y, ref, dt, "conv3 fwd (split-K)")
+    st = back(part).view(rows, Co, 2).sum(0)
+    check(st[:, 0], ref.sum(dim=(0, 2, 3, 4)), dt, "conv3 stats sum (split-K)", out_rounded=False, f32_tol=1e-4)
+    check(st[:, 1], (ref * ref).sum(dim=(0, 2, 3, 4)), dt, "conv3 stats sumsq (split-K)", out_rounded=False, f32_tol=1e-4)
+    # one-pass kernel on the same input: same rounding points except the K-summation order
+    y1 = ops.new_act(N, D, H, W, Co, dt, DEV)
+    L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y1, None, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    d = (back(y).float() - back(y1).float()).abs().max().item()
+    assert d <= (2e-4 if dt == torch.float32 else 0.05), d
+    with pytest.raises(PcrlError):
+        L.call("pcrl_conv3d_k3_fwd_ws", xa, wf, None, y, None, ws, 16, N, D, H, W, Ci, Co, dtype_code(dt), s)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -74,9 +74,13 @@ def main():
                 for impl in impls:
                     L.debug_set_conv_impl(impl)
                     if kind == "fwd":
-                        fn = lambda: L.call("pcrl_conv3d_k3_fwd", x, wf, None, y, st, N, D, H, W, Ci, Co, dtype_code(dt), s)
+                        nbf = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dt))
+                        wsf = ops.workspace(nbf, dev) if nbf else None
+                        fn = lambda: L.call("pcrl_conv3d_k3_fwd_ws", x, wf, None, y, st, wsf, nbf, N, D, H, W, Ci, Co, dtype_code(dt), s)
                     else:
-                        fn = lambda: L.call("pcrl_conv3d_k3_fwd", dy, wd, None, dx, None, N, D, H, W, Co, Ci, dtype_code(dt), s)
+                        nbd = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Co, Ci, dtype_code(dt))
+                        wsd = ops.workspace(nbd, dev) if nbd else None
+                        fn = lambda: L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, None, wsd, nbd, N, D, H, W, Co, Ci, dtype_code(dt), s)
                     med, mn = timed(fn, args.rounds)
                     line += f" {kind}[{impl}] {med:7.3f} ms {flops / med / 1e9:6.0f} TF |"
                     tot[(kind, impl)] = tot.get((kind, impl), 0.0) + med
