@@ -37,6 +37,7 @@ _FLAGS = (
     ("seed", 42, int, "python/torch seed"),
     ("amp", False, None, "bfloat16 activations and MFMA operands"),
     ("steps_per_epoch", 16, int, "only with --data synthetic"),
+    ("resume", "", str, "checkpoint to continue from (model, momentum buffers, epoch)"),
 )
 
 

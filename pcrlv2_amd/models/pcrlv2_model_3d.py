@@ -190,6 +190,16 @@ class PCRLv23d(nn.Module):
         self.flush_counters()
         return super().state_dict(*args, **kwargs)
 
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """In-place copy like nn.Module's (parameters may live in FusedSGD's flat arena), plus the two things the engine caches:
+        pending `num_batches_tracked` bumps are dropped (the loaded counters win) and packed weights are invalidated."""
+        for m in self.modules():
+            if isinstance(m, _Counted):
+                m._pending = 0
+        out = super().load_state_dict(state_dict, *args, **kwargs)
+        ops.bump_weights_epoch()
+        return out
+
     def forward(self, x, local=False):
         """-> (out [b,1,D,H,W], [[pro, pre] x 3 scales], [mask x 3] or [] when local)"""
         if not self.training:

@@ -74,6 +74,27 @@ class FusedSGD(torch.optim.SGD):
         return t
 
     @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """torch.optim.SGD layout in ('momentum_buffer' per parameter, e.g. from a checkpoint written by the reference or by
+        this class, train_3d.py:71-82); the buffers are copied into the flat arena the kernel updates."""
+        super().load_state_dict(state_dict)
+        if len(self.param_groups) != 1:
+            raise ValueError("FusedSGD supports a single param group")
+        for i, p in enumerate(self._plist):
+            buf = self.state.get(p, {}).get("momentum_buffer")
+            o, n = self._offsets_host[i], p.numel()
+            view = self.flat_buf[o:o + n].view(p.shape)
+            if buf is None:
+                view.zero_()
+                self._initialised[i] = False
+                self.state.pop(p, None)
+            else:
+                view.copy_(buf.to(device=view.device, dtype=torch.float32))
+                self.state[p]["momentum_buffer"] = view
+                self._initialised[i] = True
+        self._flag_cache.clear()
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:

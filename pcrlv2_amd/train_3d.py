@@ -12,7 +12,9 @@ assembly, LR schedule, log line, checkpoint dict and file name.  Differences, al
     (the reference calls .item() twice and cuda.synchronize() every iteration);
   * the divergence guard (train_3d.py:140-142) is evaluated as `epoch > 10 and loss > 1000`, so the device->host read
     happens only when the reference would act on it;
-  * `--seed`, ignored by the reference, seeds python `random` (the scale draws) and torch.
+  * `--seed`, ignored by the reference (SURVEY Q5), seeds python `random` (the scale draws) and torch;
+  * `--resume CKPT` (not in the reference, which only saves): restores model, momentum buffers and epoch from a checkpoint of
+    the layout above -- written by this engine or by the reference -- and continues with the next epoch.
 """
 from __future__ import print_function
 
@@ -114,6 +116,17 @@ def _checkpoint_name(args, epoch):
     return os.path.join(args.output, "{}_{}_{}_{}_{}.pt".format(args.model, args.n, args.phase, args.ratio, epoch))
 
 
+def load_checkpoint(path, model, optimizer=None):
+    """Load a checkpoint of the layout train_3d.py:71-82 writes ({'opt','state_dict','optimizer','epoch'}); keys saved from a
+    DataParallel-wrapped model ('module.' prefix, train_3d.py:54) are accepted.  Returns the stored epoch."""
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    sd = {(k[7:] if k.startswith("module.") else k): v for k, v in ckpt["state_dict"].items()}
+    model.load_state_dict(sd)
+    if optimizer is not None and ckpt.get("optimizer") is not None:
+        optimizer.load_state_dict(ckpt["optimizer"])
+    return int(ckpt.get("epoch", -1))
+
+
 def train_pcrlv2_3d(args, data_loader, out_channel=3):
     distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
     rank = 0
@@ -129,8 +142,13 @@ def train_pcrlv2_3d(args, data_loader, out_channel=3):
         _ddp.DataParallel(model, optimizer)          # hooks itself into optimizer.step()
     criterion, cosine = MSELoss().cuda(), CosineSimilarityMean().cuda()
     chatty = rank == 0
+    first_epoch = 0
+    if getattr(args, "resume", None):
+        first_epoch = load_checkpoint(args.resume, model, optimizer) + 1
+        if chatty:
+            print("==> resumed from {} (continuing with epoch {})".format(args.resume, first_epoch))
 
-    for epoch in range(0, args.epochs + 1):          # inclusive upper bound, like the reference (Q1): lr reaches 0 in the last epoch
+    for epoch in range(first_epoch, args.epochs + 1):          # inclusive upper bound, like the reference (Q1): lr reaches 0 in the last epoch
         adjust_learning_rate(epoch, args, optimizer)
         if chatty:
             print("==> training...")

@@ -443,3 +443,48 @@ def test_config_c4_large_crops_step_properties():
         del model, opt
         torch.cuda.empty_cache()
     assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_checkpoint_resume_continues_bit_exactly(dt, tmp_path):
+    """a checkpoint of the reference's layout (train_3d.py:71-82: {'opt','state_dict','optimizer','epoch'} with
+    torch.optim.SGD's state layout) written after two steps, loaded into a FRESH model + FusedSGD, must continue exactly like
+    the uninterrupted run: parameters, BatchNorm buffers (running stats, num_batches_tracked) and momentum buffers after two
+    more steps are bit-identical (the engine is deterministic; the python RNG state is carried by the test)."""
+    from pcrlv2_amd.train_3d import load_checkpoint
+    b, dhw = 2, (32, 32, 16)
+    batches = [O.fill_batch(b, dhw, dtype=torch.float32, seed=40 + s) for s in range(4)]
+    crit, cosine = MSELoss(), CosineSimilarityMean()
+
+    def fresh():
+        m = build(dt)
+        return m, FusedSGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+
+    random.seed(5)
+    model, opt = fresh()
+    for s in range(2):
+        train_step(model, opt, batches[s], 3, crit, cosine)
+    path = str(tmp_path / "pcrlv2_luna_pretask_1.0_3.pt")
+    torch.save({"opt": None, "state_dict": model.state_dict(), "optimizer": opt.state_dict(), "epoch": 3}, path)
+    rng = random.getstate()
+    for s in range(2, 4):
+        train_step(model, opt, batches[s], 3, crit, cosine)
+    want_sd = {k: v.clone() for k, v in model.state_dict().items()}
+    want_mom = opt.flat_buf.clone()
+
+    model2, opt2 = fresh()
+    train_step(model2, opt2, batches[3], 3, crit, cosine)      # dirty the fresh engine state first (packed weights, counters, momentum)
+    assert load_checkpoint(path, model2, opt2) == 3
+    random.setstate(rng)
+    for s in range(2, 4):
+        train_step(model2, opt2, batches[s], 3, crit, cosine)
+    got_sd = model2.state_dict()
+    assert list(got_sd) == list(want_sd)
+    for k in want_sd:
+        assert torch.equal(got_sd[k], want_sd[k]), k
+    assert torch.equal(opt2.flat_buf, want_mom)
+    # the optimizer state written by FusedSGD is torch.optim.SGD's: a stock SGD over the same parameters accepts it
+    stock = torch.optim.SGD(model2.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    saved = torch.load(path, weights_only=False)["optimizer"]
+    stock.load_state_dict(saved)
+    assert len(stock.state) == len(saved["state"]) > 0   # (parameters that had no gradient yet have no buffer, as in torch)
