@@ -221,7 +221,13 @@ struct BrickSplit {
 };
 BrickSplit plan(int nbricks, int Cu, int Cv) {
   const int tiles = (Cu / 64) * ((Cv + 63) / 64) * 3;
-  int splits = 768 / tiles;   // ~3 blocks per CU in flight; fewer splits = smaller partial slabs for the second pass
+  // One block per CU (one wave per SIMD, 256 CUs): the grid should be a whole number of rounds of 256 blocks -- 384 blocks run
+  // as long as 512.  Fewer rounds = fewer partial slabs for the second pass: take the smallest k <= 3 that fills >= 90 %.
+  int splits = 1;
+  for (int k = 1; k <= 3; ++k) {
+    splits = 256 * k / tiles;
+    if (splits >= 1 && tiles * splits * 10 >= 256 * k * 9) break;
+  }
   if (splits < 1) splits = 1;
   if (splits > nbricks / 16) splits = nbricks / 16;   // at least 16 bricks per block (bounds the partial slabs)
   if (splits < 1) splits = 1;
