@@ -367,23 +367,26 @@ int check_dims(const char* what, int N, int D, int H, int W, int Ci, int Co) {
 }
 
 // Second pass of the split-K convolution: y = bias + sum over splits, rounded to T; (sum, sum^2) per 128-row tile and channel
-// from the float sums, in the layout of the one-pass epilogue.  Thread = 4 consecutive channels x a row group.
+// from the float sums, in the layout of the one-pass epilogue.  Block = (128-row tile, chunk of <= 64 channels): small M is
+// exactly where this runs, so the channel chunks are what spreads it over the chip.  Thread = 4 channels x a row group.
 template <typename T>
 __global__ void __launch_bounds__(256) igemm_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                                   T* __restrict__ y, float* __restrict__ stats, int64_t M, int Nc,
                                                                   int splits) {
   __shared__ float red[256 * 8];
-  const int ncg = Nc / 4, cg = threadIdx.x % ncg, rg = threadIdx.x / ncg, nrg = 256 / ncg;
+  const int cw = Nc < 64 ? Nc : 64, c0 = blockIdx.y * cw;
+  const int ncg = cw / 4, cg = threadIdx.x % ncg, rg = threadIdx.x / ncg, nrg = 256 / ncg;
   const int64_t m0 = (int64_t)blockIdx.x * PCRL_CONV_BM;
+  const int col = c0 + cg * 4;
   f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + cg * 4);
+  if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
   f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
   for (int r = rg; r < PCRL_CONV_BM; r += nrg) {
     const int64_t m = m0 + r;
     if (m >= M) break;
     f32x4 v = bv;
-    for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)z * M + m) * Nc + cg * 4);
-    T* dst = y + m * Nc + cg * 4;
+    for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)z * M + m) * Nc + col);
+    T* dst = y + m * Nc + col;
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = from_f<T>(v[q]);
     s1 += v;
@@ -396,15 +399,16 @@ __global__ void __launch_bounds__(256) igemm_splitk_finish_kernel(const float* _
       red[(threadIdx.x * 4 + q) * 2 + 1] = s2[q];
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < Nc; c += 256) {
+    if ((int)threadIdx.x < cw) {
+      const int c = threadIdx.x;
       float a = 0.f, b = 0.f;
       for (int g = 0; g < nrg; ++g) {
         const int t = g * ncg + c / 4;
         a += red[(t * 4 + (c & 3)) * 2 + 0];
         b += red[(t * 4 + (c & 3)) * 2 + 1];
       }
-      stats[((int64_t)blockIdx.x * Nc + c) * 2 + 0] = a;
-      stats[((int64_t)blockIdx.x * Nc + c) * 2 + 1] = b;
+      stats[((int64_t)blockIdx.x * Nc + c0 + c) * 2 + 0] = a;
+      stats[((int64_t)blockIdx.x * Nc + c0 + c) * 2 + 1] = b;
     }
   }
 }
@@ -418,9 +422,9 @@ static SplitPlan splitk_plan(int64_t M, int Ci, int Co) {
   const int bn = Co % 128 == 0 ? 128 : (Co % 64 == 0 ? 64 : 32);
   const int64_t blocks = ((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM) * (Co / bn);
   const int steps = 27 * (Ci / 32);
-  const bool shape_ok = (Co / 4) <= 256 && 256 % (Co / 4) == 0;
-  if (blocks >= 256 || !shape_ok) return SplitPlan{1, steps};
-  int splits = (int)((640 + blocks - 1) / blocks);
+  const bool shape_ok = Co == 32 || Co % 64 == 0;
+  if (blocks >= 512 || !shape_ok) return SplitPlan{1, steps};
+  int splits = (int)((768 + blocks - 1) / blocks);
   if (splits > steps / 8) splits = steps / 8;   // at least 8 K-steps per split
   if (splits < 2) return SplitPlan{1, steps};
   const int per = (steps + splits - 1) / splits;
@@ -460,7 +464,7 @@ static int conv3d_k3_fwd_impl(const void* x, const void* wp, const float* bias, 
     p.ws = static_cast<float*>(ws);
     p.steps_per_split = sp.steps_per_split;
     if (int e = dispatch<GEOM_CONV3>(p, sp.splits, dtype, as_stream(stream))) return e;
-    const dim3 grid((unsigned)((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM));
+    const dim3 grid((unsigned)((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM), (unsigned)(Co < 64 ? 1 : Co / 64));
     if (dtype == PCRL_BF16)
       hipLaunchKernelGGL(igemm_splitk_finish_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), p.ws, bias, (bf16*)y, stats_partial, M, Co, sp.splits);
     else
