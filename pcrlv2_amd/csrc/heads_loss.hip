@@ -72,26 +72,34 @@ __global__ void __launch_bounds__(256) bn1d_bwd_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // Linear layers of the heads: one small LDS-tiled SGEMM, C[m][n] = sum_k A(m,k) * B(k,n) (+ bias[n]), operands addressed
 // through (row, col) strides so the three products of a Linear (y = x W^T, dx = dy W, dW = dy^T x) share the kernel.
-// 16x16 threads, 32x32 tile, K chunks of 16.  Sizes here: M, N, K <= 512.
+// 16x16 threads, 32x32 tile, K chunks of 64.  Sizes here: M, N, K <= 512.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) sgemm_small_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
                                                           const float* __restrict__ B, int64_t sbk, int64_t sbn,
                                                           const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K) {
-  __shared__ float As[16][33], Bs[16][33];
+  constexpr int KC = 64;   // K chunk: the loop is latency-bound (one global round trip per chunk), so few, fat chunks
+  __shared__ float As[KC][33], Bs[KC][33];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-  for (int k0 = 0; k0 < K; k0 += 16) {
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    float ra[KC / 8], rb[KC / 8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {   // 256 threads load 16x32 of A and of B, two elements each
+    for (int h = 0; h < KC / 8; ++h) {   // 256 threads load KC x 32 of A and of B, KC/8 elements each, all in flight together
       const int idx = threadIdx.x + 256 * h, kk = idx >> 5, mm = idx & 31;
       const int m = m0 + mm, n = n0 + mm, k = k0 + kk;
-      As[kk][mm] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
-      Bs[kk][mm] = (n < N && k < K) ? B[k * sbk + n * sbn] : 0.f;
+      ra[h] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
+      rb[h] = (n < N && k < K) ? B[k * sbk + n * sbn] : 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < KC / 8; ++h) {
+      const int idx = threadIdx.x + 256 * h, kk = idx >> 5, mm = idx & 31;
+      As[kk][mm] = ra[h];
+      Bs[kk][mm] = rb[h];
     }
     __syncthreads();
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
+    for (int kk = 0; kk < KC; ++kk) {
       const float a0 = As[kk][ty], a1 = As[kk][ty + 16], b0 = Bs[kk][tx], b1 = Bs[kk][tx + 16];
       acc[0][0] = fmaf(a0, b0, acc[0][0]);
       acc[0][1] = fmaf(a0, b1, acc[0][1]);
