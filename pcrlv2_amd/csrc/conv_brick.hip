@@ -70,7 +70,11 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 
   // ---- brick origin ----
   const int bw = p.W / TW, bh = p.H / TH, bd = p.D / TD;
+  // consecutive workgroups go to different XCDs (8, each with its own L2): give every XCD a CONTIGUOUS range of bricks so that
+  // the halo rows shared by neighbouring bricks are fetched into one L2 once
   int b = blockIdx.x;
+  if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+  const int brick_id = b;
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
   const int d0 = (b % bd) * TD; b /= bd;
@@ -285,7 +289,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
         a += red[(q * 64 + tid) * 2 + 0];
         c2 += red[(q * 64 + tid) * 2 + 1];
       }
-      float* o = p.stats + ((int64_t)blockIdx.x * p.Nc + n0 + tid) * 2;
+      float* o = p.stats + ((int64_t)brick_id * p.Nc + n0 + tid) * 2;
       o[0] = a;
       o[1] = c2;
     }
