@@ -266,15 +266,16 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 //   ws[(blockIdx.y * gridDim.x + blockIdx.x) * C + c] = sum over the tile's rows of v[n=blockIdx.y][row][c]
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) coltile_sum_kernel(const T* __restrict__ v, float* __restrict__ ws, int64_t rows_per_n, int C) {
+__global__ void __launch_bounds__(256) coltile_sum_kernel(const T* __restrict__ v, float* __restrict__ ws, int64_t rows_per_n, int C,
+                                                         int tile_rows) {
   constexpr int VEC = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C]
   const int tid = threadIdx.x;
   const int nvec = C / VEC;
   const int cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
   const T* base = v + (int64_t)blockIdx.y * rows_per_n * C;
-  const int64_t rbeg = (int64_t)blockIdx.x * TILE_ROWS;
-  const int64_t rend = (rbeg + TILE_ROWS < rows_per_n) ? rbeg + TILE_ROWS : rows_per_n;
+  const int64_t rbeg = (int64_t)blockIdx.x * tile_rows;
+  const int64_t rend = (rbeg + tile_rows < rows_per_n) ? rbeg + tile_rows : rows_per_n;
   float s[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) s[j] = 0.f;
@@ -563,18 +564,28 @@ extern "C" int pcrl_maxpool3d_2_bwd(const void* x, const void* dy, void* dx, int
   return pcrl_check_launch("maxpool_bwd");
 }
 
-extern "C" size_t pcrl_colsum_ws_bytes(int64_t M, int C) { return (size_t)((M + TILE_ROWS - 1) / TILE_ROWS) * C * sizeof(float); }
+// Rows per first-stage tile of the column sums: 1024, halved (down to 32) while the grid would have fewer than 512 blocks.
+static int coltile_rows(int N, int64_t S) {
+  int t = TILE_ROWS;
+  while (t > 32 && (int64_t)N * ((S + t - 1) / t) < 512) t >>= 1;
+  return t;
+}
+static int64_t coltile_tiles(int N, int64_t S) {
+  const int t = coltile_rows(N, S);
+  return (S + t - 1) / t;
+}
+extern "C" size_t pcrl_colsum_ws_bytes(int64_t M, int C) { return (size_t)coltile_tiles(1, M) * C * sizeof(float); }
 
 static int coltile_launch(const void* v, float* out, void* ws, size_t ws_bytes, int N, int64_t S, int C, int dtype, double scale,
                           hipStream_t stream, const char* what) {
   if (int e = check_tilevec(what, C, dtype, false)) return e;
-  const int64_t tiles = (S + TILE_ROWS - 1) / TILE_ROWS;
+  const int64_t tiles = coltile_tiles(N, S);
   const size_t need = (size_t)N * tiles * C * sizeof(float);
   if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "%s: workspace %zu < %zu", what, ws_bytes, need);
   const size_t lds = (size_t)(256 / (C / (dtype == PCRL_BF16 ? 8 : 4))) * C * sizeof(float);
   const dim3 grid((unsigned)tiles, (unsigned)N);
-  if (dtype == PCRL_BF16) hipLaunchKernelGGL(coltile_sum_kernel<bf16>, grid, dim3(256), lds, stream, (const bf16*)v, (float*)ws, S, C);
-  else hipLaunchKernelGGL(coltile_sum_kernel<float>, grid, dim3(256), lds, stream, (const float*)v, (float*)ws, S, C);
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(coltile_sum_kernel<bf16>, grid, dim3(256), lds, stream, (const bf16*)v, (float*)ws, S, C, coltile_rows(N, S));
+  else hipLaunchKernelGGL(coltile_sum_kernel<float>, grid, dim3(256), lds, stream, (const float*)v, (float*)ws, S, C, coltile_rows(N, S));
   if (int e = pcrl_check_launch(what)) return e;
   hipLaunchKernelGGL(coltile_finish_kernel, dim3((C + 31) / 32, N), dim3(256), 0, stream, (const float*)ws, out, (int)tiles, C, N, scale);
   return pcrl_check_launch(what);
@@ -585,7 +596,7 @@ extern "C" int pcrl_colsum(const void* v, float* out, void* ws, size_t ws_bytes,
   return coltile_launch(v, out, ws, ws_bytes, 1, M, C, dtype, 1.0, as_stream(stream), "colsum");
 }
 
-extern "C" size_t pcrl_gap_ws_bytes(int N, int64_t S, int C) { return (size_t)N * ((S + TILE_ROWS - 1) / TILE_ROWS) * C * sizeof(float); }
+extern "C" size_t pcrl_gap_ws_bytes(int N, int64_t S, int C) { return (size_t)N * coltile_tiles(N, S) * C * sizeof(float); }
 
 extern "C" int pcrl_gap_fwd(const void* a, float* g, void* ws, size_t ws_bytes, int N, int64_t S, int C, int dtype, pcrl_stream_t stream) {
   PCRL_REQUIRE(a && g && N > 0 && S > 0, "gap_fwd: bad arguments");

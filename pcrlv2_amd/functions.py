@@ -144,10 +144,11 @@ class UpStageFn(Function):
         # ---- ops.1, ops.0 ----
         d_a0, gw1, gb1, gg1, gbe1 = ops.luconv_backward(ctx.sv1, d_a1, w1, g1, l1._packed, dt, need_dx=True)
         grads[7], grads[8], grads[9], grads[10] = gw1, gb1, gg1, gbe1
-        d_up, gw0, gb0, gg0, gbe0 = ops.luconv_backward(ctx.sv0, d_a0, w0, g0, l0._packed, dt, need_dx=True)
+        g_upb = torch.empty(up_w.shape[1], dtype=torch.float32, device=d_a0.device)
+        d_up, gw0, gb0, gg0, gbe0 = ops.luconv_backward(ctx.sv0, d_a0, w0, g0, l0._packed, dt, need_dx=True, dx_colsum=g_upb)
         grads[3], grads[4], grads[5], grads[6] = gw0, gb0, gg0, gbe0
         # ---- up_conv ----
-        dx, g_upw, g_upb = ops.convt_backward(ctx.x, d_up, up_w, mod._packed_up, dt, need_dx=ctx.needs_input_grad[0])
+        dx, g_upw, g_upb = ops.convt_backward(ctx.x, d_up, up_w, mod._packed_up, dt, need_dx=ctx.needs_input_grad[0], db=g_upb)
         grads[0], grads[1], grads[2] = dx, g_upw, g_upb
         ctx.svd.x = None
         mark_final(ctx, ctx.plist)

@@ -207,8 +207,11 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
     return a, sv
 
 
-def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, dtype, need_dx=True, dx_add=None):
+def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, dtype, need_dx=True, dx_add=None, dx_colsum=None):
     """-> (dx | None, dw, db, dgamma, dbeta).  `dx_add`: optional activation folded into dx (to1 kind only).
+    `dx_colsum`: optional float32 [Ci] that receives sum over voxels of dx (the bias gradient of the layer that produced this
+    LUConv's input -- ConvTranspose3d in UpTransition), taken from the data-gradient kernel's float accumulators through its
+    per-tile statistics output instead of re-reading dx from HBM.
 
     db is exactly zero: a bias that is followed by a batch-statistics normalisation has an identically
     zero gradient (the reference's autograd yields round-off noise ~1e-8 there).
@@ -243,7 +246,16 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
         _, wd = packed.get(conv_w, dtype)
         dx = new_act(N, D, H, W, Ci, dtype, dev)
         nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Co, Ci, dtype_code(dtype))
-        L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, None, workspace(nb, dev) if nb else None, nb, N, D, H, W, Co, Ci, dtype_code(dtype), s)
+        part = None
+        if dx_colsum is not None:
+            rows = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Co, Ci, dtype_code(dtype))
+            part = _f32(rows * Ci * 2, dev)
+        L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, part, workspace(nb, dev) if nb else None, nb, N, D, H, W, Co, Ci, dtype_code(dtype), s)
+        if part is not None:   # [rows][Ci][2] -> column sums; the (sum) entries are the even columns
+            both = _f32(Ci * 2, dev)
+            nb2 = L.call("pcrl_colsum_ws_bytes", rows, Ci * 2)
+            L.call("pcrl_colsum", part, both, workspace(nb2, dev), nb2, rows, Ci * 2, dtype_code(torch.float32), s)
+            dx_colsum.copy_(both.view(Ci, 2)[:, 0])
     return dx, dw, db, dgamma, dbeta
 
 
@@ -274,8 +286,8 @@ def convt_forward(x, w, b, packed: PackedWeights, dtype):
     return y
 
 
-def convt_backward(x, dy, w, packed: PackedWeights, dtype, need_dx=True):
-    """-> (dx | None, dw [Ci,Co,2,2,2], db [Co])."""
+def convt_backward(x, dy, w, packed: PackedWeights, dtype, need_dx=True, db=None):
+    """-> (dx | None, dw [Ci,Co,2,2,2], db [Co]).  `db`: bias gradient if the caller already has it (luconv_backward's dx_colsum)."""
     L, s, dev = lib(), stream_handle(), x.device
     N, D, H, W, Ci = dims(x)
     Co = w.shape[1]
@@ -283,10 +295,11 @@ def convt_backward(x, dy, w, packed: PackedWeights, dtype, need_dx=True):
     dw = torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format)
     nb = L.call("pcrl_convt3d_k2s2_wgrad_ws_bytes", N, D, H, W, Ci, Co)
     L.call("pcrl_convt3d_k2s2_wgrad", x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Ci, Co, dtype_code(dtype), s)
-    Mo = N * D * H * W * 8
-    db = _f32(Co, dev)
-    nb2 = L.call("pcrl_colsum_ws_bytes", Mo, Co)
-    L.call("pcrl_colsum", dy, db, workspace(nb2, dev), nb2, Mo, Co, dtype_code(dtype), s)
+    if db is None:
+        Mo = N * D * H * W * 8
+        db = _f32(Co, dev)
+        nb2 = L.call("pcrl_colsum_ws_bytes", Mo, Co)
+        L.call("pcrl_colsum", dy, db, workspace(nb2, dev), nb2, Mo, Co, dtype_code(dtype), s)
     dx = None
     if need_dx:
         _, wd = packed.get(w, dtype)
