@@ -90,11 +90,14 @@ int pcrl_conv3d_k3_c1_wgrad(const float* x, const void* dy, float* dw_ref, void*
 
 /* Convolutions with ONE output channel: deep-supervision head conv3x3x3 C->1 (pcrlv2_model_3d.py:60,71)
  * and OutputTransition.final_conv 1x1x1 64->1 (:78).  taps = 27 or 1.  y, dy: float32 [M].
- * w_ref: [1][C][taps] float32.  `stats_partial`: [ceil(M/1024)][1][2] or NULL.  fwd, 27 taps: a pointwise MFMA
- * product z[t][m] = sum_c x[m][c] w[c][t] (x read once) + a shifted sum of the 27 planes, staged in `ws`
- * (pcrl_conv3d_to1_fwd_ws_bytes; ws = NULL falls back to the direct 27-tap gather kernel).
+ * w_ref: [1][C][taps] float32.  `stats_partial`: [pcrl_conv3d_to1_stats_rows(...)][1][2] or NULL.  fwd, 27 taps, three kernels:
+ * an LDS-halo brick kernel (bf16, D%4 == 0, H%8 == 0, W%8 == 0, C%32 == 0: z = x.w for every halo voxel on MFMA, gathered per
+ * output voxel inside the block; one statistics row per 4x8x8 brick); else a pointwise MFMA product z[t][m] = sum_c x[m][c] w[c][t]
+ * (x read once) + a shifted sum of the 27 planes, staged in `ws` (pcrl_conv3d_to1_fwd_ws_bytes; one row per 1024 voxels);
+ * ws = NULL falls back to the direct 27-tap gather kernel.
  * dgrad: dx[m][c] = add_src[m][c] + sum_t dy[m-delta_t] * w[c][t]; add_src may be NULL (zero), dx itself
  * (in-place accumulation) or another tensor of the same shape (an upstream gradient to fold in). */
+int64_t pcrl_conv3d_to1_stats_rows(int N, int D, int H, int W, int C, int taps, int dtype);
 size_t pcrl_conv3d_to1_fwd_ws_bytes(int N, int D, int H, int W, int C, int taps);
 int pcrl_conv3d_to1_fwd(const void* x, const float* w_ref, const float* bias, float* y, float* stats_partial,
                         void* ws, size_t ws_bytes, int N, int D, int H, int W, int C, int taps, int dtype,

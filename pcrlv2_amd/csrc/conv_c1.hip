@@ -64,15 +64,28 @@ __global__ void c1_fwd_kernel(const float* __restrict__ x, const float* __restri
 #pragma unroll
     for (int j = 0; j < 16; ++j) red[vox * ld + cg * 16 + j] = live ? acc[j] : 0.f;
     __syncthreads();
+    // all 8 * Co threads reduce: thread (channel c, part q of 8) sums 16 voxel rows, then Co threads combine the 8 parts
+    const int c = tid % Co, q = tid / Co;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
+    for (int r = q * 16; r < q * 16 + 16; ++r) {
+      const float v = red[r * ld + c];
+      s1 += v;
+      s2 += v * v;
+    }
+    __syncthreads();   // everyone has read its rows: the tile can be reused for the partials
+    red[(q * Co + c) * 2 + 0] = s1;
+    red[(q * Co + c) * 2 + 1] = s2;
+    __syncthreads();
     if (tid < Co) {
-      float s1 = 0.f, s2 = 0.f;
-      for (int r = 0; r < 128; ++r) {
-        const float v = red[r * ld + tid];
-        s1 += v;
-        s2 += v * v;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a += red[(k * Co + tid) * 2 + 0];
+        b += red[(k * Co + tid) * 2 + 1];
       }
-      stats[((int64_t)blockIdx.x * Co + tid) * 2 + 0] = s1;
-      stats[((int64_t)blockIdx.x * Co + tid) * 2 + 1] = s2;
+      stats[((int64_t)blockIdx.x * Co + tid) * 2 + 0] = a;
+      stats[((int64_t)blockIdx.x * Co + tid) * 2 + 1] = b;
     }
   }
 }
@@ -268,6 +281,17 @@ static int to1_check(const char* what, int C, int taps, int dtype) {
 }
 
 int pcrl_pointwise_planes_launch(const void* x, const void* wt, float* z, int64_t M, int C, int dtype, hipStream_t stream);
+// LDS-halo brick kernel (conv_to1_brick.hip)
+bool pcrl_to1_brick_eligible(int N, int D, int H, int W, int C, int taps, int dtype);
+int64_t pcrl_to1_brick_rows(int N, int D, int H, int W);
+int pcrl_to1_brick_launch(const void* x, const float* w_ref, const float* bias, float* y, float* stats, int N, int D, int H, int W, int C,
+                          hipStream_t stream);
+int pcrl_debug_conv_impl();   // conv_igemm.hip: 0 = auto
+
+extern "C" int64_t pcrl_conv3d_to1_stats_rows(int N, int D, int H, int W, int C, int taps, int dtype) {
+  if (pcrl_debug_conv_impl() == 0 && pcrl_to1_brick_eligible(N, D, H, W, C, taps, dtype)) return pcrl_to1_brick_rows(N, D, H, W);
+  return ((int64_t)N * D * H * W + TO1_VOX - 1) / TO1_VOX;
+}
 
 extern "C" size_t pcrl_conv3d_to1_fwd_ws_bytes(int N, int D, int H, int W, int C, int taps) {
   if (taps != 27 || C % 32 != 0) return 0;
@@ -279,6 +303,8 @@ extern "C" int pcrl_conv3d_to1_fwd(const void* x, const float* w_ref, const floa
                                    pcrl_stream_t stream) {
   if (int e = to1_check("conv3d_to1_fwd", C, taps, dtype)) return e;
   PCRL_REQUIRE(x && w_ref && y, "conv3d_to1_fwd: null pointer");
+  if (pcrl_debug_conv_impl() == 0 && pcrl_to1_brick_eligible(N, D, H, W, C, taps, dtype))
+    return pcrl_to1_brick_launch(x, w_ref, bias, y, stats_partial, N, D, H, W, C, as_stream(stream));
   const Dims g{N, D, H, W};
   const int64_t M = (int64_t)N * D * H * W;
   if (taps == 27 && C % 32 == 0 && M % 4 == 0 && ws && ws_bytes >= pcrl_conv3d_to1_fwd_ws_bytes(N, D, H, W, C, taps)) {

@@ -444,6 +444,7 @@ int pcrl_convt_up2_launch(const void* x, const void* wp, const float* bias, void
                           hipStream_t stream);
 static int g_conv_impl = 0;  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
 extern "C" void pcrl_debug_set_conv_impl(int impl) { g_conv_impl = impl; }
+int pcrl_debug_conv_impl() { return g_conv_impl; }
 
 extern "C" int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype) {
   if (g_conv_impl == 0 && pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype)) return pcrl_brick_conv_rows(N, D, H, W);

@@ -164,7 +164,7 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         if C != Ci:
             raise PcrlError(f"LUConv: input has {C} channels, weight expects {Ci}")
         M = N * D * H * W
-        rows = (M + 1023) // 1024
+        rows = L.call("pcrl_conv3d_to1_stats_rows", N, D, H, W, C, 27, dtype_code(dtype))
         y = _f32(M, dev)
         partial = _f32(rows * 2, dev)
         nb = L.call("pcrl_conv3d_to1_fwd_ws_bytes", N, D, H, W, C, 27)

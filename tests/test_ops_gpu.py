@@ -185,6 +185,38 @@ def test_first_layer_c1(dt):
     check(dw, wr.grad, dt, "c1 wgrad", out_rounded=False, f32_tol=3e-5)
 
 
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_conv_to_one_channel_brick_kernel(C):
+    """bf16 deep-supervision head forward on a brick-eligible volume (several bricks per axis: interior and boundary halos):
+    the LDS-halo kernel against F.conv3d with bf16-rounded operands, the per-brick BatchNorm partials, and the two-pass kernel."""
+    dt = torch.bfloat16
+    N, D, H, W = 2, 8, 16, 24
+    L, s = lib(), stream_handle()
+    x, w, b = rnd(N, C, D, H, W, seed=21), rnd(1, C, 3, 3, 3, seed=22, scale=0.2), rnd(1, seed=23)
+    ref = F.conv3d(q(x, dt), q(w, dt), b, padding=1)
+    M = N * D * H * W
+    xa = act_dev(x, dt)
+    wdev, bdev = w.float().to(DEV), b.float().to(DEV)
+    rows = L.call("pcrl_conv3d_to1_stats_rows", N, D, H, W, C, 27, dtype_code(dt))
+    assert rows == N * (D // 4) * (H // 8) * (W // 8)
+    y = torch.zeros(M, dtype=torch.float32, device=DEV)
+    part = torch.zeros(rows * 2, dtype=torch.float32, device=DEV)
+    L.call("pcrl_conv3d_to1_fwd", xa, wdev, bdev, y, part, None, 0, N, D, H, W, C, 27, dtype_code(dt), s)
+    check(y.view(N, 1, D, H, W), ref, dt, "to1 fwd (brick)", out_rounded=False)
+    st = back(part).view(-1, 2).sum(0)
+    assert abs(st[0].item() - ref.sum().item()) <= 1e-4 * max(1.0, ref.abs().sum().item())
+    assert abs(st[1].item() - (ref * ref).sum().item()) <= 1e-4 * max(1.0, (ref * ref).sum().item())
+    # the two-pass kernel (debug switch) rounds at the same points: float32 sums of bf16 products, different order only
+    L.debug_set_conv_impl(1)
+    try:
+        nbf = L.call("pcrl_conv3d_to1_fwd_ws_bytes", N, D, H, W, C, 27)
+        y2 = torch.zeros(M, dtype=torch.float32, device=DEV)
+        L.call("pcrl_conv3d_to1_fwd", xa, wdev, bdev, y2, None, ops.workspace(nbf, xa.device), nbf, N, D, H, W, C, 27, dtype_code(dt), s)
+    finally:
+        L.debug_set_conv_impl(0)
+    assert (y - y2).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("C,taps", [(64, 27), (128, 27), (256, 27), (64, 1)])
 def test_conv_to_one_channel(C, taps, dt):
