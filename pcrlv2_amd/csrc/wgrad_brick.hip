@@ -12,7 +12,8 @@
 // Operands are fetched with ds_read_b64_tr_b16 (the reduction index is the row index of both NDHWC tensors).
 // Each wave owns all 64 co x 16 ci of the 9 taps (36 accumulator fragments): the dy fragments are read once per
 // 32-voxel K-chunk and reused by 9 taps, the x fragment of a tap feeds 4 MFMAs -> 13 KB of LDS reads per 36 MFMAs.
-// The next brick is prefetched into registers while the current one is multiplied.  Split-K over brick ranges; the
+// Two LDS brick buffers: the next brick's pieces are written, and the one after that loaded, a piece every third step while
+// the current brick is multiplied (one barrier per brick).  Split-K over brick ranges; the
 // partial slabs are reduced in fixed order by the same second pass as the gather kernel.
 #include "common.h"
 
@@ -26,6 +27,8 @@ constexpr int DY_BYTES = BV * 128;        // 16 KiB
 constexpr int X_BYTES = XROWS * 128;      // 30 KiB
 constexpr int DYP = BV * 8 / 256;         // dy 16-byte pieces per thread (4)
 constexpr int XP = (XROWS * 8 + 255) / 256;  // x pieces per thread (8: 1920 pieces)
+constexpr int BUF_BYTES = DY_BYTES + X_BYTES;   // one brick buffer: 46 KiB, two of them in LDS
+static_assert(DYP + XP == 12, "one staging piece per three of the 36 steps");
 
 struct WBrickParams {
   const bf16* dy;   // [M][Cu]
@@ -53,9 +56,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
 }
 
 __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* dys = smem;
-  char* xs = smem + DY_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // two (dy, x halo) brick buffers of BUF_BYTES
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lg = lane >> 4, jr = (lane & 15) >> 2, cq = lane & 3;
@@ -100,9 +101,17 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
   // a halo row that is inside the volume for every brick: (hd = 1 for kd = 0, else 0 ; hh = 1 ; hw = 1)
   const uint32_t xsafe = (uint32_t)((((kd == 0 ? 1 : 0) * p.H + 1) * p.W + 1) * p.Cv + xcol) * 2u;
   u32x4 rdy[DYP], rx[XP];
-  uint32_t xvalid = 0;
 
-#define WB_LOAD(b_)                                                                                          \
+  // Staging pipeline (two LDS brick buffers): while brick b is multiplied out of one buffer, the registers hold brick b+1.
+  // Every third step ONE piece is written to the other buffer and its register immediately re-loaded with the same piece of
+  // brick b+2.  Loads and LDS stores are thus spread evenly over the 36 steps (4 waves x (2 transpose reads + 1/3 store) keep the
+  // LDS ~50 % busy; bunching the 12 stores of a brick into 12 consecutive steps saturated it), a load has a whole brick to land,
+  // and the block synchronises once per brick.
+  const char* dyb = nullptr;   // block-uniform bases of the brick being LOADED
+  const char* xb = nullptr;
+  uint32_t xout = 0;
+  uint32_t xvalid_w = 0, xvalid_l = 0;   // validity bits of the x pieces in registers (being written) / being loaded
+#define WB_ORIGIN(b_)                                                                                        \
   do {                                                                                                       \
     int t_ = (b_);                                                                                           \
     const int w0 = (t_ % bw) * BW; t_ /= bw;                                                                 \
@@ -110,28 +119,33 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
     const int d0 = (t_ % bd) * BD; t_ /= bd;                                                                 \
     const int n = t_;                                                                                        \
     const int64_t base0 = (((int64_t)n * p.D + d0) * p.H + h0) * p.W + w0;                                   \
-    const char* dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                               \
+    dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                           \
     /* first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
-    const char* xb = reinterpret_cast<const char*>(p.x + (base0 + ((int64_t)(kd - 1) * p.H - 1) * p.W - 1) * p.Cv); \
+    xb = reinterpret_cast<const char*>(p.x + (base0 + ((int64_t)(kd - 1) * p.H - 1) * p.W - 1) * p.Cv);      \
     /* faces of this brick's halo that stick out of the volume (BD = 2: the d faces are the two planes) */    \
-    const uint32_t out = (d0 + kd - 1 < 0 ? 1u : 0u) | (d0 + kd - 1 + BD - 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |   \
-                         (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u; \
-    _Pragma("unroll") for (int i = 0; i < DYP; ++i) rdy[i] = *reinterpret_cast<const u32x4*>(dyb + dyoff[i]); \
-    xvalid = 0;                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                         \
-      const bool ok = (xedge[i] & out) == 0;                                                                 \
-      rx[i] = *reinterpret_cast<const u32x4*>(xb + (ok ? xoff[i] : xsafe));                                  \
-      xvalid |= (uint32_t)ok << i;                                                                           \
+    xout = (d0 + kd - 1 < 0 ? 1u : 0u) | (d0 + kd - 1 + BD - 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |      \
+           (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;            \
+    xvalid_l = 0;                                                                                            \
+  } while (0)
+#define WB_LOAD_PIECE(i_)                                                                                    \
+  do {                                                                                                       \
+    if ((i_) < DYP) {                                                                                        \
+      rdy[(i_) < DYP ? (i_) : 0] = *reinterpret_cast<const u32x4*>(dyb + dyoff[(i_) < DYP ? (i_) : 0]);      \
+    } else {                                                                                                 \
+      const int j_ = (i_) < DYP ? 0 : (i_) - DYP;                                                            \
+      const bool ok = (xedge[j_] & xout) == 0;                                                               \
+      rx[j_] = *reinterpret_cast<const u32x4*>(xb + (ok ? xoff[j_] : xsafe));                                \
+      xvalid_l |= (uint32_t)ok << j_;                                                                        \
     }                                                                                                        \
   } while (0)
-
-#define WB_STORE()                                                                                           \
+#define WB_STORE_PIECE(i_, buf_)                                                                             \
   do {                                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < DYP; ++i)                                                          \
-      *reinterpret_cast<u32x4*>(dys + dy_off((tid >> 3) + 32 * i, pc * 8)) = rdy[i];                         \
-    _Pragma("unroll") for (int i = 0; i < XP; ++i) {                                                         \
-      const int r = (tid >> 3) + 32 * i;                                                                     \
-      if (r < XROWS) *reinterpret_cast<u32x4*>(xs + x_off(r, pc * 8)) = keep_if((xvalid >> i) & 1u, rx[i]);  \
+    if ((i_) < DYP) {                                                                                        \
+      *reinterpret_cast<u32x4*>((buf_) + dy_off((tid >> 3) + 32 * ((i_) < DYP ? (i_) : 0), pc * 8)) = rdy[(i_) < DYP ? (i_) : 0]; \
+    } else {                                                                                                 \
+      const int j_ = (i_) < DYP ? 0 : (i_) - DYP;                                                            \
+      const int r = (tid >> 3) + 32 * j_;                                                                    \
+      if (r < XROWS) *reinterpret_cast<u32x4*>((buf_) + DY_BYTES + x_off(r, pc * 8)) = keep_if((xvalid_w >> j_) & 1u, rx[j_]); \
     }                                                                                                        \
   } while (0)
 
@@ -147,14 +161,24 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
   }
 
   if (b_beg < b_end) {
-    WB_LOAD(b_beg);
-    WB_STORE();
+    WB_ORIGIN(b_beg);
+#pragma unroll
+    for (int i = 0; i < DYP + XP; ++i) WB_LOAD_PIECE(i);
+    xvalid_w = xvalid_l;
+#pragma unroll
+    for (int i = 0; i < DYP + XP; ++i) WB_STORE_PIECE(i, smem);
+    WB_ORIGIN(b_beg + 1 < b_end ? b_beg + 1 : b_beg);   // registers <- brick b_beg + 1
+#pragma unroll
+    for (int i = 0; i < DYP + XP; ++i) WB_LOAD_PIECE(i);
+    xvalid_w = xvalid_l;
   }
   __syncthreads();
 
   for (int b = b_beg; b < b_end; ++b) {
-    const int bn = (b + 1 < b_end) ? b + 1 : b;
-    WB_LOAD(bn);
+    const char* dys = smem + ((b - b_beg) & 1) * BUF_BYTES;
+    const char* xs = dys + DY_BYTES;
+    char* nxt = smem + (((b - b_beg) & 1) ^ 1) * BUF_BYTES;
+    WB_ORIGIN(b + 2 < b_end ? b + 2 : b_end - 1);        // the brick whose pieces are loaded during this one
     __builtin_amdgcn_sched_barrier(0);
 
     // 36 steps = 4 K-chunks x 9 taps, fully unrolled and SOFTWARE-PIPELINED: the x fragment of step s+1 (and the dy
@@ -178,6 +202,10 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
 #pragma unroll
     for (int st = 0; st < 36; ++st) {
       const int kc = st / 9, t = st % 9;
+      if (st % 3 == 0) {   // piece st/3: brick b+1 -> the other LDS buffer, then its register <- brick b+2
+        WB_STORE_PIECE(st / 3, nxt);
+        WB_LOAD_PIECE(st / 3);
+      }
       if (st + 2 < 36) fbr[(st + 2) % 3] = WB_B((st + 2) / 9, (st + 2) % 9);
       if (t == 4 && kc < 3) {
 #pragma unroll
@@ -194,12 +222,12 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
 #undef WB_B
 
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();   // all waves have finished reading this brick
-    WB_STORE();
-    __syncthreads();
+    xvalid_w = xvalid_l;
+    __syncthreads();   // this brick's reads and the next brick's stores are complete
   }
-#undef WB_LOAD
-#undef WB_STORE
+#undef WB_ORIGIN
+#undef WB_LOAD_PIECE
+#undef WB_STORE_PIECE
 
   // D[i][j]: lane holds i = 16 f + 4 lg + r, j = lane & 15
   float* out = p.ws + (int64_t)blockIdx.x * 27 * p.Cu * p.Cv;
@@ -249,7 +277,7 @@ int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co) {
 int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co,
                             hipStream_t stream) {
   static bool attr_set = false;
-  const size_t lds = DY_BYTES + X_BYTES;
+  const size_t lds = 2 * BUF_BYTES;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;

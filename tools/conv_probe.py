@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--layers", default="")
     ap.add_argument("--impls", default="0,1")
+    ap.add_argument("--fill", default="randn", choices=["randn", "zeros", "ones", "relu"], help="operand data (power is data dependent)")
     args = ap.parse_args()
     L, dev, dt = lib(), torch.device("cuda"), torch.bfloat16
     what = args.what.split(",")
@@ -63,6 +64,12 @@ def main():
         x = ops.new_act(N, D, H, W, Ci, dt, dev).normal_()
         dy = ops.new_act(N, D, H, W, Co, dt, dev).normal_()
         w = torch.randn(Co, Ci, 3, 3, 3, device=dev) * 0.05
+        if args.fill == "zeros":
+            x.zero_(); dy.zero_(); w.zero_()
+        elif args.fill == "ones":
+            x.fill_(1.0); dy.fill_(1.0); w.fill_(1.0)
+        elif args.fill == "relu":
+            x.relu_()
         wf, wd = ops.PackedWeights("conv3").get(w, dt)
         y = ops.new_act(N, D, H, W, Co, dt, dev)
         dx = ops.new_act(N, D, H, W, Ci, dt, dev)
