@@ -1,7 +1,7 @@
 """How much do the bf16 gradients of the golden b=4 step move between equally valid kernel choices (summation orders)?
 BatchNorm1d over four samples sits between the cosine losses and the decoder: see tests/test_model_gpu.py."""
 import os, sys, random
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # lives under tests/: it uses the oracle helpers (test infrastructure)
 sys.path.insert(0, R); sys.path.insert(0, R + "/tests"); sys.path.insert(0, R + "/oracle")
 import numpy as np, torch
 import pcrlv2_oracle as O

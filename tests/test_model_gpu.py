@@ -164,7 +164,7 @@ def test_bf16_step_within_stated_tolerance_of_golden(golden):
     merely re-ordering float32 K-summations -- split-K on/off, a different split count -- moved the norms of the up_tr64 stage
     (which feeds BatchNorm1d(64)) from <0.3 to 0.6 to 4.5 times the golden while everything else stayed put).  Asserted: every
     gradient finite and present/absent as in the reference; MEDIAN norm deviation over the tensors < 0.25 (measured 0.03-0.12);
-    at most a quarter of the tensors off by more than 0.3 (measured: 13 of 71, the up_tr64 stage).  `tools/chaos_probe.py` shows
+    at most a quarter of the tensors off by more than 0.3 (measured: 13 of 71, the up_tr64 stage).  `tests/chaos_probe.py` shows
     the spread between equally valid kernel choices on this input: float32 reproduces every golden norm to 1.000 with the brick,
     gather and split-K kernels alike, bfloat16 gives |g|/|g_golden| of up_tr64.up_conv.weight = 5.5 / 0.84 / 0.83 for the three.
     The tight bf16 gradient check is test_restoration_path_gradients_vs_live_oracle (well-conditioned MSE path)."""
