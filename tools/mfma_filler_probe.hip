@@ -16,7 +16,6 @@ __device__ __forceinline__ void fillers(i32x4 (&r)[4], int& addr, int& sacc) {
   for (int f = 0; f < F; ++f) {
     if (KIND == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(r[f & 3]) : "v"(addr));
     if (KIND == 1) asm volatile("v_add_u32 %0, 1, %0" : "+v"(addr));
-    if (KIND == 2) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sacc));
   }
 }
 
@@ -101,7 +100,5 @@ int main() {
   ALL(1, 0, "ds_read")
   ALL(0, 1, "valu")
   ALL(1, 1, "valu")
-  ALL(0, 2, "salu")
-  ALL(1, 2, "salu")
   return 0;
 }
