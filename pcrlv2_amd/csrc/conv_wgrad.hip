@@ -315,6 +315,135 @@ __global__ void __launch_bounds__(256) vecsum_finish_kernel(const double* __rest
   if (threadIdx.x == 0) out[0] = (float)s;
 }
 
+// Weight gradients of the 1-channel convolutions over 4x8x8 bricks, bf16 (the im2col of the scalar operand never leaves the CU):
+//   first layer (1 -> Co):  dw[c][t] = sum_m dy[m][c] * x[m + delta_t]          act = dy, s = x,  flip = 0
+//   heads       (C -> 1):   dw[c][t] = sum_m x[m][c]  * dy[m - delta_t]         act = x,  s = dy, flip = 1
+// A block walks over a range of bricks: per brick it stages act[256 voxels][64 ch] (bf16, the weight-gradient tile layout) and
+// the brick's halo of the float scalar field (6x10x10, zero outside the volume) in LDS; a wave takes two of the eight 32-voxel
+// K-chunks, fetches the act fragments with transpose reads and BUILDS the im2col fragments (32 voxels x 16 taps) from eight
+// scalar LDS reads per lane.  Per-block partial sums -> ws[block][c][32], reduced in fixed order by wgrad_reduce_kernel.
+struct ScalarWgradParams {
+  const bf16* act;    // [M][C]
+  const float* s;     // [M]
+  float* ws;          // [gridDim.x][C][32]
+  int N, D, H, W, C;
+  int nbricks, per_block, flip;
+};
+
+__global__ void __launch_bounds__(256) scalar_wgrad_brick_kernel(const ScalarWgradParams p) {
+  using WT = WTile<bf16>;
+  using WF = WFrag<bf16, true>;
+  __shared__ __attribute__((aligned(16))) char at[256 * WT::ROWB];   // 32 KiB
+  __shared__ float sh[6 * 10 * 10];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int i0 = blockIdx.y * 64;
+  const int b_beg = blockIdx.x * p.per_block;
+  const int b_end = min(b_beg + p.per_block, p.nbricks);
+  const int bw = p.W / 8, bh = p.H / 8, bd = p.D / 4;
+
+  // staging roles: act piece q = tid + 256 i -> voxel q >> 3 (brick order d,h,w), 16-byte piece q & 7
+  const int pc = tid & 7;
+  const bool col_ok = (i0 + pc * 8) < p.C;
+  uint32_t aoff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int v = (tid >> 3) + 32 * i;
+    aoff[i] = (uint32_t)((((v >> 6) * p.H + ((v >> 3) & 7)) * p.W + (v & 7)) * p.C + (col_ok ? i0 + pc * 8 : 0)) * 2u;
+  }
+  u32x4 ra[8];
+  float rs[3];
+#define SW_LOAD(b_)                                                                                          \
+  do {                                                                                                       \
+    int t_ = (b_);                                                                                           \
+    const int w0 = (t_ % bw) * 8; t_ /= bw;                                                                  \
+    const int h0 = (t_ % bh) * 8; t_ /= bh;                                                                  \
+    const int d0 = (t_ % bd) * 4; t_ /= bd;                                                                  \
+    const int n = t_;                                                                                        \
+    const int64_t base0 = (((int64_t)n * p.D + d0) * p.H + h0) * p.W + w0;                                   \
+    const char* ab = reinterpret_cast<const char*>(p.act + base0 * p.C);                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) ra[i] = *reinterpret_cast<const u32x4*>(ab + aoff[i]);     \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                          \
+      const int q = tid + 256 * i;                                                                           \
+      const int hd = q / 100, hh = (q / 10) % 10, hw = q % 10;                                               \
+      const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                           \
+      const bool ok = q < 600 && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W; \
+      const float val = p.s[ok ? (((int64_t)n * p.D + d) * p.H + h) * p.W + w : base0];                      \
+      rs[i] = ok ? val : 0.f;                                                                                \
+    }                                                                                                        \
+  } while (0)
+#define SW_STORE()                                                                                           \
+  do {                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                            \
+      *reinterpret_cast<u32x4*>(at + WT::off((tid >> 3) + 32 * i, pc * 8)) = keep_if(col_ok, ra[i]);         \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                            \
+      if (tid + 256 * i < 600) sh[tid + 256 * i] = rs[i];                                                    \
+  } while (0)
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // the lane's tap of im2col fragment j: t = 16 j + lr (27..31: no such tap -> zero column); flip: tap 26 - t
+  int toff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int t = 16 * j + lr;
+    const int tt = p.flip ? 26 - t : t;
+    toff[j] = t < 27 ? ((tt / 9) * 10 + (tt / 3) % 3) * 10 + tt % 3 : -1;
+  }
+
+  if (b_beg < b_end) {
+    SW_LOAD(b_beg);
+    SW_STORE();
+  }
+  __syncthreads();
+  for (int b = b_beg; b < b_end; ++b) {
+    SW_LOAD(b + 1 < b_end ? b + 1 : b);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int kc = wid * 2 + q;                       // 32-voxel K-chunk: brick rows 32 kc .. 32 kc + 31
+      const int line = 4 * kc + lg;                     // the lane's 8 voxels: w = 0..7 of (d,h) line `line`
+      const int hbase = ((line >> 3) * 10 + (line & 7)) * 10;
+      bf16x8 fb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fb[j][e] = toff[j] >= 0 ? (bf16)sh[hbase + toff[j] + e] : (bf16)0.f;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const bf16x8 fa = WF::read(at + kc * (32 * WT::ROWB), a * 16, lane);
+        acc[a][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[0], acc[a][0], 0, 0, 0);
+        acc[a][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[1], acc[a][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    SW_STORE();
+    __syncthreads();
+  }
+#undef SW_LOAD
+#undef SW_STORE
+  // D[c][t]: lane holds c = 16 a + 4 lg + r, t = 16 j + lr.  The four waves' sums meet in LDS (fixed order): one slab per block.
+  float* red = reinterpret_cast<float*>(at);   // [4 waves][64 c][32 t] floats = the 32 KiB of the act tile (the loop ended with a barrier)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int cl = a * 16 + lg * 4 + r;
+      red[(wid * 64 + cl) * 32 + lr] = acc[a][0][r];
+      red[(wid * 64 + cl) * 32 + 16 + lr] = acc[a][1][r];
+    }
+  __syncthreads();
+  float* out = p.ws + (int64_t)blockIdx.x * (int64_t)p.C * 32;
+  for (int q = tid; q < 64 * 32; q += 256) {
+    const int cl = q >> 5, c = i0 + cl;
+    if (c < p.C) out[(int64_t)c * 32 + (q & 31)] = (red[q] + red[2048 + q]) + (red[4096 + q] + red[6144 + q]);
+  }
+}
+
 struct SplitPlanUp2 {
   int splits;
   int64_t chunk;
@@ -485,6 +614,36 @@ int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_b
   return pcrl_check_launch("wgrad_reduce");
 }
 
+
+// ---- brick path of the 1-channel weight gradients ----
+bool scalar_brick_ok(int D, int H, int W, int C, int taps, int dtype) {
+  return dtype == PCRL_BF16 && g_wgrad_tr && taps == 27 && D % 4 == 0 && H % 8 == 0 && W % 8 == 0 && C % 8 == 0;
+}
+int scalar_brick_blocks(int64_t nbricks, int C) {
+  const int ytiles = (C + 63) / 64;
+  int64_t nb = 512 / ytiles;               // ~2 blocks per CU; every block leaves one partial slab for the second pass
+  if (nb > nbricks) nb = nbricks;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+size_t scalar_brick_ws_bytes(int N, int D, int H, int W, int C) {
+  const int64_t nbricks = (int64_t)N * (D / 4) * (H / 8) * (W / 8);
+  return 8192 + (size_t)scalar_brick_blocks(nbricks, C) * C * 32 * sizeof(float);
+}
+int scalar_brick_launch(const void* act, const float* sfield, float* dw_ref, char* ws, int N, int D, int H, int W, int C, int flip,
+                        hipStream_t stream) {
+  const int64_t nbricks = (int64_t)N * (D / 4) * (H / 8) * (W / 8);
+  const int nb = scalar_brick_blocks(nbricks, C);
+  const int per = (int)((nbricks + nb - 1) / nb);
+  const int blocks = (int)((nbricks + per - 1) / per);
+  float* part = reinterpret_cast<float*>(ws + 8192);
+  ScalarWgradParams p{(const bf16*)act, sfield, part, N, D, H, W, C, (int)nbricks, per, flip};
+  hipLaunchKernelGGL(scalar_wgrad_brick_kernel, dim3((unsigned)blocks, (unsigned)((C + 63) / 64)), dim3(256), 0, stream, p);
+  if (int e = pcrl_check_launch("scalar_wgrad_brick")) return e;
+  const int rblocks = (int)(((int64_t)C * 27 + RED_IJ - 1) / RED_IJ);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, (const float*)part, dw_ref, blocks, 1, C, 32, 27);
+  return pcrl_check_launch("wgrad_reduce");
+}
 }  // namespace
 
 // Test hook (not part of the drop-in surface): select the bf16 fragment-fetch path.
@@ -584,7 +743,9 @@ int im2col_launch(const float* s, void* out, Dims g, int64_t M, int taps, int fl
 }  // namespace
 
 extern "C" size_t pcrl_conv3d_k3_c1_wgrad_ws_bytes(int N, int D, int H, int W, int Co) {
-  return plain_ws_bytes((int64_t)N * D * H * W, Co, 4);
+  size_t need = plain_ws_bytes((int64_t)N * D * H * W, Co, 4);
+  if (D % 4 == 0 && H % 8 == 0 && W % 8 == 0 && scalar_brick_ws_bytes(N, D, H, W, Co) > need) need = scalar_brick_ws_bytes(N, D, H, W, Co);
+  return need;
 }
 
 extern "C" int pcrl_conv3d_k3_c1_wgrad(const float* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes,
@@ -594,6 +755,10 @@ extern "C" int pcrl_conv3d_k3_c1_wgrad(const float* x, const void* dy, float* dw
   PCRL_REQUIRE(Co > 0 && Co % 8 == 0, "conv3d_k3_c1_wgrad: Co must be a multiple of 8 (got %d)", Co);
   const int64_t M = (int64_t)N * D * H * W;
   const int esz = dtype == PCRL_BF16 ? 2 : 4;
+  if (g_wgrad_impl == 0 && scalar_brick_ok(D, H, W, Co, 27, dtype)) {
+    if (!ws || ws_bytes < scalar_brick_ws_bytes(N, D, H, W, Co)) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_k3_c1_wgrad: workspace too small");
+    return scalar_brick_launch(dy, x, dw_ref, (char*)ws, N, D, H, W, Co, 0, as_stream(stream));
+  }
   if (!ws || ws_bytes < plain_ws_bytes(M, Co, esz)) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_k3_c1_wgrad: workspace too small");
   const Dims g{N, D, H, W};
   char* col = (char*)ws;
@@ -603,8 +768,9 @@ extern "C" int pcrl_conv3d_k3_c1_wgrad(const float* x, const void* dy, float* dw
 }
 
 extern "C" size_t pcrl_conv3d_to1_wgrad_ws_bytes(int N, int D, int H, int W, int C, int taps) {
-  (void)taps;
-  return plain_ws_bytes((int64_t)N * D * H * W, C, 4);
+  size_t need = plain_ws_bytes((int64_t)N * D * H * W, C, 4);
+  if (taps == 27 && D % 4 == 0 && H % 8 == 0 && W % 8 == 0 && scalar_brick_ws_bytes(N, D, H, W, C) > need) need = scalar_brick_ws_bytes(N, D, H, W, C);
+  return need;
 }
 
 extern "C" int pcrl_conv3d_to1_wgrad(const void* x, const float* dy, float* dw_ref, float* db, void* ws, size_t ws_bytes,
@@ -615,13 +781,20 @@ extern "C" int pcrl_conv3d_to1_wgrad(const void* x, const float* dy, float* dw_r
   PCRL_REQUIRE(C > 0 && C % 8 == 0, "conv3d_to1_wgrad: C must be a multiple of 8 (got %d)", C);
   const int64_t M = (int64_t)N * D * H * W;
   const int esz = dtype == PCRL_BF16 ? 2 : 4;
-  if (!ws || ws_bytes < plain_ws_bytes(M, C, esz)) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_to1_wgrad: workspace too small");
   const Dims g{N, D, H, W};
   char* col = (char*)ws;
-  double* red = (double*)(col + (size_t)M * 32 * esz);
-  char* part = (char*)red + 8192;
-  if (int e = im2col_launch(dy, col, g, M, taps, 1, dtype, as_stream(stream))) return e;
-  if (int e = run_wgrad<WG_PLAIN>(x, col, dw_ref, part, ws_bytes - (size_t)(part - col), g, C, 32, 1, dtype, as_stream(stream), taps)) return e;
+  double* red;
+  if (g_wgrad_impl == 0 && scalar_brick_ok(D, H, W, C, taps, dtype)) {
+    if (!ws || ws_bytes < scalar_brick_ws_bytes(N, D, H, W, C)) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_to1_wgrad: workspace too small");
+    red = (double*)col;   // first 8 KiB of the workspace: partials of the bias gradient
+    if (int e = scalar_brick_launch(x, dy, dw_ref, col, N, D, H, W, C, 1, as_stream(stream))) return e;
+  } else {
+    if (!ws || ws_bytes < plain_ws_bytes(M, C, esz)) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_to1_wgrad: workspace too small");
+    red = (double*)(col + (size_t)M * 32 * esz);
+    char* part = (char*)red + 8192;
+    if (int e = im2col_launch(dy, col, g, M, taps, 1, dtype, as_stream(stream))) return e;
+    if (int e = run_wgrad<WG_PLAIN>(x, col, dw_ref, part, ws_bytes - (size_t)(part - col), g, C, 32, 1, dtype, as_stream(stream), taps)) return e;
+  }
   int blocks = (int)((M + 4095) / 4096);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(vecsum_partial_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), dy, red, M);

@@ -17,6 +17,7 @@ from pcrlv2_amd import ops  # noqa: E402
 from pcrlv2_amd._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_BM, PcrlError, dtype_code, lib, stream_handle  # noqa: E402
 
 DEV = "cuda"
+DEV_T = torch.device("cuda")
 DTYPES = [torch.float32, torch.bfloat16]
 
 
@@ -183,6 +184,49 @@ def test_first_layer_c1(dt):
     dw = torch.zeros(Co, 1, 3, 3, 3, dtype=torch.float32, device=DEV)
     L.call("pcrl_conv3d_k3_c1_wgrad", xd, act_dev(dy, dt), dw, ops.workspace(nb, xd.device), nb, N, D, H, W, Co, dtype_code(dt), s)
     check(dw, wr.grad, dt, "c1 wgrad", out_rounded=False, f32_tol=3e-5)
+
+
+@pytest.mark.parametrize("case", ["c1:32", "to1:64", "to1:128", "to1:256"])
+def test_one_channel_wgrad_brick_kernel(case):
+    """bf16 weight gradients of the 1-channel convolutions on a brick-eligible volume (in-LDS im2col of the scalar operand):
+    first layer dw[c][t] = sum dy[m][c] x[m+delta_t]; heads dw[c][t] = sum x[m][c] dy[m-delta_t] (+ bias gradient); against
+    autograd with the operands rounded as the kernel sees them, and against the im2col-in-HBM path (debug switch)."""
+    dt = torch.bfloat16
+    kind, C = case.split(":")
+    C = int(C)
+    N, D, H, W = 2, 8, 16, 24
+    L, s = lib(), stream_handle()
+    if kind == "c1":
+        x, w = rnd(N, 1, D, H, W, seed=31), rnd(C, 1, 3, 3, 3, seed=32)
+        dy = rnd(N, C, D, H, W, seed=33)
+        wr = w.clone().requires_grad_(True)
+        F.conv3d(q(x, dt), wr, None, padding=1).backward(q(dy, dt))
+        xd, dyd = x.float().to(DEV), act_dev(dy, dt)
+        nb = L.call("pcrl_conv3d_k3_c1_wgrad_ws_bytes", N, D, H, W, C)
+        run = lambda out: L.call("pcrl_conv3d_k3_c1_wgrad", xd, dyd, out, ops.workspace(nb, DEV_T), nb, N, D, H, W, C, dtype_code(dt), s)
+        shape = (C, 1, 3, 3, 3)
+    else:
+        x, w = rnd(N, C, D, H, W, seed=34), rnd(1, C, 3, 3, 3, seed=35, scale=0.2)
+        dy = rnd(N, 1, D, H, W, seed=36)
+        wr = w.clone().requires_grad_(True)
+        F.conv3d(q(x, dt), wr, None, padding=1).backward(q(dy, dt))   # dy enters the MFMA as bf16 too
+        xa, dyd = act_dev(x, dt), dy.float().reshape(-1).to(DEV)
+        nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, C, 27)
+        db = torch.zeros(1, dtype=torch.float32, device=DEV)
+        run = lambda out: L.call("pcrl_conv3d_to1_wgrad", xa, dyd, out, db, ops.workspace(nb, DEV_T), nb, N, D, H, W, C, 27, dtype_code(dt), s)
+        shape = (1, C, 3, 3, 3)
+    dw = torch.zeros(shape, dtype=torch.float32, device=DEV)
+    run(dw)
+    check(dw, wr.grad, dt, f"{kind} wgrad (brick)", out_rounded=False, f32_tol=3e-5)
+    if kind == "to1":
+        assert abs(db.item() - dy.sum().item()) <= 1e-4 * max(1.0, dy.abs().sum().item())
+    dw2 = torch.zeros(shape, dtype=torch.float32, device=DEV)
+    L.debug_set_wgrad_impl(1)
+    try:
+        run(dw2)
+    finally:
+        L.debug_set_wgrad_impl(0)
+    assert (dw - dw2).abs().max().item() <= 2e-3 * max(1.0, dw2.abs().max().item())
 
 
 @pytest.mark.parametrize("C", [64, 128, 256])
