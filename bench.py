@@ -185,17 +185,20 @@ def main():
                 traffic, traffic_src = round(d[dom]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
     except Exception:
         pass
+    # BASELINE configs: C2 = 64x64x32 b=32 (the metric), C4 = 128x128x64 b=8 (9.42 TFLOP per crop); anything else is labelled as such
+    cfg_name = {((64, 64, 32), 32): "C2", ((128, 128, 64), 8): "C4"}.get((dhw, args.b), "custom (not a BASELINE config)")
+    flop_per_crop = {"C2": FLOP_PER_CROP, "C4": 9.42e12}.get(cfg_name)
     line = {
-        "metric": "3D crops/sec (64x64x32, b=32) pretrain step", "value": round(crops, 2), "unit": "crops/s",
+        "metric": "3D crops/sec (64x64x32, b=32) pretrain step" if cfg_name == "C2" else f"3D crops/sec ({dhw[0]}x{dhw[1]}x{dhw[2]}, b={args.b}) pretrain step", "value": round(crops, 2), "unit": "crops/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"C2: PCRLv23d pre-train step, {dhw[0]}x{dhw[1]}x{dhw[2]} global views x2 + 6 local 16^3, "
+        "config": {"workload": f"{cfg_name}: PCRLv23d pre-train step, {dhw[0]}x{dhw[1]}x{dhw[2]} global views x2 + 6 local 16^3, "
                                f"b={args.b}/GPU, fwd+bwd+SGD", "global_batch": world * args.b, "parallelism": f"dp{world}"},
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
                      "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
                      "avg_launch_ms": round(ms / n, 4), "launches": n, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                      "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(work / n)},
-        "step_mfma_frac": round(FLOP_PER_CROP * args.b * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4),
+        "step_mfma_frac": round(flop_per_crop * args.b * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4) if flop_per_crop else None,
         "kernels": detail, "final_loss": round(loss, 5),
         "diag": {"gpu_ms_per_step": per_step,
                  "device_mallocs_in_timed_region": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
