@@ -81,7 +81,10 @@ int pcrl_conv3d_k3_wgrad(const void* x, const void* dy, float* dw_ref, void* ws,
 
 /* First layer, Ci == 1 (pcrlv2_model_3d.py:101 -> down_tr64.ops.0, K = 27: HBM-bound, no MFMA).
  * x: float32 scalar field [M]; w_ref [Co][1][27] float32; y: dtype [M][Co]; Co in {16, 32, 64}.
- * The weight gradient is an MFMA GEMM dy^T . im2col(x) (im2col in `dtype`, staged in the workspace). */
+ * `stats_partial`: [pcrl_conv3d_k3_c1_stats_rows(...)][Co][2] (bf16 on D%4 == 0, H%8 == 0, W%8 == 0 volumes: an MFMA brick kernel, one
+ * row per 4x8x8 brick, x and w enter the MFMA as bf16; otherwise one row per 128 voxels, float32 FMAs).
+ * The weight gradient is an MFMA GEMM dy^T . im2col(x) (im2col built in LDS on brick volumes, else staged in the workspace). */
+int64_t pcrl_conv3d_k3_c1_stats_rows(int N, int D, int H, int W, int Co, int dtype);
 int pcrl_conv3d_k3_c1_fwd(const float* x, const float* w_ref, const float* bias, void* y, float* stats_partial,
                           int N, int D, int H, int W, int Co, int dtype, pcrl_stream_t stream);
 size_t pcrl_conv3d_k3_c1_wgrad_ws_bytes(int N, int D, int H, int W, int Co);

@@ -90,6 +90,109 @@ __global__ void c1_fwd_kernel(const float* __restrict__ x, const float* __restri
   }
 }
 
+// First layer forward on 4x8x8 bricks, bf16: one K = 32 MFMA step covers all 27 taps.  The A operand (16 voxels x 32 taps) is
+// the im2col of the scalar field, built per lane from eight LDS reads of the brick's halo (6x10x10 floats, zero outside the
+// volume); the B operand (taps x 16 channels) is the weight row w_ref[c][8 lg .. 8 lg + 7], contiguous in the reference layout.
+// A wave = one d-plane of the brick (4 fragments of 16 voxels).  x and w enter the MFMA rounded to bf16 (like every other
+// convolution in bf16 mode); bias, the bf16 store and the BatchNorm partials (one row per brick) come from the float sums.
+template <int CO>
+__global__ void __launch_bounds__(256) c1_brick_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_ref,
+                                                           const float* __restrict__ bias, bf16* __restrict__ y,
+                                                           float* __restrict__ stats, Dims g) {
+  constexpr int FN = CO / 16;
+  __shared__ float sh[600];
+  __shared__ float red[4 * CO * 2];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int bw = g.W / 8, bh = g.H / 8, bd = g.D / 4;
+  int b = blockIdx.x;
+  const int w0 = (b % bw) * 8; b /= bw;
+  const int h0 = (b % bh) * 8; b /= bh;
+  const int d0 = (b % bd) * 4; b /= bd;
+  const int n = b;
+  const int64_t base0 = (((int64_t)n * g.D + d0) * g.H + h0) * g.W + w0;
+  for (int q = tid; q < 600; q += 256) {
+    const int hd = q / 100, hh = (q / 10) % 10, hw = q % 10;
+    const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
+    const bool ok = (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+    const float v = x[ok ? (((int64_t)n * g.D + d) * g.H + h) * g.W + w : base0];
+    sh[q] = ok ? v : 0.f;
+  }
+  // weights: fragment j, lane (lr = channel, lg = taps 8 lg .. 8 lg + 7)
+  bf16x8 fb[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int t = 8 * lg + e;
+      fb[j][e] = t < 27 ? (bf16)w_ref[(j * 16 + lr) * 27 + t] : (bf16)0.f;
+    }
+  int toff[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int t = 8 * lg + e;
+    toff[e] = t < 27 ? ((t / 9) * 10 + (t / 3) % 3) * 10 + t % 3 : -1;
+  }
+  __syncthreads();
+  f32x4 acc[4][FN];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int hb = ((wid * 10 + 2 * f + (lr >> 3)) * 10) + (lr & 7);   // halo index of the lane's voxel (tap 0,0,0 corner)
+    bf16x8 fa;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fa[e] = toff[e] >= 0 ? (bf16)sh[hb + toff[e]] : (bf16)0.f;
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+      acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+  float s1[FN], s2[FN], bv[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+    bv[j] = bias ? bias[j * 16 + lr] : 0.f;
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int v = f * 16 + lg * 4 + r;   // voxel of the wave's plane: h = v >> 3, w = v & 7
+      const int64_t row = base0 + ((int64_t)wid * g.H + (v >> 3)) * g.W + (v & 7);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const float val = acc[f][j][r] + bv[j];
+        y[row * CO + j * 16 + lr] = (bf16)val;
+        s1[j] += val;
+        s2[j] += val * val;
+      }
+    }
+  if (stats) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float a = s1[j], c2 = s2[j];
+      a += __shfl_xor(a, 16, 64);
+      c2 += __shfl_xor(c2, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      c2 += __shfl_xor(c2, 32, 64);
+      if (lg == 0) {
+        red[(wid * CO + j * 16 + lr) * 2 + 0] = a;
+        red[(wid * CO + j * 16 + lr) * 2 + 1] = c2;
+      }
+    }
+    __syncthreads();
+    if (tid < CO) {
+      float a = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a += red[(q * CO + tid) * 2 + 0];
+        c2 += red[(q * CO + tid) * 2 + 1];
+      }
+      stats[((int64_t)blockIdx.x * CO + tid) * 2 + 0] = a;
+      stats[((int64_t)blockIdx.x * CO + tid) * 2 + 1] = c2;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // C -> 1 forward: y[m] = b + sum_t sum_c x[m+delta_t][c] * w[c][t].  LPV lanes share one voxel (one 16-byte
 // channel vector each, strided if C is wider), shuffle-reduce, 1024 voxels per block.
@@ -255,12 +358,29 @@ int pow2_floor(int v) {
 
 }  // namespace
 
+int pcrl_debug_conv_impl();   // conv_igemm.hip: 0 = auto
+static bool c1_brick_ok(int D, int H, int W, int dtype) {
+  return pcrl_debug_conv_impl() == 0 && dtype == PCRL_BF16 && D % 4 == 0 && H % 8 == 0 && W % 8 == 0;
+}
+extern "C" int64_t pcrl_conv3d_k3_c1_stats_rows(int N, int D, int H, int W, int Co, int dtype) {
+  (void)Co;
+  if (c1_brick_ok(D, H, W, dtype)) return (int64_t)N * (D / 4) * (H / 8) * (W / 8);
+  return ((int64_t)N * D * H * W + 127) / 128;
+}
+
 extern "C" int pcrl_conv3d_k3_c1_fwd(const float* x, const float* w_ref, const float* bias, void* y, float* stats_partial,
                                      int N, int D, int H, int W, int Co, int dtype, pcrl_stream_t stream) {
   PCRL_REQUIRE(x && w_ref && y, "conv3d_k3_c1_fwd: null pointer");
   PCRL_REQUIRE(Co == 16 || Co == 32 || Co == 64, "conv3d_k3_c1_fwd: Co must be 16, 32 or 64 (got %d)", Co);
   const Dims g{N, D, H, W};
   const int64_t M = (int64_t)N * D * H * W;
+  if (c1_brick_ok(D, H, W, dtype)) {
+    const unsigned bricks = (unsigned)pcrl_conv3d_k3_c1_stats_rows(N, D, H, W, Co, dtype);
+    if (Co == 16) hipLaunchKernelGGL(c1_brick_fwd_kernel<16>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g);
+    else if (Co == 32) hipLaunchKernelGGL(c1_brick_fwd_kernel<32>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g);
+    else hipLaunchKernelGGL(c1_brick_fwd_kernel<64>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g);
+    return pcrl_check_launch("c1_brick_fwd");
+  }
   const unsigned blocks = (unsigned)((M + 127) / 128);
   const size_t lds = (size_t)(27 * Co + 128 * (Co + 1)) * sizeof(float);
   if (dtype == PCRL_BF16)
@@ -286,7 +406,6 @@ bool pcrl_to1_brick_eligible(int N, int D, int H, int W, int C, int taps, int dt
 int64_t pcrl_to1_brick_rows(int N, int D, int H, int W);
 int pcrl_to1_brick_launch(const void* x, const float* w_ref, const float* bias, float* y, float* stats, int N, int D, int H, int W, int C,
                           hipStream_t stream);
-int pcrl_debug_conv_impl();   // conv_igemm.hip: 0 = auto
 
 extern "C" int64_t pcrl_conv3d_to1_stats_rows(int N, int D, int H, int W, int C, int taps, int dtype) {
   if (pcrl_debug_conv_impl() == 0 && pcrl_to1_brick_eligible(N, D, H, W, C, taps, dtype)) return pcrl_to1_brick_rows(N, D, H, W);

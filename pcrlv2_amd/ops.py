@@ -178,7 +178,7 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
             raise PcrlError("first-layer input must be a contiguous float32 [N,1,D,H,W] tensor")
         N, _, D, H, W = x.shape
         M = N * D * H * W
-        rows = (M + CONV_BM - 1) // CONV_BM
+        rows = L.call("pcrl_conv3d_k3_c1_stats_rows", N, D, H, W, Co, dtype_code(dtype))
         y = new_act(N, D, H, W, Co, dtype, dev)
         partial = _f32(rows * Co * 2, dev)
         L.call("pcrl_conv3d_k3_c1_fwd", x, conv_w.detach(), conv_b.detach(), y, partial, N, D, H, W, Co, dtype_code(dtype), s)

@@ -169,7 +169,8 @@ def test_first_layer_c1(dt):
     wr = w.clone().requires_grad_(True)
     ref = F.conv3d(x, wr, b, padding=1)
     M = N * D * H * W
-    rows = (M + CONV_BM - 1) // CONV_BM
+    rows = L.call("pcrl_conv3d_k3_c1_stats_rows", N, D, H, W, Co, dtype_code(dt))
+    assert rows == (M + CONV_BM - 1) // CONV_BM
     y = ops.new_act(N, D, H, W, Co, dt, DEV)
     part = torch.zeros(rows * Co * 2, dtype=torch.float32, device=DEV)
     xd = x.float().to(DEV)
@@ -184,6 +185,26 @@ def test_first_layer_c1(dt):
     dw = torch.zeros(Co, 1, 3, 3, 3, dtype=torch.float32, device=DEV)
     L.call("pcrl_conv3d_k3_c1_wgrad", xd, act_dev(dy, dt), dw, ops.workspace(nb, xd.device), nb, N, D, H, W, Co, dtype_code(dt), s)
     check(dw, wr.grad, dt, "c1 wgrad", out_rounded=False, f32_tol=3e-5)
+
+
+@pytest.mark.parametrize("Co", [32, 64])
+def test_first_layer_c1_brick_kernel(Co):
+    """bf16 first-layer forward on a brick-eligible volume: the MFMA kernel (27 taps = one K step, im2col built from the LDS
+    halo) against F.conv3d with x and w rounded to bf16, and its per-brick BatchNorm partials."""
+    dt = torch.bfloat16
+    N, D, H, W = 2, 8, 16, 24
+    L, s = lib(), stream_handle()
+    x, w, b = rnd(N, 1, D, H, W, seed=41), rnd(Co, 1, 3, 3, 3, seed=42), rnd(Co, seed=43)
+    ref = F.conv3d(q(x, dt), q(w, dt), b, padding=1)
+    rows = L.call("pcrl_conv3d_k3_c1_stats_rows", N, D, H, W, Co, dtype_code(dt))
+    assert rows == N * (D // 4) * (H // 8) * (W // 8)
+    y = ops.new_act(N, D, H, W, Co, dt, DEV)
+    part = torch.zeros(rows * Co * 2, dtype=torch.float32, device=DEV)
+    L.call("pcrl_conv3d_k3_c1_fwd", x.float().to(DEV), w.float().to(DEV), b.float().to(DEV), y, part, N, D, H, W, Co, dtype_code(dt), s)
+    check(y, ref, dt, "c1 fwd (brick)")
+    st = back(part).view(rows, Co, 2).sum(0)
+    check(st[:, 0], ref.sum(dim=(0, 2, 3, 4)), dt, "c1 stats sum (brick)", out_rounded=False)
+    check(st[:, 1], (ref * ref).sum(dim=(0, 2, 3, 4)), dt, "c1 stats sumsq (brick)", out_rounded=False)
 
 
 @pytest.mark.parametrize("case", ["c1:32", "to1:64", "to1:128", "to1:256"])
