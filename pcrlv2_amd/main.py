@@ -52,22 +52,26 @@ def build_parser():
 
 
 class SyntheticLunaLoader:
-    """Batches with the contract of datasets/lunaDataset.py:79-81: (input1, input2, gt, gt2, [6 local views])."""
+    """Batches with the contract of datasets/lunaDataset.py:79-81: (input1, input2, gt, gt2, [6 local views]).
+    Generated on `device` (the GPU by default: at ~60 ms per b=32 step a CPU generator would be the bottleneck, as the reference's
+    CPU augmentation workers are -- SURVEY 8f N3); `train_3d` accepts tensors on either side."""
 
-    def __init__(self, b, steps, seed=0):
+    def __init__(self, b, steps, seed=0, device=None):
         import torch
-        self.b, self.steps, self.g = b, steps, torch.Generator().manual_seed(seed)
+        self.device = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.b, self.steps, self.g = b, steps, torch.Generator(device=self.device).manual_seed(seed)
 
     def __len__(self):
         return self.steps
 
     def __iter__(self):
         import torch
+        kw = dict(generator=self.g, device=self.device)
         for _ in range(self.steps):
-            x1 = torch.randn(self.b, 1, 64, 64, 32, generator=self.g)
-            x2 = x1 + 0.1 * torch.randn(self.b, 1, 64, 64, 32, generator=self.g)
-            gt = torch.rand(self.b, 1, 64, 64, 32, generator=self.g)
-            loc = [torch.randn(self.b, 1, 16, 16, 16, generator=self.g) for _ in range(6)]
+            x1 = torch.randn(self.b, 1, 64, 64, 32, **kw)
+            x2 = x1 + 0.1 * torch.randn(self.b, 1, 64, 64, 32, **kw)
+            gt = torch.rand(self.b, 1, 64, 64, 32, **kw)
+            loc = [torch.randn(self.b, 1, 16, 16, 16, **kw) for _ in range(6)]
             yield x1, x2, gt, gt, loc
 
 
