@@ -203,6 +203,16 @@ int pcrl_cosine_mean_bwd(const float* x, const float* y, const float* saved, con
                          int rows, int C, float eps, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * OPTIONAL EXTRA, not part of the reference: NT-Xent (SimCLR) contrastive loss over z = [z1; z2], R = 2N
+ * rows (row i's positive is row (i + N) mod R), temperature tau:
+ *   zn = z / max(|z|, eps);  loss = mean_i ( logsumexp_{k != i} zn_i.zn_k / tau  -  zn_i.zn_pos(i) / tau ).
+ * fwd leaves zn, the softmax and the norms in `ws` (pcrl_ntxent_ws_bytes) for bwd, which must get the same workspace. */
+size_t pcrl_ntxent_ws_bytes(int R, int C);
+int pcrl_ntxent_fwd(const float* z, float* loss, void* ws, size_t ws_bytes, int R, int C, float tau, float eps, pcrl_stream_t stream);
+int pcrl_ntxent_bwd(const float* z, const float* dloss, float* dz, void* ws, size_t ws_bytes, int R, int C, float tau, float eps,
+                    pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * torch.optim.SGD (momentum, weight decay, dampening 0, no nesterov) over a flat parameter arena --
  * train_3d.py:48-51,151.  `offsets`: int64[ntensors+1] element offsets of each tensor in the arena;
  * `flags`: int32[ntensors], bit0 = tensor has a gradient this step (others are skipped, like

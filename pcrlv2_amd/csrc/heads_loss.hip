@@ -298,6 +298,83 @@ __global__ void __launch_bounds__(256) cosine_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// NT-Xent (SimCLR) contrastive loss -- OPTIONAL EXTRA, not in the reference (the reference's contrastive
+// term is the negative cosine similarity above).  z = [z1; z2] is [R = 2N][C]; row i's positive is row (i + N) mod R.
+//   zn = z / max(|z|, eps);  S = zn zn^T / tau;  loss = mean_i ( logsumexp_{k != i} S[i][k] - S[i][pos_i] )
+// fwd: normalise (wave per row) -> S by the small SGEMM -> per-row log-softmax (S is overwritten by the softmax P, diagonal 0).
+// bwd: G = (P - onehot(pos)) * dloss / R;  dzn = (G + G^T) zn / tau;  dz = (dzn - zn (zn . dzn)) / max(|z|, eps).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) ntx_normalize_kernel(const float* __restrict__ z, float* __restrict__ zn, float* __restrict__ nrm,
+                                                            int R, int C, float eps) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = z[(int64_t)r * C + c];
+    ss += v * v;
+  }
+  const float n = fmaxf(sqrtf(wave_sum(ss)), eps);
+  for (int c = lane; c < C; c += 64) zn[(int64_t)r * C + c] = z[(int64_t)r * C + c] / n;
+  if (lane == 0) nrm[r] = n;
+}
+// one wave per row: S[i][:] (already divided by tau) -> P[i][:], li[i]
+__global__ void __launch_bounds__(256) ntx_rows_kernel(float* __restrict__ S, float* __restrict__ li, int R) {
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= R) return;
+  float* row = S + (int64_t)i * R;
+  const int pos = (i + R / 2) % R;
+  float m = -INFINITY;
+  for (int k = lane; k < R; k += 64)
+    if (k != i) m = fmaxf(m, row[k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  float se = 0.f;
+  for (int k = lane; k < R; k += 64)
+    if (k != i) se += expf(row[k] - m);
+  se = wave_sum(se);
+  const float lse = m + logf(se);
+  const float spos = row[pos];
+  for (int k = lane; k < R; k += 64) row[k] = (k == i) ? 0.f : expf(row[k] - lse);
+  if (lane == 0) li[i] = lse - spos;
+}
+__global__ void __launch_bounds__(256) scale_kernel(float* __restrict__ v, int64_t n, float a) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v[i] *= a;
+}
+__global__ void __launch_bounds__(256) ntx_mean_kernel(const float* __restrict__ li, float* __restrict__ loss, int R) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < R; i += 256) s += (double)li[i];
+  s = block_sum_256(s, red);
+  if (threadIdx.x == 0) loss[0] = (float)(s / R);
+}
+// Gs[i][k] = (G[i][k] + G[k][i]) / tau with G = (P - onehot(pos)) * dloss / R   (in place over P is not possible: needs P^T)
+__global__ void __launch_bounds__(256) ntx_gsym_kernel(const float* __restrict__ P, const float* __restrict__ dloss, float* __restrict__ Gs,
+                                                       int R, float inv_tau) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= R * R) return;
+  const int i = idx / R, k = idx % R;
+  const float g = dloss[0] / (float)R;
+  const float a = P[idx] - ((k == (i + R / 2) % R) ? 1.f : 0.f);
+  const float b = P[(int64_t)k * R + i] - ((i == (k + R / 2) % R) ? 1.f : 0.f);
+  Gs[idx] = (i == k) ? 0.f : (a + b) * g * inv_tau;
+}
+__global__ void __launch_bounds__(256) ntx_denorm_kernel(const float* __restrict__ z, const float* __restrict__ zn, const float* __restrict__ dzn,
+                                                         const float* __restrict__ nrm, float* __restrict__ dz, int R, int C, float eps) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) dot += zn[(int64_t)r * C + c] * dzn[(int64_t)r * C + c];
+  dot = wave_sum(dot);
+  const float n = nrm[r];
+  const bool clamped = n <= eps;   // |z| below eps: zn = z / eps, no projection term
+  for (int c = lane; c < C; c += 64) {
+    const int64_t q = (int64_t)r * C + c;
+    dz[q] = clamped ? dzn[q] / n : (dzn[q] - zn[q] * dot) / n;
+  }
+  (void)z;
+}
+
+// ---------------------------------------------------------------------------------------------
 // SGD over a flat arena; per-tensor flags looked up by binary search on the offsets table.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
@@ -474,3 +551,46 @@ extern "C" int pcrl_pack_convt_weight(const float* w_ref, void* w_fwd, void* w_d
   else return pcrl_fail(PCRL_EINVAL, "pack_convt_weight: bad dtype %d", dtype);
   return pcrl_check_launch("pack_convt");
 }
+
+// ---- NT-Xent (optional extra) ----
+extern "C" size_t pcrl_ntxent_ws_bytes(int R, int C) {
+  if (R <= 0 || C <= 0) return 0;
+  return ((size_t)2 * R * C + (size_t)2 * R * R + (size_t)2 * R) * sizeof(float);   // zn, dzn | P, Gs | norms, per-row losses
+}
+extern "C" int pcrl_ntxent_fwd(const float* z, float* loss, void* ws, size_t ws_bytes, int R, int C, float tau, float eps, pcrl_stream_t stream) {
+  PCRL_REQUIRE(z && loss && ws, "ntxent_fwd: null pointer");
+  PCRL_REQUIRE(R >= 4 && R % 2 == 0 && C > 0 && tau > 0.f, "ntxent_fwd: need an even number >= 4 of rows, C > 0, tau > 0 (R=%d C=%d)", R, C);
+  if (ws_bytes < pcrl_ntxent_ws_bytes(R, C)) return pcrl_fail(PCRL_EWORKSPACE, "ntxent_fwd: workspace too small");
+  float* zn = (float*)ws;
+  float* P = zn + (size_t)2 * R * C;
+  float* nrm = P + (size_t)2 * R * R;
+  float* li = nrm + R;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(ntx_normalize_kernel, dim3((R + 3) / 4), dim3(256), 0, st, z, zn, nrm, R, C, eps);
+  // S[i][k] = sum_c zn[i][c] * (zn[k][c] / tau): fold 1/tau by scaling afterwards is a second pass -- instead scale in the row kernel input
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3((R + 31) / 32, (R + 31) / 32), dim3(256), 0, st, zn, (int64_t)C, (int64_t)1, zn, (int64_t)1, (int64_t)C,
+                     (const float*)nullptr, P, R, R, C);
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for((int64_t)R * R)), dim3(256), 0, st, P, (int64_t)R * R, 1.f / tau);
+  hipLaunchKernelGGL(ntx_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, st, P, li, R);
+  hipLaunchKernelGGL(ntx_mean_kernel, dim3(1), dim3(256), 0, st, li, loss, R);
+  return pcrl_check_launch("ntxent_fwd");
+}
+extern "C" int pcrl_ntxent_bwd(const float* z, const float* dloss, float* dz, void* ws, size_t ws_bytes, int R, int C, float tau, float eps,
+                               pcrl_stream_t stream) {
+  PCRL_REQUIRE(z && dloss && dz && ws, "ntxent_bwd: null pointer");
+  PCRL_REQUIRE(R >= 4 && R % 2 == 0 && C > 0 && tau > 0.f, "ntxent_bwd: bad sizes (R=%d C=%d)", R, C);
+  if (ws_bytes < pcrl_ntxent_ws_bytes(R, C)) return pcrl_fail(PCRL_EWORKSPACE, "ntxent_bwd: workspace too small");
+  float* zn = (float*)ws;             // as left by the forward
+  float* dzn = zn + (size_t)R * C;
+  float* P = zn + (size_t)2 * R * C;
+  float* Gs = P + (size_t)R * R;
+  float* nrm = P + (size_t)2 * R * R;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(ntx_gsym_kernel, dim3((R * R + 255) / 256), dim3(256), 0, st, P, dloss, Gs, R, 1.f / tau);
+  // dzn[i][c] = sum_k Gs[i][k] * zn[k][c]
+  hipLaunchKernelGGL(sgemm_small_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, Gs, (int64_t)R, (int64_t)1, zn, (int64_t)C, (int64_t)1,
+                     (const float*)nullptr, dzn, R, C, R);
+  hipLaunchKernelGGL(ntx_denorm_kernel, dim3((R + 3) / 4), dim3(256), 0, st, z, zn, dzn, nrm, dz, R, C, eps);
+  return pcrl_check_launch("ntxent_bwd");
+}
+

@@ -231,3 +231,27 @@ def mse_loss(p, gt):
 
 def cosine_mean(x, y_detached):
     return CosineMeanFn.apply(x, y_detached.detach())
+
+
+class NTXentFn(Function):
+    """OPTIONAL EXTRA -- not the reference's loss (train_3d.py:86-92 is a negative cosine similarity with stop-gradient).
+    NT-Xent / SimCLR: cross-entropy over cosine similarities / temperature of 2N embeddings, positives = the two views."""
+
+    @staticmethod
+    def forward(ctx, z, tau):
+        z = z.contiguous().float()
+        loss, ws = ops.ntxent_forward(z, tau)
+        ctx.save_for_backward(z, ws)
+        ctx.tau = tau
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        z, ws = ctx.saved_tensors
+        return ops.ntxent_backward(z, dloss, ws, ctx.tau), None
+
+
+def ntxent_loss(z1, z2, temperature=0.5):
+    """NT-Xent over the 2N rows [z1; z2] (gradients flow to both).  Not used by train_3d (the reference has no such loss)."""
+    return NTXentFn.apply(torch.cat([z1, z2], dim=0), float(temperature))
+

@@ -438,3 +438,25 @@ def cosine_mean_backward(x, y, saved, dout, eps=1e-8):
     dx = torch.empty_like(x)
     lib().call("pcrl_cosine_mean_bwd", x, y, saved, dout.contiguous().view(1), dx, rows, C, eps, stream_handle())
     return dx
+
+
+# ----------------------------------------------------------------------------------------------
+# Optional extra (not in the reference): NT-Xent contrastive loss
+# ----------------------------------------------------------------------------------------------
+def ntxent_forward(z, tau, eps=1e-8):
+    """z: float32 [2N, C] = [z1; z2].  -> (loss scalar tensor, saved workspace for the backward)."""
+    R, C = z.shape
+    L = lib()
+    nb = L.call("pcrl_ntxent_ws_bytes", R, C)
+    ws = torch.empty(nb, dtype=torch.uint8, device=z.device)   # private: the backward reads what the forward left in it
+    loss = _f32(1, z.device)
+    L.call("pcrl_ntxent_fwd", z, loss, ws, nb, R, C, float(tau), float(eps), stream_handle())
+    return loss.view(()), ws
+
+
+def ntxent_backward(z, dloss, ws, tau, eps=1e-8):
+    R, C = z.shape
+    dz = torch.empty_like(z)
+    lib().call("pcrl_ntxent_bwd", z, dloss.contiguous().view(1), dz, ws, ws.numel(), R, C, float(tau), float(eps), stream_handle())
+    return dz
+

@@ -519,3 +519,24 @@ def test_fused_sgd_matches_torch_sgd():
         check(b.detach(), a.detach(), torch.float32, "sgd param")
     sd = mine.state_dict()
     assert set(sd["state"][0].keys()) == {"momentum_buffer"} and sd["param_groups"][0]["momentum"] == 0.9
+
+
+@pytest.mark.parametrize("N,C,tau", [(32, 64, 0.5), (96, 256, 0.1), (2, 8, 1.0)])
+def test_ntxent_optional_extra(N, C, tau):
+    """NT-Xent (named in north_star, absent from the reference) against its PyTorch float64 definition:
+    cross_entropy(zn zn^T / tau with -inf diagonal, target = the other view), value and gradient w.r.t. both views."""
+    from pcrlv2_amd.functions import ntxent_loss
+    z1, z2 = rnd(N, C, seed=51), rnd(N, C, seed=52)
+    a, b = z1.double().requires_grad_(True), z2.double().requires_grad_(True)
+    zn = F.normalize(torch.cat([a, b]), dim=1, eps=1e-8)
+    sim = zn @ zn.T / tau
+    sim = sim.masked_fill(torch.eye(2 * N, dtype=torch.bool), float("-inf"))
+    ref = F.cross_entropy(sim, (torch.arange(2 * N) + N) % (2 * N))
+    ref.backward()
+    x1, x2 = z1.float().to(DEV).detach().requires_grad_(True), z2.float().to(DEV).detach().requires_grad_(True)
+    loss = ntxent_loss(x1, x2, tau)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) <= 2e-5 * max(1.0, abs(ref.item()))
+    for g, r in ((x1.grad, a.grad), (x2.grad, b.grad)):
+        d = (g.double().cpu() - r).abs().max().item()
+        assert d <= 2e-5 * max(1e-3, r.abs().max().item()) + 1e-8, d
