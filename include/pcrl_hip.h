@@ -31,7 +31,7 @@ extern "C" {
 typedef void* pcrl_stream_t; /* hipStream_t */
 
 enum { PCRL_F32 = 0, PCRL_BF16 = 1 };
-enum { PCRL_ACT_NONE = 0, PCRL_ACT_RELU = 1, PCRL_ACT_SIGMOID = 2 };
+enum { PCRL_ACT_NONE = 0, PCRL_ACT_RELU = 1, PCRL_ACT_SIGMOID = 2, PCRL_ACT_SILU = 3 /* optional extra, not used by the reference path */ };
 enum { PCRL_OK = 0, PCRL_EINVAL = -1, PCRL_ELAUNCH = -2, PCRL_EWORKSPACE = -3 };
 
 #define PCRL_CONV_BM 128 /* rows (voxels) per conv tile == rows per BN-statistics partial */
@@ -211,6 +211,21 @@ size_t pcrl_ntxent_ws_bytes(int R, int C);
 int pcrl_ntxent_fwd(const float* z, float* loss, void* ws, size_t ws_bytes, int R, int C, float tau, float eps, pcrl_stream_t stream);
 int pcrl_ntxent_bwd(const float* z, const float* dloss, float* dz, void* ws, size_t ws_bytes, int R, int C, float tau, float eps,
                     pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * OPTIONAL EXTRA, not part of the reference: GroupNorm(G) + activation on NDHWC activations, built from the
+ * BatchNorm streaming kernels applied per sample with per-(sample, channel) coefficients:
+ *   gn_stats:        partial[n][tile][c][2] = (sum, sum^2) of y over the tile's voxels        (tiles = pcrl_gn_stats_tiles(S))
+ *   gn_finalize:     per (n, group): mean, rstd (biased variance, eps) -> mean_c, rstd_c, scale, shift as [N][C] arrays
+ *   apply:           pcrl_bn_act_apply on sample n with scale + n*C, shift + n*C   (act = PCRL_ACT_SILU for GroupNorm+SiLU)
+ *   backward:        pcrl_bn_act_bwd_reduce per sample (mean_c/rstd_c rows) -> gn_bwd_finalize (k1, kB, kA as [N][C]; per-sample
+ *                    dgamma/dbeta parts [N][C]) -> pcrl_bn_act_bwd_apply per sample. */
+int64_t pcrl_gn_stats_tiles(int64_t S);
+int pcrl_gn_stats(const void* y, float* partial, int N, int64_t S, int C, int dtype, pcrl_stream_t stream);
+int pcrl_gn_finalize(const float* partial, int tiles, int N, int64_t S, int C, int G, const float* gamma, const float* beta, float eps,
+                     float* mean_c, float* rstd_c, float* scale, float* shift, pcrl_stream_t stream);
+int pcrl_gn_bwd_finalize(const float* partial_b, int rows_b, int N, int64_t S, int C, int G, const float* gamma, const float* mean_c,
+                         const float* rstd_c, float* k1, float* kB, float* kA, float* dgamma_n, float* dbeta_n, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * torch.optim.SGD (momentum, weight decay, dampening 0, no nesterov) over a flat parameter arena --

@@ -19,7 +19,7 @@ HEADER = os.path.join(os.path.dirname(_PKG), "include", "pcrl_hip.h")
 LIBPATH = os.path.join(_PKG, "lib", "libpcrl_hip.so")
 
 PCRL_F32, PCRL_BF16 = 0, 1
-ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU = 0, 1, 2, 3   # ACT_SILU: optional extra (GroupNorm+SiLU), not on the reference path
 CONV_BM = 128
 
 _CTYPES = {

@@ -16,6 +16,7 @@ __device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + __expf
 template <int ACT> __device__ __forceinline__ float act_fwd(float z) {
   if (ACT == PCRL_ACT_RELU) return z > 0.f ? z : 0.f;
   if (ACT == PCRL_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
+  if (ACT == PCRL_ACT_SILU) return z / (1.f + expf(-z));
   return z;
 }
 template <int ACT> __device__ __forceinline__ float act_bwd(float z, float da) {
@@ -23,6 +24,10 @@ template <int ACT> __device__ __forceinline__ float act_bwd(float z, float da) {
   if (ACT == PCRL_ACT_SIGMOID) {
     const float a = 1.f / (1.f + expf(-z));
     return da * a * (1.f - a);
+  }
+  if (ACT == PCRL_ACT_SILU) {   // d/dz [z sigma(z)] = sigma (1 + z (1 - sigma))
+    const float a = 1.f / (1.f + expf(-z));
+    return da * a * (1.f + z * (1.f - a));
   }
   return da;
 }
@@ -450,6 +455,7 @@ extern "C" int pcrl_bn_finalize(const float* partial, int rows, int C, double co
   do {                                                                                                                           \
     if (act == PCRL_ACT_RELU) hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_RELU>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__); \
     else if (act == PCRL_ACT_SIGMOID) hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_SIGMOID>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__); \
+    else if (act == PCRL_ACT_SILU) hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_SILU>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_NONE>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__);                    \
   } while (0)
 

@@ -12,7 +12,7 @@ import torch
 from torch.autograd import Function
 
 from . import ops
-from ._lib import ACT_RELU, ACT_SIGMOID
+from ._lib import ACT_RELU, ACT_SIGMOID, ACT_SILU
 
 
 def _act_grad(g, dtype):
@@ -254,4 +254,27 @@ class NTXentFn(Function):
 def ntxent_loss(z1, z2, temperature=0.5):
     """NT-Xent over the 2N rows [z1; z2] (gradients flow to both).  Not used by train_3d (the reference has no such loss)."""
     return NTXentFn.apply(torch.cat([z1, z2], dim=0), float(temperature))
+
+
+class GroupNormActFn(Function):
+    """OPTIONAL EXTRA -- GroupNorm(groups) + activation (SiLU by default) on an NDHWC activation.  Not used by PCRLv23d: the
+    reference instantiates BatchNorm3d + ReLU only and its own norm='gn' option crashes at construction."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, groups, act):
+        a, saved = ops.gn_act_forward(y, gamma.detach(), beta.detach(), groups, act, y.dtype)
+        ctx.save_for_backward(*saved, gamma)
+        ctx.groups, ctx.act = groups, act
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        *saved, gamma = ctx.saved_tensors
+        dy, dg, db = ops.gn_act_backward(ops.to_act(da, saved[0].dtype), tuple(saved), gamma.detach(), ctx.groups, ctx.act, saved[0].dtype)
+        return dy, dg, db, None, None
+
+
+def group_norm_silu(y, gamma, beta, groups=8):
+    """SiLU(GroupNorm(groups)(y)) for an activation in the engine's layout (ops.to_act / channels_last_3d)."""
+    return GroupNormActFn.apply(y, gamma, beta, groups, ACT_SILU)
 

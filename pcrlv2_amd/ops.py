@@ -460,3 +460,42 @@ def ntxent_backward(z, dloss, ws, tau, eps=1e-8):
     lib().call("pcrl_ntxent_bwd", z, dloss.contiguous().view(1), dz, ws, ws.numel(), R, C, float(tau), float(eps), stream_handle())
     return dz
 
+
+# ----------------------------------------------------------------------------------------------
+# Optional extra (not in the reference): GroupNorm(G) + activation on NDHWC activations
+# ----------------------------------------------------------------------------------------------
+def gn_act_forward(y, gamma, beta, groups, act, dtype, eps=1e-5):
+    """a = act(GroupNorm(groups)(y)); y, a: activations [N, C, D, H, W] in NDHWC storage.  -> (a, saved tuple for the backward)."""
+    L, s, dev = lib(), stream_handle(), y.device
+    N, D, H, W, C = dims(y)
+    S = D * H * W
+    tiles = L.call("pcrl_gn_stats_tiles", S)
+    partial = _f32(N * tiles * C * 2, dev)
+    L.call("pcrl_gn_stats", y, partial, N, S, C, dtype_code(dtype), s)
+    mean_c, rstd_c, scale, shift = (_f32(N * C, dev) for _ in range(4))
+    L.call("pcrl_gn_finalize", partial, tiles, N, S, C, groups, gamma, beta, float(eps), mean_c, rstd_c, scale, shift, s)
+    a = torch.empty_like(y)
+    for n in range(N):   # the streaming kernels take one coefficient row per launch
+        L.call("pcrl_bn_act_apply", y[n], a[n], scale[n * C:], shift[n * C:], S, C, act, dtype_code(dtype), s)
+    return a, (y, mean_c, rstd_c, scale, shift)
+
+
+def gn_act_backward(da, saved, gamma, groups, act, dtype):
+    """-> (dy, dgamma [C], dbeta [C])."""
+    y, mean_c, rstd_c, scale, shift = saved
+    L, s, dev = lib(), stream_handle(), y.device
+    N, D, H, W, C = dims(y)
+    S = D * H * W
+    rows_b = L.call("pcrl_bn_bwd_partial_rows", S)
+    partial_b = _f32(N * rows_b * C * 2, dev)
+    for n in range(N):
+        L.call("pcrl_bn_act_bwd_reduce", da[n], y[n], scale[n * C:], shift[n * C:], mean_c[n * C:], rstd_c[n * C:],
+               partial_b[n * rows_b * C * 2:], S, C, act, dtype_code(dtype), s)
+    k1, kB, kA, dg_n, db_n = (_f32(N * C, dev) for _ in range(5))
+    L.call("pcrl_gn_bwd_finalize", partial_b, rows_b, N, S, C, groups, gamma, mean_c, rstd_c, k1, kB, kA, dg_n, db_n, s)
+    dy = torch.empty_like(y)
+    for n in range(N):
+        L.call("pcrl_bn_act_bwd_apply", da[n], y[n], dy[n], scale[n * C:], shift[n * C:], k1[n * C:], kB[n * C:], kA[n * C:], S, C, act,
+               dtype_code(dtype), s)
+    return dy, dg_n.view(N, C).sum(0), db_n.view(N, C).sum(0)
+

@@ -540,3 +540,26 @@ def test_ntxent_optional_extra(N, C, tau):
     for g, r in ((x1.grad, a.grad), (x2.grad, b.grad)):
         d = (g.double().cpu() - r).abs().max().item()
         assert d <= 2e-5 * max(1e-3, r.abs().max().item()) + 1e-8, d
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(3, 64, 4, 6, 5), (2, 32, 8, 8, 8), (2, 128, 2, 3, 4)])
+def test_groupnorm_silu_optional_extra(shape, dt):
+    """GroupNorm(8)+SiLU (named in north_star, absent from the reference) against torch's
+    F.silu(F.group_norm(...)) in float64: output, input gradient, dgamma, dbeta."""
+    from pcrlv2_amd.functions import group_norm_silu
+    N, C, D, H, W = shape
+    x, g, b = rnd(N, C, D, H, W, seed=61), rnd(C, seed=62) * 0.5 + 1.0, rnd(C, seed=63) * 0.1
+    dy = rnd(N, C, D, H, W, seed=64)
+    xq = q(x, dt).double().requires_grad_(True)
+    gr, br = g.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)
+    ref = F.silu(F.group_norm(xq, 8, gr, br, eps=1e-5))
+    ref.backward(q(dy, dt).double())
+    xa = act_dev(x, dt).detach().requires_grad_(True)
+    gd, bd = g.detach().float().to(DEV).requires_grad_(True), b.detach().float().to(DEV).requires_grad_(True)
+    out = group_norm_silu(xa, gd, bd, 8)
+    check(out, ref.detach(), dt, "gn+silu fwd")
+    out.backward(act_dev(dy, dt))
+    check(xa.grad, xq.grad, dt, "gn+silu dx")
+    check(gd.grad, gr.grad, dt, "gn+silu dgamma", out_rounded=False, f32_tol=1e-4)
+    check(bd.grad, br.grad, dt, "gn+silu dbeta", out_rounded=False, f32_tol=1e-4)
