@@ -498,3 +498,66 @@ def test_checkpoint_resume_continues_bit_exactly(dt, tmp_path):
     saved = torch.load(path, weights_only=False)["optimizer"]
     stock.load_state_dict(saved)
     assert len(stock.state) == len(saved["state"]) > 0   # (parameters that had no gradient yet have no buffer, as in torch)
+
+
+DDP2_WORKER = r'''
+import os, sys, random, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle"))
+import pcrlv2_oracle as O
+from pcrlv2_amd import ddp
+from pcrlv2_amd.models import PCRLv23d
+from pcrlv2_amd.optim import FusedSGD
+from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step
+rank, world, _ = ddp.init_process_group_from_env("gloo")     # two processes, ONE GPU: gloo moves the CUDA buffers
+torch.cuda.set_device(0)
+dt = torch.bfloat16
+batches = [O.fill_batch(2, (32, 32, 16), dtype=torch.float32, seed=70 + 10 * rank + s) for s in range(2)]   # different data per rank
+finals = []
+for overlap in (True, False):
+    random.seed(3)                       # same scale draws on every rank
+    model = PCRLv23d().cuda()
+    model.load_state_dict(O.fill_state(torch.float32))
+    model.train().set_compute_dtype(dt)
+    opt = FusedSGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    dp = ddp.DataParallel(model, opt, bucket_mb=8.0, overlap=overlap)
+    assert dp._active and opt.grad_scale == 0.5 and len(dp.reducer.buckets) >= 3
+    early = 0
+    for bt in batches:
+        losses = train_step(model, opt, bt, 3, MSELoss(), CosineSimilarityMean())
+        assert all(torch.isfinite(l) for l in losses)
+    finals.append(opt.flat_p.clone())
+    assert not getattr(dp, "_warned_late", False), "a gradient arrived after its bucket was reduced"
+# overlap on/off give the same parameters, and both ranks hold the same parameters
+assert torch.equal(finals[0], finals[1]), (finals[0] - finals[1]).abs().max()
+mine = finals[0].double().sum().reshape(1).cpu()
+both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+dist.all_gather(both, mine)
+assert both[0].item() == both[1].item(), both
+# the step really used the other rank's data: a single-rank run on this rank's batches ends elsewhere
+random.seed(3)
+model = PCRLv23d().cuda(); model.load_state_dict(O.fill_state(torch.float32)); model.train().set_compute_dtype(dt)
+opt = FusedSGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+for bt in batches:
+    train_step(model, opt, bt, 3, MSELoss(), CosineSimilarityMean())
+assert not torch.equal(opt.flat_p, finals[0])
+dist.barrier()
+print("OK", rank)
+'''
+
+
+def test_data_parallel_two_ranks_one_gpu_gloo(tmp_path):
+    """The N > 1 path on real kernels: two processes (gloo, both on cuda:0) run the full model + FusedSGD + ddp.DataParallel on
+    DIFFERENT batches.  Bucket overlap on/off give bit-identical parameters, both ranks end with the same parameters, no gradient
+    arrives after its bucket was reduced, and the result differs from a single-rank run (the exchange happened)."""
+    import subprocess
+    import sys
+    script = tmp_path / "ddp2.py"
+    script.write_text(DDP2_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29761", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert all("OK" in o for o in outs)
