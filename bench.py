@@ -113,7 +113,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank, local_rank = 0, 0
     if world > 1:
-        rank, world, local_rank = ddp.init_process_group_from_env("nccl")
+        # "nccl" IS RCCL on ROCm; PCRL_DIST_BACKEND=gloo lets the multi-rank code path be exercised with several ranks on ONE GPU
+        rank, world, local_rank = ddp.init_process_group_from_env(os.environ.get("PCRL_DIST_BACKEND", "nccl"))
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     torch.cuda.set_device(local_rank)
