@@ -7,7 +7,8 @@ Differences from the reference: `--gpus` selects the visible devices exactly as 
 process per GPU (RCCL) instead of nn.DataParallel -- with a plain `python main.py` and several ids in --gpus the script
 re-launches itself under torch.distributed.run.  `--momentum/--weight_decay` are parsed as floats.  `--d 2` (the 2D
 ResNet18 path, needs segmentation_models_pytorch) is not part of this engine yet.  `--data synthetic` trains on
-generated LUNA-shaped batches (no dataset on disk needed).
+generated LUNA-shaped batches (no dataset on disk needed); a LUNA pre-task directory is read by pcrlv2_amd/data.py (crops from
+disk, the reference's torchio augmentations restated on the GPU -- parity with torchio unpinned).
 """
 import argparse
 import os
@@ -76,11 +77,14 @@ class SyntheticLunaLoader:
 
 
 def get_dataloader(args):
+    """`DataGenerator(args).pcrlv2_luna_pretask()` of the reference (data.py:63-99) -- `--data synthetic`: generated batches."""
     if args.data == 'synthetic':
         return {'train': SyntheticLunaLoader(args.b, args.steps_per_epoch, args.seed + int(os.environ.get("RANK", "0"))), 'eval': None}
-    raise SystemExit("The LUNA/chest data pipelines (reference data.py, torchio/torchvision) are host-side code outside this engine: "
-                     "pass --data synthetic, or build the loaders with the reference's data.DataGenerator and call "
-                     "pcrlv2_amd.train_3d.train_pcrlv2_3d(args, {'train': loader}) directly (same batch contract).")
+    if args.n == 'luna' and os.path.isdir(os.path.join(args.data, 'subset0')):
+        from .data import luna_pretask_loaders     # raw .npy crops from disk, augmentations on the GPU (pcrlv2_amd/data.py)
+        return luna_pretask_loaders(args)
+    raise SystemExit("--data must be 'synthetic' or a LUNA pre-task directory (subset0..subset9 with <series>_global_<k>.npy / _local_<k>.npy, "
+                     "luna_preprocess.py:134-146).  The chest X-ray (2D) pipeline is not part of this engine.")
 
 
 def main(argv=None):
