@@ -135,8 +135,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__
 // Fast variants for C % VEC == 0 with (C/VEC) dividing 256: a thread owns ONE channel vector for its whole life, so the
 // per-channel coefficients are loaded once into registers and the streaming loop touches only the activations (the generic
 // kernels above re-load 2-5 coefficients per ELEMENT, which bounds them by VMEM issue at ~1.2 TB/s instead of HBM).
-template <typename T, int ACT>
-__global__ void __launch_bounds__(256) bn_apply_rc_kernel(const T* __restrict__ y, T* __restrict__ a, const float* __restrict__ scale,
+template <typename T, int ACT, bool NT>
+__device__ __forceinline__ void bn_apply_rc_kernel_body(const T* __restrict__ y, T* __restrict__ a, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int64_t M, int C) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const int nvec = C / VEC, cv = threadIdx.x % nvec, slot = threadIdx.x / nvec, nslots = 256 / nvec;
@@ -147,16 +147,23 @@ __global__ void __launch_bounds__(256) bn_apply_rc_kernel(const T* __restrict__ 
 #pragma unroll 4
   for (int64_t r = (int64_t)blockIdx.x * nslots + slot; r < M; r += stride) {
     const int64_t off = (r * nvec + cv) * VEC;
-    const Vec16<T> v = ld16(y + off);
+    const Vec16<T> v = ld16_sel<NT>(y + off);
     Vec16<T> o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(act_fwd<ACT>(sc[j] * to_f(v.v[j]) + sh[j]));
-    st16(a + off, o);
+    st16_sel<NT>(a + off, o);
   }
 }
 
 template <typename T, int ACT>
-__global__ void __launch_bounds__(256) bn_bwd_apply_rc_kernel(const T* __restrict__ da, const T* __restrict__ y, T* __restrict__ dy,
+__global__ void __launch_bounds__(256) bn_apply_rc_kernel(const T* __restrict__ y, T* __restrict__ a, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int64_t M, int C, bool nt) {
+  if (nt) bn_apply_rc_kernel_body<T, ACT, true>(y, a, scale, shift, M, C);
+  else bn_apply_rc_kernel_body<T, ACT, false>(y, a, scale, shift, M, C);
+}
+
+template <typename T, int ACT, bool NT>
+__device__ __forceinline__ void bn_bwd_apply_rc_kernel_body(const T* __restrict__ da, const T* __restrict__ y, T* __restrict__ dy,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ k1, const float* __restrict__ kB,
                                                               const float* __restrict__ kA, int64_t M, int C) {
@@ -172,8 +179,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rc_kernel(const T* __restric
 #pragma unroll 4
   for (int64_t r = (int64_t)blockIdx.x * nslots + slot; r < M; r += stride) {
     const int64_t off = (r * nvec + cv) * VEC;
-    const Vec16<T> g = ld16(da + off);
-    const Vec16<T> v = ld16(y + off);
+    const Vec16<T> g = ld16_sel<NT>(da + off);
+    const Vec16<T> v = ld16_sel<NT>(y + off);
     Vec16<T> o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -181,14 +188,23 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rc_kernel(const T* __restric
       const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], to_f(g.v[j]));
       o.v[j] = from_f<T>(c1[j] * dz + cB[j] * yv + cA[j]);
     }
-    st16(dy + off, o);
+    st16_sel<NT>(dy + off, o);
   }
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_apply_rc_kernel(const T* __restrict__ da, const T* __restrict__ y, T* __restrict__ dy,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ k1, const float* __restrict__ kB,
+                                                              const float* __restrict__ kA, int64_t M, int C, bool nt) {
+  if (nt) bn_bwd_apply_rc_kernel_body<T, ACT, true>(da, y, dy, scale, shift, k1, kB, kA, M, C);
+  else bn_bwd_apply_rc_kernel_body<T, ACT, false>(da, y, dy, scale, shift, k1, kB, kA, M, C);
 }
 
 // First-stage reduction of the backward: per 1024-row tile, per channel: (sum dz, sum dz*xhat).
 // Thread = (channel vector, row slot); LDS combine over row slots.  nvec = C/VEC divides 256.
-template <typename T, int ACT>
-__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ y,
+template <typename T, int ACT, bool NT>
+__device__ __forceinline__ void bn_bwd_reduce_kernel_body(const T* __restrict__ da, const T* __restrict__ y,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
                                                             float* __restrict__ partial, int64_t M, int C, int tile_rows) {
@@ -216,8 +232,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t off = ((r + u * (int64_t)nslots) * nvec + cv) * VEC;
-      g[u] = ld16(da + off);
-      v[u] = ld16(y + off);
+      g[u] = ld16_sel<NT>(da + off);
+      v[u] = ld16_sel<NT>(y + off);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -231,8 +247,8 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
   }
   for (; r < rend; r += nslots) {
     const int64_t off = (r * nvec + cv) * VEC;
-    const Vec16<T> g = ld16(da + off);
-    const Vec16<T> v = ld16(y + off);
+    const Vec16<T> g = ld16_sel<NT>(da + off);
+    const Vec16<T> v = ld16_sel<NT>(y + off);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float yv = to_f(v.v[j]);
@@ -264,6 +280,15 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
       partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
     }
   }
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ y,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ partial, int64_t M, int C, int tile_rows, bool nt) {
+  if (nt) bn_bwd_reduce_kernel_body<T, ACT, true>(da, y, scale, shift, mean, rstd, partial, M, C, tile_rows);
+  else bn_bwd_reduce_kernel_body<T, ACT, false>(da, y, scale, shift, mean, rstd, partial, M, C, tile_rows);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -471,11 +496,11 @@ extern "C" int pcrl_bn_act_apply(const void* y, void* a, const float* scale, con
   const dim3 grid_rc(rc_grid(M, C / (C % vec == 0 ? vec : 1)));
   if (dtype == PCRL_BF16) {
     using T = bf16;
-    if (rc) DISPATCH_ACT_T(bn_apply_rc_kernel, grid_rc, 0, (const T*)y, (T*)a, scale, shift, M, C);
+    if (rc) DISPATCH_ACT_T(bn_apply_rc_kernel, grid_rc, 0, (const T*)y, (T*)a, scale, shift, M, C, pcrl_streaming(M * C * (int64_t)sizeof(T)));
     else DISPATCH_ACT_T(bn_apply_kernel, grid, 0, (const T*)y, (T*)a, scale, shift, nvec, C);
   } else {
     using T = float;
-    if (rc) DISPATCH_ACT_T(bn_apply_rc_kernel, grid_rc, 0, (const T*)y, (T*)a, scale, shift, M, C);
+    if (rc) DISPATCH_ACT_T(bn_apply_rc_kernel, grid_rc, 0, (const T*)y, (T*)a, scale, shift, M, C, pcrl_streaming(M * C * (int64_t)sizeof(T)));
     else DISPATCH_ACT_T(bn_apply_kernel, grid, 0, (const T*)y, (T*)a, scale, shift, nvec, C);
   }
   return pcrl_check_launch("bn_act_apply");
@@ -505,10 +530,10 @@ extern "C" int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float
   const size_t lds = (size_t)(256 / nvec) * (nvec * vec) * 2 * sizeof(float);
   if (dtype == PCRL_BF16) {
     using T = bf16;
-    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M));
+    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M), pcrl_streaming(M * C * (int64_t)sizeof(T)));
   } else {
     using T = float;
-    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M));
+    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M), pcrl_streaming(M * C * (int64_t)sizeof(T)));
   }
   return pcrl_check_launch("bn_act_bwd_reduce");
 }
@@ -536,11 +561,11 @@ extern "C" int pcrl_bn_act_bwd_apply(const void* da, const void* y, void* dy, co
   const dim3 grid_rc(rc_grid(M, C / (C % vec == 0 ? vec : 1)));
   if (dtype == PCRL_BF16) {
     using T = bf16;
-    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C);
+    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, pcrl_streaming(M * C * (int64_t)sizeof(T)));
     else DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
   } else {
     using T = float;
-    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C);
+    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, pcrl_streaming(M * C * (int64_t)sizeof(T)));
     else DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
   }
   return pcrl_check_launch("bn_act_bwd_apply");
