@@ -20,3 +20,8 @@ def set_default_compute_dtype(dt):
     _default = _DTYPES[dt.lower()] if isinstance(dt, str) else dt
     if _default not in (torch.float32, torch.bfloat16):
         raise ValueError(f"compute dtype must be float32 or bfloat16, got {dt}")
+
+
+# Parameter gradients are delivered to `.grad` by the engine (pcrlv2_amd.functions) instead of autograd's AccumulateGrad nodes.
+# PCRL_AUTOGRAD_PARAM_GRADS=1 hands them back to autograd (needed for torch.autograd.grad(loss, params), which never accumulates).
+DIRECT_PARAM_GRADS = os.environ.get("PCRL_AUTOGRAD_PARAM_GRADS", "0") != "1"

@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256) coltile_finish_kernel(const float* __rest
   }
 }
 
-template <typename T>
+template <typename T, bool NT>
 __global__ void __launch_bounds__(256) gap_bwd_kernel(const float* __restrict__ dg, const T* add, T* da, int64_t S,
                                                       int C, int64_t nvec_total, float inv_s) {
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -354,21 +354,21 @@ __global__ void __launch_bounds__(256) gap_bwd_kernel(const float* __restrict__ 
     const float* gr = dg + n * C + cv * VEC;
     Vec16<T> o;
     if (add) {
-      const Vec16<T> old = ld16(add + i * VEC);
+      const Vec16<T> old = ld16_sel<NT>(add + i * VEC);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(to_f(old.v[j]) + gr[j] * inv_s);
     } else {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(gr[j] * inv_s);
     }
-    st16(da + i * VEC, o);
+    st16_sel<NT>(da + i * VEC, o);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
 // MaxPool3d(2): thread = (output voxel, channel vector)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, bool NT>
 __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, Dims g, int C, int64_t total) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const int nvec = C / VEC;
@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int64_t row = (((int64_t)n * g.D + 2 * d + (t >> 2)) * g.H + 2 * h + ((t >> 1) & 1)) * g.W + 2 * w + (t & 1);
-      const Vec16<T> v = ld16(x + row * C + cv * VEC);
+      const Vec16<T> v = ld16_sel<NT>(x + row * C + cv * VEC);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float f = to_f(v.v[j]);
@@ -397,7 +397,7 @@ __global__ void __launch_bounds__(256) maxpool_fwd_kernel(const T* __restrict__ 
   }
 }
 
-template <typename T>
+template <typename T, bool NT>
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, Dims g,
                                                           int C, int64_t total) {
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       rows[t] = (((int64_t)n * g.D + 2 * d + (t >> 2)) * g.H + 2 * h + ((t >> 1) & 1)) * g.W + 2 * w + (t & 1);
-      const Vec16<T> v = ld16(x + rows[t] * C + cv * VEC);
+      const Vec16<T> v = ld16_sel<NT>(x + rows[t] * C + cv * VEC);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float f = to_f(v.v[j]);
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
       Vec16<T> o;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o.v[j] = (arg[j] == t) ? gy.v[j] : from_f<T>(0.f);
-      st16(dx + rows[t] * C + cv * VEC, o);
+      st16_sel<NT>(dx + rows[t] * C + cv * VEC, o);
     }
   }
 }
@@ -578,8 +578,11 @@ extern "C" int pcrl_maxpool3d_2_fwd(const void* x, void* y, int N, int D, int H,
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
   const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vec);
   const Dims g{N, D, H, W};
-  if (dtype == PCRL_BF16) hipLaunchKernelGGL(maxpool_fwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const bf16*)x, (bf16*)y, g, C, total);
-  else hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, g, C, total);
+  const bool nt = pcrl_streaming((int64_t)N * D * H * W * C * (dtype == PCRL_BF16 ? 2 : 4));
+#define MP_FWD(T_, NT_) hipLaunchKernelGGL((maxpool_fwd_kernel<T_, NT_>), dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const T_*)x, (T_*)y, g, C, total)
+  if (dtype == PCRL_BF16) { if (nt) MP_FWD(bf16, true); else MP_FWD(bf16, false); }
+  else { if (nt) MP_FWD(float, true); else MP_FWD(float, false); }
+#undef MP_FWD
   return pcrl_check_launch("maxpool_fwd");
 }
 
@@ -590,8 +593,11 @@ extern "C" int pcrl_maxpool3d_2_bwd(const void* x, const void* dy, void* dx, int
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
   const int64_t total = (int64_t)N * (D / 2) * (H / 2) * (W / 2) * (C / vec);
   const Dims g{N, D, H, W};
-  if (dtype == PCRL_BF16) hipLaunchKernelGGL(maxpool_bwd_kernel<bf16>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const bf16*)x, (const bf16*)dy, (bf16*)dx, g, C, total);
-  else hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float*)x, (const float*)dy, (float*)dx, g, C, total);
+  const bool nt = pcrl_streaming((int64_t)N * D * H * W * C * (dtype == PCRL_BF16 ? 2 : 4));
+#define MP_BWD(T_, NT_) hipLaunchKernelGGL((maxpool_bwd_kernel<T_, NT_>), dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const T_*)x, (const T_*)dy, (T_*)dx, g, C, total)
+  if (dtype == PCRL_BF16) { if (nt) MP_BWD(bf16, true); else MP_BWD(bf16, false); }
+  else { if (nt) MP_BWD(float, true); else MP_BWD(float, false); }
+#undef MP_BWD
   return pcrl_check_launch("maxpool_bwd");
 }
 
@@ -640,7 +646,10 @@ extern "C" int pcrl_gap_bwd(const float* dg, const void* add_src, void* da, int 
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
   const int64_t nvt = (int64_t)N * S * (C / vec);
   const float inv = (float)(1.0 / (double)S);
-  if (dtype == PCRL_BF16) hipLaunchKernelGGL(gap_bwd_kernel<bf16>, dim3(grid_for(nvt)), dim3(256), 0, as_stream(stream), dg, (const bf16*)add_src, (bf16*)da, S, C, nvt, inv);
-  else hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for(nvt)), dim3(256), 0, as_stream(stream), dg, (const float*)add_src, (float*)da, S, C, nvt, inv);
+  const bool nt = pcrl_streaming(nvt * 16);
+#define GAP_BWD(T_, NT_) hipLaunchKernelGGL((gap_bwd_kernel<T_, NT_>), dim3(grid_for(nvt)), dim3(256), 0, as_stream(stream), dg, (const T_*)add_src, (T_*)da, S, C, nvt, inv)
+  if (dtype == PCRL_BF16) { if (nt) GAP_BWD(bf16, true); else GAP_BWD(bf16, false); }
+  else { if (nt) GAP_BWD(float, true); else GAP_BWD(float, false); }
+#undef GAP_BWD
   return pcrl_check_launch("gap_bwd");
 }

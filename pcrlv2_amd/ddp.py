@@ -86,16 +86,19 @@ class DataParallel:
 
     Overlap with backward.  A step runs three forwards (view 1, view 2, local views) that share all parameters, and
     autograd replays them in reverse creation order: local, view 2, view 1.  A parameter's gradient is therefore FINAL
-    once the stage of the FIRST forward of the step (pass 0) has run its backward.  The stage Functions set
-    `param._pcrl_final = True` in that case (pcrlv2_amd.functions.mark_final); a post-accumulate-grad hook then marks the
-    parameter ready, and as soon as every parameter of a bucket is ready the bucket's gradients are gathered into the flat
-    arena and its all-reduce is launched on the side stream -- while the rest of backward (earlier layers) is still
-    running.  Whatever is not final by then (parameters without a pass-0 gradient, e.g. the unused deep-supervision
-    heads) is swept up in optimizer.step().  `overlap=False` (or PCRL_DDP_OVERLAP=0) does everything in optimizer.step().
+    once the stage of the FIRST forward of the step (pass 0) has run its backward.  The stage Functions park their parameter
+    gradients (pcrlv2_amd.functions._park) and report final parameters through `functions.mark_final`; as soon as every
+    parameter of a bucket is final the bucket's parked gradients are summed into the flat arena and its all-reduce is launched
+    on the side stream -- while the rest of backward (earlier layers) is still running.  Whatever is not final by then
+    (parameters without a pass-0 gradient, e.g. the unused deep-supervision heads) is swept up in optimizer.step().
+    A gradient that arrives for a bucket already sent ("late"; cannot happen with the reference's step) is all-reduced on its
+    own and added.  `overlap=False` (or PCRL_DDP_OVERLAP=0) does everything in optimizer.step().
     """
 
     def __init__(self, model: torch.nn.Module, optimizer, group=None, bucket_mb: float = 24.0, strict_flags: bool = False,
                  overlap=None, force_collectives: bool = False):
+        from . import functions as Fn
+        self._fn = Fn
         self.model, self.opt, self.group = model, optimizer, group
         self.strict_flags = strict_flags
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -116,11 +119,12 @@ class DataParallel:
         for bi, idxs in enumerate(self._bucket_params):
             for i in idxs:
                 self._param_bucket[i] = bi
+        self._index = {id(p): i for i, p in enumerate(optimizer._plist)}
+        for p, v in zip(optimizer._plist, optimizer._gviews):
+            p._pcrl_gview = v
         self._reset_step()
-        self._hooks = []
         if self._active and self.overlap:
-            for i, p in enumerate(optimizer._plist):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+            Fn.set_ddp_callbacks(self._on_final, self._on_backward_end)
         self.broadcast_state()
 
     # ------------------------------------------------------------------
@@ -128,31 +132,49 @@ class DataParallel:
         self._ready = [0] * len(self.reducer.buckets)
         self._launched = [False] * len(self.reducer.buckets)
         self._gathered = [False] * len(self.opt._plist)
+        self._final = [False] * len(self.opt._plist)
         self._works = []
-        self._late = False
+        self._late = []            # (parameter index, summed late gradient)
 
-    def _make_hook(self, i):
-        def hook(p):
-            if self._gathered[i]:
-                self._late = True      # a gradient arrived after its bucket was sent: redo the reduction in step()
-                return
-            if getattr(p, "_pcrl_final", False) and not self._gathered[i]:
-                p._pcrl_final = False
-                self._gathered[i] = True
-                bi = self._param_bucket[i]
-                self._ready[bi] += 1
-                if self._ready[bi] == len(self._bucket_params[bi]) and not self._launched[bi]:
-                    self._launch_bucket(bi)
-        return hook
+    def _on_final(self, p):
+        """functions.mark_final: nothing will add to this parameter's gradient any more in this step."""
+        i = self._index.get(id(p))
+        if i is None or self._final[i] or self._gathered[i]:
+            return
+        self._final[i] = True
+        bi = self._param_bucket[i]
+        self._ready[bi] += 1
+        if self._ready[bi] == len(self._bucket_params[bi]) and not self._launched[bi]:
+            self._launch_bucket(bi)
 
+    @torch.no_grad()
+    def _on_backward_end(self):
+        """End of a backward pass: gradients still parked go to `.grad`; those of buckets already sent are kept aside."""
+        Fn = self._fn
+        late = []
+        if any(self._launched):
+            for p in Fn.parked_params():
+                i = self._index.get(id(p))
+                if i is not None and self._gathered[i]:
+                    late.append(p)
+        for p in late:
+            gs = Fn.take_parked(p)
+            acc = gs[0].clone()
+            for g in gs[1:]:
+                acc += g
+            self._late.append((self._index[id(p)], acc))
+        Fn.flush_param_grads()
+
+    @torch.no_grad()
     def _launch_bucket(self, bi):
-        """Gather the bucket's gradients into the flat arena (zeros for parameters without one) and start its all-reduce."""
+        """Sum the bucket's gradients into the flat arena (zeros for parameters without one) and start its all-reduce."""
         opt = self.opt
         idxs = self._bucket_params[bi]
-        have = [i for i in idxs if opt._plist[i].grad is not None]
+        self._fn.flush_param_grads([opt._plist[i] for i in idxs])
         miss = [i for i in idxs if opt._plist[i].grad is None]
-        if have:
-            torch._foreach_copy_([opt._gviews[i] for i in have], [opt._plist[i].grad for i in have])
+        copy = [i for i in idxs if opt._plist[i].grad is not None and opt._plist[i].grad.data_ptr() != opt._gviews[i].data_ptr()]
+        if copy:
+            torch._foreach_copy_([opt._gviews[i] for i in copy], [opt._plist[i].grad for i in copy])
         if miss:
             torch._foreach_zero_([opt._gviews[i] for i in miss])
         for i in idxs:
@@ -188,16 +210,6 @@ class DataParallel:
             flags = torch.tensor([1 if h else 0 for h in has], dtype=torch.int32, device=opt.flat_g.device)
             dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=self.group)
             has = [bool(v) for v in flags.tolist()]
-        if self._late:
-            # should not happen (pass-0 backward runs last); stay correct anyway: wait, then gather + reduce everything again
-            for w in self._works:
-                w.wait()
-            if self.reducer.comm_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.reducer.comm_stream)
-            self._works, self._launched = [], [False] * len(self.reducer.buckets)
-            if not getattr(self, "_warned_late", False):
-                print("[pcrlv2_amd.ddp] warning: late gradient accumulation detected; falling back to a full post-backward all-reduce")
-                self._warned_late = True
         for bi in range(len(self.reducer.buckets)):      # buckets are ordered last-parameters-first
             if not self._launched[bi]:
                 self._launch_bucket(bi)
@@ -210,8 +222,13 @@ class DataParallel:
         else:
             for w in self._works:
                 w.wait()
-        for p in opt._plist:
-            if hasattr(p, "_pcrl_final"):
-                p._pcrl_final = False
+        if self._late:
+            # a gradient arrived after its bucket was sent: by linearity, all-reduce the late part on its own and add it
+            if not getattr(self, "_warned_late", False):
+                print("[pcrlv2_amd.ddp] warning: gradient accumulation after a bucket was sent; reducing the late part separately")
+                self._warned_late = True
+            for i, acc in self._late:
+                dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=self.group)
+                opt._gviews[i].add_(acc.view_as(opt._gviews[i]))
         self._reset_step()
         return has

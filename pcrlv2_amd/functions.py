@@ -11,7 +11,7 @@ from __future__ import annotations
 import torch
 from torch.autograd import Function
 
-from . import ops
+from . import config, ops
 from ._lib import ACT_RELU, ACT_SIGMOID, ACT_SILU
 
 
@@ -19,11 +19,95 @@ def _act_grad(g, dtype):
     return ops.to_act(g, dtype)
 
 
+# ---- parameter gradients: delivered to `.grad` by the engine, not by autograd's AccumulateGrad -------------------------------
+# A step runs three forwards over the same parameters (view 1, view 2, local views; train_3d.py:118-121), so autograd would
+# launch one tiny `grad += g` kernel per parameter and extra pass (218 launches per step).  Instead the stage Functions return
+# None for their parameters and park the gradient tensors here; when the backward pass ends (engine callback) -- or earlier,
+# bucket by bucket, when the data-parallel wrapper asks -- all parked gradients are summed with three multi-tensor launches,
+# in autograd's own order (g_first + g_second + g_third), straight into the optimizer's flat gradient arena when the parameter
+# has a slot there (`p._pcrl_gview`, set by FusedSGD), and `.grad` is set like AccumulateGrad would have set it.
+# `torch.autograd.grad(loss, params)` does not accumulate and therefore needs config.DIRECT_PARAM_GRADS = False.
+_parked = {}            # id(parameter) -> (parameter, [gradient tensors in arrival order])
+_callback_queued = False
+_final_callback = None  # set by ddp.DataParallel: callable(param), a parameter's gradient is complete for this step
+_finalize_hook = None   # set by ddp.DataParallel: callable() replacing the default end-of-backward flush
+
+
+def set_ddp_callbacks(final_callback, finalize_hook):
+    global _final_callback, _finalize_hook
+    _final_callback, _finalize_hook = final_callback, finalize_hook
+
+
+def _end_of_backward():
+    global _callback_queued
+    _callback_queued = False
+    if _finalize_hook is not None:
+        _finalize_hook()
+    else:
+        flush_param_grads()
+
+
+def _park(p, g):
+    """Take the gradient `g` of parameter `p` out of autograd's hands (returns what the Function hands to autograd instead)."""
+    global _callback_queued
+    if g is None or not config.DIRECT_PARAM_GRADS:
+        return g
+    if not p.requires_grad:
+        return None
+    _parked.setdefault(id(p), (p, []))[1].append(g)
+    if not _callback_queued:
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        _callback_queued = True
+    return None
+
+
+def parked_params():
+    return [p for p, _ in _parked.values()]
+
+
+def take_parked(p):
+    return _parked.pop(id(p), (p, []))[1]
+
+
+@torch.no_grad()
+def flush_param_grads(params=None):
+    """Sum the parked gradients of `params` (default: all) into `.grad`, level by level with multi-tensor launches."""
+    keys = list(_parked.keys()) if params is None else [id(p) for p in params if id(p) in _parked]
+    items = [_parked.pop(k) for k in keys]
+    if not items:
+        return
+    targets, level = [], 0
+    copy_dst, copy_src = [], []
+    for p, gs in items:
+        if p.grad is not None:
+            targets.append((p.grad, gs, 0))            # accumulation across backward() calls: add everything
+            continue
+        view = getattr(p, "_pcrl_gview", None)
+        if view is not None:
+            copy_dst.append(view)
+            copy_src.append(gs[0])
+            p.grad = view
+        else:
+            own = gs[0].is_contiguous() and gs[0].shape == p.shape and not ops.is_shared_zero(gs[0])
+            p.grad = gs[0] if own else gs[0].reshape(p.shape).clone()
+        targets.append((p.grad, gs, 1))
+    if copy_dst:
+        torch._foreach_copy_(copy_dst, copy_src)
+    while True:
+        pairs = [(t, gs[first + level]) for t, gs, first in targets if first + level < len(gs)]
+        if not pairs:
+            break
+        pairs = [(t, g) for t, g in pairs if not ops.is_shared_zero(g)]     # conv biases in front of a BatchNorm: exactly zero
+        if pairs:
+            torch._foreach_add_([t for t, _ in pairs], [g for _, g in pairs])
+        level += 1
+
+
 def mark_final(ctx, params):
     """Backward of a stage that ran in the FIRST forward of the step: nothing will add to these gradients any more."""
-    if getattr(ctx, "pass_idx", 1) == 0:
+    if getattr(ctx, "pass_idx", 1) == 0 and _final_callback is not None:
         for p in params:
-            p._pcrl_final = True
+            _final_callback(p)
 
 
 class LUConvFn(Function):
@@ -49,8 +133,10 @@ class LUConvFn(Function):
         da = da.contiguous() if sv.kind == "to1" else _act_grad(da, ctx.dt)
         dx, dw, db, dg, dbeta = ops.luconv_backward(sv, da, ctx.wref, ctx.gref, ctx.mod._packed, ctx.dt,
                                                     need_dx=ctx.needs_input_grad[0] and sv.kind != "c1")
+        w, b, gamma, beta = ctx.plist
+        out = dx, _park(w, dw), _park(b, db), _park(gamma, dg), _park(beta, dbeta), None
         mark_final(ctx, ctx.plist)
-        return dx, dw, db, dg, dbeta, None
+        return out
 
 
 class MaxPoolFn(Function):
@@ -151,6 +237,8 @@ class UpStageFn(Function):
         dx, g_upw, g_upb = ops.convt_backward(ctx.x, d_up, up_w, mod._packed_up, dt, need_dx=ctx.needs_input_grad[0], db=g_upb)
         grads[0], grads[1], grads[2] = dx, g_upw, g_upb
         ctx.svd.x = None
+        for k, p in enumerate(ctx.plist):
+            grads[k + 1] = _park(p, grads[k + 1])
         mark_final(ctx, ctx.plist)
         return tuple(grads)
 
@@ -175,8 +263,9 @@ class OutFn(Function):
         if dout is None:
             return None, None, None, None
         dx, dw, db = ops.conv1x1_to1_backward(ctx.x, ctx.saved_tensors[0], dout, ctx.w, ctx.dt, need_dx=ctx.needs_input_grad[0])
+        out = dx, _park(ctx.plist[0], dw), _park(ctx.plist[1], db), None
         mark_final(ctx, ctx.plist)
-        return dx, dw, db, None
+        return out
 
 
 class TrilinearFn(Function):

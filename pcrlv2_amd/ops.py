@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import torch
 
+from . import config
 from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, CONV_BM, PcrlError, dtype_code, lib, stream_handle
 
 BN_EPS = 1e-5
@@ -56,6 +57,26 @@ def to_act(x: torch.Tensor, dtype) -> torch.Tensor:
 
 def _f32(n, device):
     return torch.empty(n, dtype=torch.float32, device=device)
+
+
+_zero_cache: dict = {}
+
+
+def zero_grad_vector(n, device):
+    """Gradient of a bias that is identically zero.  With engine-delivered parameter gradients the same read-only zeros are
+    handed out every time (no fill kernel; functions.flush_param_grads copies, never adopts, a shared tensor)."""
+    if not config.DIRECT_PARAM_GRADS:
+        return torch.zeros(n, dtype=torch.float32, device=device)
+    key = (n, str(device))
+    t = _zero_cache.get(key)
+    if t is None:
+        t = _zero_cache[key] = torch.zeros(n, dtype=torch.float32, device=device)
+        t._pcrl_shared_zero = True
+    return t
+
+
+def is_shared_zero(t) -> bool:
+    return getattr(t, "_pcrl_shared_zero", False)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -221,7 +242,7 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
     M = N * D * H * W
     dev = sv.y.device
     dw = torch.empty_like(conv_w, dtype=torch.float32, memory_format=torch.contiguous_format)
-    db = torch.zeros(Co, dtype=torch.float32, device=dev)
+    db = zero_grad_vector(Co, dev)
     if sv.kind == "to1":
         da = da.contiguous()
         dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, 1, sv.act, torch.float32)

@@ -137,8 +137,22 @@ DP_WORKER = r'''
 import os, sys, types, torch, torch.distributed as dist
 sys.path.insert(0, sys.argv[1])
 from pcrlv2_amd.ddp import DataParallel, init_process_group_from_env
+from pcrlv2_amd import functions as Fn
 rank, world, _ = init_process_group_from_env("gloo")
 torch.manual_seed(0)
+
+class Dot(torch.autograd.Function):
+    # stand-in for a stage Function: parks its parameter gradient, reports it final when it ran in pass 0
+    @staticmethod
+    def forward(ctx, p, x, pass_idx):
+        ctx.p, ctx.x, ctx.pass_idx = p, x, pass_idx
+        return (p.detach() * x).sum()
+    @staticmethod
+    def backward(ctx, g):
+        out = Fn._park(ctx.p, g * ctx.x)
+        Fn.mark_final(ctx, [ctx.p])
+        return out, None, None
+
 shapes = [(300,), (7, 5), (2000,), (3,), (64, 8)]
 params = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
 sizes = [p.numel() for p in params]
@@ -151,32 +165,38 @@ opt.gather_grads = lambda: None
 model = torch.nn.Module()
 dp = DataParallel(model, opt, bucket_mb=0.004, overlap=True)     # ~1000 floats per bucket -> several buckets
 assert opt.grad_scale == 1.0 / world and len(dp.reducer.buckets) >= 3
-for step in range(2):
+for step in range(3):
     # parameter 3 has no gradient at all (unused head); parameter 1 gets a gradient only from a non-final pass
     x = [torch.full(s, float(rank + 1 + step)) for s in shapes]
     for p in params: p.grad = None
-    # "pass 1" (not final) for params 0,1,2,4
-    loss = sum((p * xi).sum() for i, (p, xi) in enumerate(zip(params, x)) if i != 3)
-    loss.backward()
-    # "pass 0" (final) for params 0,2,4: mark, then accumulate again
-    for i in (0, 2, 4): params[i]._pcrl_final = True
-    loss = sum((p * xi).sum() for i, (p, xi) in enumerate(zip(params, x)) if i in (0, 2, 4))
-    loss.backward()
+    # forward "pass 0" (final) for params 0,2,4, then "pass 1" for params 0,1,2,4; ONE backward replays pass 1 first
+    l0 = sum(Dot.apply(params[i], x[i], 0) for i in (0, 2, 4))
+    l1 = sum(Dot.apply(params[i], x[i], 1) for i in (0, 1, 2, 4))
+    late = step == 2
+    if late:      # a second backward after the buckets of 0,2,4 went out: the late-gradient path
+        l0.backward(retain_graph=False)
+        gone = [i for i in (0, 1, 2, 4) if dp._gathered[i]]
+        assert len(gone) >= 1
+        l1.backward()
+        assert sorted(i for i, _ in dp._late) == gone, (dp._late, gone)
+    else:
+        (l0 + l1).backward()
+        assert sum(dp._launched) >= 1 and not dp._late      # buckets went out from inside backward
+    assert all(params[i].grad is not None for i in (0, 1, 2, 4)) and params[3].grad is None
     has = dp._pre_step(opt, None)
     assert has == [True, True, True, False, True], has
     tot = sum(r + 1 + step for r in range(world))
     for i, v in enumerate(opt._gviews):
         mult = {0: 2, 1: 1, 2: 2, 3: 0, 4: 2}[i]
         assert torch.allclose(v, torch.full_like(v, float(mult * tot))), (step, i, v.flatten()[:3], mult * tot)
-    assert not dp._late
 dist.barrier()
 print("OK", rank)
 '''
 
 
 def test_data_parallel_overlap_logic_gloo_world2(tmp_path):
-    """ddp.DataParallel (bucket readiness via final-pass marks, zero-fill of grad-less parameters, sweep in step())
-    with 2 gloo ranks on CPU and a stand-in optimizer."""
+    """ddp.DataParallel (parked parameter gradients, bucket readiness via final-pass marks, zero-fill of grad-less parameters,
+    sweep in step(), late gradients) with 2 gloo ranks on CPU and a stand-in optimizer."""
     script = tmp_path / "dp.py"
     script.write_text(DP_WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29741", WORLD_SIZE="2")
