@@ -227,6 +227,44 @@ int pcrl_gn_finalize(const float* partial, int tiles, int N, int64_t S, int C, i
 int pcrl_gn_bwd_finalize(const float* partial_b, int rows_b, int N, int64_t S, int C, int G, const float* gamma, const float* mean_c,
                          const float* rstd_c, float* k1, float* kB, float* kA, float* dgamma_n, float* dbeta_n, pcrl_stream_t stream);
 
+/* =======================================================================================
+ * 2D path: the PCRLv2 ResNet-18 U-Net of models/pcrlv2_model.py:68-209 (decoder) and the smp/torchvision ResNet-18
+ * encoder it wraps (pcrlv2_model.py:200).  Activations NHWC ([N][H][W][C], C-contiguous), float32 or bf16.
+ *
+ * Convolution KHxKW, stride 1|2, zero padding `pad`, optional fused nearest x2 upsample of the input (F.interpolate(scale_factor=2,
+ * mode="nearest") at pcrlv2_model.py:114 followed by conv1): replaces aten::convolution / convolution_backward for nn.Conv2d.
+ * Source channel counts must be powers of two >= 8: the caller zero-pads 3-channel tensors (image, 3-channel gradients) to 8.
+ *   pack  : reference weight float32 [Co][Ci][KH][KW] -> K-contiguous rows in `dtype`; mode 0 = forward ([round32(Co)][Kpad],
+ *           k = tap*CsP + ci), mode 1 = data gradient ([round32(Ci)][Kpad], k = tap*CsP + co); Kpad = round32(KH*KW*CsP);
+ *           pcrl_conv2d_packed_elems(rows, taps, CsP) elements.
+ *   fwd   : y[N][Ho][Wo][Co] (+bias), `out_f32` stores float32 whatever `dtype`; stats_partial = pcrl_conv2d_stats_rows(N,Ho,Wo)
+ *           rows of [Co][2] (sum, sum^2) for the BatchNorm2d that follows, or NULL.  Hi/Wi = stored input dims (before `up`).
+ *   dgrad : dx[N][Hi][Wi][Ci] from dy[N][Ho][Wo][CoP]  (for a fused-upsample forward Hi/Wi are the UPSAMPLED dims; follow with
+ *           pcrl_upsample2d_nearest2_bwd)
+ *   wgrad : dw float32 [CoP][Ci_out][KH][KW]; ws: pcrl_conv2d_wgrad_ws_bytes */
+int64_t pcrl_conv2d_packed_elems(int rows, int taps, int CsP);
+int pcrl_conv2d_pack(const float* w_ref, void* out, int Co, int Ci, int KH, int KW, int CsP, int mode, int dtype, pcrl_stream_t stream);
+int64_t pcrl_conv2d_stats_rows(int N, int Ho, int Wo);
+int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, int N, int Hi, int Wi, int CiP,
+                    int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream);
+int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH,
+                      int KW, int stride, int pad, int dtype, pcrl_stream_t stream);
+size_t pcrl_conv2d_wgrad_ws_bytes(int N, int Ho, int Wo, int CiP, int CoP, int KH, int KW);
+int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int CiP, int Ci_out,
+                      int Ho, int Wo, int CoP, int KH, int KW, int stride, int pad, int up, int dtype, pcrl_stream_t stream);
+
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet stem; idx: uint8 [N][Ho][Wo][C] window position of the maximum. */
+int pcrl_maxpool2d_3s2_fwd(const void* x, void* y, uint8_t* idx, int N, int H, int W, int C, int dtype, pcrl_stream_t stream);
+int pcrl_maxpool2d_3s2_bwd(const void* dy, const uint8_t* idx, void* dx, int N, int H, int W, int C, int dtype, pcrl_stream_t stream);
+/* backward of the nearest x2 upsample: dx[N][H][W][C] = sum of the 2x2 block of dy[N][2H][2W][C] */
+int pcrl_upsample2d_nearest2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype, pcrl_stream_t stream);
+/* F.interpolate(scale_factor=s, mode="bilinear", align_corners=False) on float32 NHWC maps (pcrlv2_model.py:190); N,H,W: INPUT dims */
+int pcrl_upsample2d_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int scale, pcrl_stream_t stream);
+int pcrl_upsample2d_bilinear_bwd(const float* dy, float* dx, int N, int H, int W, int C, int scale, pcrl_stream_t stream);
+/* BasicBlock tail: a = relu(t + r);  backward mask: g = da where a > 0 */
+int pcrl_add_relu_fwd(const void* t, const void* r, void* a, int64_t n, int dtype, pcrl_stream_t stream);
+int pcrl_relu_mask_bwd(const void* da, const void* a, void* g, int64_t n, int dtype, pcrl_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * torch.optim.SGD (momentum, weight decay, dampening 0, no nesterov) over a flat parameter arena --
  * train_3d.py:48-51,151.  `offsets`: int64[ntensors+1] element offsets of each tensor in the arena;

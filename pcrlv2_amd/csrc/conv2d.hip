@@ -1,0 +1,390 @@
+// 2D convolutions of the PCRLv2 (ResNet-18 U-Net) path as implicit GEMMs on MFMA for gfx950.
+//
+// Replaces aten::convolution / convolution_backward(input) dispatched from the reference's 2D model: the smp/torchvision
+// ResNet-18 encoder (7x7 s2 stem, 3x3 s1/s2 BasicBlock convs, 1x1 s2 downsample) and models/pcrlv2_model.py:68-128
+// (DecoderBlock: nearest x2 -> Conv2dReLU x2, deep-supervision head conv3x3 + conv1x1, segmentation head conv3x3).
+//
+// ONE gather kernel covers every geometry.  GEMM view: rows = output pixels (M = N*Ho*Wo), columns = output channels,
+// K = (kh, kw, source channel) flattened, k = tap * Cs + c with Cs a power of two >= 8 (the host zero-pads 3-channel
+// tensors to 8).  Activations are NHWC, so a 16-byte slot of an A-tile row is 8 (bf16) / 4 (fp32) consecutive channels of ONE
+// tap: every thread decodes the tap of ITS slot (shift/mask + a multiply-shift for tap -> kh, kw), which makes K-steps that
+// straddle taps (Cs = 8, 16) as cheap as the 32-channel case; K is padded to a multiple of 32 with zero weights.
+//   FWD   : source pixel (oh*s - p + kh, ow*s - p + kw); `up` = the source is read through a nearest x2 upsample
+//           (F.interpolate(scale_factor=2, mode="nearest") of DecoderBlock.forward fused into the gather: ih>>1, iw>>1)
+//   DGRAD : source = dy, pixel ((ih + p - kh)/s, (iw + p - kw)/s) when divisible; weights packed [ci][tap][co]
+// Tile 128 x BN (BN = 32/64/128) as in conv_igemm.hip: 4 waves 2x2, LDS double-buffered and XOR-swizzled, register-staged
+// (padding needs zero-fill), two staging register sets.  Epilogue: + bias, store (T or float32, columns >= Nc masked), and the
+// per-tile (sum, sum^2) rows for the training-mode BatchNorm2d that follows.
+#include "common.h"
+
+namespace {
+
+enum { C2_FWD = 0, C2_DGRAD = 1 };
+
+struct C2Params {
+  const void* x;      // source rows [N*Hs*Ws][Cs]
+  const void* w;      // packed weights [NcP][Kpad]
+  const float* bias;  // [Nc] or null
+  void* y;            // [M][Nc]  (T, or float when out_f32)
+  float* stats;       // [gridDim.x][Nc][2] or null
+  int N, Hs, Ws;      // source dims as stored
+  int Ho, Wo;         // GEMM row space
+  int Cs, cs_shift;
+  int Nc;
+  int KH, KW, kw_mul;  // kh = (tap * kw_mul) >> 16
+  int stride, pad, up;
+  int Ktot, Kpad;
+  int out_f32;
+  int64_t M;
+};
+
+template <typename T> struct Tile {
+  static constexpr int ROWB = 32 * (int)sizeof(T);
+  static constexpr int SLOTS = ROWB / 16;
+  static constexpr int RPB = 256 / ROWB;
+  static __device__ __forceinline__ int off(int row, int slot) {
+    const int q = row / RPB;
+    const int key = (SLOTS == 4) ? ((0x78 >> ((q & 3) * 2)) & 3) : (q & (SLOTS - 1));
+    return row * ROWB + ((slot ^ key) << 4);
+  }
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  using Frag = bf16x8;
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int g) {
+    return *reinterpret_cast<const bf16x8*>(tile + Tile<bf16>::off(row, g));
+  }
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  struct Frag { f32x4 lo, hi; };
+  static __device__ __forceinline__ Frag read(const char* tile, int row, int g) {
+    Frag f;
+    f.lo = *reinterpret_cast<const f32x4*>(tile + Tile<float>::off(row, 2 * g));
+    f.hi = *reinterpret_cast<const f32x4*>(tile + Tile<float>::off(row, 2 * g + 1));
+    return f;
+  }
+  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[e], b.lo[e], c, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[e], b.hi[e], c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN, int MODE>
+__global__ void __launch_bounds__(256) conv2d_kernel(const C2Params p) {
+  constexpr int BM = PCRL_CONV_BM;
+  using TL = Tile<T>;
+  using MM = Mma<T>;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int SLOTS = TL::SLOTS;
+  constexpr int RPP = 256 / SLOTS;
+  constexpr int AP = BM / RPP;
+  constexpr int BP = (BN + RPP - 1) / RPP;
+  constexpr int FM = 4, FN = BN / 32;
+  constexpr int A_BYTES = BM * TL::ROWB, B_BYTES = BN * TL::ROWB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* As = smem;
+  char* Bs = smem + 2 * A_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
+  const T* __restrict__ Wp = reinterpret_cast<const T*>(p.w);
+  const int slot = tid % SLOTS, rowp = tid / SLOTS;
+  const int Cs = p.Cs;
+  // logical source extent (through the nearest upsample when `up`)
+  const int Hl = p.up ? 2 * p.Hs : p.Hs, Wl = p.up ? 2 * p.Ws : p.Ws;
+  const int sshift = p.stride - 1;   // stride is 1 or 2
+
+  // ---- per-thread A rows ----
+  int64_t nbase[AP];   // row of source pixel (n, 0, 0); -1 marks a dead row
+  int oy[AP], ox[AP];
+#pragma unroll
+  for (int ps = 0; ps < AP; ++ps) {
+    const int64_t m = m0 + ps * RPP + rowp;
+    nbase[ps] = -1;
+    oy[ps] = ox[ps] = 0;
+    if (m < p.M) {
+      const int ow = (int)(m % p.Wo);
+      const int64_t t = m / p.Wo;
+      const int oh = (int)(t % p.Ho), n = (int)(t / p.Ho);
+      nbase[ps] = (int64_t)n * p.Hs * p.Ws;
+      if (MODE == C2_FWD) {
+        oy[ps] = oh * p.stride - p.pad;
+        ox[ps] = ow * p.stride - p.pad;
+      } else {
+        oy[ps] = oh + p.pad;
+        ox[ps] = ow + p.pad;
+      }
+    }
+  }
+  // ---- per-thread B rows ----
+  int64_t boff[BP];
+  bool bok[BP];
+#pragma unroll
+  for (int ps = 0; ps < BP; ++ps) {
+    const int brow = ps * RPP + rowp;
+    bok[ps] = brow < BN;
+    boff[ps] = (int64_t)(n0 + (bok[ps] ? brow : 0)) * p.Kpad + slot * VEC;
+  }
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int S = p.Kpad / 32;
+  u32x4 raA[AP], rbA[BP], raB[AP], rbB[BP];
+  uint32_t aokA = 0, aokB = 0;
+
+  // Loads are unconditional from clamped addresses (see conv_igemm.hip); validity is applied at the LDS store.
+#define C2_LOAD(s_, ra, rb, aok)                                                                        \
+  do {                                                                                                  \
+    const int k_ = (s_)*32 + slot * VEC;                                                                \
+    const int tap_ = k_ >> p.cs_shift, c_ = k_ & (Cs - 1);                                              \
+    const int kh_ = (tap_ * p.kw_mul) >> 16, kw_ = tap_ - kh_ * p.KW;                                   \
+    const bool kok_ = k_ < p.Ktot;                                                                      \
+    aok = 0;                                                                                            \
+    _Pragma("unroll") for (int ps = 0; ps < AP; ++ps) {                                                 \
+      int ih_, iw_;                                                                                     \
+      bool ok_ = kok_ && nbase[ps] >= 0;                                                                \
+      if (MODE == C2_FWD) {                                                                             \
+        ih_ = oy[ps] + kh_;                                                                             \
+        iw_ = ox[ps] + kw_;                                                                             \
+        ok_ = ok_ && (unsigned)ih_ < (unsigned)Hl && (unsigned)iw_ < (unsigned)Wl;                      \
+        if (p.up) {                                                                                     \
+          ih_ >>= 1;                                                                                    \
+          iw_ >>= 1;                                                                                    \
+        }                                                                                               \
+      } else {                                                                                          \
+        const int th_ = oy[ps] - kh_, tw_ = ox[ps] - kw_;                                               \
+        ih_ = th_ >> sshift;                                                                            \
+        iw_ = tw_ >> sshift;                                                                            \
+        ok_ = ok_ && th_ >= 0 && tw_ >= 0 && (ih_ << sshift) == th_ && (iw_ << sshift) == tw_ && ih_ < p.Hs && iw_ < p.Ws; \
+      }                                                                                                 \
+      const int64_t row_ = ok_ ? nbase[ps] + (int64_t)ih_ * p.Ws + iw_ : (int64_t)0;                    \
+      ra[ps] = *reinterpret_cast<const u32x4*>(X + row_ * Cs + (ok_ ? c_ : 0));                         \
+      aok |= (uint32_t)ok_ << ps;                                                                       \
+    }                                                                                                   \
+    _Pragma("unroll") for (int ps = 0; ps < BP; ++ps)                                                   \
+      rb[ps] = *reinterpret_cast<const u32x4*>(Wp + boff[ps] + (int64_t)(s_)*32);                       \
+  } while (0)
+
+#define C2_STORE(buf_, ra, rb, aok)                                                                     \
+  do {                                                                                                  \
+    _Pragma("unroll") for (int ps = 0; ps < AP; ++ps)                                                   \
+      *reinterpret_cast<u32x4*>(As + (buf_)*A_BYTES + TL::off(ps * RPP + rowp, slot)) =                 \
+          keep_if((aok >> ps) & 1u, ra[ps]);                                                            \
+    _Pragma("unroll") for (int ps = 0; ps < BP; ++ps) {                                                 \
+      if (bok[ps]) *reinterpret_cast<u32x4*>(Bs + (buf_)*B_BYTES + TL::off(ps * RPP + rowp, slot)) = rb[ps]; \
+    }                                                                                                   \
+  } while (0)
+
+#define C2_COMPUTE(cur_)                                                                                \
+  do {                                                                                                  \
+    const char* a = As + (cur_)*A_BYTES;                                                                \
+    const char* b = Bs + (cur_)*B_BYTES;                                                                \
+    typename MM::Frag fa[FM], fb[FN];                                                                   \
+    _Pragma("unroll") for (int i = 0; i < FM; ++i) fa[i] = MM::read(a, wm * 64 + i * 16 + lr, lg);      \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j) fb[j] = MM::read(b, wn * (BN / 2) + j * 16 + lr, lg); \
+    _Pragma("unroll") for (int i = 0; i < FM; ++i)                                                      \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j) MM::mma(fa[i], fb[j], acc[i][j]);                  \
+  } while (0)
+
+#define C2_CLAMP(s_) ((s_) < S ? (s_) : S - 1)
+
+  C2_LOAD(0, raA, rbA, aokA);
+  C2_STORE(0, raA, rbA, aokA);
+  C2_LOAD(C2_CLAMP(1), raA, rbA, aokA);
+  __syncthreads();
+  for (int s = 0; s < S; s += 2) {
+    C2_LOAD(C2_CLAMP(s + 2), raB, rbB, aokB);
+    __builtin_amdgcn_sched_barrier(0);
+    C2_COMPUTE(0);
+    __builtin_amdgcn_sched_barrier(0);
+    C2_STORE(1, raA, rbA, aokA);
+    __syncthreads();
+    if (s + 1 >= S) break;
+    C2_LOAD(C2_CLAMP(s + 3), raA, rbA, aokA);
+    __builtin_amdgcn_sched_barrier(0);
+    C2_COMPUTE(1);
+    __builtin_amdgcn_sched_barrier(0);
+    C2_STORE(0, raB, rbB, aokB);
+    __syncthreads();
+  }
+#undef C2_LOAD
+#undef C2_STORE
+#undef C2_COMPUTE
+#undef C2_CLAMP
+
+  // ---- epilogue ----
+  T* __restrict__ Y = reinterpret_cast<T*>(p.y);
+  float* __restrict__ Yf = reinterpret_cast<float*>(p.y);
+  float s1[FN], s2[FN], bv[FN];
+  bool cok[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int col = n0 + wn * (BN / 2) + j * 16 + lr;
+    cok[j] = col < p.Nc;
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+    bv[j] = (p.bias && cok[j]) ? p.bias[col] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t m = m0 + wm * 64 + i * 16 + lg * 4 + r;
+      if (m < p.M) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          if (cok[j]) {
+            const float v = acc[i][j][r] + bv[j];
+            const int64_t o = m * p.Nc + n0 + wn * (BN / 2) + j * 16 + lr;
+            if (p.out_f32) Yf[o] = v;
+            else Y[o] = from_f<T>(v);
+            s1[j] += v;
+            s2[j] += v * v;
+          }
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float a = s1[j], b = s2[j];
+      a += __shfl_xor(a, 16, 64);
+      b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (lg == 0) {
+        red[((wid * FN + j) * 16 + lr) * 2 + 0] = a;
+        red[((wid * FN + j) * 16 + lr) * 2 + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.Nc) {
+      const int wn_ = tid / (BN / 2), within = tid % (BN / 2);
+      const int j = within / 16, l = within % 16;
+      const float* r0 = red + (((0 * 2 + wn_) * FN + j) * 16 + l) * 2;
+      const float* r1 = red + (((1 * 2 + wn_) * FN + j) * 16 + l) * 2;
+      float* o = p.stats + ((int64_t)blockIdx.x * p.Nc + n0 + tid) * 2;
+      o[0] = r0[0] + r1[0];
+      o[1] = r0[1] + r1[1];
+    }
+  }
+}
+
+// Packing: reference weight [Co][Ci][KH][KW] float32 -> K-contiguous rows in T, zero padded.
+//   mode 0 (forward): out[co][tap * CsP + ci],  rows = round_up(Co, 32), CsP = padded source channels (Ci)
+//   mode 1 (dgrad)  : out[ci][tap * CsP + co],  rows = round_up(Ci, 32), CsP = padded source channels (Co)
+template <typename T>
+__global__ void __launch_bounds__(256) pack_conv2d_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int taps, int CsP,
+                                                          int rowsP, int Kpad, int mode) {
+  const int64_t total = (int64_t)rowsP * Kpad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int row = (int)(idx / Kpad), k = (int)(idx % Kpad);
+    const int tap = k / CsP, c = k % CsP;
+    float v = 0.f;
+    if (tap < taps) {
+      const int co = mode ? c : row, ci = mode ? row : c;
+      if (co < Co && ci < Ci) v = w[((int64_t)co * Ci + ci) * taps + tap];
+    }
+    out[idx] = from_f<T>(v);
+  }
+}
+
+int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return s;
+}
+
+template <typename T, int MODE> int launch_bn(const C2Params& p, int NcP, hipStream_t stream) {
+  using TL = Tile<T>;
+  const unsigned gx = (unsigned)((p.M + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
+  if (NcP % 128 == 0) {
+    hipLaunchKernelGGL((conv2d_kernel<T, 128, MODE>), dim3(gx, NcP / 128), dim3(256), 2 * (size_t)(PCRL_CONV_BM + 128) * TL::ROWB, stream, p);
+  } else if (NcP % 64 == 0) {
+    hipLaunchKernelGGL((conv2d_kernel<T, 64, MODE>), dim3(gx, NcP / 64), dim3(256), 2 * (size_t)(PCRL_CONV_BM + 64) * TL::ROWB, stream, p);
+  } else {
+    hipLaunchKernelGGL((conv2d_kernel<T, 32, MODE>), dim3(gx, NcP / 32), dim3(256), 2 * (size_t)(PCRL_CONV_BM + 32) * TL::ROWB, stream, p);
+  }
+  return pcrl_check_launch("conv2d");
+}
+
+int conv2d_common(const char* what, int mode, const void* src, const void* wp, const float* bias, void* out, float* stats, int N, int Hs, int Ws,
+                  int Cs, int Ho, int Wo, int Nc, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, hipStream_t stream) {
+  PCRL_REQUIRE(src && wp && out, "%s: null pointer", what);
+  PCRL_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0 && Nc > 0, "%s: bad dims", what);
+  PCRL_REQUIRE(dtype == PCRL_F32 || dtype == PCRL_BF16, "%s: bad dtype %d", what, dtype);
+  const int sh = ilog2_exact(Cs);
+  PCRL_REQUIRE(sh >= 3, "%s: source channels must be a power of two >= 8 (got %d; zero-pad on the host)", what, Cs);
+  PCRL_REQUIRE(KH >= 1 && KW >= 1 && KH * KW <= 49 && stride >= 1 && stride <= 2 && pad >= 0 && pad < KH, "%s: bad kernel geometry", what);
+  PCRL_REQUIRE(!(up && (mode == C2_DGRAD || stride != 1)), "%s: the fused nearest upsample needs a stride-1 forward", what);
+  C2Params p;
+  p.x = src; p.w = wp; p.bias = bias; p.y = out; p.stats = stats;
+  p.N = N; p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo;
+  p.Cs = Cs; p.cs_shift = sh; p.Nc = Nc;
+  p.KH = KH; p.KW = KW; p.kw_mul = (65536 + KW - 1) / KW;
+  p.stride = stride; p.pad = pad; p.up = up;
+  p.Ktot = KH * KW * Cs;
+  p.Kpad = (p.Ktot + 31) / 32 * 32;
+  p.out_f32 = out_f32;
+  p.M = (int64_t)N * Ho * Wo;
+  const int NcP = (Nc + 31) / 32 * 32;
+  if (dtype == PCRL_BF16) return mode == C2_FWD ? launch_bn<bf16, C2_FWD>(p, NcP, stream) : launch_bn<bf16, C2_DGRAD>(p, NcP, stream);
+  return mode == C2_FWD ? launch_bn<float, C2_FWD>(p, NcP, stream) : launch_bn<float, C2_DGRAD>(p, NcP, stream);
+}
+
+}  // namespace
+
+extern "C" int64_t pcrl_conv2d_packed_elems(int rows, int taps, int Cs) {
+  return (int64_t)((rows + 31) / 32 * 32) * ((taps * Cs + 31) / 32 * 32);
+}
+
+extern "C" int pcrl_conv2d_pack(const float* w_ref, void* out, int Co, int Ci, int KH, int KW, int CsP, int mode, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(w_ref && out && Co > 0 && Ci > 0 && KH > 0 && KW > 0, "conv2d_pack: bad arguments");
+  PCRL_REQUIRE(mode == 0 || mode == 1, "conv2d_pack: mode must be 0 (forward) or 1 (data gradient)");
+  PCRL_REQUIRE(CsP >= (mode ? Co : Ci), "conv2d_pack: padded channel count %d too small", CsP);
+  const int taps = KH * KW, rows = mode ? Ci : Co, rowsP = (rows + 31) / 32 * 32, Kpad = (taps * CsP + 31) / 32 * 32;
+  const int64_t total = (int64_t)rowsP * Kpad;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == PCRL_BF16)
+    hipLaunchKernelGGL(pack_conv2d_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), w_ref, (bf16*)out, Co, Ci, taps, CsP, rowsP, Kpad, mode);
+  else if (dtype == PCRL_F32)
+    hipLaunchKernelGGL(pack_conv2d_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), w_ref, (float*)out, Co, Ci, taps, CsP, rowsP, Kpad, mode);
+  else
+    return pcrl_fail(PCRL_EINVAL, "conv2d_pack: bad dtype %d", dtype);
+  return pcrl_check_launch("conv2d_pack");
+}
+
+extern "C" int64_t pcrl_conv2d_stats_rows(int N, int Ho, int Wo) { return ((int64_t)N * Ho * Wo + PCRL_CONV_BM - 1) / PCRL_CONV_BM; }
+
+extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, int N, int Hi, int Wi, int CiP,
+                               int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream) {
+  const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
+  const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
+  return conv2d_common("conv2d_fwd", C2_FWD, x, wp, bias, y, stats_partial, N, Hi, Wi, CiP, Ho, Wo, Co, KH, KW, stride, pad, up, out_f32, dtype,
+                       as_stream(stream));
+}
+
+// dx[N][Hi][Wi][Ci] from dy[N][Ho][Wo][CoP]; (Ho, Wo) are the forward output dims of the (Hi, Wi) input.
+extern "C" int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH,
+                                 int KW, int stride, int pad, int dtype, pcrl_stream_t stream) {
+  return conv2d_common("conv2d_dgrad", C2_DGRAD, dy, wp_dgrad, nullptr, dx, nullptr, N, Ho, Wo, CoP, Hi, Wi, Ci, KH, KW, stride, pad, 0, 0, dtype,
+                       as_stream(stream));
+}

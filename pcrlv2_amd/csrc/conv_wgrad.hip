@@ -19,7 +19,13 @@
 
 namespace {
 
-enum { WG_CONV3 = 0, WG_UP2 = 1, WG_PLAIN = 2 };  // PLAIN: V is indexed by m directly (taps == 1)
+enum { WG_CONV3 = 0, WG_UP2 = 1, WG_PLAIN = 2, WG_CONV2D = 3 };  // PLAIN: V is indexed by m directly (taps == 1)
+
+// WG_CONV2D (2D path, conv2d.hip): m = output pixel (n, oh, ow) in g = {N, 1, Ho, Wo}; V row = source pixel
+// (oh*stride - pad + kh, ow*stride - pad + kw) of [N][Hs][Ws], read through a nearest x2 upsample when `up`.
+struct Wg2d {
+  int Hs, Ws, KW, stride, pad, up;
+};
 
 struct WgradParams {
   const void* u;  // [M][Cu]
@@ -29,6 +35,7 @@ struct WgradParams {
   int64_t M;
   int Cu, Cv, taps;
   int64_t chunk;  // voxels per split, multiple of 32
+  Wg2d q;         // WG_CONV2D only
 };
 
 // 32-byte quad swizzle of a 64-channel bf16 row (4 quads of 16 channels): spreads the 8 rows a
@@ -131,6 +138,8 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   const bool v_ok = (j0 + ucol) < p.Cv;
   const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
   const int64_t delta = (GEOM == WG_CONV3) ? tap_delta27(t, g) : 0;
+  const int kh2 = (GEOM == WG_CONV2D) ? t / p.q.KW : 0, kw2 = (GEOM == WG_CONV2D) ? t % p.q.KW : 0;
+  const int Hl2 = p.q.up ? 2 * p.q.Hs : p.q.Hs, Wl2 = p.q.up ? 2 * p.q.Ws : p.q.Ws;
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -164,6 +173,15 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
         vrow = in ? m + delta : m;                                                              \
       } else if (GEOM == WG_UP2) {                                                              \
         vrow = up2_row(n, d, h, w, t, g);                                                       \
+      } else if (GEOM == WG_CONV2D) {                                                           \
+        int ih = h * p.q.stride - p.q.pad + kh2, iw = w * p.q.stride - p.q.pad + kw2;           \
+        const bool in = (unsigned)ih < (unsigned)Hl2 && (unsigned)iw < (unsigned)Wl2;           \
+        if (p.q.up) {                                                                           \
+          ih >>= 1;                                                                             \
+          iw >>= 1;                                                                             \
+        }                                                                                       \
+        ok = ok && in;                                                                          \
+        vrow = in ? ((int64_t)n * p.q.Hs + ih) * p.q.Ws + iw : (int64_t)0;                      \
       } else {                                                                                  \
         vrow = m;                                                                               \
       }                                                                                         \
@@ -230,11 +248,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // Second pass: out_ref[i][j][t] = sum_z ws[z][t][i][j] for j < Cv_out (padding columns dropped), fixed order over z.
 // Block = 32 consecutive (i,j) x all taps: a thread sums a few (t, ij) pairs over z with 128-byte coalesced reads, the
 // [t][ij] -> [ij][t] transposition goes through LDS, the stores are one contiguous run.  Requires Cv_out % 32 == 0 or
-// a tail guard (handled); taps <= 27.
+// a tail guard (handled); taps <= 49.
 constexpr int RED_IJ = 16;
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                            int splits, int taps, int Cu, int Cv, int Cv_out) {
-  __shared__ float tile[RED_IJ * 27];
+  __shared__ float tile[RED_IJ * 49];
   const int64_t per = (int64_t)Cu * Cv;
   const int64_t n_out = (int64_t)Cu * Cv_out;
   const int64_t ij0 = (int64_t)blockIdx.x * RED_IJ;
@@ -592,13 +610,13 @@ int g_wgrad_tr = 1;  // bf16 fragment fetch: 1 = ds_read_b64_tr_b16, 0 = scalar 
 
 template <int GEOM>
 int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_bytes, Dims g, int Cu, int Cv, int taps,
-              int dtype, hipStream_t stream, int Cv_out = -1) {
+              int dtype, hipStream_t stream, int Cv_out = -1, Wg2d q = Wg2d{0, 0, 1, 1, 0, 0}) {
   if (Cv_out < 0) Cv_out = Cv;
   const int64_t M = (int64_t)g.N * g.D * g.H * g.W;
   const SplitPlan sp = plan_splits(M, Cu, Cv, taps);
   const size_t need = (size_t)sp.splits * taps * Cu * Cv * sizeof(float);
   if (ws_bytes < need || !ws) return pcrl_fail(PCRL_EWORKSPACE, "wgrad: workspace %zu < %zu", ws_bytes, need);
-  WgradParams p{u, v, (float*)ws, g, M, Cu, Cv, taps, sp.chunk};
+  WgradParams p{u, v, (float*)ws, g, M, Cu, Cv, taps, sp.chunk, q};
   dim3 grid((unsigned)(((Cu + 63) / 64) * ((Cv + 63) / 64)), (unsigned)taps, (unsigned)sp.splits);
   if (dtype == PCRL_BF16) {
     if (g_wgrad_tr) hipLaunchKernelGGL((wgrad_kernel<bf16, GEOM, true>), grid, dim3(256), 0, stream, p);
@@ -801,4 +819,23 @@ extern "C" int pcrl_conv3d_to1_wgrad(const void* x, const float* dy, float* dw_r
   if (int e = pcrl_check_launch("vecsum_partial")) return e;
   hipLaunchKernelGGL(vecsum_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), (const double*)red, db, blocks);
   return pcrl_check_launch("vecsum_finish");
+}
+
+// ---- 2D path: weight gradient of a KHxKW / stride / pad convolution, optionally behind a fused nearest x2 upsample ----
+// x: [N][Hi][Wi][CiP], dy: [N][Ho][Wo][CoP] (channel counts multiples of 8 (bf16) / 4 (fp32); zero padded by the caller),
+// dw: float32 [CoP][Ci_out][KH][KW] (reference layout; padded source channels >= Ci_out dropped).
+extern "C" size_t pcrl_conv2d_wgrad_ws_bytes(int N, int Ho, int Wo, int CiP, int CoP, int KH, int KW) {
+  const SplitPlan sp = plan_splits((int64_t)N * Ho * Wo, CoP, CiP, KH * KW);
+  return (size_t)sp.splits * KH * KW * CoP * CiP * sizeof(float);
+}
+
+extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int CiP, int Ci_out,
+                                 int Ho, int Wo, int CoP, int KH, int KW, int stride, int pad, int up, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(x && dy && dw_ref, "conv2d_wgrad: null pointer");
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  PCRL_REQUIRE(CiP > 0 && CoP > 0 && CiP % vec == 0 && CoP % vec == 0 && Ci_out > 0 && Ci_out <= CiP,
+               "conv2d_wgrad: channel counts must be multiples of %d (CiP=%d CoP=%d)", vec, CiP, CoP);
+  PCRL_REQUIRE(KH >= 1 && KW >= 1 && KH * KW <= 49 && stride >= 1 && pad >= 0, "conv2d_wgrad: bad kernel geometry");
+  return run_wgrad<WG_CONV2D>(dy, x, dw_ref, ws, ws_bytes, Dims{N, 1, Ho, Wo}, CoP, CiP, KH * KW, dtype, as_stream(stream), Ci_out,
+                              Wg2d{Hi, Wi, KW, stride, pad, up});
 }

@@ -1,0 +1,185 @@
+"""Host-side wrappers of the 2D (PCRLv2 ResNet-18 U-Net) entry points of libpcrl_hip.so  --  SURVEY 8f N1.
+
+Activations are logical [N, C, H, W] tensors in NHWC memory (torch.channels_last), float32 or bfloat16.  Everything here
+launches kernels of the C ABI (include/pcrl_hip.h, "2D path"); there is no eager / CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import PcrlError, dtype_code, lib, stream_handle
+
+
+def new_act2(N, H, W, C, dtype, device) -> torch.Tensor:
+    return torch.empty((N, H, W, C), dtype=dtype, device=device).permute(0, 3, 1, 2)
+
+
+def dims2(t: torch.Tensor):
+    """(N, H, W, C) of an NHWC-memory activation."""
+    if t.dim() != 4:
+        raise PcrlError(f"expected a 4-D activation, got shape {tuple(t.shape)}")
+    N, C, H, W = t.shape
+    if not t.permute(0, 2, 3, 1).is_contiguous():
+        raise PcrlError("activation is not NHWC (channels_last) contiguous")
+    return N, H, W, C
+
+
+def to_act2(x: torch.Tensor, dtype, pad_to: int = 0) -> torch.Tensor:
+    """API-boundary glue: any [N,C,H,W] tensor -> NHWC memory in `dtype`, channels zero-padded to `pad_to` (3-channel images and
+    3-channel gradients feed kernels that want a power-of-two channel count >= 8)."""
+    N, C, H, W = x.shape
+    if pad_to and C < pad_to:
+        out = torch.zeros((N, H, W, pad_to), dtype=dtype, device=x.device)
+        out[..., :C] = x.permute(0, 2, 3, 1)
+        return out.permute(0, 3, 1, 2)
+    if x.dtype != dtype:
+        x = x.to(dtype)
+    if not x.permute(0, 2, 3, 1).is_contiguous():
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return x
+
+
+def _pow2_at_least_8(c: int) -> int:
+    p = 8
+    while p < c:
+        p *= 2
+    return p
+
+
+class PackedConv2d:
+    """K-contiguous copies (forward and data-gradient orientation) of one nn.Conv2d weight in the activation dtype."""
+
+    def __init__(self):
+        self.key = None
+        self.fwd = None
+        self.dgrad = None
+
+    def get(self, w: torch.Tensor, dtype, CiP: int):
+        key = (ops._weights_epoch, w._version, w.data_ptr(), dtype, CiP)
+        if key != self.key:
+            L, s = lib(), stream_handle()
+            Co, Ci, KH, KW = w.shape
+            CoP = _pow2_at_least_8(Co)
+            self.fwd = torch.empty(L.call("pcrl_conv2d_packed_elems", Co, KH * KW, CiP), dtype=dtype, device=w.device)
+            self.dgrad = torch.empty(L.call("pcrl_conv2d_packed_elems", Ci, KH * KW, CoP), dtype=dtype, device=w.device)
+            L.call("pcrl_conv2d_pack", w.detach(), self.fwd, Co, Ci, KH, KW, CiP, 0, dtype_code(dtype), s)
+            L.call("pcrl_conv2d_pack", w.detach(), self.dgrad, Co, Ci, KH, KW, CoP, 1, dtype_code(dtype), s)
+            self.key = key
+        return self.fwd, self.dgrad
+
+
+def out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def conv2d_forward(x, w, bias, packed: PackedConv2d, stride, pad, up, dtype, want_stats=True, out_f32=False):
+    """x: NHWC activation with CiP >= w.shape[1] channels.  -> (y, stats_partial | None, rows)"""
+    L, s = lib(), stream_handle()
+    N, Hi, Wi, CiP = dims2(x)
+    Co, Ci, KH, KW = w.shape
+    if CiP < Ci or x.dtype != dtype:
+        raise PcrlError(f"conv2d_forward: input has {CiP} channels in {x.dtype}, weight wants {Ci} in {dtype}")
+    wf, _ = packed.get(w, dtype, CiP)
+    Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
+    Ho, Wo = out_size(Hl, KH, stride, pad), out_size(Wl, KW, stride, pad)
+    y = new_act2(N, Ho, Wo, Co, torch.float32 if out_f32 else dtype, x.device)
+    rows = L.call("pcrl_conv2d_stats_rows", N, Ho, Wo)
+    partial = ops._f32(rows * Co * 2, x.device) if want_stats else None
+    L.call("pcrl_conv2d_fwd", x, wf, None if bias is None else bias.detach(), y, partial, N, Hi, Wi, CiP, Co, KH, KW, stride, pad,
+           int(up), int(out_f32), dtype_code(dtype), s)
+    return y, partial, rows
+
+
+def conv2d_backward(x, dy, w, packed: PackedConv2d, stride, pad, up, dtype, need_dx=True):
+    """x: the forward input (NHWC, CiP channels); dy: NHWC gradient of the forward output in `dtype` with CoP = pow2 >= 8 channels
+    (zero-padded by the caller when Co = 3).  -> (dx | None, dw float32 [Co][Ci][KH][KW])"""
+    L, s = lib(), stream_handle()
+    N, Hi, Wi, CiP = dims2(x)
+    _, Ho, Wo, CoP = dims2(dy)
+    Co, Ci, KH, KW = w.shape
+    nb = L.call("pcrl_conv2d_wgrad_ws_bytes", N, Ho, Wo, CiP, CoP, KH, KW)
+    dw_full = torch.empty((CoP, Ci, KH, KW), dtype=torch.float32, device=x.device)
+    L.call("pcrl_conv2d_wgrad", x, dy, dw_full, ops.workspace(nb, x.device), nb, N, Hi, Wi, CiP, Ci, Ho, Wo, CoP, KH, KW, stride, pad,
+           int(up), dtype_code(dtype), s)
+    dw = dw_full if CoP == Co else dw_full[:Co]
+    dx = None
+    if need_dx:
+        _, wd = packed.get(w, dtype, CiP)
+        Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
+        dxl = new_act2(N, Hl, Wl, Ci, dtype, x.device)
+        L.call("pcrl_conv2d_dgrad", dy, wd, dxl, N, Hl, Wl, Ci, Ho, Wo, CoP, KH, KW, stride, pad, dtype_code(dtype), s)
+        if up:
+            dx = new_act2(N, Hi, Wi, Ci, dtype, x.device)
+            L.call("pcrl_upsample2d_nearest2_bwd", dxl, dx, N, Hi, Wi, Ci, dtype_code(dtype), s)
+        else:
+            dx = dxl
+    return dx, dw
+
+
+def colsum(v, M, C, dtype):
+    """float32 [C] column sums of an [M][C] tensor (bias gradients)."""
+    L = lib()
+    out = ops._f32(C, v.device)
+    nb = L.call("pcrl_colsum_ws_bytes", M, C)
+    L.call("pcrl_colsum", v, out, ops.workspace(nb, v.device), nb, M, C, dtype_code(dtype), stream_handle())
+    return out
+
+
+def maxpool_forward(x, dtype):
+    N, H, W, C = dims2(x)
+    Ho, Wo = out_size(H, 3, 2, 1), out_size(W, 3, 2, 1)
+    y = new_act2(N, Ho, Wo, C, dtype, x.device)
+    idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=x.device)
+    lib().call("pcrl_maxpool2d_3s2_fwd", x, y, idx, N, H, W, C, dtype_code(dtype), stream_handle())
+    return y, idx
+
+
+def maxpool_backward(dy, idx, in_dims, dtype):
+    N, H, W, C = in_dims
+    dx = new_act2(N, H, W, C, dtype, dy.device)
+    lib().call("pcrl_maxpool2d_3s2_bwd", dy, idx, dx, N, H, W, C, dtype_code(dtype), stream_handle())
+    return dx
+
+
+def bilinear_forward(x, scale: int):
+    """x: float32 NHWC-memory [N,C,H,W] map."""
+    N, H, W, C = dims2(x)
+    y = new_act2(N, H * scale, W * scale, C, torch.float32, x.device)
+    lib().call("pcrl_upsample2d_bilinear_fwd", x, y, N, H, W, C, scale, stream_handle())
+    return y
+
+
+def bilinear_backward(dy, in_dims, scale: int):
+    N, H, W, C = in_dims
+    dx = new_act2(N, H, W, C, torch.float32, dy.device)
+    lib().call("pcrl_upsample2d_bilinear_bwd", dy, dx, N, H, W, C, scale, stream_handle())
+    return dx
+
+
+def add_relu_forward(t, r, dtype):
+    a = torch.empty_like(t)
+    lib().call("pcrl_add_relu_fwd", t, r, a, t.numel(), dtype_code(dtype), stream_handle())
+    return a
+
+
+def relu_mask_backward(da, a, dtype):
+    g = torch.empty_like(a)
+    lib().call("pcrl_relu_mask_bwd", da, a, g, a.numel(), dtype_code(dtype), stream_handle())
+    return g
+
+
+def gap_forward(a, dtype):
+    N, H, W, C = dims2(a)
+    g = ops._f32(N * C, a.device).view(N, C)
+    L = lib()
+    nb = L.call("pcrl_gap_ws_bytes", N, H * W, C)
+    L.call("pcrl_gap_fwd", a, g, ops.workspace(nb, a.device), nb, N, H * W, C, dtype_code(dtype), stream_handle())
+    return g
+
+
+def gap_backward(dg, like, dtype):
+    N, H, W, C = dims2(like)
+    da = torch.empty_like(like)
+    lib().call("pcrl_gap_bwd", dg.contiguous(), None, da, N, H * W, C, dtype_code(dtype), stream_handle())
+    return da

@@ -1,0 +1,126 @@
+"""2D pre-training loop on the MI355X engine -- drop-in for the reference's train_2d.py  (SURVEY 8f N1).
+
+Same entry point `train_pcrlv2(args, data_loader, out_channel=3)`, `cos_loss`, loss assembly (five scales, no divergence guard,
+train_2d.py:139-171), LR schedule, log line and checkpoint (the ENCODER's state_dict only, train_2d.py:99).  The deliberate
+differences are those listed in pcrlv2_amd/train_3d.py (bf16 for --amp, one process per GPU instead of nn.DataParallel, lazy
+meters, --seed honoured, --resume for the encoder weights).
+"""
+from __future__ import print_function
+
+import math
+import os
+import sys
+import time
+
+import torch
+
+from . import ddp as _ddp
+from .functions2d import mse_loss2d
+from .models.pcrlv2_model import PCRLv2
+from .optim import FusedSGD
+from .train_3d import BETA_PERIOD, CosineSimilarityMean, _to_gpu, cos_loss, seed_everything  # noqa: F401  (cos_loss: train_2d.py:111-117)
+from .utils import AverageMeter, adjust_learning_rate
+
+
+class MSELoss2d:
+    """`criterion` of train_2d.py:78 on NHWC-memory predictions."""
+
+    def cuda(self):
+        return self
+
+    def __call__(self, pred, target):
+        return mse_loss2d(pred, target)
+
+
+def step_losses(model, batch, epoch, criterion, cosine):
+    """Forward half of one iteration (train_2d.py:139-168).  -> (total, restoration, global-cosine, deep-supervision, local-cosine)"""
+    view1, view2, target, _unused_gt2, local_views = batch
+    n = view1.size(0)
+    target = _to_gpu(target)
+    feats1, mask1, masks1 = model(_to_gpu(view1))
+    feats2, _mask2, _ = model(_to_gpu(view2))
+    l_global, scale = cos_loss(cosine, feats1, feats2)
+    feats_loc, _, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
+    stacked = [torch.stack(pair) for pair in feats_loc]                 # [2, 6n, C] per scale
+    l_local = 0.0
+    for i in range(len(local_views)):
+        crop_i = [s[:, n * i: n * (i + 1)] for s in stacked]
+        l_local = l_local + cos_loss(cosine, feats1, crop_i)[0]
+        l_local = l_local + cos_loss(cosine, feats2, crop_i)[0]
+    l_local = l_local / (2 * len(local_views))
+    l_restore = criterion(mask1, target)
+    beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
+    l_deep = beta * criterion(masks1[scale], target)
+    return l_restore + l_global + l_local + l_deep, l_restore, l_global, l_deep, l_local
+
+
+def train_step(model, optimizer, batch, epoch, criterion, cosine):
+    losses = step_losses(model, batch, epoch, criterion, cosine)
+    optimizer.zero_grad()
+    losses[0].backward()
+    optimizer.step()
+    return tuple(l.detach() for l in losses)
+
+
+def train_pcrlv2(args, data_loader, out_channel=3):
+    distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    rank = 0
+    if distributed:
+        rank, _, local_rank = _ddp.init_process_group_from_env()
+        torch.cuda.set_device(local_rank)
+    seed_everything(getattr(args, "seed", 42))
+    model = PCRLv2(encoder_weights=getattr(args, "encoder_weights", None)).cuda()
+    if getattr(args, "amp", False):
+        model.set_compute_dtype(torch.bfloat16)
+    optimizer = FusedSGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
+    if distributed:
+        _ddp.DataParallel(model, optimizer)
+    criterion, cosine = MSELoss2d().cuda(), CosineSimilarityMean().cuda()
+    chatty = rank == 0
+    for epoch in range(0, args.epochs + 1):
+        adjust_learning_rate(epoch, args, optimizer)
+        if chatty:
+            print("==> training...")
+        t_start = time.time()
+        train_pcrlv2_inner(args, epoch, data_loader['train'], model, optimizer, criterion, cosine, verbose=chatty)
+        if chatty:
+            print('epoch {}, total time {:.2f}'.format(epoch, time.time() - t_start))
+            if epoch % 100 == 0 or epoch == 240:     # train_2d.py:96-107: the ENCODER's weights only
+                print('==> Saving...')
+                model.flush_counters()
+                state = {'opt': args, 'state_dict': model.model.encoder.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch}
+                torch.save(state, os.path.join(args.output, "{}_{}_{}_{}_{}.pt".format(args.model, args.n, args.phase, args.ratio, epoch)))
+        torch.cuda.empty_cache()
+    return model
+
+
+def train_pcrlv2_inner(args, epoch, train_loader, model, optimizer, criterion, cosine, verbose=True):
+    """One epoch (train_2d.py:120-195).  Returns (mean cosine loss, mean restoration loss, mean local loss)."""
+    model.train()
+    meters = {k: AverageMeter() for k in ("bt", "dt", "cos", "mg", "local")}
+    tick = time.time()
+    for it, batch in enumerate(train_loader, start=1):
+        meters["dt"].update(time.time() - tick)
+        out = train_step(model, optimizer, batch, epoch, criterion, cosine)
+        n = batch[0].size(0)
+        meters["mg"].update(out[1], n)
+        meters["cos"].update(out[2], n)
+        meters["local"].update(out[4], n)
+        log_now = it % 10 == 0
+        if log_now:
+            torch.cuda.synchronize()
+        meters["bt"].update(time.time() - tick)
+        tick = time.time()
+        if log_now and verbose:
+            m = meters
+            print('Train: [{0}][{1}/{2}]\t'
+                  'BT {3:.3f} ({4:.3f})\t'
+                  'DT {5:.3f} ({6:.3f})\t'
+                  'cos_loss {7:.3f} ({8:.3f})\t'
+                  'mg loss {9:.3f} ({10:.3f})\t'
+                  'local loss {11:.3f} ({12:.3f})'.format(
+                      epoch, it, len(train_loader), m["bt"].val, m["bt"].avg, m["dt"].val, m["dt"].avg,
+                      float(m["cos"].val), float(m["cos"].avg), float(m["mg"].val), float(m["mg"].avg),
+                      float(m["local"].val), float(m["local"].avg)))
+            sys.stdout.flush()
+    return float(meters["cos"].avg), float(meters["mg"].avg), float(meters["local"].avg)

@@ -1,0 +1,147 @@
+"""2D path: PCRLv2 (ResNet-18 U-Net) forward / losses / gradients / SGD on the HIP engine against the CPU oracle
+(oracle/pcrlv2_2d_oracle.py, PARITY UNPINNED: a restatement, the reference's 2D model cannot be imported in this image)."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+
+
+def _build(seed=3, dtype=torch.float32):
+    from pcrlv2_amd.models import PCRLv2
+    torch.manual_seed(seed)
+    model = PCRLv2().cuda().set_compute_dtype(dtype)
+    # non-trivial affine parameters / biases so that every gradient path is exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if p.dim() == 1:
+                p.copy_((torch.rand(p.shape, generator=g) * 0.5 + (0.75 if n.endswith("weight") else -0.25)).to(p.device))
+    return model
+
+
+def _oracle_state(model):
+    pn = set(n for n, _ in model.named_parameters())
+    sd = {}
+    for k, v in model.state_dict().items():
+        if v.is_floating_point():
+            t = v.detach().cpu().double()
+            if k in pn:
+                t.requires_grad_(True)
+            sd[k] = t
+        else:
+            sd[k] = v.cpu()
+    return sd
+
+
+def test_step_matches_oracle_fp32():
+    import pcrlv2_2d_oracle as O
+    from pcrlv2_amd import train_2d
+    from pcrlv2_amd.train_3d import CosineSimilarityMean
+    model = _build()
+    sd = _oracle_state(model)
+    batch = O.synthetic_batch(4, 64, 32, seed=11)
+    random.seed(5)
+    so = {}
+    ref = O.step_losses(sd, tuple(t.double() if torch.is_tensor(t) else [u.double() for u in t] for t in batch), epoch=3, so=so)
+    ref["loss"].backward()
+    random.seed(5)
+    model.train()
+    model.zero_grad(set_to_none=True)
+    got = train_2d.step_losses(model, batch, 3, train_2d.MSELoss2d(), CosineSimilarityMean())
+    got[0].backward()
+    for name, g_, r_ in (("loss", got[0], ref["loss"]), ("loss1", got[1], ref["loss1"]), ("loss2", got[2], ref["loss2"]),
+                         ("loss4", got[3], ref["loss4"]), ("local", got[4], ref["local_loss"])):
+        assert abs(float(g_) - float(r_)) < 2e-4 * max(1.0, abs(float(r_))), (name, float(g_), float(r_))
+    worst = []
+    for name, p in model.named_parameters():
+        r = sd[name].grad
+        if r is None:
+            assert p.grad is None, f"{name}: the oracle has no gradient, the HIP path produced one"
+            continue
+        assert p.grad is not None, f"{name}: missing gradient"
+        rn = float(r.norm())
+        if rn < 1e-9:      # conv biases in front of BatchNorm: identically zero
+            assert float(p.grad.abs().max()) < 1e-6, name
+            continue
+        worst.append((float((p.grad.double().cpu() - r).norm()) / rn, name))
+    worst.sort(reverse=True)
+    # Tolerance: float32 round-off is amplified by the cancellation inside every BatchNorm backward on the way down (the heads and the
+    # last decoder block agree to 1e-5..1e-4, the error grows layer by layer).  The same step in plain PyTorch-CPU float32 against its
+    # own float64 run shows median 5.4e-3 / max 7.4e-3 at b=8 (tests/probe2d_conditioning.py prints ours: 2.8e-3 / 4.9e-3).
+    assert worst[0][0] < 3e-2, worst[:5]
+    assert sorted(w for w, _ in worst)[len(worst) // 2] < 1e-2, worst[:5]
+    heads = [w for w, n in worst if "predictor_head" in n or "segmentation_head" in n or n.endswith(".bn.weight")]
+    assert max(heads) < 5e-4, sorted(heads)[-3:]
+    # running statistics of every BatchNorm after the three forwards of the step are chained updates; check the last written ones
+    model.flush_counters()
+    msd = model.state_dict()
+    assert int(msd["model.encoder.bn1.num_batches_tracked"]) == 3
+
+
+def test_forward_shapes_and_outputs_fp32():
+    import pcrlv2_2d_oracle as O
+    model = _build(seed=9)
+    sd = _oracle_state(model)
+    x = O.synthetic_batch(3, 96, 32, seed=2)[0]
+    model.train()
+    outs, masks, mids = model(x.cuda())
+    so = {}
+    r_outs, r_masks, r_mids = O.model_forward(x.double(), sd, so=so)
+    assert masks.shape == (3, 3, 96, 96) and len(mids) == 5 and all(m.shape == (3, 3, 96, 96) for m in mids)
+    assert [tuple(p.shape) for p, _ in outs] == [(3, c) for c in (256, 128, 64, 32, 16)]
+
+    def rel(a, b):
+        return float((a.detach().double().cpu() - b.detach()).norm() / b.detach().norm())
+    assert rel(masks, r_masks) < 1e-4
+    for a, b in zip(mids, r_mids):
+        assert rel(a, b) < 1e-4
+    for (p, q), (rp, rq) in zip(outs, r_outs):
+        assert rel(p, rp) < 1e-4 and rel(q, rq) < 1e-4
+    # running statistics
+    model.flush_counters()
+    msd = model.state_dict()
+    for k, v in so.items():
+        assert rel(msd[k], v) < 1e-4, k
+    # local=True: no segmentation map (pcrlv2_model.py:206-208)
+    outs_l, masks_l, mids_l = model(x.cuda(), local=True)
+    assert masks_l is None and len(mids_l) == 5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_steps_reduce_loss(dtype):
+    import pcrlv2_2d_oracle as O
+    from pcrlv2_amd import train_2d
+    from pcrlv2_amd.optim import FusedSGD
+    from pcrlv2_amd.train_3d import CosineSimilarityMean
+    model = _build(seed=1, dtype=dtype)
+    opt = FusedSGD(model.parameters(), lr=0.05, momentum=0.9, weight_decay=1e-4)
+    batch = O.synthetic_batch(4, 64, 32, seed=4)
+    random.seed(0)
+    crit, cos = train_2d.MSELoss2d(), CosineSimilarityMean()
+    losses = []
+    for _ in range(8):
+        out = train_2d.train_step(model, opt, batch, 0, crit, cos)
+        losses.append(float(out[1]))           # restoration term: deterministic target, must go down on a repeated batch
+    assert all(l == l for l in losses), losses
+    assert losses[-1] < losses[0], losses
+    n_none = sum(p.grad is None for p in model.parameters())
+    assert n_none >= 1    # view-2 / unselected deep-supervision heads get no gradient in a step (autograd semantics of the reference)
+
+
+def test_bf16_step_close_to_fp32():
+    import pcrlv2_2d_oracle as O
+    from pcrlv2_amd import train_2d
+    from pcrlv2_amd.train_3d import CosineSimilarityMean
+    batch = O.synthetic_batch(4, 64, 32, seed=7)
+    vals = {}
+    for dt in (torch.float32, torch.bfloat16):
+        model = _build(seed=2, dtype=dt)
+        random.seed(1)
+        vals[dt] = [float(v) for v in train_2d.step_losses(model, batch, 0, train_2d.MSELoss2d(), CosineSimilarityMean())]
+    for a, b in zip(vals[torch.float32], vals[torch.bfloat16]):
+        assert abs(a - b) < 3e-2 * max(1.0, abs(a)), vals

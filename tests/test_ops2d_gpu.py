@@ -1,0 +1,148 @@
+"""2D path: every HIP operator against a plain-PyTorch float64 CPU reference of the same op, through the C ABI."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _close(got, ref, dt, what, f32_tol=2e-5, bf_tol=2e-2):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    denom = float(ref.norm()) + 1e-30
+    err = float((got - ref).norm()) / denom
+    tol = f32_tol if dt == torch.float32 else bf_tol
+    assert err < tol, f"{what}: rel-L2 {err:.3e} > {tol}"
+
+
+def _q(t, dt):
+    """the values the kernel actually sees (bf16 rounding of the operands), as float64"""
+    return t.to(dt).double()
+
+
+GEOMS = [  # Ci, Co, K, stride, pad, up, H, W, bias
+    (3, 64, 7, 2, 3, 0, 32, 40, False),      # ResNet stem (3 channels zero-padded to 8)
+    (64, 64, 3, 1, 1, 0, 12, 20, False),     # BasicBlock conv
+    (64, 128, 3, 2, 1, 0, 16, 24, False),    # stride-2 BasicBlock conv
+    (64, 128, 1, 2, 0, 0, 16, 24, False),    # downsample
+    (32, 16, 3, 1, 1, 1, 8, 12, False),      # decoder conv1 behind the fused nearest x2 upsample
+    (16, 16, 3, 1, 1, 0, 16, 16, True),      # deep-supervision conv (bias)
+    (512, 256, 3, 1, 1, 1, 2, 2, False),     # first decoder block at the bottleneck
+]
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", GEOMS)
+def test_conv2d_fwd_dgrad_wgrad(geom, dt):
+    from pcrlv2_amd import ops2d
+    Ci, Co, K, stride, pad, up, H, W, has_bias = geom
+    N = 3
+    g = torch.Generator().manual_seed(Ci * 1000 + Co + K)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
+    b = torch.randn(Co, generator=g) if has_bias else None
+    xa = ops2d.to_act2(x.to(_dev()), dt, pad_to=8 if Ci < 8 else 0)
+    wd = w.to(_dev())
+    packed = ops2d.PackedConv2d()
+    y, partial, rows = ops2d.conv2d_forward(xa, wd, None if b is None else b.to(_dev()), packed, stride, pad, up, dt)
+    # reference on the rounded operands
+    xr = _q(x, dt).requires_grad_(True)
+    wr = _q(w, dt).requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+    yr = F.conv2d(xin, wr, None if b is None else b.double(), stride, pad)
+    _close(y, yr, dt, "conv2d fwd", bf_tol=6e-3)
+    # statistics rows: sum and sum of squares per channel from the float accumulators
+    st = partial.view(rows, Co, 2).double().sum(0).cpu()
+    _close(st[:, 0], yr.sum((0, 2, 3)), torch.float32, "conv2d stats sum", f32_tol=2e-3 if dt == torch.bfloat16 else 1e-4)
+    _close(st[:, 1], (yr * yr).sum((0, 2, 3)), torch.float32, "conv2d stats sumsq", f32_tol=2e-3 if dt == torch.bfloat16 else 1e-4)
+    # backward
+    dy = torch.randn(yr.shape, generator=g)
+    dya = ops2d.to_act2(dy.to(_dev()), dt)
+    dx, dw = ops2d.conv2d_backward(xa, dya, wd, packed, stride, pad, up, dt, need_dx=True)
+    yr.backward(_q(dy, dt))
+    _close(dx[:, :Ci], xr.grad, dt, "conv2d dgrad", bf_tol=6e-3)
+    _close(dw, wr.grad, torch.float32, "conv2d wgrad", f32_tol=3e-5 if dt == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("K,Ci", [(1, 16), (3, 16)])
+def test_conv2d_to3_float_output(K, Ci, dt):
+    """deep_supervision_head.3 (1x1 -> 3) and the segmentation head (3x3 -> 3): float32 output, 3-channel gradient padded to 8"""
+    from pcrlv2_amd import ops2d
+    N, H, W, Co = 2, 16, 24, 3
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
+    b = torch.randn(Co, generator=g)
+    xa = ops2d.to_act2(x.to(_dev()), dt)
+    packed = ops2d.PackedConv2d()
+    y, _, _ = ops2d.conv2d_forward(xa, w.to(_dev()), b.to(_dev()), packed, 1, K // 2, 0, dt, want_stats=False, out_f32=True)
+    assert y.dtype == torch.float32
+    xr, wr = _q(x, dt).requires_grad_(True), _q(w, dt).requires_grad_(True)
+    yr = F.conv2d(xr, wr, b.double(), 1, K // 2)
+    _close(y, yr, dt, "conv -> 3 fwd", bf_tol=1e-5)      # float32 store: only the operand rounding (already in the reference) remains
+    dy = torch.randn(yr.shape, generator=g)
+    dyp = ops2d.to_act2(dy.to(_dev()), dt, pad_to=8)
+    dx, dw = ops2d.conv2d_backward(xa, dyp, w.to(_dev()), packed, 1, K // 2, 0, dt)
+    yr.backward(_q(dy, dt))
+    _close(dx, xr.grad, dt, "conv -> 3 dgrad", bf_tol=6e-3)
+    _close(dw, wr.grad, torch.float32, "conv -> 3 wgrad", f32_tol=1e-4)
+    db = ops2d.colsum(ops2d.to_act2(dy.to(_dev()), torch.float32, pad_to=8), N * H * W, 8, torch.float32)[:3]
+    _close(db, dy.double().sum((0, 2, 3)), torch.float32, "bias grad", f32_tol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("H,W", [(16, 24), (15, 9)])
+def test_maxpool2d(H, W, dt):
+    from pcrlv2_amd import ops2d
+    N, C = 2, 64
+    g = torch.Generator().manual_seed(H)
+    x = torch.randn(N, C, H, W, generator=g).to(dt)
+    x[0, :, 0:3, 0:3] = 1.5            # ties: torch gives the gradient to the first maximum in scan order
+    xa = ops2d.to_act2(x.to(_dev()), dt)
+    y, idx = ops2d.maxpool_forward(xa, dt)
+    xr = x.double().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(y.double().cpu(), yr.detach())
+    dy = torch.randn(yr.shape, generator=g).to(dt)
+    dx = ops2d.maxpool_backward(ops2d.to_act2(dy.to(_dev()), dt), idx, (N, H, W, C), dt)
+    yr.backward(dy.double())
+    _close(dx, xr.grad, dt, "maxpool2d bwd", f32_tol=1e-6, bf_tol=6e-3)
+
+
+@pytest.mark.parametrize("scale", [1, 2, 4, 16])
+def test_bilinear(scale):
+    from pcrlv2_amd import ops2d
+    N, C, H, W = 2, 3, 6, 5
+    g = torch.Generator().manual_seed(scale)
+    x = torch.randn(N, C, H, W, generator=g)
+    xa = ops2d.to_act2(x.to(_dev()), torch.float32)
+    y = ops2d.bilinear_forward(xa, scale)
+    xr = x.double().requires_grad_(True)
+    yr = F.interpolate(xr, scale_factor=scale, mode="bilinear")
+    _close(y, yr, torch.float32, "bilinear fwd", f32_tol=1e-6)
+    dy = torch.randn(yr.shape, generator=g)
+    dx = ops2d.bilinear_backward(ops2d.to_act2(dy.to(_dev()), torch.float32), (N, H, W, C), scale)
+    yr.backward(dy.double())
+    _close(dx, xr.grad, torch.float32, "bilinear bwd", f32_tol=1e-6)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_add_relu_and_mask(dt):
+    from pcrlv2_amd import ops2d
+    g = torch.Generator().manual_seed(0)
+    t, r = torch.randn(2, 16, 8, 8, generator=g).to(dt), torch.randn(2, 16, 8, 8, generator=g).to(dt)
+    ta, ra = ops2d.to_act2(t.to(_dev()), dt), ops2d.to_act2(r.to(_dev()), dt)
+    a = ops2d.add_relu_forward(ta, ra, dt)
+    ref = F.relu(t.double() + r.double()).to(dt)
+    assert torch.equal(a.cpu(), ref)
+    da = torch.randn(2, 16, 8, 8, generator=g).to(dt)
+    gk = ops2d.relu_mask_backward(ops2d.to_act2(da.to(_dev()), dt), a, dt)
+    assert torch.equal(gk.cpu(), torch.where(ref > 0, da, torch.zeros_like(da)))
