@@ -23,8 +23,12 @@ enum { WG_CONV3 = 0, WG_UP2 = 1, WG_PLAIN = 2, WG_CONV2D = 3 };  // PLAIN: V is 
 
 // WG_CONV2D (2D path, conv2d.hip): m = output pixel (n, oh, ow) in g = {N, 1, Ho, Wo}; V row = source pixel
 // (oh*stride - pad + kh, ow*stride - pad + kw) of [N][Hs][Ws], read through a nearest x2 upsample when `up`.
+// The taps are FLATTENED into the column index: j = tap * CiP + ci over Cv = ntaps * CiP columns (blockIdx.y unused, taps = 1), so
+// a 64-column tile covers 64/CiP taps when the layer is narrow -- the U operand (dy) is re-read once per 64 columns, not once per
+// tap (7x7 stem on 8 padded channels: 7 passes over dy instead of 49).  Every 16-byte chunk of a tile row lies inside one tap, so a
+// thread decodes the tap of its chunk once.
 struct Wg2d {
-  int Hs, Ws, KW, stride, pad, up;
+  int Hs, Ws, KW, stride, pad, up, CiP, ntaps;
 };
 
 struct WgradParams {
@@ -107,17 +111,19 @@ template <> struct WFrag<bf16, true> {
   }
 };
 
-template <typename T, int GEOM, bool TR>
+// KS = voxels per K-step (32, or 128 for the narrow full-resolution layers of the 2D path where the two barriers per step, not
+// the MFMAs, set the pace).
+template <typename T, int GEOM, bool TR, int KS = 32>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   using WT = WTile<T>;
   using WF = WFrag<T, TR>;
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int CPR = WT::ROWB / 16;  // 16-byte chunks per tile row: 8 / 16
   constexpr int RPP = 256 / CPR;      // rows per pass: 32 / 16
-  constexpr int NP = 32 / RPP;        // passes: 1 / 2
-  constexpr int TILE_BYTES = 32 * WT::ROWB;
+  constexpr int NP = KS / RPP;        // passes: 1 / 2 at KS = 32
+  constexpr int TILE_BYTES = KS * WT::ROWB;
 
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // U[2], V[2]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // U[2], V[2]: 4 * TILE_BYTES
   char* Us = smem;
   char* Vs = smem + 2 * TILE_BYTES;
 
@@ -138,8 +144,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   const bool v_ok = (j0 + ucol) < p.Cv;
   const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
   const int64_t delta = (GEOM == WG_CONV3) ? tap_delta27(t, g) : 0;
-  const int kh2 = (GEOM == WG_CONV2D) ? t / p.q.KW : 0, kw2 = (GEOM == WG_CONV2D) ? t % p.q.KW : 0;
+  const int tap2 = (GEOM == WG_CONV2D) ? (j0 + ucol) / p.q.CiP : 0, c2 = (GEOM == WG_CONV2D) ? (j0 + ucol) % p.q.CiP : 0;
+  const int kh2 = tap2 / p.q.KW, kw2 = tap2 % p.q.KW;
   const int Hl2 = p.q.up ? 2 * p.q.Hs : p.q.Hs, Wl2 = p.q.up ? 2 * p.q.Ws : p.q.Ws;
+  const int vpitch = (GEOM == WG_CONV2D) ? p.q.CiP : p.Cv;
+  const int vcol = (GEOM == WG_CONV2D) ? (v_ok ? c2 : 0) : j0 + (v_ok ? ucol : 0);
 
   f32x4 acc[2][2];
 #pragma unroll
@@ -151,8 +160,58 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 
   // Unconditional loads from clamped (always valid) addresses; validity is applied at the LDS store (a load under a
   // per-lane condition is wrapped by hipcc in a branch + `s_waitcnt vmcnt(0)`, serialising the K-step).
-  const int ucol_u = u_ok ? ucol : 0, ucol_v = v_ok ? ucol : 0;
+  const int ucol_u = u_ok ? ucol : 0;
   uint32_t uokb = 0, vokb = 0;
+  // WG_CONV2D: the pixel coordinates of this thread's rows are carried from K-step to K-step (a step advances every row by KS
+  // pixels = (sn2, sh2, sw2) in (image, row, column) units) instead of being decoded with three 64-bit divisions per row and step
+  // -- on the narrow full-resolution layers that index arithmetic, not the MFMAs, was the kernel's instruction stream.
+  int cn2[NP], ch2[NP], cw2[NP];
+  int64_t cm2[NP];
+  int sn2 = 0, sh2 = 0, sw2 = 0;
+  if (GEOM == WG_CONV2D) {
+    sw2 = KS % g.W;
+    sh2 = (KS / g.W) % g.H;
+    sn2 = KS / (g.W * g.H);
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      cm2[ps] = mbeg + ps * RPP + rowp;
+      const int64_t mc = cm2[ps] < p.M ? cm2[ps] : 0;
+      int dd;
+      decode_voxel(mc, g, cn2[ps], dd, ch2[ps], cw2[ps]);
+    }
+  }
+#define WG_LOAD2D()                                                                             \
+  do {                                                                                          \
+    uokb = 0;                                                                                   \
+    vokb = 0;                                                                                   \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                         \
+      const bool live = cm2[ps] < mend;                                                         \
+      const int64_t m = live ? cm2[ps] : mbeg;                                                  \
+      ru[ps] = *reinterpret_cast<const u32x4*>(U + m * p.Cu + i0 + ucol_u);                     \
+      int ih = ch2[ps] * p.q.stride - p.q.pad + kh2, iw = cw2[ps] * p.q.stride - p.q.pad + kw2; \
+      const bool in = live && (unsigned)ih < (unsigned)Hl2 && (unsigned)iw < (unsigned)Wl2;     \
+      if (p.q.up) {                                                                             \
+        ih >>= 1;                                                                               \
+        iw >>= 1;                                                                               \
+      }                                                                                         \
+      const int64_t vrow = in ? ((int64_t)cn2[ps] * p.q.Hs + ih) * p.q.Ws + iw : (int64_t)0;    \
+      rv[ps] = *reinterpret_cast<const u32x4*>(V + vrow * vpitch + vcol);                       \
+      uokb |= (uint32_t)(live && u_ok) << ps;                                                   \
+      vokb |= (uint32_t)(in && v_ok) << ps;                                                     \
+      cm2[ps] += KS;                                                                            \
+      cw2[ps] += sw2;                                                                           \
+      if (cw2[ps] >= g.W) {                                                                     \
+        cw2[ps] -= g.W;                                                                         \
+        ch2[ps] += 1;                                                                           \
+      }                                                                                         \
+      ch2[ps] += sh2;                                                                           \
+      if (ch2[ps] >= g.H) {                                                                     \
+        ch2[ps] -= g.H;                                                                         \
+        cn2[ps] += 1;                                                                           \
+      }                                                                                         \
+      cn2[ps] += sn2;                                                                           \
+    }                                                                                           \
+  } while (0)
 #define WG_LOAD(ms_)                                                                            \
   do {                                                                                          \
     uokb = 0;                                                                                   \
@@ -185,7 +244,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       } else {                                                                                  \
         vrow = m;                                                                               \
       }                                                                                         \
-      rv[ps] = *reinterpret_cast<const u32x4*>(V + vrow * p.Cv + j0 + ucol_v);                  \
+      rv[ps] = *reinterpret_cast<const u32x4*>(V + vrow * vpitch + vcol);                       \
       uokb |= (uint32_t)(live && u_ok) << ps;                                                   \
       vokb |= (uint32_t)(ok && v_ok) << ps;                                                     \
     }                                                                                           \
@@ -200,9 +259,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     }                                                                                           \
   } while (0)
 
-  const int64_t nsteps = (mend > mbeg) ? (mend - mbeg + 31) / 32 : 0;
+  const int64_t nsteps = (mend > mbeg) ? (mend - mbeg + KS - 1) / KS : 0;
   if (nsteps > 0) {
-    WG_LOAD(mbeg);
+    if (GEOM == WG_CONV2D) WG_LOAD2D();
+    else WG_LOAD(mbeg);
     WG_STORE(0);
   }
   __syncthreads();
@@ -210,11 +270,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   for (int64_t s = 0; s < nsteps; ++s) {
     const int cur = (int)(s & 1);
     const int64_t sn = (s + 1 < nsteps) ? s + 1 : s;
-    WG_LOAD(mbeg + sn * 32);
+    if (GEOM == WG_CONV2D) WG_LOAD2D();      // the last iteration stages rows past `mend`: dead, zeroed at the LDS store
+    else WG_LOAD(mbeg + sn * KS);
     __builtin_amdgcn_sched_barrier(0);
-    {
-      const char* ut = Us + cur * TILE_BYTES;
-      const char* vt = Vs + cur * TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < KS / 32; ++kk) {
+      const char* ut = Us + cur * TILE_BYTES + kk * 32 * WT::ROWB;
+      const char* vt = Vs + cur * TILE_BYTES + kk * 32 * WT::ROWB;
       typename WF::Frag fa[2], fb[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) fa[a] = WF::read(ut, wi * 32 + a * 16, lane);
@@ -230,6 +292,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     __syncthreads();
   }
 #undef WG_LOAD
+#undef WG_LOAD2D
 #undef WG_STORE
 
   float* __restrict__ out = p.ws + ((int64_t)blockIdx.z * p.taps + t) * (int64_t)p.Cu * p.Cv;
@@ -283,6 +346,27 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   const int64_t base = ij0 * taps, lim = n_out * taps;
   for (int k = threadIdx.x; k < npairs; k += 256)
     if (base + k < lim) out[base + k] = tile[k];
+}
+
+// Second pass of the 2D weight gradient: out_ref[co][ci][t] = sum_z ws[z][co][t * CiP + ci], ci < Ci_out (padding channels dropped).
+__global__ void __launch_bounds__(256) wgrad2d_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int splits, int taps, int Cu,
+                                                             int CiP, int Ci_out) {
+  const int64_t per = (int64_t)Cu * taps * CiP;
+  const int64_t total = (int64_t)Cu * taps * Ci_out;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ci = (int)(idx % Ci_out);
+    const int64_t r = idx / Ci_out;
+    const int t = (int)(r % taps), co = (int)(r / taps);
+    const float* src = ws + ((int64_t)co * taps + t) * CiP + ci;
+    double a0 = 0.0, a1 = 0.0;
+    int z = 0;
+    for (; z + 1 < splits; z += 2) {
+      a0 += (double)src[(int64_t)z * per];
+      a1 += (double)src[(int64_t)(z + 1) * per];
+    }
+    if (z < splits) a0 += (double)src[(int64_t)z * per];
+    out[((int64_t)co * Ci_out + ci) * taps + t] = (float)(a0 + a1);
+  }
 }
 
 // im2col of a float32 scalar field for the 1-channel convolutions: out[m][t] = s[m + delta_t] (0 outside the volume),
@@ -610,7 +694,7 @@ int g_wgrad_tr = 1;  // bf16 fragment fetch: 1 = ds_read_b64_tr_b16, 0 = scalar 
 
 template <int GEOM>
 int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_bytes, Dims g, int Cu, int Cv, int taps,
-              int dtype, hipStream_t stream, int Cv_out = -1, Wg2d q = Wg2d{0, 0, 1, 1, 0, 0}) {
+              int dtype, hipStream_t stream, int Cv_out = -1, Wg2d q = Wg2d{0, 0, 1, 1, 0, 0, 1, 1}) {
   if (Cv_out < 0) Cv_out = Cv;
   const int64_t M = (int64_t)g.N * g.D * g.H * g.W;
   const SplitPlan sp = plan_splits(M, Cu, Cv, taps);
@@ -619,10 +703,10 @@ int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_b
   WgradParams p{u, v, (float*)ws, g, M, Cu, Cv, taps, sp.chunk, q};
   dim3 grid((unsigned)(((Cu + 63) / 64) * ((Cv + 63) / 64)), (unsigned)taps, (unsigned)sp.splits);
   if (dtype == PCRL_BF16) {
-    if (g_wgrad_tr) hipLaunchKernelGGL((wgrad_kernel<bf16, GEOM, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((wgrad_kernel<bf16, GEOM, false>), grid, dim3(256), 0, stream, p);
+    if (g_wgrad_tr) hipLaunchKernelGGL((wgrad_kernel<bf16, GEOM, true>), grid, dim3(256), 4 * 32 * 128, stream, p);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16, GEOM, false>), grid, dim3(256), 4 * 32 * 128, stream, p);
   } else if (dtype == PCRL_F32) {
-    hipLaunchKernelGGL((wgrad_kernel<float, GEOM, false>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((wgrad_kernel<float, GEOM, false>), grid, dim3(256), 4 * 32 * 256, stream, p);
   } else {
     return pcrl_fail(PCRL_EINVAL, "wgrad: bad dtype %d", dtype);
   }
@@ -824,9 +908,23 @@ extern "C" int pcrl_conv3d_to1_wgrad(const void* x, const float* dy, float* dw_r
 // ---- 2D path: weight gradient of a KHxKW / stride / pad convolution, optionally behind a fused nearest x2 upsample ----
 // x: [N][Hi][Wi][CiP], dy: [N][Ho][Wo][CoP] (channel counts multiples of 8 (bf16) / 4 (fp32); zero padded by the caller),
 // dw: float32 [CoP][Ci_out][KH][KW] (reference layout; padded source channels >= Ci_out dropped).
+static SplitPlan plan_splits2d(int64_t M, int Cu, int Cv, int ks) {
+  const int64_t tiles = (int64_t)((Cu + 63) / 64) * ((Cv + 63) / 64);
+  const int64_t steps = (M + ks - 1) / ks;
+  int64_t splits = 2048 / tiles;
+  const int64_t max_splits = (steps + 3) / 4;   // at least 4 K-steps per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int64_t per = (steps + splits - 1) / splits;
+  splits = (steps + per - 1) / per;
+  return SplitPlan{(int)splits, per * ks};
+}
+static int conv2d_wgrad_ks(int dtype) { return (dtype == PCRL_BF16 && g_wgrad_tr) ? 128 : 32; }   // 128 (template KS) measured slower: the loads, not the barriers, set the pace
+
 extern "C" size_t pcrl_conv2d_wgrad_ws_bytes(int N, int Ho, int Wo, int CiP, int CoP, int KH, int KW) {
-  const SplitPlan sp = plan_splits((int64_t)N * Ho * Wo, CoP, CiP, KH * KW);
-  return (size_t)sp.splits * KH * KW * CoP * CiP * sizeof(float);
+  // the larger of the two K-step variants (the dtype is not known here)
+  const SplitPlan a = plan_splits2d((int64_t)N * Ho * Wo, CoP, KH * KW * CiP, 32), b = plan_splits2d((int64_t)N * Ho * Wo, CoP, KH * KW * CiP, 128);
+  return (size_t)(a.splits > b.splits ? a.splits : b.splits) * KH * KW * CoP * CiP * sizeof(float);
 }
 
 extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int CiP, int Ci_out,
@@ -836,6 +934,26 @@ extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, v
   PCRL_REQUIRE(CiP > 0 && CoP > 0 && CiP % vec == 0 && CoP % vec == 0 && Ci_out > 0 && Ci_out <= CiP,
                "conv2d_wgrad: channel counts must be multiples of %d (CiP=%d CoP=%d)", vec, CiP, CoP);
   PCRL_REQUIRE(KH >= 1 && KW >= 1 && KH * KW <= 49 && stride >= 1 && pad >= 0, "conv2d_wgrad: bad kernel geometry");
-  return run_wgrad<WG_CONV2D>(dy, x, dw_ref, ws, ws_bytes, Dims{N, 1, Ho, Wo}, CoP, CiP, KH * KW, dtype, as_stream(stream), Ci_out,
-                              Wg2d{Hi, Wi, KW, stride, pad, up});
+  PCRL_REQUIRE(dtype == PCRL_BF16 || dtype == PCRL_F32, "conv2d_wgrad: bad dtype %d", dtype);
+  const int taps = KH * KW, Cv = taps * CiP;
+  const Dims g{N, 1, Ho, Wo};
+  const int64_t M = (int64_t)N * Ho * Wo;
+  const int ks = conv2d_wgrad_ks(dtype);
+  const SplitPlan sp = plan_splits2d(M, CoP, Cv, ks);
+  const size_t need = (size_t)sp.splits * CoP * Cv * sizeof(float);
+  if (ws_bytes < need || !ws) return pcrl_fail(PCRL_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+  WgradParams p{dy, x, (float*)ws, g, M, CoP, Cv, 1, sp.chunk, Wg2d{Hi, Wi, KW, stride, pad, up, CiP, taps}};
+  dim3 grid((unsigned)(((CoP + 63) / 64) * ((Cv + 63) / 64)), 1u, (unsigned)sp.splits);
+  hipStream_t st = as_stream(stream);
+  if (dtype == PCRL_BF16) {
+    if (g_wgrad_tr) hipLaunchKernelGGL((wgrad_kernel<bf16, WG_CONV2D, true, 128>), grid, dim3(256), 4 * 128 * 128, st, p);
+    else hipLaunchKernelGGL((wgrad_kernel<bf16, WG_CONV2D, false>), grid, dim3(256), 4 * 32 * 128, st, p);
+  } else {
+    hipLaunchKernelGGL((wgrad_kernel<float, WG_CONV2D, false>), grid, dim3(256), 4 * 32 * 256, st, p);
+  }
+  if (int e = pcrl_check_launch("conv2d_wgrad")) return e;
+  const int64_t total = (int64_t)CoP * taps * Ci_out;
+  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(wgrad2d_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw_ref, sp.splits, taps, CoP, CiP, Ci_out);
+  return pcrl_check_launch("conv2d_wgrad_reduce");
 }

@@ -5,10 +5,11 @@
 
 Differences from the reference: `--gpus` selects the visible devices exactly as before, but multi-GPU runs use one
 process per GPU (RCCL) instead of nn.DataParallel -- with a plain `python main.py` and several ids in --gpus the script
-re-launches itself under torch.distributed.run.  `--momentum/--weight_decay` are parsed as floats.  `--d 2` (the 2D
-ResNet18 path, needs segmentation_models_pytorch) is not part of this engine yet.  `--data synthetic` trains on
-generated LUNA-shaped batches (no dataset on disk needed); a LUNA pre-task directory is read by pcrlv2_amd/data.py (crops from
-disk, the reference's torchio augmentations restated on the GPU -- parity with torchio unpinned).
+re-launches itself under torch.distributed.run.  `--momentum/--weight_decay` are parsed as floats.  `--d 2` runs the 2D
+ResNet-18 U-Net path (pcrlv2_amd/train_2d.py; no segmentation_models_pytorch / torchvision needed) on `--data synthetic` only:
+the chest X-ray input pipeline is not part of this engine.  `--data synthetic` trains on generated batches of the reference's
+shapes (no dataset on disk needed); a LUNA pre-task directory is read by pcrlv2_amd/data.py (crops from disk, the reference's
+torchio augmentations restated on the GPU -- parity with torchio unpinned).
 """
 import argparse
 import os
@@ -39,6 +40,7 @@ _FLAGS = (
     ("amp", False, None, "bfloat16 activations and MFMA operands"),
     ("steps_per_epoch", 16, int, "only with --data synthetic"),
     ("resume", "", str, "checkpoint to continue from (model, momentum buffers, epoch)"),
+    ("size2d", 224, int, "only with --d 2 --data synthetic: side of the global views (locals are 96x96)"),
 )
 
 
@@ -76,8 +78,28 @@ class SyntheticLunaLoader:
             yield x1, x2, gt, gt, loc
 
 
+class SyntheticChestLoader(SyntheticLunaLoader):
+    """2D batches with the contract train_2d.py:133 consumes: (input1, input2, gt, gt2, [6 local views]) of [b,3,S,S] / [b,3,96,96]."""
+
+    def __init__(self, b, steps, size, seed=0, device=None):
+        super().__init__(b, steps, seed, device)
+        self.size = size
+
+    def __iter__(self):
+        import torch
+        kw = dict(generator=self.g, device=self.device)
+        for _ in range(self.steps):
+            x1 = torch.randn(self.b, 3, self.size, self.size, **kw)
+            x2 = x1 + 0.1 * torch.randn(self.b, 3, self.size, self.size, **kw)
+            gt = torch.rand(self.b, 3, self.size, self.size, **kw)
+            loc = [torch.randn(self.b, 3, 96, 96, **kw) for _ in range(6)]
+            yield x1, x2, gt, gt, loc
+
+
 def get_dataloader(args):
     """`DataGenerator(args).pcrlv2_luna_pretask()` of the reference (data.py:63-99) -- `--data synthetic`: generated batches."""
+    if args.data == 'synthetic' and args.d == 2:
+        return {'train': SyntheticChestLoader(args.b, args.steps_per_epoch, args.size2d, args.seed + int(os.environ.get("RANK", "0"))), 'eval': None}
     if args.data == 'synthetic':
         return {'train': SyntheticLunaLoader(args.b, args.steps_per_epoch, args.seed + int(os.environ.get("RANK", "0"))), 'eval': None}
     if args.n == 'luna' and os.path.isdir(os.path.join(args.data, 'subset0')):
@@ -103,8 +125,9 @@ def main(argv=None):
     if args.model == 'pcrlv2' and args.phase == 'pretask' and args.d == 3:
         from .train_3d import train_pcrlv2_3d
         train_pcrlv2_3d(args, data_loader)
-    elif args.d == 2:
-        raise SystemExit("--d 2 (PCRLv2 ResNet18 / segmentation_models_pytorch) is not built in this engine yet (SURVEY 8f N1)")
+    elif args.model == 'pcrlv2' and args.phase == 'pretask' and args.d == 2:
+        from .train_2d import train_pcrlv2
+        train_pcrlv2(args, data_loader)
 
 
 if __name__ == '__main__':

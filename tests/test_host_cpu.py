@@ -221,3 +221,63 @@ def test_model_init_matches_reference_under_seed():
         f = v.detach().double().reshape(-1).numpy()
         assert f.sum() == fx[k + "/sum"] and np.abs(f).sum() == fx[k + "/abs"], k
         assert np.array_equal(f[:4], fx[k + "/head"]), k
+
+
+def test_model2d_api_and_state_dict():
+    """PCRLv2 (2D) module tree: the attribute paths / key names the reference gets from smp.Unet('resnet18') + PCRLv2Decoder
+    (pcrlv2_model.py:197-209; train_2d.py:99 saves model.model.encoder.state_dict(); README.md:40-44 loads it into a torchvision-named
+    ResNet-18 encoder)."""
+    from pcrlv2_amd.models import PCRLv2
+    m = PCRLv2()
+    enc = m.model.encoder.state_dict()
+    assert len(enc) == 120 and not any(k.startswith("fc.") for k in enc)
+    assert sum(p.numel() for p in m.model.encoder.parameters()) == 11176512          # torchvision resnet18 minus fc (513000)
+    for k, shape in (("conv1.weight", (64, 3, 7, 7)), ("layer1.0.conv1.weight", (64, 64, 3, 3)), ("layer2.0.downsample.0.weight", (128, 64, 1, 1)),
+                     ("layer4.1.bn2.running_var", (512,)), ("layer3.0.conv1.weight", (256, 128, 3, 3))):
+        assert tuple(enc[k].shape) == shape, k
+    sd = m.state_dict()
+    for i, (cin, cout) in enumerate(((512, 256), (256, 128), (128, 64), (64, 32), (32, 16))):
+        p = f"model.decoder.blocks.{i}."
+        assert tuple(sd[p + "conv1.0.weight"].shape) == (cout, cin, 3, 3) and tuple(sd[p + "conv2.0.weight"].shape) == (cout, cout, 3, 3)
+        assert (p + "conv1.0.bias") not in sd                                          # smp Conv2dReLU: bias=False with BatchNorm
+        assert tuple(sd[p + "deep_supervision_head.0.bias"].shape) == (cout,) and tuple(sd[p + "deep_supervision_head.3.weight"].shape) == (3, cout, 1, 1)
+        assert tuple(sd[p + "predictor_head.0.weight"].shape) == (2 * cout, cout) and tuple(sd[p + "predictor_head.3.weight"].shape) == (cout, 2 * cout)
+        assert tuple(sd[p + "bn.weight"].shape) == (cout,)
+    assert tuple(sd["model.segmentation_head.0.weight"].shape) == (3, 16, 3, 3)
+    with __import__("pytest").raises(RuntimeError):
+        m(__import__("torch").zeros(2, 3, 64, 64))                                     # CPU input: no fallback
+
+
+def test_c1_plumbing_2d_oracle_cpu():
+    """BASELINE configs[0]: 2D PCRLv2 ResNet18-UNet, 224x224 crops, b=4, CPU-only torch -- plumbing (shapes, finite, loss goes down)
+    on the CPU oracle restatement (oracle/pcrlv2_2d_oracle.py, PARITY UNPINNED), initial weights from the engine's model class."""
+    import random
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pcrlv2_2d_oracle as O
+    from pcrlv2_amd.models import PCRLv2
+    torch.manual_seed(0)
+    m = PCRLv2()
+    pn = [n for n, _ in m.named_parameters()]
+    sd = {k: (v.detach().clone().requires_grad_(k in pn) if v.is_floating_point() else v.clone()) for k, v in m.state_dict().items()}
+    batch = O.synthetic_batch(4, 224, 96, seed=0)
+    random.seed(0)
+    losses = []
+    for step in range(3):
+        so = {}
+        r = O.step_losses(sd, batch, epoch=0, so=so)
+        if step == 0:
+            assert r["mask1"].shape == (4, 3, 224, 224) and all(t.shape == (4, 3, 224, 224) for t in r["mid1"])
+            assert [tuple(p.shape) for p, _ in r["out1"]] == [(4, c) for c in (256, 128, 64, 32, 16)]
+        assert torch.isfinite(r["loss"])
+        losses.append(float(r["loss1"]))
+        r["loss"].backward()
+        with torch.no_grad():
+            for k in pn:
+                if sd[k].grad is not None:
+                    sd[k] -= 0.05 * sd[k].grad
+                    sd[k].grad = None
+            for k, v in so.items():
+                sd[k] = v
+    assert losses[-1] < losses[0], losses
