@@ -83,6 +83,9 @@ class _Lib:
         self.debug_set_conv_impl = self.cdll.pcrl_debug_set_conv_impl
         self.debug_set_conv_impl.argtypes = [ctypes.c_int]
         self.debug_set_conv_impl.restype = None
+        self.debug_set_conv2d_impl = self.cdll.pcrl_debug_set_conv2d_impl
+        self.debug_set_conv2d_impl.argtypes = [ctypes.c_int]
+        self.debug_set_conv2d_impl.restype = None
 
     def version(self) -> str:
         return self.fn["pcrl_version"][0]().decode()

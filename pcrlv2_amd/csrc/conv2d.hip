@@ -11,7 +11,10 @@
 // straddle taps (Cs = 8, 16) as cheap as the 32-channel case; K is padded to a multiple of 32 with zero weights.
 //   FWD   : source pixel (oh*s - p + kh, ow*s - p + kw); `up` = the source is read through a nearest x2 upsample
 //           (F.interpolate(scale_factor=2, mode="nearest") of DecoderBlock.forward fused into the gather: ih>>1, iw>>1)
-//   DGRAD : source = dy, pixel ((ih + p - kh)/s, (iw + p - kw)/s) when divisible; weights packed [ci][tap][co]
+//   DGRAD : source = dy, pixel ((ih + p - kh)/s, (iw + p - kw)/s) when divisible; weights packed [ci][tap FLIPPED][co], i.e. the
+//           stride-1 data gradient is literally a forward convolution with these weights (what the brick kernel runs)
+// Stride-1 3x3 convolutions whose batch / extent / channel counts fit (N % 4, H % 8, W % 8, channels % 32, bf16) go to the
+// LDS-halo brick kernel instead (conv_brick.hip, KD = 1: the image index plays the role of depth), forward and data gradient.
 // Tile 128 x BN (BN = 32/64/128) as in conv_igemm.hip: 4 waves 2x2, LDS double-buffered and XOR-swizzled, register-staged
 // (padding needs zero-fill), two staging register sets.  Epilogue: + bias, store (T or float32, columns >= Nc masked), and the
 // per-tile (sum, sum^2) rows for the training-mode BatchNorm2d that follows.
@@ -167,7 +170,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const C2Params p) {
           iw_ >>= 1;                                                                                    \
         }                                                                                               \
       } else {                                                                                          \
-        const int th_ = oy[ps] - kh_, tw_ = ox[ps] - kw_;                                               \
+        const int th_ = oy[ps] - (p.KH - 1 - kh_), tw_ = ox[ps] - (p.KW - 1 - kw_); /* taps are packed flipped */ \
         ih_ = th_ >> sshift;                                                                            \
         iw_ = tw_ >> sshift;                                                                            \
         ok_ = ok_ && th_ >= 0 && tw_ >= 0 && (ih_ << sshift) == th_ && (iw_ << sshift) == tw_ && ih_ < p.Hs && iw_ < p.Ws; \
@@ -289,7 +292,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const C2Params p) {
 
 // Packing: reference weight [Co][Ci][KH][KW] float32 -> K-contiguous rows in T, zero padded.
 //   mode 0 (forward): out[co][tap * CsP + ci],  rows = round_up(Co, 32), CsP = padded source channels (Ci)
-//   mode 1 (dgrad)  : out[ci][tap * CsP + co],  rows = round_up(Ci, 32), CsP = padded source channels (Co)
+//   mode 1 (dgrad)  : out[ci][(taps-1-tap) * CsP + co],  rows = round_up(Ci, 32), CsP = padded source channels (Co); taps flipped
 template <typename T>
 __global__ void __launch_bounds__(256) pack_conv2d_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int taps, int CsP,
                                                           int rowsP, int Kpad, int mode) {
@@ -300,7 +303,7 @@ __global__ void __launch_bounds__(256) pack_conv2d_kernel(const float* __restric
     float v = 0.f;
     if (tap < taps) {
       const int co = mode ? c : row, ci = mode ? row : c;
-      if (co < Co && ci < Ci) v = w[((int64_t)co * Ci + ci) * taps + tap];
+      if (co < Co && ci < Ci) v = w[((int64_t)co * Ci + ci) * taps + (mode ? taps - 1 - tap : tap)];
     }
     out[idx] = from_f<T>(v);
   }
@@ -352,6 +355,14 @@ int conv2d_common(const char* what, int mode, const void* src, const void* wp, c
 
 }  // namespace
 
+// LDS-halo brick kernel (conv_brick.hip, KD = 1)
+bool pcrl_brick_conv2d_eligible(int N, int H, int W, int Ci, int Co, int dtype);
+int64_t pcrl_brick_conv2d_rows(int N, int H, int W);
+int pcrl_brick_conv2d_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Ci, int Co, int up,
+                             hipStream_t stream);
+static int g_conv2d_impl = 0;   // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
+extern "C" void pcrl_debug_set_conv2d_impl(int impl) { g_conv2d_impl = impl; }
+
 extern "C" int64_t pcrl_conv2d_packed_elems(int rows, int taps, int Cs) {
   return (int64_t)((rows + 31) / 32 * 32) * ((taps * Cs + 31) / 32 * 32);
 }
@@ -378,6 +389,14 @@ extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias,
                                int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream) {
   const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
   const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
+  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !out_f32 && x && wp && y &&
+      pcrl_brick_conv2d_eligible(N, Ho, Wo, CiP, Co, dtype)) {
+    if (stats_partial) {   // the caller sized the statistics for the gather kernel's 128-pixel tiles; a brick is 256 pixels: zero the rest
+      const int64_t rb = pcrl_brick_conv2d_rows(N, Ho, Wo), rg = pcrl_conv2d_stats_rows(N, Ho, Wo);
+      if (rg > rb) (void)hipMemsetAsync(stats_partial + rb * Co * 2, 0, (size_t)(rg - rb) * Co * 2 * sizeof(float), as_stream(stream));
+    }
+    return pcrl_brick_conv2d_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, up, as_stream(stream));
+  }
   return conv2d_common("conv2d_fwd", C2_FWD, x, wp, bias, y, stats_partial, N, Hi, Wi, CiP, Ho, Wo, Co, KH, KW, stride, pad, up, out_f32, dtype,
                        as_stream(stream));
 }
@@ -385,6 +404,9 @@ extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias,
 // dx[N][Hi][Wi][Ci] from dy[N][Ho][Wo][CoP]; (Ho, Wo) are the forward output dims of the (Hi, Wi) input.
 extern "C" int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH,
                                  int KW, int stride, int pad, int dtype, pcrl_stream_t stream) {
+  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
+      pcrl_brick_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype))
+    return pcrl_brick_conv2d_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, 0, as_stream(stream));
   return conv2d_common("conv2d_dgrad", C2_DGRAD, dy, wp_dgrad, nullptr, dx, nullptr, N, Ho, Wo, CoP, Hi, Wi, Ci, KH, KW, stride, pad, 0, 0, dtype,
                        as_stream(stream));
 }

@@ -21,23 +21,29 @@ namespace {
 
 constexpr int TD = 4, TH = 8, TW = 8;
 constexpr int BRICK = TD * TH * TW;                    // 256 voxels
-constexpr int HD = TD + 2, HH = TH + 2, HWU = TW + 2;  // halo extents (used)
+constexpr int HH = TH + 2, HWU = TW + 2;               // halo extents in h, w (used)
 constexpr int HW = 16;                                 // halo row pitch in w: padded 10 -> 16, see hoff_h()
-constexpr int HROWS_USED = HD * HH * HWU;              // 600 rows are loaded
-constexpr int HROWS = HD * HH * HW;                    // 960 rows of LDS
 constexpr int HLT = 240;                               // threads that stage the halo: 6 lines x 40 pieces per round
-constexpr int HPT = HD * HH / 6;                       // rounds = pieces per thread (10)
-constexpr int HALO_BYTES = HROWS * 64;                 // 60 KiB
+// KD = kernel extent in d: 3 (the 3x3x3 convolution) or 1 (a 3x3 convolution over a stack of independent images: the 2D path,
+// conv2d.hip, runs its [N][H][W][C] batches through this kernel with the batch index as d -- no halo, no mixing, in d).
+template <int KD> struct BrickGeom {
+  static constexpr int HD = TD + KD - 1;               // halo extent in d
+  static constexpr int LINES = HD * HH;                // (d,h) lines of 10 rows: 60 / 40
+  static constexpr int HPT = (LINES + 5) / 6;          // staging rounds = pieces per thread: 10 / 7 (the last round of KD = 1 is partly idle)
+  static constexpr int HALO_BYTES = HPT * 6 * HW * 64; // 60 KiB / 42 KiB
+  static constexpr int TAPS = 9 * KD, NS = 3 * KD;     // taps; stages (one (kd,kh) = three kw taps) per 32-channel chunk
+};
 // one weight stage: 3 taps x BN rows x 64 B (12 KiB for BN = 64)
 
 struct BrickParams {
   const bf16* x;
-  const bf16* w;      // packed [Nc][27][K]
+  const bf16* w;      // packed [Nc][taps][K]
   const float* bias;
   bf16* y;
   float* stats;       // [bricks][Nc][2] or null
   int N, D, H, W;
   int K, Nc;
+  int up;             // KD = 1 only: the source is [N][D][H/2][W/2] read through a nearest x2 upsample (conv2d.hip)
 };
 
 // Weight tile [64 co][32 k]: a fragment read takes 16 CONSECUTIVE rows -> same swizzle as conv_igemm.hip's Tile<bf16>.
@@ -55,8 +61,10 @@ __device__ __forceinline__ int hoff_h(int row, int slot) {
   return row * 64 + ((slot ^ (((row >> 2) & 1) << 1)) << 4);
 }
 
-template <int BN>   // output channels per block: 64, or 32 for the Co = 32 data gradient (wave tile 64 voxels x BN)
+template <int BN, int KD>   // BN = output channels per block: 64, or 32 for the Co = 32 data gradient (wave tile 64 voxels x BN)
 __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p) {
+  using BG = BrickGeom<KD>;
+  constexpr int HPT = BG::HPT, HALO_BYTES = BG::HALO_BYTES, NS = BG::NS;
   constexpr int FN = BN / 16;
   constexpr int WT_BYTES = 3 * BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -91,16 +99,21 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   for (int i = 0; i < HPT; ++i) {
     const int line = hl0 + 6 * i;
     const int hd = line / HH, hh = line % HH, hw = hq >> 2;
-    const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
-    const bool ok = (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-    grow[i] = ok ? ((n * p.D + d) * p.H + h) * p.W + w : ((n * p.D + d0) * p.H + h0) * p.W + w0;
+    const int d = d0 + hd - (KD - 1) / 2, h = h0 + hh - 1, w = w0 + hw - 1;
+    const bool ok = line < BG::LINES && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+    if (KD == 1 && p.up) {
+      const int Hs = p.H >> 1, Ws = p.W >> 1;
+      grow[i] = ok ? ((n * p.D + d) * Hs + (h >> 1)) * Ws + (w >> 1) : ((n * p.D + d0) * Hs + (h0 >> 1)) * Ws + (w0 >> 1);
+    } else {
+      grow[i] = ok ? ((n * p.D + d) * p.H + h) * p.W + w : ((n * p.D + d0) * p.H + h0) * p.W + w0;
+    }
     hvalid |= (uint32_t)ok << i;
   }
   const int hdst0 = hoff_h(hl0 * HW + (hq >> 2), hslot);   // + i * 6 * HW * 64
 
   // ---- weight staging: 3 pieces per thread (tap kw = 0,1,2 of the current (kd,kh)), row co = tid>>2, slot tid&3 ----
   const bool wthread = BN == 64 || (tid >> 2) < BN;   // BN = 32: only the first 128 threads stage weights
-  const bf16* wrow = p.w + ((int64_t)(n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8;
+  const bf16* wrow = p.w + ((int64_t)(n0 + (wthread ? (tid >> 2) : 0)) * BG::TAPS) * K + (tid & 3) * 8;
   const int wdst = hoff_w(tid >> 2, tid & 3);   // within one tap tile [64][32]
 
   f32x4 acc[4][FN];
@@ -183,11 +196,11 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #define STAGE(P_)                                                                                         \
   do {                                                                                                    \
     int cn = c, sn = s9 + 1;                                                                              \
-    if (sn == 9) { sn = 0; cn = c + 1; }                                                                  \
+    if (sn == NS) { sn = 0; cn = c + 1; }                                                                  \
     const bool last = (cn == nchunk);                                                                     \
     if (last) { cn = c; sn = s9; }                                                                        \
     LOAD_W(cn, sn);                                                                                       \
-    const bool halo_next = (s9 == 8) && !last; /* block-uniform */                                        \
+    const bool halo_next = (s9 == NS - 1) && !last; /* block-uniform */                                        \
     if (halo_next) LOAD_HALO(c + 1);                                                                      \
     const int tap64 = ((s9 / 3) * HH + (s9 % 3)) * (HW * 64);                                             \
     const int ntap64 = ((sn / 3) * HH + (sn % 3)) * (HW * 64);                                            \
@@ -226,7 +239,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   __syncthreads();
   LOADF(0, akw[0], wbuf);
 
-  const int nstage = 9 * nchunk;
+  const int nstage = NS * nchunk;
   for (int S = 0; S + 1 < nstage; S += 2) {
     STAGE(0);
     STAGE(1);
@@ -307,15 +320,33 @@ int64_t pcrl_brick_conv_rows(int N, int D, int H, int W) { return (int64_t)N * (
 
 int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                            int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
+  constexpr int HB = BrickGeom<3>::HALO_BYTES;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 32 * 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, HB + 3 * 64 * 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, HB + 3 * 32 * 64);
     attr_set = true;
   }
-  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co};
+  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0};
   const unsigned bricks = (unsigned)pcrl_brick_conv_rows(N, D, H, W);
-  if (Co % 64 == 0) hipLaunchKernelGGL(brick_conv_kernel<64>, dim3(bricks, Co / 64), dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
-  else hipLaunchKernelGGL(brick_conv_kernel<32>, dim3(bricks, Co / 32), dim3(256), HALO_BYTES + 3 * 32 * 64, stream, p);
+  if (Co % 64 == 0) hipLaunchKernelGGL((brick_conv_kernel<64, 3>), dim3(bricks, Co / 64), dim3(256), HB + 3 * 64 * 64, stream, p);
+  else hipLaunchKernelGGL((brick_conv_kernel<32, 3>), dim3(bricks, Co / 32), dim3(256), HB + 3 * 32 * 64, stream, p);
   return pcrl_check_launch("brick_conv");
+}
+
+// ---- 2D path: 3x3 / stride 1 / pad 1 convolution of a stack of N images (N % 4 == 0), optionally behind a nearest x2 upsample ----
+// H, W = OUTPUT dims (= logical input dims); weights packed [Co][9][Ci] (forward) or [Ci][9 flipped][Co] (data gradient).
+bool pcrl_brick_conv2d_eligible(int N, int H, int W, int Ci, int Co, int dtype) {
+  return dtype == PCRL_BF16 && N % TD == 0 && H % TH == 0 && W % TW == 0 && Ci % 32 == 0 && Co % 32 == 0 && (int64_t)N * H * W < (int64_t)1 << 31;
+}
+int64_t pcrl_brick_conv2d_rows(int N, int H, int W) { return (int64_t)(N / TD) * (H / TH) * (W / TW); }
+
+int pcrl_brick_conv2d_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Ci, int Co, int up,
+                             hipStream_t stream) {
+  constexpr int HB = BrickGeom<1>::HALO_BYTES;
+  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, 1, N, H, W, Ci, Co, up};
+  const unsigned bricks = (unsigned)pcrl_brick_conv2d_rows(N, H, W);
+  if (Co % 64 == 0) hipLaunchKernelGGL((brick_conv_kernel<64, 1>), dim3(bricks, Co / 64), dim3(256), HB + 3 * 64 * 64, stream, p);
+  else hipLaunchKernelGGL((brick_conv_kernel<32, 1>), dim3(bricks, Co / 32), dim3(256), HB + 3 * 32 * 64, stream, p);
+  return pcrl_check_launch("brick_conv2d");
 }

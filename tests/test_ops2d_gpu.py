@@ -146,3 +146,39 @@ def test_add_relu_and_mask(dt):
     da = torch.randn(2, 16, 8, 8, generator=g).to(dt)
     gk = ops2d.relu_mask_backward(ops2d.to_act2(da.to(_dev()), dt), a, dt)
     assert torch.equal(gk.cpu(), torch.where(ref > 0, da, torch.zeros_like(da)))
+
+
+@pytest.mark.parametrize("Ci,Co,up,H,W,N", [(64, 64, 0, 16, 24, 4), (64, 32, 0, 8, 16, 8), (128, 64, 1, 8, 8, 4), (32, 128, 0, 24, 8, 4)])
+def test_conv2d_brick_path(Ci, Co, up, H, W, N):
+    """3x3 / stride 1 bf16 convolutions with N % 4 == H % 8 == W % 8 == 0 and channels % 32 == 0 run on the LDS-halo brick kernel
+    (conv_brick.hip, KD = 1), forward (optionally behind the nearest x2 upsample) and data gradient; statistics rows included."""
+    from pcrlv2_amd import ops2d
+    from pcrlv2_amd._lib import lib
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(Ci + Co + up)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    xa = ops2d.to_act2(x.to(_dev()), dt)
+    wd = w.to(_dev())
+    xr, wr = _q(x, dt).requires_grad_(True), _q(w, dt).requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2, mode="nearest") if up else xr
+    yr = F.conv2d(xin, wr, None, 1, 1)
+    dy = torch.randn(yr.shape, generator=g)
+    yr.backward(_q(dy, dt))
+    outs = {}
+    for impl in (0, 1):            # 0 = auto (brick), 1 = gather kernel
+        lib().debug_set_conv2d_impl(impl)
+        try:
+            packed = ops2d.PackedConv2d()
+            y, partial, rows = ops2d.conv2d_forward(xa, wd, None, packed, 1, 1, up, dt)
+            dx, dw = ops2d.conv2d_backward(xa, ops2d.to_act2(dy.to(_dev()), dt), wd, packed, 1, 1, up, dt)
+        finally:
+            lib().debug_set_conv2d_impl(0)
+        _close(y, yr, dt, f"fwd impl={impl}", bf_tol=6e-3)
+        _close(dx, xr.grad, dt, f"dgrad impl={impl}", bf_tol=6e-3)
+        st = partial.view(rows, Co, 2).double().sum(0).cpu()
+        _close(st[:, 0], yr.sum((0, 2, 3)), torch.float32, f"stats sum impl={impl}", f32_tol=3e-3)
+        _close(st[:, 1], (yr * yr).sum((0, 2, 3)), torch.float32, f"stats sumsq impl={impl}", f32_tol=3e-3)
+        outs[impl] = (y.float().cpu(), dx.float().cpu())
+    # same operands, same fp32 accumulation: the two kernels differ only in summation order
+    assert (outs[0][0] - outs[1][0]).abs().max() <= 0.02 * outs[1][0].abs().max()
