@@ -145,3 +145,51 @@ def test_bf16_step_close_to_fp32():
         vals[dt] = [float(v) for v in train_2d.step_losses(model, batch, 0, train_2d.MSELoss2d(), CosineSimilarityMean())]
     for a, b in zip(vals[torch.float32], vals[torch.bfloat16]):
         assert abs(a - b) < 3e-2 * max(1.0, abs(a)), vals
+
+
+DDP2_WORKER_2D = r'''
+import os, sys, random, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle"))
+import pcrlv2_2d_oracle as O
+from pcrlv2_amd import ddp, train_2d
+from pcrlv2_amd.models import PCRLv2
+from pcrlv2_amd.optim import FusedSGD
+from pcrlv2_amd.train_3d import CosineSimilarityMean
+rank, world, _ = ddp.init_process_group_from_env("gloo")     # two processes, ONE GPU: gloo moves the CUDA buffers
+torch.cuda.set_device(0)
+batches = [O.synthetic_batch(4, 64, 32, seed=50 + 10 * rank + s) for s in range(2)]     # different data per rank
+finals = []
+for overlap in (True, False):
+    random.seed(3); torch.manual_seed(0)
+    model = PCRLv2().cuda().set_compute_dtype(torch.bfloat16)
+    opt = FusedSGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+    dp = ddp.DataParallel(model, opt, bucket_mb=8.0, overlap=overlap)
+    assert dp._active and opt.grad_scale == 0.5 and len(dp.reducer.buckets) >= 3
+    for bt in batches:
+        losses = train_2d.train_step(model, opt, bt, 3, train_2d.MSELoss2d(), CosineSimilarityMean())
+        assert all(torch.isfinite(l) for l in losses)
+    finals.append(opt.flat_p.clone())
+    assert not getattr(dp, "_warned_late", False), "a gradient arrived after its bucket was reduced"
+assert torch.equal(finals[0], finals[1]), (finals[0] - finals[1]).abs().max()
+mine = finals[0].double().sum().reshape(1).cpu()
+both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+dist.all_gather(both, mine)
+assert both[0].item() == both[1].item(), both
+dist.barrier()
+print("OK", rank)
+'''
+
+
+def test_data_parallel_two_ranks_one_gpu_gloo_2d(tmp_path):
+    """N > 1 on the 2D model: two gloo ranks on cuda:0, different batches; bucket overlap on/off bit-identical, ranks agree."""
+    import subprocess
+    script = tmp_path / "ddp2d.py"
+    script.write_text(DDP2_WORKER_2D)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29771", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert all("OK" in o for o in outs)
