@@ -6,4 +6,4 @@ shift
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -- python $R/tools/bench_2d.py --steps 4 --warmup 2 "$@" > $R/gpurun_out/$TAG.log 2>&1
 cd $R && python tools/summarize_profiles.py $TAG $(find gpurun_out/$TAG -name "*kernel_stats.csv") 6 | head -40
-rm -f profiles/${TAG}_kernel_stats.txt
+

@@ -24,7 +24,14 @@ def short(name):
                                                                 {"0": "conv3", "1": "convT_fwd", "2": "convT_dgrad"}[m.group(3)],
                                                                 ",planes" if m.group(4) == "1" else "")
             return key
-    return name[:70]
+    import re
+    m = re.search(r"conv2d_kernelI(DF16b|f)Li(\d+)ELi(\d)E", name)
+    if m:
+        return "conv2d_kernel<%s,BN=%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), "dgrad" if m.group(3) == "1" else "fwd")
+    m = re.search(r"_ZN12_GLOBAL__N_1\d+(\w+?_kernel)I", name)
+    if m:
+        return m.group(1)
+    return name.replace("void ", "").replace("(anonymous namespace)::", "")[:70]
 
 
 def main():
@@ -37,7 +44,9 @@ def main():
         a[0] += int(r["Calls"])
         a[1] += float(r["TotalDurationNs"])
     tot = sum(v[1] for v in agg.values())
-    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats -- python bench.py (b=32, 64x64x32, bf16); {steps} steps in the trace",
+    import os
+    what = os.environ.get("PROFILE_CMD", "python bench.py (b=32, 64x64x32, bf16)")
+    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats -- {what}; {steps} steps in the trace",
              f"# total kernel time {tot / 1e6 / steps:.2f} ms/step",
              f"{'kernel':52s} {'calls/step':>10s} {'ms/step':>9s} {'avg_us':>9s} {'pct':>6s}"]
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
