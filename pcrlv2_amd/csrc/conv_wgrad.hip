@@ -349,24 +349,28 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 }
 
 // Second pass of the 2D weight gradient: out_ref[co][ci][t] = sum_z ws[z][co][t * CiP + ci], ci < Ci_out (padding channels dropped).
+// Block = 64 outputs x 4 split groups: thread (o, g) sums splits g, g+4, ... in double, the four partial sums are combined in fixed
+// order through LDS (the narrow full-resolution layers have few outputs and hundreds of splits: one thread per output crawled).
 __global__ void __launch_bounds__(256) wgrad2d_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int splits, int taps, int Cu,
                                                              int CiP, int Ci_out) {
+  __shared__ double part[4][64];
   const int64_t per = (int64_t)Cu * taps * CiP;
   const int64_t total = (int64_t)Cu * taps * Ci_out;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+  const int o = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + o;
+  double a = 0.0;
+  int64_t dst = 0;
+  if (idx < total) {
     const int ci = (int)(idx % Ci_out);
     const int64_t r = idx / Ci_out;
     const int t = (int)(r % taps), co = (int)(r / taps);
     const float* src = ws + ((int64_t)co * taps + t) * CiP + ci;
-    double a0 = 0.0, a1 = 0.0;
-    int z = 0;
-    for (; z + 1 < splits; z += 2) {
-      a0 += (double)src[(int64_t)z * per];
-      a1 += (double)src[(int64_t)(z + 1) * per];
-    }
-    if (z < splits) a0 += (double)src[(int64_t)z * per];
-    out[((int64_t)co * Ci_out + ci) * taps + t] = (float)(a0 + a1);
+    dst = ((int64_t)co * Ci_out + ci) * taps + t;
+    for (int z = zg; z < splits; z += 4) a += (double)src[(int64_t)z * per];
   }
+  part[zg][o] = a;
+  __syncthreads();
+  if (zg == 0 && idx < total) out[dst] = (float)((part[0][o] + part[1][o]) + (part[2][o] + part[3][o]));
 }
 
 // im2col of a float32 scalar field for the 1-channel convolutions: out[m][t] = s[m + delta_t] (0 outside the volume),
@@ -921,10 +925,20 @@ static SplitPlan plan_splits2d(int64_t M, int Cu, int Cv, int ks) {
 }
 static int conv2d_wgrad_ks(int dtype) { return (dtype == PCRL_BF16 && g_wgrad_tr) ? 128 : 32; }   // 128 (template KS) measured slower: the loads, not the barriers, set the pace
 
+// LDS-halo brick kernel with the image index as depth (wgrad_brick.hip, nkd = 1)
+bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype);
+int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co);
+int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, hipStream_t stream);
+
 extern "C" size_t pcrl_conv2d_wgrad_ws_bytes(int N, int Ho, int Wo, int CiP, int CoP, int KH, int KW) {
-  // the larger of the two K-step variants (the dtype is not known here)
+  // the largest of the variants (the dtype is not known here)
   const SplitPlan a = plan_splits2d((int64_t)N * Ho * Wo, CoP, KH * KW * CiP, 32), b = plan_splits2d((int64_t)N * Ho * Wo, CoP, KH * KW * CiP, 128);
-  return (size_t)(a.splits > b.splits ? a.splits : b.splits) * KH * KW * CoP * CiP * sizeof(float);
+  int splits = a.splits > b.splits ? a.splits : b.splits;
+  if (KH == 3 && KW == 3 && pcrl_wgrad_brick2d_eligible(N, Ho, Wo, CiP, CoP, PCRL_BF16)) {
+    const int c = pcrl_wgrad_brick2d_splits(N, Ho, Wo, CiP, CoP);
+    if (c > splits) splits = c;
+  }
+  return (size_t)splits * KH * KW * CoP * CiP * sizeof(float);
 }
 
 extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int CiP, int Ci_out,
@@ -936,6 +950,16 @@ extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, v
   PCRL_REQUIRE(KH >= 1 && KW >= 1 && KH * KW <= 49 && stride >= 1 && pad >= 0, "conv2d_wgrad: bad kernel geometry");
   PCRL_REQUIRE(dtype == PCRL_BF16 || dtype == PCRL_F32, "conv2d_wgrad: bad dtype %d", dtype);
   const int taps = KH * KW, Cv = taps * CiP;
+  if (g_wgrad_impl == 0 && g_wgrad_tr && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !up && Hi == Ho && Wi == Wo &&
+      pcrl_wgrad_brick2d_eligible(N, Ho, Wo, CiP, CoP, dtype)) {
+    const int splits = pcrl_wgrad_brick2d_splits(N, Ho, Wo, CiP, CoP);
+    const size_t need = (size_t)splits * 9 * CoP * CiP * sizeof(float);
+    if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+    if (int e = pcrl_wgrad_brick2d_launch(x, dy, (float*)ws, N, Ho, Wo, CiP, CoP, as_stream(stream))) return e;
+    const int blocks = (int)(((int64_t)CoP * Ci_out + RED_IJ - 1) / RED_IJ);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)ws, dw_ref, splits, 9, CoP, CiP, Ci_out);
+    return pcrl_check_launch("wgrad_reduce");
+  }
   const Dims g{N, 1, Ho, Wo};
   const int64_t M = (int64_t)N * Ho * Wo;
   const int ks = conv2d_wgrad_ks(dtype);
@@ -953,7 +977,7 @@ extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, v
   }
   if (int e = pcrl_check_launch("conv2d_wgrad")) return e;
   const int64_t total = (int64_t)CoP * taps * Ci_out;
-  const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  const unsigned blocks = (unsigned)((total + 63) / 64);
   hipLaunchKernelGGL(wgrad2d_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw_ref, sp.splits, taps, CoP, CiP, Ci_out);
   return pcrl_check_launch("conv2d_wgrad_reduce");
 }

@@ -37,6 +37,8 @@ struct WBrickParams {
   int N, D, H, W;
   int Cu, Cv;
   int nbricks, per_split;
+  int nkd;          // 3: the 3x3x3 convolution (blockIdx.y = tile * 3 + kd); 1: a 3x3 convolution over a stack of images (2D path:
+                    // the image index is d and only the centre plane kd = 1 exists; slabs hold 9 taps)
 };
 
 __device__ __forceinline__ int dy_off(int v, int col) {   // 128-byte rows, 32-byte quads XOR-swizzled (see conv_wgrad.hip)
@@ -61,8 +63,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lg = lane >> 4, jr = (lane & 15) >> 2, cq = lane & 3;
   const int ntj = p.Cv / 64 > 0 ? (p.Cv + 63) / 64 : 1;
-  const int kd = blockIdx.y % 3;
-  const int tile = blockIdx.y / 3;
+  const int kd = p.nkd == 3 ? blockIdx.y % 3 : 1;
+  const int tile = blockIdx.y / p.nkd;
   const int i0 = (tile / ntj) * 64, j0 = (tile % ntj) * 64;
   const int b_beg = blockIdx.x * p.per_split;
   const int b_end = min(b_beg + p.per_split, p.nbricks);
@@ -230,12 +232,12 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
 #undef WB_STORE_PIECE
 
   // D[i][j]: lane holds i = 16 f + 4 lg + r, j = lane & 15
-  float* out = p.ws + (int64_t)blockIdx.x * 27 * p.Cu * p.Cv;
+  float* out = p.ws + (int64_t)blockIdx.x * (9 * p.nkd) * p.Cu * p.Cv;
   const int j = j0 + wid * 16 + (lane & 15);
   if (j < p.Cv) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      float* ot = out + (int64_t)(kd * 9 + t) * p.Cu * p.Cv;
+      float* ot = out + (int64_t)((p.nkd == 3 ? kd * 9 : 0) + t) * p.Cu * p.Cv;
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
@@ -247,8 +249,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
 struct BrickSplit {
   int splits, per_split;
 };
-BrickSplit plan(int nbricks, int Cu, int Cv) {
-  const int tiles = (Cu / 64) * ((Cv + 63) / 64) * 3;
+BrickSplit plan(int nbricks, int Cu, int Cv, int nkd = 3) {
+  const int tiles = (Cu / 64) * ((Cv + 63) / 64) * nkd;
   // One block per CU (one wave per SIMD, 256 CUs): the grid should be a whole number of rounds of 256 blocks -- 384 blocks run
   // as long as 512.  Fewer rounds = fewer partial slabs for the second pass: take the smallest k <= 3 that fills >= 90 %.
   int splits = 1;
@@ -284,8 +286,30 @@ int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int
   }
   const int nbricks = (int)((int64_t)N * D * H * W / BV);
   const BrickSplit sp = plan(nbricks, Co, Ci);
-  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split};
+  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 3};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64) * 3));
   hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(256), lds, stream, p);
   return pcrl_check_launch("wgrad_brick");
+}
+
+
+// ---- 2D path: weight gradient of a 3x3 / stride 1 / pad 1 convolution over N images (N % 2 == 0): the image index is the depth ----
+bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype) {
+  return dtype == PCRL_BF16 && N % BD == 0 && H % BH == 0 && W % BW == 0 && Co % 64 == 0 && Ci % 32 == 0 && (int64_t)N * H * W / BV < (1 << 30) &&
+         (int64_t)N * H * W * (Ci > Co ? Ci : Co) < ((int64_t)1 << 31);
+}
+int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co) { return plan((int)((int64_t)N * H * W / BV), Co, Ci, 1).splits; }
+int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, hipStream_t stream) {
+  static bool attr_set = false;
+  const size_t lds = 2 * BUF_BYTES;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  const int nbricks = (int)((int64_t)N * H * W / BV);
+  const BrickSplit sp = plan(nbricks, Co, Ci, 1);
+  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, 1};
+  dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64)));
+  hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(256), lds, stream, p);
+  return pcrl_check_launch("wgrad_brick2d");
 }

@@ -168,12 +168,15 @@ def test_conv2d_brick_path(Ci, Co, up, H, W, N):
     outs = {}
     for impl in (0, 1):            # 0 = auto (brick), 1 = gather kernel
         lib().debug_set_conv2d_impl(impl)
+        lib().debug_set_wgrad_impl(impl)     # weight gradient: brick kernel (wgrad_brick.hip, nkd = 1) where Co % 64 == 0 and no upsample
         try:
             packed = ops2d.PackedConv2d()
             y, partial, rows = ops2d.conv2d_forward(xa, wd, None, packed, 1, 1, up, dt)
             dx, dw = ops2d.conv2d_backward(xa, ops2d.to_act2(dy.to(_dev()), dt), wd, packed, 1, 1, up, dt)
         finally:
             lib().debug_set_conv2d_impl(0)
+            lib().debug_set_wgrad_impl(0)
+        _close(dw, wr.grad, torch.float32, f"wgrad impl={impl}", f32_tol=1e-4)
         _close(y, yr, dt, f"fwd impl={impl}", bf_tol=6e-3)
         _close(dx, xr.grad, dt, f"dgrad impl={impl}", bf_tol=6e-3)
         st = partial.view(rows, Co, 2).double().sum(0).cpu()
