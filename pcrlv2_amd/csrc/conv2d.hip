@@ -78,7 +78,10 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int BN, int MODE>
+// NSM > 0: burst variant for layers with at most NSM K-steps (16-channel layers at full resolution, the 1x1 / 3-channel heads): all
+// K-steps are loaded up front into NSM register sets, so a block waits for global memory once instead of once per step -- these
+// launches are 131 072 blocks of a few hundred MFMA cycles each and were bound by exactly that latency chain.
+template <typename T, int BN, int MODE, int NSM = 0>
 __global__ void __launch_bounds__(256) conv2d_kernel(const C2Params p) {
   constexpr int BM = PCRL_CONV_BM;
   using TL = Tile<T>;
@@ -206,6 +209,24 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const C2Params p) {
 
 #define C2_CLAMP(s_) ((s_) < S ? (s_) : S - 1)
 
+  if (NSM > 0) {
+    constexpr int NS_ = NSM > 0 ? NSM : 1;
+    u32x4 ra_[NS_][AP], rb_[NS_][BP];
+    uint32_t aok_[NS_];
+#pragma unroll
+    for (int s = 0; s < NS_; ++s) C2_LOAD(C2_CLAMP(s), ra_[s], rb_[s], aok_[s]);   // unconditional (a step past S repeats the last one, unused)
+    C2_STORE(0, ra_[0], rb_[0], aok_[0]);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS_; ++s) {
+      if (s < S) {   // block-uniform
+        if (s + 1 < NS_ && s + 1 < S) C2_STORE((s + 1) & 1, ra_[s + 1 < NS_ ? s + 1 : 0], rb_[s + 1 < NS_ ? s + 1 : 0], aok_[s + 1 < NS_ ? s + 1 : 0]);
+        if (s & 1) C2_COMPUTE(1);
+        else C2_COMPUTE(0);
+        __syncthreads();
+      }
+    }
+  } else {
   C2_LOAD(0, raA, rbA, aokA);
   C2_STORE(0, raA, rbA, aokA);
   C2_LOAD(C2_CLAMP(1), raA, rbA, aokA);
@@ -224,6 +245,7 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const C2Params p) {
     __builtin_amdgcn_sched_barrier(0);
     C2_STORE(0, raB, rbB, aokB);
     __syncthreads();
+  }
   }
 #undef C2_LOAD
 #undef C2_STORE
@@ -324,7 +346,12 @@ template <typename T, int MODE> int launch_bn(const C2Params& p, int NcP, hipStr
   } else if (NcP % 64 == 0) {
     hipLaunchKernelGGL((conv2d_kernel<T, 64, MODE>), dim3(gx, NcP / 64), dim3(256), 2 * (size_t)(PCRL_CONV_BM + 64) * TL::ROWB, stream, p);
   } else {
-    hipLaunchKernelGGL((conv2d_kernel<T, 32, MODE>), dim3(gx, NcP / 32), dim3(256), 2 * (size_t)(PCRL_CONV_BM + 32) * TL::ROWB, stream, p);
+    const int S = p.Kpad / 32;
+    const size_t lds = 2 * (size_t)(PCRL_CONV_BM + 32) * TL::ROWB;
+    if (S <= 1) hipLaunchKernelGGL((conv2d_kernel<T, 32, MODE, 1>), dim3(gx, NcP / 32), dim3(256), lds, stream, p);
+    else if (S <= 3) hipLaunchKernelGGL((conv2d_kernel<T, 32, MODE, 3>), dim3(gx, NcP / 32), dim3(256), lds, stream, p);
+    else if (S <= 5) hipLaunchKernelGGL((conv2d_kernel<T, 32, MODE, 5>), dim3(gx, NcP / 32), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((conv2d_kernel<T, 32, MODE>), dim3(gx, NcP / 32), dim3(256), lds, stream, p);
   }
   return pcrl_check_launch("conv2d");
 }
