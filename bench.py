@@ -180,7 +180,9 @@ def main():
     traffic, traffic_src = None, None
     try:
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        import re
+        # the most recent summary = the one taken at the highest throughput (file names carry it: r01_<step>_<crops/s>cps_pmc.json)
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=lambda q: int((re.search(r"_(\d+)cps_", q) or [0, 0])[1])):
             d = json.load(open(f))
             if dom in d:
                 traffic, traffic_src = round(d[dom]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
