@@ -141,13 +141,12 @@ __device__ __forceinline__ void bilinear_src(int dst, float inv_scale, int in_si
   l1 = src - (float)i0;
 }
 
-// x: float32 [N][H][W][C] (C small: the 3-channel maps), y: [N][H*s][W*s][C]
+// x: float32 [N][H][W][C] (C small: the 3-channel maps), y: [N][H*s][W*s][C]; thread = output pixel, all C channels (C <= 4 fast path)
 __global__ void __launch_bounds__(256) bilinear_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int s, int64_t total) {
   const int Ho = H * s, Wo = W * s;
   const float inv = 1.0f / (float)s;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    int64_t t = i / C;
+    int64_t t = i;
     const int ow = (int)(t % Wo);
     t /= Wo;
     const int oh = (int)(t % Ho);
@@ -156,10 +155,14 @@ __global__ void __launch_bounds__(256) bilinear_fwd_kernel(const float* __restri
     float lh, lw;
     bilinear_src(oh, inv, H, h0, h1, lh);
     bilinear_src(ow, inv, W, w0, w1, lw);
-    const float* b = x + n * H * W * C + c;
-    const float v00 = b[((int64_t)h0 * W + w0) * C], v01 = b[((int64_t)h0 * W + w1) * C];
-    const float v10 = b[((int64_t)h1 * W + w0) * C], v11 = b[((int64_t)h1 * W + w1) * C];
-    y[i] = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+    const float* b = x + n * H * W * C;
+    const float* p00 = b + ((int64_t)h0 * W + w0) * C;
+    const float* p01 = b + ((int64_t)h0 * W + w1) * C;
+    const float* p10 = b + ((int64_t)h1 * W + w0) * C;
+    const float* p11 = b + ((int64_t)h1 * W + w1) * C;
+    float* o = y + i * C;
+    for (int c = 0; c < C; ++c)
+      o[c] = (1.f - lh) * ((1.f - lw) * p00[c] + lw * p01[c]) + lh * ((1.f - lw) * p10[c] + lw * p11[c]);
   }
 }
 
@@ -278,7 +281,7 @@ extern "C" int pcrl_upsample2d_nearest2_bwd(const void* dy, void* dx, int N, int
 
 extern "C" int pcrl_upsample2d_bilinear_fwd(const float* x, float* y, int N, int H, int W, int C, int scale, pcrl_stream_t stream) {
   PCRL_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && scale >= 1, "upsample2d_bilinear_fwd: bad arguments");
-  const int64_t total = (int64_t)N * H * scale * W * scale * C;
+  const int64_t total = (int64_t)N * H * scale * W * scale;
   hipLaunchKernelGGL(bilinear_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, y, H, W, C, scale, total);
   return pcrl_check_launch("upsample2d_bilinear_fwd");
 }

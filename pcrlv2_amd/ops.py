@@ -140,6 +140,14 @@ class PackedWeights:
 # ----------------------------------------------------------------------------------------------
 def bn_finalize(partial, rows, C, count, gamma, beta, running_mean, running_var):
     dev = partial.device
+    if rows > 20000:
+        # full-resolution 2D layers leave > 100 000 statistics rows for as few as 16 channels: pcrl_bn_finalize runs one block per
+        # channel, so the rows are first summed by the tiled column-sum kernels (chip-wide, coalesced)
+        L = lib()
+        both = _f32(2 * C, dev)
+        nb = L.call("pcrl_colsum_ws_bytes", rows, 2 * C)
+        L.call("pcrl_colsum", partial, both, workspace(nb, dev), nb, rows, 2 * C, dtype_code(torch.float32), stream_handle())
+        partial, rows = both, 1
     coef = _f32(4 * C, dev)
     mean, rstd, scale, shift = coef[:C], coef[C:2 * C], coef[2 * C:3 * C], coef[3 * C:]
     lib().call("pcrl_bn_finalize", partial, rows, C, float(count), gamma, beta, running_mean, running_var,
