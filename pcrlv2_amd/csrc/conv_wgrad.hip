@@ -349,15 +349,18 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 }
 
 // Second pass of the 2D weight gradient: out_ref[co][ci][t] = sum_z ws[z][co][t * CiP + ci], ci < Ci_out (padding channels dropped).
-// Block = 64 outputs x 4 split groups: thread (o, g) sums splits g, g+4, ... in double, the four partial sums are combined in fixed
-// order through LDS (the narrow full-resolution layers have few outputs and hundreds of splits: one thread per output crawled).
+// Block = (256 / ZG) outputs x ZG split groups: thread (o, g) sums splits g, g+ZG, ... in double, the ZG partial sums are combined in
+// fixed order through LDS.  ZG = 4 for the wide layers (few splits, many outputs), 16 for the narrow full-resolution layers
+// (thousands of slabs, a few thousand outputs: one thread per output crawled).
+template <int ZG>
 __global__ void __launch_bounds__(256) wgrad2d_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int splits, int taps, int Cu,
                                                              int CiP, int Ci_out) {
-  __shared__ double part[4][64];
+  constexpr int NO = 256 / ZG;
+  __shared__ double part[ZG][NO];
   const int64_t per = (int64_t)Cu * taps * CiP;
   const int64_t total = (int64_t)Cu * taps * Ci_out;
-  const int o = threadIdx.x & 63, zg = threadIdx.x >> 6;
-  const int64_t idx = (int64_t)blockIdx.x * 64 + o;
+  const int o = threadIdx.x % NO, zg = threadIdx.x / NO;
+  const int64_t idx = (int64_t)blockIdx.x * NO + o;
   double a = 0.0;
   int64_t dst = 0;
   if (idx < total) {
@@ -366,11 +369,22 @@ __global__ void __launch_bounds__(256) wgrad2d_reduce_kernel(const float* __rest
     const int t = (int)(r % taps), co = (int)(r / taps);
     const float* src = ws + ((int64_t)co * taps + t) * CiP + ci;
     dst = ((int64_t)co * Ci_out + ci) * taps + t;
-    for (int z = zg; z < splits; z += 4) a += (double)src[(int64_t)z * per];
+    for (int z = zg; z < splits; z += ZG) a += (double)src[(int64_t)z * per];
   }
   part[zg][o] = a;
   __syncthreads();
-  if (zg == 0 && idx < total) out[dst] = (float)((part[0][o] + part[1][o]) + (part[2][o] + part[3][o]));
+  if (zg == 0 && idx < total) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < ZG; ++q) s += part[q][o];
+    out[dst] = (float)s;
+  }
+}
+static int launch_wgrad2d_reduce(const float* ws, float* out, int splits, int taps, int Cu, int CiP, int Ci_out, hipStream_t st) {
+  const int64_t total = (int64_t)Cu * taps * Ci_out;
+  if (splits > 64) hipLaunchKernelGGL(wgrad2d_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, ws, out, splits, taps, Cu, CiP, Ci_out);
+  else hipLaunchKernelGGL(wgrad2d_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, ws, out, splits, taps, Cu, CiP, Ci_out);
+  return pcrl_check_launch("conv2d_wgrad_reduce");
 }
 
 // im2col of a float32 scalar field for the 1-channel convolutions: out[m][t] = s[m + delta_t] (0 outside the volume),
@@ -930,12 +944,21 @@ bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype)
 int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co);
 int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, hipStream_t stream);
 
+// right-sized kernel for the 16/32-channel layers (wgrad2d_narrow.hip)
+bool pcrl_wgrad2d_narrow_eligible(int N, int H, int W, int CiP, int CoP, int dtype);
+int pcrl_wgrad2d_narrow_slabs(int N, int H, int W);
+int pcrl_wgrad2d_narrow_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int CiP, int CoP, int up, hipStream_t stream);
+
 extern "C" size_t pcrl_conv2d_wgrad_ws_bytes(int N, int Ho, int Wo, int CiP, int CoP, int KH, int KW) {
   // the largest of the variants (the dtype is not known here)
   const SplitPlan a = plan_splits2d((int64_t)N * Ho * Wo, CoP, KH * KW * CiP, 32), b = plan_splits2d((int64_t)N * Ho * Wo, CoP, KH * KW * CiP, 128);
   int splits = a.splits > b.splits ? a.splits : b.splits;
   if (KH == 3 && KW == 3 && pcrl_wgrad_brick2d_eligible(N, Ho, Wo, CiP, CoP, PCRL_BF16)) {
     const int c = pcrl_wgrad_brick2d_splits(N, Ho, Wo, CiP, CoP);
+    if (c > splits) splits = c;
+  }
+  if (KH == 3 && KW == 3 && pcrl_wgrad2d_narrow_eligible(N, Ho, Wo, CiP, CoP, PCRL_BF16)) {
+    const int c = pcrl_wgrad2d_narrow_slabs(N, Ho, Wo);
     if (c > splits) splits = c;
   }
   return (size_t)splits * KH * KW * CoP * CiP * sizeof(float);
@@ -950,6 +973,14 @@ extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, v
   PCRL_REQUIRE(KH >= 1 && KW >= 1 && KH * KW <= 49 && stride >= 1 && pad >= 0, "conv2d_wgrad: bad kernel geometry");
   PCRL_REQUIRE(dtype == PCRL_BF16 || dtype == PCRL_F32, "conv2d_wgrad: bad dtype %d", dtype);
   const int taps = KH * KW, Cv = taps * CiP;
+  if (g_wgrad_impl == 0 && g_wgrad_tr && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (up ? (2 * Hi == Ho && 2 * Wi == Wo) : (Hi == Ho && Wi == Wo)) &&
+      pcrl_wgrad2d_narrow_eligible(N, Ho, Wo, CiP, CoP, dtype)) {
+    const int slabs = pcrl_wgrad2d_narrow_slabs(N, Ho, Wo);
+    const size_t need = (size_t)slabs * 9 * CoP * CiP * sizeof(float);
+    if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+    if (int e = pcrl_wgrad2d_narrow_launch(x, dy, (float*)ws, N, Ho, Wo, CiP, CoP, up, as_stream(stream))) return e;
+    return launch_wgrad2d_reduce((const float*)ws, dw_ref, slabs, 9, CoP, CiP, Ci_out, as_stream(stream));
+  }
   if (g_wgrad_impl == 0 && g_wgrad_tr && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !up && Hi == Ho && Wi == Wo &&
       pcrl_wgrad_brick2d_eligible(N, Ho, Wo, CiP, CoP, dtype)) {
     const int splits = pcrl_wgrad_brick2d_splits(N, Ho, Wo, CiP, CoP);
@@ -976,8 +1007,5 @@ extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, v
     hipLaunchKernelGGL((wgrad_kernel<float, WG_CONV2D, false>), grid, dim3(256), 4 * 32 * 256, st, p);
   }
   if (int e = pcrl_check_launch("conv2d_wgrad")) return e;
-  const int64_t total = (int64_t)CoP * taps * Ci_out;
-  const unsigned blocks = (unsigned)((total + 63) / 64);
-  hipLaunchKernelGGL(wgrad2d_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)ws, dw_ref, sp.splits, taps, CoP, CiP, Ci_out);
-  return pcrl_check_launch("conv2d_wgrad_reduce");
+  return launch_wgrad2d_reduce((const float*)ws, dw_ref, sp.splits, taps, CoP, CiP, Ci_out, st);
 }

@@ -35,6 +35,12 @@ GEOMS = [  # Ci, Co, K, stride, pad, up, H, W, bias
     (32, 16, 3, 1, 1, 1, 8, 12, False),      # decoder conv1 behind the fused nearest x2 upsample
     (16, 16, 3, 1, 1, 0, 16, 16, True),      # deep-supervision conv (bias)
     (512, 256, 3, 1, 1, 1, 2, 2, False),     # first decoder block at the bottleneck
+    (16, 16, 3, 1, 1, 0, 16, 32, True),      # H % 8 == 0, W % 32 == 0: the right-sized narrow weight-gradient kernel (bf16)
+    (32, 16, 3, 1, 1, 1, 8, 16, False),      # ... behind the fused upsample (block 4 conv1)
+    (32, 32, 3, 1, 1, 0, 8, 64, False),      # ... 32 -> 32 (block 3)
+    (16, 32, 3, 1, 1, 0, 24, 32, False),     # ... 16 -> 32
+    (64, 128, 3, 2, 1, 0, 15, 9, False),     # odd extents, stride 2
+    (3, 64, 7, 2, 3, 0, 33, 21, False),      # odd extents, stem
 ]
 
 
