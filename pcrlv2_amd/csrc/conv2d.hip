@@ -387,7 +387,12 @@ bool pcrl_brick_conv2d_eligible(int N, int H, int W, int Ci, int Co, int dtype);
 int64_t pcrl_brick_conv2d_rows(int N, int H, int W);
 int pcrl_brick_conv2d_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Ci, int Co, int up,
                              hipStream_t stream);
-static int g_conv2d_impl = 0;   // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
+// right-sized kernel for layers with <= 32 channels on both sides (conv2d_narrow.hip)
+bool pcrl_conv2d_narrow_eligible(int N, int H, int W, int Cs, int Nc, int ks, int dtype);
+int64_t pcrl_conv2d_narrow_rows(int N, int H, int W);
+int pcrl_conv2d_narrow_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Cs, int Nc, int ks,
+                              int up, int out_f32, hipStream_t stream);
+static int g_conv2d_impl = 0;   // 0 = auto (brick / narrow kernels where eligible), 1 = always the gather kernel
 extern "C" void pcrl_debug_set_conv2d_impl(int impl) { g_conv2d_impl = impl; }
 
 extern "C" int64_t pcrl_conv2d_packed_elems(int rows, int taps, int Cs) {
@@ -424,6 +429,14 @@ extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias,
     }
     return pcrl_brick_conv2d_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, up, as_stream(stream));
   }
+  if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && x && wp && y &&
+      pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype)) {
+    if (stats_partial) {
+      const int64_t rb = pcrl_conv2d_narrow_rows(N, Ho, Wo), rg = pcrl_conv2d_stats_rows(N, Ho, Wo);
+      if (rg > rb) (void)hipMemsetAsync(stats_partial + rb * Co * 2, 0, (size_t)(rg - rb) * Co * 2 * sizeof(float), as_stream(stream));
+    }
+    return pcrl_conv2d_narrow_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, KH, up, out_f32, as_stream(stream));
+  }
   return conv2d_common("conv2d_fwd", C2_FWD, x, wp, bias, y, stats_partial, N, Hi, Wi, CiP, Ho, Wo, Co, KH, KW, stride, pad, up, out_f32, dtype,
                        as_stream(stream));
 }
@@ -434,6 +447,9 @@ extern "C" int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx,
   if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
       pcrl_brick_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype))
     return pcrl_brick_conv2d_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, 0, as_stream(stream));
+  if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
+      pcrl_conv2d_narrow_eligible(N, Hi, Wi, CoP, Ci, KH, dtype))
+    return pcrl_conv2d_narrow_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, KH, 0, 0, as_stream(stream));
   return conv2d_common("conv2d_dgrad", C2_DGRAD, dy, wp_dgrad, nullptr, dx, nullptr, N, Ho, Wo, CoP, Hi, Wi, Ci, KH, KW, stride, pad, 0, 0, dtype,
                        as_stream(stream));
 }

@@ -1,0 +1,196 @@
+// Forward / data gradient of the NARROW stride-1 convolutions of the 2D path (source and output channels <= 32: decoder block 4 of
+// models/pcrlv2_model.py at full resolution, its deep-supervision head, the 16 -> 3 heads and their 3 -> 16 data gradients), bf16.
+//
+//   y[px][co] = b[co] + sum_{tap, c} x[px + delta_tap][c] * w[co][tap][c]        (x optionally read through a nearest x2 upsample)
+//
+// The gather kernel (conv2d.hip) re-reads every input pixel once per tap from L2 (9x amplification: 5.4 GB of L2 traffic per
+// 512^2 x 64-image launch) and runs 131 072 blocks of a few hundred MFMA cycles each: 0.75 ms where HBM needs 0.2 ms.  Here a
+// block owns an 8 x 32-pixel patch: the patch plus its one-pixel halo (10 x 34 pixels x CS channels) is staged in LDS once,
+// the whole weight matrix lives in REGISTERS as B fragments (<= 2 x 9 fragments), and an A fragment is a plain 16-byte LDS read
+// per lane: lane (pixel lr, k-group lg) of K-step s reads channels c..c+7 of tap (s*32 + lg*8) / CS at its pixel's shifted halo
+// position -- K-steps straddle taps for CS = 8 / 16 exactly as in the gather kernel (same packed weights, k = tap * CS + c).
+// Wave = 64 pixels (two patch rows) x NF * 16 output channels.  Epilogue: + bias, bf16 or float32 store (columns >= Nc masked),
+// one (sum, sum^2) statistics row per patch for the BatchNorm2d that follows.  The stride-1 data gradient is the same kernel
+// on the tap-flipped packed weights.
+#include "common.h"
+
+namespace {
+
+constexpr int PH = 8, PW = 32, HPH = PH + 2, HPW = PW + 2;
+constexpr int NPX = PH * PW, NHP = HPH * HPW;   // 256 patch pixels, 340 halo pixels
+
+struct NarrowConvParams {
+  const bf16* x;      // [N][Hs][Ws][CS]
+  const bf16* w;      // packed [32][Kpad], k = tap * CS + c
+  const float* bias;  // [Nc] or null
+  void* y;            // [N][H][W][Nc] bf16, or float when out_f32
+  float* stats;       // [patches][Nc][2] or null
+  int N, H, W, up;
+  int Nc, out_f32;
+  int ks;             // 1 (pad 0) or 3 (pad 1)
+  int Ktot, Kpad;
+};
+
+template <int CS, int NF, int NS>   // source channels (8/16/32), output fragments (Nc <= 16 * NF), K-steps (Kpad / 32)
+__global__ void __launch_bounds__(256) conv2d_narrow_kernel(const NarrowConvParams p) {
+  constexpr int VPC = CS / 8;
+  constexpr int XPIECES = NHP * VPC, XP = (XPIECES + 255) / 256;
+  constexpr int CSH = CS == 8 ? 3 : (CS == 16 ? 4 : 5);
+  __shared__ __attribute__((aligned(16))) char xS[NHP * CS * 2];
+  __shared__ float red[4][NF * 16][2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int pw = p.W / PW, ph = p.H / PH;
+  const int Hs = p.up ? p.H >> 1 : p.H, Ws = p.up ? p.W >> 1 : p.W;
+  int t_ = blockIdx.x;
+  const int w0 = (t_ % pw) * PW; t_ /= pw;
+  const int h0 = (t_ % ph) * PH; t_ /= ph;
+  const int n = t_;
+
+  // ---- stage the halo: unconditional loads from clamped addresses, zero-fill at the LDS store ----
+  u32x4 rx[XP];
+  uint32_t xok = 0;
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int q = tid + 256 * i;
+    const int hp = q / VPC, pc = q % VPC;
+    const int hr = hp / HPW, hc = hp % HPW;
+    int h = h0 + hr - 1, w = w0 + hc - 1;
+    const bool ok = q < XPIECES && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+    if (p.up) {
+      h >>= 1;
+      w >>= 1;
+    }
+    const int64_t row = ok ? ((int64_t)n * Hs + h) * Ws + w : (int64_t)0;
+    rx[i] = *reinterpret_cast<const u32x4*>(p.x + row * CS + (ok ? pc * 8 : 0));
+    xok |= (uint32_t)ok << i;
+  }
+  // ---- weights: B fragments straight into registers (row co = nf * 16 + lr, k = s * 32 + lg * 8) ----
+  bf16x8 fb[NF][NS];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fb[nf][s] = *reinterpret_cast<const bf16x8*>(p.w + (int64_t)(nf * 16 + lr) * p.Kpad + s * 32 + lg * 8);
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int q = tid + 256 * i;
+    if (q < XPIECES) *reinterpret_cast<u32x4*>(xS + q * 16) = keep_if((xok >> i) & 1u, rx[i]);
+  }
+  // ---- per-lane byte offsets: K-step part (tap of this lane's k-group) and pixel part ----
+  int koff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int k = s * 32 + lg * 8;
+    int tap = k >> CSH;
+    const int c = k & (CS - 1);
+    const int ntap = p.ks * p.ks;
+    if (tap >= ntap) tap = ntap - 1;                       // K padding: the weights are zero there, any finite operand will do
+    const int kh = p.ks == 3 ? tap / 3 : 1, kw = p.ks == 3 ? tap - (tap / 3) * 3 : 1;   // 1x1: the centre of the halo
+    koff[s] = ((kh * HPW + kw) * CS + c) * 2;
+  }
+  int poff[4];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf) {
+    const int px = wid * 64 + mf * 16 + lr;
+    poff[mf] = (((px >> 5) * HPW) + (px & 31)) * CS * 2;
+  }
+  __syncthreads();
+
+  f32x4 acc[4][NF];
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    bf16x8 fa[4];
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) fa[mf] = *reinterpret_cast<const bf16x8*>(xS + poff[mf] + koff[s]);
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mf], fb[nf][s], acc[mf][nf], 0, 0, 0);
+  }
+
+  // ---- epilogue: lane holds pixels wid*64 + mf*16 + lg*4 + r, channel nf*16 + lr ----
+  float s1[NF], s2[NF], bv[NF];
+  bool cok[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int co = nf * 16 + lr;
+    cok[nf] = co < p.Nc;
+    bv[nf] = (p.bias && cok[nf]) ? p.bias[co] : 0.f;
+    s1[nf] = s2[nf] = 0.f;
+  }
+  bf16* __restrict__ Y = reinterpret_cast<bf16*>(p.y);
+  float* __restrict__ Yf = reinterpret_cast<float*>(p.y);
+#pragma unroll
+  for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int px = wid * 64 + mf * 16 + lg * 4 + r;
+      const int64_t row = ((int64_t)n * p.H + h0 + (px >> 5)) * p.W + w0 + (px & 31);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        if (cok[nf]) {
+          const float v = acc[mf][nf][r] + bv[nf];
+          const int64_t o = row * p.Nc + nf * 16 + lr;
+          if (p.out_f32) Yf[o] = v;
+          else Y[o] = (bf16)v;
+          s1[nf] += v;
+          s2[nf] += v * v;
+        }
+      }
+    }
+  if (p.stats) {
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      float a = s1[nf], b = s2[nf];
+      a += __shfl_xor(a, 16, 64);
+      b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (lg == 0) {
+        red[wid][nf * 16 + lr][0] = a;
+        red[wid][nf * 16 + lr][1] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < NF * 16 && tid < p.Nc) {
+      float* o = p.stats + ((int64_t)blockIdx.x * p.Nc + tid) * 2;
+      o[0] = (red[0][tid][0] + red[1][tid][0]) + (red[2][tid][0] + red[3][tid][0]);
+      o[1] = (red[0][tid][1] + red[1][tid][1]) + (red[2][tid][1] + red[3][tid][1]);
+    }
+  }
+}
+
+template <int CS, int NF> int launch_ns(const NarrowConvParams& p, unsigned blocks, hipStream_t st) {
+  constexpr int NS3 = CS == 8 ? 3 : (CS == 16 ? 5 : 9);   // K-steps of the 3x3 kernel; the 1x1 kernel has one
+  const int ns = p.Kpad / 32;
+  if (ns == 1) hipLaunchKernelGGL((conv2d_narrow_kernel<CS, NF, 1>), dim3(blocks), dim3(256), 0, st, p);
+  else if (ns == NS3) hipLaunchKernelGGL((conv2d_narrow_kernel<CS, NF, NS3>), dim3(blocks), dim3(256), 0, st, p);
+  else return pcrl_fail(PCRL_EINVAL, "conv2d_narrow: unsupported K (%d steps)", ns);
+  return pcrl_check_launch("conv2d_narrow");
+}
+
+}  // namespace
+
+// ---- internal interface used by conv2d.hip ---------------------------------------------------------------------------------------
+// H, W: output (= logical input) dims; Cs: source channels as stored; Nc: output channels.
+bool pcrl_conv2d_narrow_eligible(int N, int H, int W, int Cs, int Nc, int ks, int dtype) {
+  if (dtype != PCRL_BF16 || !(Cs == 8 || Cs == 16 || Cs == 32) || Nc < 1 || Nc > 32 || !(ks == 1 || ks == 3)) return false;
+  if (H % PH || W % PW || (int64_t)N * H * W * 32 >= ((int64_t)1 << 40)) return false;
+  return true;
+}
+int64_t pcrl_conv2d_narrow_rows(int N, int H, int W) { return (int64_t)N * (H / PH) * (W / PW); }
+
+int pcrl_conv2d_narrow_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Cs, int Nc, int ks,
+                              int up, int out_f32, hipStream_t stream) {
+  NarrowConvParams p{(const bf16*)x, (const bf16*)wp, bias, y, stats, N, H, W, up, Nc, out_f32, ks, ks * ks * Cs, (ks * ks * Cs + 31) / 32 * 32};
+  const unsigned blocks = (unsigned)pcrl_conv2d_narrow_rows(N, H, W);
+  const bool two = Nc > 16;
+  if (Cs == 8) return two ? launch_ns<8, 2>(p, blocks, stream) : launch_ns<8, 1>(p, blocks, stream);
+  if (Cs == 16) return two ? launch_ns<16, 2>(p, blocks, stream) : launch_ns<16, 1>(p, blocks, stream);
+  return two ? launch_ns<32, 2>(p, blocks, stream) : launch_ns<32, 1>(p, blocks, stream);
+}

@@ -78,11 +78,12 @@ def test_conv2d_fwd_dgrad_wgrad(geom, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("W", [24, 32])      # W % 32 == 0 (bf16): the right-sized narrow kernel, else the gather kernel
 @pytest.mark.parametrize("K,Ci", [(1, 16), (3, 16)])
-def test_conv2d_to3_float_output(K, Ci, dt):
+def test_conv2d_to3_float_output(K, Ci, W, dt):
     """deep_supervision_head.3 (1x1 -> 3) and the segmentation head (3x3 -> 3): float32 output, 3-channel gradient padded to 8"""
     from pcrlv2_amd import ops2d
-    N, H, W, Co = 2, 16, 24, 3
+    N, H, Co = 2, 16, 3
     g = torch.Generator().manual_seed(K)
     x = torch.randn(N, Ci, H, W, generator=g)
     w = torch.randn(Co, Ci, K, K, generator=g) / (Ci * K * K) ** 0.5
