@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) wgrad2d_narrow_kernel(const NarrowParams 
   constexpr int UPC = CU / 8, VPC = CV / 8;                   // 16-byte pieces per pixel
   constexpr int DYP = NPX * UPC / 256;                        // dy pieces per thread: 2 / 4
   constexpr int XPIECES = NHP * VPC, XP = (XPIECES + 255) / 256;   // 680 / 1360 -> 3 / 6 per thread
-  constexpr int FA = CU / 16, FB = CV / 16;
+  constexpr int FA = CU >= 16 ? CU / 16 : 1, FB = CV / 16;   // CU = 8 (3-channel heads, padded): one fragment whose rows 8..15 are never stored
   constexpr int DY_BYTES = NPX * CU * 2, X_BYTES = NHP * CV * 2;
   __shared__ __attribute__((aligned(16))) char smem[DY_BYTES + X_BYTES];
   char* dyS = smem;
@@ -136,7 +136,10 @@ __global__ void __launch_bounds__(256) wgrad2d_narrow_kernel(const NarrowParams 
 #pragma unroll
       for (int b = 0; b < FB; ++b)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(a * 16 + (lane >> 4) * 4 + r) * (9 * CV) + t * CV + b * 16 + (lane & 15)] = acc[a][t][b][r];
+        for (int r = 0; r < 4; ++r) {
+          const int i = a * 16 + (lane >> 4) * 4 + r;
+          if (i < CU) out[i * (9 * CV) + t * CV + b * 16 + (lane & 15)] = acc[a][t][b][r];
+        }
 }
 
 struct NarrowPlan {
@@ -153,7 +156,7 @@ NarrowPlan narrow_plan(int npatch) {
 // ---- internal interface used by conv_wgrad.hip ---------------------------------------------------------------------------------
 // H, W: OUTPUT (= logical input) dims.
 bool pcrl_wgrad2d_narrow_eligible(int N, int H, int W, int CiP, int CoP, int dtype) {
-  return dtype == PCRL_BF16 && (CiP == 16 || CiP == 32) && (CoP == 16 || CoP == 32) && H % PH == 0 && W % PW == 0 &&
+  return dtype == PCRL_BF16 && (CiP == 16 || CiP == 32) && (CoP == 8 || CoP == 16 || CoP == 32) && H % PH == 0 && W % PW == 0 &&
          (int64_t)N * H * W * 32 < ((int64_t)1 << 40);
 }
 int pcrl_wgrad2d_narrow_slabs(int N, int H, int W) { return 4 * narrow_plan((int)((int64_t)N * (H / PH) * (W / PW))).blocks; }
@@ -163,7 +166,9 @@ int pcrl_wgrad2d_narrow_launch(const void* x, const void* dy, float* ws, int N, 
   const NarrowPlan pl = narrow_plan(npatch);
   const int blocks = pl.blocks;
   NarrowParams p{(const bf16*)dy, (const bf16*)x, ws, N, H, W, up, npatch, pl.per};
-  if (CoP == 16 && CiP == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, p);
+  if (CoP == 8 && CiP == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<8, 16>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (CoP == 8) hipLaunchKernelGGL((wgrad2d_narrow_kernel<8, 32>), dim3(blocks), dim3(256), 0, stream, p);
+  else if (CoP == 16 && CiP == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, p);
   else if (CoP == 16 && CiP == 32) hipLaunchKernelGGL((wgrad2d_narrow_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, p);
   else if (CoP == 32 && CiP == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<32, 16>), dim3(blocks), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL((wgrad2d_narrow_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, p);
