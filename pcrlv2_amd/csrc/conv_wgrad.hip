@@ -942,7 +942,7 @@ static int conv2d_wgrad_ks(int dtype) { return (dtype == PCRL_BF16 && g_wgrad_tr
 // LDS-halo brick kernel with the image index as depth (wgrad_brick.hip, nkd = 1)
 bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype);
 int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co);
-int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, hipStream_t stream);
+int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, int up, hipStream_t stream);
 
 // right-sized kernel for the 16/32-channel layers (wgrad2d_narrow.hip)
 bool pcrl_wgrad2d_narrow_eligible(int N, int H, int W, int CiP, int CoP, int dtype);
@@ -981,12 +981,12 @@ extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, v
     if (int e = pcrl_wgrad2d_narrow_launch(x, dy, (float*)ws, N, Ho, Wo, CiP, CoP, up, as_stream(stream))) return e;
     return launch_wgrad2d_reduce((const float*)ws, dw_ref, slabs, 9, CoP, CiP, Ci_out, as_stream(stream));
   }
-  if (g_wgrad_impl == 0 && g_wgrad_tr && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !up && Hi == Ho && Wi == Wo &&
+  if (g_wgrad_impl == 0 && g_wgrad_tr && KH == 3 && KW == 3 && stride == 1 && pad == 1 && (up ? (2 * Hi == Ho && 2 * Wi == Wo) : (Hi == Ho && Wi == Wo)) &&
       pcrl_wgrad_brick2d_eligible(N, Ho, Wo, CiP, CoP, dtype)) {
     const int splits = pcrl_wgrad_brick2d_splits(N, Ho, Wo, CiP, CoP);
     const size_t need = (size_t)splits * 9 * CoP * CiP * sizeof(float);
     if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
-    if (int e = pcrl_wgrad_brick2d_launch(x, dy, (float*)ws, N, Ho, Wo, CiP, CoP, as_stream(stream))) return e;
+    if (int e = pcrl_wgrad_brick2d_launch(x, dy, (float*)ws, N, Ho, Wo, CiP, CoP, up, as_stream(stream))) return e;
     const int blocks = (int)(((int64_t)CoP * Ci_out + RED_IJ - 1) / RED_IJ);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)ws, dw_ref, splits, 9, CoP, CiP, Ci_out);
     return pcrl_check_launch("wgrad_reduce");

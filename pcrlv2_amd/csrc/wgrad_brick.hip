@@ -37,6 +37,7 @@ struct WBrickParams {
   int N, D, H, W;
   int Cu, Cv;
   int nbricks, per_split;
+  int up;           // nkd = 1 only: x is [D][H/2][W/2][Cv] read through a nearest x2 upsample (decoder conv1 of the 2D path)
   int nkd;          // 3: the 3x3x3 convolution (blockIdx.y = tile * 3 + kd); 1: a 3x3 convolution over a stack of images (2D path:
                     // the image index is d and only the centre plane kd = 1 exists; slabs hold 9 taps)
 };
@@ -69,6 +70,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
   const int b_beg = blockIdx.x * p.per_split;
   const int b_end = min(b_beg + p.per_split, p.nbricks);
   const int bw = p.W / BW, bh = p.H / BH, bd = p.D / BD;
+  const int Hs = p.up ? p.H >> 1 : p.H, Ws = p.up ? p.W >> 1 : p.W;   // extents of x as stored
 
   f32x4 acc[9][4];
 #pragma unroll
@@ -96,12 +98,14 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
     const int r = (tid >> 3) + 32 * i;
     const int hd = r / (XH * XW), hh = (r / XW) % XH, hw = r % XW;
     const bool row_ok = r < XROWS && hw < BW + 2;
-    xoff[i] = row_ok ? (uint32_t)(((hd * p.H + hh) * p.W + hw) * p.Cv + xcol) * 2u : 0u;
+    // upsampled source: brick origins are even, so halo row hh maps to source row (h0/2 - 1) + ((hh + 1) >> 1): still a fixed offset
+    const int shh = p.up ? (hh + 1) >> 1 : hh, shw = p.up ? (hw + 1) >> 1 : hw;
+    xoff[i] = row_ok ? (uint32_t)(((hd * Hs + shh) * Ws + shw) * p.Cv + xcol) * 2u : 0u;
     xedge[i] = (hd == 0 ? 1u : 0u) | (hd == BD - 1 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == XH - 1 ? 8u : 0u) | (hw == 0 ? 16u : 0u) |
                (hw == BW + 1 ? 32u : 0u) | (row_ok && jcol_ok ? 0u : 64u);
   }
   // a halo row that is inside the volume for every brick: (hd = 1 for kd = 0, else 0 ; hh = 1 ; hw = 1)
-  const uint32_t xsafe = (uint32_t)((((kd == 0 ? 1 : 0) * p.H + 1) * p.W + 1) * p.Cv + xcol) * 2u;
+  const uint32_t xsafe = (uint32_t)((((kd == 0 ? 1 : 0) * Hs + 1) * Ws + 1) * p.Cv + xcol) * 2u;
   u32x4 rdy[DYP], rx[XP];
 
   // Staging pipeline (two LDS brick buffers): while brick b is multiplied out of one buffer, the registers hold brick b+1.
@@ -123,7 +127,8 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
     const int64_t base0 = (((int64_t)n * p.D + d0) * p.H + h0) * p.W + w0;                                   \
     dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                           \
     /* first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
-    xb = reinterpret_cast<const char*>(p.x + (base0 + ((int64_t)(kd - 1) * p.H - 1) * p.W - 1) * p.Cv);      \
+    const int64_t xbase0 = p.up ? (((int64_t)n * p.D + d0) * Hs + (h0 >> 1)) * Ws + (w0 >> 1) : base0;       \
+    xb = reinterpret_cast<const char*>(p.x + (xbase0 + ((int64_t)(kd - 1) * Hs - 1) * Ws - 1) * p.Cv);      \
     /* faces of this brick's halo that stick out of the volume (BD = 2: the d faces are the two planes) */    \
     xout = (d0 + kd - 1 < 0 ? 1u : 0u) | (d0 + kd - 1 + BD - 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |      \
            (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;            \
@@ -286,7 +291,7 @@ int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int
   }
   const int nbricks = (int)((int64_t)N * D * H * W / BV);
   const BrickSplit sp = plan(nbricks, Co, Ci);
-  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 3};
+  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 0, 3};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64) * 3));
   hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(256), lds, stream, p);
   return pcrl_check_launch("wgrad_brick");
@@ -299,7 +304,7 @@ bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype)
          (int64_t)N * H * W * (Ci > Co ? Ci : Co) < ((int64_t)1 << 31);
 }
 int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co) { return plan((int)((int64_t)N * H * W / BV), Co, Ci, 1).splits; }
-int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, hipStream_t stream) {
+int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, int up, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds = 2 * BUF_BYTES;
   if (!attr_set) {
@@ -308,7 +313,7 @@ int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, i
   }
   const int nbricks = (int)((int64_t)N * H * W / BV);
   const BrickSplit sp = plan(nbricks, Co, Ci, 1);
-  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, 1};
+  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, up, 1};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64)));
   hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(256), lds, stream, p);
   return pcrl_check_launch("wgrad_brick2d");
