@@ -23,6 +23,7 @@ struct NarrowParams {
   float* ws;        // [blocks * 4][CU][9 * CV]
   int N, H, W, up;
   int npatch, per;
+  int xpitch, cbase;   // x row pitch in channels (CiP) and the first of the CV input channels this launch handles (CiP = 64: two launches)
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(256) wgrad2d_narrow_kernel(const NarrowParams 
         w >>= 1;                                                                                            \
       }                                                                                                     \
       const int64_t row = ok ? ((int64_t)n * Hs + h) * Ws + w : (int64_t)0;                                 \
-      rx[i] = *reinterpret_cast<const u32x4*>(p.x + row * CV + (ok ? pc * 8 : 0));                          \
+      rx[i] = *reinterpret_cast<const u32x4*>(p.x + row * p.xpitch + p.cbase + (ok ? pc * 8 : 0));         \
       xok |= (uint32_t)ok << i;                                                                             \
     }                                                                                                       \
   } while (0)
@@ -128,7 +129,7 @@ __global__ void __launch_bounds__(256) wgrad2d_narrow_kernel(const NarrowParams 
 #undef NW_STORE
 
   // D[i][j]: lane holds i = 16 a + 4 (lane >> 4) + r (co), j = 16 b + (lane & 15) (ci) of tap t
-  float* out = p.ws + ((int64_t)blockIdx.x * 4 + wid) * (CU * 9 * CV);
+  float* out = p.ws + ((int64_t)blockIdx.x * 4 + wid) * (CU * 9 * p.xpitch) + p.cbase;
 #pragma unroll
   for (int a = 0; a < FA; ++a)
 #pragma unroll
@@ -138,7 +139,7 @@ __global__ void __launch_bounds__(256) wgrad2d_narrow_kernel(const NarrowParams 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = a * 16 + (lane >> 4) * 4 + r;
-          if (i < CU) out[i * (9 * CV) + t * CV + b * 16 + (lane & 15)] = acc[a][t][b][r];
+          if (i < CU) out[i * (9 * p.xpitch) + t * p.xpitch + b * 16 + (lane & 15)] = acc[a][t][b][r];
         }
 }
 
@@ -156,7 +157,7 @@ NarrowPlan narrow_plan(int npatch) {
 // ---- internal interface used by conv_wgrad.hip ---------------------------------------------------------------------------------
 // H, W: OUTPUT (= logical input) dims.
 bool pcrl_wgrad2d_narrow_eligible(int N, int H, int W, int CiP, int CoP, int dtype) {
-  return dtype == PCRL_BF16 && (CiP == 16 || CiP == 32) && (CoP == 8 || CoP == 16 || CoP == 32) && H % PH == 0 && W % PW == 0 &&
+  return dtype == PCRL_BF16 && (CiP == 16 || CiP == 32 || CiP == 64) && (CoP == 8 || CoP == 16 || CoP == 32) && H % PH == 0 && W % PW == 0 &&
          (int64_t)N * H * W * 32 < ((int64_t)1 << 40);
 }
 int pcrl_wgrad2d_narrow_slabs(int N, int H, int W) { return 4 * narrow_plan((int)((int64_t)N * (H / PH) * (W / PW))).blocks; }
@@ -165,12 +166,15 @@ int pcrl_wgrad2d_narrow_launch(const void* x, const void* dy, float* ws, int N, 
   const int npatch = (int)((int64_t)N * (H / PH) * (W / PW));
   const NarrowPlan pl = narrow_plan(npatch);
   const int blocks = pl.blocks;
-  NarrowParams p{(const bf16*)dy, (const bf16*)x, ws, N, H, W, up, npatch, pl.per};
-  if (CoP == 8 && CiP == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<8, 16>), dim3(blocks), dim3(256), 0, stream, p);
-  else if (CoP == 8) hipLaunchKernelGGL((wgrad2d_narrow_kernel<8, 32>), dim3(blocks), dim3(256), 0, stream, p);
-  else if (CoP == 16 && CiP == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, p);
-  else if (CoP == 16 && CiP == 32) hipLaunchKernelGGL((wgrad2d_narrow_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, p);
-  else if (CoP == 32 && CiP == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<32, 16>), dim3(blocks), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((wgrad2d_narrow_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, p);
+  for (int cbase = 0; cbase < CiP; cbase += 32) {   // 64 input channels: two launches of the 32-channel kernel on disjoint columns of the same slabs
+    const int cv = CiP - cbase < 32 ? CiP - cbase : 32;
+    NarrowParams p{(const bf16*)dy, (const bf16*)x, ws, N, H, W, up, npatch, pl.per, CiP, cbase};
+    if (CoP == 8 && cv == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<8, 16>), dim3(blocks), dim3(256), 0, stream, p);
+    else if (CoP == 8) hipLaunchKernelGGL((wgrad2d_narrow_kernel<8, 32>), dim3(blocks), dim3(256), 0, stream, p);
+    else if (CoP == 16 && cv == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<16, 16>), dim3(blocks), dim3(256), 0, stream, p);
+    else if (CoP == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<16, 32>), dim3(blocks), dim3(256), 0, stream, p);
+    else if (cv == 16) hipLaunchKernelGGL((wgrad2d_narrow_kernel<32, 16>), dim3(blocks), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((wgrad2d_narrow_kernel<32, 32>), dim3(blocks), dim3(256), 0, stream, p);
+  }
   return pcrl_check_launch("wgrad2d_narrow");
 }
