@@ -140,7 +140,7 @@ class PackedWeights:
 # ----------------------------------------------------------------------------------------------
 def bn_finalize(partial, rows, C, count, gamma, beta, running_mean, running_var):
     dev = partial.device
-    if rows > 20000:
+    if rows > 20000 and C % 2 == 0:
         # full-resolution 2D layers leave > 100 000 statistics rows for as few as 16 channels: pcrl_bn_finalize runs one block per
         # channel, so the rows are first summed by the tiled column-sum kernels (chip-wide, coalesced)
         L = lib()
