@@ -17,6 +17,10 @@
 // partial slabs are reduced in fixed order by the same second pass as the gather kernel.
 #include "common.h"
 
+#ifndef WB_PF
+#define WB_PF 3
+#endif
+
 namespace {
 
 constexpr int BD = 2, BH = 8, BW = 8;
@@ -201,11 +205,12 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
 #define WB_XR(kc_, t_) ((((kc_) >> 1) * XH + ((kc_)&1) * 4 + (t_) / 3) * XW + (t_) % 3)
 #define WB_XADDR(r_) (xs + xbase[((r_)&7) < 3 ? ((r_)&7) : ((r_)&7) - 1] + (r_)*128)
 #define WB_B(kc_, t_) tr_frag(WB_XADDR(WB_XR(kc_, t_)), WB_XADDR(WB_XR(kc_, t_) + 4))
-    bf16x8 fa[2][4], fbr[3];   // fbr: 3-deep ring, the x fragment is fetched TWO steps (8 MFMAs, ~130 cycles) ahead of its use
+    constexpr int PF = WB_PF;  // the x fragment is fetched PF steps (4 PF MFMAs) ahead of its use, through a (PF + 1)-deep register ring
+    bf16x8 fa[2][4], fbr[PF + 1];
 #pragma unroll
     for (int f = 0; f < 4; ++f) fa[0][f] = WB_A(0, f);
-    fbr[0] = WB_B(0, 0);
-    fbr[1] = WB_B(0, 1);
+#pragma unroll
+    for (int q = 0; q < PF; ++q) fbr[q] = WB_B(q / 9, q % 9);
 #pragma unroll
     for (int st = 0; st < 36; ++st) {
       const int kc = st / 9, t = st % 9;
@@ -213,14 +218,14 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
         WB_STORE_PIECE(st / 3, nxt);
         WB_LOAD_PIECE(st / 3);
       }
-      if (st + 2 < 36) fbr[(st + 2) % 3] = WB_B((st + 2) / 9, (st + 2) % 9);
+      if (st + PF < 36) fbr[(st + PF) % (PF + 1)] = WB_B((st + PF) / 9, (st + PF) % 9);
       if (t == 4 && kc < 3) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) fa[(kc + 1) & 1][f] = WB_A(kc + 1, f);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this step's MFMAs (hipcc sinks them next to their use otherwise)
 #pragma unroll
-      for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st % 3], acc[t][f], 0, 0, 0);
+      for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st % (PF + 1)], acc[t][f], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef WB_A
