@@ -121,13 +121,35 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
   const char* xb = nullptr;
   uint32_t xout = 0;
   uint32_t xvalid_w = 0, xvalid_l = 0;   // validity bits of the x pieces in registers (being written) / being loaded
-#define WB_ORIGIN(b_)                                                                                        \
+  // Brick coordinates are CARRIED from brick to brick (the bricks a block originates are consecutive): decoding them with
+  // three divisions and three remainders per brick sat in front of the MFMA steps, unhidden (one wave per SIMD issues in order).
+  int ob = b_beg, ow0, oh0, od0, on;
+  {
+    int t_ = b_beg;
+    ow0 = (t_ % bw) * BW; t_ /= bw;
+    oh0 = (t_ % bh) * BH; t_ /= bh;
+    od0 = (t_ % bd) * BD; t_ /= bd;
+    on = t_;
+  }
+#define WB_ORIGIN_NEXT()                                                                                     \
   do {                                                                                                       \
-    int t_ = (b_);                                                                                           \
-    const int w0 = (t_ % bw) * BW; t_ /= bw;                                                                 \
-    const int h0 = (t_ % bh) * BH; t_ /= bh;                                                                 \
-    const int d0 = (t_ % bd) * BD; t_ /= bd;                                                                 \
-    const int n = t_;                                                                                        \
+    const int w0 = ow0, h0 = oh0, d0 = od0, n = on;                                                          \
+    if (ob + 1 < b_end) { /* advance to the next brick; the last one is repeated (its loads are unused) */   \
+      ++ob;                                                                                                  \
+      ow0 += BW;                                                                                             \
+      if (ow0 == p.W) {                                                                                      \
+        ow0 = 0;                                                                                             \
+        oh0 += BH;                                                                                           \
+        if (oh0 == p.H) {                                                                                    \
+          oh0 = 0;                                                                                           \
+          od0 += BD;                                                                                         \
+          if (od0 == p.D) {                                                                                  \
+            od0 = 0;                                                                                         \
+            ++on;                                                                                            \
+          }                                                                                                  \
+        }                                                                                                    \
+      }                                                                                                      \
+    }                                                                                                        \
     const int64_t base0 = (((int64_t)n * p.D + d0) * p.H + h0) * p.W + w0;                                   \
     dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                           \
     /* first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
@@ -172,13 +194,13 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
   }
 
   if (b_beg < b_end) {
-    WB_ORIGIN(b_beg);
+    WB_ORIGIN_NEXT();                                     // brick b_beg
 #pragma unroll
     for (int i = 0; i < DYP + XP; ++i) WB_LOAD_PIECE(i);
     xvalid_w = xvalid_l;
 #pragma unroll
     for (int i = 0; i < DYP + XP; ++i) WB_STORE_PIECE(i, smem);
-    WB_ORIGIN(b_beg + 1 < b_end ? b_beg + 1 : b_beg);   // registers <- brick b_beg + 1
+    WB_ORIGIN_NEXT();                                     // registers <- brick b_beg + 1 (or b_beg again)
 #pragma unroll
     for (int i = 0; i < DYP + XP; ++i) WB_LOAD_PIECE(i);
     xvalid_w = xvalid_l;
@@ -189,7 +211,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
     const char* dys = smem + ((b - b_beg) & 1) * BUF_BYTES;
     const char* xs = dys + DY_BYTES;
     char* nxt = smem + (((b - b_beg) & 1) ^ 1) * BUF_BYTES;
-    WB_ORIGIN(b + 2 < b_end ? b + 2 : b_end - 1);        // the brick whose pieces are loaded during this one
+    WB_ORIGIN_NEXT();                                     // brick min(b + 2, b_end - 1): its pieces are loaded during this one
     __builtin_amdgcn_sched_barrier(0);
 
     // 36 steps = 4 K-chunks x 9 taps, fully unrolled and SOFTWARE-PIPELINED: the x fragment of step s+1 (and the dy
@@ -237,7 +259,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
     xvalid_w = xvalid_l;
     __syncthreads();   // this brick's reads and the next brick's stores are complete
   }
-#undef WB_ORIGIN
+#undef WB_ORIGIN_NEXT
 #undef WB_LOAD_PIECE
 #undef WB_STORE_PIECE
 
