@@ -17,8 +17,10 @@
 // partial slabs are reduced in fixed order by the same second pass as the gather kernel.
 #include "common.h"
 
+// x-fragment prefetch distance in steps.  Two waves per SIMD (NG = 2) hide the LDS latency between them: 1 is enough and leaves the
+// kernel at 256 registers without spills (3 spilled 14 registers into the step loop: 690 instead of 1 090 TFLOP/s); NG = 1 wants 3.
 #ifndef WB_PF
-#define WB_PF 3
+#define WB_PF 1
 #endif
 
 namespace {
@@ -29,10 +31,19 @@ constexpr int XH = BH + 2, XW = 12;       // halo extents (w padded 10 -> 12 for
 constexpr int XROWS = BD * XH * XW;       // 240
 constexpr int DY_BYTES = BV * 128;        // 16 KiB
 constexpr int X_BYTES = XROWS * 128;      // 30 KiB
-constexpr int DYP = BV * 8 / 256;         // dy 16-byte pieces per thread (4)
-constexpr int XP = (XROWS * 8 + 255) / 256;  // x pieces per thread (8: 1920 pieces)
+// NG = wave groups per block: every group of 4 waves takes 4 / NG of a brick's four 32-voxel K chunks for ALL 9 taps and keeps its own
+// accumulators (one more partial slab per group).  NG = 2 puts two waves on every SIMD at the same LDS footprint: one wave per SIMD
+// issues in order, and between two MFMAs (16 cycles of pipe) there is room for three other instructions -- exactly what a step needs
+// (transpose reads, staging loads / stores, selects), so any stall showed up as an idle matrix pipe.
+#ifndef WB_NG
+#define WB_NG 2
+#endif
+constexpr int NG = WB_NG, NT = 256 * NG;
+constexpr int DYP = BV * 8 / NT;          // dy 16-byte pieces per thread (4 / 2)
+constexpr int XP = (XROWS * 8 + NT - 1) / NT;  // x pieces per thread (8 / 4: 1920 pieces)
 constexpr int BUF_BYTES = DY_BYTES + X_BYTES;   // one brick buffer: 46 KiB, two of them in LDS
-static_assert(DYP + XP == 12, "one staging piece per three of the 36 steps");
+constexpr int NSTEP = 36 / NG;            // steps per wave and brick (K chunks x taps)
+static_assert((DYP + XP) * 3 == NSTEP, "one staging piece per three steps");
 
 struct WBrickParams {
   const bf16* dy;   // [M][Cu]
@@ -62,10 +73,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
   return u.f;
 }
 
-__global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams p) {
+__global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // two (dy, x halo) brick buffers of BUF_BYTES
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, grp = tid >> 8;
   const int lg = lane >> 4, jr = (lane & 15) >> 2, cq = lane & 3;
   const int ntj = p.Cv / 64 > 0 ? (p.Cv + 63) / 64 : 1;
   const int kd = p.nkd == 3 ? blockIdx.y % 3 : 1;
@@ -94,12 +105,12 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
   uint32_t xedge[XP];              // which faces of the halo the piece's row lies on (bit: d-,d+,h-,h+,w-,w+); bit 6 = not a halo row
 #pragma unroll
   for (int i = 0; i < DYP; ++i) {
-    const int v = (tid >> 3) + 32 * i;
+    const int v = (tid >> 3) + (NT / 8) * i;
     dyoff[i] = (uint32_t)((((v >> 6) * p.H + ((v >> 3) & 7)) * p.W + (v & 7)) * p.Cu + pc * 8) * 2u;
   }
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
-    const int r = (tid >> 3) + 32 * i;
+    const int r = (tid >> 3) + (NT / 8) * i;
     const int hd = r / (XH * XW), hh = (r / XW) % XH, hw = r % XW;
     const bool row_ok = r < XROWS && hw < BW + 2;
     // upsampled source: brick origins are even, so halo row hh maps to source row (h0/2 - 1) + ((hh + 1) >> 1): still a fixed offset
@@ -174,10 +185,10 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
 #define WB_STORE_PIECE(i_, buf_)                                                                             \
   do {                                                                                                       \
     if ((i_) < DYP) {                                                                                        \
-      *reinterpret_cast<u32x4*>((buf_) + dy_off((tid >> 3) + 32 * ((i_) < DYP ? (i_) : 0), pc * 8)) = rdy[(i_) < DYP ? (i_) : 0]; \
+      *reinterpret_cast<u32x4*>((buf_) + dy_off((tid >> 3) + (NT / 8) * ((i_) < DYP ? (i_) : 0), pc * 8)) = rdy[(i_) < DYP ? (i_) : 0]; \
     } else {                                                                                                 \
       const int j_ = (i_) < DYP ? 0 : (i_) - DYP;                                                            \
-      const int r = (tid >> 3) + 32 * j_;                                                                    \
+      const int r = (tid >> 3) + (NT / 8) * j_;                                                              \
       if (r < XROWS) *reinterpret_cast<u32x4*>((buf_) + DY_BYTES + x_off(r, pc * 8)) = keep_if((xvalid_w >> j_) & 1u, rx[j_]); \
     }                                                                                                        \
   } while (0)
@@ -208,8 +219,9 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
   __syncthreads();
 
   for (int b = b_beg; b < b_end; ++b) {
-    const char* dys = smem + ((b - b_beg) & 1) * BUF_BYTES;
-    const char* xs = dys + DY_BYTES;
+    // this wave group's K chunks: chunk kc of the brick = d plane kc >> 1, h half kc & 1; NG = 2: group g owns plane g
+    const char* dys = smem + ((b - b_beg) & 1) * BUF_BYTES + grp * ((4 / NG) * 4096);
+    const char* xs = smem + ((b - b_beg) & 1) * BUF_BYTES + DY_BYTES + grp * ((4 / NG) / 2) * (XH * XW * 128);
     char* nxt = smem + (((b - b_beg) & 1) ^ 1) * BUF_BYTES;
     WB_ORIGIN_NEXT();                                     // brick min(b + 2, b_end - 1): its pieces are loaded during this one
     __builtin_amdgcn_sched_barrier(0);
@@ -234,14 +246,14 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
 #pragma unroll
     for (int q = 0; q < PF; ++q) fbr[q] = WB_B(q / 9, q % 9);
 #pragma unroll
-    for (int st = 0; st < 36; ++st) {
+    for (int st = 0; st < NSTEP; ++st) {
       const int kc = st / 9, t = st % 9;
       if (st % 3 == 0) {   // piece st/3: brick b+1 -> the other LDS buffer, then its register <- brick b+2
         WB_STORE_PIECE(st / 3, nxt);
         WB_LOAD_PIECE(st / 3);
       }
-      if (st + PF < 36) fbr[(st + PF) % (PF + 1)] = WB_B((st + PF) / 9, (st + PF) % 9);
-      if (t == 4 && kc < 3) {
+      if (st + PF < NSTEP) fbr[(st + PF) % (PF + 1)] = WB_B((st + PF) / 9, (st + PF) % 9);
+      if (t == 4 && kc < 4 / NG - 1) {
 #pragma unroll
         for (int f = 0; f < 4; ++f) fa[(kc + 1) & 1][f] = WB_A(kc + 1, f);
       }
@@ -264,7 +276,7 @@ __global__ void __launch_bounds__(256, 1) wgrad_brick_kernel(const WBrickParams 
 #undef WB_STORE_PIECE
 
   // D[i][j]: lane holds i = 16 f + 4 lg + r, j = lane & 15
-  float* out = p.ws + (int64_t)blockIdx.x * (9 * p.nkd) * p.Cu * p.Cv;
+  float* out = p.ws + ((int64_t)blockIdx.x * NG + grp) * (9 * p.nkd) * p.Cu * p.Cv;
   const int j = j0 + wid * 16 + (lane & 15);
   if (j < p.Cv) {
 #pragma unroll
@@ -306,7 +318,7 @@ bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int d
          (int64_t)N * D * H * W / BV < (1 << 30);
 }
 int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co) {
-  return plan((int)((int64_t)N * D * H * W / BV), Co, Ci).splits;
+  return plan((int)((int64_t)N * D * H * W / BV), Co, Ci).splits * NG;   // partial slabs for the second pass
 }
 int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co,
                             hipStream_t stream) {
@@ -320,7 +332,7 @@ int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int
   const BrickSplit sp = plan(nbricks, Co, Ci);
   WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 0, 3};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64) * 3));
-  hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(NT), lds, stream, p);
   return pcrl_check_launch("wgrad_brick");
 }
 
@@ -330,7 +342,7 @@ bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype)
   return dtype == PCRL_BF16 && N % BD == 0 && H % BH == 0 && W % BW == 0 && Co % 64 == 0 && Ci % 32 == 0 && (int64_t)N * H * W / BV < (1 << 30) &&
          (int64_t)N * H * W * (Ci > Co ? Ci : Co) < ((int64_t)1 << 31);
 }
-int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co) { return plan((int)((int64_t)N * H * W / BV), Co, Ci, 1).splits; }
+int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co) { return plan((int)((int64_t)N * H * W / BV), Co, Ci, 1).splits * NG; }
 int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, int up, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds = 2 * BUF_BYTES;
@@ -342,6 +354,6 @@ int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, i
   const BrickSplit sp = plan(nbricks, Co, Ci, 1);
   WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, up, 1};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64)));
-  hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(256), lds, stream, p);
+  hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(NT), lds, stream, p);
   return pcrl_check_launch("wgrad_brick2d");
 }
