@@ -180,9 +180,10 @@ def main():
     traffic, traffic_src = None, None
     try:
         import glob
-        import re
-        # the most recent summary = the one taken at the highest throughput (file names carry it: r01_<step>_<crops/s>cps_pmc.json)
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=lambda q: int((re.search(r"_(\d+)cps_", q) or [0, 0])[1])):
+        # profiles/LATEST_PMC.txt names the summary that belongs to the current kernels; older ones stay as the record of the round
+        latest = os.path.join(ROOT, "profiles", "LATEST_PMC.txt")
+        names = [os.path.join(ROOT, "profiles", open(latest).read().strip())] if os.path.exists(latest) else sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+        for f in names:
             d = json.load(open(f))
             if dom in d:
                 traffic, traffic_src = round(d[dom]["hbm_bytes_per_launch"]), os.path.relpath(f, ROOT)
