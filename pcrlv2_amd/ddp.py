@@ -125,6 +125,8 @@ class DataParallel:
         self._reset_step()
         if self._active and self.overlap:
             Fn.set_ddp_callbacks(self._on_final, self._on_backward_end)
+        else:
+            Fn.set_ddp_callbacks(None, None)     # a wrapper built earlier in this process must not keep receiving callbacks
         self.broadcast_state()
 
     # ------------------------------------------------------------------
