@@ -9,7 +9,6 @@ import torch
 from torch.autograd import Function
 
 from . import ops, ops2d
-from ._lib import ACT_NONE, ACT_RELU
 from .functions import _park, mark_final
 
 
