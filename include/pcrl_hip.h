@@ -249,6 +249,12 @@ int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, f
                     int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream);
 int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH,
                       int KW, int stride, int pad, int dtype, pcrl_stream_t stream);
+/* Stride-2 data gradient without idle taps: the parity classes (a, b) = (ih & 1, iw & 1) of dx are four stride-1 gathers over dy
+ * (3x3/pad 1: 1, 2, 2, 4 taps; 1x1/pad 0: class (0,0) only, the caller zero-fills dx).  Hi, Wi even.  pack_s2: rows round32(Ci),
+ * K = taps(a) * taps(b) * CoP -> pcrl_conv2d_packed_elems(Ci, taps(a) * taps(b), CoP) elements, taps(0) = 1, taps(1) = 2 (3x3). */
+int pcrl_conv2d_pack_s2(const float* w_ref, void* out, int Co, int Ci, int KH, int KW, int CoP, int a, int b, int dtype, pcrl_stream_t stream);
+int pcrl_conv2d_dgrad_s2(const void* dy, const void* wp_class, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH, int KW,
+                         int a, int b, int dtype, pcrl_stream_t stream);
 size_t pcrl_conv2d_wgrad_ws_bytes(int N, int Ho, int Wo, int CiP, int CoP, int KH, int KW);
 int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes, int N, int Hi, int Wi, int CiP, int Ci_out,
                       int Ho, int Wo, int CoP, int KH, int KW, int stride, int pad, int up, int dtype, pcrl_stream_t stream);

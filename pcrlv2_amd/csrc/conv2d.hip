@@ -38,6 +38,8 @@ struct C2Params {
   int stride, pad, up;
   int Ktot, Kpad;
   int out_f32;
+  int placed;          // output row (n, oh, ow) is stored at pixel (oh * 2 + pa, ow * 2 + pb) of an [N][Hf][Wf] tensor (stride-2 data gradient)
+  int pa, pb, Hf, Wf;
   int64_t M;
 };
 
@@ -271,11 +273,18 @@ __global__ void __launch_bounds__(256) conv2d_kernel(const C2Params p) {
     for (int r = 0; r < 4; ++r) {
       const int64_t m = m0 + wm * 64 + i * 16 + lg * 4 + r;
       if (m < p.M) {
+        int64_t orow = m;
+        if (p.placed) {   // block-uniform
+          const int ow = (int)(m % p.Wo);
+          const int64_t t = m / p.Wo;
+          const int oh = (int)(t % p.Ho);
+          orow = ((t / p.Ho) * p.Hf + oh * 2 + p.pa) * p.Wf + ow * 2 + p.pb;
+        }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           if (cok[j]) {
             const float v = acc[i][j][r] + bv[j];
-            const int64_t o = m * p.Nc + n0 + wn * (BN / 2) + j * 16 + lr;
+            const int64_t o = orow * p.Nc + n0 + wn * (BN / 2) + j * 16 + lr;
             if (p.out_f32) Yf[o] = v;
             else Y[o] = from_f<T>(v);
             s1[j] += v;
@@ -331,6 +340,25 @@ __global__ void __launch_bounds__(256) pack_conv2d_kernel(const float* __restric
   }
 }
 
+// Parity-class packing for the stride-2 data gradient (see pcrl_conv2d_dgrad_s2): rows ci, k = (kh' * KWc + kw') * CsP + co with
+// kh' -> original kh through khmap (3x3: class 0 = {1}, class 1 = {2, 0}; 1x1: {0}).
+template <typename T>
+__global__ void __launch_bounds__(256) pack_conv2d_s2_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int KH, int KW, int CsP,
+                                                             int rowsP, int Kpad, int KHc, int KWc, int kh0, int kh1, int kw0, int kw1) {
+  const int64_t total = (int64_t)rowsP * Kpad;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int ci = (int)(idx / Kpad), k = (int)(idx % Kpad);
+    const int tap = k / CsP, co = k % CsP;
+    float v = 0.f;
+    if (tap < KHc * KWc && ci < Ci && co < Co) {
+      const int khc = tap / KWc, kwc = tap % KWc;
+      const int kh = khc ? kh1 : kh0, kw = kwc ? kw1 : kw0;
+      v = w[(((int64_t)co * Ci + ci) * KH + kh) * KW + kw];
+    }
+    out[idx] = from_f<T>(v);
+  }
+}
+
 int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;
   int s = 0;
@@ -357,7 +385,8 @@ template <typename T, int MODE> int launch_bn(const C2Params& p, int NcP, hipStr
 }
 
 int conv2d_common(const char* what, int mode, const void* src, const void* wp, const float* bias, void* out, float* stats, int N, int Hs, int Ws,
-                  int Cs, int Ho, int Wo, int Nc, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, hipStream_t stream) {
+                  int Cs, int Ho, int Wo, int Nc, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, hipStream_t stream,
+                  int placed = 0, int pa = 0, int pb = 0, int Hf = 0, int Wf = 0) {
   PCRL_REQUIRE(src && wp && out, "%s: null pointer", what);
   PCRL_REQUIRE(N > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0 && Nc > 0, "%s: bad dims", what);
   PCRL_REQUIRE(dtype == PCRL_F32 || dtype == PCRL_BF16, "%s: bad dtype %d", what, dtype);
@@ -374,6 +403,7 @@ int conv2d_common(const char* what, int mode, const void* src, const void* wp, c
   p.Ktot = KH * KW * Cs;
   p.Kpad = (p.Ktot + 31) / 32 * 32;
   p.out_f32 = out_f32;
+  p.placed = placed; p.pa = pa; p.pb = pb; p.Hf = Hf; p.Wf = Wf;
   p.M = (int64_t)N * Ho * Wo;
   const int NcP = (Nc + 31) / 32 * 32;
   if (dtype == PCRL_BF16) return mode == C2_FWD ? launch_bn<bf16, C2_FWD>(p, NcP, stream) : launch_bn<bf16, C2_DGRAD>(p, NcP, stream);
@@ -452,4 +482,52 @@ extern "C" int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx,
     return pcrl_conv2d_narrow_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, KH, 0, 0, as_stream(stream));
   return conv2d_common("conv2d_dgrad", C2_DGRAD, dy, wp_dgrad, nullptr, dx, nullptr, N, Ho, Wo, CoP, Hi, Wi, Ci, KH, KW, stride, pad, 0, 0, dtype,
                        as_stream(stream));
+}
+
+// ---- stride-2 data gradient by parity classes ------------------------------------------------------------------------------------
+// dx[ih][iw] of a stride-2 convolution only receives taps whose parity matches (ih + pad - kh even): run as ONE gather over all
+// taps, 3 of 4 taps are idle (conv2d_dgrad above).  Here the four parity classes (a, b) = (ih & 1, iw & 1) are four small stride-1
+// convolutions over dy with 1, 2, 2 and 4 taps whose outputs are stored at pixels (2q + a, 2r + b): no idle taps.
+//   3x3 / pad 1: class 0 = tap kh 1 (source row q); class 1 = taps kh 2 (source q) and kh 0 (source q + 1)
+//   1x1 / pad 0: only class (0, 0) is non-zero (the caller zero-fills dx)
+// Hi, Wi even.  pack: rows round32(Ci), K = KHc * KWc * CoP (pcrl_conv2d_packed_elems(Ci, KHc * KWc, CoP)).
+static void s2_class(int KH, int a, int& KHc, int& k0, int& k1) {
+  if (KH == 3) {
+    KHc = a ? 2 : 1;
+    k0 = a ? 2 : 1;
+    k1 = 0;
+  } else {
+    KHc = 1;
+    k0 = k1 = 0;
+  }
+}
+
+extern "C" int pcrl_conv2d_pack_s2(const float* w_ref, void* out, int Co, int Ci, int KH, int KW, int CoP, int a, int b, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(w_ref && out && Co > 0 && Ci > 0 && CoP >= Co, "conv2d_pack_s2: bad arguments");
+  PCRL_REQUIRE((KH == 3 && KW == 3) || (KH == 1 && KW == 1 && a == 0 && b == 0), "conv2d_pack_s2: 3x3 (pad 1) or 1x1 (class 0,0) only");
+  int KHc, KWc, kh0, kh1, kw0, kw1;
+  s2_class(KH, a, KHc, kh0, kh1);
+  s2_class(KW, b, KWc, kw0, kw1);
+  const int rowsP = (Ci + 31) / 32 * 32, Kpad = (KHc * KWc * CoP + 31) / 32 * 32;
+  const int64_t total = (int64_t)rowsP * Kpad;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (dtype == PCRL_BF16)
+    hipLaunchKernelGGL(pack_conv2d_s2_kernel<bf16>, dim3(grid), dim3(256), 0, as_stream(stream), w_ref, (bf16*)out, Co, Ci, KH, KW, CoP, rowsP, Kpad, KHc, KWc, kh0, kh1, kw0, kw1);
+  else if (dtype == PCRL_F32)
+    hipLaunchKernelGGL(pack_conv2d_s2_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), w_ref, (float*)out, Co, Ci, KH, KW, CoP, rowsP, Kpad, KHc, KWc, kh0, kh1, kw0, kw1);
+  else
+    return pcrl_fail(PCRL_EINVAL, "conv2d_pack_s2: bad dtype %d", dtype);
+  return pcrl_check_launch("conv2d_pack_s2");
+}
+
+extern "C" int pcrl_conv2d_dgrad_s2(const void* dy, const void* wp_class, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH, int KW,
+                                    int a, int b, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE((KH == 3 && KW == 3) || (KH == 1 && KW == 1 && a == 0 && b == 0), "conv2d_dgrad_s2: 3x3 (pad 1) or 1x1 (class 0,0) only");
+  PCRL_REQUIRE(Hi % 2 == 0 && Wi % 2 == 0 && Ho == Hi / 2 && Wo == Wi / 2, "conv2d_dgrad_s2: even input extents and Ho = Hi / 2 expected");
+  int KHc, KWc, k0, k1;
+  s2_class(KH, a, KHc, k0, k1);
+  s2_class(KW, b, KWc, k0, k1);
+  // a stride-1, pad-0 forward gather over dy with KHc x KWc taps at offsets {0, +1}; rows = the class's pixels (q, r)
+  return conv2d_common("conv2d_dgrad_s2", C2_FWD, dy, wp_class, nullptr, dx, nullptr, N, Ho, Wo, CoP, Hi / 2, Wi / 2, Ci, KHc, KWc, 1, 0, 0, 0, dtype,
+                       as_stream(stream), 1, a, b, Hi, Wi);
 }

@@ -54,6 +54,24 @@ class PackedConv2d:
         self.key = None
         self.fwd = None
         self.dgrad = None
+        self.s2_key = None
+        self.s2 = None        # stride-2 data gradient: {(a, b): parity-class pack}
+
+    def get_s2(self, w: torch.Tensor, dtype):
+        """Parity-class packs of the stride-2 data gradient (pcrl_conv2d_dgrad_s2): 3x3 -> four classes, 1x1 -> class (0, 0)."""
+        key = (ops._weights_epoch, w._version, w.data_ptr(), dtype)
+        if key != self.s2_key:
+            L, s = lib(), stream_handle()
+            Co, Ci, KH, KW = w.shape
+            CoP = _pow2_at_least_8(Co)
+            self.s2 = {}
+            for a, b in (((0, 0), (0, 1), (1, 0), (1, 1)) if KH == 3 else ((0, 0),)):
+                taps = ((2 if a else 1) * (2 if b else 1)) if KH == 3 else 1
+                t = torch.empty(L.call("pcrl_conv2d_packed_elems", Ci, taps, CoP), dtype=dtype, device=w.device)
+                L.call("pcrl_conv2d_pack_s2", w.detach(), t, Co, Ci, KH, KW, CoP, a, b, dtype_code(dtype), s)
+                self.s2[(a, b)] = t
+            self.s2_key = key
+        return self.s2
 
     def get(self, w: torch.Tensor, dtype, CiP: int):
         key = (ops._weights_epoch, w._version, w.data_ptr(), dtype, CiP)
@@ -104,7 +122,16 @@ def conv2d_backward(x, dy, w, packed: PackedConv2d, stride, pad, up, dtype, need
            int(up), dtype_code(dtype), s)
     dw = dw_full if CoP == Co else dw_full[:Co]
     dx = None
-    if need_dx:
+    if need_dx and stride == 2 and not up and Hi % 2 == 0 and Wi % 2 == 0 and ((KH == 3 and pad == 1) or (KH == 1 and pad == 0)) and KH == KW \
+            and _pow2_at_least_8(Co) == CoP:
+        # stride 2: four parity classes of dx, each a small stride-1 gather over dy (no idle taps); 1x1: three classes are zero
+        packs = packed.get_s2(w, dtype)
+        dx = new_act2(N, Hi, Wi, Ci, dtype, x.device)
+        if KH == 1:
+            dx.zero_()
+        for (a, b), wp in packs.items():
+            L.call("pcrl_conv2d_dgrad_s2", dy, wp, dx, N, Hi, Wi, Ci, Ho, Wo, CoP, KH, KW, a, b, dtype_code(dtype), s)
+    elif need_dx:
         _, wd = packed.get(w, dtype, CiP)
         Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
         dxl = new_act2(N, Hl, Wl, Ci, dtype, x.device)

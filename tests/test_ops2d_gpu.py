@@ -40,7 +40,9 @@ GEOMS = [  # Ci, Co, K, stride, pad, up, H, W, bias
     (32, 32, 3, 1, 1, 0, 8, 64, False),      # ... 32 -> 32 (block 3)
     (16, 32, 3, 1, 1, 0, 24, 32, False),     # ... 16 -> 32
     (64, 32, 3, 1, 1, 1, 8, 16, False),      # ... 64 -> 32 behind the upsample (block 3 conv1): two 32-channel launches
-    (64, 128, 3, 2, 1, 0, 15, 9, False),     # odd extents, stride 2
+    (64, 128, 3, 2, 1, 0, 15, 9, False),     # odd extents, stride 2 (one gather over all taps)
+    (128, 256, 3, 2, 1, 0, 8, 12, False),    # stride 2, even extents: parity-class data gradient
+    (128, 256, 1, 2, 0, 0, 8, 12, False),    # downsample, parity class (0, 0)
     (3, 64, 7, 2, 3, 0, 33, 21, False),      # odd extents, stem
 ]
 
