@@ -25,3 +25,7 @@ def set_default_compute_dtype(dt):
 # Parameter gradients are delivered to `.grad` by the engine (pcrlv2_amd.functions) instead of autograd's AccumulateGrad nodes.
 # PCRL_AUTOGRAD_PARAM_GRADS=1 hands them back to autograd (needed for torch.autograd.grad(loss, params), which never accumulates).
 DIRECT_PARAM_GRADS = os.environ.get("PCRL_AUTOGRAD_PARAM_GRADS", "0") != "1"
+
+# Weight-gradient kernels run on a side stream, concurrently with the data-gradient / BatchNorm-backward chain of the layers below
+# (MFMA-bound next to HBM-bound work); joined before the parameter gradients are summed.  PCRL_WGRAD_STREAM=0 keeps everything on one stream.
+WGRAD_SIDE_STREAM = os.environ.get("PCRL_WGRAD_STREAM", "1") != "0"

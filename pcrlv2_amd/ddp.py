@@ -153,6 +153,8 @@ class DataParallel:
     def _on_backward_end(self):
         """End of a backward pass: gradients still parked go to `.grad`; those of buckets already sent are kept aside."""
         Fn = self._fn
+        from . import ops
+        ops.join_side_stream()
         late = []
         if any(self._launched):
             for p in Fn.parked_params():

@@ -50,7 +50,10 @@ def _end_of_backward():
 def _park(p, g):
     """Take the gradient `g` of parameter `p` out of autograd's hands (returns what the Function hands to autograd instead)."""
     global _callback_queued
-    if g is None or not config.DIRECT_PARAM_GRADS:
+    if g is None:
+        return g
+    if not config.DIRECT_PARAM_GRADS:
+        ops.join_side_stream()     # autograd's AccumulateGrad reads g on the main stream
         return g
     if not p.requires_grad:
         return None
@@ -76,6 +79,7 @@ def flush_param_grads(params=None):
     items = [_parked.pop(k) for k in keys]
     if not items:
         return
+    ops.join_side_stream()        # weight gradients are produced on a side stream (ops.side_wgrad)
     targets, level = [], 0
     copy_dst, copy_src = [], []
     for p, gs in items:

@@ -22,14 +22,64 @@ BN_MOMENTUM = 0.1
 _ws_cache: dict = {}
 
 
-def workspace(nbytes: int, device) -> torch.Tensor:
-    """Grow-only scratch arena per device; safe to share because all calls are stream-ordered."""
-    key = (device.type, device.index)
+def workspace(nbytes: int, device, arena: str = "main") -> torch.Tensor:
+    """Grow-only scratch arena per device and stream (`arena`); safe to share because all calls on one stream are ordered."""
+    key = (device.type, device.index, arena)
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
         t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws_cache[key] = t
     return t
+
+
+# ----------------------------------------------------------------------------------------------
+# side stream for the weight gradients
+# ----------------------------------------------------------------------------------------------
+# In backward a layer's weight gradient (MFMA-bound) has no consumer until the optimizer step, while the chain that everything else
+# waits for -- data gradient -> BatchNorm backward of the layer below (HBM-bound) -> ... -- does not depend on it.  The weight
+# gradients are therefore launched on a second stream: the matrix pipes work on them while the BatchNorm passes stream through HBM.
+# Ordering: the side stream waits for the main stream before every launch (its operands were just produced there); the main stream
+# waits for the side stream once, before the parked parameter gradients are summed (functions.flush_param_grads) -- operands are
+# `record_stream`-ed so the caching allocator does not recycle them under the side stream; the side stream has its own scratch arena.
+_side_streams: dict = {}
+_side_pending: dict = {}
+
+
+class side_wgrad:
+    """`with side_wgrad(device, x, dy) as ws:` -- launches inside run on the side stream; ws(nbytes) is its scratch arena."""
+
+    def __init__(self, device, *operands):
+        self.device, self.operands = device, operands
+        self.active = config.WGRAD_SIDE_STREAM and device.type == "cuda"
+
+    def __enter__(self):
+        if not self.active:
+            return lambda nb: workspace(nb, self.device)
+        key = (self.device.type, self.device.index)
+        side = _side_streams.get(key)
+        if side is None:
+            side = _side_streams[key] = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        for t in self.operands:
+            t.record_stream(side)
+        _side_pending[key] = True
+        self._cm = torch.cuda.stream(side)
+        self._cm.__enter__()
+        return lambda nb: workspace(nb, self.device, arena="side")
+
+    def __exit__(self, *exc):
+        if self.active:
+            self._cm.__exit__(*exc)
+        return False
+
+
+def join_side_stream(device=None):
+    """The current stream waits for every weight gradient launched so far (no-op when none is outstanding)."""
+    for key, pending in list(_side_pending.items()):
+        if pending and (device is None or (device.type, device.index) == key):
+            dev = torch.device(key[0], key[1])
+            torch.cuda.current_stream(dev).wait_stream(_side_streams[key])
+            _side_pending[key] = False
 
 
 def new_act(N, D, H, W, C, dtype, device) -> torch.Tensor:
@@ -269,7 +319,8 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
         L.call("pcrl_conv3d_k3_c1_wgrad", sv.x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Co, dtype_code(dtype), s)
         return None, dw, db, dgamma, dbeta
     nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
-    L.call("pcrl_conv3d_k3_wgrad", sv.x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    with side_wgrad(dev, sv.x, dy) as ws:
+        L.call("pcrl_conv3d_k3_wgrad", sv.x, dy, dw, ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
     dx = None
     if need_dx:
         _, wd = packed.get(conv_w, dtype)
@@ -323,7 +374,8 @@ def convt_backward(x, dy, w, packed: PackedWeights, dtype, need_dx=True, db=None
     dims(dy)
     dw = torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format)
     nb = L.call("pcrl_convt3d_k2s2_wgrad_ws_bytes", N, D, H, W, Ci, Co)
-    L.call("pcrl_convt3d_k2s2_wgrad", x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    with side_wgrad(dev, x, dy) as ws:
+        L.call("pcrl_convt3d_k2s2_wgrad", x, dy, dw, ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
     if db is None:
         Mo = N * D * H * W * 8
         db = _f32(Co, dev)

@@ -118,8 +118,9 @@ def conv2d_backward(x, dy, w, packed: PackedConv2d, stride, pad, up, dtype, need
     Co, Ci, KH, KW = w.shape
     nb = L.call("pcrl_conv2d_wgrad_ws_bytes", N, Ho, Wo, CiP, CoP, KH, KW)
     dw_full = torch.empty((CoP, Ci, KH, KW), dtype=torch.float32, device=x.device)
-    L.call("pcrl_conv2d_wgrad", x, dy, dw_full, ops.workspace(nb, x.device), nb, N, Hi, Wi, CiP, Ci, Ho, Wo, CoP, KH, KW, stride, pad,
-           int(up), dtype_code(dtype), s)
+    with ops.side_wgrad(x.device, x, dy) as ws:      # weight gradients run next to the data-gradient / BatchNorm chain (ops.side_wgrad)
+        L.call("pcrl_conv2d_wgrad", x, dy, dw_full, ws(nb), nb, N, Hi, Wi, CiP, Ci, Ho, Wo, CoP, KH, KW, stride, pad,
+               int(up), dtype_code(dtype), stream_handle())
     dw = dw_full if CoP == Co else dw_full[:Co]
     dx = None
     if need_dx and stride == 2 and not up and Hi % 2 == 0 and Wi % 2 == 0 and ((KH == 3 and pad == 1) or (KH == 1 and pad == 0)) and KH == KW \

@@ -103,6 +103,7 @@ class FusedSGD(torch.optim.SGD):
             with torch.enable_grad():
                 loss = closure()
         g = self.param_groups[0]
+        ops.join_side_stream()
         if self.pre_step is not None:
             has = self.pre_step(self, None)       # the data-parallel wrapper gathers (bucket by bucket) and all-reduces
         else:
