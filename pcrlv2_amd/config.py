@@ -26,6 +26,11 @@ def set_default_compute_dtype(dt):
 # PCRL_AUTOGRAD_PARAM_GRADS=1 hands them back to autograd (needed for torch.autograd.grad(loss, params), which never accumulates).
 DIRECT_PARAM_GRADS = os.environ.get("PCRL_AUTOGRAD_PARAM_GRADS", "0") != "1"
 
-# Weight-gradient kernels run on a side stream, concurrently with the data-gradient / BatchNorm-backward chain of the layers below
-# (MFMA-bound next to HBM-bound work); joined before the parameter gradients are summed.  PCRL_WGRAD_STREAM=0 keeps everything on one stream.
-WGRAD_SIDE_STREAM = os.environ.get("PCRL_WGRAD_STREAM", "1") != "0"
+# Weight-gradient kernels on a side stream, concurrently with the data-gradient / BatchNorm-backward chain of the layers below
+# (MFMA-bound next to HBM-bound work); joined before the parameter gradients are summed (ops.side_wgrad).
+#   PCRL_WGRAD_STREAM unset: on for the 2D path (+3.6 % at C5), off for the 3D path -- there it gains 1.5 % of step time but every
+#   kernel then shares the chip with a neighbour, so the per-launch HIP-event times that bench.py's roofline reports (and that must
+#   agree with the rocprofv3 summary) stop describing the kernel alone;  =1: on everywhere;  =0: off everywhere.
+_ws = os.environ.get("PCRL_WGRAD_STREAM", "")
+WGRAD_SIDE_STREAM_3D = _ws == "1"
+WGRAD_SIDE_STREAM_2D = _ws != "0"

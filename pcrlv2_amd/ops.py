@@ -48,9 +48,9 @@ _side_pending: dict = {}
 class side_wgrad:
     """`with side_wgrad(device, x, dy) as ws:` -- launches inside run on the side stream; ws(nbytes) is its scratch arena."""
 
-    def __init__(self, device, *operands):
+    def __init__(self, device, *operands, path2d=False):
         self.device, self.operands = device, operands
-        self.active = config.WGRAD_SIDE_STREAM and device.type == "cuda"
+        self.active = (config.WGRAD_SIDE_STREAM_2D if path2d else config.WGRAD_SIDE_STREAM_3D) and device.type == "cuda"
 
     def __enter__(self):
         if not self.active:

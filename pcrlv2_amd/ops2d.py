@@ -118,7 +118,7 @@ def conv2d_backward(x, dy, w, packed: PackedConv2d, stride, pad, up, dtype, need
     Co, Ci, KH, KW = w.shape
     nb = L.call("pcrl_conv2d_wgrad_ws_bytes", N, Ho, Wo, CiP, CoP, KH, KW)
     dw_full = torch.empty((CoP, Ci, KH, KW), dtype=torch.float32, device=x.device)
-    with ops.side_wgrad(x.device, x, dy) as ws:      # weight gradients run next to the data-gradient / BatchNorm chain (ops.side_wgrad)
+    with ops.side_wgrad(x.device, x, dy, path2d=True) as ws:      # weight gradients run next to the data-gradient / BatchNorm chain (ops.side_wgrad)
         L.call("pcrl_conv2d_wgrad", x, dy, dw_full, ws(nb), nb, N, Hi, Wi, CiP, Ci, Ho, Wo, CoP, KH, KW, stride, pad,
                int(up), dtype_code(dtype), stream_handle())
     dw = dw_full if CoP == Co else dw_full[:Co]
