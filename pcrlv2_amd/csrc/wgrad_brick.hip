@@ -32,7 +32,7 @@ constexpr int XROWS = BD * XH * XW;       // 240
 constexpr int DY_BYTES = BV * 128;        // 16 KiB
 constexpr int X_BYTES = XROWS * 128;      // 30 KiB
 // NG = wave groups per block: every group of 4 waves takes 4 / NG of a brick's four 32-voxel K chunks for ALL 9 taps and keeps its own
-// accumulators (one more partial slab per group).  NG = 2 puts two waves on every SIMD at the same LDS footprint: one wave per SIMD
+// accumulators (combined through LDS at the end of the kernel).  NG = 2 puts two waves on every SIMD at the same LDS footprint: one wave per SIMD
 // issues in order, and between two MFMAs (16 cycles of pipe) there is room for three other instructions -- exactly what a step needs
 // (transpose reads, staging loads / stores, selects), so any stall showed up as an idle matrix pipe.
 #ifndef WB_NG
@@ -275,8 +275,32 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #undef WB_LOAD_PIECE
 #undef WB_STORE_PIECE
 
+  // ---- the two wave groups hold partial sums over different K chunks: group 1 hands its accumulators to group 0 through the (now
+  //      idle) LDS brick buffers in two halves (5 + 4 taps: 80 KB of the 92 KB), so the block writes ONE partial slab ----
+  if (NG == 2) {
+    f32x4* xch = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int t0 = half * 5, t1 = half ? 9 : 5;
+      __syncthreads();   // the brick loop's last reads / the previous half's reads are done
+      if (grp == 1) {
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) xch[(((t - t0) * 4 + f) * 4 + wid) * 64 + lane] = acc[t][f];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+#pragma unroll
+          for (int f = 0; f < 4; ++f) acc[t][f] += xch[(((t - t0) * 4 + f) * 4 + wid) * 64 + lane];
+      }
+    }
+    if (grp == 1) return;
+  }
   // D[i][j]: lane holds i = 16 f + 4 lg + r, j = lane & 15
-  float* out = p.ws + ((int64_t)blockIdx.x * NG + grp) * (9 * p.nkd) * p.Cu * p.Cv;
+  float* out = p.ws + (int64_t)blockIdx.x * (9 * p.nkd) * p.Cu * p.Cv;
   const int j = j0 + wid * 16 + (lane & 15);
   if (j < p.Cv) {
 #pragma unroll
@@ -318,7 +342,7 @@ bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int d
          (int64_t)N * D * H * W / BV < (1 << 30);
 }
 int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co) {
-  return plan((int)((int64_t)N * D * H * W / BV), Co, Ci).splits * NG;   // partial slabs for the second pass
+  return plan((int)((int64_t)N * D * H * W / BV), Co, Ci).splits;
 }
 int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co,
                             hipStream_t stream) {
@@ -342,7 +366,7 @@ bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype)
   return dtype == PCRL_BF16 && N % BD == 0 && H % BH == 0 && W % BW == 0 && Co % 64 == 0 && Ci % 32 == 0 && (int64_t)N * H * W / BV < (1 << 30) &&
          (int64_t)N * H * W * (Ci > Co ? Ci : Co) < ((int64_t)1 << 31);
 }
-int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co) { return plan((int)((int64_t)N * H * W / BV), Co, Ci, 1).splits * NG; }
+int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co) { return plan((int)((int64_t)N * H * W / BV), Co, Ci, 1).splits; }
 int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, int up, hipStream_t stream) {
   static bool attr_set = false;
   const size_t lds = 2 * BUF_BYTES;
