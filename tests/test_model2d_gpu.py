@@ -38,13 +38,14 @@ def _oracle_state(model):
     return sd
 
 
-def test_step_matches_oracle_fp32():
+@pytest.mark.parametrize("b,size,local", [(4, 64, 32), (4, 224, 96)])     # the second is BASELINE configs[0] (C1: 224x224, b=4) on the GPU
+def test_step_matches_oracle_fp32(b, size, local):
     import pcrlv2_2d_oracle as O
     from pcrlv2_amd import train_2d
     from pcrlv2_amd.train_3d import CosineSimilarityMean
     model = _build()
     sd = _oracle_state(model)
-    batch = O.synthetic_batch(4, 64, 32, seed=11)
+    batch = O.synthetic_batch(b, size, local, seed=11)
     random.seed(5)
     so = {}
     ref = O.step_losses(sd, tuple(t.double() if torch.is_tensor(t) else [u.double() for u in t] for t in batch), epoch=3, so=so)
