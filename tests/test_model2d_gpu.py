@@ -194,3 +194,71 @@ def test_data_parallel_two_ranks_one_gpu_gloo_2d(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
     assert all("OK" in o for o in outs)
+
+
+@pytest.mark.parametrize("layer", [
+    # N, Hi, Wi, Ci, Co, K, stride, pad, up      (BASELINE C5: b = 64, 512 x 512, bf16)
+    (64, 128, 128, 64, 64, 3, 1, 1, 0),          # layer1: brick forward / data gradient / weight gradient
+    (64, 512, 512, 16, 16, 3, 1, 1, 0),          # decoder block 4 conv2: the right-sized narrow kernels
+    (64, 256, 256, 32, 16, 3, 1, 1, 1),          # block 4 conv1 behind the fused upsample
+    (64, 128, 128, 64, 128, 3, 2, 1, 0),         # layer2.0.conv1: stride 2, parity-class data gradient
+    (64, 512, 512, 8, 64, 7, 2, 3, 0),           # stem (3 channels padded to 8)
+])
+def test_full_size_conv2d_adjoint_identities_bf16(layer):
+    """BASELINE C5 sizes.  No CPU reference is affordable, but forward, data gradient and weight gradient -- three different kernels
+    per geometry -- must be mutually adjoint:  <conv(x; w), dy> == <x, dgrad(dy; w)> == <w, wgrad(x, dy)>."""
+    from pcrlv2_amd import ops2d
+    N, Hi, Wi, Ci, Co, K, stride, pad, up = layer
+    dt, dev = torch.bfloat16, torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = ops2d.new_act2(N, Hi, Wi, Ci, dt, dev)
+    x.normal_(generator=g)
+    Cw = 3 if K == 7 else Ci                      # the stem's weight has 3 input channels; x carries 5 zero channels
+    if K == 7:
+        x[:, 3:] = 0
+    w = torch.randn(Co, Cw, K, K, device=dev, generator=g) * 0.05
+    packed = ops2d.PackedConv2d()
+    y, _, _ = ops2d.conv2d_forward(x, w, None, packed, stride, pad, up, dt)
+    dy = torch.empty_like(y)
+    dy.normal_(generator=g)
+    dx, dw = ops2d.conv2d_backward(x, dy, w, packed, stride, pad, up, dt, need_dx=True)
+    wq = w.to(dt).double()
+    a = float((y.double() * dy.double()).sum())
+    b_ = float((x[:, :dx.shape[1]].double() * dx.double()).sum())
+    c = float((wq * dw.double()).sum())
+    scale = float(y.double().norm() * dy.double().norm())
+    print(f"adjoint: <y,dy>={a:.6e} <x,dx>={b_:.6e} <w,dw>={c:.6e} (|y||dy|={scale:.3e})")
+    assert abs(a - c) < 2e-4 * scale and abs(b_ - c) < 2e-4 * scale
+
+
+def test_full_size_step_properties_2d_bf16():
+    """One BASELINE-C5 step (b=64, 512x512 x2 + 6 local 96x96, bf16): finite losses in the expected ranges, finite gradients, the
+    unselected deep-supervision heads receive none, and the step is deterministic (bit-identical when repeated)."""
+    from pcrlv2_amd import train_2d
+    from pcrlv2_amd.models import PCRLv2
+    from pcrlv2_amd.optim import FusedSGD
+    from pcrlv2_amd.train_3d import CosineSimilarityMean
+    dev = torch.device("cuda:0")
+    b = 64
+    g = torch.Generator(device=dev).manual_seed(1234)
+    kw = dict(generator=g, device=dev)
+    x1 = torch.randn(b, 3, 512, 512, **kw)
+    batch = (x1, x1 + 0.1 * torch.randn(b, 3, 512, 512, **kw), torch.rand(b, 3, 512, 512, **kw), None, [torch.randn(b, 3, 96, 96, **kw) for _ in range(6)])
+    results = []
+    for rep in range(2):
+        torch.manual_seed(0)
+        model = PCRLv2().cuda().set_compute_dtype(torch.bfloat16)
+        opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+        random.seed(0)
+        out = train_2d.train_step(model, opt, batch, 0, train_2d.MSELoss2d(), CosineSimilarityMean())
+        vals = [float(v) for v in out]
+        assert all(v == v and abs(v) < 1e4 for v in vals), vals
+        assert vals[1] > 0 and -1.0 <= vals[2] <= 1.0 and -1.0 <= vals[4] <= 1.0 and vals[3] > 0
+        grads = [p.grad for p in model.parameters()]
+        assert sum(gr is None for gr in grads) == 4 * 6          # four unselected deep-supervision heads x (conv w, b, bn w, b, conv w, b)
+        assert all(torch.isfinite(gr).all() for gr in grads if gr is not None)
+        results.append((vals, opt.flat_p.clone()))
+        del model, opt
+        torch.cuda.empty_cache()
+    assert results[0][0] == results[1][0], "losses differ between identical runs (non-deterministic reduction?)"
+    assert torch.equal(results[0][1], results[1][1]), "parameters differ between identical runs"
