@@ -10,10 +10,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$TAG/write -- $B > $R/gpurun_out/$TAG.write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $R/gpurun_out/$TAG/sq -- $B > $R/gpurun_out/$TAG.sq.log 2>&1
 find $R/gpurun_out/$TAG -name "*.csv" | grep -v agent_info | xargs ls -la | awk '{print $5, $9}'
-# the counter CSVs hold one row per dispatch and counter: keep only the two big kernels (the merge-back limit is 64 MiB)
+# the counter CSVs hold one row per dispatch and counter: keep only the two big kernels and the HBM-bound streaming kernels (the merge-back limit is 64 MiB)
 for d in fetch write sq; do
   f=$(find $R/gpurun_out/$TAG/$d -name "*counter_collection.csv")
   head -1 $f > $R/gpurun_out/$TAG/$d.csv
-  grep "brick_conv_kernel\|wgrad_brick_kernel" $f >> $R/gpurun_out/$TAG/$d.csv
+  grep "brick_conv_kernel\|wgrad_brick_kernel\|bn_bwd_apply_rc_kernel\|bn_bwd_reduce_kernel\|bn_apply_rc_kernel\|maxpool_\|gap_bwd_kernel\|coltile_sum_kernel" $f >> $R/gpurun_out/$TAG/$d.csv
   rm -f $f $(find $R/gpurun_out/$TAG/$d -name "*kernel_trace.csv")
 done

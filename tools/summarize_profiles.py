@@ -80,6 +80,18 @@ def main():
                     f"MFMA busy {100 * util:5.1f} %  CU busy {m['SQ_BUSY_CU_CYCLES'] / m['GRBM_GUI_ACTIVE'] / 32 * 100:5.1f} %  "
                     f"LDS bank-conflict cycles / LDS active {100 * conf:4.1f} %\n")
             traffic[k] = {"hbm_bytes_per_launch": (f_mb + w_mb) * 1e6, "mfma_busy": util}
+        # HBM-bound kernels: measured bytes per launch / average launch duration (kernel stats of the same command) -> TB/s
+        dur = {k: t / c for k, (c, t) in agg.items()}      # ns per launch
+        hb = [k for k in ("bn_bwd_apply_rc_kernel", "bn_bwd_reduce_kernel", "bn_apply_rc_kernel", "maxpool_bwd_kernel", "maxpool_fwd_kernel",
+                          "gap_bwd_kernel", "coltile_sum_kernel") if k in fd and k in wd and k in dur]
+        if hb:
+            out += "\n# HBM-bound kernels: PMC bytes per launch (FETCH x2 + WRITE) / average launch duration from the stats pass\n"
+        for k in hb:
+            f_mb = 2 * fa[k]["FETCH_SIZE"] / len(fd[k]) * 1024 / 1e6
+            w_mb = wa[k]["WRITE_SIZE"] / len(wd[k]) * 1024 / 1e6
+            tbs = (f_mb + w_mb) * 1e6 / (dur[k] * 1e-9) / 1e12
+            out += f"{k:24s} launches {len(fd[k]):4d}  fetch {f_mb:8.1f} MB  write {w_mb:8.1f} MB  avg {dur[k] / 1e3:7.1f} us  -> {tbs:5.2f} TB/s of ~8\n"
+            traffic[k] = {"hbm_bytes_per_launch": (f_mb + w_mb) * 1e6, "hbm_TBps": tbs}
         json.dump(traffic, open(f"profiles/{tag}_pmc.json", "w"), indent=1)
     open(f"profiles/{tag}_kernel_stats.txt", "w").write(out)
     print(out)
