@@ -22,8 +22,11 @@ BN_MOMENTUM = 0.1
 _ws_cache: dict = {}
 
 
-def workspace(nbytes: int, device, arena: str = "main") -> torch.Tensor:
-    """Grow-only scratch arena per device and stream (`arena`); safe to share because all calls on one stream are ordered."""
+def workspace(nbytes: int, device, arena=None) -> torch.Tensor:
+    """Grow-only scratch arena per device AND stream (the launches of one stream are ordered, so they can share one; a second
+    stream -- ops.side_wgrad -- gets its own)."""
+    if arena is None:
+        arena = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
     key = (device.type, device.index, arena)
     t = _ws_cache.get(key)
     if t is None or t.numel() < nbytes:
@@ -65,7 +68,7 @@ class side_wgrad:
         _side_pending[key] = True
         self._cm = torch.cuda.stream(side)
         self._cm.__enter__()
-        return lambda nb: workspace(nb, self.device, arena="side")
+        return lambda nb: workspace(nb, self.device)      # keyed by the (now current) side stream
 
     def __exit__(self, *exc):
         if self.active:
