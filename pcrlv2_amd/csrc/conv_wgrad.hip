@@ -212,6 +212,56 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       cn2[ps] += sn2;                                                                           \
     }                                                                                           \
   } while (0)
+  // WG_CONV3: the same for the 3x3x3 geometry (the gather kernel serves the small volumes -- local views at 4^3 and 2^3 -- where a block
+  // has few K-steps of 4 MFMAs each and the three 64-bit divisions per row and step were most of its instructions).
+  int c3n[NP], c3d[NP], c3h[NP], c3w[NP];
+  int64_t c3m[NP];
+  int s3n = 0, s3d = 0, s3h = 0, s3w = 0;
+  if (GEOM == WG_CONV3) {
+    s3w = KS % g.W;
+    s3h = (KS / g.W) % g.H;
+    s3d = (KS / (g.W * g.H)) % g.D;
+    s3n = KS / (g.W * g.H * g.D);
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      c3m[ps] = mbeg + ps * RPP + rowp;
+      const int64_t mc = c3m[ps] < p.M ? c3m[ps] : 0;
+      decode_voxel(mc, g, c3n[ps], c3d[ps], c3h[ps], c3w[ps]);
+    }
+  }
+#define WG_LOAD3D()                                                                             \
+  do {                                                                                          \
+    uokb = 0;                                                                                   \
+    vokb = 0;                                                                                   \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                         \
+      const bool live = c3m[ps] < mend;                                                         \
+      const int64_t m = live ? c3m[ps] : mbeg;                                                  \
+      ru[ps] = *reinterpret_cast<const u32x4*>(U + m * p.Cu + i0 + ucol_u);                     \
+      const bool in = live && (unsigned)(c3d[ps] + kd - 1) < (unsigned)g.D && (unsigned)(c3h[ps] + kh - 1) < (unsigned)g.H && \
+                      (unsigned)(c3w[ps] + kw - 1) < (unsigned)g.W;                             \
+      const int64_t vrow = in ? m + delta : m;                                                  \
+      rv[ps] = *reinterpret_cast<const u32x4*>(V + vrow * vpitch + vcol);                       \
+      uokb |= (uint32_t)(live && u_ok) << ps;                                                   \
+      vokb |= (uint32_t)(in && v_ok) << ps;                                                     \
+      c3m[ps] += KS;                                                                            \
+      c3w[ps] += s3w;                                                                           \
+      if (c3w[ps] >= g.W) {                                                                     \
+        c3w[ps] -= g.W;                                                                         \
+        c3h[ps] += 1;                                                                           \
+      }                                                                                         \
+      c3h[ps] += s3h;                                                                           \
+      if (c3h[ps] >= g.H) {                                                                     \
+        c3h[ps] -= g.H;                                                                         \
+        c3d[ps] += 1;                                                                           \
+      }                                                                                         \
+      c3d[ps] += s3d;                                                                           \
+      if (c3d[ps] >= g.D) {                                                                     \
+        c3d[ps] -= g.D;                                                                         \
+        c3n[ps] += 1;                                                                           \
+      }                                                                                         \
+      c3n[ps] += s3n;                                                                           \
+    }                                                                                           \
+  } while (0)
 #define WG_LOAD(ms_)                                                                            \
   do {                                                                                          \
     uokb = 0;                                                                                   \
@@ -262,6 +312,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   const int64_t nsteps = (mend > mbeg) ? (mend - mbeg + KS - 1) / KS : 0;
   if (nsteps > 0) {
     if (GEOM == WG_CONV2D) WG_LOAD2D();
+    else if (GEOM == WG_CONV3) WG_LOAD3D();
     else WG_LOAD(mbeg);
     WG_STORE(0);
   }
@@ -271,6 +322,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     const int cur = (int)(s & 1);
     const int64_t sn = (s + 1 < nsteps) ? s + 1 : s;
     if (GEOM == WG_CONV2D) WG_LOAD2D();      // the last iteration stages rows past `mend`: dead, zeroed at the LDS store
+    else if (GEOM == WG_CONV3) WG_LOAD3D();
     else WG_LOAD(mbeg + sn * KS);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -293,6 +345,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   }
 #undef WG_LOAD
 #undef WG_LOAD2D
+#undef WG_LOAD3D
 #undef WG_STORE
 
   float* __restrict__ out = p.ws + ((int64_t)blockIdx.z * p.taps + t) * (int64_t)p.Cu * p.Cv;
