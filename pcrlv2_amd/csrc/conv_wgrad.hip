@@ -659,14 +659,28 @@ __global__ void __launch_bounds__(256, 2) wgrad_up2_alltaps_kernel(const WgradPa
 
   u32x4 ru, rv[8];
   bool live = false;
+  // the voxel coordinates of this thread's row are carried from K-step to K-step (+32 voxels) instead of decoded with divisions
+  int64_t um = mbeg + rowp;
+  int un, ud, uh, uw;
+  decode_voxel(um < p.M ? um : 0, g, un, ud, uh, uw);
+  const int us_w = 32 % g.W, us_h = (32 / g.W) % g.H, us_d = (32 / (g.W * g.H)) % g.D, us_n = 32 / (g.W * g.H * g.D);
+  int64_t vm0 = mbeg;
+  int vn0, vd0, vh0, vw0;   // coordinates of row mbeg (the stand-in for dead rows)
+  decode_voxel(mbeg < p.M ? mbeg : 0, g, vn0, vd0, vh0, vw0);
 #define WU_LOAD(ms_)                                                                            \
   do {                                                                                          \
-    const int64_t m_ = (ms_) + rowp;                                                            \
-    live = m_ < mend;                                                                           \
-    const int64_t m = live ? m_ : mbeg;                                                         \
+    live = um < mend;                                                                           \
+    const int64_t m = live ? um : vm0;                                                          \
     ru = *reinterpret_cast<const u32x4*>(U + m * p.Cu + i0 + ucol);                             \
-    int n, d, h, w;                                                                             \
-    decode_voxel(m, g, n, d, h, w);                                                             \
+    const int n = live ? un : vn0, d = live ? ud : vd0, h = live ? uh : vh0, w = live ? uw : vw0; \
+    um += 32;                                                                                   \
+    uw += us_w;                                                                                 \
+    if (uw >= g.W) { uw -= g.W; uh += 1; }                                                      \
+    uh += us_h;                                                                                 \
+    if (uh >= g.H) { uh -= g.H; ud += 1; }                                                      \
+    ud += us_d;                                                                                 \
+    if (ud >= g.D) { ud -= g.D; un += 1; }                                                      \
+    un += us_n;                                                                                 \
     const bf16* v0 = V + up2_row(n, d, h, w, 0, g) * p.Cv + j0 + ucol;                          \
     _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                             \
       const int64_t dlt = ((int64_t)(t >> 2) * (2 * g.H) + ((t >> 1) & 1)) * (2 * g.W) + (t & 1); \
