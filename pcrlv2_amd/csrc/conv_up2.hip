@@ -31,6 +31,7 @@ struct Up2Params {
   int64_t M;
   int K, Nc;
   int tiles_per_block;   // column tiles (tap, 64 channels) handled by one block (grid.y splits the 8 * Nc / 64 tiles)
+  int nt;                // non-temporal stores: the output is a stream far larger than the caches
 };
 
 // Weight tile rows are 256 B = 16 slots of 16 B; a fragment read takes 16 consecutive rows at slots {s, s+1}: XOR the slot
@@ -141,8 +142,13 @@ __global__ void __launch_bounds__(256) convt_up2_fwd_kernel(const Up2Params p) {
         for (int r = 0; r < 4; ++r) o.h[j * 4 + r] = (bf16)(acc[f][j][r] + bv[j * 4 + r]);
       if (vok[f]) {
         bf16* dst = p.y + (orow[f] + tdelta) * Nc + c0;
-        *reinterpret_cast<u32x4*>(dst) = o.v[0];
-        *reinterpret_cast<u32x4*>(dst + 8) = o.v[1];
+        if (p.nt) {   // block-uniform: y is written once and far larger than L2 + MALL (common.h: pcrl_streaming)
+          __builtin_nontemporal_store(o.v[0], reinterpret_cast<u32x4*>(dst));
+          __builtin_nontemporal_store(o.v[1], reinterpret_cast<u32x4*>(dst + 8));
+        } else {
+          *reinterpret_cast<u32x4*>(dst) = o.v[0];
+          *reinterpret_cast<u32x4*>(dst + 8) = o.v[1];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[f][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -171,7 +177,7 @@ int pcrl_convt_up2_launch(const void* x, const void* wp, const float* bias, void
   const int64_t mblocks = (M + UM - 1) / UM;
   int split = 1;   // small volumes: spread the column tiles over grid.y (x is then read `split` times -- it is small)
   while (mblocks * split < 768 && split * 2 <= ntiles && ntiles % (split * 2) == 0) split *= 2;
-  Up2Params p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, Dims{N, D, H, W}, M, Ci, Co, ntiles / split};
+  Up2Params p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, Dims{N, D, H, W}, M, Ci, Co, ntiles / split, pcrl_streaming(M * 8 * Co * 2) ? 1 : 0};
   const dim3 grid((unsigned)mblocks, (unsigned)split);
   if (Ci == 128) return launch<1>(p, grid, stream);
   if (Ci == 256) return launch<2>(p, grid, stream);
