@@ -139,6 +139,11 @@ def main():
     for _ in range(args.warmup):
         train_step(model, opt, batch, 0, crit, cosine, guard=False)
     L = _lib.lib()
+    # same-box A/B of launch variants (tools/conv_probe.py documents the codes); not used by the default run
+    if os.environ.get("PCRL_DEBUG_CONV_IMPL"):
+        L.debug_set_conv_impl(int(os.environ["PCRL_DEBUG_CONV_IMPL"]))
+    if os.environ.get("PCRL_DEBUG_WGRAD_IMPL"):
+        L.debug_set_wgrad_impl(int(os.environ["PCRL_DEBUG_WGRAD_IMPL"]))
     prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad"}, keyfn)
     import gc
     gc.collect()

@@ -44,6 +44,8 @@ struct BrickParams {
   int N, D, H, W;
   int K, Nc;
   int up;             // KD = 1 only: the source is [N][D][H/2][W/2] read through a nearest x2 upsample (conv2d.hip)
+  int ny;             // > 0: 1-D grid of bricks x ny ids, the ny output-channel tiles of a brick on consecutive slots of ONE XCD (they
+                      // stage the same halo: fetched into that L2 once); 0: 2-D grid (bricks, tiles)
 };
 
 // Weight tile [64 co][32 k]: a fragment read takes 16 CONSECUTIVE rows -> same swizzle as conv_igemm.hip's Tile<bf16>.
@@ -74,14 +76,26 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;   // wave = 64 voxels x all 64 output channels
   const int lr = lane & 15, lg = lane >> 4;
   const int K = p.K, nchunk = K / 32;
-  const int n0 = blockIdx.y * BN;
 
   // ---- brick origin ----
   const int bw = p.W / TW, bh = p.H / TH, bd = p.D / TD;
   // consecutive workgroups go to different XCDs (8, each with its own L2): give every XCD a CONTIGUOUS range of bricks so that
   // the halo rows shared by neighbouring bricks are fetched into one L2 once
-  int b = blockIdx.x;
-  if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+  int b = blockIdx.x, ytile = blockIdx.y;
+  if (p.ny > 0) {
+    const int nbr = gridDim.x / p.ny;
+    if ((nbr & 7) == 0) {
+      const int slot = b >> 3;
+      ytile = slot % p.ny;
+      b = (b & 7) * (nbr >> 3) + slot / p.ny;
+    } else {
+      ytile = b % p.ny;
+      b = b / p.ny;
+    }
+  } else if ((gridDim.x & 7) == 0) {
+    b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+  }
+  const int n0 = ytile * BN;
   const int brick_id = b;
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
@@ -318,6 +332,9 @@ bool pcrl_brick_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dt
 }
 int64_t pcrl_brick_conv_rows(int N, int D, int H, int W) { return (int64_t)N * (D / TD) * (H / TH) * (W / TW); }
 
+static int g_brick_ymap = 1;
+void pcrl_brick_conv_set_ymap(int on) { g_brick_ymap = on; }
+
 int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                            int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
   constexpr int HB = BrickGeom<3>::HALO_BYTES;
@@ -327,10 +344,16 @@ int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, voi
     hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, HB + 3 * 32 * 64);
     attr_set = true;
   }
-  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0};
+  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0, 0};
   const unsigned bricks = (unsigned)pcrl_brick_conv_rows(N, D, H, W);
-  if (Co % 64 == 0) hipLaunchKernelGGL((brick_conv_kernel<64, 3>), dim3(bricks, Co / 64), dim3(256), HB + 3 * 64 * 64, stream, p);
-  else hipLaunchKernelGGL((brick_conv_kernel<32, 3>), dim3(bricks, Co / 32), dim3(256), HB + 3 * 32 * 64, stream, p);
+  const int BN = Co % 64 == 0 ? 64 : 32, ny = Co / BN;
+  dim3 grid(bricks, ny);
+  if (g_brick_ymap && ny > 1 && (uint64_t)bricks * ny < (1u << 31)) {
+    p.ny = ny;
+    grid = dim3(bricks * ny);
+  }
+  if (BN == 64) hipLaunchKernelGGL((brick_conv_kernel<64, 3>), grid, dim3(256), HB + 3 * 64 * 64, stream, p);
+  else hipLaunchKernelGGL((brick_conv_kernel<32, 3>), grid, dim3(256), HB + 3 * 32 * 64, stream, p);
   return pcrl_check_launch("brick_conv");
 }
 
@@ -344,7 +367,7 @@ int64_t pcrl_brick_conv2d_rows(int N, int H, int W) { return (int64_t)(N / TD) *
 int pcrl_brick_conv2d_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Ci, int Co, int up,
                              hipStream_t stream) {
   constexpr int HB = BrickGeom<1>::HALO_BYTES;
-  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, 1, N, H, W, Ci, Co, up};
+  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, 1, N, H, W, Ci, Co, up, 0};
   const unsigned bricks = (unsigned)pcrl_brick_conv2d_rows(N, H, W);
   if (Co % 64 == 0) hipLaunchKernelGGL((brick_conv_kernel<64, 1>), dim3(bricks, Co / 64), dim3(256), HB + 3 * 64 * 64, stream, p);
   else hipLaunchKernelGGL((brick_conv_kernel<32, 1>), dim3(bricks, Co / 32), dim3(256), HB + 3 * 32 * 64, stream, p);

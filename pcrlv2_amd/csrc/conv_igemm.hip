@@ -443,7 +443,13 @@ bool pcrl_convt_up2_eligible(int Ci, int Co, int dtype);   // conv_up2.hip
 int pcrl_convt_up2_launch(const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Ci, int Co,
                           hipStream_t stream);
 static int g_conv_impl = 0;  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
-extern "C" void pcrl_debug_set_conv_impl(int impl) { g_conv_impl = impl; }
+void pcrl_brick_conv_set_ymap(int on);
+// 0 = auto (brick kernel where eligible), 1 = always the gather kernel, 2 = gather kernel without split-K,
+// 3 = brick kernel on its 2-D grid (channel tiles of a brick not co-located)
+extern "C" void pcrl_debug_set_conv_impl(int impl) {
+  g_conv_impl = impl == 3 ? 0 : impl;
+  pcrl_brick_conv_set_ymap(impl != 3);
+}
 int pcrl_debug_conv_impl() { return g_conv_impl; }
 
 extern "C" int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype) {

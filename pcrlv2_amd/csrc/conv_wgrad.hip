@@ -840,9 +840,15 @@ extern "C" void pcrl_debug_set_wgrad_tr(int on) { g_wgrad_tr = on; }
 bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);
 int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co);
 int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
+int pcrl_wgrad_brick_slabs(int N, int D, int H, int W, int Ci, int Co);   // partial slabs the launch writes (<= pcrl_wgrad_brick_splits)
+void pcrl_wgrad_brick_set_xcd(int on, int order);
 
-static int g_wgrad_impl = 0;  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
-extern "C" void pcrl_debug_set_wgrad_impl(int impl) { g_wgrad_impl = impl; }
+static int g_wgrad_impl = 0;  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel, 2 = brick kernel on its 2-D grid (no XCD co-location)
+extern "C" void pcrl_debug_set_wgrad_impl(int impl) {
+  // experiments: 4 = co-located launch with the old walk order, 5 = 2-D grid with the new walk order
+  g_wgrad_impl = impl == 1 ? 1 : 0;
+  pcrl_wgrad_brick_set_xcd(impl == 0 || impl == 4, impl == 0 || impl == 5);
+}
 
 extern "C" size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
   const SplitPlan sp = plan_splits((int64_t)N * D * H * W, Co, Ci, 27);
@@ -859,7 +865,7 @@ extern "C" int pcrl_conv3d_k3_wgrad(const void* x, const void* dy, float* dw_ref
   PCRL_REQUIRE(x && dy && dw_ref, "conv3d_k3_wgrad: null pointer");
   PCRL_REQUIRE(Ci > 0 && Co > 0 && Ci % 32 == 0 && Co % 32 == 0, "conv3d_k3_wgrad: channels must be multiples of 32 (Ci=%d Co=%d)", Ci, Co);
   if (g_wgrad_impl == 0 && pcrl_wgrad_brick_eligible(N, D, H, W, Ci, Co, dtype)) {
-    const int splits = pcrl_wgrad_brick_splits(N, D, H, W, Ci, Co);
+    const int splits = pcrl_wgrad_brick_slabs(N, D, H, W, Ci, Co);
     const size_t need = (size_t)splits * 27 * Co * Ci * sizeof(float);
     if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_k3_wgrad: workspace %zu < %zu", ws_bytes, need);
     if (int e = pcrl_wgrad_brick_launch(x, dy, (float*)ws, N, D, H, W, Ci, Co, as_stream(stream))) return e;

@@ -55,6 +55,12 @@ struct WBrickParams {
   int up;           // nkd = 1 only: x is [D][H/2][W/2][Cv] read through a nearest x2 upsample (decoder conv1 of the 2D path)
   int nkd;          // 3: the 3x3x3 convolution (blockIdx.y = tile * 3 + kd); 1: a 3x3 convolution over a stack of images (2D path:
                     // the image index is d and only the centre plane kd = 1 exists; slabs hold 9 taps)
+  // XCD co-located launch (nkd = 3, see plan_xcd()): a 1-D grid in chunks of 256 ids; the G = 3 * gs blocks that walk the SAME brick
+  // range (three kd planes x gs tiles) get ids that are congruent mod 8, i.e. run on one XCD at the same time, so that the dy tile and
+  // the overlapping x planes of a brick are fetched into that XCD's L2 once and hit there G - 1 times.  0 = the 2-D grid above.
+  int xcd_map;
+  int order;        // brick walk order: 0 = w, h, d, n ; 1 = w, d, h, n
+  int G, Q, gpc, ngroups, ntg, pair;   // group size, groups per XCD and chunk, groups per chunk, groups, tile groups per range, 0 none / 1 pair over j / 2 pair over i
 };
 
 __device__ __forceinline__ int dy_off(int v, int col) {   // 128-byte rows, 32-byte quads XOR-swizzled (see conv_wgrad.hip)
@@ -79,10 +85,32 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
   const int tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, grp = tid >> 8;
   const int lg = lane >> 4, jr = (lane & 15) >> 2, cq = lane & 3;
   const int ntj = p.Cv / 64 > 0 ? (p.Cv + 63) / 64 : 1;
-  const int kd = p.nkd == 3 ? blockIdx.y % 3 : 1;
-  const int tile = blockIdx.y / p.nkd;
+  int kd, tile, split;
+  if (p.xcd_map) {
+    const int id = blockIdx.x, chunk = id >> 8, r = id & 255, QG8 = 8 * p.Q * p.G;
+    int rank, m;   // rank of the block's group inside its chunk (filled XCD by XCD in rounds, so a part-filled chunk stays balanced); member
+    if (r < QG8) {
+      const int slot = r >> 3;
+      rank = (slot / p.G) * 8 + (r & 7);
+      m = slot % p.G;
+    } else {       // the 16 ids of a chunk that do not make whole co-located groups: plain groups of consecutive ids
+      rank = 8 * p.Q + (r - QG8) / p.G;
+      m = (r - QG8) % p.G;
+      if (rank >= p.gpc) return;
+    }
+    const int g = chunk * p.gpc + rank;
+    if (g >= p.ngroups) return;
+    split = g / p.ntg;
+    const int tg = g % p.ntg, sub = m / 3;
+    kd = m % 3;
+    tile = p.pair == 0 ? tg : p.pair == 1 ? 2 * tg + sub : (2 * (tg / ntj) + sub) * ntj + tg % ntj;
+  } else {
+    kd = p.nkd == 3 ? blockIdx.y % 3 : 1;
+    tile = blockIdx.y / p.nkd;
+    split = blockIdx.x;
+  }
   const int i0 = (tile / ntj) * 64, j0 = (tile % ntj) * 64;
-  const int b_beg = blockIdx.x * p.per_split;
+  const int b_beg = split * p.per_split;
   const int b_end = min(b_beg + p.per_split, p.nbricks);
   const int bw = p.W / BW, bh = p.H / BH, bd = p.D / BD;
   const int Hs = p.up ? p.H >> 1 : p.H, Ws = p.up ? p.W >> 1 : p.W;   // extents of x as stored
@@ -136,10 +164,17 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
   // three divisions and three remainders per brick sat in front of the MFMA steps, unhidden (one wave per SIMD issues in order).
   int ob = b_beg, ow0, oh0, od0, on;
   {
+    // walk order: w, h, d, n -- or, with the co-located launch, w, d, h, n: the kd blocks of a group read x planes d0 + kd - 1 and
+    // d0 + kd, so a plane is read again by the next brick in d; with d second-fastest that is bw bricks later (an L2 hit), not bw * bh.
     int t_ = b_beg;
     ow0 = (t_ % bw) * BW; t_ /= bw;
-    oh0 = (t_ % bh) * BH; t_ /= bh;
-    od0 = (t_ % bd) * BD; t_ /= bd;
+    if (p.order) {
+      od0 = (t_ % bd) * BD; t_ /= bd;
+      oh0 = (t_ % bh) * BH; t_ /= bh;
+    } else {
+      oh0 = (t_ % bh) * BH; t_ /= bh;
+      od0 = (t_ % bd) * BD; t_ /= bd;
+    }
     on = t_;
   }
 #define WB_ORIGIN_NEXT()                                                                                     \
@@ -150,13 +185,25 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
       ow0 += BW;                                                                                             \
       if (ow0 == p.W) {                                                                                      \
         ow0 = 0;                                                                                             \
-        oh0 += BH;                                                                                           \
-        if (oh0 == p.H) {                                                                                    \
-          oh0 = 0;                                                                                           \
+        if (p.order) {                                                                                       \
           od0 += BD;                                                                                         \
           if (od0 == p.D) {                                                                                  \
             od0 = 0;                                                                                         \
-            ++on;                                                                                            \
+            oh0 += BH;                                                                                       \
+            if (oh0 == p.H) {                                                                                \
+              oh0 = 0;                                                                                       \
+              ++on;                                                                                          \
+            }                                                                                                \
+          }                                                                                                  \
+        } else {                                                                                             \
+          oh0 += BH;                                                                                         \
+          if (oh0 == p.H) {                                                                                  \
+            oh0 = 0;                                                                                         \
+            od0 += BD;                                                                                       \
+            if (od0 == p.D) {                                                                                \
+              od0 = 0;                                                                                       \
+              ++on;                                                                                          \
+            }                                                                                                \
           }                                                                                                  \
         }                                                                                                    \
       }                                                                                                      \
@@ -300,7 +347,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     if (grp == 1) return;
   }
   // D[i][j]: lane holds i = 16 f + 4 lg + r, j = lane & 15
-  float* out = p.ws + (int64_t)blockIdx.x * (9 * p.nkd) * p.Cu * p.Cv;
+  float* out = p.ws + (int64_t)split * (9 * p.nkd) * p.Cu * p.Cv;
   const int j = j0 + wid * 16 + (lane & 15);
   if (j < p.Cv) {
 #pragma unroll
@@ -316,6 +363,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 
 struct BrickSplit {
   int splits, per_split;
+  int xcd_map, G, Q, gpc, ngroups, ntg, pair, blocks;   // co-located launch (see WBrickParams); blocks = grid size
 };
 BrickSplit plan(int nbricks, int Cu, int Cv, int nkd = 3) {
   const int tiles = (Cu / 64) * ((Cv + 63) / 64) * nkd;
@@ -331,8 +379,40 @@ BrickSplit plan(int nbricks, int Cu, int Cv, int nkd = 3) {
   if (splits < 1) splits = 1;
   const int per = (nbricks + splits - 1) / splits;
   splits = (nbricks + per - 1) / per;
-  return BrickSplit{splits, per};
+  return BrickSplit{splits, per, 0, 0, 0, 0, 0, 0, 0, splits * tiles};
 }
+
+// Co-located plan (3x3x3 only).  Groups of G = 3 (kd) x gs (tiles) blocks share a brick range; gs = 2 pairs the two tiles that
+// share the larger operand stream when the tile grid allows it.  A chunk of 256 ids holds 8 * Q co-located groups (Q = 32 / G per
+// XCD: 30 of its 32 CUs) plus (256 - 8 Q G) / G groups of consecutive ids on the 16 CUs left over.
+BrickSplit plan_xcd(int nbricks, int Cu, int Cv) {
+  const int ni = Cu / 64, ntj = (Cv + 63) / 64, ntiles = ni * ntj;
+  // fabric bytes ~ 1.25 X ni + Y ntj without pairing (X = |x|, Y = |dy|, a block reads X / ntj and Y / ni); pairing over i halves the x
+  // term, pairing over j the dy term
+  const double X = 1.25 * Cv * ni, Y = 1.0 * Cu * ntj;
+  int pair = 0;
+  if (ni % 2 == 0 && ntj % 2 == 0) pair = X >= Y ? 2 : 1;
+  else if (ni % 2 == 0) pair = 2;
+  else if (ntj % 2 == 0) pair = 1;
+  const int gs = pair ? 2 : 1, G = 3 * gs, Q = 32 / G, gpc = 8 * Q + (256 - 8 * Q * G) / G, ntg = ntiles / gs;
+  int splits = 1, k = 1;
+  for (k = 1; k <= 3; ++k) {
+    splits = k * gpc / ntg;
+    if (splits >= 1 && splits * ntg * 10 >= k * gpc * 9) break;
+  }
+  if (k > 3) k = 3;
+  if (splits < 1) splits = 1;
+  if (splits > nbricks / 16) splits = nbricks / 16;
+  if (splits < 1) splits = 1;
+  const int per = (nbricks + splits - 1) / splits;
+  splits = (nbricks + per - 1) / per;
+  const int ngroups = splits * ntg, chunks = (ngroups + gpc - 1) / gpc;
+  return BrickSplit{splits, per, 1, G, Q, gpc, ngroups, ntg, pair, chunks * 256};
+}
+int g_wb_xcd = 1;   // 0: the 2-D grid (a (tile, kd) block range per blockIdx.y)
+int g_wb_order = 1;
+
+BrickSplit plan3(int nbricks, int Cu, int Cv) { return g_wb_xcd ? plan_xcd(nbricks, Cu, Cv) : plan(nbricks, Cu, Cv); }
 
 }  // namespace
 
@@ -342,8 +422,13 @@ bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int d
          (int64_t)N * D * H * W / BV < (1 << 30);
 }
 int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co) {
-  return plan((int)((int64_t)N * D * H * W / BV), Co, Ci).splits;
+  // the workspace must hold the partial slabs of either launch form
+  const int nb = (int)((int64_t)N * D * H * W / BV);
+  const int a = plan(nb, Co, Ci).splits, b = plan_xcd(nb, Co, Ci).splits;
+  return a > b ? a : b;
 }
+int pcrl_wgrad_brick_slabs(int N, int D, int H, int W, int Ci, int Co) { return plan3((int)((int64_t)N * D * H * W / BV), Co, Ci).splits; }
+void pcrl_wgrad_brick_set_xcd(int on, int order) { g_wb_xcd = on; g_wb_order = order; }
 int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co,
                             hipStream_t stream) {
   static bool attr_set = false;
@@ -353,9 +438,10 @@ int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int
     attr_set = true;
   }
   const int nbricks = (int)((int64_t)N * D * H * W / BV);
-  const BrickSplit sp = plan(nbricks, Co, Ci);
-  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 0, 3};
+  const BrickSplit sp = plan3(nbricks, Co, Ci);
+  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 0, 3, sp.xcd_map, g_wb_order, sp.G, sp.Q, sp.gpc, sp.ngroups, sp.ntg, sp.pair};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64) * 3));
+  if (sp.xcd_map) grid = dim3((unsigned)sp.blocks);
   hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(NT), lds, stream, p);
   return pcrl_check_launch("wgrad_brick");
 }
@@ -376,7 +462,7 @@ int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, i
   }
   const int nbricks = (int)((int64_t)N * H * W / BV);
   const BrickSplit sp = plan(nbricks, Co, Ci, 1);
-  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, up, 1};
+  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, up, 1, 0, 0, 0, 0, 0, 0, 0, 0};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64)));
   hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(NT), lds, stream, p);
   return pcrl_check_launch("wgrad_brick2d");

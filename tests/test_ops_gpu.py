@@ -54,6 +54,10 @@ SHAPES3 = [  # N, D, H, W, Ci, Co   (M deliberately not a multiple of 128 in the
     (3, 6, 5, 7, 32, 64), (2, 4, 4, 4, 64, 32), (1, 8, 8, 4, 64, 128), (2, 2, 2, 2, 128, 256), (1, 16, 8, 8, 32, 64),
     # shapes served by the LDS-halo brick kernel in bf16 (D%4 == H%8 == W%8 == 0): edge bricks in every direction
     (2, 8, 16, 8, 64, 64), (1, 4, 8, 16, 96, 128), (3, 4, 8, 8, 32, 64), (1, 12, 24, 16, 64, 64), (2, 2, 8, 8, 128, 64),
+    # several channel tiles: the XCD co-located launches (output-channel tiles of a brick in conv_brick.hip; kd planes x tile pairs of a
+    # brick range in wgrad_brick.hip: pairing over ci tiles, over co tiles, both possible) and more than one brick range
+    (2, 8, 16, 16, 64, 128), (2, 8, 16, 16, 128, 64), (1, 8, 16, 16, 128, 128), (1, 8, 16, 16, 64, 192), (3, 16, 16, 16, 32, 64),
+    (1, 4, 16, 16, 256, 128),
 ]
 
 
@@ -90,8 +94,9 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
     check(dx, xr.grad, dt, "conv3 dgrad")
     # weight gradient (float32 out in both modes): both bf16 fragment-fetch paths
     nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
-    # impl 0 = auto (LDS-halo brick kernel where eligible), 1 = gather kernel; tr = bf16 fragment fetch of the gather kernel
-    for impl, tr in (((0, 1), (1, 1), (1, 0)) if dt == torch.bfloat16 else ((0, 1),)):
+    # impl 0 = auto (LDS-halo brick kernel where eligible, XCD co-located launch), 2 = the brick kernel on its plain 2-D grid,
+    # 1 = gather kernel; tr = bf16 fragment fetch of the gather kernel
+    for impl, tr in (((0, 1), (2, 1), (1, 1), (1, 0)) if dt == torch.bfloat16 else ((0, 1),)):
         L.debug_set_wgrad_impl(impl)
         L.debug_set_wgrad_tr(tr)
         dw = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float32, device=DEV)
@@ -107,6 +112,14 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
     L.debug_set_conv_impl(0)
     check(y, ref, dt, "conv3 fwd (gather kernel)")
     check(back(part1).view(rows1, Co, 2).sum(0)[:, 0], ref.sum(dim=(0, 2, 3, 4)), dt, "conv3 stats (gather)", out_rounded=False, f32_tol=1e-4)
+    if dt == torch.bfloat16 and Co > 64:   # the brick kernel on its 2-D grid (impl 3): bit-identical to the co-located launch
+        y3 = ops.new_act(N, D, H, W, Co, dt, DEV)
+        part3 = torch.zeros(rows * Co * 2, dtype=torch.float32, device=DEV)
+        L.debug_set_conv_impl(3)
+        L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y3, part3, N, D, H, W, Ci, Co, dtype_code(dt), s)
+        L.debug_set_conv_impl(0)
+        L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y, part, N, D, H, W, Ci, Co, dtype_code(dt), s)
+        assert torch.equal(y3, y) and torch.equal(part3, part)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

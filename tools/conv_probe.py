@@ -26,28 +26,39 @@ LAYERS = [  # name, Ci, Co, (D, H, W) for 64x64x32 inputs
 ]
 
 
-def timed(fn, rounds):
-    fn()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(rounds):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+def timed_ab(fns, rounds, inner=3):
+    """Interleaved A/B: every round runs each variant (its setup, then `inner` back-to-back calls between two events).
+    -> [(median ms per call, min ms per call)] per variant."""
+    ts = [[] for _ in fns]
+    for setup, fn in fns:
+        setup()
         fn()
-        e1.record()
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    ts.sort()
-    return ts[len(ts) // 2], ts[0]
+    torch.cuda.synchronize()
+    for _ in range(rounds):
+        for k, (setup, fn) in enumerate(fns):
+            setup()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(inner):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ts[k].append(e0.elapsed_time(e1) / inner)
+    out = []
+    for t in ts:
+        t.sort()
+        out.append((t[len(t) // 2], t[0]))
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--b", type=int, default=32)
-    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--rounds", type=int, default=9)
     ap.add_argument("--what", default="fwd,dgrad,wgrad")
     ap.add_argument("--layers", default="")
-    ap.add_argument("--impls", default="0,1")
+    ap.add_argument("--impls", default="0,1", help="fwd / dgrad: 0 auto (brick kernel, co-located channel tiles), 1 gather, 3 brick kernel on its 2-D grid")
+    ap.add_argument("--wimpls", default="0,1", help="wgrad: 0 auto (brick kernel, XCD co-located launch), 1 gather, 2 brick kernel on its 2-D grid")
     ap.add_argument("--fill", default="randn", choices=["randn", "zeros", "ones", "relu"], help="operand data (power is data dependent)")
     args = ap.parse_args()
     L, dev, dt = lib(), torch.device("cuda"), torch.bfloat16
@@ -78,31 +89,34 @@ def main():
         line = f"{name:10s} Ci={Ci:3d} Co={Co:3d} {D}x{H}x{W} M={M:8d} {flops / 1e9:8.1f} GF |"
         for kind in what:
             if kind in ("fwd", "dgrad"):
+                fns = []
                 for impl in impls:
                     L.debug_set_conv_impl(impl)
                     if kind == "fwd":
                         nbf = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dt))
                         wsf = ops.workspace(nbf, dev) if nbf else None
-                        fn = lambda: L.call("pcrl_conv3d_k3_fwd_ws", x, wf, None, y, st, wsf, nbf, N, D, H, W, Ci, Co, dtype_code(dt), s)
+                        fn = lambda wsf=wsf, nbf=nbf: L.call("pcrl_conv3d_k3_fwd_ws", x, wf, None, y, st, wsf, nbf, N, D, H, W, Ci, Co, dtype_code(dt), s)
                     else:
                         nbd = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Co, Ci, dtype_code(dt))
                         wsd = ops.workspace(nbd, dev) if nbd else None
-                        fn = lambda: L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, None, wsd, nbd, N, D, H, W, Co, Ci, dtype_code(dt), s)
-                    med, mn = timed(fn, args.rounds)
+                        fn = lambda wsd=wsd, nbd=nbd: L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, None, wsd, nbd, N, D, H, W, Co, Ci, dtype_code(dt), s)
+                    fns.append((lambda impl=impl: L.debug_set_conv_impl(impl), fn))
+                res = timed_ab(fns, args.rounds)
+                L.debug_set_conv_impl(0)
+                for impl, (med, mn) in zip(impls, res):
                     line += f" {kind}[{impl}] {med:7.3f} ms {flops / med / 1e9:6.0f} TF |"
                     tot[(kind, impl)] = tot.get((kind, impl), 0.0) + med
-                L.debug_set_conv_impl(0)
             elif kind == "wgrad":
                 nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
                 ws = ops.workspace(nb, dev)
                 dw = torch.empty_like(w)
                 fn = lambda: L.call("pcrl_conv3d_k3_wgrad", x, dy, dw, ws, nb, N, D, H, W, Ci, Co, dtype_code(dt), s)
-                for impl in impls:
-                    L.debug_set_wgrad_impl(impl)
-                    med, mn = timed(fn, args.rounds)
+                wimpls = [int(v) for v in args.wimpls.split(",")]
+                res = timed_ab([(lambda impl=impl: L.debug_set_wgrad_impl(impl), fn) for impl in wimpls], args.rounds)
+                L.debug_set_wgrad_impl(0)
+                for impl, (med, mn) in zip(wimpls, res):
                     line += f" wgrad[{impl}] {med:7.3f} ms {flops / med / 1e9:6.0f} TF |"
                     tot[("wgrad", impl)] = tot.get(("wgrad", impl), 0.0) + med
-                L.debug_set_wgrad_impl(0)
         print(line, flush=True)
     print("totals (ms, one pass over the listed layers):", {f"{k[0]}[{k[1]}]": round(v, 2) for k, v in tot.items()})
 
