@@ -105,6 +105,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, torchrun rendezvous on
+        # 127.0.0.1), as pcrlv2_amd/main.py does for `--gpus 0,1,..`.  Rank 0 of the children prints the JSON line.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
+
     from pcrlv2_amd import _lib, ddp
     from pcrlv2_amd.models import PCRLv23d
     from pcrlv2_amd.optim import FusedSGD
@@ -117,8 +129,28 @@ def main():
         rank, world, local_rank = ddp.init_process_group_from_env(os.environ.get("PCRL_DIST_BACKEND", "nccl"))
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    # several ranks on fewer GPUs (PCRL_DIST_BACKEND=gloo on a one-GPU box): ranks share devices round-robin
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist_info = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = dist.get_backend()
+        # every rank reports its device; rank 0 keeps the table (proof that N ranks on N devices took part in the timed region)
+        mine = {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)}
+        table = [None] * world
+        dist.all_gather_object(table, mine)
+        ver = None
+        if backend == "nccl":
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = "unknown"
+        dist_info = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": ver, "world_size": dist.get_world_size(),
+                     "visible_devices": ndev, "ranks": table}
+        print(f"[bench] rank {rank}/{world} on cuda:{local_rank} backend={backend}", file=sys.stderr)
     dhw = tuple(int(v) for v in args.dhw.split(","))
 
     torch.manual_seed(0)
@@ -136,14 +168,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        train_step(model, opt, batch, 0, crit, cosine, guard=False)
     L = _lib.lib()
     # same-box A/B of launch variants (tools/conv_probe.py documents the codes); not used by the default run
     if os.environ.get("PCRL_DEBUG_CONV_IMPL"):
         L.debug_set_conv_impl(int(os.environ["PCRL_DEBUG_CONV_IMPL"]))
     if os.environ.get("PCRL_DEBUG_WGRAD_IMPL"):
         L.debug_set_wgrad_impl(int(os.environ["PCRL_DEBUG_WGRAD_IMPL"]))
+    for _ in range(args.warmup):
+        train_step(model, opt, batch, 0, crit, cosine, guard=False)
     prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad"}, keyfn)
     import gc
     gc.collect()
@@ -214,6 +246,16 @@ def main():
                  "alloc_retries": ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
                  "reserved_GB": round(ms1.get("reserved_bytes.all.peak", 0) / 2**30, 1)},
     }
+    if dist_info is not None:
+        line["distributed"] = dist_info
+        line["per_gpu_value"] = round(crops / world, 2)
+        # relative to the committed one-GPU record of the same code, if there is one (the driver computes efficiency itself)
+        try:
+            one = json.load(open(os.path.join(ROOT, "profiles", "LATEST_BENCH.json")))
+            if one.get("n_gpus") == 1 and one.get("config", {}).get("workload") == line["config"]["workload"]:
+                line["scaling_vs_committed_1gpu"] = round(crops / one["value"], 3)
+        except Exception:
+            pass
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
     print(json.dumps(line))

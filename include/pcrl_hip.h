@@ -15,7 +15,9 @@
  *   - Every call is asynchronous on `stream`; nothing synchronises, allocates or frees.
  *     The caller owns all memory, including workspaces (sizes from the *_ws_bytes helpers).
  *   - Returns 0 on success, a negative PCRL_E* code on failure; pcrl_last_error() returns a
- *     thread-local message.  Nothing throws across the ABI.  Re-entrant: no mutable globals.
+ *     thread-local message.  Nothing throws across the ABI.  Re-entrant: the entry points keep no mutable state of their own;
+ *     the only process-wide state is the set of kernel-selection switches of the "Test hooks" section at the end of this
+ *     header (std::atomic<int>, defaults = the product path; tests and probes flip them to A/B the kernels behind one entry point).
  *   - Reductions are deterministic (two-stage, fixed order; no floating-point atomics).
  */
 #ifndef PCRL_HIP_H
@@ -279,6 +281,21 @@ int pcrl_relu_mask_bwd(const void* da, const void* a, void* g, int64_t n, int dt
  * g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
 int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
                   int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Test hooks (NOT part of the drop-in surface; process-wide atomics, default 0 / tr 1 = the product path).  They select which
+ * of the kernels behind one entry point runs, so that tests can check every kernel against the same reference and probes can
+ * time them against each other inside one process (tools/conv_probe.py).
+ *   conv  impl: 0 auto (LDS-halo brick kernel where eligible, co-located launch), 1 gather kernel, 2 gather kernel without
+ *               split-K, 3 brick kernel on its plain 2-D grid
+ *   wgrad impl: 0 auto (brick kernel where eligible, XCD co-located launch), 1 gather kernel, 2 brick kernel on its plain 2-D grid,
+ *               4 / 5 co-located launch with the old walk order / plain grid with the new walk order (experiments)
+ *   wgrad tr  : bf16 fragment fetch of the gather weight-gradient kernel: 1 ds_read_b64_tr_b16, 0 scalar LDS reads
+ *   conv2d impl: 0 auto (brick / narrow kernels where eligible), 1 gather kernel */
+void pcrl_debug_set_conv_impl(int impl);
+void pcrl_debug_set_wgrad_impl(int impl);
+void pcrl_debug_set_wgrad_tr(int on);
+void pcrl_debug_set_conv2d_impl(int impl);
 
 #ifdef __cplusplus
 }

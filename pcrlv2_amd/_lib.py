@@ -26,7 +26,7 @@ _CTYPES = {
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "float": ctypes.c_float,
     "double": ctypes.c_double, "pcrl_stream_t": ctypes.c_void_p,
 }
-_RET = {"int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}
+_RET = {"void": None, "int": ctypes.c_int, "int64_t": ctypes.c_int64, "size_t": ctypes.c_size_t, "const char*": ctypes.c_char_p}
 
 
 def parse_header(path: str = HEADER):
@@ -34,7 +34,7 @@ def parse_header(path: str = HEADER):
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const char\*|int64_t|size_t|int)\s+(pcrl_\w+)\s*\(([^;{]*?)\)\s*;", src):
+    for m in re.finditer(r"(const char\*|int64_t|size_t|int|void)\s+(pcrl_\w+)\s*\(([^;{]*?)\)\s*;", src):
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         lst = []
         if args and args != "void":

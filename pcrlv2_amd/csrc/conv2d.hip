@@ -19,6 +19,8 @@
 // (padding needs zero-fill), two staging register sets.  Epilogue: + bias, store (T or float32, columns >= Nc masked), and the
 // per-tile (sum, sum^2) rows for the training-mode BatchNorm2d that follows.
 #include "common.h"
+#include "mma_tile.h"
+#include <atomic>
 
 namespace {
 
@@ -43,42 +45,6 @@ struct C2Params {
   int64_t M;
 };
 
-template <typename T> struct Tile {
-  static constexpr int ROWB = 32 * (int)sizeof(T);
-  static constexpr int SLOTS = ROWB / 16;
-  static constexpr int RPB = 256 / ROWB;
-  static __device__ __forceinline__ int off(int row, int slot) {
-    const int q = row / RPB;
-    const int key = (SLOTS == 4) ? ((0x78 >> ((q & 3) * 2)) & 3) : (q & (SLOTS - 1));
-    return row * ROWB + ((slot ^ key) << 4);
-  }
-};
-
-template <typename T> struct Mma;
-template <> struct Mma<bf16> {
-  using Frag = bf16x8;
-  static __device__ __forceinline__ Frag read(const char* tile, int row, int g) {
-    return *reinterpret_cast<const bf16x8*>(tile + Tile<bf16>::off(row, g));
-  }
-  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
-    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Mma<float> {
-  struct Frag { f32x4 lo, hi; };
-  static __device__ __forceinline__ Frag read(const char* tile, int row, int g) {
-    Frag f;
-    f.lo = *reinterpret_cast<const f32x4*>(tile + Tile<float>::off(row, 2 * g));
-    f.hi = *reinterpret_cast<const f32x4*>(tile + Tile<float>::off(row, 2 * g + 1));
-    return f;
-  }
-  static __device__ __forceinline__ void mma(const Frag& a, const Frag& b, f32x4& c) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[e], b.lo[e], c, 0, 0, 0);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[e], b.hi[e], c, 0, 0, 0);
-  }
-};
 
 // NSM > 0: burst variant for layers with at most NSM K-steps (16-channel layers at full resolution, the 1x1 / 3-channel heads): all
 // K-steps are loaded up front into NSM register sets, so a block waits for global memory once instead of once per step -- these
@@ -422,7 +388,7 @@ bool pcrl_conv2d_narrow_eligible(int N, int H, int W, int Cs, int Nc, int ks, in
 int64_t pcrl_conv2d_narrow_rows(int N, int H, int W);
 int pcrl_conv2d_narrow_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Cs, int Nc, int ks,
                               int up, int out_f32, hipStream_t stream);
-static int g_conv2d_impl = 0;   // 0 = auto (brick / narrow kernels where eligible), 1 = always the gather kernel
+static std::atomic<int> g_conv2d_impl{0};   // 0 = auto (brick / narrow kernels where eligible), 1 = always the gather kernel
 extern "C" void pcrl_debug_set_conv2d_impl(int impl) { g_conv2d_impl = impl; }
 
 extern "C" int64_t pcrl_conv2d_packed_elems(int rows, int taps, int Cs) {

@@ -16,6 +16,8 @@
 //      the next chunk is prefetched into registers during the last tap row -- + one weight stage (3 taps x 64 x 64 B =
 //      12 KiB, next stage prefetched into registers) -> 72 KiB, two blocks per CU.
 #include "common.h"
+#include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -332,18 +334,17 @@ bool pcrl_brick_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dt
 }
 int64_t pcrl_brick_conv_rows(int N, int D, int H, int W) { return (int64_t)N * (D / TD) * (H / TH) * (W / TW); }
 
-static int g_brick_ymap = 1;
+static std::atomic<int> g_brick_ymap{1};
 void pcrl_brick_conv_set_ymap(int on) { g_brick_ymap = on; }
 
 int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                            int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
   constexpr int HB = BrickGeom<3>::HALO_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;   // hipFuncSetAttribute once per process, race-free
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, HB + 3 * 64 * 64);
     hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, HB + 3 * 32 * 64);
-    attr_set = true;
-  }
+  });
   BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0, 0};
   const unsigned bricks = (unsigned)pcrl_brick_conv_rows(N, D, H, W);
   const int BN = Co % 64 == 0 ? 64 : 32, ny = Co / BN;

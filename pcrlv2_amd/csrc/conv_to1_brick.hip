@@ -12,6 +12,7 @@
 // thread gathers the 27 entries of its output voxel.  HBM traffic: the input once (+ halo overlap, mostly L2 hits) and 4 bytes
 // per voxel out.  The statistics row of the BatchNorm that follows is one (sum, sum^2) pair per brick.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -180,11 +181,10 @@ int pcrl_to1_brick_launch(const void* x, const float* w_ref, const float* bias, 
                           hipStream_t stream) {
   const int lds_w = HALO_BYTES + (C / 32) * 2048;
   const int lds = lds_w > Z_BYTES ? lds_w : Z_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::once_flag attr_once;   // hipFuncSetAttribute once per process, race-free
+  std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(to1_brick_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 16 * 2048);
-    attr_set = true;
-  }
+  });
   To1Params p{(const bf16*)x, w_ref, bias, y, stats, N, D, H, W, C};
   hipLaunchKernelGGL(to1_brick_fwd_kernel, dim3((unsigned)pcrl_to1_brick_rows(N, D, H, W)), dim3(256), lds, stream, p);
   return pcrl_check_launch("to1_brick_fwd");

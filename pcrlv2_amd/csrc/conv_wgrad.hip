@@ -16,6 +16,8 @@
 // Block = 64(i) x 64(j) result tile of ONE tap and ONE voxel split; 4 waves as 2x2, each 32x32
 // (2x2 fragments); K-step = 32 voxels, double-buffered register-staged LDS tiles.
 #include "common.h"
+#include <atomic>
+#include <mutex>
 
 namespace {
 
@@ -775,7 +777,7 @@ SplitPlan plan_splits(int64_t M, int Cu, int Cv, int taps) {
   return SplitPlan{(int)splits, steps_per * 32};
 }
 
-int g_wgrad_tr = 1;  // bf16 fragment fetch: 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
+std::atomic<int> g_wgrad_tr{1};  // bf16 fragment fetch: 1 = ds_read_b64_tr_b16, 0 = scalar LDS reads
 
 template <int GEOM>
 int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_bytes, Dims g, int Cu, int Cv, int taps,
@@ -843,7 +845,7 @@ int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int
 int pcrl_wgrad_brick_slabs(int N, int D, int H, int W, int Ci, int Co);   // partial slabs the launch writes (<= pcrl_wgrad_brick_splits)
 void pcrl_wgrad_brick_set_xcd(int on, int order);
 
-static int g_wgrad_impl = 0;  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel, 2 = brick kernel on its 2-D grid (no XCD co-location)
+static std::atomic<int> g_wgrad_impl{0};  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel, 2 = brick kernel on its 2-D grid (no XCD co-location)
 extern "C" void pcrl_debug_set_wgrad_impl(int impl) {
   // experiments: 4 = co-located launch with the old walk order, 5 = 2-D grid with the new walk order
   g_wgrad_impl = impl == 1 ? 1 : 0;
@@ -898,12 +900,11 @@ extern "C" int pcrl_convt3d_k2s2_wgrad(const void* x, const void* dy, float* dw_
     const SplitPlanUp2 sp = plan_up2(M, Ci, Co);
     const size_t need = (size_t)sp.splits * 8 * Co * Ci * sizeof(float);
     if (ws_bytes < need || !ws) return pcrl_fail(PCRL_EWORKSPACE, "convt3d_k2s2_wgrad: workspace %zu < %zu", ws_bytes, need);
-    static bool attr_set = false;
+    static std::once_flag attr_once;   // hipFuncSetAttribute once per process, race-free
     constexpr int LDS = 2 * 4096 + 2 * 8 * 4096;
-    if (!attr_set) {
+    std::call_once(attr_once, [&] {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_up2_alltaps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      attr_set = true;
-    }
+  });
     WgradParams p{x, dy, (float*)ws, Dims{N, D, H, W}, M, Ci, Co, 8, sp.chunk};
     hipLaunchKernelGGL(wgrad_up2_alltaps_kernel, dim3((unsigned)((Ci / 64) * (Co / 64)), (unsigned)sp.splits), dim3(256), LDS, as_stream(stream), p);
     if (int e = pcrl_check_launch("convt3d_k2s2_wgrad")) return e;

@@ -16,6 +16,8 @@
 // the current brick is multiplied (one barrier per brick).  Split-K over brick ranges; the
 // partial slabs are reduced in fixed order by the same second pass as the gather kernel.
 #include "common.h"
+#include <atomic>
+#include <mutex>
 
 // x-fragment prefetch distance in steps.  Two waves per SIMD (NG = 2) hide the LDS latency between them: 1 is enough and leaves the
 // kernel at 256 registers without spills (3 spilled 14 registers into the step loop: 690 instead of 1 090 TFLOP/s); NG = 1 wants 3.
@@ -409,8 +411,8 @@ BrickSplit plan_xcd(int nbricks, int Cu, int Cv) {
   const int ngroups = splits * ntg, chunks = (ngroups + gpc - 1) / gpc;
   return BrickSplit{splits, per, 1, G, Q, gpc, ngroups, ntg, pair, chunks * 256};
 }
-int g_wb_xcd = 1;   // 0: the 2-D grid (a (tile, kd) block range per blockIdx.y)
-int g_wb_order = 1;
+std::atomic<int> g_wb_xcd{1};   // 0: the 2-D grid (a (tile, kd) block range per blockIdx.y)
+std::atomic<int> g_wb_order{1};
 
 BrickSplit plan3(int nbricks, int Cu, int Cv) { return g_wb_xcd ? plan_xcd(nbricks, Cu, Cv) : plan(nbricks, Cu, Cv); }
 
@@ -431,12 +433,11 @@ int pcrl_wgrad_brick_slabs(int N, int D, int H, int W, int Ci, int Co) { return 
 void pcrl_wgrad_brick_set_xcd(int on, int order) { g_wb_xcd = on; g_wb_order = order; }
 int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co,
                             hipStream_t stream) {
-  static bool attr_set = false;
+  static std::once_flag attr_once;   // hipFuncSetAttribute once per process, race-free
   const size_t lds = 2 * BUF_BYTES;
-  if (!attr_set) {
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   const int nbricks = (int)((int64_t)N * D * H * W / BV);
   const BrickSplit sp = plan3(nbricks, Co, Ci);
   WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 0, 3, sp.xcd_map, g_wb_order, sp.G, sp.Q, sp.gpc, sp.ngroups, sp.ntg, sp.pair};
@@ -454,12 +455,11 @@ bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype)
 }
 int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co) { return plan((int)((int64_t)N * H * W / BV), Co, Ci, 1).splits; }
 int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, int up, hipStream_t stream) {
-  static bool attr_set = false;
+  static std::once_flag attr_once;   // hipFuncSetAttribute once per process, race-free
   const size_t lds = 2 * BUF_BYTES;
-  if (!attr_set) {
+  std::call_once(attr_once, [&] {
     hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  });
   const int nbricks = (int)((int64_t)N * H * W / BV);
   const BrickSplit sp = plan(nbricks, Co, Ci, 1);
   WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, up, 1, 0, 0, 0, 0, 0, 0, 0, 0};

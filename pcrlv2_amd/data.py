@@ -211,9 +211,9 @@ class GpuLunaAugment:
 class AugmentedLoader:
     """DataLoader over raw crops + GpuLunaAugment: iterates batches with the contract of datasets/lunaDataset.py:79-81."""
 
-    def __init__(self, files, batch_size, workers, device, shuffle=True, seed=0):
+    def __init__(self, files, batch_size, workers, device, shuffle=True, seed=0, drop_last=False):
         self.loader = torch.utils.data.DataLoader(LunaCropPairs(files), batch_size=batch_size, shuffle=shuffle, num_workers=workers,
-                                                  pin_memory=torch.device(device).type == "cuda", drop_last=False)
+                                                  pin_memory=torch.device(device).type == "cuda", drop_last=drop_last)
         self.augment = GpuLunaAugment(device, seed)
 
     def __len__(self):
@@ -232,5 +232,10 @@ def luna_pretask_loaders(args, device=None):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     seed = getattr(args, "seed", 0)
-    return {"train": AugmentedLoader(x_train[rank::world], args.b, args.workers, device, True, seed + rank),
+    # One process per GPU: every rank must run the SAME number of optimizer steps (each step ends in a collective), so the shards are
+    # cut to equal length (like DistributedSampler's drop) and the ragged last batch is dropped; a single process keeps the
+    # reference's loader (data.py:90-93: drop_last=False).
+    if world > 1:
+        x_train = x_train[:len(x_train) - len(x_train) % world]
+    return {"train": AugmentedLoader(x_train[rank::world], args.b, args.workers, device, True, seed + rank, drop_last=world > 1),
             "eval": AugmentedLoader(x_valid, args.b, args.workers, device, False, seed)}

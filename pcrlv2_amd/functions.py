@@ -64,6 +64,14 @@ def _park(p, g):
     return None
 
 
+def reset_parked():
+    """Start of a step: drop gradients parked by a backward pass that raised before its end-of-backward callback ran (the engine
+    discards the queued callback then, and a stale flag would park every later gradient without ever delivering it)."""
+    global _callback_queued
+    _parked.clear()
+    _callback_queued = False
+
+
 def parked_params():
     return [p for p, _ in _parked.values()]
 

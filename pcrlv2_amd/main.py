@@ -40,6 +40,8 @@ _FLAGS = (
     ("amp", False, None, "bfloat16 activations and MFMA operands"),
     ("steps_per_epoch", 16, int, "only with --data synthetic"),
     ("resume", "", str, "checkpoint to continue from (model, momentum buffers, epoch)"),
+    ("encoder_weights", "", str, "only with --d 2: local ResNet-18 state_dict (torchvision key names) for the encoder; empty = random init "
+                                 "(the reference's smp.Unet('resnet18') downloads ImageNet weights, which an offline engine cannot)"),
     ("size2d", 224, int, "only with --d 2 --data synthetic: side of the global views (locals are 96x96)"),
 )
 

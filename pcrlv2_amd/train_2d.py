@@ -3,7 +3,10 @@
 Same entry point `train_pcrlv2(args, data_loader, out_channel=3)`, `cos_loss`, loss assembly (five scales, no divergence guard,
 train_2d.py:139-171), LR schedule, log line and checkpoint (the ENCODER's state_dict only, train_2d.py:99).  The deliberate
 differences are those listed in pcrlv2_amd/train_3d.py (bf16 for --amp, one process per GPU instead of nn.DataParallel, lazy
-meters, --seed honoured, --resume for the encoder weights).
+meters, --seed honoured).  `--encoder_weights FILE` initialises the encoder from a local torchvision-named ResNet-18 state_dict (the
+reference downloads ImageNet weights at construction, pcrlv2_model.py:200; offline the default is random init, with a warning).
+`--resume CKPT` continues from a checkpoint of the reference's 2D layout: that layout holds the ENCODER only (train_2d.py:99), so
+the encoder, the epoch counter and -- when the shapes match -- the momentum buffers are restored, the decoder and heads restart.
 """
 from __future__ import print_function
 
@@ -69,15 +72,30 @@ def train_pcrlv2(args, data_loader, out_channel=3):
         rank, _, local_rank = _ddp.init_process_group_from_env()
         torch.cuda.set_device(local_rank)
     seed_everything(getattr(args, "seed", 42))
-    model = PCRLv2(encoder_weights=getattr(args, "encoder_weights", None)).cuda()
+    enc_w = getattr(args, "encoder_weights", None) or None
+    chatty = rank == 0
+    if enc_w is None and chatty:
+        print("==> warning: encoder starts from RANDOM weights (no --encoder_weights); the reference starts from ImageNet ResNet-18")
+    model = PCRLv2(encoder_weights=enc_w).cuda()
     if getattr(args, "amp", False):
         model.set_compute_dtype(torch.bfloat16)
     optimizer = FusedSGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
     if distributed:
         _ddp.DataParallel(model, optimizer)
     criterion, cosine = MSELoss2d().cuda(), CosineSimilarityMean().cuda()
-    chatty = rank == 0
-    for epoch in range(0, args.epochs + 1):
+    first_epoch = 0
+    if getattr(args, "resume", None):
+        ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
+        model.model.encoder.load_state_dict(ckpt["state_dict"])
+        try:
+            optimizer.load_state_dict(ckpt["optimizer"])
+        except Exception as e:       # a checkpoint of another parameter list: keep fresh momentum
+            if chatty:
+                print("==> optimizer state not restored:", e)
+        first_epoch = int(ckpt.get("epoch", -1)) + 1
+        if chatty:
+            print("==> resumed the ENCODER from {} (the 2D checkpoint layout holds nothing else); continuing with epoch {}".format(args.resume, first_epoch))
+    for epoch in range(first_epoch, args.epochs + 1):
         adjust_learning_rate(epoch, args, optimizer)
         if chatty:
             print("==> training...")

@@ -25,8 +25,11 @@ import sys
 import time
 
 import torch
+import torch.distributed as dist
 
 from . import ddp as _ddp
+from . import functions as _fn
+from . import ops as _ops
 from .functions import cosine_mean, mse_loss
 from .models import PCRLv23d
 from .optim import FusedSGD
@@ -99,13 +102,26 @@ def step_losses(model, batch, epoch, criterion, cosine):
     return l_restore + l_global + l_deep + l_local, l_restore, l_global, l_deep, l_local
 
 
+def begin_step():
+    """Reset the per-step engine state (ops pass counter; gradients parked by a backward that raised)."""
+    _ops.begin_step()
+    _fn.reset_parked()
+
+
 def train_step(model, optimizer, batch, epoch, criterion, cosine, guard=True):
     """One iteration of train_3d.py:113-151.  Returns (loss, loss1, loss2, loss4, local_loss) as detached device
     scalars, or None when the divergence guard skipped the update."""
+    begin_step()            # forward-pass numbering / parked-gradient state start clean even after a skipped or failed step
     losses = step_losses(model, batch, epoch, criterion, cosine)
-    if guard and epoch > 10 and losses[0] > 1000:
-        print('skip the step')
-        return None
+    if guard and epoch > 10:
+        # The reference is one process (nn.DataParallel): one loss, one decision.  With one process per GPU the decision must be
+        # COLLECTIVE -- a rank that skipped alone would never enter the gradient all-reduce its peers wait in.
+        diverged = (losses[0].detach() > 1000).to(torch.float32)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(diverged, op=dist.ReduceOp.MAX)
+        if bool(diverged):
+            print('skip the step')
+            return None
     optimizer.zero_grad()
     losses[0].backward()
     optimizer.step()
