@@ -115,7 +115,10 @@ def main():
             port = sk.getsockname()[1]
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
+        r = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), stdout=subprocess.PIPE, text=True)
+        for ln in r.stdout.splitlines():      # stdout carries exactly the JSON line; library chatter (gloo's connection notes) goes to stderr
+            print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr)
+        raise SystemExit(r.returncode)
 
     from pcrlv2_amd import _lib, ddp
     from pcrlv2_amd.models import PCRLv23d
