@@ -58,9 +58,9 @@ int pcrl_pack_convt_weight(const float* w_ref, void* w_fwd, void* w_dgrad, int C
  *   y[m][co] = bias[co] + sum_{t,ci} x[m+delta_t][ci] * wp[co][t][ci]      (zero outside the volume)
  * `stats_partial` (optional): [pcrl_conv3d_k3_stats_rows(...)][Co][2] float; row r receives (sum y, sum y^2) of
  * output tile r, taken from the fp32 accumulators, for the training-mode BatchNorm that follows (:12,33).
- * Two kernels sit behind this entry point: an LDS-halo "brick" kernel (bf16, D%4 == 0, H%8 == 0, W%8 == 0, Co%64 == 0:
- * 4x8x8-voxel tiles) and a gather kernel (any shape, both dtypes: 128-voxel tiles); the helper tells which tiling
- * the given shape gets.
+ * Three kernels sit behind this entry point: two LDS-halo "brick" kernels (bf16, D%4 == 0, H%8 == 0: 4x8x16-voxel tiles when
+ * W%16 == 0, 4x8x8-voxel tiles when W%8 == 0) and a gather kernel (any shape, both dtypes: 128-voxel tiles); the helper tells
+ * which tiling the given shape gets.
  * The data gradient (aten::convolution_backward, input half) is the same call with wp = w_dgrad,
  * Ci/Co exchanged, bias = NULL, stats_partial = NULL. */
 int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype);
@@ -287,7 +287,7 @@ int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, 
  * of the kernels behind one entry point runs, so that tests can check every kernel against the same reference and probes can
  * time them against each other inside one process (tools/conv_probe.py).
  *   conv  impl: 0 auto (LDS-halo brick kernel where eligible, co-located launch), 1 gather kernel, 2 gather kernel without
- *               split-K, 3 brick kernel on its plain 2-D grid
+ *               split-K, 3 brick kernel on its plain 2-D grid, 4 the 4x8x8-brick kernel also where the 4x8x16-brick one is eligible
  *   wgrad impl: 0 auto (brick kernel where eligible, XCD co-located launch), 1 gather kernel, 2 brick kernel on its plain 2-D grid,
  *               4 / 5 co-located launch with the old walk order / plain grid with the new walk order (experiments)
  *   wgrad tr  : bf16 fragment fetch of the gather weight-gradient kernel: 1 ds_read_b64_tr_b16, 0 scalar LDS reads

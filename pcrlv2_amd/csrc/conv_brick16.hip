@@ -1,0 +1,353 @@
+// Wide-brick LDS-halo implicit-GEMM 3x3x3 convolution for gfx950, bf16 -- the throughput path of pcrl_conv3d_k3_fwd (forward and
+// data gradient) for volumes with D % 4 == 0, H % 8 == 0, W % 16 == 0 (the 64x64x32 and 32x32x16 levels and the 16^3 local views:
+// 80 % of the convolution FLOPs of a step).  conv_brick.hip (4x8x8 bricks) keeps the narrower volumes and the 2D path.
+//
+// Replaces aten::convolution / convolution_backward(input) of LUConv.conv1 (models/pcrlv2_model_3d.py:9,33).
+//
+// Why a second brick kernel: conv_brick.hip sits against the chip's power cap with the matrix pipe ~55 % busy; what moves it
+// is bytes moved per FLOP.  Here a block owns a 4 x 8 x 16 brick (512 output voxels) and a wave owns one d-plane of it, 128 voxels x BN
+// output channels:
+//   * LDS fragment reads per MFMA: 12 x ds_read_b128 per 32 MFMAs (8 A + 4 B) instead of 8 per 16                      (x 0.75)
+//   * staged bytes per MFMA: the 27 weight tiles of a 32-channel chunk (108 KiB) serve 512 voxels instead of 256, the halo is
+//     6 x 10 x 18 rows for 512 voxels (2.1x) instead of 6 x 10 x 10 for 256 (2.3x)                                    (x 0.6)
+//   * the halo goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write_b128 (the slowest LDS
+//     instruction, 13 cycles per wave), no staging registers -- which is what lets a 128-accumulator wave keep two fragment sets in
+//     ping-pong at two waves per SIMD.
+// A-fragment rows are 16 CONSECUTIVE w positions of one (d, h) line, so the halo keeps its natural w pitch of 18 rows; the 16-byte slot
+// of a row is XOR-ed with a key that depends only on the row's w position (the d, h tap offsets are multiples of the pitch, so a lane's
+// three kw addresses are computed once): key = 2 for w in {4,5,10..15}, else 0 -- found by exhaustive search over gfx950's
+// ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) for both parities of the line index; conflict-free for every tap.  LDS-DMA writes
+// lane-linear, so the swizzle is applied to the SOURCE address (lane (row, physical slot s) loads logical slot s ^ key(row)).
+// Halo rows outside the volume are loaded from a 16-byte zero page.
+//
+// LDS: halo 68 KiB (single buffer: 1080 rows x 64 B, rounded up to whole 1 KiB DMA pieces) + one weight stage 12 KiB = 80 KiB -> two
+// blocks (eight waves) per CU.  The next chunk's halo is requested as soon as every wave holds the last fragments of the current one
+// (first barrier of the chunk's last stage) and lands under that stage's remaining MFMAs and the co-resident block's work.
+#include "common.h"
+#include <atomic>
+#include <mutex>
+
+namespace {
+
+constexpr int TD = 4, TH = 8, TW = 16;
+constexpr int HD = TD + 2, HH = TH + 2, HP = TW + 2;   // halo extents; w pitch = natural 18
+constexpr int ROWS = HD * HH * HP;                     // 1080 rows of 64 B
+constexpr int NDMA = (ROWS + 15) / 16;                 // 68 wave-instructions of 16 rows (1 KiB)
+constexpr int HALO_BYTES = NDMA * 1024;                // 69632
+constexpr int NS = 9;                                  // stages per chunk: (kd, kh); a stage = three kw taps
+
+__device__ uint4 g_zero_page[4];                       // source of halo rows outside the volume (zero-initialised device memory)
+
+struct Brick16Params {
+  const bf16* x;
+  const bf16* w;      // packed [Nc][27][K]
+  const float* bias;
+  bf16* y;
+  float* stats;       // [bricks][Nc][2] or null
+  int N, D, H, W;
+  int K, Nc;
+  int ny;             // > 0: 1-D grid of bricks x ny ids (channel tiles of a brick on one XCD, see conv_brick.hip); 0: 2-D grid
+};
+
+__device__ __forceinline__ int key_w(int hw) { return ((0xFC30 >> hw) & 1) << 1; }   // hw in [0, 18)
+// weight tile [BN co][32 k]: fragment reads take 16 consecutive rows from a 16-aligned row (same swizzle as conv_brick.hip)
+__device__ __forceinline__ int woff(int row, int slot) {
+  const int key = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
+  return row * 64 + ((slot ^ key) << 4);
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+
+template <int BN>
+__global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Params p) {
+  constexpr int FN = BN / 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* halo = smem;
+  char* wbuf = smem + HALO_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int K = p.K, nchunk = K / 32;
+
+  // ---- brick origin (XCD-contiguous brick ranges; the channel tiles of a brick adjacent on one XCD) ----
+  const int bw = p.W / TW, bh = p.H / TH, bd = p.D / TD;
+  int b = blockIdx.x, ytile = blockIdx.y;
+  if (p.ny > 0) {
+    const int nbr = gridDim.x / p.ny;
+    if ((nbr & 7) == 0) {
+      const int slot = b >> 3;
+      ytile = slot % p.ny;
+      b = (b & 7) * (nbr >> 3) + slot / p.ny;
+    } else {
+      ytile = b % p.ny;
+      b = b / p.ny;
+    }
+  } else if ((gridDim.x & 7) == 0) {
+    b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
+  }
+  const int n0 = ytile * BN;
+  const int brick_id = b;
+  const int w0 = (b % bw) * TW; b /= bw;
+  const int h0 = (b % bh) * TH; b /= bh;
+  const int d0 = (b % bd) * TD; b /= bd;
+  const int n = b;
+
+  // ---- halo DMA: wave `wid` issues pieces wid, wid + 4, ...; a piece = 16 rows, lane -> (row = piece * 16 + lane / 4, slot lane & 3).
+  //      The source voxel of a row is fixed for the block: element offsets are computed once (17 registers), -1 = outside. ----
+  constexpr int PPW = NDMA / 4;   // 17 pieces per wave
+  const char* xb = reinterpret_cast<const char*>(p.x);
+  const char* zp = reinterpret_cast<const char*>(g_zero_page);
+  // The source address of a piece is recomputed per request (a few dozen VALU operations per piece and chunk, nothing next to a chunk's
+  // 864 MFMAs): 17 precomputed addresses per lane do not fit beside 128 accumulators.  `lo` is made opaque so that the compiler does
+  // not hoist the 17 address computations out of the chunk loop (and spill them).
+#define DMA_HALO(c_)                                                                                       \
+  do {                                                                                                     \
+    int lo = lane;                                                                                         \
+    asm volatile("" : "+v"(lo));                                                                           \
+    _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                      \
+      const int row = (wid + 4 * i) * 16 + (lo >> 2);                                                      \
+      const int hd = row / (HH * HP), rem = row % (HH * HP), hh = rem / HP, hw = rem % HP;                 \
+      const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                         \
+      const bool ok = row < ROWS && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W; \
+      const int ls = (lo & 3) ^ key_w(hw);                                                                 \
+      const int64_t vox = (((int64_t)n * p.D + d) * p.H + h) * p.W + w;                                    \
+      const char* src = ok ? xb + ((vox * K + (c_)*32 + ls * 8) << 1) : zp;                                \
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(halo + (wid + 4 * i) * 1024), 16, 0, 0); \
+    }                                                                                                      \
+  } while (0)
+
+  // ---- weight staging through registers: 3 pieces per thread (taps kw = 0,1,2 of the stage), row co = tid >> 2, slot tid & 3 ----
+  const bool wthread = BN == 64 || (tid >> 2) < BN;
+  const bf16* wrow = p.w + ((int64_t)(n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8;
+  const int wdst = woff(tid >> 2, tid & 3);
+  u32x4 rw[3];
+#define LOAD_W(c_, s9_)                                                                                    \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                          \
+      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)((s9_)*3 + j) * K + (c_)*32);                \
+  } while (0)
+#define STORE_W()                                                                                          \
+  do {                                                                                                     \
+    if (wthread) {                                                                                         \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                        \
+        *reinterpret_cast<u32x4*>(wbuf + j * (BN * 64) + wdst) = rw[j];                                    \
+    }                                                                                                      \
+  } while (0)
+
+  f32x4 acc[8][FN];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Fragment addressing: wave = d-plane `wid`; fragment fm = h line fm, rows = 16 consecutive w.  Row of tap (kd,kh,kw):
+  // ((wid + kd) * HH + fm + kh) * HP + lr + kw; the key depends on lr + kw only -> three lane offsets, (kd,kh) and fm are adds.
+  int akw[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) akw[kw] = ((wid * HH) * HP + lr + kw) * 64 + ((lg ^ key_w(lr + kw)) << 4);
+  const int bofs = woff(lr, lg);
+
+  bf16x8 fa[2][4], fb[2][FN];
+#define LOADA(S_, aoff_, half_)                                                                            \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
+      fa[S_][q] = *reinterpret_cast<const bf16x8*>(halo + (aoff_) + ((half_)*4 + q) * (HP * 64));          \
+  } while (0)
+#define LOADB(S_, wt_)                                                                                     \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                         \
+      fb[S_][j] = *reinterpret_cast<const bf16x8*>((wt_) + bofs + j * 1024);                               \
+  } while (0)
+#define MFMA_HALF(SA_, SB_, half_, Q0_, Q1_)                                                               \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int q = (Q0_); q < (Q1_); ++q)                                                  \
+      _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                       \
+        acc[(half_)*4 + q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[SA_][q], fb[SB_][j], acc[(half_)*4 + q][j], 0, 0, 0); \
+  } while (0)
+#define PIPE_READS(n_, m_)                                                                                 \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < (n_); ++q) {                                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, (m_), 0);                                                \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
+    }                                                                                                      \
+  } while (0)
+#define PIPE_WRITES(n_, m_)                                                                                \
+  do {                                                                                                     \
+    _Pragma("unroll") for (int q = 0; q < (n_); ++q) {                                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, (m_), 0);                                                \
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                   \
+    }                                                                                                      \
+  } while (0)
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+  // One stage = six half-taps (kw = 0,1,2 x voxel halves 0,1), 16 MFMAs each.  A sets alternate per half-tap (fa[0] = half 0,
+  // fa[1] = half 1); B sets alternate per tap: P = the set that holds kw = 0 on entry (a stage has three taps, so P flips per stage).
+  // The two barriers of a stage sit inside the LAST half-tap, whose operands are in registers: the next stage's weights are stored,
+  // the next chunk's halo requested and the first fragments of the next stage read under its MFMAs.
+  int c = 0, s9 = 0;
+#define STAGE(P_)                                                                                          \
+  do {                                                                                                     \
+    int cn = c, sn = s9 + 1;                                                                               \
+    if (sn == NS) { sn = 0; cn = c + 1; }                                                                  \
+    const bool last = (cn == nchunk);                                                                      \
+    if (last) { cn = c; sn = s9; }                                                                         \
+    LOAD_W(cn, sn);                                                                                        \
+    const bool halo_next = (s9 == NS - 1) && !last; /* block-uniform */                                    \
+    const int tap64 = ((s9 / 3) * HH + (s9 % 3)) * (HP * 64);                                              \
+    const int ntap64 = ((sn / 3) * HH + (sn % 3)) * (HP * 64);                                             \
+    /* ht0: kw 0, half 0 */                                                                                \
+    LOADA(1, akw[0] + tap64, 1);                                                                           \
+    MFMA_HALF(0, P_, 0, 0, 4);                                                                             \
+    PIPE_READS(4, FN);                                                                                     \
+    SB();                                                                                                  \
+    /* ht1: kw 0, half 1 */                                                                                \
+    LOADA(0, akw[1] + tap64, 0);                                                                           \
+    LOADB((P_) ^ 1, wbuf + 1 * (BN * 64));                                                                 \
+    MFMA_HALF(1, P_, 1, 0, 4);                                                                             \
+    PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
+    SB();                                                                                                  \
+    /* ht2: kw 1, half 0 */                                                                                \
+    LOADA(1, akw[1] + tap64, 1);                                                                           \
+    MFMA_HALF(0, (P_) ^ 1, 0, 0, 4);                                                                       \
+    PIPE_READS(4, FN);                                                                                     \
+    SB();                                                                                                  \
+    /* ht3: kw 1, half 1 */                                                                                \
+    LOADA(0, akw[2] + tap64, 0);                                                                           \
+    LOADB(P_, wbuf + 2 * (BN * 64));                                                                       \
+    MFMA_HALF(1, (P_) ^ 1, 1, 0, 4);                                                                       \
+    PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
+    SB();                                                                                                  \
+    /* ht4: kw 2, half 0 */                                                                                \
+    LOADA(1, akw[2] + tap64, 1);                                                                           \
+    MFMA_HALF(0, P_, 0, 0, 4);                                                                             \
+    PIPE_READS(4, FN);                                                                                     \
+    SB();                                                                                                  \
+    /* ht5: kw 2, half 1 -- every LDS read of this stage (and, in a chunk's last stage, of this chunk's halo) is complete */ \
+    __syncthreads();                                                                                       \
+    STORE_W();                                                                                             \
+    if (halo_next) DMA_HALO(c + 1);                                                                        \
+    MFMA_HALF(1, P_, 1, 0, 2);                                                                             \
+    PIPE_WRITES(3, FN / 2);                                                                                     \
+    SB();                                                                                                  \
+    if (halo_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+    __syncthreads();                                                                                       \
+    LOADA(0, akw[0] + ntap64, 0);                                                                          \
+    LOADB((P_) ^ 1, wbuf);                                                                                 \
+    MFMA_HALF(1, P_, 1, 2, 4);                                                                             \
+    PIPE_READS(4 + FN, 1);                                                                                 \
+    SB();                                                                                                  \
+    c = cn;                                                                                                \
+    s9 = sn;                                                                                               \
+  } while (0)
+
+  DMA_HALO(0);
+  LOAD_W(0, 0);
+  STORE_W();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  LOADA(0, akw[0], 0);
+  LOADB(0, wbuf);
+
+  const int nstage = NS * nchunk;
+  for (int S = 0; S + 1 < nstage; S += 2) {
+    STAGE(0);
+    STAGE(1);
+  }
+  if (nstage & 1) STAGE(0);
+  __syncthreads();   // the epilogue reuses the LDS
+#undef STAGE
+#undef SB
+#undef MFMA_HALF
+#undef LOADA
+#undef LOADB
+#undef PIPE_READS
+#undef PIPE_WRITES
+#undef DMA_HALO
+#undef LOAD_W
+#undef STORE_W
+
+  // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick).  acc[fm][j][r]: voxel (d0 + wid, h0 + fm,
+  //      w0 + 4 lg + r), channel n0 + 16 j + lr ----
+  float s1[FN], s2[FN], bv[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+    bv[j] = p.bias ? p.bias[n0 + j * 16 + lr] : 0.f;
+  }
+#pragma unroll
+  for (int fm = 0; fm < 8; ++fm) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t row = (((int64_t)n * p.D + d0 + wid) * p.H + h0 + fm) * p.W + w0 + lg * 4 + r;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const float val = acc[fm][j][r] + bv[j];
+        p.y[row * p.Nc + n0 + j * 16 + lr] = (bf16)val;
+        s1[j] += val;
+        s2[j] += val * val;
+      }
+    }
+  }
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][64 ch][2]; the loop ended with a barrier
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float a = s1[j], c2 = s2[j];
+      a += __shfl_xor(a, 16, 64);
+      c2 += __shfl_xor(c2, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      c2 += __shfl_xor(c2, 32, 64);
+      if (lg == 0) {
+        red[(wid * 64 + j * 16 + lr) * 2 + 0] = a;
+        red[(wid * 64 + j * 16 + lr) * 2 + 1] = c2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float a = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a += red[(q * 64 + tid) * 2 + 0];
+        c2 += red[(q * 64 + tid) * 2 + 1];
+      }
+      float* o = p.stats + ((int64_t)brick_id * p.Nc + n0 + tid) * 2;
+      o[0] = a;
+      o[1] = c2;
+    }
+  }
+}
+
+std::atomic<int> g_brick16_on{1};
+
+}  // namespace
+
+// ---- internal interface used by conv_igemm.hip's dispatcher -------------------------------------------------------
+void pcrl_brick16_set(int on) { g_brick16_on = on; }
+bool pcrl_brick16_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return g_brick16_on && dtype == PCRL_BF16 && D % TD == 0 && H % TH == 0 && W % TW == 0 && Ci % 32 == 0 && Co % 32 == 0 &&
+         (int64_t)N * D * H * W < ((int64_t)1 << 29);
+}
+int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W) { return (int64_t)N * (D / TD) * (H / TH) * (W / TW); }
+
+int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
+                             int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 32 * 64);
+  });
+  Brick16Params p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0};
+  const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
+  const int BN = Co % 64 == 0 ? 64 : 32, ny = Co / BN;
+  if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16_conv: grid too large");
+  dim3 grid((unsigned)bricks, ny);
+  if (ny > 1) {
+    p.ny = ny;
+    grid = dim3((unsigned)(bricks * ny));
+  }
+  if (BN == 64) hipLaunchKernelGGL((brick16_conv_kernel<64>), grid, dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
+  else hipLaunchKernelGGL((brick16_conv_kernel<32>), grid, dim3(256), HALO_BYTES + 3 * 32 * 64, stream, p);
+  return pcrl_check_launch("brick16_conv");
+}

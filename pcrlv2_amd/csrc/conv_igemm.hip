@@ -399,20 +399,29 @@ int64_t pcrl_brick_conv_rows(int N, int D, int H, int W);
 int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                            int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
 
+// wide-brick kernel (conv_brick16.hip): W % 16 == 0
+bool pcrl_brick16_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);
+int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W);
+int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
+                             int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
+void pcrl_brick16_set(int on);
+
 bool pcrl_convt_up2_eligible(int Ci, int Co, int dtype);   // conv_up2.hip
 int pcrl_convt_up2_launch(const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Ci, int Co,
                           hipStream_t stream);
 static std::atomic<int> g_conv_impl{0};  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
 void pcrl_brick_conv_set_ymap(int on);
 // 0 = auto (brick kernel where eligible), 1 = always the gather kernel, 2 = gather kernel without split-K,
-// 3 = brick kernel on its 2-D grid (channel tiles of a brick not co-located)
+// 3 = brick kernel on its 2-D grid (channel tiles of a brick not co-located), 4 = 4x8x8-brick kernel also where the 4x8x16 one is eligible
 extern "C" void pcrl_debug_set_conv_impl(int impl) {
-  g_conv_impl = impl == 3 ? 0 : impl;
+  g_conv_impl = (impl == 3 || impl == 4) ? 0 : impl;
   pcrl_brick_conv_set_ymap(impl != 3);
+  pcrl_brick16_set(impl == 0);
 }
 int pcrl_debug_conv_impl() { return g_conv_impl; }
 
 extern "C" int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  if (g_conv_impl == 0 && pcrl_brick16_conv_eligible(N, D, H, W, Ci, Co, dtype)) return pcrl_brick16_conv_rows(N, D, H, W);
   if (g_conv_impl == 0 && pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype)) return pcrl_brick_conv_rows(N, D, H, W);
   return ((int64_t)N * D * H * W + PCRL_CONV_BM - 1) / PCRL_CONV_BM;
 }
@@ -421,6 +430,8 @@ static int conv3d_k3_fwd_impl(const void* x, const void* wp, const float* bias, 
                              int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_dims("conv3d_k3_fwd", N, D, H, W, Ci, Co)) return e;
   PCRL_REQUIRE(x && wp && y, "conv3d_k3_fwd: null pointer");
+  if (g_conv_impl == 0 && pcrl_brick16_conv_eligible(N, D, H, W, Ci, Co, dtype))
+    return pcrl_brick16_conv_launch(x, wp, bias, y, stats_partial, N, D, H, W, Ci, Co, as_stream(stream));
   if (g_conv_impl == 0 && pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype))
     return pcrl_brick_conv_launch(x, wp, bias, y, stats_partial, N, D, H, W, Ci, Co, as_stream(stream));
   const int64_t M = (int64_t)N * D * H * W;
@@ -448,7 +459,7 @@ extern "C" int pcrl_conv3d_k3_fwd(const void* x, const void* wp, const float* bi
 
 extern "C" int64_t pcrl_conv3d_k3_fwd_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 32 != 0 || Co % 32 != 0) return 0;
-  if (g_conv_impl == 0 && pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype)) return 0;
+  if (g_conv_impl == 0 && (pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype) || pcrl_brick16_conv_eligible(N, D, H, W, Ci, Co, dtype))) return 0;
   const int64_t M = (int64_t)N * D * H * W;
   const SplitPlan sp = splitk_plan(M, Ci, Co);
   return sp.splits > 1 ? (int64_t)sp.splits * M * Co * 4 : 0;

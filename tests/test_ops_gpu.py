@@ -58,6 +58,8 @@ SHAPES3 = [  # N, D, H, W, Ci, Co   (M deliberately not a multiple of 128 in the
     # brick range in wgrad_brick.hip: pairing over ci tiles, over co tiles, both possible) and more than one brick range
     (2, 8, 16, 16, 64, 128), (2, 8, 16, 16, 128, 64), (1, 8, 16, 16, 128, 128), (1, 8, 16, 16, 64, 192), (3, 16, 16, 16, 32, 64),
     (1, 4, 16, 16, 256, 128),
+    # 4x8x16-brick kernel (conv_brick16.hip): edge bricks in d, h, w; one and several bricks per direction; BN = 32 (Co = 32), Co = 96
+    (1, 8, 16, 32, 32, 64), (2, 4, 8, 16, 64, 32), (1, 12, 24, 48, 32, 96), (2, 8, 8, 32, 96, 64),
 ]
 
 
@@ -112,14 +114,31 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
     L.debug_set_conv_impl(0)
     check(y, ref, dt, "conv3 fwd (gather kernel)")
     check(back(part1).view(rows1, Co, 2).sum(0)[:, 0], ref.sum(dim=(0, 2, 3, 4)), dt, "conv3 stats (gather)", out_rounded=False, f32_tol=1e-4)
+    if dt == torch.bfloat16 and D % 4 == 0 and H % 8 == 0 and W % 16 == 0:   # the 4x8x8-brick kernel where impl 0 took the 4x8x16 one
+        L.debug_set_conv_impl(4)
+        rows4 = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Ci, Co, dtype_code(dt))
+        part4 = torch.zeros(rows4 * Co * 2, dtype=torch.float32, device=DEV)
+        y4 = ops.new_act(N, D, H, W, Co, dt, DEV)
+        L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y4, part4, N, D, H, W, Ci, Co, dtype_code(dt), s)
+        dx4 = ops.new_act(N, D, H, W, Ci, dt, DEV)
+        L.call("pcrl_conv3d_k3_fwd", dya, wd, None, dx4, None, N, D, H, W, Co, Ci, dtype_code(dt), s)
+        L.debug_set_conv_impl(0)
+        assert rows4 == 2 * rows
+        check(y4, ref, dt, "conv3 fwd (4x8x8 bricks)")
+        check(dx4, xr.grad, dt, "conv3 dgrad (4x8x8 bricks)")
+        check(back(part4).view(rows4, Co, 2).sum(0)[:, 1], (ref * ref).sum(dim=(0, 2, 3, 4)), dt, "conv3 stats (4x8x8 bricks)", out_rounded=False, f32_tol=1e-4)
     if dt == torch.bfloat16 and Co > 64:   # the brick kernel on its 2-D grid (impl 3): bit-identical to the co-located launch
         y3 = ops.new_act(N, D, H, W, Co, dt, DEV)
         part3 = torch.zeros(rows * Co * 2, dtype=torch.float32, device=DEV)
+        L.debug_set_conv_impl(4)    # both launches on the 4x8x8-brick kernel: 2-D grid vs co-located
+        rows3 = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Ci, Co, dtype_code(dt))
+        part3 = torch.zeros(rows3 * Co * 2, dtype=torch.float32, device=DEV)
+        part3b = torch.zeros_like(part3)
+        L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y, part3b, N, D, H, W, Ci, Co, dtype_code(dt), s)
         L.debug_set_conv_impl(3)
         L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y3, part3, N, D, H, W, Ci, Co, dtype_code(dt), s)
         L.debug_set_conv_impl(0)
-        L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y, part, N, D, H, W, Ci, Co, dtype_code(dt), s)
-        assert torch.equal(y3, y) and torch.equal(part3, part)
+        assert torch.equal(y3, y) and torch.equal(part3, part3b)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
