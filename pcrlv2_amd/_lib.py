@@ -16,7 +16,8 @@ import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_PKG), "include", "pcrl_hip.h")
-LIBPATH = os.path.join(_PKG, "lib", "libpcrl_hip.so")
+# PCRL_LIB: another build of the same ABI (tools/ A/B probes only: a previous revision's library next to the current one)
+LIBPATH = os.environ.get("PCRL_LIB") or os.path.join(_PKG, "lib", "libpcrl_hip.so")
 
 PCRL_F32, PCRL_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU = 0, 1, 2, 3   # ACT_SILU: optional extra (GroupNorm+SiLU), not on the reference path

@@ -45,7 +45,7 @@ constexpr int DYP = BV * 8 / NT;          // dy 16-byte pieces per thread (4 / 2
 constexpr int XP = (XROWS * 8 + NT - 1) / NT;  // x pieces per thread (8 / 4: 1920 pieces)
 constexpr int BUF_BYTES = DY_BYTES + X_BYTES;   // one brick buffer: 46 KiB, two of them in LDS
 constexpr int NSTEP = 36 / NG;            // steps per wave and brick (K chunks x taps)
-static_assert((DYP + XP) * 3 == NSTEP, "one staging piece per three steps");
+static_assert(DYP + XP <= NSTEP, "one staging request per step");
 
 struct WBrickParams {
   const bf16* dy;   // [M][Cu]
@@ -74,6 +74,19 @@ __device__ __forceinline__ int x_off(int row, int col) {  // rows R0+{0..3} and 
 }
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_void;
+__device__ uint4 g_wb_zero[4];   // source of halo rows outside the volume (zero-initialised device memory)
+
+// One LDS-DMA request: every lane's 16 bytes at `gsrc` land at LDS byte address `lds_dst` (wave-uniform) + 16 * lane.  M0 carries the
+// destination and is compiler-reserved: saved and restored inside the statement.  Not counted by hipcc: wait with s_waitcnt vmcnt.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
 __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
   union { struct { s16x4 a, b; } s; bf16x8 f; } u;
   u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
@@ -128,7 +141,13 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
   // halo voxel, computed once per thread; per brick only a block-uniform 64-bit base pointer, a 6-bit boundary mask and
   // one select per piece remain.  (The first version decoded every piece per brick with 64-bit multiplies under divergent
   // branches: 2400 of the 6200 cycles a brick took, with the matrix pipe idle -- one wave per SIMD.)
-  const int pc = tid & 7;
+  // Staging is LDS-DMA (global_load_lds_dwordx4): a wave's request fills 1 KiB = 8 rows x 128 B lane-linearly, so lane l lands on row
+  // l >> 3, PHYSICAL 16-byte position l & 7 of that row; the XOR swizzle of the images is therefore applied to the SOURCE: the lane
+  // fetches the logical piece that belongs at its position (the keys repeat every 64 rows, so one logical piece per thread and image).
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave index 0 .. NT / 64 - 1
+  const int pp = tid & 7, srow = tid >> 3;
+  const int key_dy = ((srow >> 1) & 1) | (((srow >> 3) & 1) << 1), key_x = (srow >> 1) & 3;
+  const int pc_dy = ((((pp >> 1) ^ key_dy) & 3) << 1) | (pp & 1), pc = ((((pp >> 1) ^ key_x) & 3) << 1) | (pp & 1);
   const bool jcol_ok = (j0 + pc * 8) < p.Cv;       // Cv is a multiple of 32: a 64-wide tile may hang over
   const int xcol = jcol_ok ? j0 + pc * 8 : 0;
   uint32_t dyoff[DYP], xoff[XP];   // byte offsets from the brick bases
@@ -136,7 +155,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #pragma unroll
   for (int i = 0; i < DYP; ++i) {
     const int v = (tid >> 3) + (NT / 8) * i;
-    dyoff[i] = (uint32_t)((((v >> 6) * p.H + ((v >> 3) & 7)) * p.W + (v & 7)) * p.Cu + pc * 8) * 2u;
+    dyoff[i] = (uint32_t)((((v >> 6) * p.H + ((v >> 3) & 7)) * p.W + (v & 7)) * p.Cu + pc_dy * 8) * 2u;
   }
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
@@ -149,19 +168,14 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     xedge[i] = (hd == 0 ? 1u : 0u) | (hd == BD - 1 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == XH - 1 ? 8u : 0u) | (hw == 0 ? 16u : 0u) |
                (hw == BW + 1 ? 32u : 0u) | (row_ok && jcol_ok ? 0u : 64u);
   }
-  // a halo row that is inside the volume for every brick: (hd = 1 for kd = 0, else 0 ; hh = 1 ; hw = 1)
-  const uint32_t xsafe = (uint32_t)((((kd == 0 ? 1 : 0) * Hs + 1) * Ws + 1) * p.Cv + xcol) * 2u;
-  u32x4 rdy[DYP], rx[XP];
-
-  // Staging pipeline (two LDS brick buffers): while brick b is multiplied out of one buffer, the registers hold brick b+1.
-  // Every third step ONE piece is written to the other buffer and its register immediately re-loaded with the same piece of
-  // brick b+2.  Loads and LDS stores are thus spread evenly over the 36 steps (4 waves x (2 transpose reads + 1/3 store) keep the
-  // LDS ~50 % busy; bunching the 12 stores of a brick into 12 consecutive steps saturated it), a load has a whole brick to land,
-  // and the block synchronises once per brick.
+  // Staging pipeline (two LDS brick buffers): while brick b is multiplied out of one buffer, the pieces of brick b+1 are requested
+  // into the other one, one request per wave on each of the first DYP + XP steps (they have the rest of the brick to land); rows
+  // outside the volume come from a 16-byte zero page.  No staging registers, no ds_write, no selects; one wait + barrier per brick.
+  const char* zpage = reinterpret_cast<const char*>(g_wb_zero);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;   // LDS byte address of the buffers
   const char* dyb = nullptr;   // block-uniform bases of the brick being LOADED
   const char* xb = nullptr;
   uint32_t xout = 0;
-  uint32_t xvalid_w = 0, xvalid_l = 0;   // validity bits of the x pieces in registers (being written) / being loaded
   // Brick coordinates are CARRIED from brick to brick (the bricks a block originates are consecutive): decoding them with
   // three divisions and three remainders per brick sat in front of the MFMA steps, unhidden (one wave per SIMD issues in order).
   int ob = b_beg, ow0, oh0, od0, on;
@@ -218,27 +232,20 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     /* faces of this brick's halo that stick out of the volume (BD = 2: the d faces are the two planes) */    \
     xout = (d0 + kd - 1 < 0 ? 1u : 0u) | (d0 + kd - 1 + BD - 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |      \
            (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;            \
-    xvalid_l = 0;                                                                                            \
   } while (0)
-#define WB_LOAD_PIECE(i_)                                                                                    \
+  // The request is issued from inline asm: behind the builtin hipcc waits vmcnt(0) in front of the next ds_read (it cannot prove
+  // that the read does not alias the DMA's LDS destination), which would expose every request's latency.  Completion is counted
+  // by hand: one s_waitcnt vmcnt(0) at the end of the brick, before the barrier that hands the buffer to the readers.
+#define WB_DMA_PIECE(i_, buf_)                                                                               \
   do {                                                                                                       \
     if ((i_) < DYP) {                                                                                        \
-      rdy[(i_) < DYP ? (i_) : 0] = *reinterpret_cast<const u32x4*>(dyb + dyoff[(i_) < DYP ? (i_) : 0]);      \
+      lds_dma16(dyb + dyoff[(i_) < DYP ? (i_) : 0], lds_base + (uint32_t)((buf_)-smem) + wv * 1024 + ((i_) < DYP ? (i_) : 0) * (NT * 16)); \
     } else {                                                                                                 \
       const int j_ = (i_) < DYP ? 0 : (i_) - DYP;                                                            \
-      const bool ok = (xedge[j_] & xout) == 0;                                                               \
-      rx[j_] = *reinterpret_cast<const u32x4*>(xb + (ok ? xoff[j_] : xsafe));                                \
-      xvalid_l |= (uint32_t)ok << j_;                                                                        \
-    }                                                                                                        \
-  } while (0)
-#define WB_STORE_PIECE(i_, buf_)                                                                             \
-  do {                                                                                                       \
-    if ((i_) < DYP) {                                                                                        \
-      *reinterpret_cast<u32x4*>((buf_) + dy_off((tid >> 3) + (NT / 8) * ((i_) < DYP ? (i_) : 0), pc * 8)) = rdy[(i_) < DYP ? (i_) : 0]; \
-    } else {                                                                                                 \
-      const int j_ = (i_) < DYP ? 0 : (i_) - DYP;                                                            \
-      const int r = (tid >> 3) + (NT / 8) * j_;                                                              \
-      if (r < XROWS) *reinterpret_cast<u32x4*>((buf_) + DY_BYTES + x_off(r, pc * 8)) = keep_if((xvalid_w >> j_) & 1u, rx[j_]); \
+      if (8 * wv + (NT / 8) * j_ < XROWS) { /* wave-uniform: the last round covers only the first XROWS rows */ \
+        const bool ok = (xedge[j_] & xout) == 0;                                                             \
+        lds_dma16(ok ? xb + xoff[j_] : zpage, lds_base + (uint32_t)((buf_)-smem) + DY_BYTES + wv * 1024 + j_ * (NT * 16)); \
+      }                                                                                                      \
     }                                                                                                        \
   } while (0)
 
@@ -256,15 +263,9 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
   if (b_beg < b_end) {
     WB_ORIGIN_NEXT();                                     // brick b_beg
 #pragma unroll
-    for (int i = 0; i < DYP + XP; ++i) WB_LOAD_PIECE(i);
-    xvalid_w = xvalid_l;
-#pragma unroll
-    for (int i = 0; i < DYP + XP; ++i) WB_STORE_PIECE(i, smem);
-    WB_ORIGIN_NEXT();                                     // registers <- brick b_beg + 1 (or b_beg again)
-#pragma unroll
-    for (int i = 0; i < DYP + XP; ++i) WB_LOAD_PIECE(i);
-    xvalid_w = xvalid_l;
+    for (int i = 0; i < DYP + XP; ++i) WB_DMA_PIECE(i, smem);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int b = b_beg; b < b_end; ++b) {
@@ -272,7 +273,8 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     const char* dys = smem + ((b - b_beg) & 1) * BUF_BYTES + grp * ((4 / NG) * 4096);
     const char* xs = smem + ((b - b_beg) & 1) * BUF_BYTES + DY_BYTES + grp * ((4 / NG) / 2) * (XH * XW * 128);
     char* nxt = smem + (((b - b_beg) & 1) ^ 1) * BUF_BYTES;
-    WB_ORIGIN_NEXT();                                     // brick min(b + 2, b_end - 1): its pieces are loaded during this one
+    const bool more = b + 1 < b_end;                      // block-uniform
+    WB_ORIGIN_NEXT();                                     // brick b + 1: its pieces are requested during this one
     __builtin_amdgcn_sched_barrier(0);
 
     // 36 steps = 4 K-chunks x 9 taps, fully unrolled and SOFTWARE-PIPELINED: the x fragment of step s+1 (and the dy
@@ -297,9 +299,8 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
       const int kc = st / 9, t = st % 9;
-      if (st % 3 == 0) {   // piece st/3: brick b+1 -> the other LDS buffer, then its register <- brick b+2
-        WB_STORE_PIECE(st / 3, nxt);
-        WB_LOAD_PIECE(st / 3);
+      if (st < DYP + XP) {   // piece st of brick b+1 -> the other LDS buffer
+        if (more) WB_DMA_PIECE(st, nxt);
       }
       if (st + PF < NSTEP) fbr[(st + PF) % (PF + 1)] = WB_B((st + PF) / 9, (st + PF) % 9);
       if (t == 4 && kc < 4 / NG - 1) {
@@ -317,12 +318,11 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #undef WB_B
 
     __builtin_amdgcn_sched_barrier(0);
-    xvalid_w = xvalid_l;
-    __syncthreads();   // this brick's reads and the next brick's stores are complete
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // this brick's reads and the next brick's pieces are complete
   }
 #undef WB_ORIGIN_NEXT
-#undef WB_LOAD_PIECE
-#undef WB_STORE_PIECE
+#undef WB_DMA_PIECE
 
   // ---- the two wave groups hold partial sums over different K chunks: group 1 hands its accumulators to group 0 through the (now
   //      idle) LDS brick buffers in two halves (5 + 4 taps: 80 KB of the 92 KB), so the block writes ONE partial slab ----
