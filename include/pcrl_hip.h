@@ -289,7 +289,8 @@ int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, 
  *   conv  impl: 0 auto (LDS-halo brick kernel where eligible, co-located launch), 1 gather kernel, 2 gather kernel without
  *               split-K, 3 brick kernel on its plain 2-D grid, 4 the 4x8x8-brick kernel also where the 4x8x16-brick one is eligible
  *   wgrad impl: 0 auto (brick kernel where eligible, XCD co-located launch), 1 gather kernel, 2 brick kernel on its plain 2-D grid,
- *               4 / 5 co-located launch with the old walk order / plain grid with the new walk order (experiments)
+ *               4 / 5 co-located launch with the old walk order / plain grid with the new walk order (experiments),
+ *               6 co-located launch with 64 x 64 tiles only (0 also uses 128 x 64, 64 x 128 and 64 x 32 tiles)
  *   wgrad tr  : bf16 fragment fetch of the gather weight-gradient kernel: 1 ds_read_b64_tr_b16, 0 scalar LDS reads
  *   conv2d impl: 0 auto (brick / narrow kernels where eligible), 1 gather kernel */
 void pcrl_debug_set_conv_impl(int impl);

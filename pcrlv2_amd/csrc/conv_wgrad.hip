@@ -843,13 +843,13 @@ bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int d
 int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co);
 int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
 int pcrl_wgrad_brick_slabs(int N, int D, int H, int W, int Ci, int Co);   // partial slabs the launch writes (<= pcrl_wgrad_brick_splits)
-void pcrl_wgrad_brick_set_xcd(int on, int order);
+void pcrl_wgrad_brick_set_xcd(int on, int order, int tiles);
 
 static std::atomic<int> g_wgrad_impl{0};  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel, 2 = brick kernel on its 2-D grid (no XCD co-location)
 extern "C" void pcrl_debug_set_wgrad_impl(int impl) {
-  // experiments: 4 = co-located launch with the old walk order, 5 = 2-D grid with the new walk order
+  // experiments: 4 = co-located launch with the old walk order, 5 = 2-D grid with the new walk order, 6 = co-located launch with 64 x 64 tiles only
   g_wgrad_impl = impl == 1 ? 1 : 0;
-  pcrl_wgrad_brick_set_xcd(impl == 0 || impl == 4, impl == 0 || impl == 5);
+  pcrl_wgrad_brick_set_xcd(impl == 0 || impl == 4 || impl == 6, impl == 0 || impl == 5 || impl == 6, impl != 6);
 }
 
 extern "C" size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {

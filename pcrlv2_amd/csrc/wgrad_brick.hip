@@ -6,23 +6,32 @@
 //   dW[co][ci][t] = sum_m dy[m][co] * x[m + delta_t][ci]
 //
 // The gather kernel (conv_wgrad.hip) re-reads both operand tiles from L2 for each of the 27 taps (8 KB per 64 MFMA
-// cycles: L2-bandwidth bound, ~240 TF).  Here a block owns a 64(co) x 64(ci) tile of ONE kd plane (9 taps) and walks
-// over bricks of 2 x 8 x 8 = 128 voxels: per brick it stages dy[128][64] and the x halo for that kd
-// ([2][10][12-padded] rows x 64 ch, zero outside the volume) in LDS ONCE and runs all 9 (kh,kw) taps from it.
+// cycles: L2-bandwidth bound, ~240 TF).  Here a block owns a TCO(co) x TCI(ci) tile of ONE kd plane (9 taps) and walks
+// over bricks of 2 x 8 x 8 = 128 voxels: per brick it stages dy[128][TCO] and the x halo for that kd
+// ([2][10][12-padded] rows x TCI ch, zero outside the volume) in LDS ONCE and runs all 9 (kh,kw) taps from it.
 // Operands are fetched with ds_read_b64_tr_b16 (the reduction index is the row index of both NDHWC tensors).
-// Each wave owns all 64 co x 16 ci of the 9 taps (36 accumulator fragments): the dy fragments are read once per
+// Each wave owns 64 co x 16 ci of the 9 taps (36 accumulator fragments): the dy fragments are read once per
 // 32-voxel K-chunk and reused by 9 taps, the x fragment of a tap feeds 4 MFMAs -> 13 KB of LDS reads per 36 MFMAs.
-// Two LDS brick buffers: the next brick's pieces are written, and the one after that loaded, a piece every third step while
-// the current brick is multiplied (one barrier per brick).  Split-K over brick ranges; the
-// partial slabs are reduced in fixed order by the same second pass as the gather kernel.
+// Two LDS brick buffers: the next brick's pieces are requested (LDS-DMA) while the current brick is multiplied (one wait + barrier per
+// brick).  Split-K over brick ranges; the partial slabs are reduced in fixed order by the same second pass as the gather kernel.
+//
+// Tile shapes.  Measured (timing ablation, same box): without the staging requests the kernel runs at 1 840 TFLOP/s instead of
+// 1 250 -- moving 46 KB per brick and block from L2 into LDS (8.7 TB/s chip-wide) is what it spends its power on; fragment reads and
+// barriers are free.  Staged bytes per MFMA go as 256 / TCI + 400 / TCO, so the eight waves of a block are used in one of four ways:
+//   64 x 64   two wave groups split a brick's four K chunks (own accumulators, combined through LDS at the end)        10.3
+//   128 x 64  two dy images; group g owns co half g, every wave walks all four K chunks (Co % 128 == 0)                  7.1
+//   64 x 128  two x images; group g owns ci half g (Ci % 128 == 0)                                                       8.3
+//   64 x 32   Ci == 32: a wave owns 32 co x 16 ci (two A fragments) -- with 64 x 64 tiles half of the waves multiplied zero columns
 #include "common.h"
 #include <atomic>
 #include <mutex>
 
-// x-fragment prefetch distance in steps.  Two waves per SIMD (NG = 2) hide the LDS latency between them: 1 is enough and leaves the
-// kernel at 256 registers without spills (3 spilled 14 registers into the step loop: 690 instead of 1 090 TFLOP/s); NG = 1 wants 3.
+// x-fragment prefetch distance in steps.  Two waves per SIMD hide the LDS latency between them: 1 is enough (2 and 3 measured equal).
 #ifndef WB_PF
 #define WB_PF 1
+#endif
+#ifndef WB_ABL
+#define WB_ABL 0   // timing ablations (wrong results): 1 no staging requests, 2 no x-fragment reads after the first brick, 3 no per-brick wait + barrier
 #endif
 
 namespace {
@@ -31,21 +40,22 @@ constexpr int BD = 2, BH = 8, BW = 8;
 constexpr int BV = BD * BH * BW;          // 128 voxels per brick
 constexpr int XH = BH + 2, XW = 12;       // halo extents (w padded 10 -> 12 for conflict-free transpose reads)
 constexpr int XROWS = BD * XH * XW;       // 240
-constexpr int DY_BYTES = BV * 128;        // 16 KiB
-constexpr int X_BYTES = XROWS * 128;      // 30 KiB
-// NG = wave groups per block: every group of 4 waves takes 4 / NG of a brick's four 32-voxel K chunks for ALL 9 taps and keeps its own
-// accumulators (combined through LDS at the end of the kernel).  NG = 2 puts two waves on every SIMD at the same LDS footprint: one wave per SIMD
-// issues in order, and between two MFMAs (16 cycles of pipe) there is room for three other instructions -- exactly what a step needs
-// (transpose reads, staging loads / stores, selects), so any stall showed up as an idle matrix pipe.
-#ifndef WB_NG
-#define WB_NG 2
-#endif
-constexpr int NG = WB_NG, NT = 256 * NG;
-constexpr int DYP = BV * 8 / NT;          // dy 16-byte pieces per thread (4 / 2)
-constexpr int XP = (XROWS * 8 + NT - 1) / NT;  // x pieces per thread (8 / 4: 1920 pieces)
-constexpr int BUF_BYTES = DY_BYTES + X_BYTES;   // one brick buffer: 46 KiB, two of them in LDS
-constexpr int NSTEP = 36 / NG;            // steps per wave and brick (K chunks x taps)
-static_assert(DYP + XP <= NSTEP, "one staging request per step");
+constexpr int DY_BYTES = BV * 128;        // one dy image [128 voxels][64 ch]: 16 KiB
+constexpr int X_BYTES = XROWS * 128;      // one x image [240 halo rows][64 ch]: 30 KiB
+constexpr int NT = 512;                   // eight waves = two groups of four: two waves per SIMD
+constexpr int DYP = BV * 8 / NT;          // 16-byte pieces per thread and dy image (2)
+constexpr int XP = (XROWS * 8 + NT - 1) / NT;  // pieces per thread and x image (4: 1920 pieces)
+
+template <int TCO, int TCI> struct WCfg {
+  static constexpr int IMG_DY = TCO / 64, IMG_X = TCI == 128 ? 2 : 1;
+  static constexpr int KSPLIT = (TCO == 64 && TCI <= 64) ? 2 : 1;   // wave groups split the K chunks of a brick
+  static constexpr bool HALFCI = TCI == 32;
+  static constexpr int FA = HALFCI ? 2 : 4;                          // dy fragments (16 co each) per wave
+  static constexpr int NSTEP = 36 / KSPLIT;                          // steps per wave and brick (K chunks x taps)
+  static constexpr int BUF_BYTES = IMG_DY * DY_BYTES + IMG_X * X_BYTES;
+  static constexpr int NPIECE = IMG_DY * DYP + IMG_X * XP;
+  static_assert(NPIECE <= NSTEP, "one staging request per step");
+};
 
 struct WBrickParams {
   const bf16* dy;   // [M][Cu]
@@ -94,12 +104,15 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
   return u.f;
 }
 
+template <int TCO, int TCI>
 __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // two (dy, x halo) brick buffers of BUF_BYTES
+  using C = WCfg<TCO, TCI>;
+  constexpr int FA = C::FA, NSTEP = C::NSTEP, BUF_BYTES = C::BUF_BYTES, NPIECE = C::NPIECE, KSPLIT = C::KSPLIT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // two (dy images, x halo images) brick buffers of BUF_BYTES
 
   const int tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, grp = tid >> 8;
   const int lg = lane >> 4, jr = (lane & 15) >> 2, cq = lane & 3;
-  const int ntj = p.Cv / 64 > 0 ? (p.Cv + 63) / 64 : 1;
+  const int ntj = (p.Cv + TCI - 1) / TCI;
   int kd, tile, split;
   if (p.xcd_map) {
     const int id = blockIdx.x, chunk = id >> 8, r = id & 255, QG8 = 8 * p.Q * p.G;
@@ -124,17 +137,20 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     tile = blockIdx.y / p.nkd;
     split = blockIdx.x;
   }
-  const int i0 = (tile / ntj) * 64, j0 = (tile % ntj) * 64;
+  const int i0 = (tile / ntj) * TCO, j0 = (tile % ntj) * TCI;
+  // roles of this wave: dy image / x image of its group, its 16-ci block and (TCI = 32) its co half
+  const int dyimg = C::IMG_DY == 2 ? grp : 0, ximg = C::IMG_X == 2 ? grp : 0;
+  const int cib = C::HALFCI ? (wid & 1) : wid, cobase = C::HALFCI ? (wid >> 1) * 32 : 0;
   const int b_beg = split * p.per_split;
   const int b_end = min(b_beg + p.per_split, p.nbricks);
   const int bw = p.W / BW, bh = p.H / BH, bd = p.D / BD;
   const int Hs = p.up ? p.H >> 1 : p.H, Ws = p.up ? p.W >> 1 : p.W;   // extents of x as stored
 
-  f32x4 acc[9][4];
+  f32x4 acc[9][FA];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int f = 0; f < 4; ++f) acc[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < FA; ++f) acc[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // staging roles: dy piece q = tid + 256*i -> voxel q>>3, 16-byte piece q&7 ; x piece likewise over 240 halo rows.
   // Address generation is kept off the critical path: a brick's pieces sit at FIXED byte offsets from the brick's first
@@ -148,8 +164,11 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
   const int pp = tid & 7, srow = tid >> 3;
   const int key_dy = ((srow >> 1) & 1) | (((srow >> 3) & 1) << 1), key_x = (srow >> 1) & 3;
   const int pc_dy = ((((pp >> 1) ^ key_dy) & 3) << 1) | (pp & 1), pc = ((((pp >> 1) ^ key_x) & 3) << 1) | (pp & 1);
-  const bool jcol_ok = (j0 + pc * 8) < p.Cv;       // Cv is a multiple of 32: a 64-wide tile may hang over
-  const int xcol = jcol_ok ? j0 + pc * 8 : 0;
+  // channel validity of this thread's x piece per image (Cv is a multiple of 32: a 64-wide image may hang over; TCI = 32 uses half an image)
+  bool jok[C::IMG_X];
+#pragma unroll
+  for (int m = 0; m < C::IMG_X; ++m) jok[m] = (j0 + 64 * m + pc * 8) < p.Cv && (!C::HALFCI || pc < 4);
+  const int xcol = j0 + pc * 8;
   uint32_t dyoff[DYP], xoff[XP];   // byte offsets from the brick bases
   uint32_t xedge[XP];              // which faces of the halo the piece's row lies on (bit: d-,d+,h-,h+,w-,w+); bit 6 = not a halo row
 #pragma unroll
@@ -166,7 +185,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     const int shh = p.up ? (hh + 1) >> 1 : hh, shw = p.up ? (hw + 1) >> 1 : hw;
     xoff[i] = row_ok ? (uint32_t)(((hd * Hs + shh) * Ws + shw) * p.Cv + xcol) * 2u : 0u;
     xedge[i] = (hd == 0 ? 1u : 0u) | (hd == BD - 1 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == XH - 1 ? 8u : 0u) | (hw == 0 ? 16u : 0u) |
-               (hw == BW + 1 ? 32u : 0u) | (row_ok && jcol_ok ? 0u : 64u);
+               (hw == BW + 1 ? 32u : 0u) | (row_ok ? 0u : 64u);
   }
   // Staging pipeline (two LDS brick buffers): while brick b is multiplied out of one buffer, the pieces of brick b+1 are requested
   // into the other one, one request per wave on each of the first DYP + XP steps (they have the rest of the brick to land); rows
@@ -238,40 +257,43 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
   // by hand: one s_waitcnt vmcnt(0) at the end of the brick, before the barrier that hands the buffer to the readers.
 #define WB_DMA_PIECE(i_, buf_)                                                                               \
   do {                                                                                                       \
-    if ((i_) < DYP) {                                                                                        \
-      lds_dma16(dyb + dyoff[(i_) < DYP ? (i_) : 0], lds_base + (uint32_t)((buf_)-smem) + wv * 1024 + ((i_) < DYP ? (i_) : 0) * (NT * 16)); \
+    constexpr int NDY_ = C::IMG_DY * DYP;                                                                    \
+    if ((i_) < NDY_) {                                                                                       \
+      const int m_ = ((i_) < NDY_ ? (i_) : 0) / DYP, k_ = ((i_) < NDY_ ? (i_) : 0) % DYP;                    \
+      lds_dma16(dyb + dyoff[k_] + m_ * 128, lds_base + (uint32_t)((buf_)-smem) + m_ * DY_BYTES + wv * 1024 + k_ * (NT * 16)); \
     } else {                                                                                                 \
-      const int j_ = (i_) < DYP ? 0 : (i_) - DYP;                                                            \
-      if (8 * wv + (NT / 8) * j_ < XROWS) { /* wave-uniform: the last round covers only the first XROWS rows */ \
-        const bool ok = (xedge[j_] & xout) == 0;                                                             \
-        lds_dma16(ok ? xb + xoff[j_] : zpage, lds_base + (uint32_t)((buf_)-smem) + DY_BYTES + wv * 1024 + j_ * (NT * 16)); \
+      const int q_ = (i_) < NDY_ ? 0 : (i_) - NDY_, m_ = q_ / XP, k_ = q_ % XP;                              \
+      if (8 * wv + (NT / 8) * k_ < XROWS) { /* wave-uniform: the last round covers only the first XROWS rows */ \
+        const bool ok = (xedge[k_] & xout) == 0 && jok[m_];                                                  \
+        lds_dma16(ok ? xb + xoff[k_] + m_ * 128 : zpage,                                                     \
+                  lds_base + (uint32_t)((buf_)-smem) + C::IMG_DY * DY_BYTES + m_ * X_BYTES + wv * 1024 + k_ * (NT * 16)); \
       }                                                                                                      \
     }                                                                                                        \
   } while (0)
 
   // lane parts of the fragment addresses (see the brick loop)
-  int abase[4], xbase[6];
+  int abase[FA], xbase[6];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) abase[f] = dy_off(8 * lg + jr, f * 16 + 4 * cq);
+  for (int f = 0; f < FA; ++f) abase[f] = dy_off(8 * lg + jr, cobase + f * 16 + 4 * cq);
 #pragma unroll
   for (int ci = 0; ci < 6; ++ci) {
     const int c = ci < 3 ? ci : ci + 1;   // R mod 8 is one of 0,1,2,4,5,6 (R = 12 a + b, b < 3)
-    const int lrow = lg * XW + jr, col = wid * 16 + 4 * cq;
+    const int lrow = lg * XW + jr, col = cib * 16 + 4 * cq;
     xbase[ci] = lrow * 128 + ((((col >> 4) ^ ((c + lrow) >> 1)) & 3) << 5) + ((col & 15) << 1);
   }
 
   if (b_beg < b_end) {
     WB_ORIGIN_NEXT();                                     // brick b_beg
 #pragma unroll
-    for (int i = 0; i < DYP + XP; ++i) WB_DMA_PIECE(i, smem);
+    for (int i = 0; i < NPIECE; ++i) WB_DMA_PIECE(i, smem);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int b = b_beg; b < b_end; ++b) {
-    // this wave group's K chunks: chunk kc of the brick = d plane kc >> 1, h half kc & 1; NG = 2: group g owns plane g
-    const char* dys = smem + ((b - b_beg) & 1) * BUF_BYTES + grp * ((4 / NG) * 4096);
-    const char* xs = smem + ((b - b_beg) & 1) * BUF_BYTES + DY_BYTES + grp * ((4 / NG) / 2) * (XH * XW * 128);
+    // this wave's images; K chunk kc of the brick = d plane kc >> 1, h half kc & 1; KSPLIT = 2: group g owns plane g (chunks 2g, 2g + 1)
+    const char* dys = smem + ((b - b_beg) & 1) * BUF_BYTES + dyimg * DY_BYTES + (KSPLIT == 2 ? grp * (2 * 4096) : 0);
+    const char* xs = smem + ((b - b_beg) & 1) * BUF_BYTES + C::IMG_DY * DY_BYTES + ximg * X_BYTES + (KSPLIT == 2 ? grp * (XH * XW * 128) : 0);
     char* nxt = smem + (((b - b_beg) & 1) ^ 1) * BUF_BYTES;
     const bool more = b + 1 < b_end;                      // block-uniform
     WB_ORIGIN_NEXT();                                     // brick b + 1: its pieces are requested during this one
@@ -291,25 +313,31 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #define WB_XADDR(r_) (xs + xbase[((r_)&7) < 3 ? ((r_)&7) : ((r_)&7) - 1] + (r_)*128)
 #define WB_B(kc_, t_) tr_frag(WB_XADDR(WB_XR(kc_, t_)), WB_XADDR(WB_XR(kc_, t_) + 4))
     constexpr int PF = WB_PF;  // the x fragment is fetched PF steps (4 PF MFMAs) ahead of its use, through a (PF + 1)-deep register ring
-    bf16x8 fa[2][4], fbr[PF + 1];
+    bf16x8 fa[2][FA], fbr[PF + 1];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) fa[0][f] = WB_A(0, f);
+    for (int f = 0; f < FA; ++f) fa[0][f] = WB_A(0, f);
 #pragma unroll
     for (int q = 0; q < PF; ++q) fbr[q] = WB_B(q / 9, q % 9);
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
       const int kc = st / 9, t = st % 9;
-      if (st < DYP + XP) {   // piece st of brick b+1 -> the other LDS buffer
-        if (more) WB_DMA_PIECE(st, nxt);
+      if (st < NPIECE) {   // piece st of brick b+1 -> the other LDS buffer
+#if WB_ABL != 1
+        if (more) WB_DMA_PIECE(st < NPIECE ? st : 0, nxt);
+#endif
       }
+#if WB_ABL == 2
+      if (st + PF < NSTEP && b == b_beg) fbr[(st + PF) % (PF + 1)] = WB_B((st + PF) / 9, (st + PF) % 9);
+#else
       if (st + PF < NSTEP) fbr[(st + PF) % (PF + 1)] = WB_B((st + PF) / 9, (st + PF) % 9);
-      if (t == 4 && kc < 4 / NG - 1) {
+#endif
+      if (t == 4 && kc < 4 / KSPLIT - 1) {
 #pragma unroll
-        for (int f = 0; f < 4; ++f) fa[(kc + 1) & 1][f] = WB_A(kc + 1, f);
+        for (int f = 0; f < FA; ++f) fa[(kc + 1) & 1][f] = WB_A(kc + 1, f);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this step's MFMAs (hipcc sinks them next to their use otherwise)
 #pragma unroll
-      for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st % (PF + 1)], acc[t][f], 0, 0, 0);
+      for (int f = 0; f < FA; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st % (PF + 1)], acc[t][f], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
 #undef WB_A
@@ -318,15 +346,17 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #undef WB_B
 
     __builtin_amdgcn_sched_barrier(0);
+#if WB_ABL != 3
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // this brick's reads and the next brick's pieces are complete
+#endif
   }
 #undef WB_ORIGIN_NEXT
 #undef WB_DMA_PIECE
 
-  // ---- the two wave groups hold partial sums over different K chunks: group 1 hands its accumulators to group 0 through the (now
-  //      idle) LDS brick buffers in two halves (5 + 4 taps: 80 KB of the 92 KB), so the block writes ONE partial slab ----
-  if (NG == 2) {
+  // ---- KSPLIT = 2: the two wave groups hold partial sums over different K chunks: group 1 hands its accumulators to group 0 through the
+  //      (now idle) LDS brick buffers in two halves (5 + 4 taps: 80 KB of the 92 KB), so the block writes ONE partial slab ----
+  if (KSPLIT == 2) {
     f32x4* xch = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -336,29 +366,29 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #pragma unroll
         for (int t = t0; t < t1; ++t)
 #pragma unroll
-          for (int f = 0; f < 4; ++f) xch[(((t - t0) * 4 + f) * 4 + wid) * 64 + lane] = acc[t][f];
+          for (int f = 0; f < FA; ++f) xch[(((t - t0) * FA + f) * 4 + wid) * 64 + lane] = acc[t][f];
       }
       __syncthreads();
       if (grp == 0) {
 #pragma unroll
         for (int t = t0; t < t1; ++t)
 #pragma unroll
-          for (int f = 0; f < 4; ++f) acc[t][f] += xch[(((t - t0) * 4 + f) * 4 + wid) * 64 + lane];
+          for (int f = 0; f < FA; ++f) acc[t][f] += xch[(((t - t0) * FA + f) * 4 + wid) * 64 + lane];
       }
     }
     if (grp == 1) return;
   }
-  // D[i][j]: lane holds i = 16 f + 4 lg + r, j = lane & 15
+  // D[i][j]: lane holds i = 16 f + 4 lg + r, j = lane & 15 (of the wave's co / ci block)
   float* out = p.ws + (int64_t)split * (9 * p.nkd) * p.Cu * p.Cv;
-  const int j = j0 + wid * 16 + (lane & 15);
+  const int j = j0 + ximg * 64 + cib * 16 + (lane & 15);
   if (j < p.Cv) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       float* ot = out + (int64_t)((p.nkd == 3 ? kd * 9 : 0) + t) * p.Cu * p.Cv;
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
+      for (int f = 0; f < FA; ++f)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ot[(int64_t)(i0 + f * 16 + lg * 4 + r) * p.Cv + j] = acc[t][f][r];
+        for (int r = 0; r < 4; ++r) ot[(int64_t)(i0 + dyimg * 64 + cobase + f * 16 + lg * 4 + r) * p.Cv + j] = acc[t][f][r];
     }
   }
 }
@@ -366,7 +396,22 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 struct BrickSplit {
   int splits, per_split;
   int xcd_map, G, Q, gpc, ngroups, ntg, pair, blocks;   // co-located launch (see WBrickParams); blocks = grid size
+  int cfg;                                              // tile shape: 0 = 64 x 64, 1 = 128 x 64, 2 = 64 x 128, 3 = 64 x 32
 };
+constexpr int TCO_OF[4] = {64, 128, 64, 64}, TCI_OF[4] = {64, 64, 128, 32};
+std::atomic<int> g_wb_xcd{1};    // 0: the 2-D grid (a (tile, kd) block range per blockIdx.y)
+std::atomic<int> g_wb_order{1};
+std::atomic<int> g_wb_tiles{1};  // 0: 64 x 64 tiles only
+
+// tile shape by staged bytes per MFMA (256 / TCI + 400 / TCO, see the head of the file)
+int pick_cfg(int Cu, int Cv) {
+  if (!g_wb_tiles) return 0;
+  if (Cv == 32) return 3;
+  if (Cu % 128 == 0) return 1;
+  if (Cv % 128 == 0) return 2;
+  return 0;
+}
+
 BrickSplit plan(int nbricks, int Cu, int Cv, int nkd = 3) {
   const int tiles = (Cu / 64) * ((Cv + 63) / 64) * nkd;
   // One block per CU (one wave per SIMD, 256 CUs): the grid should be a whole number of rounds of 256 blocks -- 384 blocks run
@@ -381,14 +426,15 @@ BrickSplit plan(int nbricks, int Cu, int Cv, int nkd = 3) {
   if (splits < 1) splits = 1;
   const int per = (nbricks + splits - 1) / splits;
   splits = (nbricks + per - 1) / per;
-  return BrickSplit{splits, per, 0, 0, 0, 0, 0, 0, 0, splits * tiles};
+  return BrickSplit{splits, per, 0, 0, 0, 0, 0, 0, 0, splits * tiles, 0};
 }
 
 // Co-located plan (3x3x3 only).  Groups of G = 3 (kd) x gs (tiles) blocks share a brick range; gs = 2 pairs the two tiles that
 // share the larger operand stream when the tile grid allows it.  A chunk of 256 ids holds 8 * Q co-located groups (Q = 32 / G per
 // XCD: 30 of its 32 CUs) plus (256 - 8 Q G) / G groups of consecutive ids on the 16 CUs left over.
-BrickSplit plan_xcd(int nbricks, int Cu, int Cv) {
-  const int ni = Cu / 64, ntj = (Cv + 63) / 64, ntiles = ni * ntj;
+BrickSplit plan_xcd(int nbricks, int Cu, int Cv, int cfg) {
+  const int TCO = TCO_OF[cfg], TCI = TCI_OF[cfg];
+  const int ni = Cu / TCO, ntj = (Cv + TCI - 1) / TCI, ntiles = ni * ntj;
   // fabric bytes ~ 1.25 X ni + Y ntj without pairing (X = |x|, Y = |dy|, a block reads X / ntj and Y / ni); pairing over i halves the x
   // term, pairing over j the dy term
   const double X = 1.25 * Cv * ni, Y = 1.0 * Cu * ntj;
@@ -409,12 +455,29 @@ BrickSplit plan_xcd(int nbricks, int Cu, int Cv) {
   const int per = (nbricks + splits - 1) / splits;
   splits = (nbricks + per - 1) / per;
   const int ngroups = splits * ntg, chunks = (ngroups + gpc - 1) / gpc;
-  return BrickSplit{splits, per, 1, G, Q, gpc, ngroups, ntg, pair, chunks * 256};
+  return BrickSplit{splits, per, 1, G, Q, gpc, ngroups, ntg, pair, chunks * 256, cfg};
 }
-std::atomic<int> g_wb_xcd{1};   // 0: the 2-D grid (a (tile, kd) block range per blockIdx.y)
-std::atomic<int> g_wb_order{1};
 
-BrickSplit plan3(int nbricks, int Cu, int Cv) { return g_wb_xcd ? plan_xcd(nbricks, Cu, Cv) : plan(nbricks, Cu, Cv); }
+BrickSplit plan3(int nbricks, int Cu, int Cv) {
+  if (!g_wb_xcd) return plan(nbricks, Cu, Cv);
+  const int cfg = pick_cfg(Cu, Cv);
+  const BrickSplit a = plan_xcd(nbricks, Cu, Cv, cfg);
+  if (cfg == 0 || cfg == 3) return a;
+  // a larger tile halves the number of blocks per brick range: on small volumes (the 16x16x8 level: 512 bricks, at least 16 per
+  // block) that leaves CUs idle -- measured 874 -> 763 TFLOP/s on 128 -> 128 channels -- so keep 64 x 64 tiles there
+  const BrickSplit b = plan_xcd(nbricks, Cu, Cv, 0);
+  const int used_a = a.ngroups * a.G, used_b = b.ngroups * b.G;
+  return (used_a < 230 && used_b > used_a) ? b : a;
+}
+
+template <int TCO, int TCI> void launch_cfg(dim3 grid, hipStream_t stream, const WBrickParams& p) {
+  static std::once_flag attr_once;   // hipFuncSetAttribute once per process and instantiation, race-free
+  constexpr int lds = 2 * WCfg<TCO, TCI>::BUF_BYTES;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel<TCO, TCI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  });
+  hipLaunchKernelGGL((wgrad_brick_kernel<TCO, TCI>), grid, dim3(NT), lds, stream, p);
+}
 
 }  // namespace
 
@@ -424,26 +487,31 @@ bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int d
          (int64_t)N * D * H * W / BV < (1 << 30);
 }
 int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co) {
-  // the workspace must hold the partial slabs of either launch form
+  // the workspace must hold the partial slabs of every launch form
   const int nb = (int)((int64_t)N * D * H * W / BV);
-  const int a = plan(nb, Co, Ci).splits, b = plan_xcd(nb, Co, Ci).splits;
-  return a > b ? a : b;
+  int m = plan(nb, Co, Ci).splits;
+  for (int cfg = 0; cfg < 4; ++cfg) {
+    if ((cfg == 1 && Co % 128) || (cfg == 2 && Ci % 128) || (cfg == 3 && Ci != 32)) continue;
+    const int b = plan_xcd(nb, Co, Ci, cfg).splits;
+    if (b > m) m = b;
+  }
+  return m;
 }
 int pcrl_wgrad_brick_slabs(int N, int D, int H, int W, int Ci, int Co) { return plan3((int)((int64_t)N * D * H * W / BV), Co, Ci).splits; }
-void pcrl_wgrad_brick_set_xcd(int on, int order) { g_wb_xcd = on; g_wb_order = order; }
+void pcrl_wgrad_brick_set_xcd(int on, int order, int tiles) { g_wb_xcd = on; g_wb_order = order; g_wb_tiles = tiles; }
 int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co,
                             hipStream_t stream) {
-  static std::once_flag attr_once;   // hipFuncSetAttribute once per process, race-free
-  const size_t lds = 2 * BUF_BYTES;
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  });
   const int nbricks = (int)((int64_t)N * D * H * W / BV);
   const BrickSplit sp = plan3(nbricks, Co, Ci);
   WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 0, 3, sp.xcd_map, g_wb_order, sp.G, sp.Q, sp.gpc, sp.ngroups, sp.ntg, sp.pair};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64) * 3));
   if (sp.xcd_map) grid = dim3((unsigned)sp.blocks);
-  hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(NT), lds, stream, p);
+  switch (sp.cfg) {
+    case 1: launch_cfg<128, 64>(grid, stream, p); break;
+    case 2: launch_cfg<64, 128>(grid, stream, p); break;
+    case 3: launch_cfg<64, 32>(grid, stream, p); break;
+    default: launch_cfg<64, 64>(grid, stream, p); break;
+  }
   return pcrl_check_launch("wgrad_brick");
 }
 
@@ -455,15 +523,10 @@ bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype)
 }
 int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co) { return plan((int)((int64_t)N * H * W / BV), Co, Ci, 1).splits; }
 int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, int up, hipStream_t stream) {
-  static std::once_flag attr_once;   // hipFuncSetAttribute once per process, race-free
-  const size_t lds = 2 * BUF_BYTES;
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  });
   const int nbricks = (int)((int64_t)N * H * W / BV);
   const BrickSplit sp = plan(nbricks, Co, Ci, 1);
   WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, up, 1, 0, 0, 0, 0, 0, 0, 0, 0};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64)));
-  hipLaunchKernelGGL(wgrad_brick_kernel, grid, dim3(NT), lds, stream, p);
+  launch_cfg<64, 64>(grid, stream, p);
   return pcrl_check_launch("wgrad_brick2d");
 }

@@ -96,9 +96,9 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
     check(dx, xr.grad, dt, "conv3 dgrad")
     # weight gradient (float32 out in both modes): both bf16 fragment-fetch paths
     nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
-    # impl 0 = auto (LDS-halo brick kernel where eligible, XCD co-located launch), 2 = the brick kernel on its plain 2-D grid,
-    # 1 = gather kernel; tr = bf16 fragment fetch of the gather kernel
-    for impl, tr in (((0, 1), (2, 1), (1, 1), (1, 0)) if dt == torch.bfloat16 else ((0, 1),)):
+    # impl 0 = auto (LDS-halo brick kernel where eligible, XCD co-located launch, tile shape by channel counts), 6 = the same with
+    # 64 x 64 tiles only, 2 = the brick kernel on its plain 2-D grid, 1 = gather kernel; tr = bf16 fragment fetch of the gather kernel
+    for impl, tr in (((0, 1), (6, 1), (2, 1), (1, 1), (1, 0)) if dt == torch.bfloat16 else ((0, 1),)):
         L.debug_set_wgrad_impl(impl)
         L.debug_set_wgrad_tr(tr)
         dw = torch.zeros(Co, Ci, 3, 3, 3, dtype=torch.float32, device=DEV)
