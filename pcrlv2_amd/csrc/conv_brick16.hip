@@ -20,12 +20,23 @@
 // lane-linear, so the swizzle is applied to the SOURCE address (lane (row, physical slot s) loads logical slot s ^ key(row)).
 // Halo rows outside the volume are loaded from a 16-byte zero page.
 //
+// Measured (timing ablations, same box, 128 -> 64 channels at 64x64x32): without the halo requests after the first chunk -17 %, without the
+// weight staging -13 %, without both -22 % (1 560 TFLOP/s); requesting the dead planes early changes nothing.  What is left on the
+// table is bytes staged per MFMA, not latency.
+//
 // LDS: halo 68 KiB (single buffer: 1080 rows x 64 B, rounded up to whole 1 KiB DMA pieces) + one weight stage 12 KiB = 80 KiB -> two
 // blocks (eight waves) per CU.  The next chunk's halo is requested as soon as every wave holds the last fragments of the current one
 // (first barrier of the chunk's last stage) and lands under that stage's remaining MFMAs and the co-resident block's work.
 #include "common.h"
 #include <atomic>
 #include <mutex>
+
+#ifndef B16_EARLY
+#define B16_EARLY 0   // 1: request the dead planes of the halo early (measured equal to 0, the whole halo at the end of the chunk: the co-resident block covers the latency)
+#endif
+#ifndef B16_ABL
+#define B16_ABL 0   // timing ablations (wrong results): bit 0 no weight staging after the first stage, bit 1 no halo requests after the first chunk
+#endif
 
 namespace {
 
@@ -56,8 +67,18 @@ __device__ __forceinline__ int woff(int row, int slot) {
   return row * 64 + ((slot ^ key) << 4);
 }
 
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(1))) const void gbl_void;
+// One LDS-DMA request: every lane's 16 bytes at `gsrc` land at LDS byte address `lds_dst` (wave-uniform) + 16 * lane.  M0 carries the
+// destination and is compiler-reserved: saved and restored inside the statement.  Issued from inline asm because hipcc waits
+// vmcnt(0) before the next barrier / LDS access behind the builtin (it cannot prove they do not touch the DMA's destination), which
+// would expose the latency of the requests that are issued early (see STAGE); completion is counted by hand (s_waitcnt vmcnt(0) at
+// the end of the chunk; the compiler's own counted waits for the weight loads can only over-wait, vmcnt retires in order).
+__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
 
 template <int BN>
 __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Params p) {
@@ -101,11 +122,13 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   // The source address of a piece is recomputed per request (a few dozen VALU operations per piece and chunk, nothing next to a chunk's
   // 864 MFMAs): 17 precomputed addresses per lane do not fit beside 128 accumulators.  `lo` is made opaque so that the compiler does
   // not hoist the 17 address computations out of the chunk loop (and spill them).
-#define DMA_HALO(c_)                                                                                       \
+#define DMA_HALO(c_, P0_, P1_) /* pieces [P0_, P1_) */                                                     \
   do {                                                                                                     \
     int lo = lane;                                                                                         \
     asm volatile("" : "+v"(lo));                                                                           \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                      \
+      if (4 * i + 3 < (P0_) || 4 * i >= (P1_)) continue;         /* compile time */                        \
+      if (wid + 4 * i < (P0_) || wid + 4 * i >= (P1_)) continue; /* wave-uniform */                        \
       const int row = (wid + 4 * i) * 16 + (lo >> 2);                                                      \
       const int hd = row / (HH * HP), rem = row % (HH * HP), hh = rem / HP, hw = rem % HP;                 \
       const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                         \
@@ -113,9 +136,14 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
       const int ls = (lo & 3) ^ key_w(hw);                                                                 \
       const int64_t vox = (((int64_t)n * p.D + d) * p.H + h) * p.W + w;                                    \
       const char* src = ok ? xb + ((vox * K + (c_)*32 + ls * 8) << 1) : zp;                                \
-      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(halo + (wid + 4 * i) * 1024), 16, 0, 0); \
+      lds_dma16(src, lds_base + (wid + 4 * i) * 1024);                                                     \
     }                                                                                                      \
   } while (0)
+  // Rows of the halo die plane by plane: stage (kd, kh) reads planes kd .. kd + 3, so plane 0 is dead after the three kd = 0 stages and
+  // plane 1 after the kd = 1 stages.  The pieces that lie inside those planes (11 + 11 of 68) are requested at those points, two and one
+  // thirds of a chunk ahead of their use; the other 46 at the end of the chunk.
+  constexpr int PA = (HH * HP) / 16, PB = (2 * HH * HP) / 16;   // 11, 22: pieces wholly inside plane 0 / planes 0-1
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   // ---- weight staging through registers: 3 pieces per thread (taps kw = 0,1,2 of the stage), row co = tid >> 2, slot tid & 3 ----
   const bool wthread = BN == 64 || (tid >> 2) < BN;
@@ -192,8 +220,9 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     if (sn == NS) { sn = 0; cn = c + 1; }                                                                  \
     const bool last = (cn == nchunk);                                                                      \
     if (last) { cn = c; sn = s9; }                                                                         \
-    LOAD_W(cn, sn);                                                                                        \
-    const bool halo_next = (s9 == NS - 1) && !last; /* block-uniform */                                    \
+    if (!(B16_ABL & 1)) LOAD_W(cn, sn);                                                                    \
+    const bool halo_next = (s9 == NS - 1) && !last && !(B16_ABL & 2); /* block-uniform */                  \
+    const bool more_chunks = c + 1 < nchunk && !(B16_ABL & 2);                                             \
     const int tap64 = ((s9 / 3) * HH + (s9 % 3)) * (HP * 64);                                              \
     const int ntap64 = ((sn / 3) * HH + (sn % 3)) * (HP * 64);                                             \
     /* ht0: kw 0, half 0 */                                                                                \
@@ -225,8 +254,10 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     SB();                                                                                                  \
     /* ht5: kw 2, half 1 -- every LDS read of this stage (and, in a chunk's last stage, of this chunk's halo) is complete */ \
     __syncthreads();                                                                                       \
-    STORE_W();                                                                                             \
-    if (halo_next) DMA_HALO(c + 1);                                                                        \
+    if (!(B16_ABL & 1)) STORE_W();                                                                         \
+    if (B16_EARLY && more_chunks && s9 == 2) DMA_HALO(c + 1, 0, PA);                                        \
+    if (B16_EARLY && more_chunks && s9 == 5) DMA_HALO(c + 1, PA, PB);                                       \
+    if (halo_next) DMA_HALO(c + 1, B16_EARLY ? PB : 0, NDMA);                                               \
     MFMA_HALF(1, P_, 1, 0, 2);                                                                             \
     PIPE_WRITES(3, FN / 2);                                                                                     \
     SB();                                                                                                  \
@@ -241,7 +272,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     s9 = sn;                                                                                               \
   } while (0)
 
-  DMA_HALO(0);
+  DMA_HALO(0, 0, NDMA);
   LOAD_W(0, 0);
   STORE_W();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
