@@ -257,6 +257,38 @@ def make_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, base_
     print(f"[{tag}] wrote fixture; oracle == reference over {nsteps} steps")
 
 
+def make_eval(tag, b, dhw, refmod, ref_train, ref_utils):
+    """Eval-mode forward of the REAL reference (model.eval(): running statistics) on a state whose buffers were moved by one oracle
+    training step -- what a consumer of the checkpoint runs (README.md:48-55).  The tests rebuild the state with the oracle (it is
+    deterministic) and compare the HIP eval forward with these outputs."""
+    dt = torch.float64
+    st0 = O.fill_state(dt)
+    with torch.backends.mkldnn.flags(enabled=False):
+        st1, _, _, _ = O.train_steps(st0, [O.fill_batch(b, dhw, dtype=dt, seed=31)], 0, 1e-3, 240, 0)
+        x = O.fill_batch(b, dhw, dtype=dt, seed=77)[0]
+        model = refmod.PCRLv23d().double()
+        model.load_state_dict(st1, strict=True)
+        model.eval()
+        with torch.no_grad():
+            out, feats, masks = model(x)
+            o_out, o_feats, o_masks = O.forward(st1, x, training=False)
+    close(o_out, out, 1e-10, "eval out")
+    for i in range(3):
+        close(o_feats[i][0], feats[i][0], 1e-9, f"eval pro{i}")
+        close(o_feats[i][1], feats[i][1], 1e-9, f"eval pre{i}")
+        close(o_masks[i], masks[i], 1e-10, f"eval mask{i}")
+    fx = OrderedDict()
+    fx["meta/b"], fx["meta/dhw"], fx["meta/state_batch_seed"], fx["meta/input_seed"] = np.int64(b), np.array(dhw), np.int64(31), np.int64(77)
+    for k, v in summarize(out, 512).items():
+        fx[f"out/{k}"] = v
+    for i in range(3):
+        fx[f"pro{i}"], fx[f"pre{i}"] = feats[i][0].numpy().copy(), feats[i][1].numpy().copy()
+        for k, v in summarize(masks[i], 512).items():
+            fx[f"mask{i}/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **fx)
+    print(f"[{tag}] oracle eval == reference eval; wrote fixture")
+
+
 def make_init(tag, refmod, seed=7):
     """Freshly constructed reference model under torch.manual_seed(seed): per-tensor sum, |sum| and leading entries.
     A drop-in model class must consume the RNG in the same order to start from the same point (models/pcrlv2_model_3d.py:85-104)."""
@@ -277,6 +309,9 @@ def main():
     refmod, ref_train, ref_utils = load_reference()
     make_init("init_seed7", refmod)
     if "--init-only" in sys.argv:
+        return
+    make_eval("eval_b2_32x32x16", 2, (32, 32, 16), refmod, ref_train, ref_utils)
+    if "--eval-only" in sys.argv:
         return
     make_case("c_small_b4_32x32x16", 4, (32, 32, 16), 2, refmod, ref_train, ref_utils)
     make_case("c_luna_b2_64x64x32", 2, (64, 64, 32), 1, refmod, ref_train, ref_utils)

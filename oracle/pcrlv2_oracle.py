@@ -160,10 +160,17 @@ def fill_batch(b: int, dhw=(32, 32, 16), local=16, dtype=torch.float64, seed: in
 # ----------------------------------------------------------------------------------------
 # Forward pass
 # ----------------------------------------------------------------------------------------
+_EVAL = False   # set by forward(training=False): batch norms use the running statistics (nn.Module.eval() semantics)
+
+
 def _bn_train(x, st, p, new_bufs):
     """Training-mode batch norm (any rank, channel dim 1): biased batch variance for the
     normalisation, unbiased for running_var, momentum 0.1 (nn.BatchNorm{1,3}d defaults as
-    used at pcrlv2_model_3d.py:12,55,57)."""
+    used at pcrlv2_model_3d.py:12,55,57).  In eval mode (forward(training=False)): running statistics, no update."""
+    if _EVAL:
+        shp = [1, -1] + [1] * (x.dim() - 2)
+        rm, rv = st[p + ".running_mean"].to(x.dtype), st[p + ".running_var"].to(x.dtype)
+        return (x - rm.view(shp)) / torch.sqrt(rv.view(shp) + BN_EPS) * st[p + ".weight"].view(shp) + st[p + ".bias"].view(shp)
     dims = [0] + list(range(2, x.dim()))
     m = x.numel() // x.shape[1]
     mean = x.mean(dim=dims)
@@ -184,6 +191,10 @@ def _bn_train(x, st, p, new_bufs):
 def _luconv(x, st, p, new_bufs, act="relu"):
     """LUConv.forward, pcrlv2_model_3d.py:32-34: act(bn1(conv1(x))); conv 3x3x3 pad 1 with bias (:9)."""
     y = F.conv3d(x, st[p + ".conv1.weight"], st[p + ".conv1.bias"], padding=1)
+    if (p + ".bn1.running_mean") not in st:
+        # OPTIONAL non-reference mode of the engine (PCRLv23d(norm='gn', act='silu'), north_star's GroupNorm + SiLU): the state has
+        # no running statistics for this layer -> GroupNorm(8) + SiLU.  Checked against torch's own F.group_norm / F.silu only.
+        return F.silu(F.group_norm(y, 8, st[p + ".bn1.weight"], st[p + ".bn1.bias"], eps=1e-5))
     y = _bn_train(y, st, p + ".bn1", new_bufs)
     return torch.relu(y) if act == "relu" else torch.sigmoid(y)
 
@@ -202,10 +213,18 @@ def _up_transition(x, st, name, new_bufs):
     return x, x_pro, x_pre, x_mask
 
 
-def forward(st, x, local: bool = False, new_bufs=None):
+def forward(st, x, local: bool = False, new_bufs=None, training: bool = True):
     """PCRLv23d.forward, pcrlv2_model_3d.py:112-133.  `st` maps state_dict names to tensors
     (parameters may require grad).  Returns (out, [[pro,pre]x3], [mask x3] or []).
-    `new_bufs` (dict) receives the updated BN running statistics, in call order."""
+    `new_bufs` (dict) receives the updated BN running statistics, in call order.
+    training=False: the module in .eval() mode (what a consumer of the checkpoint runs for validation, README.md:48-55)."""
+    global _EVAL
+    if not training:
+        _EVAL = True
+        try:
+            return forward(st, x, local, None, True)
+        finally:
+            _EVAL = False
     h = x
     for i, (p, _, _) in enumerate(ENCODER):
         if i in (2, 4, 6):

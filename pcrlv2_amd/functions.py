@@ -128,7 +128,9 @@ class LUConvFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, mod):
         dt = mod.compute_dtype
-        a, sv = ops.luconv_forward(x, w, b, gamma, beta, mod.bn1.running_mean, mod.bn1.running_var, mod._packed, mod._act, dt)
+        gn = getattr(mod, "_gn_groups", 0)
+        a, sv = ops.luconv_forward(x, w, b, gamma, beta, None if gn else mod.bn1.running_mean, None if gn else mod.bn1.running_var,
+                                   mod._packed, mod._act, dt, gn_groups=gn)
         mod._count_batch()
         ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
         ctx.wref, ctx.gref = w, gamma
@@ -182,8 +184,10 @@ class UpStageFn(Function):
         x = ops.to_act(x, dt)
         up = ops.convt_forward(x, up_w, up_b, mod._packed_up, dt)
         l0, l1, ld = mod.ops[0], mod.ops[1], mod.deep_supervision_head
-        a0, sv0 = ops.luconv_forward(up, w0, b0, g0, be0, l0.bn1.running_mean, l0.bn1.running_var, l0._packed, ACT_RELU, dt)
-        a1, sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, l1.bn1.running_mean, l1.bn1.running_var, l1._packed, ACT_RELU, dt)
+        gn = getattr(l0, "_gn_groups", 0)
+        rs = lambda m: (None, None) if gn else (m.bn1.running_mean, m.bn1.running_var)
+        a0, sv0 = ops.luconv_forward(up, w0, b0, g0, be0, *rs(l0), l0._packed, l0._act, dt, gn_groups=gn)
+        a1, sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gn_groups=gn)
         g = ops.gap_forward(a1, dt)
         x_pro, m_pro, r_pro = ops.bn1d_forward(g, bn_g, bn_b, mod.bn.running_mean, mod.bn.running_var, relu=False)
         h0 = ops.linear_forward(x_pro, p0_w, p0_b)

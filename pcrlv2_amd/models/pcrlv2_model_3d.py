@@ -5,6 +5,7 @@ Same public classes, constructor arguments, forward signatures, return tuples, a
 through `pcrlv2_amd.functions`.  torch.nn layers appear here ONLY as parameter containers: they provide the reference's
 parameter names / shapes / default initialisation (so an identical `torch.manual_seed` yields identical initial
 weights); their forward() is never called.  There is no CPU / eager fallback: non-GPU inputs raise.
+`model.eval()` runs the same kernels on the running statistics (inference; `_forward_eval`).
 
 Unsupported on purpose (NotImplementedError at construction): norm in {'gn','in'} and act in {'prelu','elu'} -- accepted
 as strings by the reference but never instantiated ('gn' crashes there) -- in_channels != 1, n_class != 1.
@@ -15,11 +16,14 @@ import torch
 import torch.nn as nn
 
 from .. import config, functions as Fn, ops
-from .._lib import ACT_RELU, ACT_SIGMOID
+from .._lib import ACT_RELU, ACT_SIGMOID, ACT_SILU
 
-_ACTS = {"relu": ACT_RELU, "sigmoid": ACT_SIGMOID}
+# 'silu' and norm='gn' are OPTIONAL, NON-REFERENCE modes (BASELINE.json's north_star names GroupNorm + SiLU; the reference rejects
+# 'silu' and crashes on 'gn'): PCRLv23d(norm='gn', act='silu') runs conv -> GroupNorm(8) -> SiLU in every LUConv except
+# the 1-channel deep-supervision heads, which keep BatchNorm + sigmoid (GroupNorm(8, 1) cannot exist).  Default = the reference.
+_ACTS = {"relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "silu": ACT_SILU}
 _NO_KERNEL_ACTS = ("prelu", "elu")
-_NO_KERNEL_NORMS = ("gn", "in")
+_NO_KERNEL_NORMS = ("in",)
 
 
 class _Counted:
@@ -46,18 +50,22 @@ class LUConv(nn.Module, _Counted):
         super().__init__()
         if norm in _NO_KERNEL_NORMS:
             raise NotImplementedError(f"normalization type {norm} has no gfx950 kernel ('bn' is the reference default and its only working setting)")
-        if norm != "bn":
+        if norm not in ("bn", "gn"):
             raise ValueError('normalization type {} is not supported'.format(norm))
         if act in _NO_KERNEL_ACTS:
             raise NotImplementedError(f"activation type {act} has no gfx950 kernel")
         if act not in _ACTS:
             raise ValueError('activation type {} is not supported'.format(act))
         self.conv1 = nn.Conv3d(in_chan, out_chan, 3, padding=1)               # container: weight [Co,Ci,3,3,3], bias [Co]
-        self.bn1 = nn.BatchNorm3d(out_chan, momentum=ops.BN_MOMENTUM)          # container: affine + running statistics
+        self._gn_groups = 8 if (norm == "gn" and out_chan > 1) else 0
+        if self._gn_groups:
+            self.bn1 = nn.GroupNorm(8, out_chan)                              # the reference's attribute name for either norm (:13-14)
+        else:
+            self.bn1 = nn.BatchNorm3d(out_chan, momentum=ops.BN_MOMENTUM)      # container: affine + running statistics
         self._act = _ACTS[act]
         self.compute_dtype = config.default_compute_dtype()
         self._packed = ops.PackedWeights("conv3")
-        self._init_counter([self.bn1])
+        self._init_counter([] if self._gn_groups else [self.bn1])
 
     def forward(self, x):
         x = x.float().contiguous() if self.conv1.in_channels == 1 else ops.to_act(x, self.compute_dtype)
@@ -77,8 +85,8 @@ class UpTransition(nn.Module, _Counted):
 
     def __init__(self, inChans, outChans, depth, act, norm):
         super().__init__()
-        if act != "relu":
-            raise NotImplementedError("UpTransition is implemented for act='relu' (the reference default)")
+        if act not in ("relu", "silu"):
+            raise NotImplementedError("UpTransition is implemented for act='relu' (the reference default) and the optional 'silu'")
         c = 64 << depth
         self.depth = depth
         self.up_conv = nn.ConvTranspose3d(inChans, outChans, 2, stride=2)
@@ -86,6 +94,7 @@ class UpTransition(nn.Module, _Counted):
         self.bn = nn.BatchNorm1d(c)
         self.predictor_head = nn.Sequential(nn.Linear(c, 2 * c), nn.BatchNorm1d(2 * c), nn.ReLU(inplace=True), nn.Linear(2 * c, c))
         self.deep_supervision_head = LUConv(c, 1, "sigmoid", norm)
+        self._act = _ACTS[act]
         self.compute_dtype = config.default_compute_dtype()
         self._packed_up = ops.PackedWeights("convt")
         self._init_counter([self.bn, self.predictor_head[1]])
@@ -200,12 +209,43 @@ class PCRLv23d(nn.Module):
         ops.bump_weights_epoch()
         return out
 
+    @torch.no_grad()
+    def _forward_eval(self, x, local):
+        """`model.eval()` forward (what a consumer of the checkpoint runs for validation, README.md:48-55): the same kernels with every
+        BatchNorm on its RUNNING statistics, nothing updated, no autograd graph (inference only: fine-tuning runs in train mode)."""
+        dt = self.compute_dtype
+
+        def lu(m, h):
+            c, n, gn = m.conv1, m.bn1, m._gn_groups
+            return ops.luconv_forward(h, c.weight, c.bias, n.weight, n.bias, None if gn else n.running_mean, None if gn else n.running_var,
+                                      m._packed, m._act, dt, training=False, gn_groups=gn)[0]
+
+        h = x.float().contiguous()
+        for i, ((name, _, _), attr) in enumerate(zip(_ENCODER, _SKIPS)):
+            if i:
+                h = ops.maxpool_forward(ops.to_act(h, dt), dt)
+            st = getattr(self, name)
+            h = lu(st.ops[1], lu(st.ops[0], h))
+            setattr(self, attr, h)
+        feats, masks = [], []
+        for (name, _, _), factor in zip(_DECODER, _UPSAMPLE):
+            up = getattr(self, name)
+            h = lu(up.ops[1], lu(up.ops[0], ops.convt_forward(ops.to_act(h, dt), up.up_conv.weight, up.up_conv.bias, up._packed_up, dt)))
+            ph = up.predictor_head
+            pro = ops.bn1d_eval(ops.gap_forward(h, dt), up.bn.weight, up.bn.bias, up.bn.running_mean, up.bn.running_var, relu=False)
+            hid = ops.bn1d_eval(ops.linear_forward(pro, ph[0].weight, ph[0].bias), ph[1].weight, ph[1].bias, ph[1].running_mean, ph[1].running_var, relu=True)
+            feats.append([pro, ops.linear_forward(hid, ph[3].weight, ph[3].bias)])
+            if not local:
+                mask = lu(up.deep_supervision_head, h)
+                masks.append(mask if factor == 1 else ops.upsample_forward(mask, factor))
+        return ops.conv1x1_to1_forward(ops.to_act(h, dt), self.out_tr.final_conv.weight, self.out_tr.final_conv.bias, dt), feats, masks
+
     def forward(self, x, local=False):
         """-> (out [b,1,D,H,W], [[pro, pre] x 3 scales], [mask x 3] or [] when local)"""
-        if not self.training:
-            raise NotImplementedError("PCRLv23d on the MI355X engine implements the pre-training (train-mode) path only")
         if not x.is_cuda:
             raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
+        if not self.training:
+            return self._forward_eval(x, local)
         pass_idx = ops.next_pass()          # 0 = first forward since the last optimizer step (its backward runs last)
         for m in self._stage_modules():
             m._pass_idx = pass_idx

@@ -191,7 +191,18 @@ class PackedWeights:
 # ----------------------------------------------------------------------------------------------
 # BatchNorm(+activation) on conv outputs
 # ----------------------------------------------------------------------------------------------
-def bn_finalize(partial, rows, C, count, gamma, beta, running_mean, running_var):
+def bn_eval_coef(gamma, beta, running_mean, running_var):
+    """Eval-mode BatchNorm (nn.Module.eval(): running statistics, no update) as the per-channel (scale, shift) the apply kernels take.
+    C-element vector arithmetic on the device -- the normalisation itself runs in pcrl_bn_act_apply."""
+    scale = (gamma.detach().float() * torch.rsqrt(running_var.float() + BN_EPS)).contiguous()
+    shift = (beta.detach().float() - running_mean.float() * scale).contiguous()
+    return scale, shift
+
+
+def bn_finalize(partial, rows, C, count, gamma, beta, running_mean, running_var, training=True):
+    if not training:
+        scale, shift = bn_eval_coef(gamma, beta, running_mean, running_var)
+        return None, None, scale, shift
     dev = partial.device
     if rows > 20000 and C % 2 == 0:
         # full-resolution 2D layers leave > 100 000 statistics rows for as few as 16 channels: pcrl_bn_finalize runs one block per
@@ -232,15 +243,36 @@ def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype):
 # LUConv = conv3x3x3 + BatchNorm3d(train) + activation      (models/pcrlv2_model_3d.py:6-34)
 # ----------------------------------------------------------------------------------------------
 class LUConvSaved:
-    __slots__ = ("kind", "x", "y", "mean", "rstd", "scale", "shift", "geom", "act")
+    __slots__ = ("kind", "x", "y", "mean", "rstd", "scale", "shift", "geom", "act", "gn")
 
 
-def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, packed: PackedWeights, act: int, dtype):
-    """x: activation (or float32 [N,1,D,H,W] for the first layer).  Returns (a, saved)."""
+def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, packed: PackedWeights, act: int, dtype, training=True, gn_groups=0):
+    """x: activation (or float32 [N,1,D,H,W] for the first layer).  Returns (a, saved).
+    training=False: eval mode -- the normalisation uses the running statistics, nothing is updated, no statistics are gathered."""
     L, s, dev = lib(), stream_handle(), x.device
     Co, Ci = conv_w.shape[0], conv_w.shape[1]
     sv = LUConvSaved()
     sv.act = act
+    sv.gn = None
+    if gn_groups and Co > 1:
+        # OPTIONAL, NOT IN THE REFERENCE (north_star's GroupNorm + SiLU; the reference's own norm='gn' crashes, SURVEY D1):
+        # conv -> GroupNorm(groups) -> activation.  Per-sample statistics: the same in train and eval mode, no running buffers.
+        N, D, H, W = (x.shape[0], x.shape[2], x.shape[3], x.shape[4])
+        y = new_act(N, D, H, W, Co, dtype, dev)
+        if Ci == 1:
+            L.call("pcrl_conv3d_k3_c1_fwd", x, conv_w.detach(), conv_b.detach(), y, None, N, D, H, W, Co, dtype_code(dtype), s)
+            sv.kind = "c1"
+        else:
+            wf, _ = packed.get(conv_w, dtype)
+            nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
+            L.call("pcrl_conv3d_k3_fwd_ws", x, wf, conv_b.detach(), y, None, workspace(nb, dev) if nb else None, nb, N, D, H, W, Ci, Co,
+                   dtype_code(dtype), s)
+            sv.kind = "gemm"
+        a, saved = gn_act_forward(y, gamma.detach(), beta.detach(), gn_groups, act, dtype)
+        sv.gn = (saved, gn_groups)
+        sv.x, sv.y, sv.mean, sv.rstd, sv.scale, sv.shift = x, y, None, None, None, None
+        sv.geom = (N, D, H, W, Ci, Co)
+        return a, sv
     if Co == 1:  # deep-supervision head: C -> 1, float32 map out
         N, D, H, W, C = dims(x)
         if C != Ci:
@@ -248,11 +280,11 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         M = N * D * H * W
         rows = L.call("pcrl_conv3d_to1_stats_rows", N, D, H, W, C, 27, dtype_code(dtype))
         y = _f32(M, dev)
-        partial = _f32(rows * 2, dev)
+        partial = _f32(rows * 2, dev) if training else None
         nb = L.call("pcrl_conv3d_to1_fwd_ws_bytes", N, D, H, W, C, 27)
         L.call("pcrl_conv3d_to1_fwd", x, conv_w.detach(), conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb,
                N, D, H, W, C, 27, dtype_code(dtype), s)
-        mean, rstd, scale, shift = bn_finalize(partial, rows, 1, M, gamma.detach(), beta.detach(), running_mean, running_var)
+        mean, rstd, scale, shift = bn_finalize(partial, rows, 1, M, gamma.detach(), beta.detach(), running_mean, running_var, training)
         a = bn_act_apply(y, scale, shift, M, 1, act, torch.float32).view(N, 1, D, H, W)
         sv.kind = "to1"
     elif Ci == 1:  # first layer: 1 -> Co on a float32 scalar field
@@ -262,9 +294,9 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         M = N * D * H * W
         rows = L.call("pcrl_conv3d_k3_c1_stats_rows", N, D, H, W, Co, dtype_code(dtype))
         y = new_act(N, D, H, W, Co, dtype, dev)
-        partial = _f32(rows * Co * 2, dev)
+        partial = _f32(rows * Co * 2, dev) if training else None
         L.call("pcrl_conv3d_k3_c1_fwd", x, conv_w.detach(), conv_b.detach(), y, partial, N, D, H, W, Co, dtype_code(dtype), s)
-        mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var)
+        mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, training)
         a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
         sv.kind = "c1"
     else:
@@ -277,11 +309,11 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         rows = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Ci, Co, dtype_code(dtype))
         wf, _ = packed.get(conv_w, dtype)
         y = new_act(N, D, H, W, Co, dtype, dev)
-        partial = _f32(rows * Co * 2, dev)
+        partial = _f32(rows * Co * 2, dev) if training else None
         nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
         L.call("pcrl_conv3d_k3_fwd_ws", x, wf, conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb, N, D, H, W, Ci, Co,
                dtype_code(dtype), s)
-        mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var)
+        mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, training)
         a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
         sv.kind = "gemm"
     sv.x, sv.y, sv.mean, sv.rstd, sv.scale, sv.shift = x, y, mean, rstd, scale, shift
@@ -316,7 +348,13 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
             L.call("pcrl_conv3d_to1_dgrad", dy, conv_w.detach(), dx_add, dx, N, D, H, W, Ci, 27, dtype_code(dtype), s)
         return dx, dw, db, dgamma, dbeta
     dims(da)
-    dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype)
+    if sv.gn is not None:   # optional GroupNorm mode: the conv bias is NOT cancelled by the normalisation -> db = column sums of dy
+        dy, dgamma, dbeta = gn_act_backward(da, sv.gn[0], gamma.detach(), sv.gn[1], sv.act, dtype)
+        db = _f32(Co, dev)
+        nbc = L.call("pcrl_colsum_ws_bytes", M, Co)
+        L.call("pcrl_colsum", dy, db, workspace(nbc, dev), nbc, M, Co, dtype_code(dtype), s)
+    else:
+        dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype)
     if sv.kind == "c1":
         nb = L.call("pcrl_conv3d_k3_c1_wgrad_ws_bytes", N, D, H, W, Co)
         L.call("pcrl_conv3d_k3_c1_wgrad", sv.x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Co, dtype_code(dtype), s)
@@ -413,6 +451,13 @@ def gap_backward(dg, like, add_src, dtype):
 # ----------------------------------------------------------------------------------------------
 # heads: BatchNorm1d / Linear on [rows, C] float32
 # ----------------------------------------------------------------------------------------------
+def bn1d_eval(x, gamma, beta, running_mean, running_var, relu: bool):
+    """Eval-mode BatchNorm1d (+ReLU) on [rows, C] float32: the per-channel apply kernel with coefficients from the running statistics."""
+    rows, C = x.shape
+    scale, shift = bn_eval_coef(gamma, beta, running_mean, running_var)
+    return bn_act_apply(x.contiguous(), scale, shift, rows, C, ACT_RELU if relu else ACT_NONE, torch.float32)
+
+
 def bn1d_forward(x, gamma, beta, running_mean, running_var, relu: bool):
     rows, C = x.shape
     y = torch.empty_like(x)

@@ -202,6 +202,77 @@ def test_bf16_step_within_stated_tolerance_of_golden(golden):
     assert len(far) <= 0.25 * len(devs), far
 
 
+def test_optional_groupnorm_silu_mode_vs_torch_definition():
+    """PCRLv23d(norm='gn', act='silu') -- an OPTIONAL, NON-REFERENCE mode (BASELINE.json's north_star names GroupNorm + SiLU; the
+    reference's own norm='gn' crashes at construction and it rejects 'silu').  Checked against the oracle's torch
+    restatement (F.group_norm / F.silu in float64) in float32: outputs and every parameter gradient of a restoration + feature loss."""
+    torch.manual_seed(3)
+    model = PCRLv23d(norm="gn", act="silu").to(DEV).train()
+    model.set_compute_dtype(torch.float32)
+    sd = model.state_dict()
+    assert "down_tr64.ops.0.bn1.running_mean" not in sd and "up_tr64.deep_supervision_head.bn1.running_mean" in sd
+    b, dhw = 2, (16, 16, 16)
+    x, _, gt, _, _ = O.fill_batch(b, dhw, dtype=torch.float32, seed=5)
+    out, feats, masks = model(x.to(DEV))
+    loss = ((out - gt.to(DEV)) ** 2).mean() + sum(f.sum() * 0.01 for pair in feats for f in pair) + masks[0].mean()
+    loss.backward()
+    st = {k: (v.detach().double().cpu().requires_grad_(v.is_floating_point() and not O.is_buffer(k)) if v.is_floating_point() else v.cpu())
+          for k, v in sd.items()}
+    with torch.backends.mkldnn.flags(enabled=False):
+        o_out, o_feats, o_masks = O.forward(st, x.double())
+        o_loss = ((o_out - gt.double()) ** 2).mean() + sum(f.sum() * 0.01 for pair in o_feats for f in pair) + o_masks[0].mean()
+        o_loss.backward()
+    assert abs(float(loss) - float(o_loss)) < 2e-5
+    np.testing.assert_allclose(out.detach().double().cpu().numpy(), o_out.detach().numpy(), rtol=0, atol=5e-5)
+    worst = 0.0
+    for name, p in model.named_parameters():
+        g, r = p.grad, st[name].grad
+        assert (g is None) == (r is None), name
+        if g is None:
+            continue
+        rel = float((g.double().cpu() - r).norm() / max(float(r.norm()), 1e-12))
+        if float(r.norm()) < 1e-9:   # biases in front of a BATCH norm (the deep-supervision heads keep BatchNorm): exact zero
+            assert float(g.abs().max()) < 1e-5, name
+            continue
+        worst = max(worst, rel)
+        assert rel < 2e-2, (name, rel)
+    print(f"gn+silu mode: worst gradient rel-L2 vs float64 torch definition = {worst:.2e}")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_eval_mode_forward_matches_reference_golden(dt, golden_dir):
+    """model.eval() on the HIP path against the REAL reference in .eval() (tests/golden/eval_b2_32x32x16.npz).  The state (running
+    statistics moved by one training step) is rebuilt with the deterministic oracle.  float32: maps 5e-5 / features 2e-4 abs (the
+    forward envelope of SURVEY App. C); bfloat16: maps 2e-2 abs, features by cosine > 0.995."""
+    fx = np.load(os.path.join(golden_dir, "eval_b2_32x32x16.npz"))
+    b, dhw = int(fx["meta/b"]), tuple(int(v) for v in fx["meta/dhw"])
+    with torch.backends.mkldnn.flags(enabled=False):
+        st1, _, _, _ = O.train_steps(O.fill_state(torch.float64), [O.fill_batch(b, dhw, dtype=torch.float64, seed=int(fx["meta/state_batch_seed"]))], 0, 1e-3, 240, 0)
+    x = O.fill_batch(b, dhw, dtype=torch.float32, seed=int(fx["meta/input_seed"]))[0].to(DEV)
+    model = build(dt, {k: (v.float() if v.is_floating_point() else v) for k, v in st1.items()})
+    model.eval()
+    sd_before = {k: v.clone() for k, v in model.state_dict().items()}
+    out, feats, masks = model(x)
+    assert not out.requires_grad and len(masks) == 3 and out.shape == x.shape
+    map_tol = 5e-5 if dt == torch.float32 else 2e-2
+    assert np.abs(samples(out, 512) - fx["out/samples"]).max() < map_tol
+    for i in range(3):
+        assert np.abs(samples(masks[i], 512) - fx[f"mask{i}/samples"]).max() < map_tol, i
+        for j, nm in enumerate(("pro", "pre")):
+            a, r = feats[i][j].double().cpu().numpy(), fx[f"{nm}{i}"]
+            if dt == torch.float32:
+                np.testing.assert_allclose(a, r, rtol=0, atol=2e-4, err_msg=f"{nm}{i}")
+            else:
+                cs = float(a.ravel() @ r.ravel() / (np.linalg.norm(a) * np.linalg.norm(r)))
+                assert cs > 0.995, (nm, i, cs)
+    # inference leaves parameters, running statistics and counters alone; local=True returns no masks
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, sd_before[k]), k
+    assert model(x, local=True)[2] == []
+    model.train()
+    assert model(x)[0].requires_grad
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_restoration_path_gradients_vs_live_oracle(dt):
     """loss = MSE(out, gt) + MSE(mid[2], gt) + MSE(mid[0], gt) on one view (every conv / BN / pool / convT / trilinear

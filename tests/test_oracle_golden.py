@@ -97,3 +97,23 @@ def test_cosine_similarity_semantics():
     y = torch.tensor([[4.0, 3.0], [1.0, 0.0]], dtype=torch.float64)
     ref = torch.nn.CosineSimilarity()(x, y)
     np.testing.assert_allclose(O.cosine_similarity(x, y).numpy(), ref.numpy(), atol=1e-15)
+
+
+def test_eval_mode_forward_matches_reference(golden_dir):
+    """oracle.forward(training=False) against the REAL reference in .eval() (tests/golden/eval_b2_32x32x16.npz): running statistics
+    moved by one training step, then an inference forward -- what a consumer of the checkpoint runs (README.md:48-55)."""
+    fx = _load(golden_dir, "eval_b2_32x32x16")
+    b, dhw = int(fx["meta/b"]), tuple(int(v) for v in fx["meta/dhw"])
+    dt = torch.float64
+    with torch.backends.mkldnn.flags(enabled=False):
+        st1, _, _, _ = O.train_steps(O.fill_state(dt), [O.fill_batch(b, dhw, dtype=dt, seed=int(fx["meta/state_batch_seed"]))], 0, 1e-3, 240, 0)
+        x = O.fill_batch(b, dhw, dtype=dt, seed=int(fx["meta/input_seed"]))[0]
+        out, feats, masks = O.forward(st1, x, training=False)
+    np.testing.assert_allclose(_samples(out, 512), fx["out/samples"], rtol=0, atol=1e-10)
+    for i in range(3):
+        np.testing.assert_allclose(feats[i][0].numpy(), fx[f"pro{i}"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(feats[i][1].numpy(), fx[f"pre{i}"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(_samples(masks[i], 512), fx[f"mask{i}/samples"], rtol=0, atol=1e-10)
+    # eval mode leaves the state alone
+    out2, _, _ = O.forward(st1, x, training=False)
+    assert torch.equal(out, out2)
