@@ -248,6 +248,60 @@ def test_model2d_api_and_state_dict():
         m(__import__("torch").zeros(2, 3, 64, 64))                                     # CPU input: no fallback
 
 
+def test_2d_encoder_checkpoint_round_trip_into_torchvision_named_resnet18(tmp_path):
+    """What IS pinned of the 2D path without smp / torchvision in the image (the numerics stay "parity unpinned"): the on-disk
+    contract.  A checkpoint of the layout train_2d.py:96-107 writes ('state_dict' = the ENCODER's state_dict) must load, after the
+    README's `encoder_dict['fc.bias'] = 0; encoder_dict['fc.weight'] = 0` (README.md:40-44), into a ResNet-18 with torchvision's public
+    key names the way smp's ResNetEncoder.load_state_dict does it (pop fc.*, strict load).  The skeleton below is torchvision's
+    published BasicBlock ResNet-18 layout, written out; the file is produced by this engine's own model class."""
+    import argparse
+    import torch
+    import torch.nn as nn
+    from pcrlv2_amd.models import PCRLv2
+
+    def block(cin, cout, stride):
+        m = nn.Module()
+        m.conv1, m.bn1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False), nn.BatchNorm2d(cout)
+        m.conv2, m.bn2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False), nn.BatchNorm2d(cout)
+        if stride != 1 or cin != cout:
+            m.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+        return m
+
+    class TorchvisionNamedResNet18(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1, self.bn1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64)
+            for i, (cin, cout, stride) in enumerate(((64, 64, 1), (64, 128, 2), (128, 256, 2), (256, 512, 2)), start=1):
+                setattr(self, f"layer{i}", nn.Sequential(block(cin, cout, stride), block(cout, cout, 1)))
+
+        def load_state_dict(self, state_dict, **kw):      # smp.encoders.resnet.ResNetEncoder.load_state_dict
+            state_dict.pop("fc.bias", None)
+            state_dict.pop("fc.weight", None)
+            return super().load_state_dict(state_dict, **kw)
+
+    torch.manual_seed(1)
+    m = PCRLv2()
+    args = argparse.Namespace(model="pcrlv2", n="chest", phase="pretask", ratio=0.8)
+    path = tmp_path / "pcrlv2_chest_pretask_0.8_240.pt"
+    torch.save({'opt': args, 'state_dict': m.model.encoder.state_dict(), 'optimizer': {}, 'epoch': 240}, path)
+    encoder_dict = torch.load(path, weights_only=False)['state_dict']
+    encoder_dict['fc.bias'] = 0
+    encoder_dict['fc.weight'] = 0
+    tv = TorchvisionNamedResNet18()
+    res = tv.load_state_dict(encoder_dict, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert list(tv.state_dict().keys()) == list(m.model.encoder.state_dict().keys())          # same keys in the same order
+    for k, v in tv.state_dict().items():
+        assert torch.equal(v, m.model.encoder.state_dict()[k]), k
+    # and back: the engine's --encoder_weights path takes a torchvision-named state_dict (with or without fc.*)
+    sd = dict(tv.state_dict(), **{"fc.weight": torch.zeros(1000, 512), "fc.bias": torch.zeros(1000)})
+    wpath = tmp_path / "resnet18.pth"
+    torch.save(sd, wpath)
+    m2 = PCRLv2(encoder_weights=str(wpath))
+    for k, v in m2.model.encoder.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+
+
 def test_c1_plumbing_2d_oracle_cpu():
     """BASELINE configs[0]: 2D PCRLv2 ResNet18-UNet, 224x224 crops, b=4, CPU-only torch -- plumbing (shapes, finite, loss goes down)
     on the CPU oracle restatement (oracle/pcrlv2_2d_oracle.py, PARITY UNPINNED), initial weights from the engine's model class."""
