@@ -283,6 +283,27 @@ int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, 
                   int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Input pipeline: the torchio transforms of data.py:73-89 / datasets/lunaDataset.py:28-81 on float32 volumes
+ * [B][D][H][W] resident on the device, one random parameter set per volume (drawn by the caller).  PARITY UNPINNED against torchio
+ * (absent from the image; the reference holds no vectors); each entry point states the definition it implements.
+ *   volume_min : vmin[b] = min over the volume (RandomAffine's default_pad_value='minimum')
+ *   affine     : RandomFlip(axes=0) then RandomAffine: y(o) = trilinear sample of flip_d^{flip[b]}(x) at centre + inv[b] (o - centre),
+ *                inv[b] row-major 3x3 in (d,h,w) order and isotropic voxel units, samples outside the volume = fill[b]
+ *   blur_axis  : one axis (0=d,1=h,2=w) of RandomBlur: Gaussian of std sigma[b] voxels, taps -radius..radius, symmetric borders
+ *   noise_gamma: RandomNoise then RandomGamma: v = x + noise_std[b] * n(0,1) (counter-based generator keyed by seed, b, index),
+ *                y = sign(v) |v|^gamma[b]
+ *   meanstd / znorm : ZNormalization: (x - mean[b]) * rstd[b], rstd = 1 / unbiased standard deviation
+ *   swap       : RandomSwap, in place: for it < iters, exchange patch origins[it][b][0] with patch origins[it][b][1] ([d,h,w] corners,
+ *                patch pd x ph x pw); the caller makes the two corners of a skipped (overlapping) draw equal */
+int pcrl_aug_volume_min(const float* x, float* vmin, int B, int64_t S, pcrl_stream_t stream);
+int pcrl_aug_affine(const float* x, float* y, const float* inv, const int* flip, const float* fill, int B, int D, int H, int W, pcrl_stream_t stream);
+int pcrl_aug_blur_axis(const float* x, float* y, const float* sigma, int B, int D, int H, int W, int axis, int radius, pcrl_stream_t stream);
+int pcrl_aug_noise_gamma(const float* x, float* y, const float* noise_std, const float* gamma, int B, int64_t S, int64_t seed, pcrl_stream_t stream);
+int pcrl_aug_meanstd(const float* x, float* mean, float* rstd, int B, int64_t S, pcrl_stream_t stream);
+int pcrl_aug_znorm(const float* x, float* y, const float* mean, const float* rstd, int B, int64_t S, pcrl_stream_t stream);
+int pcrl_aug_swap(float* x, const int* origins, int B, int D, int H, int W, int pd, int ph, int pw, int iters, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Test hooks (NOT part of the drop-in surface; process-wide atomics, default 0 / tr 1 = the product path).  They select which
  * of the kernels behind one entry point runs, so that tests can check every kernel against the same reference and probes can
  * time them against each other inside one process (tools/conv_probe.py).

@@ -8,11 +8,14 @@ The reference runs seven torchio transforms per crop in CPU DataLoader workers; 
 cannot keep one MI355X fed.  Here the workers only `np.load`; flips, affine resampling, blur, noise, gamma, patch swapping and
 z-normalisation run batched on the device on the raw crops.
 
+The transforms are hand-written gfx950 kernels (csrc/augment.hip, `pcrl_aug_*` in include/pcrl_hip.h); only the per-volume random
+parameters are drawn with torch.
+
 PARITY UNPINNED.  torchio is not installed in the build image and the reference holds no vectors for its augmentations, so these
 are restatements of torchio's documented defaults (RandomFlip(axes=0, p=0.5); RandomAffine(scales 0.9-1.1, degrees +-10 per axis,
 linear, pad with the image minimum); RandomBlur(std 0-2 per axis); RandomNoise(std 0-0.25); RandomGamma(log_gamma +-0.3);
-RandomSwap(patch (8,4,4), 100 iterations); ZNormalization), tested for their defining properties (tests/test_data_cpu.py), not
-against torchio.  The batch contract -- (input1, input2, gt, gt2, [6 local views]), gt = the spatially transformed crop BEFORE the
+RandomSwap(patch (8,4,4), 100 iterations); ZNormalization), tested against a float64 PyTorch restatement of the same definitions
+(tests/aug_reference.py, tests/test_augment_gpu.py) and for their defining properties, not against torchio.  The batch contract -- (input1, input2, gt, gt2, [6 local views]), gt = the spatially transformed crop BEFORE the
 intensity transforms (lunaDataset.py:37-41) -- is the reference's.
 """
 from __future__ import annotations
@@ -22,7 +25,6 @@ import os
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 TRAIN_FOLDS, VALID_FOLDS = (0, 1, 2, 3, 4, 5, 6), (7, 8, 9)     # data.py:67-68
 
@@ -66,16 +68,15 @@ class LunaCropPairs(torch.utils.data.Dataset):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# Batched device-side transforms on [B, D, H, W] volumes (one random parameter set per volume)
+# Batched device-side transforms on [B, D, H, W] float32 volumes: the random PARAMETERS (one set per volume) are drawn here with the
+# torch generator; the transforms themselves are the hand-written kernels of csrc/augment.hip behind pcrl_aug_* (no torch arithmetic
+# on the volumes).  tests/aug_reference.py restates the same definitions in float64 PyTorch for the parity tests.
 # ---------------------------------------------------------------------------------------------------------------
+BLUR_RADIUS = 8     # ceil(4 * max_std): torchio truncates its Gaussian at 4 sigma
+
+
 def _u(gen, n, lo, hi, device):
     return lo + (hi - lo) * torch.rand(n, generator=gen, device=device)
-
-
-def random_flip(x, gen, p=0.5):
-    """torchio.RandomFlip(axes=0): mirror the first spatial axis with probability p."""
-    flip = torch.rand(x.shape[0], generator=gen, device=x.device) < p
-    return torch.where(flip.view(-1, 1, 1, 1), x.flip(1), x)
 
 
 def _rotation(deg):
@@ -89,92 +90,68 @@ def _rotation(deg):
     return rz @ ry @ rx
 
 
-def random_affine(x, gen, scales=0.1, degrees=10.0):
-    """torchio.RandomAffine defaults: per-axis scale U(1-s, 1+s), per-axis rotation U(-deg, deg) about the image centre, no
-    translation, trilinear resampling, outside filled with the volume's minimum."""
-    B = x.shape[0]
-    sc = _u(gen, B * 3, 1.0 - scales, 1.0 + scales, x.device).view(B, 3)
-    rot = _rotation(_u(gen, B * 3, -degrees, degrees, x.device).view(B, 3))
-    # output voxel -> input coordinate: inverse of (rotate . scale); normalised coordinates of affine_grid are centred on the image
-    fwd = rot @ torch.diag_embed(sc)
-    inv = torch.linalg.inv(fwd)
-    # physical (voxel) isotropy: normalised axes have different lengths, conjugate with the half-extents
-    ext = torch.tensor([x.shape[3], x.shape[2], x.shape[1]], dtype=x.dtype, device=x.device) / 2.0     # affine_grid order: (W, H, D)
-    perm = torch.tensor([2, 1, 0], device=x.device)                                                     # spatial (D,H,W) <-> grid (x=W,y=H,z=D)
-    inv_g = inv[:, perm][:, :, perm]
-    theta = (inv_g * ext.view(1, 1, 3)) / ext.view(1, 3, 1)
-    theta = torch.cat([theta, torch.zeros(B, 3, 1, dtype=x.dtype, device=x.device)], dim=2)
-    grid = F.affine_grid(theta, (B, 1) + tuple(x.shape[1:]), align_corners=False)
-    lo = x.amin(dim=(1, 2, 3), keepdim=True)
-    out = F.grid_sample((x - lo).unsqueeze(1), grid, mode="bilinear", padding_mode="zeros", align_corners=False).squeeze(1)
-    return out + lo
+def draw_spatial(gen, B, device, p_flip=0.5, scales=0.1, degrees=10.0):
+    """RandomFlip(axes=0, p) + RandomAffine(scales, degrees) parameters -> (flip int32 [B], inv float32 [B,3,3]): `inv` maps an
+    output voxel's centred coordinate to the input's (inverse of rotate . scale, (d,h,w) order, voxel units)."""
+    flip = (torch.rand(B, generator=gen, device=device) < p_flip).to(torch.int32)
+    sc = _u(gen, B * 3, 1.0 - scales, 1.0 + scales, device).view(B, 3)
+    rot = _rotation(_u(gen, B * 3, -degrees, degrees, device).view(B, 3))
+    inv = torch.linalg.inv(rot @ torch.diag_embed(sc)).to(torch.float32).contiguous()
+    return flip, inv
 
 
-def _gauss_kernels(sigma, radius):
-    """[B] standard deviations (voxels) -> [B, 2*radius+1] normalised Gaussian taps (sigma -> 0: identity)."""
-    t = torch.arange(-radius, radius + 1, device=sigma.device, dtype=sigma.dtype).view(1, -1)
-    k = torch.exp(-0.5 * (t / sigma.clamp_min(1e-3).view(-1, 1)) ** 2)
-    return k / k.sum(dim=1, keepdim=True)
+def draw_intensity(gen, B, device, max_blur=2.0, max_noise=0.25, log_gamma=0.3):
+    """RandomBlur / RandomNoise / RandomGamma parameters -> (sigma [3,B], noise_std [B], gamma [B], seed)."""
+    sigma = _u(gen, 3 * B, 0.0, max_blur, device).view(3, B).contiguous()
+    noise_std = _u(gen, B, 0.0, max_noise, device)
+    gamma = torch.exp(_u(gen, B, -log_gamma, log_gamma, device))
+    seed = int(torch.randint(0, 2 ** 62, (1,), generator=gen, device=device).item())
+    return sigma, noise_std, gamma, seed
 
 
-def random_blur(x, gen, max_std=2.0):
-    """torchio.RandomBlur: separable Gaussian, one std U(0, max_std) per axis and volume; symmetric ('reflect' in scipy) borders."""
-    B = x.shape[0]
-    radius = int(math.ceil(4.0 * max_std))
-    out = x
-    for axis in (1, 2, 3):
-        k = _gauss_kernels(_u(gen, B, 0.0, max_std, x.device), radius)              # [B, K]
-        n = out.shape[axis]
-        r = min(radius, n)
-        pad_lo = out.narrow(axis, 0, r).flip(axis)
-        pad_hi = out.narrow(axis, n - r, r).flip(axis)
-        padded = torch.cat([pad_lo, out, pad_hi], dim=axis)
-        kk = k[:, radius - r: radius + r + 1]
-        kk = kk / kk.sum(dim=1, keepdim=True)
-        shape = [B, 1, 1, 1, 1]
-        shape[axis + 1] = 2 * r + 1
-        out = F.conv3d(padded.unsqueeze(0), kk.view(shape), groups=B).squeeze(0)     # batch folded into channels
-    return out
-
-
-def random_noise(x, gen, max_std=0.25):
-    std = _u(gen, x.shape[0], 0.0, max_std, x.device).view(-1, 1, 1, 1)
-    return x + std * torch.randn(x.shape, generator=gen, device=x.device, dtype=x.dtype)
-
-
-def random_gamma(x, gen, log_gamma=0.3):
-    g = torch.exp(_u(gen, x.shape[0], -log_gamma, log_gamma, x.device)).view(-1, 1, 1, 1)
-    return torch.sign(x) * torch.abs(x) ** g          # torchio keeps the sign of negative intensities
-
-
-def random_swap(x, gen, patch=(8, 4, 4), iterations=100):
-    """torchio.RandomSwap: `iterations` times, exchange the contents of two random patches (per volume; a draw whose two patches
-    overlap is skipped).  A permutation of the voxels: the multiset of intensities is unchanged."""
-    B, D, H, W = x.shape
+def draw_swap(gen, B, dhw, device, patch=(8, 4, 4), iterations=100):
+    """RandomSwap draws -> int32 [iterations, B, 2, 3] patch corners; a draw whose two patches overlap is skipped by torchio: both
+    corners are set equal (an exchange with itself)."""
+    D, H, W = dhw
     pd, ph, pw = patch
-    dev = x.device
-    od, oh, ow = torch.meshgrid(torch.arange(pd, device=dev), torch.arange(ph, device=dev), torch.arange(pw, device=dev), indexing="ij")
-    offs = (od * H + oh) * W + ow                                                     # [pd,ph,pw] flat offsets inside a volume
-    flat = x.reshape(B, -1).clone()
-    # all draws up front (one launch each); only the data-dependent gather/scatter chain stays sequential
-    r = torch.rand(iterations, B, 2, 3, generator=gen, device=dev)
-    o = (r * torch.tensor([D - pd + 1, H - ph + 1, W - pw + 1], device=dev)).long()               # [I,B,2,3] patch origins
-    overlap = ((o[:, :, 0] - o[:, :, 1]).abs() < torch.tensor([pd, ph, pw], device=dev)).all(dim=2)     # overlapping pair: skip this swap
+    r = torch.rand(iterations, B, 2, 3, generator=gen, device=device)
+    o = (r * torch.tensor([D - pd + 1, H - ph + 1, W - pw + 1], device=device)).long()
+    overlap = ((o[:, :, 0] - o[:, :, 1]).abs() < torch.tensor([pd, ph, pw], device=device)).all(dim=2)
     o = torch.where(overlap.view(iterations, B, 1, 1), o[:, :, :1].expand(-1, -1, 2, -1), o)
-    base = (o[..., 0] * H + o[..., 1]) * W + o[..., 2]                                              # [I,B,2]
-    idx = base.unsqueeze(-1) + offs.view(1, 1, 1, -1)                                               # [I,B,2,P]
-    for it in range(iterations):
-        ia, ib = idx[it, :, 0], idx[it, :, 1]
-        a, b = flat.gather(1, ia), flat.gather(1, ib)
-        flat.scatter_(1, ia, b)                                                                      # as torchio: first <- second ...
-        flat.scatter_(1, ib, a)                                                                      # ... second <- (old) first
-    return flat.view(B, D, H, W)
+    return o.to(torch.int32).contiguous()
 
 
-def z_normalize(x):
-    m = x.mean(dim=(1, 2, 3), keepdim=True)
-    s = x.std(dim=(1, 2, 3), keepdim=True)            # unbiased, as torch.Tensor.std in torchio.ZNormalization
-    return (x - m) / s.clamp_min(1e-12)
+def _call(name, *args):
+    from ._lib import lib, stream_handle
+    lib().call(name, *args, stream_handle())
+
+
+def apply_spatial(x, flip, inv):
+    """flip + affine resampling of [B,D,H,W] float32 volumes on the device (pcrl_aug_volume_min, pcrl_aug_affine)."""
+    B, D, H, W = x.shape
+    x = x.contiguous()
+    vmin = torch.empty(B, dtype=torch.float32, device=x.device)
+    _call("pcrl_aug_volume_min", x, vmin, B, D * H * W)
+    y = torch.empty_like(x)
+    _call("pcrl_aug_affine", x, y, inv, flip, vmin, B, D, H, W)
+    return y
+
+
+def apply_intensity(x, sigma, noise_std, gamma, seed, swap_origins=None, patch=(8, 4, 4)):
+    """blur (three separable passes) -> noise -> gamma -> [patch swaps] -> z-normalisation, all in csrc/augment.hip."""
+    B, D, H, W = x.shape
+    S = D * H * W
+    a, b = x.contiguous(), torch.empty_like(x)
+    for axis in range(3):
+        _call("pcrl_aug_blur_axis", a, b, sigma[axis], B, D, H, W, axis, BLUR_RADIUS)
+        a, b = b, (torch.empty_like(x) if axis == 0 else a)      # never write into the caller's tensor
+    _call("pcrl_aug_noise_gamma", a, b, noise_std, gamma, B, S, seed)
+    mean, rstd = torch.empty(B, dtype=torch.float32, device=x.device), torch.empty(B, dtype=torch.float32, device=x.device)
+    _call("pcrl_aug_meanstd", b, mean, rstd, B, S)               # a permutation of the voxels leaves mean and std alone
+    if swap_origins is not None:
+        _call("pcrl_aug_swap", b, swap_origins, B, D, H, W, patch[0], patch[1], patch[2], swap_origins.shape[0])
+    _call("pcrl_aug_znorm", b, a, mean, rstd, B, S)
+    return a
 
 
 class GpuLunaAugment:
@@ -182,16 +159,18 @@ class GpuLunaAugment:
 
     def __init__(self, device, seed=0):
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("GpuLunaAugment runs on the GPU (libpcrl_hip.so); there is no CPU fallback")
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
 
     def spatial(self, v):
-        return random_affine(random_flip(v, self.gen), self.gen)
+        flip, inv = draw_spatial(self.gen, v.shape[0], self.device)
+        return apply_spatial(v, flip, inv)
 
     def intensity(self, v, swap):
-        v = random_gamma(random_noise(random_blur(v, self.gen), self.gen), self.gen)
-        if swap:
-            v = random_swap(v, self.gen)
-        return z_normalize(v)
+        sigma, noise_std, gamma, seed = draw_intensity(self.gen, v.shape[0], self.device)
+        origins = draw_swap(self.gen, v.shape[0], tuple(v.shape[1:]), self.device) if swap else None
+        return apply_intensity(v, sigma, noise_std, gamma, seed, origins)
 
     @torch.no_grad()
     def __call__(self, pair, local):
@@ -199,7 +178,7 @@ class GpuLunaAugment:
         local = local.to(self.device, torch.float32, non_blocking=True)
         B = pair.shape[0]
         views = self.spatial(pair.reshape((2 * B,) + tuple(pair.shape[2:])))                  # both global crops of every sample
-        gt = views.clone()                                                                  # lunaDataset.py:37-38: before the intensity transforms
+        gt = views                                                                          # lunaDataset.py:37-38: before the intensity transforms (never written again)
         inp = self.intensity(views, swap=True)
         nl = local.shape[1]
         loc = self.intensity(self.spatial(local.reshape((nl * B,) + tuple(local.shape[2:]))), swap=False)

@@ -54,7 +54,7 @@ class LUConv(nn.Module, _Counted):
             raise ValueError('normalization type {} is not supported'.format(norm))
         if act in _NO_KERNEL_ACTS:
             raise NotImplementedError(f"activation type {act} has no gfx950 kernel")
-        if act not in _ACTS:
+        if act not in _ACTS or (act == "silu" and norm != "gn"):    # the reference rejects 'silu' (:30); only the optional 'gn' mode takes it
             raise ValueError('activation type {} is not supported'.format(act))
         self.conv1 = nn.Conv3d(in_chan, out_chan, 3, padding=1)               # container: weight [Co,Ci,3,3,3], bias [Co]
         self._gn_groups = 8 if (norm == "gn" and out_chan > 1) else 0

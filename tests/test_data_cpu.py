@@ -1,6 +1,7 @@
 """Input pipeline, CPU: file selection as the reference's utils.get_luna_list, the batch contract of
-datasets/lunaDataset.py:79-81, and the DEFINING PROPERTIES of the device-side augmentations.  Parity with torchio itself is
-unpinned (torchio is not installed here and the reference holds no vectors): see pcrlv2_amd/data.py."""
+datasets/lunaDataset.py:79-81, the host-side parameter draws, and the DEFINING PROPERTIES of the float64 restatement the augmentation kernels are tested
+against on the GPU (tests/test_augment_gpu.py).  Parity with torchio itself is unpinned (torchio is not installed here and the reference
+holds no vectors): see pcrlv2_amd/data.py."""
 import os
 import types
 
@@ -38,65 +39,75 @@ def test_file_lists_follow_the_reference_folds(tmp_path):
     assert pair.shape == (2, 64, 64, 32) and loc.shape == (6, 16, 16, 16) and pair.dtype == torch.float32
 
 
-def test_batch_contract_and_determinism():
-    aug = D.GpuLunaAugment("cpu", seed=7)
-    pair, loc = torch.rand(3, 2, 32, 32, 16), torch.rand(3, 6, 16, 16, 16)
-    x1, x2, g1, g2, locs = aug(pair, loc)
-    assert x1.shape == x2.shape == g1.shape == g2.shape == (3, 1, 32, 32, 16)
-    assert len(locs) == 6 and all(t.shape == (3, 1, 16, 16, 16) for t in locs)
-    # inputs and locals are z-normalised per volume; the targets are NOT (they keep the crop's intensities)
-    for t in (x1, x2, locs[0], locs[5]):
-        assert torch.allclose(t.mean(dim=(1, 2, 3, 4)), torch.zeros(3), atol=1e-4) and torch.allclose(t.std(dim=(1, 2, 3, 4)), torch.ones(3), atol=1e-3)
-    assert g1.min() >= -1e-5 and g1.max() <= 1 + 1e-5
-    again = D.GpuLunaAugment("cpu", seed=7)(pair, loc)
-    assert torch.equal(again[0], x1) and torch.equal(again[4][3], locs[3])
-    other = D.GpuLunaAugment("cpu", seed=8)(pair, loc)
-    assert not torch.equal(other[0], x1)
-
-
-def test_transform_properties():
+def test_parameter_draws_follow_the_torchio_defaults():
+    """The random PARAMETERS are host-side (torch); the transforms run in csrc/augment.hip (tests/test_augment_gpu.py)."""
     g = torch.Generator().manual_seed(1)
-    x = torch.rand(8, 16, 12, 10, generator=g)
-    f = D.random_flip(x, g)
-    assert all(torch.equal(f[i], x[i]) or torch.equal(f[i], x[i].flip(0)) for i in range(8))
-    assert any(torch.equal(f[i], x[i].flip(0)) for i in range(8)) and any(torch.equal(f[i], x[i]) for i in range(8))
-    assert torch.allclose(D.random_affine(x, g, scales=0.0, degrees=0.0), x, atol=1e-5)            # identity parameters
-    a = D.random_affine(x, g)
-    assert a.shape == x.shape and (a.amin(dim=(1, 2, 3)) >= x.amin(dim=(1, 2, 3)) - 1e-5).all()      # padded with the volume minimum
-    assert torch.allclose(D.random_blur(x, g, max_std=1e-6), x, atol=1e-5)                           # sigma -> 0: identity
-    b = D.random_blur(x, g)
-    assert (b.var(dim=(1, 2, 3)) < x.var(dim=(1, 2, 3))).all() and torch.allclose(b.mean(dim=(1, 2, 3)), x.mean(dim=(1, 2, 3)), atol=2e-2)
-    n = D.random_noise(torch.zeros(64, 8, 8, 8), g)
-    assert (n.std(dim=(1, 2, 3)) <= 0.25 * 1.2).all() and n.std(dim=(1, 2, 3)).max() > 0.1
-    assert torch.allclose(D.random_gamma(x, g, log_gamma=0.0), x)
-    y = D.random_gamma(x - 0.5, g)
-    assert torch.equal(torch.sign(y), torch.sign(x - 0.5))
-    s = D.random_swap(x, g, patch=(4, 2, 2), iterations=20)
-    assert not torch.equal(s, x)
-    assert torch.equal(s.reshape(8, -1).sort(dim=1).values, x.reshape(8, -1).sort(dim=1).values)     # a permutation of the voxels
-    z = D.z_normalize(x * 3 + 2)
-    assert torch.allclose(z.mean(dim=(1, 2, 3)), torch.zeros(8), atol=1e-5) and torch.allclose(z.std(dim=(1, 2, 3)), torch.ones(8), atol=1e-5)
+    flip, inv = D.draw_spatial(g, 2000, "cpu")
+    assert flip.dtype == torch.int32 and 0.45 < flip.float().mean() < 0.55                             # RandomFlip(p=0.5)
+    fwd = torch.linalg.inv(inv)                                                                        # rotate . scale
+    sc = torch.linalg.svdvals(fwd)
+    assert sc.min() >= 0.9 - 1e-5 and sc.max() <= 1.1 + 1e-5                                           # scales U(0.9, 1.1)
+    sigma, nstd, gamma, seed = D.draw_intensity(g, 2000, "cpu")
+    assert sigma.shape == (3, 2000) and 0 <= sigma.min() and sigma.max() <= 2.0 and 0.9 < sigma.mean() < 1.1
+    assert nstd.min() >= 0 and nstd.max() <= 0.25 and gamma.min() >= np.exp(-0.3) - 1e-6 and gamma.max() <= np.exp(0.3) + 1e-6
+    o = D.draw_swap(g, 64, (64, 64, 32), "cpu")
+    assert o.shape == (100, 64, 2, 3) and o.dtype == torch.int32
+    assert (o >= 0).all() and (o[..., 0] <= 64 - 8).all() and (o[..., 1] <= 64 - 4).all() and (o[..., 2] <= 32 - 4).all()
+    d = (o[:, :, 0] - o[:, :, 1]).abs()
+    apart = (d >= torch.tensor([8, 4, 4])).any(dim=2)
+    same = (d == 0).all(dim=2)
+    assert (apart | same).all() and apart.float().mean() > 0.9                                         # overlapping draws are skipped
+    # same seed -> same draws
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    assert torch.equal(D.draw_spatial(g1, 8, "cpu")[1], D.draw_spatial(g2, 8, "cpu")[1])
+
+
+def test_reference_restatement_properties():
+    """Defining properties of the float64 restatement the GPU kernels are tested against (tests/aug_reference.py)."""
+    import aug_reference as R
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(4, 16, 12, 10, generator=g)
+    eye, zero = torch.eye(3).repeat(4, 1, 1), torch.zeros(4, dtype=torch.int32)
+    assert torch.allclose(R.ref_spatial(x, zero, eye), x.double(), atol=1e-12)
+    assert torch.allclose(R.ref_spatial(x, zero + 1, eye), x.flip(1).double(), atol=1e-12)
+    flip, inv = D.draw_spatial(g, 4, "cpu")
+    a = R.ref_spatial(x, flip, inv)
+    assert (a.amin(dim=(1, 2, 3)) >= x.amin(dim=(1, 2, 3)) - 1e-9).all() and (a.amax(dim=(1, 2, 3)) <= x.amax(dim=(1, 2, 3)) + 1e-9).all()
+    sig = torch.full((3, 4), 1e-6)
+    assert torch.allclose(R.ref_blur(x, sig), x.double(), atol=1e-9)                                    # sigma -> 0: identity
+    b = R.ref_blur(x, torch.full((3, 4), 1.5))
+    assert (b.var(dim=(1, 2, 3)) < x.var(dim=(1, 2, 3))).all() and torch.allclose(b.mean(dim=(1, 2, 3)), x.double().mean(dim=(1, 2, 3)), atol=2e-2)
+    assert torch.allclose(R.ref_gamma(x, torch.ones(4)), x.double())
+    assert torch.equal(torch.sign(R.ref_gamma(x - 0.5, torch.full((4,), 1.2))), torch.sign(x - 0.5).double())
+    o = D.draw_swap(g, 4, (16, 12, 10), "cpu", patch=(4, 2, 2), iterations=20)
+    s2 = R.ref_swap(x, o, patch=(4, 2, 2))
+    assert not torch.equal(s2, x) and torch.equal(s2.reshape(4, -1).sort(dim=1).values, x.reshape(4, -1).sort(dim=1).values)
+    z = R.ref_znorm(x * 3 + 2)
+    assert torch.allclose(z.mean(dim=(1, 2, 3)), torch.zeros(4, dtype=torch.float64), atol=1e-9) and torch.allclose(z.std(dim=(1, 2, 3)), torch.ones(4, dtype=torch.float64), atol=1e-9)
 
 
 def test_rotation_is_a_rotation_about_the_centre():
-    # 90 degrees about the first spatial axis maps the (h, w) plane onto itself: compare with torch.rot90 on a cube
-    x = torch.rand(2, 8, 8, 8)
     deg = torch.tensor([[90.0, 0.0, 0.0], [0.0, 0.0, 0.0]])
     r = D._rotation(deg)
     assert torch.allclose(r @ r.transpose(1, 2), torch.eye(3).expand(2, 3, 3), atol=1e-6) and torch.allclose(torch.linalg.det(r), torch.ones(2), atol=1e-6)
     assert torch.allclose(r[1], torch.eye(3), atol=1e-7)
 
 
-def test_loader_end_to_end(tmp_path):
-    names = _make_tree(tmp_path, series_per_fold=1, pairs=1)
-    args = types.SimpleNamespace(data=str(tmp_path), ratio=1.0, b=3, workers=0, seed=0)
-    cwd = os.getcwd()
-    os.chdir(tmp_path)        # no train_val_txt/luna_train.txt here: every series is kept
-    try:
-        loaders = D.luna_pretask_loaders(args, device="cpu")
-    finally:
-        os.chdir(cwd)
-    assert len(loaders["train"]) == 3 and len(loaders["eval"]) == 1           # 7 files in batches of 3; 3 validation files
-    batch = next(iter(loaders["train"]))
-    assert batch[0].shape == (3, 1, 64, 64, 32) and batch[2].shape == (3, 1, 64, 64, 32) and len(batch[4]) == 6
-    assert batch[4][0].shape == (3, 1, 16, 16, 16)
+def test_loader_shards_have_equal_length(tmp_path, monkeypatch):
+    """One process per GPU: every rank must see the same number of batches (each step ends in a collective)."""
+    _make_tree(tmp_path, series_per_fold=1, pairs=1)          # 7 training files
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(D, "AugmentedLoader", lambda files, b, workers, device, shuffle=True, seed=0, drop_last=False: (list(files), drop_last))
+    lens = []
+    for rank in range(2):
+        monkeypatch.setenv("RANK", str(rank))
+        monkeypatch.setenv("WORLD_SIZE", "2")
+        args = types.SimpleNamespace(data=str(tmp_path), ratio=1.0, b=2, workers=0, seed=0)
+        files, drop = D.luna_pretask_loaders(args, device="cpu")["train"]
+        lens.append(len(files))
+        assert drop is True
+    assert lens == [3, 3]                                      # 7 files -> 6, three per rank
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    files, drop = D.luna_pretask_loaders(types.SimpleNamespace(data=str(tmp_path), ratio=1.0, b=2, workers=0, seed=0), device="cpu")["train"]
+    assert len(files) == 7 and drop is False                   # single process: the reference's loader (drop_last=False)

@@ -53,7 +53,8 @@ def test_model_api_and_state_dict(golden_dir):
     with pytest.raises(ValueError, match="normalization type xx is not supported"):
         PCRLv23d(norm="xx")
     with pytest.raises(ValueError, match="activation type silu is not supported"):
-        PCRLv23d(act="silu")
+        PCRLv23d(act="silu")                                         # as the reference (:30); only the optional norm='gn' mode takes 'silu'
+    assert "down_tr64.ops.0.bn1.running_mean" not in PCRLv23d(norm="gn", act="silu").state_dict()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(2, 1, 16, 16, 16))
     m.set_compute_dtype("bf16")
