@@ -274,6 +274,18 @@ int pcrl_add_relu_fwd(const void* t, const void* r, void* a, int64_t n, int dtyp
 int pcrl_relu_mask_bwd(const void* da, const void* a, void* g, int64_t n, int dtype, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * All cosine terms of one step in one launch -- train_3d.py:119-134 (13 cos_loss calls = 26 cosine means, :86-92).
+ *   out[g] = sum_{t : group[t] == g} w[t] * mean_r cos(x[t][r], y[t][r]),  x[t], y[t]: float32 [rows][C[t]] on the device
+ * `x`, `y`, `dx`, `w`, `C`, `group`, `first` are HOST arrays of `nterms` <= 32 entries (device pointers / scalars); they are copied into
+ * the kernel arguments.  bwd: dx[t] (device float32 [rows][C[t]]; several terms may name the same buffer) receives
+ * dout[group[t]] * w[t] * d(mean cos)/dx[t]: stored when first[t] != 0, accumulated otherwise, terms in order (deterministic).
+ * y is the reference's detached operand: no gradient. */
+int pcrl_cosine_terms_fwd(const void* const* x, const void* const* y, const float* w, const int* C, const int* group, int nterms, int rows,
+                          int ngroups, float eps, float* out, pcrl_stream_t stream);
+int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y, void* const* dx, const float* w, const int* C, const int* group,
+                          const int* first, int nterms, int rows, int ngroups, float eps, const float* dout, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * torch.optim.SGD (momentum, weight decay, dampening 0, no nesterov) over a flat parameter arena --
  * train_3d.py:48-51,151.  `offsets`: int64[ntensors+1] element offsets of each tensor in the arena;
  * `flags`: int32[ntensors], bit0 = tensor has a gradient this step (others are skipped, like

@@ -315,6 +315,9 @@ def main():
         return
     make_case("c_small_b4_32x32x16", 4, (32, 32, 16), 2, refmod, ref_train, ref_utils)
     make_case("c_luna_b2_64x64x32", 2, (64, 64, 32), 1, refmod, ref_train, ref_utils)
+    # well-conditioned (BatchNorm1d over 16 rows) and BASELINE-shaped (64x64x32) steps; b = 16 at 64x64x32 needs > 63 GB in float64
+    make_case("c_b16_32x32x16", 16, (32, 32, 16), 1, refmod, ref_train, ref_utils)
+    make_case("c_luna_b8_64x64x32", 8, (64, 64, 32), 1, refmod, ref_train, ref_utils)
     make_curve("curve_b8_32x32x16_12steps", 8, (32, 32, 16), 12, refmod, ref_train, ref_utils)
     # LR schedule vector (utils.py:101-114) for epochs 0..240 at lr=1e-3
     class A:

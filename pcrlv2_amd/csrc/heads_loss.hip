@@ -298,6 +298,96 @@ __global__ void __launch_bounds__(256) cosine_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// All cosine terms of one training step in ONE launch (train_3d.py:119-134: the global pair and the twelve (global, local_i) pairs, two
+// cosine means each = 26 terms over [rows, C_t] matrices at randomly drawn scales).  out[g] = sum over the terms of group g of
+// w_t * mean_r cos(x_t[r], y_t[r]); the gradient flows to the x operands only (the reference detaches y).  One block: a step has
+// 26 x 32 rows of <= 256 channels; separate launches (26 forward + 26 backward + ~150 elementwise kernels for the negations, halves,
+// sums and stacks) cost ~1 ms per step in launch latency.  Descriptors travel in the kernel arguments (<= 32 terms).
+// ---------------------------------------------------------------------------------------------
+constexpr int COS_MAX_TERMS = 32;
+struct CosTerms {
+  const float* x[COS_MAX_TERMS];
+  const float* y[COS_MAX_TERMS];
+  float* dx[COS_MAX_TERMS];     // backward: gradient buffer of the term's x (several terms may share one)
+  float w[COS_MAX_TERMS];
+  int C[COS_MAX_TERMS];
+  int group[COS_MAX_TERMS];
+  int first[COS_MAX_TERMS];     // backward: 1 = first term that writes its dx buffer (store), 0 = accumulate
+  int n, rows, ngroups;
+  float eps;
+};
+__global__ void __launch_bounds__(1024) cosine_terms_fwd_kernel(const CosTerms t, float* __restrict__ out) {
+  __shared__ double part[16][8];   // [wave][group]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  double acc[8];
+#pragma unroll
+  for (int g = 0; g < 8; ++g) acc[g] = 0.0;
+  for (int k = 0; k < t.n; ++k) {
+    const float* __restrict__ x = t.x[k];
+    const float* __restrict__ y = t.y[k];
+    const int C = t.C[k];
+    double s = 0.0;
+    for (int r = wid; r < t.rows; r += nw) {
+      float dot = 0.f, xx = 0.f, yy = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float a = x[(int64_t)r * C + c], b = y[(int64_t)r * C + c];
+        dot += a * b;
+        xx += a * a;
+        yy += b * b;
+      }
+      dot = wave_sum(dot);
+      xx = wave_sum(xx);
+      yy = wave_sum(yy);
+      s += (double)(dot / (fmaxf(sqrtf(xx), t.eps) * fmaxf(sqrtf(yy), t.eps)));
+    }
+    const int g = t.group[k];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (q == g) acc[q] += s * (double)t.w[k] / (double)t.rows;
+  }
+  if (lane == 0)
+    for (int g = 0; g < t.ngroups; ++g) part[wid][g] = acc[g];
+  __syncthreads();
+  if ((int)threadIdx.x < t.ngroups) {
+    double v = 0.0;
+    for (int w = 0; w < nw; ++w) v += part[w][threadIdx.x];   // fixed order
+    out[threadIdx.x] = (float)v;
+  }
+}
+// dx_t += dout[group_t] * w_t / rows * d cos(x, y) / dx, terms in order (block-wide barrier between terms: shared buffers are race-free
+// and the summation order is fixed).
+__global__ void __launch_bounds__(1024) cosine_terms_bwd_kernel(const CosTerms t, const float* __restrict__ dout) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int k = 0; k < t.n; ++k) {
+    const float* __restrict__ x = t.x[k];
+    const float* __restrict__ y = t.y[k];
+    float* __restrict__ dx = t.dx[k];
+    const int C = t.C[k];
+    const float g = dout[t.group[k]] * t.w[k] / (float)t.rows;
+    for (int r = wid; r < t.rows; r += nw) {
+      float dot = 0.f, xx = 0.f, yy = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float a = x[(int64_t)r * C + c], b = y[(int64_t)r * C + c];
+        dot += a * b;
+        xx += a * a;
+        yy += b * b;
+      }
+      dot = wave_sum(dot);
+      xx = wave_sum(xx);
+      yy = wave_sum(yy);
+      const float nx = sqrtf(xx), ny = sqrtf(yy), nxc = fmaxf(nx, t.eps), nyc = fmaxf(ny, t.eps);
+      for (int c = lane; c < C; c += 64) {
+        float v = y[(int64_t)r * C + c] / (nxc * nyc);
+        if (nx > t.eps) v -= dot * x[(int64_t)r * C + c] / (nxc * nxc * nxc * nyc);
+        const int64_t i = (int64_t)r * C + c;
+        dx[i] = t.first[k] ? g * v : dx[i] + g * v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // NT-Xent (SimCLR) contrastive loss -- OPTIONAL EXTRA, not in the reference (the reference's contrastive
 // term is the negative cosine similarity above).  z = [z1; z2] is [R = 2N][C]; row i's positive is row (i + N) mod R.
 //   zn = z / max(|z|, eps);  S = zn zn^T / tau;  loss = mean_i ( logsumexp_{k != i} S[i][k] - S[i][pos_i] )
@@ -525,6 +615,44 @@ extern "C" int pcrl_cosine_mean_bwd(const float* x, const float* y, const float*
   PCRL_REQUIRE(x && y && saved && dout && dx, "cosine_mean_bwd: null pointer");
   hipLaunchKernelGGL(cosine_bwd_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, as_stream(stream), x, y, saved, dout, dx, rows, C, eps);
   return pcrl_check_launch("cosine_bwd");
+}
+
+static int fill_cos_terms(CosTerms& t, const void* const* x, const void* const* y, void* const* dx, const float* w, const int* C,
+                          const int* group, const int* first, int nterms, int rows, int ngroups, float eps, const char* what) {
+  PCRL_REQUIRE(x && y && w && C && group && nterms > 0 && nterms <= COS_MAX_TERMS && rows > 0 && ngroups > 0 && ngroups <= 8,
+               "%s: bad arguments (1..%d terms, 1..8 groups)", what, COS_MAX_TERMS);
+  for (int k = 0; k < nterms; ++k) {
+    PCRL_REQUIRE(x[k] && y[k] && C[k] > 0 && group[k] >= 0 && group[k] < ngroups, "%s: bad term %d", what, k);
+    t.x[k] = (const float*)x[k];
+    t.y[k] = (const float*)y[k];
+    t.dx[k] = dx ? (float*)dx[k] : nullptr;
+    t.w[k] = w[k];
+    t.C[k] = C[k];
+    t.group[k] = group[k];
+    t.first[k] = first ? first[k] : 1;
+  }
+  t.n = nterms;
+  t.rows = rows;
+  t.ngroups = ngroups;
+  t.eps = eps;
+  return PCRL_OK;
+}
+extern "C" int pcrl_cosine_terms_fwd(const void* const* x, const void* const* y, const float* w, const int* C, const int* group, int nterms, int rows,
+                                     int ngroups, float eps, float* out, pcrl_stream_t stream) {
+  CosTerms t;
+  if (int e = fill_cos_terms(t, x, y, nullptr, w, C, group, nullptr, nterms, rows, ngroups, eps, "cosine_terms_fwd")) return e;
+  PCRL_REQUIRE(out, "cosine_terms_fwd: null output");
+  hipLaunchKernelGGL(cosine_terms_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), t, out);
+  return pcrl_check_launch("cosine_terms_fwd");
+}
+extern "C" int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y, void* const* dx, const float* w, const int* C, const int* group,
+                                     const int* first, int nterms, int rows, int ngroups, float eps, const float* dout, pcrl_stream_t stream) {
+  CosTerms t;
+  PCRL_REQUIRE(dx && first && dout, "cosine_terms_bwd: null pointer");
+  if (int e = fill_cos_terms(t, x, y, dx, w, C, group, first, nterms, rows, ngroups, eps, "cosine_terms_bwd")) return e;
+  for (int k = 0; k < nterms; ++k) PCRL_REQUIRE(dx[k], "cosine_terms_bwd: term %d has no gradient buffer", k);
+  hipLaunchKernelGGL(cosine_terms_bwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), t, dout);
+  return pcrl_check_launch("cosine_terms_bwd");
 }
 
 extern "C" int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,

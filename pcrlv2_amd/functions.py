@@ -330,6 +330,61 @@ class CosineMeanFn(Function):
         return ops.cosine_mean_backward(ctx.x, ctx.y, ctx.saved, dout), None
 
 
+class CosineTermsFn(Function):
+    """Every cosine term of one step in one launch (train_3d.py:119-134): out[g] = sum_t w_t * mean_r cos(x_t[r], y_t[r].detach()).
+
+    forward(ctx, spec, rows, ngroups, *tensors): `tensors` are float32 [R, C] matrices; spec = [(xi, x_row0, yi, y_row0, w, group), ...]
+    names a term by the indices of its operands in `tensors` and the first of its `rows` rows (local views are row blocks of [6n, C]).
+    Gradients flow to the x operands only; a tensor that is no term's x gets None (like an unused scale in the reference)."""
+
+    @staticmethod
+    def forward(ctx, spec, rows, ngroups, *tensors):
+        import ctypes
+        ts = [t.contiguous().float() for t in tensors]
+        n = len(spec)
+        P, F32, I32 = ctypes.c_void_p * n, ctypes.c_float * n, ctypes.c_int * n
+        ptr = lambda i, r0: ts[i].data_ptr() + 4 * r0 * ts[i].shape[1]
+        x, y = P(*[ptr(s[0], s[1]) for s in spec]), P(*[ptr(s[2], s[3]) for s in spec])
+        w, C, grp = F32(*[float(s[4]) for s in spec]), I32(*[ts[s[0]].shape[1] for s in spec]), I32(*[int(s[5]) for s in spec])
+        out = torch.empty(ngroups, dtype=torch.float32, device=ts[0].device)
+        adr = ctypes.addressof
+        ops.lib().call("pcrl_cosine_terms_fwd", adr(x), adr(y), adr(w), adr(C), adr(grp), n, rows, ngroups, 1e-8, out, ops.stream_handle())
+        ctx.ts, ctx.spec, ctx.rows, ctx.ngroups = ts, spec, rows, ngroups
+        ctx.host = (x, y, w, C, grp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        ts, spec, n = ctx.ts, ctx.spec, len(ctx.spec)
+        x, y, w, C, grp = ctx.host
+        grads, seen = [None] * len(ts), set()
+        first = []
+        for s in spec:
+            if grads[s[0]] is None:
+                grads[s[0]] = torch.empty_like(ts[s[0]])
+            key = (s[0], s[1])                      # a row block of a tensor: the first term that touches it stores, later ones add
+            first.append(0 if key in seen else 1)
+            seen.add(key)
+        # row blocks of a multi-block tensor (the local views) that no term wrote stay undefined: zero them
+        for i, g in enumerate(grads):
+            if g is not None and g.shape[0] != ctx.rows:
+                blocks = {r0 for (xi, r0) in seen if xi == i}
+                if len(blocks) * ctx.rows != g.shape[0]:
+                    g.zero_()
+        P, I32 = ctypes.c_void_p * n, ctypes.c_int * n
+        dx = P(*[grads[s[0]].data_ptr() + 4 * s[1] * ts[s[0]].shape[1] for s in spec])
+        fst = I32(*first)
+        adr = ctypes.addressof
+        ops.lib().call("pcrl_cosine_terms_bwd", adr(x), adr(y), adr(dx), adr(w), adr(C), adr(grp), adr(fst), n, ctx.rows, ctx.ngroups, 1e-8,
+                       dout.contiguous().float(), ops.stream_handle())
+        return (None, None, None) + tuple(grads)
+
+
+def cosine_terms(spec, rows, ngroups, tensors):
+    return CosineTermsFn.apply(spec, rows, ngroups, *tensors)
+
+
 def mse_loss(p, gt):
     return MSELossFn.apply(p, gt)
 

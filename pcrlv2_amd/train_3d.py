@@ -48,9 +48,14 @@ class MSELoss:
         return mse_loss(pred, target)
 
 
+FUSED_COS_LOSSES = os.environ.get("PCRL_FUSED_COS", "1") != "0"   # all 26 cosine means of a step in one launch (0: one launch per mean)
+
+
 class CosineSimilarityMean:
-    """train_3d.py:57's nn.CosineSimilarity(), fused with the `.mean()` that every call site applies to it."""
+    """train_3d.py:57's nn.CosineSimilarity(), fused with the `.mean()` that every call site applies to it.  `fusable`: the training
+    step may hand all of its cosine terms to one kernel launch instead of calling this object 26 times (same arithmetic)."""
     returns_mean = True
+    fusable = True
 
     def cuda(self):
         return self
@@ -79,6 +84,32 @@ def _to_gpu(t):
     return t.float().cuda(non_blocking=True)
 
 
+def _fused_cos_losses(feats1, feats2, feats_loc, n, nlocal):
+    """The 13 cos_loss calls of train_3d.py:119-134 as ONE launch: the scales are drawn from python's `random` in the reference's
+    order (global pair; then for every local view (view 1, local_i), (view 2, local_i)), the 26 cosine means and their weights
+    (-1/2 per call; /(2 * nlocal) for the local group) go to pcrl_cosine_terms_*.  -> (global term, local term, first drawn scale)."""
+    ns = len(feats1)
+    tensors, idx = [], {}
+    for name, fs in (("1", feats1), ("2", feats2), ("L", feats_loc)):
+        for k in range(ns):
+            idx[name, k, 0], idx[name, k, 1] = len(tensors), len(tensors) + 1          # 0 = projection, 1 = prediction
+            tensors += [fs[k][0], fs[k][1]]
+    spec = []
+
+    def add(a, ra, b, rb, k, w, g):        # -(cos(pre_a, pro_b) + cos(pre_b, pro_a)) / 2 * w   at scale k
+        spec.append((idx[a, k, 1], ra, idx[b, k, 0], rb, -0.5 * w, g))
+        spec.append((idx[b, k, 1], rb, idx[a, k, 0], ra, -0.5 * w, g))
+
+    k0 = random.randint(0, ns - 1)
+    add("1", 0, "2", 0, k0, 1.0, 0)
+    wl = 1.0 / (2 * nlocal)
+    for i in range(nlocal):
+        add("1", 0, "L", n * i, random.randint(0, ns - 1), wl, 1)
+        add("2", 0, "L", n * i, random.randint(0, ns - 1), wl, 1)
+    out = _fn.cosine_terms(spec, n, 2, tensors)
+    return out[0], out[1], k0
+
+
 def step_losses(model, batch, epoch, criterion, cosine):
     """Forward half of one iteration (train_3d.py:113-138): three forwards, 13 cosine terms, two restoration terms.
     Returns (total, restoration, global-cosine, deep-supervision, local-cosine) as device scalars."""
@@ -87,6 +118,13 @@ def step_losses(model, batch, epoch, criterion, cosine):
     target = _to_gpu(target)
     out1, feats1, masks1 = model(_to_gpu(view1))
     _out2, feats2, _ = model(_to_gpu(view2))                            # mask2 / its deep-supervision maps stay unused (Q3)
+    if getattr(cosine, "fusable", False) and FUSED_COS_LOSSES:
+        _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
+        l_global, l_local, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
+        l_restore = criterion(out1, target)
+        beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
+        l_deep = beta * criterion(masks1[scale], target)
+        return l_restore + l_global + l_deep + l_local, l_restore, l_global, l_deep, l_local
     l_global, scale = cos_loss(cosine, feats1, feats2)
     _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
     stacked = [torch.stack(pair) for pair in feats_loc]                 # [2, 6n, C] per scale
