@@ -214,7 +214,8 @@ GOLDEN_STEPS = {
     # fp32: (map max, feature abs, (MSE-loss, other-loss) abs, gradient rel-L2)
     # bf16: (map max [mean = 1/4 of it], feature cosine, (MSE-loss, other-loss) abs, gradient-norm median, gradient-norm worst, gradient cosine min)
     "c_b16_32x32x16": dict(fp32=(5e-5, 2e-4, (1e-5, 1e-5), 1.5e-2), bf16=(6e-2, 0.997, (5e-5, 2e-3), 0.02, 0.25, 0.8), grads=True),
-    "c_luna_b8_64x64x32": dict(fp32=(5e-5, 2e-4, (1e-5, 1e-5), 1.5e-2), bf16=(6e-2, 0.997, (5e-5, 2e-3), 0.02, 0.25, 0.8), grads=True),
+    # b = 8 rows in BatchNorm1d, 8x the voxels per crop: measured bf16 maps max 5.8e-2, cosine losses 1.5e-3, norms median 1.8 % / worst 10 %, direction 0.85
+    "c_luna_b8_64x64x32": dict(fp32=(5e-5, 2e-4, (1e-5, 1e-5), 1.5e-2), bf16=(9e-2, 0.996, (5e-5, 4e-3), 0.04, 0.25, 0.75), grads=True),
     "c_luna_b2_64x64x32": dict(fp32=(5e-5, 5e-4, (1e-5, 2e-5), None), bf16=(1e-1, 0.975, (5e-5, 2e-2), None, None, None), grads=False),
 }
 
