@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    for key in ("brick_conv_kernel", "wgrad_brick_kernel", "wgrad_reduce_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_rc_kernel",
+    for key in ("brick16_conv_kernel", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_reduce_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_rc_kernel",
                 "bn_apply_rc_kernel", "igemm_kernel", "wgrad_kernel", "coltile_sum_kernel", "sgemm_small_kernel", "shift_sum27_kernel",
                 "c1_fwd_kernel", "maxpool_bwd_kernel", "maxpool_fwd_kernel", "im2col27_kernel", "gap_bwd_kernel", "to1_dgrad_kernel",
                 "to1_fwd_kernel", "bn_finalize_kernel", "bn_bwd_finalize_kernel", "coltile_finish_kernel", "sgd_kernel", "tri_fwd_kernel",
@@ -69,7 +69,9 @@ def main():
                 "# SQ counters are sampled on ONE XCD (SQ_BUSY_CU_CYCLES / GRBM_GUI_ACTIVE ~ 30 of its 32 CUs): MFMA busy fraction =\n"
                 "# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 32 CUs * 4 SIMDs).\n")
         traffic = {}
-        for k in ("brick_conv_kernel", "wgrad_brick_kernel"):
+        for k in ("brick16_conv_kernel", "brick_conv_kernel", "wgrad_brick_kernel"):
+            if k not in fd or k not in wd or k not in md:
+                continue
             nf, nw, nm = len(fd[k]), len(wd[k]), len(md[k])
             f_mb = 2 * fa[k]["FETCH_SIZE"] / nf * 1024 / 1e6
             w_mb = wa[k]["WRITE_SIZE"] / nw * 1024 / 1e6
