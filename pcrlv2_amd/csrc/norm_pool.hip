@@ -295,9 +295,11 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict_
 // Column sums over row tiles (used by colsum and the global average pool).
 //   ws[(blockIdx.y * gridDim.x + blockIdx.x) * C + c] = sum over the tile's rows of v[n=blockIdx.y][row][c]
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// WEIGHTED: every row is multiplied by a float scalar first (rowscale[n][row]): the weight gradient of a 1x1x1 convolution to ONE channel,
+// dw[c] = sum_m x[m][c] * dy[m] (OutputTransition.final_conv, models/pcrlv2_model_3d.py:78), as one pass over x.
+template <typename T, bool WEIGHTED = false>
 __global__ void __launch_bounds__(256) coltile_sum_kernel(const T* __restrict__ v, float* __restrict__ ws, int64_t rows_per_n, int C,
-                                                         int tile_rows) {
+                                                         int tile_rows, const float* __restrict__ rowscale = nullptr) {
   constexpr int VEC = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C]
   const int tid = threadIdx.x;
@@ -311,8 +313,9 @@ __global__ void __launch_bounds__(256) coltile_sum_kernel(const T* __restrict__ 
   for (int j = 0; j < VEC; ++j) s[j] = 0.f;
   for (int64_t r = rbeg + slot; r < rend; r += nslots) {
     const Vec16<T> x = ld16(base + (r * nvec + cv) * VEC);
+    const float wr = WEIGHTED ? rowscale[(int64_t)blockIdx.y * rows_per_n + r] : 1.f;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) s[j] += to_f(x.v[j]);
+    for (int j = 0; j < VEC; ++j) s[j] += WEIGHTED ? to_f(x.v[j]) * wr : to_f(x.v[j]);
   }
 #pragma unroll
   for (int j = 0; j < VEC; ++j) sm[slot * C + cv * VEC + j] = s[j];
@@ -631,6 +634,22 @@ static int coltile_launch(const void* v, float* out, void* ws, size_t ws_bytes, 
 extern "C" int pcrl_colsum(const void* v, float* out, void* ws, size_t ws_bytes, int64_t M, int C, int dtype, pcrl_stream_t stream) {
   PCRL_REQUIRE(v && out, "colsum: null pointer");
   return coltile_launch(v, out, ws, ws_bytes, 1, M, C, dtype, 1.0, as_stream(stream), "colsum");
+}
+
+// out[c] = sum_m v[m][c] * rowscale[m]  (internal: the taps == 1 path of pcrl_conv3d_to1_wgrad, conv_wgrad.hip)
+size_t pcrl_weighted_colsum_ws_bytes(int64_t M, int C) { return pcrl_colsum_ws_bytes(M, C); }
+int pcrl_weighted_colsum(const void* v, const float* rowscale, float* out, void* ws, size_t ws_bytes, int64_t M, int C, int dtype, hipStream_t stream) {
+  if (int e = check_tilevec("weighted_colsum", C, dtype, false)) return e;
+  const int64_t tiles = coltile_tiles(1, M);
+  const size_t need = (size_t)tiles * C * sizeof(float);
+  if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "weighted_colsum: workspace %zu < %zu", ws_bytes, need);
+  const size_t lds = (size_t)(256 / (C / (dtype == PCRL_BF16 ? 8 : 4))) * C * sizeof(float);
+  const dim3 grid((unsigned)tiles, 1);
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL((coltile_sum_kernel<bf16, true>), grid, dim3(256), lds, stream, (const bf16*)v, (float*)ws, M, C, coltile_rows(1, M), rowscale);
+  else hipLaunchKernelGGL((coltile_sum_kernel<float, true>), grid, dim3(256), lds, stream, (const float*)v, (float*)ws, M, C, coltile_rows(1, M), rowscale);
+  if (int e = pcrl_check_launch("weighted_colsum")) return e;
+  hipLaunchKernelGGL(coltile_finish_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, stream, (const float*)ws, out, (int)tiles, C, 1, 1.0);
+  return pcrl_check_launch("weighted_colsum");
 }
 
 extern "C" size_t pcrl_gap_ws_bytes(int N, int64_t S, int C) { return (size_t)N * coltile_tiles(N, S) * C * sizeof(float); }
