@@ -39,7 +39,7 @@ def conv_key(name, args):
     N, D, H, W, Ci, Co, dt = args[7:14] if name == "pcrl_conv3d_k3_fwd_ws" else args[5:12]
     if dt == 1 and D % 4 == 0 and H % 8 == 0 and W % 16 == 0 and Co % 32 == 0 and os.environ.get("PCRL_DEBUG_CONV_IMPL", "0") == "0":
         key = "brick16_conv_kernel"
-    elif dt == 1 and D % 4 == 0 and H % 8 == 0 and W % 8 == 0 and Co % 32 == 0:
+    elif dt == 1 and Co % 32 == 0 and ((D % 4 == 0 and H % 8 == 0 and W % 8 == 0) or (W % 4 == 0 and D % 8 == 0 and H % 8 == 0)):
         key = "brick_conv_kernel"
     else:
         bn = 128 if Co % 128 == 0 else (64 if Co % 64 == 0 else 32)

@@ -48,6 +48,10 @@ struct BrickParams {
   int up;             // KD = 1 only: the source is [N][D][H/2][W/2] read through a nearest x2 upsample (conv2d.hip)
   int ny;             // > 0: 1-D grid of bricks x ny ids, the ny output-channel tiles of a brick on consecutive slots of ONE XCD (they
                       // stage the same halo: fetched into that L2 once); 0: 2-D grid (bricks, tiles)
+  // Axis permutation (KD = 3 only).  The kernel tiles an index space (D, H, W) = "brick axes" with 4 x 8 x 8 bricks; sd, sh, sw are the
+  // strides (in voxels) of those axes in memory and td, th, tw the tap-index strides (a permutation of 9, 3, 1), so a volume whose
+  // innermost extent is 4 (the 8 x 8 x 4 bottleneck level) runs with its W as the 4-deep brick axis.  Identity: (H*W, W, 1), (9, 3, 1).
+  int sd, sh, sw, td, th, tw;
 };
 
 // Weight tile [64 co][32 k]: a fragment read takes 16 CONSECUTIVE rows -> same swizzle as conv_igemm.hip's Tile<bf16>.
@@ -121,7 +125,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
       const int Hs = p.H >> 1, Ws = p.W >> 1;
       grow[i] = ok ? ((n * p.D + d) * Hs + (h >> 1)) * Ws + (w >> 1) : ((n * p.D + d0) * Hs + (h0 >> 1)) * Ws + (w0 >> 1);
     } else {
-      grow[i] = ok ? ((n * p.D + d) * p.H + h) * p.W + w : ((n * p.D + d0) * p.H + h0) * p.W + w0;
+      grow[i] = n * (p.D * p.H * p.W) + (ok ? d * p.sd + h * p.sh + w * p.sw : d0 * p.sd + h0 * p.sh + w0 * p.sw);
     }
     hvalid |= (uint32_t)ok << i;
   }
@@ -154,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #define LOAD_W(c_, s9_)                                                                                   \
   do {                                                                                                    \
     _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                         \
-      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)((s9_)*3 + j) * K + (c_)*32);               \
+      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)(KD == 3 ? ((s9_) / 3) * p.td + ((s9_) % 3) * p.th + j * p.tw : (s9_)*3 + j) * K + (c_)*32); \
   } while (0)
 #define STORE_W()                                                                                         \
   do {                                                                                                    \
@@ -286,7 +290,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int v = wid * 64 + fm * 16 + lg * 4 + r;
-      const int64_t row = (((int64_t)n * p.D + d0 + (v >> 6)) * p.H + h0 + ((v >> 3) & 7)) * p.W + w0 + (v & 7);
+      const int64_t row = (int64_t)n * p.D * p.H * p.W + (int64_t)(d0 + (v >> 6)) * p.sd + (h0 + ((v >> 3) & 7)) * p.sh + (w0 + (v & 7)) * p.sw;
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const float val = acc[fm][j][r] + bv[j];
@@ -328,11 +332,14 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 }  // namespace
 
 // ---- internal interface used by conv_igemm.hip's dispatcher -------------------------------------------------------
+// natural orientation (W % 8 == 0), or W % 4 == 0 with D % 8 == 0 and H % 8 == 0 (W becomes the 4-deep brick axis: the 8 x 8 x 4 level)
+static bool brick_natural(int D, int H, int W) { return D % TD == 0 && H % TH == 0 && W % TW == 0; }
+static bool brick_permuted(int D, int H, int W) { return W % TD == 0 && D % TH == 0 && H % TW == 0; }
 bool pcrl_brick_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  return dtype == PCRL_BF16 && D % TD == 0 && H % TH == 0 && W % TW == 0 && Ci % 32 == 0 && Co % 32 == 0 &&
+  return dtype == PCRL_BF16 && (brick_natural(D, H, W) || brick_permuted(D, H, W)) && Ci % 32 == 0 && Co % 32 == 0 &&
          (int64_t)N * D * H * W < (int64_t)1 << 31;
 }
-int64_t pcrl_brick_conv_rows(int N, int D, int H, int W) { return (int64_t)N * (D / TD) * (H / TH) * (W / TW); }
+int64_t pcrl_brick_conv_rows(int N, int D, int H, int W) { return (int64_t)N * D * H * W / BRICK; }
 
 static std::atomic<int> g_brick_ymap{1};
 void pcrl_brick_conv_set_ymap(int on) { g_brick_ymap = on; }
@@ -345,9 +352,15 @@ int pcrl_brick_conv_launch(const void* x, const void* wp, const float* bias, voi
     hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<64, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, HB + 3 * 64 * 64);
     hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<32, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, HB + 3 * 32 * 64);
   });
-  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0, 0};
+  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0, 0, H * W, W, 1, 9, 3, 1};
+  if (W % TW != 0) {   // W == 4: memory (D, H, W) -> brick axes (W, D, H); tap (kd', kh', kw') = (kw, kd, kh) -> index kh' * 9 + kw' * 3 + kd'
+    p.D = W; p.H = D; p.W = H;
+    p.sd = 1; p.sh = H * W; p.sw = W;
+    p.td = 1; p.th = 9; p.tw = 3;
+  }
   const unsigned bricks = (unsigned)pcrl_brick_conv_rows(N, D, H, W);
-  const int BN = Co % 64 == 0 ? 64 : 32, ny = Co / BN;
+  // few bricks (the 8 x 8 x 4 level: 32 at b = 32): 32-channel tiles double the number of blocks (128 -> 256 for 256 output channels)
+  const int BN = (Co % 64 == 0 && (int64_t)bricks * (Co / 64) > 192) ? 64 : 32, ny = Co / BN;
   dim3 grid(bricks, ny);
   if (g_brick_ymap && ny > 1 && (uint64_t)bricks * ny < (1u << 31)) {
     p.ny = ny;
@@ -368,7 +381,7 @@ int64_t pcrl_brick_conv2d_rows(int N, int H, int W) { return (int64_t)(N / TD) *
 int pcrl_brick_conv2d_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Ci, int Co, int up,
                              hipStream_t stream) {
   constexpr int HB = BrickGeom<1>::HALO_BYTES;
-  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, 1, N, H, W, Ci, Co, up, 0};
+  BrickParams p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, 1, N, H, W, Ci, Co, up, 0, H * W, W, 1, 9, 3, 1};
   const unsigned bricks = (unsigned)pcrl_brick_conv2d_rows(N, H, W);
   if (Co % 64 == 0) hipLaunchKernelGGL((brick_conv_kernel<64, 1>), dim3(bricks, Co / 64), dim3(256), HB + 3 * 64 * 64, stream, p);
   else hipLaunchKernelGGL((brick_conv_kernel<32, 1>), dim3(bricks, Co / 32), dim3(256), HB + 3 * 32 * 64, stream, p);
