@@ -50,7 +50,7 @@ def conv_key(name, args):
 def wgrad_key(name, args):
     # pcrl_conv3d_k3_wgrad(x, dy, dw, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)
     N, D, H, W, Ci, Co, dt = args[5:12]
-    if dt == 1 and D % 2 == 0 and H % 8 == 0 and W % 8 == 0 and Co % 64 == 0:
+    if dt == 1 and Co % 64 == 0 and ((D % 2 == 0 and H % 8 == 0 and W % 8 == 0) or (W % 2 == 0 and D % 8 == 0 and H % 8 == 0)):
         key = "wgrad_brick_kernel(+reduce)"
     else:
         key = "wgrad_kernel<%s,conv3>(+reduce)" % ("bf16" if dt == 1 else "f32")

@@ -70,6 +70,10 @@ struct WBrickParams {
   // XCD co-located launch (nkd = 3, see plan_xcd()): a 1-D grid in chunks of 256 ids; the G = 3 * gs blocks that walk the SAME brick
   // range (three kd planes x gs tiles) get ids that are congruent mod 8, i.e. run on one XCD at the same time, so that the dy tile and
   // the overlapping x planes of a brick are fetched into that XCD's L2 once and hit there G - 1 times.  0 = the 2-D grid above.
+  // Axis permutation (nkd = 3, up = 0): D, H, W above are the extents of the BRICK axes (tiled 2 x 8 x 8), sd / sh / sw their strides
+  // in memory (voxels) and td / th / tw the tap-index strides (a permutation of 9, 3, 1): a volume with innermost extent 4 (the
+  // 8 x 8 x 4 level) runs with its W as the 2-deep brick axis.  Identity: (H * W, W, 1), (9, 3, 1).
+  int sd, sh, sw, td, th, tw;
   int xcd_map;
   int order;        // brick walk order: 0 = w, h, d, n ; 1 = w, d, h, n
   int G, Q, gpc, ngroups, ntg, pair;   // group size, groups per XCD and chunk, groups per chunk, groups, tile groups per range, 0 none / 1 pair over j / 2 pair over i
@@ -174,7 +178,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #pragma unroll
   for (int i = 0; i < DYP; ++i) {
     const int v = (tid >> 3) + (NT / 8) * i;
-    dyoff[i] = (uint32_t)((((v >> 6) * p.H + ((v >> 3) & 7)) * p.W + (v & 7)) * p.Cu + pc_dy * 8) * 2u;
+    dyoff[i] = (uint32_t)(((v >> 6) * p.sd + ((v >> 3) & 7) * p.sh + (v & 7) * p.sw) * p.Cu + pc_dy * 8) * 2u;
   }
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     const bool row_ok = r < XROWS && hw < BW + 2;
     // upsampled source: brick origins are even, so halo row hh maps to source row (h0/2 - 1) + ((hh + 1) >> 1): still a fixed offset
     const int shh = p.up ? (hh + 1) >> 1 : hh, shw = p.up ? (hw + 1) >> 1 : hw;
-    xoff[i] = row_ok ? (uint32_t)(((hd * Hs + shh) * Ws + shw) * p.Cv + xcol) * 2u : 0u;
+    xoff[i] = row_ok ? (uint32_t)((p.up ? (hd * Hs + shh) * Ws + shw : hd * p.sd + hh * p.sh + hw * p.sw) * p.Cv + xcol) * 2u : 0u;
     xedge[i] = (hd == 0 ? 1u : 0u) | (hd == BD - 1 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == XH - 1 ? 8u : 0u) | (hw == 0 ? 16u : 0u) |
                (hw == BW + 1 ? 32u : 0u) | (row_ok ? 0u : 64u);
   }
@@ -243,11 +247,11 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
-    const int64_t base0 = (((int64_t)n * p.D + d0) * p.H + h0) * p.W + w0;                                   \
+    const int64_t base0 = (int64_t)n * p.D * p.H * p.W + (int64_t)d0 * p.sd + h0 * p.sh + w0 * p.sw;          \
     dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                           \
     /* first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
     const int64_t xbase0 = p.up ? (((int64_t)n * p.D + d0) * Hs + (h0 >> 1)) * Ws + (w0 >> 1) : base0;       \
-    xb = reinterpret_cast<const char*>(p.x + (xbase0 + ((int64_t)(kd - 1) * Hs - 1) * Ws - 1) * p.Cv);      \
+    xb = reinterpret_cast<const char*>(p.x + (xbase0 + (p.up ? ((int64_t)(kd - 1) * Hs - 1) * Ws - 1 : (int64_t)(kd - 1) * p.sd - p.sh - p.sw)) * p.Cv); \
     /* faces of this brick's halo that stick out of the volume (BD = 2: the d faces are the two planes) */    \
     xout = (d0 + kd - 1 < 0 ? 1u : 0u) | (d0 + kd - 1 + BD - 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |      \
            (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;            \
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
   if (j < p.Cv) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      float* ot = out + (int64_t)((p.nkd == 3 ? kd * 9 : 0) + t) * p.Cu * p.Cv;
+      float* ot = out + (int64_t)(p.nkd == 3 ? kd * p.td + (t / 3) * p.th + (t % 3) * p.tw : t) * p.Cu * p.Cv;
 #pragma unroll
       for (int f = 0; f < FA; ++f)
 #pragma unroll
@@ -482,9 +486,12 @@ template <int TCO, int TCI> void launch_cfg(dim3 grid, hipStream_t stream, const
 }  // namespace
 
 // ---- internal interface used by conv_wgrad.hip ---------------------------------------------------------------------
+// natural orientation (W % 8 == 0), or the innermost extent as the 2-deep brick axis (W % 2 == 0, D % 8 == 0, H % 8 == 0: the 8 x 8 x 4 level)
+static bool wb_natural(int D, int H, int W) { return D % BD == 0 && H % BH == 0 && W % BW == 0; }
+static bool wb_permuted(int D, int H, int W) { return W % BD == 0 && D % BH == 0 && H % BW == 0; }
 bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  return dtype == PCRL_BF16 && D % BD == 0 && H % BH == 0 && W % BW == 0 && Co % 64 == 0 && Ci % 32 == 0 &&
-         (int64_t)N * D * H * W / BV < (1 << 30);
+  return dtype == PCRL_BF16 && (wb_natural(D, H, W) || wb_permuted(D, H, W)) && Co % 64 == 0 && Ci % 32 == 0 &&
+         (int64_t)N * D * H * W / BV < (1 << 30) && (int64_t)N * D * H * W * (Ci > Co ? Ci : Co) < ((int64_t)1 << 31);
 }
 int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co) {
   // the workspace must hold the partial slabs of every launch form
@@ -503,7 +510,13 @@ int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int
                             hipStream_t stream) {
   const int nbricks = (int)((int64_t)N * D * H * W / BV);
   const BrickSplit sp = plan3(nbricks, Co, Ci);
-  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 0, 3, sp.xcd_map, g_wb_order, sp.G, sp.Q, sp.gpc, sp.ngroups, sp.ntg, sp.pair};
+  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 0, 3, H * W, W, 1, 9, 3, 1,
+                 sp.xcd_map, g_wb_order, sp.G, sp.Q, sp.gpc, sp.ngroups, sp.ntg, sp.pair};
+  if (!wb_natural(D, H, W)) {   // memory (D, H, W) -> brick axes (W, D, H); tap (kd', kh', kw') = (kw, kd, kh) -> index kh' * 9 + kw' * 3 + kd'
+    p.D = W; p.H = D; p.W = H;
+    p.sd = 1; p.sh = H * W; p.sw = W;
+    p.td = 1; p.th = 9; p.tw = 3;
+  }
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64) * 3));
   if (sp.xcd_map) grid = dim3((unsigned)sp.blocks);
   switch (sp.cfg) {
@@ -525,7 +538,7 @@ int pcrl_wgrad_brick2d_splits(int N, int H, int W, int Ci, int Co) { return plan
 int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int Ci, int Co, int up, hipStream_t stream) {
   const int nbricks = (int)((int64_t)N * H * W / BV);
   const BrickSplit sp = plan(nbricks, Co, Ci, 1);
-  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, up, 1, 0, 0, 0, 0, 0, 0, 0, 0};
+  WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, 1, N, H, W, Co, Ci, nbricks, sp.per_split, up, 1, H * W, W, 1, 9, 3, 1, 0, 0, 0, 0, 0, 0, 0, 0};
   dim3 grid((unsigned)sp.splits, (unsigned)((Co / 64) * ((Ci + 63) / 64)));
   launch_cfg<64, 64>(grid, stream, p);
   return pcrl_check_launch("wgrad_brick2d");
