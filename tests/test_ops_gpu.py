@@ -144,7 +144,7 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("shape", [(4, 8, 8, 4, 64, 128), (3, 2, 2, 2, 96, 64), (2, 4, 4, 4, 256, 32)])
+@pytest.mark.parametrize("shape", [(4, 8, 4, 4, 64, 128), (3, 2, 2, 2, 96, 64), (2, 4, 4, 4, 256, 32)])   # (8x8x4 runs on the brick kernel: axis permutation)
 def test_conv3d_small_volume_split_k(shape, dt):
     """pcrl_conv3d_k3_fwd_ws: the K-split gather path of small volumes (8x8x4 bottleneck, 4^3 / 2^3 local-view levels) must give
     the one-pass result: output, bias, and the BatchNorm partial statistics (same row count)."""
