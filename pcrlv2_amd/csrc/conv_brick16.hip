@@ -22,7 +22,8 @@
 //
 // Measured (timing ablations, same box, 128 -> 64 channels at 64x64x32): without the halo requests after the first chunk -17 %, without the
 // weight staging -13 %, without both -22 % (1 560 TFLOP/s); requesting the dead planes early changes nothing.  What is left on the
-// table is bytes staged per MFMA, not latency.
+// table is bytes staged per MFMA, not latency.  (Also tried: weight fragments straight from global memory into registers, no weight stage
+// in LDS and no per-stage barriers -- 16 x 64-byte segments per load instruction, L1 / address-path bound: -30 %.)
 //
 // LDS: halo 68 KiB (single buffer: 1080 rows x 64 B, rounded up to whole 1 KiB DMA pieces) + one weight stage 12 KiB = 80 KiB -> two
 // blocks (eight waves) per CU.  The next chunk's halo is requested as soon as every wave holds the last fragments of the current one
