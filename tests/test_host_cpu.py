@@ -29,7 +29,11 @@ def test_library_exports_every_declared_symbol():
     assert L.call("pcrl_conv3d_k3_wgrad_ws_bytes", 2, 16, 16, 16, 64, 64) > 0
     assert L.call("pcrl_bn_bwd_partial_rows", 1 << 22) == 4096      # 1024-row tiles on the big volumes
     assert L.call("pcrl_bn_bwd_partial_rows", 5000) == 157          # 32-row tiles: small volumes still spread over the chip
-    assert L.call("pcrl_conv3d_k3_fwd_ws_bytes", 32, 8, 8, 4, 256, 256, 1) > 0   # 8x8x4 bottleneck level: split-K
+    assert L.call("pcrl_conv3d_k3_fwd_ws_bytes", 32, 8, 8, 4, 256, 256, 1) == 0   # 8x8x4 bottleneck level in bf16: brick kernel (axis permutation)
+    assert L.call("pcrl_conv3d_k3_fwd_ws_bytes", 32, 8, 8, 4, 256, 256, 0) > 0    # float32 parity mode: gather kernel with split-K
+    assert L.call("pcrl_conv3d_k3_fwd_ws_bytes", 192, 4, 4, 4, 256, 256, 1) > 0   # 4^3 level of the local views: split-K
+    assert L.call("pcrl_conv3d_k3_stats_rows", 32, 64, 64, 32, 64, 64, 1) == 32 * 16 * 8 * 2      # 4x8x16 bricks where W % 16 == 0
+    assert L.call("pcrl_conv3d_k3_stats_rows", 32, 16, 16, 8, 128, 128, 1) == 32 * 4 * 2 * 1       # 4x8x8 bricks
     assert L.call("pcrl_conv3d_k3_fwd_ws_bytes", 32, 64, 64, 32, 64, 64, 1) == 0
 
 
