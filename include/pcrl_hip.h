@@ -274,14 +274,16 @@ int pcrl_add_relu_fwd(const void* t, const void* r, void* a, int64_t n, int dtyp
 int pcrl_relu_mask_bwd(const void* da, const void* a, void* g, int64_t n, int dtype, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
- * All cosine terms of one step in one launch -- train_3d.py:119-134 (13 cos_loss calls = 26 cosine means, :86-92).
+ * All cosine terms of one step in one call -- train_3d.py:119-134 (13 cos_loss calls = 26 cosine means, :86-92).
  *   out[g] = sum_{t : group[t] == g} w[t] * mean_r cos(x[t][r], y[t][r]),  x[t], y[t]: float32 [rows][C[t]] on the device
  * `x`, `y`, `dx`, `w`, `C`, `group`, `first` are HOST arrays of `nterms` <= 32 entries (device pointers / scalars); they are copied into
  * the kernel arguments.  bwd: dx[t] (device float32 [rows][C[t]]; several terms may name the same buffer) receives
- * dout[group[t]] * w[t] * d(mean cos)/dx[t]: stored when first[t] != 0, accumulated otherwise, terms in order (deterministic).
- * y is the reference's detached operand: no gradient. */
+ * the sum, in term order (deterministic), of dout[group[t]] * w[t] * d(mean cos)/dx[t] over the terms that name it; first[t] != 0
+ * must mark exactly the first term of every buffer (checked), and terms that share a buffer share C.
+ * y is the reference's detached operand: no gradient.  fwd: `ws` = pcrl_cosine_terms_ws_bytes(nterms) bytes of device scratch. */
+size_t pcrl_cosine_terms_ws_bytes(int nterms);
 int pcrl_cosine_terms_fwd(const void* const* x, const void* const* y, const float* w, const int* C, const int* group, int nterms, int rows,
-                          int ngroups, float eps, float* out, pcrl_stream_t stream);
+                          int ngroups, float eps, float* out, void* ws, size_t ws_bytes, pcrl_stream_t stream);
 int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y, void* const* dx, const float* w, const int* C, const int* group,
                           const int* first, int nterms, int rows, int ngroups, float eps, const float* dout, pcrl_stream_t stream);
 

@@ -327,25 +327,36 @@ int check_dims(const char* what, int N, int D, int H, int W, int Ci, int Co) {
 }
 
 // Second pass of the split-K convolution: y = bias + sum over splits, rounded to T; (sum, sum^2) per 128-row tile and channel
-// from the float sums, in the layout of the one-pass epilogue.  Block = (128-row tile, chunk of <= 64 channels): small M is
-// exactly where this runs, so the channel chunks are what spreads it over the chip.  Thread = 4 channels x a row group.
+// from the float sums, in the layout of the one-pass epilogue.  Block = (128-row tile, chunk of cw = Nc / gridDim.y <= 64
+// channels): small M is exactly where this runs, so the channel chunks (16 wide when the row tiles are few) are what spreads
+// it over the chip.  Thread = 4 channels x a row group; the loads of the splits are issued four at a time (the pass is
+// latency bound: one dependent 16-byte load per split and row was 55 us for 1536 rows, rocprofv3 r02c).
 template <typename T>
 __global__ void __launch_bounds__(256) igemm_splitk_finish_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
                                                                   T* __restrict__ y, float* __restrict__ stats, int64_t M, int Nc,
                                                                   int splits) {
   __shared__ float red[256 * 8];
-  const int cw = Nc < 64 ? Nc : 64, c0 = blockIdx.y * cw;
+  const int cw = Nc / (int)gridDim.y, c0 = blockIdx.y * cw;
   const int ncg = cw / 4, cg = threadIdx.x % ncg, rg = threadIdx.x / ncg, nrg = 256 / ncg;
   const int64_t m0 = (int64_t)blockIdx.x * PCRL_CONV_BM;
   const int col = c0 + cg * 4;
   f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f};
   if (bias) bv = *reinterpret_cast<const f32x4*>(bias + col);
   f32x4 s1 = f32x4{0.f, 0.f, 0.f, 0.f}, s2 = s1;
+  const int64_t zs = M * Nc;
   for (int r = rg; r < PCRL_CONV_BM; r += nrg) {
     const int64_t m = m0 + r;
     if (m >= M) break;
-    f32x4 v = bv;
-    for (int z = 0; z < splits; ++z) v += *reinterpret_cast<const f32x4*>(ws + ((int64_t)z * M + m) * Nc + col);
+    const float* src = ws + m * Nc + col;
+    f32x4 v0 = bv, v1 = f32x4{0.f, 0.f, 0.f, 0.f}, v2 = v1, v3 = v1;
+    int z = 0;
+    for (; z + 3 < splits; z += 4) {
+      const f32x4 t0 = *reinterpret_cast<const f32x4*>(src + (z + 0) * zs), t1 = *reinterpret_cast<const f32x4*>(src + (z + 1) * zs);
+      const f32x4 t2 = *reinterpret_cast<const f32x4*>(src + (z + 2) * zs), t3 = *reinterpret_cast<const f32x4*>(src + (z + 3) * zs);
+      v0 += t0; v1 += t1; v2 += t2; v3 += t3;
+    }
+    for (; z < splits; ++z) v0 += *reinterpret_cast<const f32x4*>(src + z * zs);
+    const f32x4 v = (v0 + v1) + (v2 + v3);
     T* dst = y + m * Nc + col;
 #pragma unroll
     for (int q = 0; q < 4; ++q) dst[q] = from_f<T>(v[q]);
@@ -442,7 +453,10 @@ static int conv3d_k3_fwd_impl(const void* x, const void* wp, const float* bias, 
     p.ws = static_cast<float*>(ws);
     p.steps_per_split = sp.steps_per_split;
     if (int e = dispatch<GEOM_CONV3>(p, sp.splits, dtype, as_stream(stream))) return e;
-    const dim3 grid((unsigned)((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM), (unsigned)(Co < 64 ? 1 : Co / 64));
+    const int64_t row_tiles = (M + PCRL_CONV_BM - 1) / PCRL_CONV_BM;
+    int cw = Co < 64 ? Co : 64;                                   // channel chunk of a block: narrower while the grid is small
+    while (cw > 16 && row_tiles * (Co / cw) < 512) cw >>= 1;
+    const dim3 grid((unsigned)row_tiles, (unsigned)(Co / cw));
     if (dtype == PCRL_BF16)
       hipLaunchKernelGGL(igemm_splitk_finish_kernel<bf16>, grid, dim3(256), 0, as_stream(stream), p.ws, bias, (bf16*)y, stats_partial, M, Co, sp.splits);
     else

@@ -364,43 +364,67 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 }
 
 // Second pass: out_ref[i][j][t] = sum_z ws[z][t][i][j] for j < Cv_out (padding columns dropped), fixed order over z.
-// Block = 32 consecutive (i,j) x all taps: a thread sums a few (t, ij) pairs over z with 128-byte coalesced reads, the
-// [t][ij] -> [ij][t] transposition goes through LDS, the stores are one contiguous run.  Requires Cv_out % 32 == 0 or
-// a tail guard (handled); taps <= 49.
+// Block = 16 consecutive (i,j) x all taps: a thread sums a few (t, ij) pairs over z (64-byte runs per tap), the [t][ij] -> [ij][t]
+// transposition goes through LDS, the stores are one contiguous run.  When a block has <= 128 (t, ij) pairs (1 or 8 taps) the
+// slabs are spread over 256 / pairs thread groups whose partial sums are combined in group order (the 512-slab partials of the
+// 1-channel layer: 44 -> 6 us).  taps <= 49.
+// [measured, r02d: a float4 / z-group form with 4-16 (i,j) per block was SLOWER (1.06 -> 1.85 ms per step): with 27 taps a wave then
+//  touches 64 different 128-byte lines for 1 KB of data; the pass is bound by line requests, not by load latency.]
 constexpr int RED_IJ = 16;
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                            int splits, int taps, int Cu, int Cv, int Cv_out) {
   __shared__ float tile[RED_IJ * 49];
+  __shared__ double part[256];
   const int64_t per = (int64_t)Cu * Cv;
   const int64_t n_out = (int64_t)Cu * Cv_out;
   const int64_t ij0 = (int64_t)blockIdx.x * RED_IJ;
   const int npairs = taps * RED_IJ;
-  for (int q = threadIdx.x; q < npairs; q += 256) {
+  const int zg = npairs <= 128 ? 256 / npairs : 1;
+  const int span = zg > 1 ? npairs * zg : npairs;
+  for (int q0 = threadIdx.x; q0 < span; q0 += 256) {
+    const int g = q0 / npairs, q = q0 - g * npairs;
     const int t = q / RED_IJ, l = q % RED_IJ;
     const int64_t ij = ij0 + l;
-    float s = 0.f;
+    double s = 0.0;
     if (ij < n_out) {
       const int i = (int)(ij / Cv_out), j = (int)(ij % Cv_out);
       const float* src = ws + (int64_t)t * per + (int64_t)i * Cv + j;
       const int64_t zs = (int64_t)taps * per;
       // four independent partial sums (a fixed tree, so still deterministic) keep 4+ loads in flight per thread
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      int z = 0;
-      for (; z + 3 < splits; z += 4) {
-        a0 += (double)src[(z + 0) * zs];
-        a1 += (double)src[(z + 1) * zs];
-        a2 += (double)src[(z + 2) * zs];
-        a3 += (double)src[(z + 3) * zs];
+      int z = g;
+      for (; z + 3 * zg < splits; z += 4 * zg) {
+        a0 += (double)src[(int64_t)(z + 0 * zg) * zs];
+        a1 += (double)src[(int64_t)(z + 1 * zg) * zs];
+        a2 += (double)src[(int64_t)(z + 2 * zg) * zs];
+        a3 += (double)src[(int64_t)(z + 3 * zg) * zs];
       }
-      for (; z < splits; ++z) a0 += (double)src[z * zs];
-      s = (float)((a0 + a1) + (a2 + a3));
+      for (; z < splits; z += zg) a0 += (double)src[(int64_t)z * zs];
+      s = (a0 + a1) + (a2 + a3);
     }
-    tile[l * taps + t] = s;
+    if (zg > 1) part[q0] = s;
+    else tile[l * taps + t] = (float)s;
+  }
+  if (zg > 1) {
+    __syncthreads();
+    if ((int)threadIdx.x < npairs) {
+      double s = part[threadIdx.x];
+      for (int k = 1; k < zg; ++k) s += part[k * npairs + threadIdx.x];
+      tile[(threadIdx.x % RED_IJ) * taps + threadIdx.x / RED_IJ] = (float)s;
+    }
   }
   __syncthreads();
   const int64_t base = ij0 * taps, lim = n_out * taps;
   for (int k = threadIdx.x; k < npairs; k += 256)
     if (base + k < lim) out[base + k] = tile[k];
+}
+
+// every weight-gradient path ends here
+int launch_wgrad_reduce(const float* ws, float* out, int splits, int taps, int Cu, int Cv, int Cv_out, hipStream_t stream) {
+  if (taps < 1 || taps > 49) return pcrl_fail(PCRL_EINVAL, "wgrad_reduce: %d taps", taps);
+  const int blocks = (int)(((int64_t)Cu * Cv_out + RED_IJ - 1) / RED_IJ);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, out, splits, taps, Cu, Cv, Cv_out);
+  return pcrl_check_launch("wgrad_reduce");
 }
 
 // Second pass of the 2D weight gradient: out_ref[co][ci][t] = sum_z ws[z][co][t * CiP + ci], ci < Ci_out (padding channels dropped).
@@ -798,9 +822,7 @@ int run_wgrad(const void* u, const void* v, float* dw_ref, void* ws, size_t ws_b
     return pcrl_fail(PCRL_EINVAL, "wgrad: bad dtype %d", dtype);
   }
   if (int e = pcrl_check_launch("wgrad")) return e;
-  const int blocks = (int)(((int64_t)Cu * Cv_out + RED_IJ - 1) / RED_IJ);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)ws, dw_ref, sp.splits, taps, Cu, Cv, Cv_out);
-  return pcrl_check_launch("wgrad_reduce");
+  return launch_wgrad_reduce((const float*)ws, dw_ref, sp.splits, taps, Cu, Cv, Cv_out, stream);
 }
 
 
@@ -829,9 +851,7 @@ int scalar_brick_launch(const void* act, const float* sfield, float* dw_ref, cha
   ScalarWgradParams p{(const bf16*)act, sfield, part, N, D, H, W, C, (int)nbricks, per, flip};
   hipLaunchKernelGGL(scalar_wgrad_brick_kernel, dim3((unsigned)blocks, (unsigned)((C + 63) / 64)), dim3(256), 0, stream, p);
   if (int e = pcrl_check_launch("scalar_wgrad_brick")) return e;
-  const int rblocks = (int)(((int64_t)C * 27 + RED_IJ - 1) / RED_IJ);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, stream, (const float*)part, dw_ref, blocks, 1, C, 32, 27);
-  return pcrl_check_launch("wgrad_reduce");
+  return launch_wgrad_reduce((const float*)part, dw_ref, blocks, 1, C, 32, 27, stream);
 }
 }  // namespace
 
@@ -871,9 +891,7 @@ extern "C" int pcrl_conv3d_k3_wgrad(const void* x, const void* dy, float* dw_ref
     const size_t need = (size_t)splits * 27 * Co * Ci * sizeof(float);
     if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv3d_k3_wgrad: workspace %zu < %zu", ws_bytes, need);
     if (int e = pcrl_wgrad_brick_launch(x, dy, (float*)ws, N, D, H, W, Ci, Co, as_stream(stream))) return e;
-    const int blocks = (int)(((int64_t)Co * Ci + RED_IJ - 1) / RED_IJ);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)ws, dw_ref, splits, 27, Co, Ci, Ci);
-    return pcrl_check_launch("wgrad_reduce");
+    return launch_wgrad_reduce((const float*)ws, dw_ref, splits, 27, Co, Ci, Ci, as_stream(stream));
   }
   return run_wgrad<WG_CONV3>(dy, x, dw_ref, ws, ws_bytes, Dims{N, D, H, W}, Co, Ci, 27, dtype, as_stream(stream));
 }
@@ -908,9 +926,7 @@ extern "C" int pcrl_convt3d_k2s2_wgrad(const void* x, const void* dy, float* dw_
     WgradParams p{x, dy, (float*)ws, Dims{N, D, H, W}, M, Ci, Co, 8, sp.chunk};
     hipLaunchKernelGGL(wgrad_up2_alltaps_kernel, dim3((unsigned)((Ci / 64) * (Co / 64)), (unsigned)sp.splits), dim3(256), LDS, as_stream(stream), p);
     if (int e = pcrl_check_launch("convt3d_k2s2_wgrad")) return e;
-    const int blocks = (int)(((int64_t)Ci * Co + RED_IJ - 1) / RED_IJ);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)ws, dw_ref, sp.splits, 8, Ci, Co, Co);
-    return pcrl_check_launch("wgrad_reduce");
+    return launch_wgrad_reduce((const float*)ws, dw_ref, sp.splits, 8, Ci, Co, Co, as_stream(stream));
   }
   return run_wgrad<WG_UP2>(x, dy, dw_ref, ws, ws_bytes, Dims{N, D, H, W}, Ci, Co, 8, dtype, as_stream(stream));
 }
@@ -1073,9 +1089,7 @@ extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, v
     const size_t need = (size_t)splits * 9 * CoP * CiP * sizeof(float);
     if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
     if (int e = pcrl_wgrad_brick2d_launch(x, dy, (float*)ws, N, Ho, Wo, CiP, CoP, up, as_stream(stream))) return e;
-    const int blocks = (int)(((int64_t)CoP * Ci_out + RED_IJ - 1) / RED_IJ);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float*)ws, dw_ref, splits, 9, CoP, CiP, Ci_out);
-    return pcrl_check_launch("wgrad_reduce");
+    return launch_wgrad_reduce((const float*)ws, dw_ref, splits, 9, CoP, CiP, Ci_out, as_stream(stream));
   }
   const Dims g{N, 1, Ho, Wo};
   const int64_t M = (int64_t)N * Ho * Wo;

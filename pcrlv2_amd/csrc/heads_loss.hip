@@ -72,32 +72,41 @@ __global__ void __launch_bounds__(256) bn1d_bwd_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------
 // Linear layers of the heads: one small LDS-tiled SGEMM, C[m][n] = sum_k A(m,k) * B(k,n) (+ bias[n]), operands addressed
 // through (row, col) strides so the three products of a Linear (y = x W^T, dx = dy W, dW = dy^T x) share the kernel.
-// 16x16 threads, 32x32 tile, K chunks of 64.  Sizes here: M, N, K <= 512.
+// 16x16 threads, 32x32 tile, K chunks of 64.  Sizes here: M, N, K <= 512: a handful of blocks, so a launch costs its chain of
+// global round trips.  The staging index therefore runs along whichever axis of an operand is contiguous (k for x W^T, the
+// row/column index for the transposed products: full 256-byte runs instead of 32 scattered words per wave), and chunk c+1 is
+// in flight in registers while chunk c is multiplied out of LDS.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) sgemm_small_kernel(const float* __restrict__ A, int64_t sam, int64_t sak,
                                                           const float* __restrict__ B, int64_t sbk, int64_t sbn,
                                                           const float* __restrict__ bias, float* __restrict__ Cm, int M, int N, int K) {
-  constexpr int KC = 64;   // K chunk: the loop is latency-bound (one global round trip per chunk), so few, fat chunks
+  constexpr int KC = 64;
   __shared__ float As[KC][33], Bs[KC][33];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const bool a_kfast = sak == 1, b_kfast = sbk == 1;   // block-uniform
   float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  float ra[KC / 8], rb[KC / 8];
+#define SG_LOAD(k0_)                                                                                   \
+  _Pragma("unroll") for (int h = 0; h < KC / 8; ++h) {                                                 \
+    const int idx = threadIdx.x + 256 * h;                                                             \
+    const int ka = a_kfast ? (idx & (KC - 1)) : (idx >> 5), ma = a_kfast ? (idx >> 6) : (idx & 31);    \
+    const int kb = b_kfast ? (idx & (KC - 1)) : (idx >> 5), nb = b_kfast ? (idx >> 6) : (idx & 31);    \
+    ra[h] = (m0 + ma < M && (k0_) + ka < K) ? A[(m0 + ma) * sam + ((k0_) + ka) * sak] : 0.f;           \
+    rb[h] = (n0 + nb < N && (k0_) + kb < K) ? B[((k0_) + kb) * sbk + (n0 + nb) * sbn] : 0.f;           \
+  }
+  SG_LOAD(0)
   for (int k0 = 0; k0 < K; k0 += KC) {
-    float ra[KC / 8], rb[KC / 8];
-#pragma unroll
-    for (int h = 0; h < KC / 8; ++h) {   // 256 threads load KC x 32 of A and of B, KC/8 elements each, all in flight together
-      const int idx = threadIdx.x + 256 * h, kk = idx >> 5, mm = idx & 31;
-      const int m = m0 + mm, n = n0 + mm, k = k0 + kk;
-      ra[h] = (m < M && k < K) ? A[m * sam + k * sak] : 0.f;
-      rb[h] = (n < N && k < K) ? B[k * sbk + n * sbn] : 0.f;
-    }
 #pragma unroll
     for (int h = 0; h < KC / 8; ++h) {
-      const int idx = threadIdx.x + 256 * h, kk = idx >> 5, mm = idx & 31;
-      As[kk][mm] = ra[h];
-      Bs[kk][mm] = rb[h];
+      const int idx = threadIdx.x + 256 * h;
+      const int ka = a_kfast ? (idx & (KC - 1)) : (idx >> 5), ma = a_kfast ? (idx >> 6) : (idx & 31);
+      const int kb = b_kfast ? (idx & (KC - 1)) : (idx >> 5), nb = b_kfast ? (idx >> 6) : (idx & 31);
+      As[ka][ma] = ra[h];
+      Bs[kb][nb] = rb[h];
     }
     __syncthreads();
+    if (k0 + KC < K) { SG_LOAD(k0 + KC) }
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
       const float a0 = As[kk][ty], a1 = As[kk][ty + 16], b0 = Bs[kk][tx], b1 = Bs[kk][tx + 16];
@@ -108,6 +117,7 @@ __global__ void __launch_bounds__(256) sgemm_small_kernel(const float* __restric
     }
     __syncthreads();
   }
+#undef SG_LOAD
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -298,10 +308,10 @@ __global__ void __launch_bounds__(256) cosine_bwd_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// All cosine terms of one training step in ONE launch (train_3d.py:119-134: the global pair and the twelve (global, local_i) pairs, two
+// All cosine terms of one training step in one call (train_3d.py:119-134: the global pair and the twelve (global, local_i) pairs, two
 // cosine means each = 26 terms over [rows, C_t] matrices at randomly drawn scales).  out[g] = sum over the terms of group g of
-// w_t * mean_r cos(x_t[r], y_t[r]); the gradient flows to the x operands only (the reference detaches y).  One block: a step has
-// 26 x 32 rows of <= 256 channels; separate launches (26 forward + 26 backward + ~150 elementwise kernels for the negations, halves,
+// w_t * mean_r cos(x_t[r], y_t[r]); the gradient flows to the x operands only (the reference detaches y).  A step has
+// 26 x 32 rows of <= 512 channels; separate launches (26 forward + 26 backward + ~150 elementwise kernels for the negations, halves,
 // sums and stacks) cost ~1 ms per step in launch latency.  Descriptors travel in the kernel arguments (<= 32 terms).
 // ---------------------------------------------------------------------------------------------
 constexpr int COS_MAX_TERMS = 32;
@@ -316,55 +326,65 @@ struct CosTerms {
   int n, rows, ngroups;
   float eps;
 };
-__global__ void __launch_bounds__(1024) cosine_terms_fwd_kernel(const CosTerms t, float* __restrict__ out) {
-  __shared__ double part[16][8];   // [wave][group]
+// Forward, launch 1 of 2: block k = term k (16 waves, a wave per row at a time) -> vals[k] = w_k * mean_r cos(x_k[r], y_k[r]).
+// One block for all terms walked them one after the other: 84 us of dependent loads for 26 terms (rocprofv3 r02c).
+__global__ void __launch_bounds__(1024) cosine_terms_fwd_kernel(const CosTerms t, double* __restrict__ vals) {
+  __shared__ double part[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  double acc[8];
-#pragma unroll
-  for (int g = 0; g < 8; ++g) acc[g] = 0.0;
-  for (int k = 0; k < t.n; ++k) {
-    const float* __restrict__ x = t.x[k];
-    const float* __restrict__ y = t.y[k];
-    const int C = t.C[k];
-    double s = 0.0;
-    for (int r = wid; r < t.rows; r += nw) {
-      float dot = 0.f, xx = 0.f, yy = 0.f;
-      for (int c = lane; c < C; c += 64) {
-        const float a = x[(int64_t)r * C + c], b = y[(int64_t)r * C + c];
-        dot += a * b;
-        xx += a * a;
-        yy += b * b;
-      }
-      dot = wave_sum(dot);
-      xx = wave_sum(xx);
-      yy = wave_sum(yy);
-      s += (double)(dot / (fmaxf(sqrtf(xx), t.eps) * fmaxf(sqrtf(yy), t.eps)));
+  const int k = blockIdx.x;
+  const float* __restrict__ x = t.x[k];
+  const float* __restrict__ y = t.y[k];
+  const int C = t.C[k];
+  double s = 0.0;
+  for (int r = wid; r < t.rows; r += nw) {
+    float dot = 0.f, xx = 0.f, yy = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float a = x[(int64_t)r * C + c], b = y[(int64_t)r * C + c];
+      dot += a * b;
+      xx += a * a;
+      yy += b * b;
     }
-    const int g = t.group[k];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-      if (q == g) acc[q] += s * (double)t.w[k] / (double)t.rows;
+    dot = wave_sum(dot);
+    xx = wave_sum(xx);
+    yy = wave_sum(yy);
+    s += (double)(dot / (fmaxf(sqrtf(xx), t.eps) * fmaxf(sqrtf(yy), t.eps)));
   }
-  if (lane == 0)
-    for (int g = 0; g < t.ngroups; ++g) part[wid][g] = acc[g];
+  if (lane == 0) part[wid] = s;
   __syncthreads();
-  if ((int)threadIdx.x < t.ngroups) {
+  if (threadIdx.x == 0) {
     double v = 0.0;
-    for (int w = 0; w < nw; ++w) v += part[w][threadIdx.x];   // fixed order
-    out[threadIdx.x] = (float)v;
+    for (int w = 0; w < nw; ++w) v += part[w];   // fixed order
+    vals[k] = v * (double)t.w[k] / (double)t.rows;
   }
 }
-// dx_t += dout[group_t] * w_t / rows * d cos(x, y) / dx, terms in order (block-wide barrier between terms: shared buffers are race-free
-// and the summation order is fixed).
-__global__ void __launch_bounds__(1024) cosine_terms_bwd_kernel(const CosTerms t, const float* __restrict__ dout) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  for (int k = 0; k < t.n; ++k) {
-    const float* __restrict__ x = t.x[k];
-    const float* __restrict__ y = t.y[k];
-    float* __restrict__ dx = t.dx[k];
-    const int C = t.C[k];
-    const float g = dout[t.group[k]] * t.w[k] / (float)t.rows;
-    for (int r = wid; r < t.rows; r += nw) {
+// launch 2 of 2: out[g] = sum of the terms of group g, in term order
+__global__ void __launch_bounds__(64) cosine_terms_sum_kernel(const CosTerms t, const double* __restrict__ vals, float* __restrict__ out) {
+  const int g = threadIdx.x;
+  if (g >= t.ngroups) return;
+  double v = 0.0;
+  for (int k = 0; k < t.n; ++k)
+    if (t.group[k] == g) v += vals[k];
+  out[g] = (float)v;
+}
+// Backward: dx_t = sum over the terms that share the buffer dx_t, in term order, of dout[group] * w / rows * d cos(x, y) / dx.
+// Block = (4 rows, term k): only the FIRST term of a buffer does work -- it walks the later terms with the same dx, keeps the
+// row's gradient in registers and stores it once (no read-modify-write, no ordering between blocks; the summation order is the
+// term order, as in the one-block form this replaces: 148 us -> a few us).
+__global__ void __launch_bounds__(256) cosine_terms_bwd_kernel(const CosTerms t, const float* __restrict__ dout) {
+  const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int k0 = blockIdx.y;
+  if (!t.first[k0] || r >= t.rows) return;
+  float* __restrict__ dx = t.dx[k0];
+  const int C = t.C[k0];
+  for (int cb = 0; cb < C; cb += 512) {
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int k = k0; k < t.n; ++k) {
+      if (t.dx[k] != dx) continue;
+      const float* __restrict__ x = t.x[k];
+      const float* __restrict__ y = t.y[k];
+      const float g = dout[t.group[k]] * t.w[k] / (float)t.rows;
       float dot = 0.f, xx = 0.f, yy = 0.f;
       for (int c = lane; c < C; c += 64) {
         const float a = x[(int64_t)r * C + c], b = y[(int64_t)r * C + c];
@@ -376,14 +396,21 @@ __global__ void __launch_bounds__(1024) cosine_terms_bwd_kernel(const CosTerms t
       xx = wave_sum(xx);
       yy = wave_sum(yy);
       const float nx = sqrtf(xx), ny = sqrtf(yy), nxc = fmaxf(nx, t.eps), nyc = fmaxf(ny, t.eps);
-      for (int c = lane; c < C; c += 64) {
-        float v = y[(int64_t)r * C + c] / (nxc * nyc);
-        if (nx > t.eps) v -= dot * x[(int64_t)r * C + c] / (nxc * nxc * nxc * nyc);
-        const int64_t i = (int64_t)r * C + c;
-        dx[i] = t.first[k] ? g * v : dx[i] + g * v;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = cb + q * 64 + lane;
+        if (c < C) {
+          float v = y[(int64_t)r * C + c] / (nxc * nyc);
+          if (nx > t.eps) v -= dot * x[(int64_t)r * C + c] / (nxc * nxc * nxc * nyc);
+          acc[q] += g * v;
+        }
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int c = cb + q * 64 + lane;
+      if (c < C) dx[(int64_t)r * C + c] = acc[q];
+    }
   }
 }
 
@@ -637,12 +664,15 @@ static int fill_cos_terms(CosTerms& t, const void* const* x, const void* const* 
   t.eps = eps;
   return PCRL_OK;
 }
+extern "C" size_t pcrl_cosine_terms_ws_bytes(int nterms) { return nterms > 0 ? (size_t)nterms * sizeof(double) : 0; }
 extern "C" int pcrl_cosine_terms_fwd(const void* const* x, const void* const* y, const float* w, const int* C, const int* group, int nterms, int rows,
-                                     int ngroups, float eps, float* out, pcrl_stream_t stream) {
+                                     int ngroups, float eps, float* out, void* ws, size_t ws_bytes, pcrl_stream_t stream) {
   CosTerms t;
   if (int e = fill_cos_terms(t, x, y, nullptr, w, C, group, nullptr, nterms, rows, ngroups, eps, "cosine_terms_fwd")) return e;
   PCRL_REQUIRE(out, "cosine_terms_fwd: null output");
-  hipLaunchKernelGGL(cosine_terms_fwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), t, out);
+  if (!ws || ws_bytes < pcrl_cosine_terms_ws_bytes(nterms)) return pcrl_fail(PCRL_EWORKSPACE, "cosine_terms_fwd: workspace too small");
+  hipLaunchKernelGGL(cosine_terms_fwd_kernel, dim3(nterms), dim3(1024), 0, as_stream(stream), t, (double*)ws);
+  hipLaunchKernelGGL(cosine_terms_sum_kernel, dim3(1), dim3(64), 0, as_stream(stream), t, (const double*)ws, out);
   return pcrl_check_launch("cosine_terms_fwd");
 }
 extern "C" int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y, void* const* dx, const float* w, const int* C, const int* group,
@@ -650,8 +680,14 @@ extern "C" int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y,
   CosTerms t;
   PCRL_REQUIRE(dx && first && dout, "cosine_terms_bwd: null pointer");
   if (int e = fill_cos_terms(t, x, y, dx, w, C, group, first, nterms, rows, ngroups, eps, "cosine_terms_bwd")) return e;
-  for (int k = 0; k < nterms; ++k) PCRL_REQUIRE(dx[k], "cosine_terms_bwd: term %d has no gradient buffer", k);
-  hipLaunchKernelGGL(cosine_terms_bwd_kernel, dim3(1), dim3(1024), 0, as_stream(stream), t, dout);
+  for (int k = 0; k < nterms; ++k) {
+    PCRL_REQUIRE(dx[k], "cosine_terms_bwd: term %d has no gradient buffer", k);
+    bool seen = false;   // `first` must mark exactly the first term of every buffer: the kernel keys its work on it
+    for (int j = 0; j < k; ++j) seen = seen || dx[j] == dx[k];
+    PCRL_REQUIRE((first[k] != 0) == !seen, "cosine_terms_bwd: first[%d] does not mark the first term of its gradient buffer", k);
+    for (int j = 0; j < k; ++j) PCRL_REQUIRE(dx[j] != dx[k] || C[j] == C[k], "cosine_terms_bwd: terms %d and %d share a buffer but not a width", j, k);
+  }
+  hipLaunchKernelGGL(cosine_terms_bwd_kernel, dim3((rows + 3) / 4, nterms), dim3(256), 0, as_stream(stream), t, dout);
   return pcrl_check_launch("cosine_terms_bwd");
 }
 

@@ -348,7 +348,10 @@ class CosineTermsFn(Function):
         w, C, grp = F32(*[float(s[4]) for s in spec]), I32(*[ts[s[0]].shape[1] for s in spec]), I32(*[int(s[5]) for s in spec])
         out = torch.empty(ngroups, dtype=torch.float32, device=ts[0].device)
         adr = ctypes.addressof
-        ops.lib().call("pcrl_cosine_terms_fwd", adr(x), adr(y), adr(w), adr(C), adr(grp), n, rows, ngroups, 1e-8, out, ops.stream_handle())
+        L = ops.lib()
+        nb = L.call("pcrl_cosine_terms_ws_bytes", n)
+        L.call("pcrl_cosine_terms_fwd", adr(x), adr(y), adr(w), adr(C), adr(grp), n, rows, ngroups, 1e-8, out, ops.workspace(nb, out.device), nb,
+               ops.stream_handle())
         ctx.ts, ctx.spec, ctx.rows, ctx.ngroups = ts, spec, rows, ngroups
         ctx.host = (x, y, w, C, grp)
         return out
