@@ -156,6 +156,18 @@ int pcrl_bn_bwd_finalize(const float* partial, int rows, int C, double count, co
 int pcrl_bn_act_bwd_apply(const void* da, const void* y, void* dy, const float* scale, const float* shift,
                           const float* k1, const float* kB, const float* kA,
                           int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
+/* The same two passes with a per-(sample, channel) term folded into the incoming gradient: da_eff[n][s][c] = da[n][s][c] + row_g[n][c] / S
+ * (M = N * S rows; da may be NULL: the term alone).  This is the global-average-pool branch of UpTransition.forward
+ * (pcrlv2_model_3d.py:67; autograd: adaptive_avg_pool3d_backward + the add of the two gradients of x) without materialising the
+ * broadcast (pcrl_gap_bwd).  Available when pcrl_bn_act_bwd_rowadd_ok(C, dtype) != 0 (C a multiple of the 16-byte vector that
+ * divides 256 vectors). */
+int64_t pcrl_bn_act_bwd_rowadd_ok(int C, int dtype);   /* 1 / 0 */
+int pcrl_bn_act_bwd_reduce_rowadd(const void* da, const float* row_g, int N, int64_t S, const void* y, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd, float* partial,
+                                  int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
+int pcrl_bn_act_bwd_apply_rowadd(const void* da, const float* row_g, int N, int64_t S, const void* y, void* dy, const float* scale,
+                                 const float* shift, const float* k1, const float* kB, const float* kA,
+                                 int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * MaxPool3d(2) -- aten::max_pool3d_with_indices(+backward) at pcrlv2_model_3d.py:100,115-117.

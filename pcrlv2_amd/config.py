@@ -34,3 +34,8 @@ DIRECT_PARAM_GRADS = os.environ.get("PCRL_AUTOGRAD_PARAM_GRADS", "0") != "1"
 _ws = os.environ.get("PCRL_WGRAD_STREAM", "")
 WGRAD_SIDE_STREAM_3D = _ws == "1"
 WGRAD_SIDE_STREAM_2D = _ws != "0"
+
+# The global-average-pool branch of UpTransition (pcrlv2_model_3d.py:67) sends d_g[n][c] / S back to every voxel of a1: folded into the
+# two passes of ops.1's BatchNorm backward (pcrl_bn_act_bwd_*_rowadd) instead of materialised (pcrl_gap_bwd).  PCRL_FOLD_GAP_GRAD=0:
+# materialise (A/B switch; the folded form skips one bf16 rounding of the summed gradient).
+FOLD_GAP_GRAD = os.environ.get("PCRL_FOLD_GAP_GRAD", "1") != "0"

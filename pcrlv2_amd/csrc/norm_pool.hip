@@ -178,30 +178,57 @@ __global__ void __launch_bounds__(256) bn_apply_rc_kernel(const T* __restrict__ 
   else bn_apply_rc_kernel_body<T, ACT, false>(y, a, scale, shift, M, C);
 }
 
+// The gradient that enters the BatchNorm backward may carry a per-(sample, channel) term on top of (or instead of) the tensor `da`:
+// the global-average-pool branch of UpTransition (pcrlv2_model_3d.py:67: d a1 += dg[n][c] / S).  `RowAdd` folds it into both passes, so
+// the broadcast is never materialised (pcrl_gap_bwd: one read + one write of the full-resolution gradient, and a write + two reads
+// of a tensor that is ONLY the broadcast on the passes whose reconstruction output is unused).  da == nullptr: the term alone.
+struct RowAdd {
+  const float* g;   // [N][C] or null
+  int64_t S;        // rows per sample
+  float inv_s;
+};
+
 template <typename T, int ACT, bool NT>
 __device__ __forceinline__ void bn_bwd_apply_rc_kernel_body(const T* __restrict__ da, const T* __restrict__ y, T* __restrict__ dy,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ k1, const float* __restrict__ kB,
-                                                              const float* __restrict__ kA, int64_t M, int C) {
+                                                              const float* __restrict__ kA, int64_t M, int C, RowAdd ra) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const int nvec = C / VEC, cv = threadIdx.x % nvec, slot = threadIdx.x / nvec, nslots = 256 / nvec;
-  float sc[VEC], sh[VEC], c1[VEC], cB[VEC], cA[VEC];
+  float sc[VEC], sh[VEC], c1[VEC], cB[VEC], cA[VEC], add[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     const int c = cv * VEC + j;
     sc[j] = scale[c]; sh[j] = shift[c]; c1[j] = k1[c]; cB[j] = kB[c]; cA[j] = kA[c];
+    add[j] = 0.f;
   }
   const int64_t stride = (int64_t)gridDim.x * nslots;
+  const int64_t r0 = (int64_t)blockIdx.x * nslots + slot;
+  // sample of the row, kept incrementally (the stride is fixed): no division per row
+  int64_t n = 0, rem = 0, n_have = -1;
+  const int64_t dn = ra.g ? stride / ra.S : 0, drem = ra.g ? stride % ra.S : 0;
+  if (ra.g) { n = r0 / ra.S; rem = r0 % ra.S; }
 #pragma unroll 4
-  for (int64_t r = (int64_t)blockIdx.x * nslots + slot; r < M; r += stride) {
+  for (int64_t r = r0; r < M; r += stride) {
     const int64_t off = (r * nvec + cv) * VEC;
-    const Vec16<T> g = ld16_sel<NT>(da + off);
+    Vec16<T> g;
+    if (da) g = ld16_sel<NT>(da + off);
     const Vec16<T> v = ld16_sel<NT>(y + off);
+    if (ra.g) {
+      if (n != n_have) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) add[j] = ra.g[n * C + cv * VEC + j] * ra.inv_s;
+        n_have = n;
+      }
+      n += dn; rem += drem;
+      if (rem >= ra.S) { rem -= ra.S; ++n; }
+    }
     Vec16<T> o;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float yv = to_f(v.v[j]);
-      const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], to_f(g.v[j]));
+      const float gin = (da ? to_f(g.v[j]) : 0.f) + add[j];
+      const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], gin);
       o.v[j] = from_f<T>(c1[j] * dz + cB[j] * yv + cA[j]);
     }
     st16_sel<NT>(dy + off, o);
@@ -212,9 +239,9 @@ template <typename T, int ACT>
 __global__ void __launch_bounds__(256) bn_bwd_apply_rc_kernel(const T* __restrict__ da, const T* __restrict__ y, T* __restrict__ dy,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ k1, const float* __restrict__ kB,
-                                                              const float* __restrict__ kA, int64_t M, int C, bool nt) {
-  if (nt) bn_bwd_apply_rc_kernel_body<T, ACT, true>(da, y, dy, scale, shift, k1, kB, kA, M, C);
-  else bn_bwd_apply_rc_kernel_body<T, ACT, false>(da, y, dy, scale, shift, k1, kB, kA, M, C);
+                                                              const float* __restrict__ kA, int64_t M, int C, bool nt, RowAdd ra) {
+  if (nt) bn_bwd_apply_rc_kernel_body<T, ACT, true>(da, y, dy, scale, shift, k1, kB, kA, M, C, ra);
+  else bn_bwd_apply_rc_kernel_body<T, ACT, false>(da, y, dy, scale, shift, k1, kB, kA, M, C, ra);
 }
 
 // First-stage reduction of the backward: per 1024-row tile, per channel: (sum dz, sum dz*xhat).
@@ -223,7 +250,7 @@ template <typename T, int ACT, bool NT>
 __device__ __forceinline__ void bn_bwd_reduce_kernel_body(const T* __restrict__ da, const T* __restrict__ y,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ partial, int64_t M, int C, int tile_rows) {
+                                                            float* __restrict__ partial, int64_t M, int C, int tile_rows, RowAdd ra) {
   constexpr int VEC = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C'][2], C' = max(C, VEC)
   const int tid = threadIdx.x;
@@ -234,45 +261,67 @@ __device__ __forceinline__ void bn_bwd_reduce_kernel_body(const T* __restrict__ 
   const int tile = (C == 1) ? tile_rows / VEC : tile_rows;
   const int64_t rbeg = (int64_t)blockIdx.x * tile;
   const int64_t rend = (rbeg + tile < rows_total) ? rbeg + tile : rows_total;
-  float s1[VEC], s2[VEC], sc[VEC], sh[VEC], mu[VEC], rs[VEC];
+  float s1[VEC], s2[VEC], sc[VEC], sh[VEC], mu[VEC], rs[VEC], add[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
     const int c = (C == 1) ? 0 : cv * VEC + j;
     s1[j] = 0.f; s2[j] = 0.f;
     sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
+    add[j] = 0.f;
+  }
+  // row term (C > 1 only, checked by the host): one sample per tile when the tile divides the sample, else looked up per row
+  const bool ra_tile = ra.g && ra.S % tile == 0;
+  int64_t n_have = -1;
+  if (ra_tile) {
+    const int64_t n = rbeg / ra.S;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) add[j] = ra.g[n * C + cv * VEC + j] * ra.inv_s;
+  }
+#define BR_ROWADD(r_)                                                                            \
+  if (ra.g && !ra_tile) {                                                                        \
+    const int64_t n_ = (r_) / ra.S;                                                              \
+    if (n_ != n_have) {                                                                          \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) add[j] = ra.g[n_ * C + cv * VEC + j] * ra.inv_s; \
+      n_have = n_;                                                                               \
+    }                                                                                            \
   }
   // four rows in flight per thread (eight 16-byte loads): the tile is streamed once and nothing else hides HBM latency
   int64_t r = rbeg + slot;
-  for (; r + 3 * (int64_t)nslots < rend; r += 4 * (int64_t)nslots) {
-    Vec16<T> g[4], v[4];
+  if (!ra.g || ra_tile) {
+    for (; r + 3 * (int64_t)nslots < rend; r += 4 * (int64_t)nslots) {
+      Vec16<T> g[4], v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t off = ((r + u * (int64_t)nslots) * nvec + cv) * VEC;
-      g[u] = ld16_sel<NT>(da + off);
-      v[u] = ld16_sel<NT>(y + off);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        const float yv = to_f(v[u].v[j]);
-        const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], to_f(g[u].v[j]));
-        s1[j] += dz;
-        s2[j] += dz * (yv - mu[j]) * rs[j];
+      for (int u = 0; u < 4; ++u) {
+        const int64_t off = ((r + u * (int64_t)nslots) * nvec + cv) * VEC;
+        if (da) g[u] = ld16_sel<NT>(da + off);
+        v[u] = ld16_sel<NT>(y + off);
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float yv = to_f(v[u].v[j]);
+          const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], (da ? to_f(g[u].v[j]) : 0.f) + add[j]);
+          s1[j] += dz;
+          s2[j] += dz * (yv - mu[j]) * rs[j];
+        }
+    }
   }
   for (; r < rend; r += nslots) {
     const int64_t off = (r * nvec + cv) * VEC;
-    const Vec16<T> g = ld16_sel<NT>(da + off);
+    Vec16<T> g;
+    if (da) g = ld16_sel<NT>(da + off);
     const Vec16<T> v = ld16_sel<NT>(y + off);
+    BR_ROWADD(r)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float yv = to_f(v.v[j]);
-      const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], to_f(g.v[j]));
+      const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], (da ? to_f(g.v[j]) : 0.f) + add[j]);
       s1[j] += dz;
       s2[j] += dz * (yv - mu[j]) * rs[j];
     }
   }
+#undef BR_ROWADD
   const int Cp = nvec * VEC;
 #pragma unroll
   for (int j = 0; j < VEC; ++j) {
@@ -302,9 +351,9 @@ template <typename T, int ACT>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const T* __restrict__ da, const T* __restrict__ y,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            float* __restrict__ partial, int64_t M, int C, int tile_rows, bool nt) {
-  if (nt) bn_bwd_reduce_kernel_body<T, ACT, true>(da, y, scale, shift, mean, rstd, partial, M, C, tile_rows);
-  else bn_bwd_reduce_kernel_body<T, ACT, false>(da, y, scale, shift, mean, rstd, partial, M, C, tile_rows);
+                                                            float* __restrict__ partial, int64_t M, int C, int tile_rows, bool nt, RowAdd ra) {
+  if (nt) bn_bwd_reduce_kernel_body<T, ACT, true>(da, y, scale, shift, mean, rstd, partial, M, C, tile_rows, ra);
+  else bn_bwd_reduce_kernel_body<T, ACT, false>(da, y, scale, shift, mean, rstd, partial, M, C, tile_rows, ra);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -537,11 +586,16 @@ extern "C" int64_t pcrl_bn_bwd_partial_rows(int64_t M) {
   return (M + t - 1) / t;
 }
 
-extern "C" int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, const float* shift,
-                                      const float* mean, const float* rstd, float* partial,
-                                      int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+static bool rowadd_ok(int C, int dtype) {
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  return C > 1 && C % vec == 0 && (C / vec) <= 256 && 256 % (C / vec) == 0;
+}
+extern "C" int64_t pcrl_bn_act_bwd_rowadd_ok(int C, int dtype) { return rowadd_ok(C, dtype) ? 1 : 0; }
+
+static int bn_bwd_reduce_impl(const void* da, const void* y, const float* scale, const float* shift, const float* mean, const float* rstd,
+                              float* partial, int64_t M, int C, int act, int dtype, RowAdd ra, pcrl_stream_t stream) {
   if (int e = check_tilevec("bn_act_bwd_reduce", C, dtype, true)) return e;
-  PCRL_REQUIRE(da && y && scale && shift && mean && rstd && partial, "bn_act_bwd_reduce: null pointer");
+  PCRL_REQUIRE((da || ra.g) && y && scale && shift && mean && rstd && partial, "bn_act_bwd_reduce: null pointer");
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
   PCRL_REQUIRE(C != 1 || M % vec == 0, "bn_act_bwd_reduce: M must be a multiple of %d for C == 1", vec);
   const dim3 grid((unsigned)pcrl_bn_bwd_partial_rows(M));
@@ -549,12 +603,31 @@ extern "C" int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float
   const size_t lds = (size_t)(256 / nvec) * (nvec * vec) * 2 * sizeof(float);
   if (dtype == PCRL_BF16) {
     using T = bf16;
-    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M), pcrl_streaming(M * C * (int64_t)sizeof(T)));
+    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M), pcrl_streaming(M * C * (int64_t)sizeof(T)), ra);
   } else {
     using T = float;
-    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M), pcrl_streaming(M * C * (int64_t)sizeof(T)));
+    DISPATCH_ACT_T(bn_bwd_reduce_kernel, grid, lds, (const T*)da, (const T*)y, scale, shift, mean, rstd, partial, M, C, bn_bwd_tile_rows(M), pcrl_streaming(M * C * (int64_t)sizeof(T)), ra);
   }
   return pcrl_check_launch("bn_act_bwd_reduce");
+}
+extern "C" int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, const float* shift,
+                                      const float* mean, const float* rstd, float* partial,
+                                      int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(da, "bn_act_bwd_reduce: null pointer");
+  return bn_bwd_reduce_impl(da, y, scale, shift, mean, rstd, partial, M, C, act, dtype, RowAdd{nullptr, 1, 0.f}, stream);
+}
+static int rowadd_check(const char* what, const float* row_g, int N, int64_t S, int64_t M, int C, int dtype, RowAdd& ra) {
+  PCRL_REQUIRE(row_g && N > 0 && S > 0 && (int64_t)N * S == M, "%s: the row term needs N * S == M (N=%d S=%lld M=%lld)", what, N, (long long)S, (long long)M);
+  PCRL_REQUIRE(rowadd_ok(C, dtype), "%s: the row term is not available for C=%d (pcrl_bn_act_bwd_rowadd_ok)", what, C);
+  ra = RowAdd{row_g, S, (float)(1.0 / (double)S)};
+  return PCRL_OK;
+}
+extern "C" int pcrl_bn_act_bwd_reduce_rowadd(const void* da, const float* row_g, int N, int64_t S, const void* y, const float* scale,
+                                             const float* shift, const float* mean, const float* rstd, float* partial,
+                                             int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+  RowAdd ra;
+  if (int e = rowadd_check("bn_act_bwd_reduce_rowadd", row_g, N, S, M, C, dtype, ra)) return e;
+  return bn_bwd_reduce_impl(da, y, scale, shift, mean, rstd, partial, M, C, act, dtype, ra, stream);
 }
 
 extern "C" int pcrl_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* mean,
@@ -567,27 +640,41 @@ extern "C" int pcrl_bn_bwd_finalize(const float* partial, int rows, int C, doubl
   return pcrl_check_launch("bn_bwd_finalize");
 }
 
-extern "C" int pcrl_bn_act_bwd_apply(const void* da, const void* y, void* dy, const float* scale, const float* shift,
-                                     const float* k1, const float* kB, const float* kA,
-                                     int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+static int bn_bwd_apply_impl(const void* da, const void* y, void* dy, const float* scale, const float* shift,
+                             const float* k1, const float* kB, const float* kA,
+                             int64_t M, int C, int act, int dtype, RowAdd ra, pcrl_stream_t stream) {
   if (int e = check_vec("bn_act_bwd_apply", C, dtype, true)) return e;
-  PCRL_REQUIRE(da && y && dy && scale && shift && k1 && kB && kA, "bn_act_bwd_apply: null pointer");
+  PCRL_REQUIRE((da || ra.g) && y && dy && scale && shift && k1 && kB && kA, "bn_act_bwd_apply: null pointer");
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
   PCRL_REQUIRE((M * C) % vec == 0, "bn_act_bwd_apply: M*C must be a multiple of %d", vec);
   const int64_t nvec = M * C / vec;
   const dim3 grid(grid_for(nvec));
   const bool rc = C % vec == 0 && (C / vec) <= 256 && 256 % (C / vec) == 0;
+  PCRL_REQUIRE(rc || !ra.g, "bn_act_bwd_apply: the row term needs the channel-vector kernel (C=%d)", C);
   const dim3 grid_rc(rc_grid(M, C / (C % vec == 0 ? vec : 1)));
   if (dtype == PCRL_BF16) {
     using T = bf16;
-    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, pcrl_streaming(M * C * (int64_t)sizeof(T)));
+    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, pcrl_streaming(M * C * (int64_t)sizeof(T)), ra);
     else DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
   } else {
     using T = float;
-    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, pcrl_streaming(M * C * (int64_t)sizeof(T)));
+    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, pcrl_streaming(M * C * (int64_t)sizeof(T)), ra);
     else DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
   }
   return pcrl_check_launch("bn_act_bwd_apply");
+}
+extern "C" int pcrl_bn_act_bwd_apply(const void* da, const void* y, void* dy, const float* scale, const float* shift,
+                                     const float* k1, const float* kB, const float* kA,
+                                     int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(da, "bn_act_bwd_apply: null pointer");
+  return bn_bwd_apply_impl(da, y, dy, scale, shift, k1, kB, kA, M, C, act, dtype, RowAdd{nullptr, 1, 0.f}, stream);
+}
+extern "C" int pcrl_bn_act_bwd_apply_rowadd(const void* da, const float* row_g, int N, int64_t S, const void* y, void* dy, const float* scale,
+                                            const float* shift, const float* k1, const float* kB, const float* kA,
+                                            int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+  RowAdd ra;
+  if (int e = rowadd_check("bn_act_bwd_apply_rowadd", row_g, N, S, M, C, dtype, ra)) return e;
+  return bn_bwd_apply_impl(da, y, dy, scale, shift, k1, kB, kA, M, C, act, dtype, ra, stream);
 }
 
 extern "C" int pcrl_maxpool3d_2_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, pcrl_stream_t stream) {

@@ -223,6 +223,7 @@ class UpStageFn(Function):
         g, m_pro, r_pro, h0, h1, m_h, r_h = ctx.heads
         l0, l1, ld = mod.ops[0], mod.ops[1], mod.deep_supervision_head
         grads = [None] * n_in
+        row_g = None
 
         # ---- gradient w.r.t. a1 (output of ops.1): up to three sources, combined by our kernels ----
         d_a1 = _act_grad(d_out, dt) if d_out is not None else None
@@ -237,14 +238,17 @@ class UpStageFn(Function):
                 grads[13], grads[14], grads[15], grads[16], grads[17], grads[18] = g_p0w, g_p0b, g_p1g, g_p1b, g_p3w, g_p3b
             d_g, g_bng, g_bnb = ops.bn1d_backward(d_xpro, g, x_pro, bn_g, m_pro, r_pro, relu=False)
             grads[11], grads[12] = g_bng, g_bnb
-            d_a1 = ops.gap_backward(d_g, a1, d_a1, dt)
+            if config.FOLD_GAP_GRAD and ctx.sv1.gn is None and ops.bn_rowadd_ok(a1.shape[1], dt):
+                row_g = d_g        # d a1 += d_g[n][c] / S: folded into the BatchNorm backward of ops.1, never materialised
+            else:
+                d_a1 = ops.gap_backward(d_g, a1, d_a1, dt)
         # deep-supervision head (pcrlv2_model_3d.py:60,71)
         if d_mask is not None:
             dx_ds, g_dw, g_db, g_dg, g_dbe = ops.luconv_backward(ctx.svd, d_mask, dsw, dsg, ld._packed, dt, need_dx=True, dx_add=d_a1)
             d_a1 = dx_ds
             grads[19], grads[20], grads[21], grads[22] = g_dw, g_db, g_dg, g_dbe
         # ---- ops.1, ops.0 ----
-        d_a0, gw1, gb1, gg1, gbe1 = ops.luconv_backward(ctx.sv1, d_a1, w1, g1, l1._packed, dt, need_dx=True)
+        d_a0, gw1, gb1, gg1, gbe1 = ops.luconv_backward(ctx.sv1, d_a1, w1, g1, l1._packed, dt, need_dx=True, da_row_g=row_g)
         grads[7], grads[8], grads[9], grads[10] = gw1, gb1, gg1, gbe1
         g_upb = torch.empty(up_w.shape[1], dtype=torch.float32, device=d_a0.device)
         d_up, gw0, gb0, gg0, gbe0 = ops.luconv_backward(ctx.sv0, d_a0, w0, g0, l0._packed, dt, need_dx=True, dx_colsum=g_upb)

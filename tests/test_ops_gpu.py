@@ -407,6 +407,47 @@ def test_batchnorm_act(shape, act, dt):
     check(dbeta, br.grad, dt, "bn dbeta", out_rounded=False, f32_tol=1e-4)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("with_da", [True, False])
+@pytest.mark.parametrize("shape", [(3, 8, 8, 16, 64), (2, 4, 4, 4, 256), (5, 2, 2, 2, 32), (2, 6, 5, 7, 32)])
+def test_batchnorm_backward_with_global_average_pool_branch_folded_in(shape, with_da, dt):
+    """UpTransition.forward (pcrlv2_model_3d.py:64-70): a1 = relu(bn(conv)) feeds the next stage AND adaptive_avg_pool3d.  autograd's
+    gradient of a1 is d_out + d_g[n][c] / S; pcrl_bn_act_bwd_*_rowadd takes the pool branch as a [N][C] term inside both passes of the
+    BatchNorm backward (d_out may be absent: passes whose reconstruction output is unused).  Reference: torch float64 autograd of
+    relu(batch_norm(y)) with gradients arriving through both consumers.  (tile divides the sample / several samples per tile / rows
+    that are no multiple of anything all occur in the shapes.)"""
+    N, D, H, W, C = shape
+    S, M = D * H * W, N * D * H * W
+    assert ops.bn_rowadd_ok(C, dt)
+    y = rnd(N, C, D, H, W, seed=1, scale=2.0) + rnd(1, C, 1, 1, 1, seed=9)
+    gamma, beta = 1 + 0.3 * rnd(C, seed=2), 0.3 * rnd(C, seed=3)
+    yq = q(y, dt).requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a = torch.relu(F.batch_norm(yq, None, None, gr, br, training=True, eps=1e-5))
+    da = q(rnd(N, C, D, H, W, seed=4), dt)
+    dg = rnd(N, C, seed=5, scale=float(S) ** 0.5).float().double()     # float32 on the device: use the same values here
+    loss = (a.mean(dim=(2, 3, 4)) * dg).sum()
+    if with_da:
+        loss = loss + (a * da).sum()
+    loss.backward()
+    ya = act_dev(y, dt)
+    flat = back(ya).permute(0, 2, 3, 4, 1).reshape(M, C)
+    rows = (M + CONV_BM - 1) // CONV_BM
+    fp = torch.cat([flat, torch.zeros(rows * CONV_BM - M, C, dtype=torch.float64)]).view(rows, CONV_BM, C)
+    part = torch.stack([fp.sum(1), (fp * fp).sum(1)], dim=-1).float().to(DEV).contiguous()
+    g32, b32 = gamma.float().to(DEV), beta.float().to(DEV)
+    mean, rstd, scale, shift = ops.bn_finalize(part.view(-1), rows, C, M, g32, b32, torch.zeros(C, device=DEV), torch.ones(C, device=DEV))
+    dy, dgam, dbeta = ops.bn_act_backward(act_dev(da, dt) if with_da else None, ya, g32, mean, rstd, scale, shift, M, C, ACT_RELU, dt,
+                                          row_g=dg.float().to(DEV).contiguous())
+    check(dy, yq.grad, dt, "bn bwd dx (row term)")
+    check(dgam, gr.grad, dt, "bn dgamma (row term)", out_rounded=False, f32_tol=1e-4)
+    check(dbeta, br.grad, dt, "bn dbeta (row term)", out_rounded=False, f32_tol=1e-4)
+    # and the materialised form it replaces: same result up to the one bf16 rounding of the materialised sum
+    dsum = ops.gap_backward(dg.float().to(DEV).contiguous(), ya, act_dev(da, dt) if with_da else None, dt)
+    dy2, dgam2, dbeta2 = ops.bn_act_backward(dsum, ya, g32, mean, rstd, scale, shift, M, C, ACT_RELU, dt)
+    check(dy, back(dy2), dt, "row term vs materialised", bf_tol=2e-2)
+
+
 def test_batchnorm_one_channel_sigmoid():
     N, D, H, W = 2, 8, 8, 4
     M = N * D * H * W
