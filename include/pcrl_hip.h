@@ -150,6 +150,21 @@ int64_t pcrl_bn_bwd_partial_rows(int64_t M);
 int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, const float* shift,
                            const float* mean, const float* rstd, float* partial,
                            int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
+/* The two passes for a LUConv whose activation is consumed through nn.MaxPool3d(2) ONLY (pcrlv2_model_3d.py:115-117: the second LUConv
+ * of an encoder stage; the skip tensors are never used): max_pool3d_backward folded in.  dp: dtype [N][D/2][H/2][W/2][C] gradient of the
+ * POOLED tensor; y: dtype [N][D][H][W][C] the layer's pre-normalisation output.  The activation is recomputed from y exactly as the
+ * forward stored it; the first maximum of a window in scan order (d, h, w) receives the gradient, NaN wins (aten's rule).  The
+ * full-resolution gradient of the activation is never materialised.  Available when pcrl_bn_act_bwd_pool_ok() != 0 (even D, H, W and
+ * pcrl_bn_act_bwd_rowadd_ok(C, dtype)); partial: [pcrl_bn_act_bwd_pool_partial_rows(N, D, H, W)][C][2] -> pcrl_bn_bwd_finalize with
+ * count = N*D*H*W. */
+int64_t pcrl_bn_act_bwd_pool_ok(int D, int H, int W, int C, int dtype);   /* 1 / 0 */
+int64_t pcrl_bn_act_bwd_pool_partial_rows(int N, int D, int H, int W);
+int pcrl_bn_act_bwd_reduce_pool(const void* dp, const void* y, const float* scale, const float* shift, const float* mean,
+                                const float* rstd, float* partial, int N, int D, int H, int W, int C, int act, int dtype,
+                                pcrl_stream_t stream);
+int pcrl_bn_act_bwd_apply_pool(const void* dp, const void* y, void* dy, const float* scale, const float* shift, const float* k1,
+                               const float* kB, const float* kA, int N, int D, int H, int W, int C, int act, int dtype,
+                               pcrl_stream_t stream);
 int pcrl_bn_bwd_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* mean,
                          const float* rstd, float* dgamma, float* dbeta, float* k1, float* kB, float* kA,
                          pcrl_stream_t stream);

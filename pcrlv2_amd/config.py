@@ -39,3 +39,8 @@ WGRAD_SIDE_STREAM_2D = _ws != "0"
 # two passes of ops.1's BatchNorm backward (pcrl_bn_act_bwd_*_rowadd) instead of materialised (pcrl_gap_bwd).  PCRL_FOLD_GAP_GRAD=0:
 # materialise (A/B switch; the folded form skips one bf16 rounding of the summed gradient).
 FOLD_GAP_GRAD = os.environ.get("PCRL_FOLD_GAP_GRAD", "1") != "0"
+
+# The second LUConv of an encoder stage and the MaxPool3d(2) behind it run as one autograd node whose backward folds
+# max_pool3d_backward into the BatchNorm backward passes (functions.LUConvPoolFn, pcrl_bn_act_bwd_*_pool).  PCRL_FOLD_POOL_GRAD=0: the
+# separate nodes (A/B switch).
+FOLD_POOL_GRAD = os.environ.get("PCRL_FOLD_POOL_GRAD", "1") != "0"

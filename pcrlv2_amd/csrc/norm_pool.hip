@@ -501,6 +501,146 @@ __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// BatchNorm backward of a LUConv whose activation a = act(bn(y)) is consumed through MaxPool3d(2) only (the second LUConv of an
+// encoder stage: pcrlv2_model_3d.py:114-117, the skip tensors are never used).  autograd runs max_pool3d_backward
+// (read a, write the full-resolution gradient), then the two BatchNorm passes read that gradient and y again: 7 full-resolution
+// tensor passes.  Here thread = (pooled voxel, channel vector): the eight y vectors of the window are loaded, a is RECOMPUTED from
+// them exactly as the forward stored it (same expression, same rounding), the first maximum in scan order takes the pooled
+// gradient (max_pool3d_backward's rule; NaN wins like in aten), and the passes use that directly -- the full-resolution gradient
+// is never written or read: 3 full-resolution passes (y twice, dy once) plus the pooled gradient.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int ACT, bool NT>
+__device__ __forceinline__ void pool_window(const T* __restrict__ y, const Dims& g, int C, int cv, int64_t pv, Vec16<T> (&v)[8], int64_t (&rows)[8]) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const Dims go{g.N, g.D / 2, g.H / 2, g.W / 2};
+  int n, d, h, w;
+  decode_voxel(pv, go, n, d, h, w);
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    rows[t] = (((int64_t)n * g.D + 2 * d + (t >> 2)) * g.H + 2 * h + ((t >> 1) & 1)) * g.W + 2 * w + (t & 1);
+    v[t] = ld16_sel<NT>(y + rows[t] * C + cv * VEC);
+  }
+}
+// channel j of the window: -> index of the first maximum of a = round_T(act(sc * y + sh)), and dz of that element for pooled gradient gp
+template <typename T, int ACT>
+__device__ __forceinline__ int pool_argmax(const Vec16<T> (&v)[8], int j, float sc, float sh, float gp, float& dz, float& ybest) {
+  float m = -INFINITY, zb = 0.f;
+  int arg = 0;
+  ybest = 0.f;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const float yv = to_f(v[t].v[j]);
+    const float z = sc * yv + sh;
+    const float a = to_f(from_f<T>(act_fwd<ACT>(z)));
+    if (a > m || a != a) { m = a; arg = t; zb = z; ybest = yv; }
+  }
+  dz = act_bwd<ACT>(zb, gp);
+  return arg;
+}
+
+template <typename T, int ACT, bool NT>
+__device__ __forceinline__ void bn_bwd_reduce_pool_body(const T* __restrict__ dp, const T* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ partial, Dims g, int C, int tile_p) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C][2]
+  const int tid = threadIdx.x;
+  const int nvec = C / VEC, cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
+  const int64_t Mp = (int64_t)g.N * (g.D / 2) * (g.H / 2) * (g.W / 2);
+  const int64_t pbeg = (int64_t)blockIdx.x * tile_p;
+  const int64_t pend = (pbeg + tile_p < Mp) ? pbeg + tile_p : Mp;
+  float s1[VEC], s2[VEC], sc[VEC], sh[VEC], mu[VEC], rs[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int c = cv * VEC + j;
+    s1[j] = 0.f; s2[j] = 0.f;
+    sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; rs[j] = rstd[c];
+  }
+  for (int64_t pv = pbeg + slot; pv < pend; pv += nslots) {
+    Vec16<T> v[8];
+    int64_t rows[8];
+    pool_window<T, ACT, NT>(y, g, C, cv, pv, v, rows);
+    const Vec16<T> gp = ld16(dp + (pv * nvec + cv) * VEC);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float dz, yb;
+      pool_argmax<T, ACT>(v, j, sc[j], sh[j], to_f(gp.v[j]), dz, yb);
+      s1[j] += dz;
+      s2[j] += dz * (yb - mu[j]) * rs[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    sm[(slot * C + cv * VEC + j) * 2 + 0] = s1[j];
+    sm[(slot * C + cv * VEC + j) * 2 + 1] = s2[j];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int q = 0; q < nslots; ++q) { a += sm[(q * C + c) * 2]; b += sm[(q * C + c) * 2 + 1]; }
+    partial[((int64_t)blockIdx.x * C + c) * 2 + 0] = a;
+    partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = b;
+  }
+}
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_reduce_pool_kernel(const T* __restrict__ dp, const T* __restrict__ y, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, float* __restrict__ partial, Dims g, int C,
+                                                                 int tile_p, bool nt) {
+  if (nt) bn_bwd_reduce_pool_body<T, ACT, true>(dp, y, scale, shift, mean, rstd, partial, g, C, tile_p);
+  else bn_bwd_reduce_pool_body<T, ACT, false>(dp, y, scale, shift, mean, rstd, partial, g, C, tile_p);
+}
+
+template <typename T, int ACT, bool NT>
+__device__ __forceinline__ void bn_bwd_apply_pool_body(const T* __restrict__ dp, const T* __restrict__ y, T* __restrict__ dy,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ k1, const float* __restrict__ kB,
+                                                         const float* __restrict__ kA, Dims g, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nvec = C / VEC, cv = threadIdx.x % nvec;   // 256 % nvec == 0: the channel vector of a thread never changes
+  const int64_t Mp = (int64_t)g.N * (g.D / 2) * (g.H / 2) * (g.W / 2);
+  float sc[VEC], sh[VEC], c1[VEC], cB[VEC], cA[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int c = cv * VEC + j;
+    sc[j] = scale[c]; sh[j] = shift[c]; c1[j] = k1[c]; cB[j] = kB[c]; cA[j] = kA[c];
+  }
+  const int64_t total = Mp * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t pv = i / nvec;
+    Vec16<T> v[8];
+    int64_t rows[8];
+    pool_window<T, ACT, NT>(y, g, C, cv, pv, v, rows);
+    const Vec16<T> gp = ld16(dp + i * VEC);
+    int arg[VEC];
+    float dzb[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float yb;
+      arg[j] = pool_argmax<T, ACT>(v, j, sc[j], sh[j], to_f(gp.v[j]), dzb[j], yb);
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        const float dz = (arg[j] == t) ? dzb[j] : 0.f;
+        o.v[j] = from_f<T>(c1[j] * dz + cB[j] * to_f(v[t].v[j]) + cA[j]);
+      }
+      st16_sel<NT>(dy + rows[t] * C + cv * VEC, o);
+    }
+  }
+}
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_bwd_apply_pool_kernel(const T* __restrict__ dp, const T* __restrict__ y, T* __restrict__ dy,
+                                                                const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                const float* __restrict__ k1, const float* __restrict__ kB,
+                                                                const float* __restrict__ kA, Dims g, int C, bool nt) {
+  if (nt) bn_bwd_apply_pool_body<T, ACT, true>(dp, y, dy, scale, shift, k1, kB, kA, g, C);
+  else bn_bwd_apply_pool_body<T, ACT, false>(dp, y, dy, scale, shift, k1, kB, kA, g, C);
+}
+
 inline unsigned grid_for(int64_t work_items) {
   int64_t b = (work_items + 255) / 256;
   if (b > 16384) b = 16384;
@@ -675,6 +815,60 @@ extern "C" int pcrl_bn_act_bwd_apply_rowadd(const void* da, const float* row_g, 
   RowAdd ra;
   if (int e = rowadd_check("bn_act_bwd_apply_rowadd", row_g, N, S, M, C, dtype, ra)) return e;
   return bn_bwd_apply_impl(da, y, dy, scale, shift, k1, kB, kA, M, C, act, dtype, ra, stream);
+}
+
+// ---- BatchNorm backward with MaxPool3d(2) backward folded in (see bn_bwd_reduce_pool_body) ----
+static int bn_pool_tile(int64_t Mp) {
+  int t = TILE_ROWS / 8;   // 128 pooled voxels = 1024 rows
+  while (t > 4 && Mp / t < 1024) t >>= 1;
+  return t;
+}
+extern "C" int64_t pcrl_bn_act_bwd_pool_ok(int D, int H, int W, int C, int dtype) {
+  return (D > 0 && H > 0 && W > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && rowadd_ok(C, dtype)) ? 1 : 0;
+}
+extern "C" int64_t pcrl_bn_act_bwd_pool_partial_rows(int N, int D, int H, int W) {
+  const int64_t Mp = (int64_t)N * (D / 2) * (H / 2) * (W / 2);
+  const int t = bn_pool_tile(Mp);
+  return (Mp + t - 1) / t;
+}
+extern "C" int pcrl_bn_act_bwd_reduce_pool(const void* dp, const void* y, const float* scale, const float* shift, const float* mean,
+                                           const float* rstd, float* partial, int N, int D, int H, int W, int C, int act, int dtype,
+                                           pcrl_stream_t stream) {
+  PCRL_REQUIRE(dp && y && scale && shift && mean && rstd && partial && N > 0, "bn_act_bwd_reduce_pool: bad arguments");
+  PCRL_REQUIRE(pcrl_bn_act_bwd_pool_ok(D, H, W, C, dtype), "bn_act_bwd_reduce_pool: not available for %dx%dx%d, C=%d (pcrl_bn_act_bwd_pool_ok)", D, H, W, C);
+  const int64_t Mp = (int64_t)N * (D / 2) * (H / 2) * (W / 2);
+  const dim3 grid((unsigned)pcrl_bn_act_bwd_pool_partial_rows(N, D, H, W));
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  const size_t lds = (size_t)(256 / (C / vec)) * C * 2 * sizeof(float);
+  const Dims g{N, D, H, W};
+  const bool nt = pcrl_streaming(Mp * 8 * C * (dtype == PCRL_BF16 ? 2 : 4));
+  if (dtype == PCRL_BF16) {
+    using T = bf16;
+    DISPATCH_ACT_T(bn_bwd_reduce_pool_kernel, grid, lds, (const T*)dp, (const T*)y, scale, shift, mean, rstd, partial, g, C, bn_pool_tile(Mp), nt);
+  } else {
+    using T = float;
+    DISPATCH_ACT_T(bn_bwd_reduce_pool_kernel, grid, lds, (const T*)dp, (const T*)y, scale, shift, mean, rstd, partial, g, C, bn_pool_tile(Mp), nt);
+  }
+  return pcrl_check_launch("bn_act_bwd_reduce_pool");
+}
+extern "C" int pcrl_bn_act_bwd_apply_pool(const void* dp, const void* y, void* dy, const float* scale, const float* shift, const float* k1,
+                                          const float* kB, const float* kA, int N, int D, int H, int W, int C, int act, int dtype,
+                                          pcrl_stream_t stream) {
+  PCRL_REQUIRE(dp && y && dy && scale && shift && k1 && kB && kA && N > 0, "bn_act_bwd_apply_pool: bad arguments");
+  PCRL_REQUIRE(pcrl_bn_act_bwd_pool_ok(D, H, W, C, dtype), "bn_act_bwd_apply_pool: not available for %dx%dx%d, C=%d (pcrl_bn_act_bwd_pool_ok)", D, H, W, C);
+  const int64_t Mp = (int64_t)N * (D / 2) * (H / 2) * (W / 2);
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  const dim3 grid(grid_for(Mp * (C / vec)));
+  const Dims g{N, D, H, W};
+  const bool nt = pcrl_streaming(Mp * 8 * C * (dtype == PCRL_BF16 ? 2 : 4));
+  if (dtype == PCRL_BF16) {
+    using T = bf16;
+    DISPATCH_ACT_T(bn_bwd_apply_pool_kernel, grid, 0, (const T*)dp, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, g, C, nt);
+  } else {
+    using T = float;
+    DISPATCH_ACT_T(bn_bwd_apply_pool_kernel, grid, 0, (const T*)dp, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, g, C, nt);
+  }
+  return pcrl_check_launch("bn_act_bwd_apply_pool");
 }
 
 extern "C" int pcrl_maxpool3d_2_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int dtype, pcrl_stream_t stream) {

@@ -153,6 +153,50 @@ class LUConvFn(Function):
         return out
 
 
+class LUConvPoolFn(Function):
+    """(a, p) = (act(bn1(conv1(x))), MaxPool3d(2)(a))  --  the second LUConv of an encoder stage and the `self.maxpool` that follows it
+    (models/pcrlv2_model_3d.py:32-34,115-117) as ONE autograd node.  When only the pooled tensor carries a gradient (the skip tensors
+    are never consumed) max_pool3d_backward is folded into the BatchNorm backward passes (ops.bn_act_backward, pool_dp):
+    the full-resolution gradient of `a` is never written or read."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, mod):
+        dt = mod.compute_dtype
+        a, sv = ops.luconv_forward(x, w, b, gamma, beta, mod.bn1.running_mean, mod.bn1.running_var, mod._packed, mod._act, dt)
+        p = ops.maxpool_forward(a, dt)
+        mod._count_batch()
+        ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
+        ctx.wref, ctx.gref = w, gamma
+        ctx.pass_idx = getattr(mod, "_pass_idx", 1)
+        ctx.plist = (w, b, gamma, beta)
+        ctx.set_materialize_grads(False)
+        return a, p
+
+    @staticmethod
+    def backward(ctx, da, dp):
+        if da is None and dp is None:
+            return (None,) * 6
+        sv, dt = ctx.sv, ctx.dt
+        N, D, H, W, _, Co = sv.geom
+        pool_dp = None
+        if dp is not None:
+            dp = _act_grad(dp, dt)
+            if da is None and ops.bn_pool_ok(D, H, W, Co, dt):
+                pool_dp = dp
+            else:   # somebody consumed the full-resolution activation too: materialise max_pool3d_backward and add
+                a = ops.bn_act_apply(sv.y, sv.scale, sv.shift, N * D * H * W, Co, sv.act, dt)
+                dfull = ops.maxpool_backward(a, dp, dt)
+                da = dfull if da is None else _act_grad(da, dt) + dfull
+        elif da is not None:
+            da = _act_grad(da, dt)
+        dx, dw, db, dg, dbeta = ops.luconv_backward(sv, da, ctx.wref, ctx.gref, ctx.mod._packed, dt, need_dx=ctx.needs_input_grad[0],
+                                                    pool_dp=pool_dp)
+        w, b, gamma, beta = ctx.plist
+        out = dx, _park(w, dw), _park(b, db), _park(gamma, dg), _park(beta, dbeta), None
+        mark_final(ctx, ctx.plist)
+        return out
+
+
 class MaxPoolFn(Function):
     """nn.MaxPool3d(2)  --  models/pcrlv2_model_3d.py:100,115-117."""
 

@@ -72,6 +72,12 @@ class LUConv(nn.Module, _Counted):
         c, n = self.conv1, self.bn1
         return Fn.LUConvFn.apply(x, c.weight, c.bias, n.weight, n.bias, self)
 
+    def forward_pooled(self, x):
+        """-> (act(bn1(conv1(x))), MaxPool3d(2) of it) as one autograd node (Fn.LUConvPoolFn): what PCRLv23d.forward asks of the second
+        LUConv of an encoder stage.  BatchNorm layers with more than one input channel only."""
+        c, n = self.conv1, self.bn1
+        return Fn.LUConvPoolFn.apply(ops.to_act(x, self.compute_dtype), c.weight, c.bias, n.weight, n.bias, self)
+
 
 def _make_nConv(in_channel, depth, act, norm, double_chnnel=False):
     """Two LUConvs.  Encoder stage d: in -> 32*2^d -> 64*2^d; decoder stage (double_chnnel): in -> 64*2^d -> 64*2^d   [:37-45]"""
@@ -249,9 +255,16 @@ class PCRLv23d(nn.Module):
         pass_idx = ops.next_pass()          # 0 = first forward since the last optimizer step (its backward runs last)
         for m in self._stage_modules():
             m._pass_idx = pass_idx
-        h = x
+        h, pooled = x, None
         for i, ((name, _, _), attr) in enumerate(zip(_ENCODER, _SKIPS)):
-            h = getattr(self, name)(h if i == 0 else self.maxpool(h))
+            stage = getattr(self, name)
+            h = h if i == 0 else (pooled if pooled is not None else self.maxpool(h))
+            last = stage.ops[1]
+            if config.FOLD_POOL_GRAD and i + 1 < len(_ENCODER) and not last._gn_groups:
+                # stage output and `self.maxpool` of it (:115-117) as one node: the pool's backward folds into the BatchNorm backward
+                h, pooled = last.forward_pooled(stage.ops[0](h))
+            else:
+                h, pooled = stage(h), None
             setattr(self, attr, h)          # the reference keeps these alive as attributes; the skips are never consumed (D6)
         middle_features, middle_masks = [], []
         for (name, _, _), factor in zip(_DECODER, _UPSAMPLE):

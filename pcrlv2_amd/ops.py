@@ -229,23 +229,37 @@ def bn_rowadd_ok(C, dtype) -> bool:
     return bool(lib().call("pcrl_bn_act_bwd_rowadd_ok", C, dtype_code(dtype)))
 
 
-def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, row_g=None):
+def bn_pool_ok(D, H, W, C, dtype) -> bool:
+    return bool(lib().call("pcrl_bn_act_bwd_pool_ok", D, H, W, C, dtype_code(dtype)))
+
+
+def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, row_g=None, pool_dp=None):
     """-> (dy, dgamma, dbeta): gradient w.r.t. the pre-normalisation tensor and the affine parameters.
     `row_g` (float32 [N, C]): the incoming gradient is da + row_g[n] / S broadcast over the S = M / N voxels of a sample (the
-    global-average-pool branch, folded into both passes instead of materialised by gap_backward); `da` may then be None."""
+    global-average-pool branch, folded into both passes instead of materialised by gap_backward); `da` may then be None.
+    `pool_dp` (activation [N, C, D/2, H/2, W/2]): the activation was consumed through MaxPool3d(2) only and THIS is the gradient of
+    the pooled tensor (da must be None): max_pool3d_backward happens inside the two passes."""
     L, s, dev = lib(), stream_handle(), y.device
-    rows = L.call("pcrl_bn_bwd_partial_rows", M)
-    partial = _f32(rows * C * 2, dev)
-    if row_g is not None:
-        N = row_g.shape[0]
-        L.call("pcrl_bn_act_bwd_reduce_rowadd", da, row_g, N, M // N, y, scale, shift, mean, rstd, partial, M, C, act, dtype_code(dtype), s)
+    if pool_dp is not None:
+        N, D, H, W, _ = dims(y)
+        rows = L.call("pcrl_bn_act_bwd_pool_partial_rows", N, D, H, W)
+        partial = _f32(rows * C * 2, dev)
+        L.call("pcrl_bn_act_bwd_reduce_pool", pool_dp, y, scale, shift, mean, rstd, partial, N, D, H, W, C, act, dtype_code(dtype), s)
     else:
-        L.call("pcrl_bn_act_bwd_reduce", da, y, scale, shift, mean, rstd, partial, M, C, act, dtype_code(dtype), s)
+        rows = L.call("pcrl_bn_bwd_partial_rows", M)
+        partial = _f32(rows * C * 2, dev)
+        if row_g is not None:
+            N = row_g.shape[0]
+            L.call("pcrl_bn_act_bwd_reduce_rowadd", da, row_g, N, M // N, y, scale, shift, mean, rstd, partial, M, C, act, dtype_code(dtype), s)
+        else:
+            L.call("pcrl_bn_act_bwd_reduce", da, y, scale, shift, mean, rstd, partial, M, C, act, dtype_code(dtype), s)
     out = _f32(5 * C, dev)
     dgamma, dbeta, k1, kB, kA = (out[i * C:(i + 1) * C] for i in range(5))
     L.call("pcrl_bn_bwd_finalize", partial, rows, C, float(M), gamma, mean, rstd, dgamma, dbeta, k1, kB, kA, s)
     dy = torch.empty_like(y)
-    if row_g is not None:
+    if pool_dp is not None:
+        L.call("pcrl_bn_act_bwd_apply_pool", pool_dp, y, dy, scale, shift, k1, kB, kA, N, D, H, W, C, act, dtype_code(dtype), s)
+    elif row_g is not None:
         L.call("pcrl_bn_act_bwd_apply_rowadd", da, row_g, row_g.shape[0], M // row_g.shape[0], y, dy, scale, shift, k1, kB, kA, M, C, act,
                dtype_code(dtype), s)
     else:
@@ -335,10 +349,13 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
     return a, sv
 
 
-def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, dtype, need_dx=True, dx_add=None, dx_colsum=None, da_row_g=None):
+def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, dtype, need_dx=True, dx_add=None, dx_colsum=None, da_row_g=None,
+                    pool_dp=None):
     """-> (dx | None, dw, db, dgamma, dbeta).  `dx_add`: optional activation folded into dx (to1 kind only).
     `da_row_g`: optional float32 [N, Co] -- the gradient of this LUConv's output is da + da_row_g[n] / (D*H*W) (bn_act_backward; da may
     be None then).  Only for BatchNorm layers with bn_rowadd_ok(Co, dtype).
+    `pool_dp`: the output was consumed through MaxPool3d(2) only; this is the pooled tensor's gradient and da is None
+    (bn_act_backward; BatchNorm layers with bn_pool_ok).
     `dx_colsum`: optional float32 [Ci] that receives sum over voxels of dx (the bias gradient of the layer that produced this
     LUConv's input -- ConvTranspose3d in UpTransition), taken from the data-gradient kernel's float accumulators through its
     per-tile statistics output instead of re-reading dx from HBM.
@@ -372,7 +389,7 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
         L.call("pcrl_colsum", dy, db, workspace(nbc, dev), nbc, M, Co, dtype_code(dtype), s)
     else:
         dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype,
-                                            row_g=da_row_g)
+                                            row_g=da_row_g, pool_dp=pool_dp)
     if sv.kind == "c1":
         nb = L.call("pcrl_conv3d_k3_c1_wgrad_ws_bytes", N, D, H, W, Co)
         L.call("pcrl_conv3d_k3_c1_wgrad", sv.x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Co, dtype_code(dtype), s)

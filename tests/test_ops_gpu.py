@@ -448,6 +448,50 @@ def test_batchnorm_backward_with_global_average_pool_branch_folded_in(shape, wit
     check(dy, back(dy2), dt, "row term vs materialised", bf_tol=2e-2)
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 16, 64), (3, 2, 4, 6, 32), (1, 4, 4, 4, 256)])
+def test_batchnorm_backward_with_maxpool_backward_folded_in(shape, ties, dt):
+    """Encoder stage end (pcrlv2_model_3d.py:115-117): a = relu(bn(y)) is consumed by nn.MaxPool3d(2) only.  pcrl_bn_act_bwd_*_pool take
+    the POOLED tensor's gradient and fold max_pool3d_backward into both BatchNorm passes.  Checked against (1) torch float64 autograd of
+    max_pool3d(relu(batch_norm(y))) where no ties exist, and (2) the device's own three-kernel route (bn_act_apply -> maxpool_backward ->
+    bn_act_backward) on inputs full of ties -- equal positive values inside a window and whole windows of zeros -- where the first
+    maximum in scan order must take the gradient."""
+    N, D, H, W, C = shape
+    M = N * D * H * W
+    assert ops.bn_pool_ok(D, H, W, C, dt)
+    y = rnd(N, C, D, H, W, seed=1, scale=2.0) + rnd(1, C, 1, 1, 1, seed=9)
+    if ties:
+        y = (y * 2).round() / 2          # a handful of distinct values: every window has repeated maxima
+    gamma, beta = 1 + 0.3 * rnd(C, seed=2), 0.3 * rnd(C, seed=3)
+    dp = rnd(N, C, D // 2, H // 2, W // 2, seed=4)
+    ya = act_dev(y, dt)
+    flat = back(ya).permute(0, 2, 3, 4, 1).reshape(M, C)
+    rows = (M + CONV_BM - 1) // CONV_BM
+    fp = torch.cat([flat, torch.zeros(rows * CONV_BM - M, C, dtype=torch.float64)]).view(rows, CONV_BM, C)
+    part = torch.stack([fp.sum(1), (fp * fp).sum(1)], dim=-1).float().to(DEV).contiguous()
+    g32, b32 = gamma.float().to(DEV), beta.float().to(DEV)
+    mean, rstd, scale, shift = ops.bn_finalize(part.view(-1), rows, C, M, g32, b32, torch.zeros(C, device=DEV), torch.ones(C, device=DEV))
+    dpa = act_dev(dp, dt)
+    dy, dgam, dbeta = ops.bn_act_backward(None, ya, g32, mean, rstd, scale, shift, M, C, ACT_RELU, dt, pool_dp=dpa)
+    # the three-kernel route on the same inputs
+    a = ops.bn_act_apply(ya, scale, shift, M, C, ACT_RELU, dt)
+    dfull = ops.maxpool_backward(a, dpa, dt)
+    dy2, dgam2, dbeta2 = ops.bn_act_backward(dfull, ya, g32, mean, rstd, scale, shift, M, C, ACT_RELU, dt)
+    check(dgam, back(dgam2), dt, "dgamma vs three kernels", out_rounded=False, f32_tol=2e-5)
+    check(dbeta, back(dbeta2), dt, "dbeta vs three kernels", out_rounded=False, f32_tol=2e-5)
+    check(dy, back(dy2), dt, "dy vs three kernels", f32_tol=2e-5, bf_tol=8e-3)
+    if not ties:
+        yq = q(y, dt).requires_grad_(True)
+        gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        pooled = F.max_pool3d(torch.relu(F.batch_norm(yq, None, None, gr, br, training=True, eps=1e-5)), 2)
+        pooled.backward(q(dp, dt))
+        if dt == torch.float32:     # in bf16 the device's argmax is taken on the ROUNDED activation: near-ties may pick another voxel
+            check(dy, yq.grad, dt, "dy vs torch")
+        check(dgam, gr.grad, dt, "dgamma vs torch", out_rounded=False, f32_tol=1e-4 if dt == torch.float32 else 2e-2)
+        check(dbeta, br.grad, dt, "dbeta vs torch", out_rounded=False, f32_tol=1e-4 if dt == torch.float32 else 2e-2)
+
+
 def test_batchnorm_one_channel_sigmoid():
     N, D, H, W = 2, 8, 8, 4
     M = N * D * H * W
