@@ -158,6 +158,9 @@ int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, co
  * pcrl_bn_act_bwd_rowadd_ok(C, dtype)); partial: [pcrl_bn_act_bwd_pool_partial_rows(N, D, H, W)][C][2] -> pcrl_bn_bwd_finalize with
  * count = N*D*H*W. */
 int64_t pcrl_bn_act_bwd_pool_ok(int D, int H, int W, int C, int dtype);   /* 1 / 0 */
+/* forward of the same pair: a = act(scale*y + shift) and p = MaxPool3d(2)(a) in one pass (same availability) */
+int pcrl_bn_act_apply_pool(const void* y, void* a, void* p, const float* scale, const float* shift, int N, int D, int H, int W, int C,
+                           int act, int dtype, pcrl_stream_t stream);
 int64_t pcrl_bn_act_bwd_pool_partial_rows(int N, int D, int H, int W);
 int pcrl_bn_act_bwd_reduce_pool(const void* dp, const void* y, const float* scale, const float* shift, const float* mean,
                                 const float* rstd, float* partial, int N, int D, int H, int W, int C, int act, int dtype,
@@ -197,6 +200,11 @@ int pcrl_maxpool3d_2_bwd(const void* x, const void* dy, void* dx, int N, int D, 
 size_t pcrl_gap_ws_bytes(int N, int64_t S, int C);
 int pcrl_gap_fwd(const void* a, float* g, void* ws, size_t ws_bytes, int N, int64_t S, int C, int dtype, pcrl_stream_t stream);
 int pcrl_gap_bwd(const float* dg, const void* add_src, void* da, int N, int64_t S, int C, int dtype, pcrl_stream_t stream);
+/* pcrl_bn_act_apply and pcrl_gap_fwd of its result in one pass over y (UpTransition: ops.1's activation feeds the pool, :64-67):
+ * a = act(scale*y + shift) (dtype [N][S][C]), g[n][c] = mean_s a (the stored, rounded values).  ws: pcrl_gap_ws_bytes(N, S, C).
+ * Available when pcrl_bn_act_bwd_rowadd_ok(C, dtype) != 0. */
+int pcrl_bn_act_apply_gap(const void* y, void* a, float* g, const float* scale, const float* shift, void* ws, size_t ws_bytes,
+                          int N, int64_t S, int C, int act, int dtype, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Projection / predictor heads on [rows][C] float32 -- BatchNorm1d, Linear, ReLU at

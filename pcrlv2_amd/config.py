@@ -44,3 +44,8 @@ FOLD_GAP_GRAD = os.environ.get("PCRL_FOLD_GAP_GRAD", "1") != "0"
 # max_pool3d_backward into the BatchNorm backward passes (functions.LUConvPoolFn, pcrl_bn_act_bwd_*_pool).  PCRL_FOLD_POOL_GRAD=0: the
 # separate nodes (A/B switch).
 FOLD_POOL_GRAD = os.environ.get("PCRL_FOLD_POOL_GRAD", "1") != "0"
+
+# Forward: the normalise+activate pass of a LUConv also produces what its only other consumer needs -- MaxPool3d(2) of the result (encoder
+# stage end) or its global average pool (UpTransition) -- instead of a second kernel re-reading the activation it just wrote
+# (pcrl_bn_act_apply_pool / pcrl_bn_act_apply_gap).  PCRL_FUSE_APPLY_CONSUMERS=0: separate kernels (A/B switch; results are bit-identical).
+FUSE_APPLY_CONSUMERS = os.environ.get("PCRL_FUSE_APPLY_CONSUMERS", "1") != "0"

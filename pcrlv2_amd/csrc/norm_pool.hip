@@ -411,6 +411,51 @@ __global__ void __launch_bounds__(256) coltile_finish_kernel(const float* __rest
   }
 }
 
+// a = act(bn(y)) and the per-sample column sums of the ROUNDED a in one pass: the global average pool of UpTransition
+// (pcrlv2_model_3d.py:67) re-read the full-resolution activation that bn_act_apply had just written.  Block = (row tile, sample) as in
+// coltile_sum_kernel; ws[(n * tiles + tile) * C + c], finished by coltile_finish_kernel.
+template <typename T, int ACT, bool NT>
+__device__ __forceinline__ void bn_apply_gap_body(const T* __restrict__ y, T* __restrict__ a, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, float* __restrict__ ws, int64_t rows_per_n, int C, int tile_rows) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [slots][C]
+  const int tid = threadIdx.x;
+  const int nvec = C / VEC, cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
+  const int64_t base = (int64_t)blockIdx.y * rows_per_n;
+  const int64_t rbeg = (int64_t)blockIdx.x * tile_rows;
+  const int64_t rend = (rbeg + tile_rows < rows_per_n) ? rbeg + tile_rows : rows_per_n;
+  float sc[VEC], sh[VEC], acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sc[j] = scale[cv * VEC + j]; sh[j] = shift[cv * VEC + j]; acc[j] = 0.f; }
+#pragma unroll 4
+  for (int64_t r = rbeg + slot; r < rend; r += nslots) {
+    const int64_t off = ((base + r) * nvec + cv) * VEC;
+    const Vec16<T> v = ld16_sel<NT>(y + off);
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      o.v[j] = from_f<T>(act_fwd<ACT>(sc[j] * to_f(v.v[j]) + sh[j]));
+      acc[j] += to_f(o.v[j]);
+    }
+    st16_sel<NT>(a + off, o);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) sm[slot * C + cv * VEC + j] = acc[j];
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float t = 0.f;
+    for (int q = 0; q < nslots; ++q) t += sm[q * C + c];
+    ws[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * C + c] = t;
+  }
+}
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_apply_gap_kernel(const T* __restrict__ y, T* __restrict__ a, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ ws, int64_t rows_per_n, int C,
+                                                           int tile_rows, bool nt) {
+  if (nt) bn_apply_gap_body<T, ACT, true>(y, a, scale, shift, ws, rows_per_n, C, tile_rows);
+  else bn_apply_gap_body<T, ACT, false>(y, a, scale, shift, ws, rows_per_n, C, tile_rows);
+}
+
 template <typename T, bool NT>
 __global__ void __launch_bounds__(256) gap_bwd_kernel(const float* __restrict__ dg, const T* add, T* da, int64_t S,
                                                       int C, int64_t nvec_total, float inv_s) {
@@ -537,6 +582,49 @@ __device__ __forceinline__ int pool_argmax(const Vec16<T> (&v)[8], int j, float 
   }
   dz = act_bwd<ACT>(zb, gp);
   return arg;
+}
+
+// Forward counterpart: a = act(bn(y)) and p = MaxPool3d(2)(a) in one pass (thread = pooled voxel x channel vector): the separate
+// pool re-read the full-resolution activation that bn_act_apply had just written.
+template <typename T, int ACT, bool NT>
+__device__ __forceinline__ void bn_apply_pool_body(const T* __restrict__ y, T* __restrict__ a, T* __restrict__ p, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, Dims g, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int nvec = C / VEC, cv = threadIdx.x % nvec;
+  const int64_t Mp = (int64_t)g.N * (g.D / 2) * (g.H / 2) * (g.W / 2);
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { sc[j] = scale[cv * VEC + j]; sh[j] = shift[cv * VEC + j]; }
+  const int64_t total = Mp * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    Vec16<T> v[8];
+    int64_t rows[8];
+    pool_window<T, ACT, NT>(y, g, C, cv, i / nvec, v, rows);
+    float m[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) m[j] = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      Vec16<T> o;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        o.v[j] = from_f<T>(act_fwd<ACT>(sc[j] * to_f(v[t].v[j]) + sh[j]));
+        const float f = to_f(o.v[j]);
+        if (f > m[j] || f != f) m[j] = f;
+      }
+      st16_sel<NT>(a + rows[t] * C + cv * VEC, o);
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o.v[j] = from_f<T>(m[j]);
+    st16(p + i * VEC, o);
+  }
+}
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) bn_apply_pool_kernel(const T* __restrict__ y, T* __restrict__ a, T* __restrict__ p,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift, Dims g, int C, bool nt) {
+  if (nt) bn_apply_pool_body<T, ACT, true>(y, a, p, scale, shift, g, C);
+  else bn_apply_pool_body<T, ACT, false>(y, a, p, scale, shift, g, C);
 }
 
 template <typename T, int ACT, bool NT>
@@ -831,6 +919,24 @@ extern "C" int64_t pcrl_bn_act_bwd_pool_partial_rows(int N, int D, int H, int W)
   const int t = bn_pool_tile(Mp);
   return (Mp + t - 1) / t;
 }
+extern "C" int pcrl_bn_act_apply_pool(const void* y, void* a, void* p, const float* scale, const float* shift, int N, int D, int H, int W, int C,
+                                      int act, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(y && a && p && scale && shift && N > 0, "bn_act_apply_pool: bad arguments");
+  PCRL_REQUIRE(pcrl_bn_act_bwd_pool_ok(D, H, W, C, dtype), "bn_act_apply_pool: not available for %dx%dx%d, C=%d (pcrl_bn_act_bwd_pool_ok)", D, H, W, C);
+  const int64_t Mp = (int64_t)N * (D / 2) * (H / 2) * (W / 2);
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  const dim3 grid(grid_for(Mp * (C / vec)));
+  const Dims g{N, D, H, W};
+  const bool nt = pcrl_streaming(Mp * 8 * C * (dtype == PCRL_BF16 ? 2 : 4));
+  if (dtype == PCRL_BF16) {
+    using T = bf16;
+    DISPATCH_ACT_T(bn_apply_pool_kernel, grid, 0, (const T*)y, (T*)a, (T*)p, scale, shift, g, C, nt);
+  } else {
+    using T = float;
+    DISPATCH_ACT_T(bn_apply_pool_kernel, grid, 0, (const T*)y, (T*)a, (T*)p, scale, shift, g, C, nt);
+  }
+  return pcrl_check_launch("bn_act_apply_pool");
+}
 extern "C" int pcrl_bn_act_bwd_reduce_pool(const void* dp, const void* y, const float* scale, const float* shift, const float* mean,
                                            const float* rstd, float* partial, int N, int D, int H, int W, int C, int act, int dtype,
                                            pcrl_stream_t stream) {
@@ -954,6 +1060,30 @@ extern "C" size_t pcrl_gap_ws_bytes(int N, int64_t S, int C) { return (size_t)N 
 extern "C" int pcrl_gap_fwd(const void* a, float* g, void* ws, size_t ws_bytes, int N, int64_t S, int C, int dtype, pcrl_stream_t stream) {
   PCRL_REQUIRE(a && g && N > 0 && S > 0, "gap_fwd: bad arguments");
   return coltile_launch(a, g, ws, ws_bytes, N, S, C, dtype, 1.0 / (double)S, as_stream(stream), "gap_fwd");
+}
+
+// a = act(scale*y + shift) and g[n][c] = mean over the sample's voxels of a (the rounded values), one pass over y.  ws: pcrl_gap_ws_bytes.
+extern "C" int pcrl_bn_act_apply_gap(const void* y, void* a, float* g, const float* scale, const float* shift, void* ws, size_t ws_bytes,
+                                     int N, int64_t S, int C, int act, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(y && a && g && scale && shift && N > 0 && S > 0, "bn_act_apply_gap: bad arguments");
+  PCRL_REQUIRE(rowadd_ok(C, dtype), "bn_act_apply_gap: not available for C=%d (pcrl_bn_act_bwd_rowadd_ok)", C);
+  const int64_t tiles = coltile_tiles(N, S);
+  const size_t need = (size_t)N * tiles * C * sizeof(float);
+  if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "bn_act_apply_gap: workspace %zu < %zu", ws_bytes, need);
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  const size_t lds = (size_t)(256 / (C / vec)) * C * sizeof(float);
+  const dim3 grid((unsigned)tiles, (unsigned)N);
+  const bool nt = pcrl_streaming((int64_t)N * S * C * (dtype == PCRL_BF16 ? 2 : 4));
+  if (dtype == PCRL_BF16) {
+    using T = bf16;
+    DISPATCH_ACT_T(bn_apply_gap_kernel, grid, lds, (const T*)y, (T*)a, scale, shift, (float*)ws, S, C, coltile_rows(N, S), nt);
+  } else {
+    using T = float;
+    DISPATCH_ACT_T(bn_apply_gap_kernel, grid, lds, (const T*)y, (T*)a, scale, shift, (float*)ws, S, C, coltile_rows(N, S), nt);
+  }
+  if (int e = pcrl_check_launch("bn_act_apply_gap")) return e;
+  hipLaunchKernelGGL(coltile_finish_kernel, dim3((C + 31) / 32, N), dim3(256), 0, as_stream(stream), (const float*)ws, g, (int)tiles, C, N, 1.0 / (double)S);
+  return pcrl_check_launch("bn_act_apply_gap");
 }
 
 extern "C" int pcrl_gap_bwd(const float* dg, const void* add_src, void* da, int N, int64_t S, int C, int dtype, pcrl_stream_t stream) {

@@ -162,8 +162,7 @@ class LUConvPoolFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, mod):
         dt = mod.compute_dtype
-        a, sv = ops.luconv_forward(x, w, b, gamma, beta, mod.bn1.running_mean, mod.bn1.running_var, mod._packed, mod._act, dt)
-        p = ops.maxpool_forward(a, dt)
+        (a, p), sv = ops.luconv_forward(x, w, b, gamma, beta, mod.bn1.running_mean, mod.bn1.running_var, mod._packed, mod._act, dt, pooled=True)
         mod._count_batch()
         ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
         ctx.wref, ctx.gref = w, gamma
@@ -231,8 +230,11 @@ class UpStageFn(Function):
         gn = getattr(l0, "_gn_groups", 0)
         rs = lambda m: (None, None) if gn else (m.bn1.running_mean, m.bn1.running_var)
         a0, sv0 = ops.luconv_forward(up, w0, b0, g0, be0, *rs(l0), l0._packed, l0._act, dt, gn_groups=gn)
-        a1, sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gn_groups=gn)
-        g = ops.gap_forward(a1, dt)
+        if gn:
+            a1, sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gn_groups=gn)
+            g = ops.gap_forward(a1, dt)
+        else:   # activation and its global average pool (:67) from one pass over the convolution output
+            (a1, g), sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gap=True)
         x_pro, m_pro, r_pro = ops.bn1d_forward(g, bn_g, bn_b, mod.bn.running_mean, mod.bn.running_var, relu=False)
         h0 = ops.linear_forward(x_pro, p0_w, p0_b)
         ph1 = mod.predictor_head[1]

@@ -274,8 +274,11 @@ class LUConvSaved:
     __slots__ = ("kind", "x", "y", "mean", "rstd", "scale", "shift", "geom", "act", "gn")
 
 
-def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, packed: PackedWeights, act: int, dtype, training=True, gn_groups=0):
-    """x: activation (or float32 [N,1,D,H,W] for the first layer).  Returns (a, saved).
+def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, packed: PackedWeights, act: int, dtype, training=True, gn_groups=0,
+                   pooled=False, gap=False):
+    """x: activation (or float32 [N,1,D,H,W] for the first layer).  Returns (a, saved); with `pooled` ((a, MaxPool3d(2)(a)), saved) --
+    one pass where bn_pool_ok (BatchNorm layers of the MFMA path), else the separate pool; with `gap` ((a, global average pool [N, C]
+    float32 of a), saved), likewise in one pass where bn_rowadd_ok.
     training=False: eval mode -- the normalisation uses the running statistics, nothing is updated, no statistics are gathered."""
     L, s, dev = lib(), stream_handle(), x.device
     Co, Ci = conv_w.shape[0], conv_w.shape[1]
@@ -342,10 +345,24 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         L.call("pcrl_conv3d_k3_fwd_ws", x, wf, conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb, N, D, H, W, Ci, Co,
                dtype_code(dtype), s)
         mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, training)
-        a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
+        if pooled and config.FUSE_APPLY_CONSUMERS and bn_pool_ok(D, H, W, Co, dtype):
+            a, p = torch.empty_like(y), new_act(N, D // 2, H // 2, W // 2, Co, dtype, dev)
+            L.call("pcrl_bn_act_apply_pool", y, a, p, scale, shift, N, D, H, W, Co, act, dtype_code(dtype), s)
+            a, pooled = (a, p), False
+        elif gap and config.FUSE_APPLY_CONSUMERS and bn_rowadd_ok(Co, dtype):
+            a, g = torch.empty_like(y), _f32(N * Co, dev).view(N, Co)
+            nbg = L.call("pcrl_gap_ws_bytes", N, D * H * W, Co)
+            L.call("pcrl_bn_act_apply_gap", y, a, g, scale, shift, workspace(nbg, dev), nbg, N, D * H * W, Co, act, dtype_code(dtype), s)
+            a, gap = (a, g), False
+        else:
+            a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
         sv.kind = "gemm"
     sv.x, sv.y, sv.mean, sv.rstd, sv.scale, sv.shift = x, y, mean, rstd, scale, shift
     sv.geom = (N, D, H, W, Ci, Co)
+    if pooled:
+        a = (a, maxpool_forward(a, dtype))
+    elif gap:
+        a = (a, gap_forward(a, dtype))
     return a, sv
 
 

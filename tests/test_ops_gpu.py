@@ -442,6 +442,13 @@ def test_batchnorm_backward_with_global_average_pool_branch_folded_in(shape, wit
     check(dy, yq.grad, dt, "bn bwd dx (row term)")
     check(dgam, gr.grad, dt, "bn dgamma (row term)", out_rounded=False, f32_tol=1e-4)
     check(dbeta, br.grad, dt, "bn dbeta (row term)", out_rounded=False, f32_tol=1e-4)
+    # forward side of the same fusion: activation + global average pool in one pass (pcrl_bn_act_apply_gap)
+    a_ref = ops.bn_act_apply(ya, scale, shift, M, C, ACT_RELU, dt)
+    a1, g1 = torch.empty_like(ya), torch.empty(N, C, dtype=torch.float32, device=DEV)
+    nb = lib().call("pcrl_gap_ws_bytes", N, S, C)
+    lib().call("pcrl_bn_act_apply_gap", ya, a1, g1, scale, shift, ops.workspace(nb, DEV_T), nb, N, S, C, ACT_RELU, dtype_code(dt), stream_handle())
+    assert torch.equal(a1, a_ref)
+    check(g1, back(a_ref).mean(dim=(2, 3, 4)), dt, "fused global average pool", out_rounded=False, f32_tol=1e-5)
     # and the materialised form it replaces: same result up to the one bf16 rounding of the materialised sum
     dsum = ops.gap_backward(dg.float().to(DEV).contiguous(), ya, act_dev(da, dt) if with_da else None, dt)
     dy2, dgam2, dbeta2 = ops.bn_act_backward(dsum, ya, g32, mean, rstd, scale, shift, M, C, ACT_RELU, dt)
@@ -476,6 +483,10 @@ def test_batchnorm_backward_with_maxpool_backward_folded_in(shape, ties, dt):
     dy, dgam, dbeta = ops.bn_act_backward(None, ya, g32, mean, rstd, scale, shift, M, C, ACT_RELU, dt, pool_dp=dpa)
     # the three-kernel route on the same inputs
     a = ops.bn_act_apply(ya, scale, shift, M, C, ACT_RELU, dt)
+    # forward pair in one pass (pcrl_bn_act_apply_pool): bit-identical to apply + pool
+    a1, p1 = torch.empty_like(ya), ops.new_act(N, D // 2, H // 2, W // 2, C, dt, DEV_T)
+    lib().call("pcrl_bn_act_apply_pool", ya, a1, p1, scale, shift, N, D, H, W, C, ACT_RELU, dtype_code(dt), stream_handle())
+    assert torch.equal(a1, a) and torch.equal(p1, ops.maxpool_forward(a, dt))
     dfull = ops.maxpool_backward(a, dpa, dt)
     dy2, dgam2, dbeta2 = ops.bn_act_backward(dfull, ya, g32, mean, rstd, scale, shift, M, C, ACT_RELU, dt)
     check(dgam, back(dgam2), dt, "dgamma vs three kernels", out_rounded=False, f32_tol=2e-5)
