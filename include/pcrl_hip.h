@@ -309,6 +309,34 @@ int pcrl_add_relu_fwd(const void* t, const void* r, void* a, int64_t n, int dtyp
 int pcrl_relu_mask_bwd(const void* da, const void* a, void* g, int64_t n, int dtype, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * UpTransition's first two linear layers as ONE operator: ConvTranspose3d(Ci -> Cm, k=2, s=2) followed directly by
+ * Conv3d(Cm -> Co, 3x3x3, pad 1) -- `self.ops(self.up_conv(x))`, pcrlv2_model_3d.py:64 (layers :52 and :9/33), nothing in between.
+ * Same function, same parameters (w_up [Ci][Cm][2][2][2], b_up [Cm], w0 [Co][Cm][3][3][3], b0 [Co], reference layouts, float32) and the
+ * same four parameter gradients as the two aten calls, computed on the COARSE grid: a fine voxel 2v+p sees only 2x2x2 coarse voxels
+ * through its 3x3x3 window, so the composed operator has 8 taps per output phase (0.30 of the multiply-adds) and the Cm-channel
+ * 2x-upsampled tensor (and its gradient) never exists.  See csrc/upconv_fused.hip for the algebra.
+ *   compose : wf (dtype [8][Co][8][Ci]), wd (dtype [Ci][64][Co]), bias_tab (float32 [27][Co]: border classes of the fine voxel) from
+ *             the four parameters; once per optimizer step.  ws: pcrl_upconv_compose_ws_bytes().
+ *   fwd     : x dtype [N][D][H][W][Ci] -> y0 dtype [N][2D][2H][2W][Co];  stats_partial: [pcrl_upconv_stats_rows()][Co][2] (sum, sum^2)
+ *             for the BatchNorm that follows (or NULL).
+ *   dgrad   : dy0 -> dx (dtype [N][D][H][W][Ci]).
+ *   wgrad   : x, dy0 -> dw_up, db_up, dw0 (float32, reference layouts; db0 is the column sum of dy0 -- identically cancelled by the
+ *             BatchNorm that follows in the reference model and not produced here).  ws: pcrl_upconv_wgrad_ws_bytes().
+ * Channels are multiples of 32. */
+size_t pcrl_upconv_compose_ws_bytes(int Ci, int Cm, int Co, int dtype);
+int pcrl_upconv_compose(const float* w_up, const float* b_up, const float* w0, const float* b0, void* wf, void* wd, float* bias_tab,
+                        void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream);
+int64_t pcrl_upconv_stats_rows(int N, int D, int H, int W);
+int pcrl_upconv_fwd(const void* x, const void* wf, const float* bias_tab, void* y0, float* stats_partial, int N, int D, int H, int W,
+                    int Ci, int Co, int dtype, pcrl_stream_t stream);
+int pcrl_upconv_dgrad(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
+                      pcrl_stream_t stream);
+size_t pcrl_upconv_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype);
+int pcrl_upconv_wgrad(const void* x, const void* dy0, const float* w_up, const float* b_up, const float* w0, float* dw_up, float* db_up,
+                      float* dw0, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype,
+                      pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * All cosine terms of one step in one call -- train_3d.py:119-134 (13 cos_loss calls = 26 cosine means, :86-92).
  *   out[g] = sum_{t : group[t] == g} w[t] * mean_r cos(x[t][r], y[t][r]),  x[t], y[t]: float32 [rows][C[t]] on the device
  * `x`, `y`, `dx`, `w`, `C`, `group`, `first` are HOST arrays of `nterms` <= 32 entries (device pointers / scalars); they are copied into

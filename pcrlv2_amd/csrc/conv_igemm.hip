@@ -24,7 +24,15 @@
 
 namespace {
 
-enum { GEOM_CONV3 = 0, GEOM_UP2_FWD = 1, GEOM_UP2_DGRAD = 2 };
+enum { GEOM_CONV3 = 0, GEOM_UP2_FWD = 1, GEOM_UP2_DGRAD = 2, GEOM_UPC_FWD = 3, GEOM_UPC_DGRAD = 4 };
+// GEOM_UPC_*: ConvTranspose3d(k2,s2) followed directly by Conv3d(3x3x3, pad 1) -- UpTransition's up_conv and ops.0's conv1
+// (pcrlv2_model_3d.py:52,64 then :9,33), nothing in between -- as ONE linear operator on the COARSE grid (upconv_fused.hip composes
+// the weights).  A fine output voxel f = 2v + p (phase p in {0,1}^3) sees, through its 3x3x3 window on the fine grid, only the
+// 2x2x2 coarse voxels v + p - 1 + q (q in {0,1}^3): 8 taps instead of 27 and no 2x-upsampled intermediate tensor.
+//   UPC_FWD  : rows = coarse voxels, blockIdx.z = phase, 8 taps of K = Ci channels, output row = the phase's fine voxel; the bias is a
+//              table over the 27 border classes of the fine voxel (the inner convolution zero-pads the UPSAMPLED tensor, whose bias
+//              therefore enters through a position-dependent number of taps); statistics rows = 8 x tiles.
+//   UPC_DGRAD: rows = coarse voxels, 64 taps = the 4x4x4 fine voxels 2u - 1 .. 2u + 2 of K = Co channels (each belongs to one (p, q)).
 
 struct IgemmParams {
   const void* x;      // A source rows [*][K]
@@ -92,10 +100,26 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       } else if (GEOM == GEOM_UP2_FWD) {
         abase[ps] = m;
         amask[ps] = 1u;
+      } else if (GEOM == GEOM_UPC_FWD) {
+        abase[ps] = m;
+        const int od = (z >> 2) - 1, oh = ((z >> 1) & 1) - 1, ow = (z & 1) - 1;
+        uint32_t mk = 0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if ((unsigned)(d + od + (t >> 2)) < (unsigned)g.D && (unsigned)(h + oh + ((t >> 1) & 1)) < (unsigned)g.H &&
+              (unsigned)(w + ow + (t & 1)) < (unsigned)g.W)
+            mk |= 1u << t;
+        amask[ps] = mk;
+      } else if (GEOM == GEOM_UPC_DGRAD) {
+        abase[ps] = up2_row(n, d, h, w, 0, g);
+        amask[ps] = (d == 0 ? 1u : 0u) | (d == g.D - 1 ? 2u : 0u) | (h == 0 ? 4u : 0u) | (h == g.H - 1 ? 8u : 0u) | (w == 0 ? 16u : 0u) |
+                    (w == g.W - 1 ? 32u : 0u);   // border flags; a tap is dead when it needs a flagged side
       } else {
         abase[ps] = up2_row(n, d, h, w, 0, g);
         amask[ps] = 0xFFu;
       }
+    } else if (GEOM == GEOM_UPC_DGRAD) {
+      amask[ps] = 64u;   // row past M: every tap dead
     }
   }
   // ---- per-thread B rows ----
@@ -128,13 +152,21 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 #define IGEMM_LOAD(t_, c_, ra, rb, aok)                                                                 \
   do {                                                                                                  \
     int64_t delta_;                                                                                     \
+    uint32_t kill_ = 0;                                                                                 \
     if (GEOM == GEOM_CONV3) delta_ = tap_delta27((t_), g);                                              \
     else if (GEOM == GEOM_UP2_DGRAD)                                                                    \
       delta_ = ((int64_t)((t_) >> 2) * (2 * g.H) + (((t_) >> 1) & 1)) * (2 * g.W) + ((t_)&1);           \
-    else delta_ = 0;                                                                                    \
+    else if (GEOM == GEOM_UPC_FWD)                                                                      \
+      delta_ = ((int64_t)((z >> 2) - 1 + ((t_) >> 2)) * g.H + (((z >> 1) & 1) - 1 + (((t_) >> 1) & 1))) * g.W + ((z & 1) - 1 + ((t_)&1)); \
+    else if (GEOM == GEOM_UPC_DGRAD) {                                                                  \
+      const int ed_ = (t_) >> 4, eh_ = ((t_) >> 2) & 3, ew_ = (t_)&3;                                   \
+      delta_ = ((int64_t)(ed_ - 1) * (2 * g.H) + (eh_ - 1)) * (2 * g.W) + (ew_ - 1);                    \
+      kill_ = 64u | (ed_ == 0 ? 1u : 0u) | (ed_ == 3 ? 2u : 0u) | (eh_ == 0 ? 4u : 0u) | (eh_ == 3 ? 8u : 0u) | (ew_ == 0 ? 16u : 0u) | \
+              (ew_ == 3 ? 32u : 0u);                                                                    \
+    } else delta_ = 0;                                                                                  \
     aok = 0;                                                                                            \
     _Pragma("unroll") for (int ps = 0; ps < AP; ++ps) {                                                 \
-      const uint32_t ok_ = (amask[ps] >> (t_)) & 1u;                                                    \
+      const uint32_t ok_ = (GEOM == GEOM_UPC_DGRAD) ? ((amask[ps] & kill_) == 0u ? 1u : 0u) : ((amask[ps] >> (t_)) & 1u); \
       const int64_t row_ = abase[ps] + (ok_ ? delta_ : (int64_t)0);                                     \
       ra[ps] = *reinterpret_cast<const u32x4*>(X + row_ * K + (c_)*32 + slot * VEC);                    \
       aok |= ok_ << ps;                                                                                 \
@@ -247,7 +279,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   for (int j = 0; j < FN; ++j) {
     s1[j] = 0.f;
     s2[j] = 0.f;
-    bv[j] = p.bias ? p.bias[n0 + wn * (BN / 2) + j * 16 + lr] : 0.f;
+    bv[j] = (p.bias && GEOM != GEOM_UPC_FWD) ? p.bias[n0 + wn * (BN / 2) + j * 16 + lr] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
@@ -256,10 +288,17 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       const int64_t m = m0 + wm * 64 + i * 16 + lg * 4 + r;
       if (m < p.M) {
         int64_t orow = m;
-        if (GEOM == GEOM_UP2_FWD) {
+        if (GEOM == GEOM_UP2_FWD || GEOM == GEOM_UPC_FWD) {
           int n, d, h, w;
           decode_voxel(m, g, n, d, h, w);
           orow = up2_row(n, d, h, w, z, g);
+          if (GEOM == GEOM_UPC_FWD) {   // border class of the fine voxel (0 first, 1 inside, 2 last per axis) -> row of the bias table
+            const int fd = 2 * d + (z >> 2), fh = 2 * h + ((z >> 1) & 1), fw = 2 * w + (z & 1);
+            const int cls = ((fd == 0 ? 0 : (fd == 2 * g.D - 1 ? 2 : 1)) * 3 + (fh == 0 ? 0 : (fh == 2 * g.H - 1 ? 2 : 1))) * 3 +
+                            (fw == 0 ? 0 : (fw == 2 * g.W - 1 ? 2 : 1));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bv[j] = p.bias[cls * p.Nc + n0 + wn * (BN / 2) + j * 16 + lr];
+          }
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
@@ -291,7 +330,8 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       const int j = within / 16, l = within % 16;
       const float* r0 = red + (((0 * 2 + wn_) * FN + j) * 16 + l) * 2;
       const float* r1 = red + (((1 * 2 + wn_) * FN + j) * 16 + l) * 2;
-      float* o = p.stats + ((int64_t)blockIdx.x * p.Nc + n0 + tid) * 2;
+      const int64_t srow = (GEOM == GEOM_UPC_FWD) ? (int64_t)blockIdx.z * gridDim.x + blockIdx.x : (int64_t)blockIdx.x;
+      float* o = p.stats + (srow * p.Nc + n0 + tid) * 2;
       o[0] = r0[0] + r1[0];
       o[1] = r0[1] + r1[1];
     }
@@ -501,6 +541,40 @@ extern "C" int pcrl_convt3d_k2s2_dgrad(const void* dy, const void* wp_dgrad, voi
   // rows = input voxels, K per tap = Co (channels of dy), output channels = Ci
   IgemmParams p{dy, wp_dgrad, nullptr, dx, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Co, Ci, 8, nullptr, 0};
   return dispatch<GEOM_UP2_DGRAD>(p, 1, dtype, as_stream(stream));
+}
+
+// ---- fused ConvTranspose3d(k2,s2) -> Conv3d(3x3x3): the two MFMA passes (internal; the C ABI is in upconv_fused.hip) ----
+int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
+                        int dtype, hipStream_t stream) {
+  IgemmParams p{x, wf, bias_tab, y0, stats, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 8, nullptr, 0};
+  return dispatch<GEOM_UPC_FWD>(p, 8, dtype, stream);
+}
+int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype, hipStream_t stream) {
+  // rows = coarse voxels, K per tap = Co (channels of dy0), 64 taps, output channels = Ci
+  IgemmParams p{dy0, wd, nullptr, dx, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Co, Ci, 64, nullptr, 0};
+  return dispatch<GEOM_UPC_DGRAD>(p, 1, dtype, stream);
+}
+// Plain GEMM with a float32 plane-major result: z[col * M + m] = sum_k a[m][k] * b[col][k]   (M % 4 == 0, K % 32 == 0, Nc % 32 == 0)
+template <typename T, int BN> static void gemm_planes_bn(const IgemmParams& p, hipStream_t stream) {
+  const unsigned gx = (unsigned)((p.M + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
+  const size_t lds = 2 * (size_t)(PCRL_CONV_BM + BN) * Tile<T>::ROWB;
+  hipLaunchKernelGGL((igemm_kernel<T, BN, GEOM_UP2_FWD, true>), dim3(gx, (unsigned)(p.Nc / BN), 1), dim3(256), lds, stream, p);
+}
+int pcrl_gemm_planes_launch(const void* a, const void* b, float* z, int64_t M, int K, int Nc, int dtype, hipStream_t stream) {
+  if (M <= 0 || M % 4 != 0 || K % 32 != 0 || Nc % 32 != 0) return pcrl_fail(PCRL_EINVAL, "gemm_planes: bad sizes M=%lld K=%d Nc=%d", (long long)M, K, Nc);
+  IgemmParams p{a, b, nullptr, z, nullptr, Dims{1, 1, 1, (int)(M > 0x7fffffff ? 0x7fffffff : M)}, M, K, Nc, 1, nullptr, 0};
+  if (dtype == PCRL_BF16) {
+    if (Nc % 128 == 0) gemm_planes_bn<bf16, 128>(p, stream);
+    else if (Nc % 64 == 0) gemm_planes_bn<bf16, 64>(p, stream);
+    else gemm_planes_bn<bf16, 32>(p, stream);
+  } else if (dtype == PCRL_F32) {
+    if (Nc % 128 == 0) gemm_planes_bn<float, 128>(p, stream);
+    else if (Nc % 64 == 0) gemm_planes_bn<float, 64>(p, stream);
+    else gemm_planes_bn<float, 32>(p, stream);
+  } else {
+    return pcrl_fail(PCRL_EINVAL, "gemm_planes: bad dtype %d", dtype);
+  }
+  return pcrl_check_launch("gemm_planes");
 }
 
 // Pointwise product for the C -> 1 convolutions (conv_c1.hip): z[t][m] = sum_c x[m][c] * wt[t][c], t < 32 (27 taps + zero

@@ -21,7 +21,9 @@
 
 namespace {
 
-enum { WG_CONV3 = 0, WG_UP2 = 1, WG_PLAIN = 2, WG_CONV2D = 3 };  // PLAIN: V is indexed by m directly (taps == 1)
+enum { WG_CONV3 = 0, WG_UP2 = 1, WG_PLAIN = 2, WG_CONV2D = 3, WG_UPC = 4 };  // PLAIN: V is indexed by m directly (taps == 1)
+// WG_UPC: the fused ConvTranspose3d(k2,s2) -> Conv3d(3x3x3) operator (conv_igemm.hip, GEOM_UPC_*): m = coarse voxel, 64 taps
+// t = phase p (3 bits) x coarse tap q (3 bits); U = dy0 at the phase's fine voxel 2m + p, V = x at the coarse voxel m + p - 1 + q.
 
 // WG_CONV2D (2D path, conv2d.hip): m = output pixel (n, oh, ow) in g = {N, 1, Ho, Wo}; V row = source pixel
 // (oh*stride - pad + kh, ow*stride - pad + kw) of [N][Hs][Ws], read through a nearest x2 upsample when `up`.
@@ -264,6 +266,55 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
       c3n[ps] += s3n;                                                                           \
     }                                                                                           \
   } while (0)
+  // WG_UPC: coarse coordinates carried like WG_CONV3's
+  const int upd = (t >> 5) & 1, uph = (t >> 4) & 1, upw = (t >> 3) & 1;            // phase
+  const int uod = upd - 1 + ((t >> 2) & 1), uoh = uph - 1 + ((t >> 1) & 1), uow = upw - 1 + (t & 1);   // coarse offset of the tap
+  if (GEOM == WG_UPC) {
+    s3w = KS % g.W;
+    s3h = (KS / g.W) % g.H;
+    s3d = (KS / (g.W * g.H)) % g.D;
+    s3n = KS / (g.W * g.H * g.D);
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      c3m[ps] = mbeg + ps * RPP + rowp;
+      const int64_t mc = c3m[ps] < p.M ? c3m[ps] : 0;
+      decode_voxel(mc, g, c3n[ps], c3d[ps], c3h[ps], c3w[ps]);
+    }
+  }
+#define WG_LOADUPC()                                                                            \
+  do {                                                                                          \
+    uokb = 0;                                                                                   \
+    vokb = 0;                                                                                   \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                         \
+      const bool live = c3m[ps] < mend;                                                         \
+      const int cn_ = live ? c3n[ps] : 0, cd_ = live ? c3d[ps] : 0, ch_ = live ? c3h[ps] : 0, cw_ = live ? c3w[ps] : 0; \
+      const int64_t urow = (((int64_t)cn_ * (2 * g.D) + 2 * cd_ + upd) * (2 * g.H) + 2 * ch_ + uph) * (2 * g.W) + 2 * cw_ + upw; \
+      ru[ps] = *reinterpret_cast<const u32x4*>(U + urow * p.Cu + i0 + ucol_u);                  \
+      const bool in = live && (unsigned)(cd_ + uod) < (unsigned)g.D && (unsigned)(ch_ + uoh) < (unsigned)g.H && \
+                      (unsigned)(cw_ + uow) < (unsigned)g.W;                                    \
+      const int64_t vrow = in ? (((int64_t)cn_ * g.D + cd_ + uod) * g.H + ch_ + uoh) * g.W + cw_ + uow : (int64_t)0; \
+      rv[ps] = *reinterpret_cast<const u32x4*>(V + vrow * vpitch + vcol);                       \
+      uokb |= (uint32_t)(live && u_ok) << ps;                                                   \
+      vokb |= (uint32_t)(in && v_ok) << ps;                                                     \
+      c3m[ps] += KS;                                                                            \
+      c3w[ps] += s3w;                                                                           \
+      if (c3w[ps] >= g.W) {                                                                     \
+        c3w[ps] -= g.W;                                                                         \
+        c3h[ps] += 1;                                                                           \
+      }                                                                                         \
+      c3h[ps] += s3h;                                                                           \
+      if (c3h[ps] >= g.H) {                                                                     \
+        c3h[ps] -= g.H;                                                                         \
+        c3d[ps] += 1;                                                                           \
+      }                                                                                         \
+      c3d[ps] += s3d;                                                                           \
+      if (c3d[ps] >= g.D) {                                                                     \
+        c3d[ps] -= g.D;                                                                         \
+        c3n[ps] += 1;                                                                           \
+      }                                                                                         \
+      c3n[ps] += s3n;                                                                           \
+    }                                                                                           \
+  } while (0)
 #define WG_LOAD(ms_)                                                                            \
   do {                                                                                          \
     uokb = 0;                                                                                   \
@@ -315,6 +366,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   if (nsteps > 0) {
     if (GEOM == WG_CONV2D) WG_LOAD2D();
     else if (GEOM == WG_CONV3) WG_LOAD3D();
+    else if (GEOM == WG_UPC) WG_LOADUPC();
     else WG_LOAD(mbeg);
     WG_STORE(0);
   }
@@ -325,6 +377,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
     const int64_t sn = (s + 1 < nsteps) ? s + 1 : s;
     if (GEOM == WG_CONV2D) WG_LOAD2D();      // the last iteration stages rows past `mend`: dead, zeroed at the LDS store
     else if (GEOM == WG_CONV3) WG_LOAD3D();
+    else if (GEOM == WG_UPC) WG_LOADUPC();
     else WG_LOAD(mbeg + sn * KS);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -347,6 +400,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
   }
 #undef WG_LOAD
 #undef WG_LOAD2D
+#undef WG_LOADUPC
 #undef WG_LOAD3D
 #undef WG_STORE
 
@@ -367,13 +421,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 // Block = 16 consecutive (i,j) x all taps: a thread sums a few (t, ij) pairs over z (64-byte runs per tap), the [t][ij] -> [ij][t]
 // transposition goes through LDS, the stores are one contiguous run.  When a block has <= 128 (t, ij) pairs (1 or 8 taps) the
 // slabs are spread over 256 / pairs thread groups whose partial sums are combined in group order (the 512-slab partials of the
-// 1-channel layer: 44 -> 6 us).  taps <= 49.
+// 1-channel layer: 44 -> 6 us).  taps <= 64.
 // [measured, r02d: a float4 / z-group form with 4-16 (i,j) per block was SLOWER (1.06 -> 1.85 ms per step): with 27 taps a wave then
 //  touches 64 different 128-byte lines for 1 KB of data; the pass is bound by line requests, not by load latency.]
 constexpr int RED_IJ = 16;
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
                                                            int splits, int taps, int Cu, int Cv, int Cv_out) {
-  __shared__ float tile[RED_IJ * 49];
+  __shared__ float tile[RED_IJ * 64];
   __shared__ double part[256];
   const int64_t per = (int64_t)Cu * Cv;
   const int64_t n_out = (int64_t)Cu * Cv_out;
@@ -421,7 +475,7 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
 
 // every weight-gradient path ends here
 int launch_wgrad_reduce(const float* ws, float* out, int splits, int taps, int Cu, int Cv, int Cv_out, hipStream_t stream) {
-  if (taps < 1 || taps > 49) return pcrl_fail(PCRL_EINVAL, "wgrad_reduce: %d taps", taps);
+  if (taps < 1 || taps > 64) return pcrl_fail(PCRL_EINVAL, "wgrad_reduce: %d taps", taps);
   const int blocks = (int)(((int64_t)Cu * Cv_out + RED_IJ - 1) / RED_IJ);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, out, splits, taps, Cu, Cv, Cv_out);
   return pcrl_check_launch("wgrad_reduce");
@@ -870,6 +924,17 @@ extern "C" void pcrl_debug_set_wgrad_impl(int impl) {
   // experiments: 4 = co-located launch with the old walk order, 5 = 2-D grid with the new walk order, 6 = co-located launch with 64 x 64 tiles only
   g_wgrad_impl = impl == 1 ? 1 : 0;
   pcrl_wgrad_brick_set_xcd(impl == 0 || impl == 4 || impl == 6, impl == 0 || impl == 5 || impl == 6, impl != 6);
+}
+
+// ---- fused ConvTranspose3d(k2,s2) -> Conv3d(3x3x3): gradient of the COMPOSED weights (internal; the C ABI is in upconv_fused.hip) ----
+// dweff[co][ci][t], t = phase * 8 + coarse tap = sum over coarse voxels v of dy0[2v + p][co] * x[v + p - 1 + q][ci]
+size_t pcrl_upc_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
+  const SplitPlan sp = plan_splits((int64_t)N * D * H * W, Co, Ci, 64);
+  return (size_t)sp.splits * 64 * Co * Ci * sizeof(float);
+}
+int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
+                          int dtype, hipStream_t stream) {
+  return run_wgrad<WG_UPC>(dy0, x, dweff, ws, ws_bytes, Dims{N, D, H, W}, Co, Ci, 64, dtype, stream);
 }
 
 extern "C" size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {

@@ -1,0 +1,374 @@
+// UpTransition's ConvTranspose3d(k=2, s=2) followed DIRECTLY by ops.0's Conv3d(3x3x3, pad 1) (models/pcrlv2_model_3d.py:52,64 then :9,33:
+// `self.ops(self.up_conv(x))`, nothing between the two linear maps) as ONE linear operator on the coarse grid.
+//
+// The reference materialises the 2x-upsampled tensor `up` (C channels at the fine resolution: 1.07 GB at up_tr64, b = 32) and runs a
+// 27-tap convolution over it; 55 % of the model's convolution FLOPs sit in these three layers.  But the 3x3x3 window of a fine
+// voxel f = 2v + p (phase p in {0,1}^3) only reaches the 2x2x2 coarse voxels v + p - 1 + q (q in {0,1}^3), so
+//     y0[2v + p][co] = bias_class(f)[co] + sum_q sum_ci x[v + p - 1 + q][ci] * Weff[p][q][ci][co]
+//     Weff[p][q][ci][co] = sum over the (fine tap t, sub-position s) pairs that lead from q to p   of   sum_cm Wup[ci][cm][s] * W0[co][cm][t]
+// -- 8 taps instead of 27 (0.30 of the multiply-adds), no `up`, no gradient of `up`.  Per axis the (t, s) pairs are
+//     (p,q) = (0,0): (t=0,s=1)   (0,1): (1,0),(2,1)   (1,0): (0,0),(1,1)   (1,1): (2,0)          [t = 0,1,2 <-> offset -1,0,+1]
+// and every (t, s) belongs to exactly one (p, q).  The inner convolution zero-pads `up` (not x): the transposed convolution's bias
+// reaches a fine voxel through as many taps as lie inside the fine grid, hence a bias TABLE over the 27 border classes
+// (first / inside / last per axis).  Zero-padding x reproduces the zero-padding of `up` for the weight part exactly.
+//
+// Backward (dy0 = gradient of y0):
+//     dx[u][ci]            = sum over the 4x4x4 fine voxels g = 2u - 1 .. 2u + 2 of dy0[g][co] * Weff[p(g)][q(g)][ci][co]
+//     dWeff[p][q][ci][co]  = sum_v x[v + p - 1 + q][ci] * dy0[2v + p][co]                       (64 small GEMMs over the coarse voxels)
+//     dW0[co][cm][t]       = sum_s  sum_ci dWeff[pq(t,s)][ci][co] * Wup[ci][cm][s]  +  b_up[cm] * B_t[co]
+//                            (B_t[co] = sum of dy0[.][co] over the fine voxels from which tap t stays inside the grid: `up` carries b_up)
+//     dWup[ci][cm][s]      = sum_t  sum_co dWeff[pq(t,s)][ci][co] * W0[co][cm][t]
+//     db_up[cm]            = sum_t sum_co W0[co][cm][t] * B_t[co]
+// The three data-sized passes (forward, dx, dWeff) run in the gather implicit-GEMM kernels (conv_igemm.hip GEOM_UPC_*, conv_wgrad.hip
+// WG_UPC); the weight-sized algebra runs as MFMA GEMMs with float32 plane-major results (pcrl_gemm_planes_launch) between small
+// re-layout kernels in this file.  Parameters, their gradients and the state_dict stay those of the two reference layers.
+#include "common.h"
+
+// conv_igemm.hip / conv_wgrad.hip
+int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
+                        int dtype, hipStream_t stream);
+int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype, hipStream_t stream);
+int pcrl_gemm_planes_launch(const void* a, const void* b, float* z, int64_t M, int K, int Nc, int dtype, hipStream_t stream);
+size_t pcrl_upc_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co);
+int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
+                          int dtype, hipStream_t stream);
+
+namespace {
+
+// per axis: the k-th (t, s) pair of (p, q); returns the number of pairs (1 or 2)
+__host__ __device__ __forceinline__ int ts_axis(int p, int q, int k, int& t, int& s) {
+  if (p == 0 && q == 0) { t = 0; s = 1; return 1; }
+  if (p == 0 && q == 1) { t = 1 + k; s = k; return 2; }          // (1,0), (2,1)
+  if (p == 1 && q == 0) { t = k; s = k; return 2; }              // (0,0), (1,1)
+  t = 2; s = 0; return 1;
+}
+// per axis: (t, s) -> (p, q)
+__host__ __device__ __forceinline__ void pq_axis(int t, int s, int& p, int& q) {
+  if (s == 1) { p = (t == 1) ? 1 : 0; q = (t == 0) ? 0 : (t == 1 ? 0 : 1); }   // (0,1)->(0,0)  (1,1)->(1,0)  (2,1)->(0,1)
+  else { p = (t == 1) ? 0 : 1; q = (t == 0) ? 0 : 1; }                          // (0,0)->(1,0)  (1,0)->(0,1)  (2,0)->(1,1)
+}
+// per axis: fine offset e = 0..3 (voxel 2u - 1 + e) -> (p, q)
+__host__ __device__ __forceinline__ void pq_of_e(int e, int& p, int& q) {
+  p = (e & 1) ? 0 : 1;            // e = 0 -> (1,1), 1 -> (0,1), 2 -> (1,0), 3 -> (0,0)
+  q = (e < 2) ? 1 : 0;
+}
+// tap t (0..2 on one axis) lies inside the fine grid for a voxel of border class c (0 first, 1 inside, 2 last)
+__host__ __device__ __forceinline__ bool tap_in(int t, int c) { return !(t == 0 && c == 0) && !(t == 2 && c == 2); }
+
+template <typename T> __device__ __forceinline__ T cvt(float v) { return from_f<T>(v); }
+
+// a0[(t*Co+co)][cm] = w0[co][cm][t];  bu[(s*Ci+ci)][cm] = wup[ci][cm][s];  b1[cm][(s*Ci+ci)] = wup[ci][cm][s];  b2[cm][(t*Co+co)] = w0[co][cm][t]
+// (any of the four outputs may be null)
+template <typename T>
+__global__ void __launch_bounds__(256) upc_prep_kernel(const float* __restrict__ wup, const float* __restrict__ w0, T* __restrict__ a0,
+                                                       T* __restrict__ bu, T* __restrict__ b1, T* __restrict__ b2, int Ci, int Cm, int Co) {
+  const int64_t n0 = (int64_t)27 * Co * Cm, nu = (int64_t)8 * Ci * Cm;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n0 + nu; i += (int64_t)gridDim.x * 256) {
+    if (i < n0) {                       // i enumerates w0 in its own order [co][cm][t]: coalesced read
+      const int t = (int)(i % 27), cm = (int)((i / 27) % Cm), co = (int)(i / ((int64_t)27 * Cm));
+      const T v = cvt<T>(w0[i]);
+      if (a0) a0[((int64_t)t * Co + co) * Cm + cm] = v;
+      if (b2) b2[(int64_t)cm * (27 * Co) + t * Co + co] = v;
+    } else {
+      const int64_t k = i - n0;         // [ci][cm][s]
+      const int s = (int)(k % 8), cm = (int)((k / 8) % Cm), ci = (int)(k / ((int64_t)8 * Cm));
+      const T v = cvt<T>(wup[k]);
+      if (bu) bu[((int64_t)s * Ci + ci) * Cm + cm] = v;
+      if (b1) b1[(int64_t)cm * (8 * Ci) + s * Ci + ci] = v;
+    }
+  }
+}
+
+// P[(s*Ci+ci)][(t*Co+co)] (float32, row length M27 = 27*Co) -> Weff, stored as
+//   wd[(ci*64 + e)*Co + co]            e = the fine offset triple of (p, q)        (threads: co fastest -> coalesced both ways)
+//   wf[((p*Co + co)*8 + q)*Ci + ci]
+template <typename T>
+__global__ void __launch_bounds__(256) upc_pack_kernel(const float* __restrict__ P, T* __restrict__ wf, T* __restrict__ wd, int Ci, int Co) {
+  const int64_t M27 = (int64_t)27 * Co;
+  const int64_t total = (int64_t)64 * Ci * Co;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int co = (int)(i % Co), e = (int)((i / Co) % 64), ci = (int)(i / ((int64_t)64 * Co));
+    int pd, qd, ph, qh, pw, qw;
+    pq_of_e(e >> 4, pd, qd);
+    pq_of_e((e >> 2) & 3, ph, qh);
+    pq_of_e(e & 3, pw, qw);
+    float acc = 0.f;
+    int td, sd, th, sh, tw, sw;
+    const int nd = ts_axis(pd, qd, 0, td, sd), nh = ts_axis(ph, qh, 0, th, sh), nw = ts_axis(pw, qw, 0, tw, sw);
+    for (int a = 0; a < nd; ++a) {
+      ts_axis(pd, qd, a, td, sd);
+      for (int b = 0; b < nh; ++b) {
+        ts_axis(ph, qh, b, th, sh);
+        for (int c = 0; c < nw; ++c) {
+          ts_axis(pw, qw, c, tw, sw);
+          const int t = td * 9 + th * 3 + tw, s = sd * 4 + sh * 2 + sw;
+          acc += P[((int64_t)s * Ci + ci) * M27 + (int64_t)t * Co + co];
+        }
+      }
+    }
+    const T v = cvt<T>(acc);
+    wd[i] = v;
+    const int p = pd * 4 + ph * 2 + pw, q = qd * 4 + qh * 2 + qw;
+    wf[(((int64_t)p * Co + co) * 8 + q) * Ci + ci] = v;
+  }
+}
+
+// bias_tab[cls][co] = b0[co] + sum over the taps t inside the grid for class cls of sum_cm w0[co][cm][t] * b_up[cm]
+__global__ void __launch_bounds__(256) upc_bias_kernel(const float* __restrict__ w0, const float* __restrict__ b_up, const float* __restrict__ b0,
+                                                       float* __restrict__ tab, int Cm, int Co) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 27 * Co) return;
+  const int co = i % Co, cls = i / Co;
+  const int cd = cls / 9, ch = (cls / 3) % 3, cw = cls % 3;
+  double acc = b0 ? (double)b0[co] : 0.0;
+  for (int t = 0; t < 27; ++t) {
+    if (!tap_in(t / 9, cd) || !tap_in((t / 3) % 3, ch) || !tap_in(t % 3, cw)) continue;
+    double s = 0.0;
+    for (int cm = 0; cm < Cm; ++cm) s += (double)w0[((int64_t)co * Cm + cm) * 27 + t] * (double)b_up[cm];
+    acc += s;
+  }
+  tab[i] = (float)acc;
+}
+
+// dweff[co][ci][pq] (float32) -> a1[(t*Co+co)][(s*Ci+ci)] and a2[(s*Ci+ci)][(t*Co+co)], value dWeff[pq(t,s)][ci][co]
+template <typename T>
+__global__ void __launch_bounds__(256) upc_chain_pack_kernel(const float* __restrict__ dweff, T* __restrict__ a1, T* __restrict__ a2, int Ci, int Co) {
+  const int64_t K1 = (int64_t)8 * Ci, K2 = (int64_t)27 * Co;
+  const int64_t total = (int64_t)27 * 8 * Ci * Co;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ci = (int)(i % Ci), s = (int)((i / Ci) % 8), co = (int)((i / ((int64_t)8 * Ci)) % Co), t = (int)(i / ((int64_t)8 * Ci * Co));
+    int pd, qd, ph, qh, pw, qw;
+    pq_axis(t / 9, s >> 2, pd, qd);
+    pq_axis((t / 3) % 3, (s >> 1) & 1, ph, qh);
+    pq_axis(t % 3, s & 1, pw, qw);
+    const int pq = (pd * 4 + ph * 2 + pw) * 8 + (qd * 4 + qh * 2 + qw);
+    const T v = cvt<T>(dweff[((int64_t)co * Ci + ci) * 64 + pq]);
+    a1[((int64_t)t * Co + co) * K1 + (int64_t)s * Ci + ci] = v;      // = index i: coalesced
+    a2[((int64_t)s * Ci + ci) * K2 + (int64_t)t * Co + co] = v;
+  }
+}
+
+// z1[cm][(t*Co+co)] -> dw0[co][cm][t];   z2[cm][(s*Ci+ci)] -> dwup[ci][cm][s]
+__global__ void __launch_bounds__(256) upc_chain_unpack_kernel(const float* __restrict__ z1, const float* __restrict__ z2, const float* __restrict__ b_up,
+                                                               const float* __restrict__ box, float* __restrict__ dw0,
+                                                               float* __restrict__ dwup, int Ci, int Cm, int Co) {
+  const int64_t n0 = (int64_t)27 * Co * Cm, nu = (int64_t)8 * Ci * Cm;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n0 + nu; i += (int64_t)gridDim.x * 256) {
+    if (i < n0) {
+      const int t = (int)(i % 27), cm = (int)((i / 27) % Cm), co = (int)(i / ((int64_t)27 * Cm));
+      dw0[i] = z1[(int64_t)cm * (27 * Co) + t * Co + co] + b_up[cm] * box[t * Co + co];
+    } else {
+      const int64_t k = i - n0;
+      const int s = (int)(k % 8), cm = (int)((k / 8) % Cm), ci = (int)(k / ((int64_t)8 * Cm));
+      dwup[k] = z2[(int64_t)cm * (8 * Ci) + s * Ci + ci];
+    }
+  }
+}
+
+// Border-class sums of dy0 for the gradient of the transposed convolution's bias.  Block = one (n, fine d) plane of dy0 [2H][2W][C];
+// thread = (channel vector, row slot) keeps 9 accumulators (h class x w class); part[plane][9][C].
+template <typename T>
+__global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict__ dy, float* __restrict__ part, int FH, int FW, int C) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [slots][C]
+  const int tid = threadIdx.x, nvec = C / VEC, cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
+  const int64_t rows = (int64_t)FH * FW;
+  const T* base = dy + (int64_t)blockIdx.x * rows * C;
+  float acc[9][VEC];
+#pragma unroll
+  for (int k = 0; k < 9; ++k)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[k][j] = 0.f;
+  for (int64_t r = slot; r < rows; r += nslots) {
+    const int h = (int)(r / FW), w = (int)(r % FW);
+    const int k = (h == 0 ? 0 : (h == FH - 1 ? 2 : 1)) * 3 + (w == 0 ? 0 : (w == FW - 1 ? 2 : 1));
+    const Vec16<T> v = ld16(base + (r * nvec + cv) * VEC);
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[q][j] += (q == k) ? to_f(v.v[j]) : 0.f;
+  }
+  for (int q = 0; q < 9; ++q) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float v = 0.f;
+#pragma unroll
+      for (int qq = 0; qq < 9; ++qq) v = (qq == q) ? acc[qq][j] : v;
+      sm[slot * C + cv * VEC + j] = v;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      float a = 0.f;
+      for (int s = 0; s < nslots; ++s) a += sm[s * C + c];
+      part[((int64_t)blockIdx.x * 9 + q) * C + c] = a;
+    }
+  }
+}
+// S[cls][co] = sum over the planes of class cd of part[plane][ch*3+cw][co]   (planes = N * FD, plane = n * FD + fd)
+__global__ void __launch_bounds__(256) upc_class_total_kernel(const float* __restrict__ part, float* __restrict__ S, int N, int FD, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 27 * C) return;
+  const int co = i % C, cls = i / C, cd = cls / 9, k9 = cls % 9;
+  double a = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const int f0 = cd == 0 ? 0 : (cd == 2 ? FD - 1 : 1), f1 = cd == 0 ? 1 : (cd == 2 ? FD : FD - 1);
+    for (int fd = f0; fd < f1; ++fd) a += (double)part[(((int64_t)n * FD + fd) * 9 + k9) * C + co];
+  }
+  S[i] = (float)a;
+}
+// box[t][co] = sum over the classes for which tap t is inside the grid of S[cls][co]
+__global__ void __launch_bounds__(256) upc_box_kernel(const float* __restrict__ S, float* __restrict__ box, int Co) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 27 * Co) return;
+  const int co = i % Co, t = i / Co;
+  double st = 0.0;
+  for (int cls = 0; cls < 27; ++cls)
+    if (tap_in(t / 9, cls / 9) && tap_in((t / 3) % 3, (cls / 3) % 3) && tap_in(t % 3, cls % 3)) st += (double)S[cls * Co + co];
+  box[i] = (float)st;
+}
+// db_up[cm] = sum_t sum_co w0[co][cm][t] * box[t][co];  block = cm
+__global__ void __launch_bounds__(256) upc_dbup_kernel(const float* __restrict__ w0, const float* __restrict__ box, float* __restrict__ db_up, int Cm,
+                                                       int Co) {
+  __shared__ double red[4];
+  const int cm = blockIdx.x;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < 27 * Co; i += 256) {
+    const int t = i % 27, co = i / 27;
+    a += (double)w0[((int64_t)co * Cm + cm) * 27 + t] * (double)box[t * Co + co];
+  }
+  a = block_sum_256(a, red);
+  if (threadIdx.x == 0) db_up[cm] = (float)a;
+}
+
+inline size_t al(size_t n) { return (n + 255) & ~(size_t)255; }
+inline int esz(int dtype) { return dtype == PCRL_BF16 ? 2 : 4; }
+inline unsigned blocks_for(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+int check_upc(const char* what, int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return pcrl_fail(PCRL_EINVAL, "%s: bad dims %d %d %d %d", what, N, D, H, W);
+  if (Ci <= 0 || Cm <= 0 || Co <= 0 || Ci % 32 || Cm % 32 || Co % 32) return pcrl_fail(PCRL_EINVAL, "%s: channels must be positive multiples of 32 (%d %d %d)", what, Ci, Cm, Co);
+  if (dtype != PCRL_BF16 && dtype != PCRL_F32) return pcrl_fail(PCRL_EINVAL, "%s: bad dtype %d", what, dtype);
+  if ((int64_t)N * D * H * W * 8 >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "%s: volume too large", what);
+  return PCRL_OK;
+}
+
+}  // namespace
+
+// ---- composed weights (once per optimizer step) ----
+extern "C" size_t pcrl_upconv_compose_ws_bytes(int Ci, int Cm, int Co, int dtype) {
+  if (Ci <= 0 || Cm <= 0 || Co <= 0) return 0;
+  return al((size_t)27 * Co * Cm * esz(dtype)) + al((size_t)8 * Ci * Cm * esz(dtype)) + al((size_t)27 * Co * 8 * Ci * sizeof(float));
+}
+extern "C" int pcrl_upconv_compose(const float* w_up, const float* b_up, const float* w0, const float* b0, void* wf, void* wd, float* bias_tab,
+                                   void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream) {
+  if (int e = check_upc("upconv_compose", 1, 1, 1, 1, Ci, Cm, Co, dtype)) return e;
+  PCRL_REQUIRE(w_up && b_up && w0 && wf && wd && bias_tab, "upconv_compose: null pointer");
+  if (!ws || ws_bytes < pcrl_upconv_compose_ws_bytes(Ci, Cm, Co, dtype)) return pcrl_fail(PCRL_EWORKSPACE, "upconv_compose: workspace too small");
+  hipStream_t st = as_stream(stream);
+  char* a0 = (char*)ws;
+  char* bu = a0 + al((size_t)27 * Co * Cm * esz(dtype));
+  float* P = (float*)(bu + al((size_t)8 * Ci * Cm * esz(dtype)));
+  const unsigned gb = blocks_for((int64_t)27 * Co * Cm + (int64_t)8 * Ci * Cm);
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_prep_kernel<bf16>, dim3(gb), dim3(256), 0, st, w_up, w0, (bf16*)a0, (bf16*)bu, (bf16*)nullptr, (bf16*)nullptr, Ci, Cm, Co);
+  else hipLaunchKernelGGL(upc_prep_kernel<float>, dim3(gb), dim3(256), 0, st, w_up, w0, (float*)a0, (float*)bu, (float*)nullptr, (float*)nullptr, Ci, Cm, Co);
+  if (int e = pcrl_check_launch("upconv_compose (prep)")) return e;
+  // P[(s,ci)][(t,co)] = sum_cm w0[co][cm][t] * wup[ci][cm][s]
+  if (int e = pcrl_gemm_planes_launch(a0, bu, P, (int64_t)27 * Co, Cm, 8 * Ci, dtype, st)) return e;
+  const unsigned gp = blocks_for((int64_t)64 * Ci * Co);
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_pack_kernel<bf16>, dim3(gp), dim3(256), 0, st, (const float*)P, (bf16*)wf, (bf16*)wd, Ci, Co);
+  else hipLaunchKernelGGL(upc_pack_kernel<float>, dim3(gp), dim3(256), 0, st, (const float*)P, (float*)wf, (float*)wd, Ci, Co);
+  if (int e = pcrl_check_launch("upconv_compose (pack)")) return e;
+  hipLaunchKernelGGL(upc_bias_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, w0, b_up, b0, bias_tab, Cm, Co);
+  return pcrl_check_launch("upconv_compose (bias)");
+}
+
+// ---- forward / data gradient ----
+extern "C" int64_t pcrl_upconv_stats_rows(int N, int D, int H, int W) {
+  return 8 * (((int64_t)N * D * H * W + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
+}
+extern "C" int pcrl_upconv_fwd(const void* x, const void* wf, const float* bias_tab, void* y0, float* stats_partial, int N, int D, int H, int W,
+                               int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  if (int e = check_upc("upconv_fwd", N, D, H, W, Ci, 32, Co, dtype)) return e;
+  PCRL_REQUIRE(x && wf && bias_tab && y0, "upconv_fwd: null pointer");
+  return pcrl_upc_fwd_launch(x, wf, bias_tab, y0, stats_partial, N, D, H, W, Ci, Co, dtype, as_stream(stream));
+}
+extern "C" int pcrl_upconv_dgrad(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
+                                 pcrl_stream_t stream) {
+  if (int e = check_upc("upconv_dgrad", N, D, H, W, Ci, 32, Co, dtype)) return e;
+  PCRL_REQUIRE(dy0 && wd && dx, "upconv_dgrad: null pointer");
+  return pcrl_upc_dgrad_launch(dy0, wd, dx, N, D, H, W, Ci, Co, dtype, as_stream(stream));
+}
+
+// ---- parameter gradients ----
+namespace {
+struct WgLayout {
+  size_t dweff, wg, a1, a2, b1, b2, z1, z2, part, S, box, total;
+};
+WgLayout wg_layout(int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype) {
+  WgLayout L;
+  size_t o = 0;
+  L.dweff = o; o += al((size_t)64 * Co * Ci * sizeof(float));
+  L.wg = o;    o += al(pcrl_upc_wgrad_ws_bytes(N, D, H, W, Ci, Co));
+  L.a1 = o;    o += al((size_t)27 * Co * 8 * Ci * esz(dtype));
+  L.a2 = o;    o += al((size_t)27 * Co * 8 * Ci * esz(dtype));
+  L.b1 = o;    o += al((size_t)Cm * 8 * Ci * esz(dtype));
+  L.b2 = o;    o += al((size_t)Cm * 27 * Co * esz(dtype));
+  L.z1 = o;    o += al((size_t)Cm * 27 * Co * sizeof(float));
+  L.z2 = o;    o += al((size_t)Cm * 8 * Ci * sizeof(float));
+  L.part = o;  o += al((size_t)N * 2 * D * 9 * Co * sizeof(float));
+  L.S = o;     o += al((size_t)27 * Co * sizeof(float));
+  L.box = o;   o += al((size_t)27 * Co * sizeof(float));
+  L.total = o;
+  return L;
+}
+}  // namespace
+extern "C" size_t pcrl_upconv_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Cm <= 0 || Co <= 0) return 0;
+  return wg_layout(N, D, H, W, Ci, Cm, Co, dtype).total;
+}
+extern "C" int pcrl_upconv_wgrad(const void* x, const void* dy0, const float* w_up, const float* b_up, const float* w0, float* dw_up, float* db_up,
+                                 float* dw0, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype,
+                                 pcrl_stream_t stream) {
+  if (int e = check_upc("upconv_wgrad", N, D, H, W, Ci, Cm, Co, dtype)) return e;
+  PCRL_REQUIRE(x && dy0 && w_up && b_up && w0 && dw_up && db_up && dw0, "upconv_wgrad: null pointer");
+  const WgLayout L = wg_layout(N, D, H, W, Ci, Cm, Co, dtype);
+  if (!ws || ws_bytes < L.total) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad: workspace %zu < %zu", ws_bytes, L.total);
+  hipStream_t st = as_stream(stream);
+  char* w = (char*)ws;
+  float* dweff = (float*)(w + L.dweff);
+  // (1) gradient of the composed weights: dweff[co][ci][p*8+q]
+  if (int e = pcrl_upc_wgrad_launch(dy0, x, dweff, w + L.wg, pcrl_upc_wgrad_ws_bytes(N, D, H, W, Ci, Co), N, D, H, W, Ci, Co, dtype, st)) return e;
+  // (2) chain rule to the two reference parameters: two GEMMs over the weight-sized operands
+  const unsigned gpre = blocks_for((int64_t)27 * Co * Cm + (int64_t)8 * Ci * Cm), gpk = blocks_for((int64_t)216 * Ci * Co);
+  if (dtype == PCRL_BF16) {
+    hipLaunchKernelGGL(upc_prep_kernel<bf16>, dim3(gpre), dim3(256), 0, st, w_up, w0, (bf16*)nullptr, (bf16*)nullptr, (bf16*)(w + L.b1), (bf16*)(w + L.b2), Ci, Cm, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<bf16>, dim3(gpk), dim3(256), 0, st, (const float*)dweff, (bf16*)(w + L.a1), (bf16*)(w + L.a2), Ci, Co);
+  } else {
+    hipLaunchKernelGGL(upc_prep_kernel<float>, dim3(gpre), dim3(256), 0, st, w_up, w0, (float*)nullptr, (float*)nullptr, (float*)(w + L.b1), (float*)(w + L.b2), Ci, Cm, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<float>, dim3(gpk), dim3(256), 0, st, (const float*)dweff, (float*)(w + L.a1), (float*)(w + L.a2), Ci, Co);
+  }
+  if (int e = pcrl_check_launch("upconv_wgrad (pack)")) return e;
+  if (int e = pcrl_gemm_planes_launch(w + L.a1, w + L.b1, (float*)(w + L.z1), (int64_t)27 * Co, 8 * Ci, Cm, dtype, st)) return e;   // z1[cm][(t,co)]
+  if (int e = pcrl_gemm_planes_launch(w + L.a2, w + L.b2, (float*)(w + L.z2), (int64_t)8 * Ci, 27 * Co, Cm, dtype, st)) return e;   // z2[cm][(s,ci)]
+  // (3) border-class sums of dy0 -> box sums: the transposed convolution's bias enters `up`, hence dW0, and has its own gradient
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  if (Co % vec != 0 || (Co / vec) > 256 || 256 % (Co / vec) != 0) return pcrl_fail(PCRL_EINVAL, "upconv_wgrad: Co=%d not supported by the class-sum kernel", Co);
+  const size_t lds = (size_t)(256 / (Co / vec)) * Co * sizeof(float);
+  float* part = (float*)(w + L.part);
+  float* S = (float*)(w + L.S);
+  float* box = (float*)(w + L.box);
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_class_sums_kernel<bf16>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const bf16*)dy0, part, 2 * H, 2 * W, Co);
+  else hipLaunchKernelGGL(upc_class_sums_kernel<float>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const float*)dy0, part, 2 * H, 2 * W, Co);
+  hipLaunchKernelGGL(upc_class_total_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)part, S, N, 2 * D, Co);
+  hipLaunchKernelGGL(upc_box_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)S, box, Co);
+  hipLaunchKernelGGL(upc_dbup_kernel, dim3(Cm), dim3(256), 0, st, w0, (const float*)box, db_up, Cm, Co);
+  if (int e = pcrl_check_launch("upconv_wgrad (bias)")) return e;
+  hipLaunchKernelGGL(upc_chain_unpack_kernel, dim3(gpre), dim3(256), 0, st, (const float*)(w + L.z1), (const float*)(w + L.z2), b_up, (const float*)box, dw0,
+                     dw_up, Ci, Cm, Co);
+  return pcrl_check_launch("upconv_wgrad (unpack)");
+}

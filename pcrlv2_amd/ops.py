@@ -482,6 +482,78 @@ def convt_backward(x, dy, w, packed: PackedWeights, dtype, need_dx=True, db=None
     return dx, dw, db
 
 
+# ----------------------------------------------------------------------------------------------
+# UpTransition: ConvTranspose3d(k2,s2) -> conv1 of ops.0 as one operator on the coarse grid   (models/pcrlv2_model_3d.py:64; csrc/upconv_fused.hip)
+# ----------------------------------------------------------------------------------------------
+class ComposedUpConv:
+    """Composed weights of (up_conv, ops.0.conv1), rebuilt when either parameter changed (once per optimizer step)."""
+
+    def __init__(self):
+        self.key = None
+        self.wf = self.wd = self.bias_tab = None
+
+    def get(self, w_up, b_up, w0, b0, dtype):
+        key = (_weights_epoch, w_up._version, w_up.data_ptr(), b_up._version, w0._version, w0.data_ptr(), b0._version, dtype)
+        if key != self.key:
+            L, s, dev = lib(), stream_handle(), w_up.device
+            Ci, Cm, Co = w_up.shape[0], w_up.shape[1], w0.shape[0]
+            if w0.shape[1] != Cm:
+                raise PcrlError(f"composed up-conv: up_conv has {Cm} output channels, conv1 expects {w0.shape[1]}")
+            self.wf = torch.empty(64 * Ci * Co, dtype=dtype, device=dev)
+            self.wd = torch.empty(64 * Ci * Co, dtype=dtype, device=dev)
+            self.bias_tab = _f32(27 * Co, dev)
+            nb = L.call("pcrl_upconv_compose_ws_bytes", Ci, Cm, Co, dtype_code(dtype))
+            L.call("pcrl_upconv_compose", w_up.detach(), b_up.detach(), w0.detach(), b0.detach(), self.wf, self.wd, self.bias_tab,
+                   workspace(nb, dev), nb, Ci, Cm, Co, dtype_code(dtype), s)
+            self.key = key
+        return self.wf, self.wd, self.bias_tab
+
+
+def upconv_luconv_forward(x, w_up, b_up, conv_w, conv_b, gamma, beta, running_mean, running_var, composed: ComposedUpConv, act, dtype):
+    """act(bn(conv1(up_conv(x)))) with the two convolutions composed.  x: coarse activation [N, Ci, D, H, W] -> (a [N, Co, 2D, 2H, 2W], saved).
+    Training mode, BatchNorm only (the GroupNorm / eval routes keep the two separate kernels)."""
+    L, s, dev = lib(), stream_handle(), x.device
+    N, D, H, W, Ci = dims(x)
+    Co = conv_w.shape[0]
+    if w_up.shape[0] != Ci:
+        raise PcrlError(f"up_conv: input has {Ci} channels, weight expects {w_up.shape[0]}")
+    wf, _, bias_tab = composed.get(w_up, b_up, conv_w, conv_b, dtype)
+    M = N * D * H * W * 8
+    rows = L.call("pcrl_upconv_stats_rows", N, D, H, W)
+    y = new_act(N, 2 * D, 2 * H, 2 * W, Co, dtype, dev)
+    partial = _f32(rows * Co * 2, dev)
+    L.call("pcrl_upconv_fwd", x, wf, bias_tab, y, partial, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, True)
+    a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
+    sv = LUConvSaved()
+    sv.kind, sv.act, sv.gn = "upc", act, None
+    sv.x, sv.y, sv.mean, sv.rstd, sv.scale, sv.shift = x, y, mean, rstd, scale, shift
+    sv.geom = (N, D, H, W, Ci, Co)      # COARSE dims
+    return a, sv
+
+
+def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamma, composed: ComposedUpConv, dtype, need_dx=True):
+    """-> (dx | None, dw_up, db_up, dw0, db0 (exactly zero: a bias in front of batch statistics), dgamma, dbeta)."""
+    L, s, dev = lib(), stream_handle(), sv.y.device
+    N, D, H, W, Ci, Co = sv.geom
+    Cm = w_up.shape[1]
+    M = N * D * H * W * 8
+    dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype)
+    dw_up = torch.empty_like(w_up, dtype=torch.float32, memory_format=torch.contiguous_format)
+    dw0 = torch.empty_like(conv_w, dtype=torch.float32, memory_format=torch.contiguous_format)
+    db_up = _f32(Cm, dev)
+    nb = L.call("pcrl_upconv_wgrad_ws_bytes", N, D, H, W, Ci, Cm, Co, dtype_code(dtype))
+    with side_wgrad(dev, sv.x, dy) as ws:
+        L.call("pcrl_upconv_wgrad", sv.x, dy, w_up.detach(), b_up.detach(), conv_w.detach(), dw_up, db_up, dw0, ws(nb), nb, N, D, H, W, Ci, Cm, Co,
+               dtype_code(dtype), stream_handle())
+    dx = None
+    if need_dx:
+        _, wd, _ = composed.get(w_up, b_up, conv_w, conv_b, dtype)
+        dx = new_act(N, D, H, W, Ci, dtype, dev)
+        L.call("pcrl_upconv_dgrad", dy, wd, dx, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    return dx, dw_up, db_up, dw0, zero_grad_vector(Co, dev), dgamma, dbeta
+
+
 def gap_forward(a, dtype):
     N, D, H, W, C = dims(a)
     S = D * H * W

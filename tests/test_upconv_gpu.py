@@ -1,0 +1,129 @@
+"""GPU parity of the composed ConvTranspose3d(k2,s2) -> Conv3d(3x3x3) operator (csrc/upconv_fused.hip; UpTransition.forward's
+`self.ops(self.up_conv(x))`, pcrlv2_model_3d.py:64) against torch float64 autograd of the TWO aten calls it replaces.
+
+The composed operator never forms the upsampled tensor, so there is no operand to pre-round on both sides:
+  float32 mode : exact-fp32 MFMA chains on both factorizations -> 1e-4 * max|ref| (two nested sums, composition included);
+  bfloat16 mode: x, dy0 and the COMPOSED weights are rounded to bf16 (the two-call route rounds x, both weights and the upsampled
+                 tensor instead) -> 2e-2 * max|ref| on data-sized results, 3e-2 on the weight gradients (they pass through a second
+                 bf16 rounding in the chain rule GEMMs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from pcrlv2_amd import ops  # noqa: E402
+from pcrlv2_amd._lib import ACT_RELU, dtype_code, lib, stream_handle  # noqa: E402
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def back(t):
+    return t.detach().double().cpu().contiguous()
+
+
+def close(got, ref, tol, what):
+    got, ref = back(got), ref.double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max|d|={err:.3e} > {tol:.1e} * {scale:.3e}"
+
+
+SHAPES = [  # N, D, H, W (coarse), Ci, Cm, Co
+    (2, 3, 4, 5, 32, 32, 32),       # odd extents, rows not a multiple of the 128-row tile
+    (1, 1, 1, 1, 32, 64, 32),       # a single coarse voxel: every fine voxel is a corner
+    (2, 1, 2, 3, 64, 32, 64),       # fine extent 2 along d: first and last class only
+    (1, 4, 4, 4, 128, 128, 64),     # up_tr64's channels
+    (3, 2, 2, 2, 64, 64, 32),
+    (1, 8, 8, 4, 64, 64, 32),       # several row tiles
+]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_composed_upconv_matches_the_two_aten_calls(shape, dt):
+    N, D, H, W, Ci, Cm, Co = shape
+    L, s = lib(), stream_handle()
+    bf = dt == torch.bfloat16
+    x = rnd(N, Ci, D, H, W, seed=1)
+    w_up, b_up = rnd(Ci, Cm, 2, 2, 2, seed=2, scale=0.2), rnd(Cm, seed=3, scale=0.5)
+    w0, b0 = rnd(Co, Cm, 3, 3, 3, seed=4, scale=0.1), rnd(Co, seed=5, scale=0.5)
+    dy0 = rnd(N, Co, 2 * D, 2 * H, 2 * W, seed=6)
+    xq, dyq = x.to(dt).double(), dy0.to(dt).double()
+    xr = xq.clone().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) for t in (w_up, b_up, w0, b0)]
+    y_ref = F.conv3d(F.conv_transpose3d(xr, pr[0], pr[1], stride=2), pr[2], pr[3], padding=1)
+    y_ref.backward(dyq)
+
+    # device
+    to_dev = lambda t: t.float().to(DEV).contiguous()
+    wu, bu, wc, bc = (to_dev(t) for t in (w_up, b_up, w0, b0))
+    xa = ops.to_act(xq.to(dt).to(DEV), dt)
+    comp = ops.ComposedUpConv()
+    wf, wd, tab = comp.get(wu, bu, wc, bc, dt)
+    rows = L.call("pcrl_upconv_stats_rows", N, D, H, W)
+    y = ops.new_act(N, 2 * D, 2 * H, 2 * W, Co, dt, torch.device(DEV))
+    part = torch.full((rows, Co, 2), float("nan"), dtype=torch.float32, device=DEV)
+    L.call("pcrl_upconv_fwd", xa, wf, tab, y, part, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    close(y, y_ref.detach(), 2e-2 if bf else 1e-4, "y0")
+    # statistics rows: (sum, sum^2) of the unrounded accumulators -- against the reference tensor
+    got = part.double().sum(0).cpu()
+    assert torch.isfinite(got).all()
+    ref_s = torch.stack([y_ref.detach().sum((0, 2, 3, 4)), (y_ref.detach() ** 2).sum((0, 2, 3, 4))], dim=1)
+    close(got, ref_s, 2e-2 if bf else 1e-4, "statistics")
+
+    dya = ops.to_act(dyq.to(dt).to(DEV), dt)
+    dx = ops.new_act(N, D, H, W, Ci, dt, torch.device(DEV))
+    L.call("pcrl_upconv_dgrad", dya, wd, dx, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    close(dx, xr.grad, 2e-2 if bf else 1e-4, "dx")
+
+    dwu, dbu, dwc = torch.empty_like(wu), torch.empty_like(bu), torch.empty_like(wc)
+    nb = L.call("pcrl_upconv_wgrad_ws_bytes", N, D, H, W, Ci, Cm, Co, dtype_code(dt))
+    L.call("pcrl_upconv_wgrad", xa, dya, wu, bu, wc, dwu, dbu, dwc, ops.workspace(nb, torch.device(DEV)), nb, N, D, H, W, Ci, Cm, Co, dtype_code(dt), s)
+    close(dwu, pr[0].grad, 3e-2 if bf else 1e-4, "dw_up")
+    close(dwc, pr[2].grad, 3e-2 if bf else 1e-4, "dw0")
+    close(dbu, pr[1].grad, 1e-2 if bf else 1e-4, "db_up")
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_composed_stage_head_through_ops(dt):
+    """ops.upconv_luconv_forward / _backward (the pair UpStageFn calls): act(bn(conv1(up_conv(x)))) and every gradient against torch
+    float64 autograd with training-mode batch_norm."""
+    N, D, H, W, Ci, Cm, Co = 2, 4, 4, 4, 64, 64, 32
+    bf = dt == torch.bfloat16
+    x = rnd(N, Ci, D, H, W, seed=1)
+    w_up, b_up = rnd(Ci, Cm, 2, 2, 2, seed=2, scale=0.2), rnd(Cm, seed=3, scale=0.5)
+    w0, b0 = rnd(Co, Cm, 3, 3, 3, seed=4, scale=0.1), rnd(Co, seed=5, scale=0.5)
+    gamma, beta = 1 + 0.3 * rnd(Co, seed=7), 0.3 * rnd(Co, seed=8)
+    da = rnd(N, Co, 2 * D, 2 * H, 2 * W, seed=6)
+    xq, daq = x.to(dt).double(), da.to(dt).double()
+    xr = xq.clone().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) for t in (w_up, b_up, w0, b0, gamma, beta)]
+    y = F.conv3d(F.conv_transpose3d(xr, pr[0], pr[1], stride=2), pr[2], pr[3], padding=1)
+    a_ref = torch.relu(F.batch_norm(y, None, None, pr[4], pr[5], training=True, eps=1e-5))
+    a_ref.backward(daq)
+
+    to_dev = lambda t: t.float().to(DEV).contiguous()
+    wu, bu, wc, bc, g32, be32 = (to_dev(t) for t in (w_up, b_up, w0, b0, gamma, beta))
+    rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+    comp = ops.ComposedUpConv()
+    a, sv = ops.upconv_luconv_forward(ops.to_act(xq.to(dt).to(DEV), dt), wu, bu, wc, bc, g32, be32, rm, rv, comp, ACT_RELU, dt)
+    close(a, a_ref.detach(), 3e-2 if bf else 2e-4, "activation")
+    dx, dwu, dbu, dwc, dbc, dg, dbe = ops.upconv_luconv_backward(sv, ops.to_act(daq.to(dt).to(DEV), dt), wu, bu, wc, bc, g32, comp, dt)
+    # bf16: the ReLU mask is taken from the bf16 y0; ~0.4 % of the elements sit within one rounding step of bn(y0) = 0 and flip their
+    # mask w.r.t. the float64 run, each flip moves a gradient term by O(1) -> ~sqrt(16)/sqrt(4096) = 6 % of a 4096-term sum (measured
+    # 8 %).  The float32 run (no flips) pins the algebra to 5e-4.
+    tol = 1.5e-1 if bf else 5e-4
+    close(dx, xr.grad, tol, "dx")
+    close(dwu, pr[0].grad, tol, "dw_up")
+    close(dwc, pr[2].grad, tol, "dw0")
+    close(dbu, pr[1].grad, tol, "db_up")
+    close(dg, pr[4].grad, tol, "dgamma")
+    close(dbe, pr[5].grad, tol, "dbeta")
+    assert float(dbc.abs().max()) == 0.0
