@@ -57,7 +57,24 @@ def wgrad_key(name, args):
     return key, 2.0 * N * D * H * W * 27 * Ci * Co
 
 
+def upconv_key(name, args):
+    """The composed ConvTranspose3d -> Conv3d operator (csrc/upconv_fused.hip): EXECUTED flops = 8 phases x 8 coarse taps per coarse voxel
+    (the 27-tap convolution over the upsampled tensor it replaces would be 27/8 of that, plus the transposed convolution)."""
+    if name == "pcrl_upconv_fwd":       # (x, wf, tab, y0, stats, N, D, H, W, Ci, Co, dtype, stream)
+        N, D, H, W, Ci, Co, dt = args[5:12]
+        key = "igemm_kernel<%s,upconv_fwd>" % ("bf16" if dt == 1 else "f32")
+    elif name == "pcrl_upconv_dgrad":   # (dy0, wd, dx, N, D, H, W, Ci, Co, dtype, stream)
+        N, D, H, W, Ci, Co, dt = args[3:10]
+        key = "igemm_kernel<%s,upconv_dgrad>" % ("bf16" if dt == 1 else "f32")
+    else:                               # pcrl_upconv_wgrad(x, dy0, w_up, b_up, w0, dw_up, db_up, dw0, ws, ws_bytes, N, D, H, W, Ci, Cm, Co, dtype, stream)
+        N, D, H, W, Ci, _cm, Co, dt = args[10:18]
+        key = "wgrad_kernel<%s,upconv>(+chain rule)" % ("bf16" if dt == 1 else "f32")
+    return key, 2.0 * N * D * H * W * 64 * Ci * Co
+
+
 def keyfn(name, args):
+    if name.startswith("pcrl_upconv"):
+        return upconv_key(name, args)
     return conv_key(name, args) if name.startswith("pcrl_conv3d_k3_fwd") else wgrad_key(name, args)
 
 
@@ -190,7 +207,8 @@ def main():
         L.debug_set_wgrad_impl(int(os.environ["PCRL_DEBUG_WGRAD_IMPL"]))
     for _ in range(args.warmup):
         train_step(model, opt, batch, 0, crit, cosine, guard=False)
-    prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad"}, keyfn)
+    prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad",
+                               "pcrl_upconv_wgrad"}, keyfn)
     import gc
     gc.collect()
     if os.environ.get("PCRL_BENCH_NOGC", "0") == "1":

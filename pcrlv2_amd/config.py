@@ -49,3 +49,8 @@ FOLD_POOL_GRAD = os.environ.get("PCRL_FOLD_POOL_GRAD", "1") != "0"
 # stage end) or its global average pool (UpTransition) -- instead of a second kernel re-reading the activation it just wrote
 # (pcrl_bn_act_apply_pool / pcrl_bn_act_apply_gap).  PCRL_FUSE_APPLY_CONSUMERS=0: separate kernels (A/B switch; results are bit-identical).
 FUSE_APPLY_CONSUMERS = os.environ.get("PCRL_FUSE_APPLY_CONSUMERS", "1") != "0"
+
+# UpTransition: up_conv (ConvTranspose3d k2 s2) and ops.0.conv1 (3x3x3) are applied back to back (pcrlv2_model_3d.py:64) -- composed into
+# one 8-tap operator on the coarse grid (csrc/upconv_fused.hip): 0.30 of the multiply-adds of the 27-tap convolution over the upsampled
+# tensor, which is never formed.  Training-mode BatchNorm route only.  PCRL_COMPOSE_UPCONV=0: the two separate kernels (A/B switch).
+COMPOSE_UPCONV = os.environ.get("PCRL_COMPOSE_UPCONV", "1") != "0"

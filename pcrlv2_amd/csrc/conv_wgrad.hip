@@ -426,7 +426,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradParams p) {
 //  touches 64 different 128-byte lines for 1 KB of data; the pass is bound by line requests, not by load latency.]
 constexpr int RED_IJ = 16;
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out,
-                                                           int splits, int taps, int Cu, int Cv, int Cv_out) {
+                                                           int splits, int taps, int Cu, int Cv, int Cv_out, bool accumulate = false) {
   __shared__ float tile[RED_IJ * 64];
   __shared__ double part[256];
   const int64_t per = (int64_t)Cu * Cv;
@@ -470,14 +470,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
   __syncthreads();
   const int64_t base = ij0 * taps, lim = n_out * taps;
   for (int k = threadIdx.x; k < npairs; k += 256)
-    if (base + k < lim) out[base + k] = tile[k];
+    if (base + k < lim) out[base + k] = accumulate ? out[base + k] + tile[k] : tile[k];
 }
 
-// every weight-gradient path ends here
-int launch_wgrad_reduce(const float* ws, float* out, int splits, int taps, int Cu, int Cv, int Cv_out, hipStream_t stream) {
+// every weight-gradient path ends here (`accumulate`: out += the sum, for gradients gathered over several passes)
+int launch_wgrad_reduce(const float* ws, float* out, int splits, int taps, int Cu, int Cv, int Cv_out, hipStream_t stream, bool accumulate = false) {
   if (taps < 1 || taps > 64) return pcrl_fail(PCRL_EINVAL, "wgrad_reduce: %d taps", taps);
   const int blocks = (int)(((int64_t)Cu * Cv_out + RED_IJ - 1) / RED_IJ);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, out, splits, taps, Cu, Cv, Cv_out);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, out, splits, taps, Cu, Cv, Cv_out, accumulate);
   return pcrl_check_launch("wgrad_reduce");
 }
 
@@ -825,6 +825,143 @@ __global__ void __launch_bounds__(256, 2) wgrad_up2_alltaps_kernel(const WgradPa
   }
 }
 
+// WG_UPC with the eight coarse taps of a phase in ONE block: the U tile (dy0 at the phase's fine voxels) is staged once per K-step and
+// multiplied against the eight shifted x tiles (128 MFMAs per nine staged tiles; the one-tap-per-block form above stages two tiles per
+// 16 MFMAs and ran at 150-190 TFLOP/s).  Block = 64 (co) x 64 (ci) tile of one phase and one voxel split; grid (tiles, 8 phases, splits);
+// slabs ws[split][p * 8 + q][Cu][Cv] as wgrad_kernel writes them.
+template <typename T, bool TR>
+__global__ void __launch_bounds__(256) wgrad_upc8_kernel(const WgradParams p) {
+  using WT = WTile<T>;
+  using WF = WFrag<T, TR>;
+  constexpr int KS = 32;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int CPR = WT::ROWB / 16;  // 8 / 16
+  constexpr int RPP = 256 / CPR;      // 32 / 16
+  constexpr int NP = KS / RPP;        // 1 / 2
+  constexpr int TILE_BYTES = KS * WT::ROWB;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][U, V0..V7]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wi = wid >> 1, wj = wid & 1;
+  const int ntj = (p.Cv + 63) / 64;
+  const int i0 = (blockIdx.x / ntj) * 64, j0 = (blockIdx.x % ntj) * 64;
+  const int ph = blockIdx.y;
+  const int pd = (ph >> 2) & 1, phh = (ph >> 1) & 1, pw = ph & 1;
+  const int64_t mbeg = (int64_t)blockIdx.z * p.chunk;
+  const int64_t mend = (mbeg + p.chunk < p.M) ? (mbeg + p.chunk) : p.M;
+  const T* __restrict__ U = reinterpret_cast<const T*>(p.u);
+  const T* __restrict__ V = reinterpret_cast<const T*>(p.v);
+  const Dims g = p.g;
+  const int chunk16 = tid % CPR, rowp = tid / CPR;
+  const int ucol = chunk16 * VEC;
+  const bool u_ok = (i0 + ucol) < p.Cu, v_ok = (j0 + ucol) < p.Cv;
+  const int ucol_u = u_ok ? ucol : 0, vcol = j0 + (v_ok ? ucol : 0);
+
+  f32x4 acc[8][2][2];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[q][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int cn[NP], cd[NP], ch[NP], cw[NP];
+  int64_t cm[NP];
+  const int sw = KS % g.W, sh = (KS / g.W) % g.H, sd = (KS / (g.W * g.H)) % g.D, sn = KS / (g.W * g.H * g.D);
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    cm[ps] = mbeg + ps * RPP + rowp;
+    const int64_t mc = cm[ps] < p.M ? cm[ps] : 0;
+    decode_voxel(mc, g, cn[ps], cd[ps], ch[ps], cw[ps]);
+  }
+  u32x4 ru[NP], rv[8][NP];
+  uint32_t uokb = 0, vokb = 0;   // vokb: bit q * NP + ps
+#define W8_LOAD()                                                                                 \
+  do {                                                                                            \
+    uokb = 0;                                                                                     \
+    vokb = 0;                                                                                     \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                           \
+      const bool live = cm[ps] < mend;                                                            \
+      const int n_ = live ? cn[ps] : 0, d_ = live ? cd[ps] : 0, h_ = live ? ch[ps] : 0, w_ = live ? cw[ps] : 0; \
+      const int64_t urow = (((int64_t)n_ * (2 * g.D) + 2 * d_ + pd) * (2 * g.H) + 2 * h_ + phh) * (2 * g.W) + 2 * w_ + pw; \
+      ru[ps] = *reinterpret_cast<const u32x4*>(U + urow * p.Cu + i0 + ucol_u);                    \
+      uokb |= (uint32_t)(live && u_ok) << ps;                                                     \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q) {                                             \
+        const int dd = d_ + pd - 1 + (q >> 2), hh = h_ + phh - 1 + ((q >> 1) & 1), ww = w_ + pw - 1 + (q & 1); \
+        const bool in = live && (unsigned)dd < (unsigned)g.D && (unsigned)hh < (unsigned)g.H && (unsigned)ww < (unsigned)g.W; \
+        const int64_t vrow = in ? (((int64_t)n_ * g.D + dd) * g.H + hh) * g.W + ww : (int64_t)0;  \
+        rv[q][ps] = *reinterpret_cast<const u32x4*>(V + vrow * p.Cv + vcol);                      \
+        vokb |= (uint32_t)(in && v_ok) << (q * NP + ps);                                          \
+      }                                                                                           \
+      cm[ps] += KS;                                                                               \
+      cw[ps] += sw;                                                                               \
+      if (cw[ps] >= g.W) { cw[ps] -= g.W; ch[ps] += 1; }                                          \
+      ch[ps] += sh;                                                                               \
+      if (ch[ps] >= g.H) { ch[ps] -= g.H; cd[ps] += 1; }                                          \
+      cd[ps] += sd;                                                                               \
+      if (cd[ps] >= g.D) { cd[ps] -= g.D; cn[ps] += 1; }                                          \
+      cn[ps] += sn;                                                                               \
+    }                                                                                             \
+  } while (0)
+#define W8_STORE(buf_)                                                                            \
+  do {                                                                                            \
+    char* base_ = smem + (buf_) * (9 * TILE_BYTES);                                               \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                           \
+      const int row = ps * RPP + rowp;                                                            \
+      *reinterpret_cast<u32x4*>(base_ + WT::off(row, ucol)) = keep_if((uokb >> ps) & 1u, ru[ps]); \
+      _Pragma("unroll") for (int q = 0; q < 8; ++q)                                               \
+        *reinterpret_cast<u32x4*>(base_ + (1 + q) * TILE_BYTES + WT::off(row, ucol)) = keep_if((vokb >> (q * NP + ps)) & 1u, rv[q][ps]); \
+    }                                                                                             \
+  } while (0)
+
+  const int64_t nsteps = (mend > mbeg) ? (mend - mbeg + KS - 1) / KS : 0;
+  if (nsteps > 0) {
+    W8_LOAD();
+    W8_STORE(0);
+  }
+  __syncthreads();
+  for (int64_t s = 0; s < nsteps; ++s) {
+    const int cur = (int)(s & 1);
+    W8_LOAD();   // the last iteration stages rows past `mend`: dead, zeroed at the LDS store
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const char* base = smem + cur * (9 * TILE_BYTES);
+      typename WF::Frag fa[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = WF::read(base, wi * 32 + a * 16, lane);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        typename WF::Frag fb[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[b] = WF::read(base + (1 + q) * TILE_BYTES, wj * 32 + b * 16, lane);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) WF::mma(fa[a], fb[b], acc[q][a][b]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    W8_STORE(cur ^ 1);
+    __syncthreads();
+  }
+#undef W8_LOAD
+#undef W8_STORE
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    float* __restrict__ out = p.ws + ((int64_t)blockIdx.z * p.taps + ph * 8 + q) * (int64_t)p.Cu * p.Cv;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = i0 + wi * 32 + a * 16 + (lane >> 4) * 4 + r;
+          const int j = j0 + wj * 32 + b * 16 + (lane & 15);
+          if (i < p.Cu && j < p.Cv) out[(int64_t)i * p.Cv + j] = acc[q][a][b][r];
+        }
+  }
+}
+
 // split plan of the all-taps kernel: whole rounds of 512 blocks (2 per CU), at least 16 K-steps per block
 SplitPlanUp2 plan_up2(int64_t M, int Cu, int Cv) {
   const int64_t tiles = (int64_t)(Cu / 64) * (Cv / 64);
@@ -928,13 +1065,46 @@ extern "C" void pcrl_debug_set_wgrad_impl(int impl) {
 
 // ---- fused ConvTranspose3d(k2,s2) -> Conv3d(3x3x3): gradient of the COMPOSED weights (internal; the C ABI is in upconv_fused.hip) ----
 // dweff[co][ci][t], t = phase * 8 + coarse tap = sum over coarse voxels v of dy0[2v + p][co] * x[v + p - 1 + q][ci]
+static SplitPlan plan_upc8(int64_t M, int Cu, int Cv) {
+  const int64_t tiles = (int64_t)((Cu + 63) / 64) * ((Cv + 63) / 64) * 8;
+  const int64_t steps = (M + 31) / 32;
+  int64_t splits = 1024 / tiles;
+  if (splits < 1) splits = 1;
+  const int64_t max_splits = (steps + 7) / 8;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int64_t per = (steps + splits - 1) / splits;
+  splits = (steps + per - 1) / per;
+  return SplitPlan{(int)splits, per * 32};
+}
 size_t pcrl_upc_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
-  const SplitPlan sp = plan_splits((int64_t)N * D * H * W, Co, Ci, 64);
+  const SplitPlan sp = plan_upc8((int64_t)N * D * H * W, Co, Ci);
   return (size_t)sp.splits * 64 * Co * Ci * sizeof(float);
 }
 int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
-                          int dtype, hipStream_t stream) {
-  return run_wgrad<WG_UPC>(dy0, x, dweff, ws, ws_bytes, Dims{N, D, H, W}, Co, Ci, 64, dtype, stream);
+                          int dtype, hipStream_t stream, bool accumulate) {
+  const int64_t M = (int64_t)N * D * H * W;
+  const SplitPlan sp = plan_upc8(M, Co, Ci);
+  const size_t need = (size_t)sp.splits * 64 * Co * Ci * sizeof(float);
+  if (ws_bytes < need || !ws) return pcrl_fail(PCRL_EWORKSPACE, "upconv wgrad: workspace %zu < %zu", ws_bytes, need);
+  WgradParams p{dy0, x, (float*)ws, Dims{N, D, H, W}, M, Co, Ci, 64, sp.chunk, Wg2d{0, 0, 1, 1, 0, 0, 1, 1}};
+  const dim3 grid((unsigned)(((Co + 63) / 64) * ((Ci + 63) / 64)), 8, (unsigned)sp.splits);
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_upc8_kernel<bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 9 * 32 * 128);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_upc8_kernel<bf16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 9 * 32 * 128);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_upc8_kernel<float, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 9 * 32 * 256);
+  });
+  if (dtype == PCRL_BF16) {
+    if (g_wgrad_tr) hipLaunchKernelGGL((wgrad_upc8_kernel<bf16, true>), grid, dim3(256), 2 * 9 * 32 * 128, stream, p);
+    else hipLaunchKernelGGL((wgrad_upc8_kernel<bf16, false>), grid, dim3(256), 2 * 9 * 32 * 128, stream, p);
+  } else if (dtype == PCRL_F32) {
+    hipLaunchKernelGGL((wgrad_upc8_kernel<float, false>), grid, dim3(256), 2 * 9 * 32 * 256, stream, p);
+  } else {
+    return pcrl_fail(PCRL_EINVAL, "upconv wgrad: bad dtype %d", dtype);
+  }
+  if (int e = pcrl_check_launch("upconv wgrad")) return e;
+  return launch_wgrad_reduce((const float*)ws, dweff, sp.splits, 64, Co, Ci, Ci, stream, accumulate);
 }
 
 extern "C" size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {

@@ -31,7 +31,7 @@ int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, int N, int 
 int pcrl_gemm_planes_launch(const void* a, const void* b, float* z, int64_t M, int K, int Nc, int dtype, hipStream_t stream);
 size_t pcrl_upc_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co);
 int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
-                          int dtype, hipStream_t stream);
+                          int dtype, hipStream_t stream, bool accumulate);
 
 namespace {
 
@@ -113,21 +113,31 @@ __global__ void __launch_bounds__(256) upc_pack_kernel(const float* __restrict__
   }
 }
 
-// bias_tab[cls][co] = b0[co] + sum over the taps t inside the grid for class cls of sum_cm w0[co][cm][t] * b_up[cm]
+// bias_tab[cls][co] = b0[co] + sum over the taps t inside the grid for class cls of wb[co][t],  wb[co][t] = sum_cm w0[co][cm][t] * b_up[cm].
+// Block = one co: lane t < 27 of the eight 32-lane groups walks cm (the 27 taps of a (co, cm) are contiguous: coalesced), LDS combine.
 __global__ void __launch_bounds__(256) upc_bias_kernel(const float* __restrict__ w0, const float* __restrict__ b_up, const float* __restrict__ b0,
                                                        float* __restrict__ tab, int Cm, int Co) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 27 * Co) return;
-  const int co = i % Co, cls = i / Co;
-  const int cd = cls / 9, ch = (cls / 3) % 3, cw = cls % 3;
-  double acc = b0 ? (double)b0[co] : 0.0;
-  for (int t = 0; t < 27; ++t) {
-    if (!tap_in(t / 9, cd) || !tap_in((t / 3) % 3, ch) || !tap_in(t % 3, cw)) continue;
-    double s = 0.0;
-    for (int cm = 0; cm < Cm; ++cm) s += (double)w0[((int64_t)co * Cm + cm) * 27 + t] * (double)b_up[cm];
-    acc += s;
+  __shared__ double part[8][32];
+  __shared__ double wb[27];
+  const int co = blockIdx.x, t = threadIdx.x & 31, g = threadIdx.x >> 5;
+  double a = 0.0;
+  if (t < 27)
+    for (int cm = g; cm < Cm; cm += 8) a += (double)w0[((int64_t)co * Cm + cm) * 27 + t] * (double)b_up[cm];
+  part[g][t] = a;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    double v = 0.0;
+    for (int k = 0; k < 8; ++k) v += part[k][threadIdx.x];
+    wb[threadIdx.x] = v;
   }
-  tab[i] = (float)acc;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int cls = threadIdx.x, cd = cls / 9, ch = (cls / 3) % 3, cw = cls % 3;
+    double acc = b0 ? (double)b0[co] : 0.0;
+    for (int tt = 0; tt < 27; ++tt)
+      if (tap_in(tt / 9, cd) && tap_in((tt / 3) % 3, ch) && tap_in(tt % 3, cw)) acc += wb[tt];
+    tab[cls * Co + co] = (float)acc;
+  }
 }
 
 // dweff[co][ci][pq] (float32) -> a1[(t*Co+co)][(s*Ci+ci)] and a2[(s*Ci+ci)][(t*Co+co)], value dWeff[pq(t,s)][ci][co]
@@ -205,27 +215,40 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
     }
   }
 }
-// S[cls][co] = sum over the planes of class cd of part[plane][ch*3+cw][co]   (planes = N * FD, plane = n * FD + fd)
-__global__ void __launch_bounds__(256) upc_class_total_kernel(const float* __restrict__ part, float* __restrict__ S, int N, int FD, int C) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 27 * C) return;
-  const int co = i % C, cls = i / C, cd = cls / 9, k9 = cls % 9;
-  double a = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const int f0 = cd == 0 ? 0 : (cd == 2 ? FD - 1 : 1), f1 = cd == 0 ? 1 : (cd == 2 ? FD : FD - 1);
-    for (int fd = f0; fd < f1; ++fd) a += (double)part[(((int64_t)n * FD + fd) * 9 + k9) * C + co];
+// S[cls][co] = sum over the planes of class cd of part[plane][ch*3+cw][co]   (planes = N * FD, plane = n * FD + fd).
+// Block = (k9, 64 channels) x cd: 16 groups of 64 lanes walk the class's planes four at a time (the plane count reaches thousands: a
+// single chain of dependent loads took 320 us), combined in group order through LDS.
+__global__ void __launch_bounds__(1024) upc_class_total_kernel(const float* __restrict__ part, float* __restrict__ S, int N, int FD, int C) {
+  __shared__ double red[16][64];
+  const int cb = C / 64 > 0 ? (C + 63) / 64 : 1;
+  const int k9 = blockIdx.x / cb, co = (blockIdx.x % cb) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, cd = blockIdx.y;
+  const int f0 = cd == 0 ? 0 : (cd == 2 ? FD - 1 : 1), f1 = cd == 0 ? 1 : (cd == 2 ? FD : FD - 1);
+  const int nf = f1 > f0 ? f1 - f0 : 0;
+  const int64_t cnt = (int64_t)N * nf;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (co < C) {
+    auto at = [&](int64_t j) { return (double)part[((((j / nf) * FD) + f0 + (j % nf)) * 9 + k9) * C + co]; };
+    int64_t j = g;
+    for (; j + 48 < cnt; j += 64) { a0 += at(j); a1 += at(j + 16); a2 += at(j + 32); a3 += at(j + 48); }
+    for (; j < cnt; j += 16) a0 += at(j);
   }
-  S[i] = (float)a;
+  red[g][threadIdx.x & 63] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0 && co < C) {
+    double v = 0.0;
+    for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
+    S[(cd * 9 + k9) * C + co] = (float)v;
+  }
 }
 // box[t][co] = sum over the classes for which tap t is inside the grid of S[cls][co]
-__global__ void __launch_bounds__(256) upc_box_kernel(const float* __restrict__ S, float* __restrict__ box, int Co) {
+__global__ void __launch_bounds__(256) upc_box_kernel(const float* __restrict__ S, float* __restrict__ box, int Co, bool accumulate) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 27 * Co) return;
   const int co = i % Co, t = i / Co;
   double st = 0.0;
   for (int cls = 0; cls < 27; ++cls)
     if (tap_in(t / 9, cls / 9) && tap_in((t / 3) % 3, (cls / 3) % 3) && tap_in(t % 3, cls % 3)) st += (double)S[cls * Co + co];
-  box[i] = (float)st;
+  box[i] = accumulate ? box[i] + (float)st : (float)st;
 }
 // db_up[cm] = sum_t sum_co w0[co][cm][t] * box[t][co];  block = cm
 __global__ void __launch_bounds__(256) upc_dbup_kernel(const float* __restrict__ w0, const float* __restrict__ box, float* __restrict__ db_up, int Cm,
@@ -283,7 +306,7 @@ extern "C" int pcrl_upconv_compose(const float* w_up, const float* b_up, const f
   if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_pack_kernel<bf16>, dim3(gp), dim3(256), 0, st, (const float*)P, (bf16*)wf, (bf16*)wd, Ci, Co);
   else hipLaunchKernelGGL(upc_pack_kernel<float>, dim3(gp), dim3(256), 0, st, (const float*)P, (float*)wf, (float*)wd, Ci, Co);
   if (int e = pcrl_check_launch("upconv_compose (pack)")) return e;
-  hipLaunchKernelGGL(upc_bias_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, w0, b_up, b0, bias_tab, Cm, Co);
+  hipLaunchKernelGGL(upc_bias_kernel, dim3(Co), dim3(256), 0, st, w0, b_up, b0, bias_tab, Cm, Co);
   return pcrl_check_launch("upconv_compose (bias)");
 }
 
@@ -305,70 +328,107 @@ extern "C" int pcrl_upconv_dgrad(const void* dy0, const void* wd, void* dx, int 
 }
 
 // ---- parameter gradients ----
+// Two stages, because both are LINEAR in (dWeff, box sums): `accum` runs once per backward pass and adds that pass's gradient of the
+// composed weights and its border-class sums of dy0 to two small persistent buffers; `finish` runs the chain rule to the reference
+// parameters once, after the last pass (three passes share the weights in a pre-training step: the weight-sized GEMMs run once).
 namespace {
-struct WgLayout {
-  size_t dweff, wg, a1, a2, b1, b2, z1, z2, part, S, box, total;
+struct AccLayout {
+  size_t wg, part, S, total;
 };
-WgLayout wg_layout(int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype) {
-  WgLayout L;
+AccLayout acc_layout(int N, int D, int H, int W, int Ci, int Co) {
+  AccLayout L;
   size_t o = 0;
-  L.dweff = o; o += al((size_t)64 * Co * Ci * sizeof(float));
   L.wg = o;    o += al(pcrl_upc_wgrad_ws_bytes(N, D, H, W, Ci, Co));
+  L.part = o;  o += al((size_t)N * 2 * D * 9 * Co * sizeof(float));
+  L.S = o;     o += al((size_t)27 * Co * sizeof(float));
+  L.total = o;
+  return L;
+}
+struct FinLayout {
+  size_t a1, a2, b1, b2, z1, z2, total;
+};
+FinLayout fin_layout(int Ci, int Cm, int Co, int dtype) {
+  FinLayout L;
+  size_t o = 0;
   L.a1 = o;    o += al((size_t)27 * Co * 8 * Ci * esz(dtype));
   L.a2 = o;    o += al((size_t)27 * Co * 8 * Ci * esz(dtype));
   L.b1 = o;    o += al((size_t)Cm * 8 * Ci * esz(dtype));
   L.b2 = o;    o += al((size_t)Cm * 27 * Co * esz(dtype));
   L.z1 = o;    o += al((size_t)Cm * 27 * Co * sizeof(float));
   L.z2 = o;    o += al((size_t)Cm * 8 * Ci * sizeof(float));
-  L.part = o;  o += al((size_t)N * 2 * D * 9 * Co * sizeof(float));
-  L.S = o;     o += al((size_t)27 * Co * sizeof(float));
-  L.box = o;   o += al((size_t)27 * Co * sizeof(float));
   L.total = o;
   return L;
 }
 }  // namespace
+extern "C" size_t pcrl_upconv_wgrad_accum_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
+  return acc_layout(N, D, H, W, Ci, Co).total;
+}
+// dweff_acc: float32 [Co][Ci][64]; box_acc: float32 [27][Co]; first != 0: store, else add
+extern "C" int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* box_acc, int first, void* ws, size_t ws_bytes, int N,
+                                       int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  if (int e = check_upc("upconv_wgrad_accum", N, D, H, W, Ci, 32, Co, dtype)) return e;
+  PCRL_REQUIRE(x && dy0 && dweff_acc && box_acc, "upconv_wgrad_accum: null pointer");
+  const AccLayout L = acc_layout(N, D, H, W, Ci, Co);
+  if (!ws || ws_bytes < L.total) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad_accum: workspace %zu < %zu", ws_bytes, L.total);
+  hipStream_t st = as_stream(stream);
+  char* w = (char*)ws;
+  if (int e = pcrl_upc_wgrad_launch(dy0, x, dweff_acc, w + L.wg, pcrl_upc_wgrad_ws_bytes(N, D, H, W, Ci, Co), N, D, H, W, Ci, Co, dtype, st, first == 0)) return e;
+  const int vec = dtype == PCRL_BF16 ? 8 : 4;
+  if (Co % vec != 0 || (Co / vec) > 256 || 256 % (Co / vec) != 0) return pcrl_fail(PCRL_EINVAL, "upconv_wgrad_accum: Co=%d not supported by the class-sum kernel", Co);
+  const size_t lds = (size_t)(256 / (Co / vec)) * Co * sizeof(float);
+  float* part = (float*)(w + L.part);
+  float* S = (float*)(w + L.S);
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_class_sums_kernel<bf16>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const bf16*)dy0, part, 2 * H, 2 * W, Co);
+  else hipLaunchKernelGGL(upc_class_sums_kernel<float>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const float*)dy0, part, 2 * H, 2 * W, Co);
+  hipLaunchKernelGGL(upc_class_total_kernel, dim3((unsigned)(9 * ((Co + 63) / 64)), 3), dim3(1024), 0, st, (const float*)part, S, N, 2 * D, Co);
+  hipLaunchKernelGGL(upc_box_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)S, box_acc, Co, first == 0);
+  return pcrl_check_launch("upconv_wgrad_accum");
+}
+extern "C" size_t pcrl_upconv_wgrad_finish_ws_bytes(int Ci, int Cm, int Co, int dtype) {
+  if (Ci <= 0 || Cm <= 0 || Co <= 0) return 0;
+  return fin_layout(Ci, Cm, Co, dtype).total;
+}
+extern "C" int pcrl_upconv_wgrad_finish(const float* dweff_acc, const float* box_acc, const float* w_up, const float* b_up, const float* w0, float* dw_up,
+                                        float* db_up, float* dw0, void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream) {
+  if (int e = check_upc("upconv_wgrad_finish", 1, 1, 1, 1, Ci, Cm, Co, dtype)) return e;
+  PCRL_REQUIRE(dweff_acc && box_acc && w_up && b_up && w0 && dw_up && db_up && dw0, "upconv_wgrad_finish: null pointer");
+  const FinLayout L = fin_layout(Ci, Cm, Co, dtype);
+  if (!ws || ws_bytes < L.total) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad_finish: workspace %zu < %zu", ws_bytes, L.total);
+  hipStream_t st = as_stream(stream);
+  char* w = (char*)ws;
+  const unsigned gpre = blocks_for((int64_t)27 * Co * Cm + (int64_t)8 * Ci * Cm), gpk = blocks_for((int64_t)216 * Ci * Co);
+  if (dtype == PCRL_BF16) {
+    hipLaunchKernelGGL(upc_prep_kernel<bf16>, dim3(gpre), dim3(256), 0, st, w_up, w0, (bf16*)nullptr, (bf16*)nullptr, (bf16*)(w + L.b1), (bf16*)(w + L.b2), Ci, Cm, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<bf16>, dim3(gpk), dim3(256), 0, st, dweff_acc, (bf16*)(w + L.a1), (bf16*)(w + L.a2), Ci, Co);
+  } else {
+    hipLaunchKernelGGL(upc_prep_kernel<float>, dim3(gpre), dim3(256), 0, st, w_up, w0, (float*)nullptr, (float*)nullptr, (float*)(w + L.b1), (float*)(w + L.b2), Ci, Cm, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<float>, dim3(gpk), dim3(256), 0, st, dweff_acc, (float*)(w + L.a1), (float*)(w + L.a2), Ci, Co);
+  }
+  if (int e = pcrl_check_launch("upconv_wgrad_finish (pack)")) return e;
+  if (int e = pcrl_gemm_planes_launch(w + L.a1, w + L.b1, (float*)(w + L.z1), (int64_t)27 * Co, 8 * Ci, Cm, dtype, st)) return e;   // z1[cm][(t,co)]
+  if (int e = pcrl_gemm_planes_launch(w + L.a2, w + L.b2, (float*)(w + L.z2), (int64_t)8 * Ci, 27 * Co, Cm, dtype, st)) return e;   // z2[cm][(s,ci)]
+  hipLaunchKernelGGL(upc_dbup_kernel, dim3(Cm), dim3(256), 0, st, w0, box_acc, db_up, Cm, Co);
+  hipLaunchKernelGGL(upc_chain_unpack_kernel, dim3(gpre), dim3(256), 0, st, (const float*)(w + L.z1), (const float*)(w + L.z2), b_up, box_acc, dw0, dw_up, Ci, Cm,
+                     Co);
+  return pcrl_check_launch("upconv_wgrad_finish");
+}
+// both stages for one pass (dweff / box scratch inside ws)
 extern "C" size_t pcrl_upconv_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Cm <= 0 || Co <= 0) return 0;
-  return wg_layout(N, D, H, W, Ci, Cm, Co, dtype).total;
+  const size_t a = acc_layout(N, D, H, W, Ci, Co).total, f = fin_layout(Ci, Cm, Co, dtype).total;
+  return al((size_t)64 * Co * Ci * sizeof(float)) + al((size_t)27 * Co * sizeof(float)) + (a > f ? a : f);
 }
 extern "C" int pcrl_upconv_wgrad(const void* x, const void* dy0, const float* w_up, const float* b_up, const float* w0, float* dw_up, float* db_up,
                                  float* dw0, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype,
                                  pcrl_stream_t stream) {
   if (int e = check_upc("upconv_wgrad", N, D, H, W, Ci, Cm, Co, dtype)) return e;
-  PCRL_REQUIRE(x && dy0 && w_up && b_up && w0 && dw_up && db_up && dw0, "upconv_wgrad: null pointer");
-  const WgLayout L = wg_layout(N, D, H, W, Ci, Cm, Co, dtype);
-  if (!ws || ws_bytes < L.total) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad: workspace %zu < %zu", ws_bytes, L.total);
-  hipStream_t st = as_stream(stream);
+  if (!ws || ws_bytes < pcrl_upconv_wgrad_ws_bytes(N, D, H, W, Ci, Cm, Co, dtype)) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad: workspace too small");
   char* w = (char*)ws;
-  float* dweff = (float*)(w + L.dweff);
-  // (1) gradient of the composed weights: dweff[co][ci][p*8+q]
-  if (int e = pcrl_upc_wgrad_launch(dy0, x, dweff, w + L.wg, pcrl_upc_wgrad_ws_bytes(N, D, H, W, Ci, Co), N, D, H, W, Ci, Co, dtype, st)) return e;
-  // (2) chain rule to the two reference parameters: two GEMMs over the weight-sized operands
-  const unsigned gpre = blocks_for((int64_t)27 * Co * Cm + (int64_t)8 * Ci * Cm), gpk = blocks_for((int64_t)216 * Ci * Co);
-  if (dtype == PCRL_BF16) {
-    hipLaunchKernelGGL(upc_prep_kernel<bf16>, dim3(gpre), dim3(256), 0, st, w_up, w0, (bf16*)nullptr, (bf16*)nullptr, (bf16*)(w + L.b1), (bf16*)(w + L.b2), Ci, Cm, Co);
-    hipLaunchKernelGGL(upc_chain_pack_kernel<bf16>, dim3(gpk), dim3(256), 0, st, (const float*)dweff, (bf16*)(w + L.a1), (bf16*)(w + L.a2), Ci, Co);
-  } else {
-    hipLaunchKernelGGL(upc_prep_kernel<float>, dim3(gpre), dim3(256), 0, st, w_up, w0, (float*)nullptr, (float*)nullptr, (float*)(w + L.b1), (float*)(w + L.b2), Ci, Cm, Co);
-    hipLaunchKernelGGL(upc_chain_pack_kernel<float>, dim3(gpk), dim3(256), 0, st, (const float*)dweff, (float*)(w + L.a1), (float*)(w + L.a2), Ci, Co);
-  }
-  if (int e = pcrl_check_launch("upconv_wgrad (pack)")) return e;
-  if (int e = pcrl_gemm_planes_launch(w + L.a1, w + L.b1, (float*)(w + L.z1), (int64_t)27 * Co, 8 * Ci, Cm, dtype, st)) return e;   // z1[cm][(t,co)]
-  if (int e = pcrl_gemm_planes_launch(w + L.a2, w + L.b2, (float*)(w + L.z2), (int64_t)8 * Ci, 27 * Co, Cm, dtype, st)) return e;   // z2[cm][(s,ci)]
-  // (3) border-class sums of dy0 -> box sums: the transposed convolution's bias enters `up`, hence dW0, and has its own gradient
-  const int vec = dtype == PCRL_BF16 ? 8 : 4;
-  if (Co % vec != 0 || (Co / vec) > 256 || 256 % (Co / vec) != 0) return pcrl_fail(PCRL_EINVAL, "upconv_wgrad: Co=%d not supported by the class-sum kernel", Co);
-  const size_t lds = (size_t)(256 / (Co / vec)) * Co * sizeof(float);
-  float* part = (float*)(w + L.part);
-  float* S = (float*)(w + L.S);
-  float* box = (float*)(w + L.box);
-  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_class_sums_kernel<bf16>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const bf16*)dy0, part, 2 * H, 2 * W, Co);
-  else hipLaunchKernelGGL(upc_class_sums_kernel<float>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const float*)dy0, part, 2 * H, 2 * W, Co);
-  hipLaunchKernelGGL(upc_class_total_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)part, S, N, 2 * D, Co);
-  hipLaunchKernelGGL(upc_box_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)S, box, Co);
-  hipLaunchKernelGGL(upc_dbup_kernel, dim3(Cm), dim3(256), 0, st, w0, (const float*)box, db_up, Cm, Co);
-  if (int e = pcrl_check_launch("upconv_wgrad (bias)")) return e;
-  hipLaunchKernelGGL(upc_chain_unpack_kernel, dim3(gpre), dim3(256), 0, st, (const float*)(w + L.z1), (const float*)(w + L.z2), b_up, (const float*)box, dw0,
-                     dw_up, Ci, Cm, Co);
-  return pcrl_check_launch("upconv_wgrad (unpack)");
+  float* dweff = (float*)w;
+  float* box = (float*)(w + al((size_t)64 * Co * Ci * sizeof(float)));
+  char* rest = (char*)box + al((size_t)27 * Co * sizeof(float));
+  const size_t rest_bytes = ws_bytes - (size_t)(rest - w);
+  if (int e = pcrl_upconv_wgrad_accum(x, dy0, dweff, box, 1, rest, rest_bytes, N, D, H, W, Ci, Co, dtype, stream)) return e;
+  return pcrl_upconv_wgrad_finish(dweff, box, w_up, b_up, w0, dw_up, db_up, dw0, rest, rest_bytes, Ci, Cm, Co, dtype, stream);
 }

@@ -41,10 +41,24 @@ def set_ddp_callbacks(final_callback, finalize_hook):
 def _end_of_backward():
     global _callback_queued
     _callback_queued = False
+    # composed up-conv stages (ops.ComposedUpConv): the chain rule from the accumulated gradient of the composed weights to
+    # up_conv.weight / up_conv.bias / ops.0.conv1.weight runs once per backward() call, here
+    for p, g in ops.deliver_composed():
+        if p.requires_grad:
+            _parked.setdefault(id(p), (p, []))[1].append(g)
+            if _final_callback is not None:
+                _final_callback(p)
     if _finalize_hook is not None:
         _finalize_hook()
     else:
         flush_param_grads()
+
+
+def _queue_end_of_backward():
+    global _callback_queued
+    if not _callback_queued:
+        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
+        _callback_queued = True
 
 
 def _park(p, g):
@@ -58,9 +72,7 @@ def _park(p, g):
     if not p.requires_grad:
         return None
     _parked.setdefault(id(p), (p, []))[1].append(g)
-    if not _callback_queued:
-        torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward)
-        _callback_queued = True
+    _queue_end_of_backward()
     return None
 
 
@@ -225,11 +237,16 @@ class UpStageFn(Function):
                 dw_, db_, dg_, dbe_, mod):
         dt = mod.compute_dtype
         x = ops.to_act(x, dt)
-        up = ops.convt_forward(x, up_w, up_b, mod._packed_up, dt)
         l0, l1, ld = mod.ops[0], mod.ops[1], mod.deep_supervision_head
         gn = getattr(l0, "_gn_groups", 0)
         rs = lambda m: (None, None) if gn else (m.bn1.running_mean, m.bn1.running_var)
-        a0, sv0 = ops.luconv_forward(up, w0, b0, g0, be0, *rs(l0), l0._packed, l0._act, dt, gn_groups=gn)
+        if config.COMPOSE_UPCONV and not gn:
+            # up_conv and ops.0's conv1 are two linear maps with nothing in between (:64): one 8-tap operator on the coarse grid,
+            # the upsampled tensor is never formed (ops.upconv_luconv_forward, csrc/upconv_fused.hip)
+            a0, sv0 = ops.upconv_luconv_forward(x, up_w, up_b, w0, b0, g0, be0, *rs(l0), mod._composed_up, l0._act, dt)
+        else:
+            up = ops.convt_forward(x, up_w, up_b, mod._packed_up, dt)
+            a0, sv0 = ops.luconv_forward(up, w0, b0, g0, be0, *rs(l0), l0._packed, l0._act, dt, gn_groups=gn)
         if gn:
             a1, sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gn_groups=gn)
             g = ops.gap_forward(a1, dt)
@@ -296,16 +313,26 @@ class UpStageFn(Function):
         # ---- ops.1, ops.0 ----
         d_a0, gw1, gb1, gg1, gbe1 = ops.luconv_backward(ctx.sv1, d_a1, w1, g1, l1._packed, dt, need_dx=True, da_row_g=row_g)
         grads[7], grads[8], grads[9], grads[10] = gw1, gb1, gg1, gbe1
-        g_upb = torch.empty(up_w.shape[1], dtype=torch.float32, device=d_a0.device)
-        d_up, gw0, gb0, gg0, gbe0 = ops.luconv_backward(ctx.sv0, d_a0, w0, g0, l0._packed, dt, need_dx=True, dx_colsum=g_upb)
+        deferred = ()
+        if ctx.sv0.kind == "upc":     # composed up_conv + conv1: both layers' gradients from one set of coarse-grid passes
+            defer = config.DIRECT_PARAM_GRADS
+            dx, g_upw, g_upb, gw0, gb0, gg0, gbe0 = ops.upconv_luconv_backward(ctx.sv0, d_a0, up_w, ctx.plist[1], w0, ctx.plist[3], g0,
+                                                                               mod._composed_up, dt, need_dx=ctx.needs_input_grad[0],
+                                                                               defer=defer)
+            if defer:                 # delivered (and marked final) by _end_of_backward
+                deferred = (0, 1, 2)
+                _queue_end_of_backward()
+        else:
+            g_upb = torch.empty(up_w.shape[1], dtype=torch.float32, device=d_a0.device)
+            d_up, gw0, gb0, gg0, gbe0 = ops.luconv_backward(ctx.sv0, d_a0, w0, g0, l0._packed, dt, need_dx=True, dx_colsum=g_upb)
+            # ---- up_conv ----
+            dx, g_upw, g_upb = ops.convt_backward(ctx.x, d_up, up_w, mod._packed_up, dt, need_dx=ctx.needs_input_grad[0], db=g_upb)
         grads[3], grads[4], grads[5], grads[6] = gw0, gb0, gg0, gbe0
-        # ---- up_conv ----
-        dx, g_upw, g_upb = ops.convt_backward(ctx.x, d_up, up_w, mod._packed_up, dt, need_dx=ctx.needs_input_grad[0], db=g_upb)
         grads[0], grads[1], grads[2] = dx, g_upw, g_upb
         ctx.svd.x = None
         for k, p in enumerate(ctx.plist):
             grads[k + 1] = _park(p, grads[k + 1])
-        mark_final(ctx, ctx.plist)
+        mark_final(ctx, [p for k, p in enumerate(ctx.plist) if k not in deferred])
         return tuple(grads)
 
 

@@ -103,6 +103,7 @@ class UpTransition(nn.Module, _Counted):
         self._act = _ACTS[act]
         self.compute_dtype = config.default_compute_dtype()
         self._packed_up = ops.PackedWeights("convt")
+        self._composed_up = ops.ComposedUpConv()
         self._init_counter([self.bn, self.predictor_head[1]])
 
     def _count_batch_heads(self):

@@ -154,6 +154,7 @@ _pass_index = 0
 def begin_step():
     global _pass_index
     _pass_index = 0
+    drop_pending_composed()
 
 
 def next_pass() -> int:
@@ -486,11 +487,16 @@ def convt_backward(x, dy, w, packed: PackedWeights, dtype, need_dx=True, db=None
 # UpTransition: ConvTranspose3d(k2,s2) -> conv1 of ops.0 as one operator on the coarse grid   (models/pcrlv2_model_3d.py:64; csrc/upconv_fused.hip)
 # ----------------------------------------------------------------------------------------------
 class ComposedUpConv:
-    """Composed weights of (up_conv, ops.0.conv1), rebuilt when either parameter changed (once per optimizer step)."""
+    """Composed weights of (up_conv, ops.0.conv1), rebuilt when either parameter changed (once per optimizer step), and the
+    accumulators of their gradients: every backward pass adds its gradient of the COMPOSED weights (and the border-class sums of dy0)
+    here; the chain rule to the two reference parameters is linear in those, so it runs once per backward() call, from the engine's
+    end-of-backward callback (deliver_composed), however many forward passes shared the weights."""
 
     def __init__(self):
         self.key = None
         self.wf = self.wd = self.bias_tab = None
+        self.dweff = self.box = None
+        self.pending = None     # (w_up, b_up, w0, dtype) while accumulated gradients wait for delivery
 
     def get(self, w_up, b_up, w0, b0, dtype):
         key = (_weights_epoch, w_up._version, w_up.data_ptr(), b_up._version, w0._version, w0.data_ptr(), b0._version, dtype)
@@ -507,6 +513,59 @@ class ComposedUpConv:
                    workspace(nb, dev), nb, Ci, Cm, Co, dtype_code(dtype), s)
             self.key = key
         return self.wf, self.wd, self.bias_tab
+
+    def accumulate(self, x, dy, geom, w_up, b_up, w0, dtype):
+        """One backward pass: dweff += d(composed weights), box += border-class sums of dy (pcrl_upconv_wgrad_accum)."""
+        L, dev = lib(), x.device
+        N, D, H, W, Ci, Co = geom
+        first = self.pending is None
+        if first:
+            if self.dweff is None or self.dweff.numel() != 64 * Ci * Co or self.dweff.device != dev:
+                self.dweff, self.box = _f32(64 * Ci * Co, dev), _f32(27 * Co, dev)
+            self.pending = (w_up, b_up, w0, dtype)
+            _pending_composed.append(self)
+        nb = L.call("pcrl_upconv_wgrad_accum_ws_bytes", N, D, H, W, Ci, Co)
+        with side_wgrad(dev, x, dy) as ws:
+            L.call("pcrl_upconv_wgrad_accum", x, dy, self.dweff, self.box, 1 if first else 0, ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype),
+                   stream_handle())
+
+    def finish(self):
+        """-> (w_up, b_up, w0, dw_up, db_up, dw0) for everything accumulated since the last delivery."""
+        w_up, b_up, w0, dtype = self.pending
+        self.pending = None
+        L, dev = lib(), w_up.device
+        Ci, Cm, Co = w_up.shape[0], w_up.shape[1], w0.shape[0]
+        dw_up = torch.empty_like(w_up, dtype=torch.float32, memory_format=torch.contiguous_format)
+        dw0 = torch.empty_like(w0, dtype=torch.float32, memory_format=torch.contiguous_format)
+        db_up = _f32(Cm, dev)
+        nb = L.call("pcrl_upconv_wgrad_finish_ws_bytes", Ci, Cm, Co, dtype_code(dtype))
+        L.call("pcrl_upconv_wgrad_finish", self.dweff, self.box, w_up.detach(), b_up.detach(), w0.detach(), dw_up, db_up, dw0, workspace(nb, dev), nb,
+               Ci, Cm, Co, dtype_code(dtype), stream_handle())
+        return w_up, b_up, w0, dw_up, db_up, dw0
+
+
+_pending_composed: list = []
+
+
+def deliver_composed():
+    """End of a backward() call: run the chain rule of every composed up-conv that accumulated gradients in it.
+    -> [(parameter, gradient), ...] for up_conv.weight, up_conv.bias and ops.0.conv1.weight of each."""
+    out = []
+    if _pending_composed:
+        join_side_stream()        # the accumulations may have run on the weight-gradient side stream
+        for c in _pending_composed:
+            if c.pending is not None:
+                w_up, b_up, w0, dw_up, db_up, dw0 = c.finish()
+                out += [(w_up, dw_up), (b_up, db_up), (w0, dw0)]
+        _pending_composed.clear()
+    return out
+
+
+def drop_pending_composed():
+    """Start of a step: forget accumulations of a backward pass that raised before its end-of-backward callback ran."""
+    for c in _pending_composed:
+        c.pending = None
+    _pending_composed.clear()
 
 
 def upconv_luconv_forward(x, w_up, b_up, conv_w, conv_b, gamma, beta, running_mean, running_var, composed: ComposedUpConv, act, dtype):
@@ -532,20 +591,20 @@ def upconv_luconv_forward(x, w_up, b_up, conv_w, conv_b, gamma, beta, running_me
     return a, sv
 
 
-def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamma, composed: ComposedUpConv, dtype, need_dx=True):
-    """-> (dx | None, dw_up, db_up, dw0, db0 (exactly zero: a bias in front of batch statistics), dgamma, dbeta)."""
+def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamma, composed: ComposedUpConv, dtype, need_dx=True, defer=False):
+    """-> (dx | None, dw_up, db_up, dw0, db0 (exactly zero: a bias in front of batch statistics), dgamma, dbeta).
+    defer=True (the autograd engine's route): the three convolution-parameter gradients come back as None -- this pass's share is added to
+    `composed`'s accumulators and delivered once per backward() by deliver_composed()."""
     L, s, dev = lib(), stream_handle(), sv.y.device
     N, D, H, W, Ci, Co = sv.geom
-    Cm = w_up.shape[1]
     M = N * D * H * W * 8
     dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype)
-    dw_up = torch.empty_like(w_up, dtype=torch.float32, memory_format=torch.contiguous_format)
-    dw0 = torch.empty_like(conv_w, dtype=torch.float32, memory_format=torch.contiguous_format)
-    db_up = _f32(Cm, dev)
-    nb = L.call("pcrl_upconv_wgrad_ws_bytes", N, D, H, W, Ci, Cm, Co, dtype_code(dtype))
-    with side_wgrad(dev, sv.x, dy) as ws:
-        L.call("pcrl_upconv_wgrad", sv.x, dy, w_up.detach(), b_up.detach(), conv_w.detach(), dw_up, db_up, dw0, ws(nb), nb, N, D, H, W, Ci, Cm, Co,
-               dtype_code(dtype), stream_handle())
+    composed.accumulate(sv.x, dy, sv.geom, w_up, b_up, conv_w, dtype)
+    dw_up = db_up = dw0 = None
+    if not defer:
+        join_side_stream()
+        _pending_composed.remove(composed)
+        _, _, _, dw_up, db_up, dw0 = composed.finish()
     dx = None
     if need_dx:
         _, wd, _ = composed.get(w_up, b_up, conv_w, conv_b, dtype)
