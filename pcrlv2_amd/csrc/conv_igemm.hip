@@ -47,6 +47,12 @@ struct IgemmParams {
   int taps;           // taps accumulated inside one GEMM (27, 1 or 8)
   float* ws;          // split-K (GEOM_CONV3 only): [gridDim.z][M][Nc] float partial sums, or null
   int steps_per_split;
+  // GEOM_UPC_* only.  1-D grid over (row tile, phase): the phases of a tile run back to back on ONE XCD and every XCD owns a contiguous
+  // range of tiles (the eight phases gather the same x rows, neighbouring tiles share faces: one L2 serves them; with the phase as the
+  // slow grid index every phase re-read x from HBM -- 1.6 GB per launch at up_tr64, rocprofv3 r02e).  bd * bh * bw == 128 (0: linear
+  // order): the 128 rows of a tile are a compact bd x bh x bw box of voxels instead of 128 consecutive ones, so the 8 / 64 gathered
+  // neighbours of a tile's rows are mostly each other's.
+  int nt, zdim, bd, bh, bw;
 };
 
 
@@ -73,13 +79,43 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
   const int lr = lane & 15, lg = lane >> 4;
-  const int64_t m0 = (int64_t)blockIdx.x * BM;
+  constexpr bool UPC = GEOM == GEOM_UPC_FWD || GEOM == GEOM_UPC_DGRAD;
+  int tile_ = blockIdx.x, z_ = (GEOM == GEOM_CONV3) ? 0 : blockIdx.z;   // convT forward: tap; conv3: blockIdx.z = K split
+  if (UPC) {
+    const int id = blockIdx.x;
+    if ((p.nt & 7) == 0) {
+      const int k = id >> 3;
+      z_ = k % p.zdim;
+      tile_ = (id & 7) * (p.nt >> 3) + k / p.zdim;
+    } else {
+      z_ = id % p.zdim;
+      tile_ = id / p.zdim;
+    }
+  }
+  const int z = z_;
+  const int64_t m0 = (int64_t)tile_ * BM;
   const int n0 = blockIdx.y * BN;
-  const int z = (GEOM == GEOM_CONV3) ? 0 : blockIdx.z;   // convT forward: tap; conv3: blockIdx.z = K split
   const T* __restrict__ X = reinterpret_cast<const T*>(p.x);
   const T* __restrict__ Wp = reinterpret_cast<const T*>(p.w);
   const Dims g = p.g;
   const int K = p.K;
+  // row index -> voxel: linear order, or (UPC, bd > 0) tile-major boxes
+  auto row_voxel = [&](int64_t m, int& n, int& d, int& h, int& w) {
+    if (UPC && p.bd > 0) {
+      const int r = (int)(m & (BM - 1));
+      int t = (int)(m / BM);
+      const int nbw = g.W / p.bw, nbh = g.H / p.bh, nbd = g.D / p.bd;
+      const int bx = t % nbw; t /= nbw;
+      const int by = t % nbh; t /= nbh;
+      const int bz = t % nbd;
+      n = t / nbd;
+      w = bx * p.bw + r % p.bw;
+      h = by * p.bh + (r / p.bw) % p.bh;
+      d = bz * p.bd + r / (p.bw * p.bh);
+    } else {
+      decode_voxel(m, g, n, d, h, w);
+    }
+  };
 
   const int slot = tid % SLOTS, rowp = tid / SLOTS;
 
@@ -93,7 +129,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     amask[ps] = 0;
     if (m < p.M) {
       int n, d, h, w;
-      decode_voxel(m, g, n, d, h, w);
+      row_voxel(m, n, d, h, w);
       if (GEOM == GEOM_CONV3) {
         abase[ps] = m;
         amask[ps] = tap_mask27(d, h, w, g);
@@ -101,7 +137,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
         abase[ps] = m;
         amask[ps] = 1u;
       } else if (GEOM == GEOM_UPC_FWD) {
-        abase[ps] = m;
+        abase[ps] = (((int64_t)n * g.D + d) * g.H + h) * g.W + w;
         const int od = (z >> 2) - 1, oh = ((z >> 1) & 1) - 1, ow = (z & 1) - 1;
         uint32_t mk = 0;
 #pragma unroll
@@ -288,9 +324,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       const int64_t m = m0 + wm * 64 + i * 16 + lg * 4 + r;
       if (m < p.M) {
         int64_t orow = m;
+        if (GEOM == GEOM_UPC_DGRAD) {
+          int n, d, h, w;
+          row_voxel(m, n, d, h, w);
+          orow = (((int64_t)n * g.D + d) * g.H + h) * g.W + w;
+        }
         if (GEOM == GEOM_UP2_FWD || GEOM == GEOM_UPC_FWD) {
           int n, d, h, w;
-          decode_voxel(m, g, n, d, h, w);
+          row_voxel(m, n, d, h, w);
           orow = up2_row(n, d, h, w, z, g);
           if (GEOM == GEOM_UPC_FWD) {   // border class of the fine voxel (0 first, 1 inside, 2 last per axis) -> row of the bias table
             const int fd = 2 * d + (z >> 2), fh = 2 * h + ((z >> 1) & 1), fw = 2 * w + (z & 1);
@@ -330,7 +371,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       const int j = within / 16, l = within % 16;
       const float* r0 = red + (((0 * 2 + wn_) * FN + j) * 16 + l) * 2;
       const float* r1 = red + (((1 * 2 + wn_) * FN + j) * 16 + l) * 2;
-      const int64_t srow = (GEOM == GEOM_UPC_FWD) ? (int64_t)blockIdx.z * gridDim.x + blockIdx.x : (int64_t)blockIdx.x;
+      const int64_t srow = (GEOM == GEOM_UPC_FWD) ? (int64_t)z * p.nt + tile_ : (int64_t)blockIdx.x;
       float* o = p.stats + (srow * p.Nc + n0 + tid) * 2;
       o[0] = r0[0] + r1[0];
       o[1] = r0[1] + r1[1];
@@ -343,6 +384,7 @@ int launch_igemm(const IgemmParams& p, int zdim, hipStream_t stream) {
   using TL = Tile<T>;
   const size_t lds = 2 * (size_t)(PCRL_CONV_BM + BN) * TL::ROWB;
   dim3 grid((unsigned)((p.M + PCRL_CONV_BM - 1) / PCRL_CONV_BM), (unsigned)(p.Nc / BN), (unsigned)zdim);
+  if (GEOM == GEOM_UPC_FWD || GEOM == GEOM_UPC_DGRAD) grid = dim3((unsigned)(p.nt * p.zdim), (unsigned)(p.Nc / BN), 1);
   hipLaunchKernelGGL((igemm_kernel<T, BN, GEOM>), grid, dim3(256), lds, stream, p);
   return pcrl_check_launch("igemm");
 }
@@ -544,15 +586,32 @@ extern "C" int pcrl_convt3d_k2s2_dgrad(const void* dy, const void* wp_dgrad, voi
 }
 
 // ---- fused ConvTranspose3d(k2,s2) -> Conv3d(3x3x3): the two MFMA passes (internal; the C ABI is in upconv_fused.hip) ----
+// tile shape of the row order: a 128-voxel box that divides the volume, as cubic as the extents allow
+static void upc_box(int D, int H, int W, IgemmParams& p) {
+  static const int cand[][3] = {{4, 4, 8}, {4, 8, 4}, {8, 4, 4}, {2, 8, 8}, {8, 8, 2}, {8, 2, 8}, {2, 4, 16}, {4, 2, 16}, {1, 8, 16}, {8, 16, 1}, {16, 8, 1}, {1, 4, 32}};
+  p.bd = p.bh = p.bw = 0;
+  for (auto& c : cand)
+    if (D % c[0] == 0 && H % c[1] == 0 && W % c[2] == 0) {
+      p.bd = c[0]; p.bh = c[1]; p.bw = c[2];
+      return;
+    }
+}
+template <int GEOM> static int launch_upc(IgemmParams& p, int zdim, int dtype, hipStream_t stream) {
+  upc_box(p.g.D, p.g.H, p.g.W, p);
+  p.nt = (int)((p.M + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
+  p.zdim = zdim;
+  if ((int64_t)p.nt * zdim >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "upconv: grid too large");
+  return dispatch<GEOM>(p, 1, dtype, stream);
+}
 int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
                         int dtype, hipStream_t stream) {
   IgemmParams p{x, wf, bias_tab, y0, stats, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 8, nullptr, 0};
-  return dispatch<GEOM_UPC_FWD>(p, 8, dtype, stream);
+  return launch_upc<GEOM_UPC_FWD>(p, 8, dtype, stream);
 }
 int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype, hipStream_t stream) {
   // rows = coarse voxels, K per tap = Co (channels of dy0), 64 taps, output channels = Ci
   IgemmParams p{dy0, wd, nullptr, dx, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Co, Ci, 64, nullptr, 0};
-  return dispatch<GEOM_UPC_DGRAD>(p, 1, dtype, stream);
+  return launch_upc<GEOM_UPC_DGRAD>(p, 1, dtype, stream);
 }
 // Plain GEMM with a float32 plane-major result: z[col * M + m] = sum_k a[m][k] * b[col][k]   (M % 4 == 0, K % 32 == 0, Nc % 32 == 0)
 template <typename T, int BN> static void gemm_planes_bn(const IgemmParams& p, hipStream_t stream) {

@@ -844,10 +844,23 @@ __global__ void __launch_bounds__(256) wgrad_upc8_kernel(const WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wi = wid >> 1, wj = wid & 1;
   const int ntj = (p.Cv + 63) / 64;
-  const int i0 = (blockIdx.x / ntj) * 64, j0 = (blockIdx.x % ntj) * 64;
-  const int ph = blockIdx.y;
+  // 1-D grid: the tiles x 8 phases blocks of ONE voxel split walk the same x and dy0 rows -- they get ids congruent mod 8 (one XCD, one
+  // L2) and consecutive there; the splits are dealt round-robin to the XCDs.  (With (tile, phase, split) as a 3-D grid the blocks of a
+  // split were spread over all eight L2s: 750 MB fetched per launch for 130 MB of operands, rocprofv3 r02e.)
+  const int ntile = ((p.Cu + 63) / 64) * ntj, per = ntile * 8, nsplit = p.q.ntaps;   // q.ntaps carries the split count here
+  int member, zsplit;
+  if ((nsplit & 7) == 0) {
+    const int k = blockIdx.x >> 3;
+    member = k % per;
+    zsplit = (k / per) * 8 + (blockIdx.x & 7);
+  } else {
+    member = blockIdx.x % per;
+    zsplit = blockIdx.x / per;
+  }
+  const int tix = member % ntile, ph = member / ntile;
+  const int i0 = (tix / ntj) * 64, j0 = (tix % ntj) * 64;
   const int pd = (ph >> 2) & 1, phh = (ph >> 1) & 1, pw = ph & 1;
-  const int64_t mbeg = (int64_t)blockIdx.z * p.chunk;
+  const int64_t mbeg = (int64_t)zsplit * p.chunk;
   const int64_t mend = (mbeg + p.chunk < p.M) ? (mbeg + p.chunk) : p.M;
   const T* __restrict__ U = reinterpret_cast<const T*>(p.u);
   const T* __restrict__ V = reinterpret_cast<const T*>(p.v);
@@ -948,7 +961,7 @@ __global__ void __launch_bounds__(256) wgrad_upc8_kernel(const WgradParams p) {
 #undef W8_STORE
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
-    float* __restrict__ out = p.ws + ((int64_t)blockIdx.z * p.taps + ph * 8 + q) * (int64_t)p.Cu * p.Cv;
+    float* __restrict__ out = p.ws + ((int64_t)zsplit * p.taps + ph * 8 + q) * (int64_t)p.Cu * p.Cv;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1073,8 +1086,10 @@ static SplitPlan plan_upc8(int64_t M, int Cu, int Cv) {
   const int64_t max_splits = (steps + 7) / 8;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
+  if (splits >= 8) splits &= ~(int64_t)7;      // whole rounds of the eight XCDs (see the kernel's block map)
   const int64_t per = (steps + splits - 1) / splits;
-  splits = (steps + per - 1) / per;
+  const int64_t used = (steps + per - 1) / per;
+  if (!(splits >= 8 && (used & 7))) splits = used;   // keep the multiple of eight even if the last splits come out empty
   return SplitPlan{(int)splits, per * 32};
 }
 size_t pcrl_upc_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
@@ -1087,8 +1102,8 @@ int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws
   const SplitPlan sp = plan_upc8(M, Co, Ci);
   const size_t need = (size_t)sp.splits * 64 * Co * Ci * sizeof(float);
   if (ws_bytes < need || !ws) return pcrl_fail(PCRL_EWORKSPACE, "upconv wgrad: workspace %zu < %zu", ws_bytes, need);
-  WgradParams p{dy0, x, (float*)ws, Dims{N, D, H, W}, M, Co, Ci, 64, sp.chunk, Wg2d{0, 0, 1, 1, 0, 0, 1, 1}};
-  const dim3 grid((unsigned)(((Co + 63) / 64) * ((Ci + 63) / 64)), 8, (unsigned)sp.splits);
+  WgradParams p{dy0, x, (float*)ws, Dims{N, D, H, W}, M, Co, Ci, 64, sp.chunk, Wg2d{0, 0, 1, 1, 0, 0, 1, sp.splits}};
+  const dim3 grid((unsigned)(((Co + 63) / 64) * ((Ci + 63) / 64) * 8 * sp.splits));
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_upc8_kernel<bf16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 9 * 32 * 128);

@@ -10,7 +10,8 @@ import sys
 
 
 def short(name):
-    for key in ("brick16_conv_kernel", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_reduce_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_rc_kernel",
+    for key in ("brick16_conv_kernel", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_upc8_kernel", "wgrad_reduce_kernel", "bn_bwd_reduce_pool_kernel",
+                "bn_bwd_apply_pool_kernel", "bn_apply_pool_kernel", "bn_apply_gap_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_rc_kernel",
                 "bn_apply_rc_kernel", "igemm_kernel", "wgrad_kernel", "coltile_sum_kernel", "sgemm_small_kernel", "shift_sum27_kernel",
                 "c1_fwd_kernel", "maxpool_bwd_kernel", "maxpool_fwd_kernel", "im2col27_kernel", "gap_bwd_kernel", "to1_dgrad_kernel",
                 "to1_fwd_kernel", "bn_finalize_kernel", "bn_bwd_finalize_kernel", "coltile_finish_kernel", "sgd_kernel", "tri_fwd_kernel",
@@ -21,7 +22,7 @@ def short(name):
                 m = re.search(r"igemm_kernelI(DF16b|f)Li(\d+)ELi(\d)ELb(\d)", name)
                 if m:
                     return "igemm_kernel<%s,BN=%s,geom=%s%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2),
-                                                                {"0": "conv3", "1": "convT_fwd", "2": "convT_dgrad"}[m.group(3)],
+                                                                {"0": "conv3", "1": "convT_fwd", "2": "convT_dgrad", "3": "upconv_fwd", "4": "upconv_dgrad"}[m.group(3)],
                                                                 ",planes" if m.group(4) == "1" else "")
             return key
     import re
@@ -69,7 +70,8 @@ def main():
                 "# SQ counters are sampled on ONE XCD (SQ_BUSY_CU_CYCLES / GRBM_GUI_ACTIVE ~ 30 of its 32 CUs): MFMA busy fraction =\n"
                 "# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 32 CUs * 4 SIMDs).\n")
         traffic = {}
-        for k in ("brick16_conv_kernel", "brick_conv_kernel", "wgrad_brick_kernel"):
+        mfma_kernels = ["brick16_conv_kernel", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_upc8_kernel"] + sorted(k for k in fd if k.startswith("igemm_kernel<") and "upconv" in k)
+        for k in mfma_kernels:
             if k not in fd or k not in wd or k not in md:
                 continue
             nf, nw, nm = len(fd[k]), len(wd[k]), len(md[k])
@@ -84,7 +86,8 @@ def main():
             traffic[k] = {"hbm_bytes_per_launch": (f_mb + w_mb) * 1e6, "mfma_busy": util}
         # HBM-bound kernels: measured bytes per launch / average launch duration (kernel stats of the same command) -> TB/s
         dur = {k: t / c for k, (c, t) in agg.items()}      # ns per launch
-        hb = [k for k in ("bn_bwd_apply_rc_kernel", "bn_bwd_reduce_kernel", "bn_apply_rc_kernel", "maxpool_bwd_kernel", "maxpool_fwd_kernel",
+        hb = [k for k in ("bn_bwd_apply_rc_kernel", "bn_bwd_reduce_kernel", "bn_apply_rc_kernel", "bn_apply_gap_kernel", "bn_apply_pool_kernel",
+                          "bn_bwd_apply_pool_kernel", "bn_bwd_reduce_pool_kernel", "maxpool_bwd_kernel", "maxpool_fwd_kernel",
                           "gap_bwd_kernel", "coltile_sum_kernel") if k in fd and k in wd and k in dur]
         if hb:
             out += "\n# HBM-bound kernels: PMC bytes per launch (FETCH x2 + WRITE) / average launch duration from the stats pass\n"
