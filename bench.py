@@ -66,9 +66,10 @@ def upconv_key(name, args):
     elif name == "pcrl_upconv_dgrad":   # (dy0, wd, dx, N, D, H, W, Ci, Co, dtype, stream)
         N, D, H, W, Ci, Co, dt = args[3:10]
         key = "igemm_kernel<%s,upconv_dgrad>" % ("bf16" if dt == 1 else "f32")
-    else:                               # pcrl_upconv_wgrad(x, dy0, w_up, b_up, w0, dw_up, db_up, dw0, ws, ws_bytes, N, D, H, W, Ci, Cm, Co, dtype, stream)
-        N, D, H, W, Ci, _cm, Co, dt = args[10:18]
-        key = "wgrad_kernel<%s,upconv>(+chain rule)" % ("bf16" if dt == 1 else "f32")
+    else:                               # pcrl_upconv_wgrad_accum(x, dy0, dweff, dw3, box, first, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)
+        N, D, H, W, Ci, Co, dt = args[8:15]
+        brick = dt == 1 and Co % 64 == 0 and ((D % 2 == 0 and H % 8 == 0 and W % 8 == 0) or (W % 2 == 0 and D % 8 == 0 and H % 8 == 0))
+        key = "wgrad<%s,upconv,%s>(+reduce, class sums)" % ("bf16" if dt == 1 else "f32", "brick kernel, 18 of 27 taps" if brick else "gather kernel")
     return key, 2.0 * N * D * H * W * 64 * Ci * Co
 
 
@@ -208,7 +209,7 @@ def main():
     for _ in range(args.warmup):
         train_step(model, opt, batch, 0, crit, cosine, guard=False)
     prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad",
-                               "pcrl_upconv_wgrad"}, keyfn)
+                               "pcrl_upconv_wgrad_accum"}, keyfn)
     import gc
     gc.collect()
     if os.environ.get("PCRL_BENCH_NOGC", "0") == "1":

@@ -1122,6 +1122,26 @@ int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws
   return launch_wgrad_reduce((const float*)ws, dweff, sp.splits, 64, Co, Ci, Ci, stream, accumulate);
 }
 
+// the same gradient from the brick kernel (wgrad_brick.hip, composed up-conv mode): dw3[8 * Co][Ci][27], the zero-embedded 3x3x3 form on the
+// coarse grid (tap (p + q) per axis of phase p holds dWeff[p][q]; the other 19 taps of a phase are unwritten / meaningless)
+bool pcrl_wgrad_brick_upc_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);
+int pcrl_wgrad_brick_upc_slabs(int N, int D, int H, int W, int Ci, int Co);
+int pcrl_wgrad_brick_upc_launch(const void* x, const void* dy0, float* ws, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
+bool pcrl_upc_wgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return g_wgrad_impl == 0 && g_wgrad_tr && pcrl_wgrad_brick_upc_eligible(N, D, H, W, Ci, Co, dtype);
+}
+size_t pcrl_upc_wgrad3_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
+  return (size_t)pcrl_wgrad_brick_upc_slabs(N, D, H, W, Ci, Co) * 27 * 8 * Co * Ci * sizeof(float);
+}
+int pcrl_upc_wgrad3_launch(const void* dy0, const void* x, float* dw3, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
+                           hipStream_t stream, bool accumulate) {
+  const int splits = pcrl_wgrad_brick_upc_slabs(N, D, H, W, Ci, Co);
+  const size_t need = (size_t)splits * 27 * 8 * Co * Ci * sizeof(float);
+  if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "upconv wgrad (brick): workspace %zu < %zu", ws_bytes, need);
+  if (int e = pcrl_wgrad_brick_upc_launch(x, dy0, (float*)ws, N, D, H, W, Ci, Co, stream)) return e;
+  return launch_wgrad_reduce((const float*)ws, dw3, splits, 27, 8 * Co, Ci, Ci, stream, accumulate);
+}
+
 extern "C" size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
   const SplitPlan sp = plan_splits((int64_t)N * D * H * W, Co, Ci, 27);
   size_t a = (size_t)sp.splits * 27 * Co * Ci * sizeof(float);

@@ -77,6 +77,14 @@ struct WBrickParams {
   int xcd_map;
   int order;        // brick walk order: 0 = w, h, d, n ; 1 = w, d, h, n
   int G, Q, gpc, ngroups, ntg, pair;   // group size, groups per XCD and chunk, groups per chunk, groups, tile groups per range, 0 none / 1 pair over j / 2 pair over i
+  // Composed up-conv mode (upc > 0; conv_wgrad.hip / upconv_fused.hip): x is the COARSE tensor [N][D][H][W][Cv] and "dy" the fine gradient
+  // dy0 [N][2D][2H][2W][upc] seen as 8 * upc channels on the coarse grid -- tile i0 belongs to phase i0 / upc and reads the fine voxels
+  // 2v + phase: dsd / dsh / dsw are the strides of the BRICK axes in fine voxels, dyn the fine voxels per sample, phoff[8] the phase's
+  // voxel offset.  A phase needs only 2 of the 3 taps along every axis: blocks whose kd plane is the unused one exit (pax = the bit of the
+  // phase index that belongs to the brick d axis); their slab entries stay unwritten and are never read (upc_chain_pack_kernel).
+  int upc, dsd, dsh, dsw, pax;
+  int64_t dyn;
+  int phoff[8];
 };
 
 __device__ __forceinline__ int dy_off(int v, int col) {   // 128-byte rows, 32-byte quads XOR-swizzled (see conv_wgrad.hip)
@@ -142,6 +150,9 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     split = blockIdx.x;
   }
   const int i0 = (tile / ntj) * TCO, j0 = (tile % ntj) * TCI;
+  const int uph = p.upc ? i0 / p.upc : 0, uco = p.upc ? i0 % p.upc : i0;   // composed up-conv: phase and channel offset inside the phase
+  if (p.upc && kd == (((uph >> p.pax) & 1) ? 0 : 2)) return;               // this phase has no tap in that plane
+  const int dpitch = p.upc ? p.upc : p.Cu;
   // roles of this wave: dy image / x image of its group, its 16-ci block and (TCI = 32) its co half
   const int dyimg = C::IMG_DY == 2 ? grp : 0, ximg = C::IMG_X == 2 ? grp : 0;
   const int cib = C::HALFCI ? (wid & 1) : wid, cobase = C::HALFCI ? (wid >> 1) * 32 : 0;
@@ -178,7 +189,8 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #pragma unroll
   for (int i = 0; i < DYP; ++i) {
     const int v = (tid >> 3) + (NT / 8) * i;
-    dyoff[i] = (uint32_t)(((v >> 6) * p.sd + ((v >> 3) & 7) * p.sh + (v & 7) * p.sw) * p.Cu + pc_dy * 8) * 2u;
+    dyoff[i] = p.upc ? (uint32_t)(((v >> 6) * p.dsd + ((v >> 3) & 7) * p.dsh + (v & 7) * p.dsw) * dpitch + pc_dy * 8) * 2u
+                     : (uint32_t)(((v >> 6) * p.sd + ((v >> 3) & 7) * p.sh + (v & 7) * p.sw) * p.Cu + pc_dy * 8) * 2u;
   }
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
@@ -248,7 +260,8 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
       }                                                                                                      \
     }                                                                                                        \
     const int64_t base0 = (int64_t)n * p.D * p.H * p.W + (int64_t)d0 * p.sd + h0 * p.sh + w0 * p.sw;          \
-    dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                           \
+    dyb = p.upc ? reinterpret_cast<const char*>(p.dy + ((int64_t)n * p.dyn + (int64_t)d0 * p.dsd + h0 * p.dsh + w0 * p.dsw + p.phoff[uph]) * dpitch + uco) \
+                : reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                   \
     /* first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
     const int64_t xbase0 = p.up ? (((int64_t)n * p.D + d0) * Hs + (h0 >> 1)) * Ws + (w0 >> 1) : base0;       \
     xb = reinterpret_cast<const char*>(p.x + (xbase0 + (p.up ? ((int64_t)(kd - 1) * Hs - 1) * Ws - 1 : (int64_t)(kd - 1) * p.sd - p.sh - p.sw)) * p.Cv); \
@@ -528,6 +541,44 @@ int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int
   return pcrl_check_launch("wgrad_brick");
 }
 
+
+// ---- composed up-conv (upconv_fused.hip): gradient of the zero-embedded 3x3x3 weights W3[8 * Co][Ci][27] on the COARSE grid ----
+// x: coarse [N][D][H][W][Ci]; dy0: fine [N][2D][2H][2W][Co]; slabs ws[split][27][8 * Co][Ci] (entries of a phase's unused planes unwritten)
+static int upc_cfg(int Ci, int Co) {
+  if (Co % 128 == 0) return 1;          // 128 x 64 tiles inside a phase
+  if (Ci % 128 == 0) return 2;          // Co == 64: 64 x 128
+  return Ci == 32 ? 3 : 0;
+}
+bool pcrl_wgrad_brick_upc_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return pcrl_wgrad_brick_eligible(N, D, H, W, Ci, 8 * Co, dtype) && Co % 64 == 0 && (int64_t)N * D * H * W * 8 * Co < ((int64_t)1 << 31);
+}
+int pcrl_wgrad_brick_upc_slabs(int N, int D, int H, int W, int Ci, int Co) {
+  return plan_xcd((int)((int64_t)N * D * H * W / BV), 8 * Co, Ci, upc_cfg(Ci, Co)).splits;
+}
+int pcrl_wgrad_brick_upc_launch(const void* x, const void* dy0, float* ws, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
+  const int nbricks = (int)((int64_t)N * D * H * W / BV);
+  const BrickSplit sp = plan_xcd(nbricks, 8 * Co, Ci, upc_cfg(Ci, Co));
+  WBrickParams p{(const bf16*)dy0, (const bf16*)x, ws, N, D, H, W, 8 * Co, Ci, nbricks, sp.per_split, 0, 3, H * W, W, 1, 9, 3, 1};
+  p.xcd_map = sp.xcd_map; p.order = g_wb_order; p.G = sp.G; p.Q = sp.Q; p.gpc = sp.gpc; p.ngroups = sp.ngroups; p.ntg = sp.ntg; p.pair = sp.pair;
+  p.upc = Co;
+  p.dyn = (int64_t)8 * D * H * W;
+  for (int ph = 0; ph < 8; ++ph) p.phoff[ph] = (((ph >> 2) & 1) * (2 * H) + ((ph >> 1) & 1)) * (2 * W) + (ph & 1);
+  p.dsd = 8 * H * W; p.dsh = 4 * W; p.dsw = 2; p.pax = 2;       // brick d axis = memory d = bit 2 of the phase index
+  if (!wb_natural(D, H, W)) {   // memory (D, H, W) -> brick axes (W, D, H)
+    p.D = W; p.H = D; p.W = H;
+    p.sd = 1; p.sh = H * W; p.sw = W;
+    p.td = 1; p.th = 9; p.tw = 3;
+    p.dsd = 2; p.dsh = 8 * H * W; p.dsw = 4 * W; p.pax = 0;    // brick d axis = memory w = bit 0
+  }
+  dim3 grid((unsigned)sp.blocks);
+  switch (sp.cfg) {
+    case 1: launch_cfg<128, 64>(grid, stream, p); break;
+    case 2: launch_cfg<64, 128>(grid, stream, p); break;
+    case 3: launch_cfg<64, 32>(grid, stream, p); break;
+    default: launch_cfg<64, 64>(grid, stream, p); break;
+  }
+  return pcrl_check_launch("wgrad_brick (composed up-conv)");
+}
 
 // ---- 2D path: weight gradient of a 3x3 / stride 1 / pad 1 convolution over N images (N % 2 == 0): the image index is the depth ----
 bool pcrl_wgrad_brick2d_eligible(int N, int H, int W, int Ci, int Co, int dtype) {

@@ -42,6 +42,12 @@ SHAPES = [  # N, D, H, W (coarse), Ci, Cm, Co
     (1, 4, 4, 4, 128, 128, 64),     # up_tr64's channels
     (3, 2, 2, 2, 64, 64, 32),
     (1, 8, 8, 4, 64, 64, 32),       # several row tiles
+    # shapes whose composed-weight gradient runs on the brick kernel in bf16 (coarse D % 2 == H % 8 == W % 8 == 0 or the permuted form, Co % 64 == 0):
+    (1, 2, 8, 8, 64, 64, 64),       # 64 x 64 tiles, one brick range
+    (2, 4, 8, 8, 128, 128, 64),     # 64 x 128 tiles (up_tr64's channels)
+    (1, 2, 8, 16, 64, 64, 128),     # 128 x 64 tiles inside a phase
+    (1, 8, 8, 2, 64, 64, 64),       # innermost extent 2: permuted brick axes
+    (3, 2, 8, 8, 32, 64, 64),       # Ci = 32 tiles
 ]
 
 
