@@ -82,7 +82,7 @@ struct WBrickParams {
   // 2v + phase: dsd / dsh / dsw are the strides of the BRICK axes in fine voxels, dyn the fine voxels per sample, phoff[8] the phase's
   // voxel offset.  A phase needs only 2 of the 3 taps along every axis: blocks whose kd plane is the unused one exit (pax = the bit of the
   // phase index that belongs to the brick d axis); their slab entries stay unwritten and are never read (upc_chain_pack_kernel).
-  int upc, dsd, dsh, dsw, pax;
+  int upc, dsd, dsh, dsw, pax, pbh, pbw;   // pbh / pbw: phase-index bits of the brick h / w axes (in-plane taps a phase uses)
   int64_t dyn;
   int phoff[8];
 };
@@ -116,7 +116,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
   return u.f;
 }
 
-template <int TCO, int TCI>
+template <int TCO, int TCI, bool UPC = false>   // UPC: composed up-conv mode (compile-time: the 3x3x3 instantiations carry none of its branches)
 __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p) {
   using C = WCfg<TCO, TCI>;
   constexpr int FA = C::FA, NSTEP = C::NSTEP, BUF_BYTES = C::BUF_BYTES, NPIECE = C::NPIECE, KSPLIT = C::KSPLIT;
@@ -150,9 +150,16 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     split = blockIdx.x;
   }
   const int i0 = (tile / ntj) * TCO, j0 = (tile % ntj) * TCI;
-  const int uph = p.upc ? i0 / p.upc : 0, uco = p.upc ? i0 % p.upc : i0;   // composed up-conv: phase and channel offset inside the phase
-  if (p.upc && kd == (((uph >> p.pax) & 1) ? 0 : 2)) return;               // this phase has no tap in that plane
-  const int dpitch = p.upc ? p.upc : p.Cu;
+  const int uph = UPC ? i0 / p.upc : 0, uco = UPC ? i0 % p.upc : i0;   // composed up-conv: phase and channel offset inside the phase
+  if (UPC && kd == (((uph >> p.pax) & 1) ? 0 : 2)) return;                 // this phase has no tap in that plane
+  const int dpitch = UPC ? p.upc : p.Cu;
+  uint32_t tmask = 0x1FFu;   // in-plane taps (kh * 3 + kw) to multiply
+  if (UPC) {
+    const int bh_ = (uph >> p.pbh) & 1, bw_ = (uph >> p.pbw) & 1;
+    tmask = 0;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) tmask |= 1u << ((bh_ + a) * 3 + bw_ + b);
+  }
   // roles of this wave: dy image / x image of its group, its 16-ci block and (TCI = 32) its co half
   const int dyimg = C::IMG_DY == 2 ? grp : 0, ximg = C::IMG_X == 2 ? grp : 0;
   const int cib = C::HALFCI ? (wid & 1) : wid, cobase = C::HALFCI ? (wid >> 1) * 32 : 0;
@@ -189,7 +196,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #pragma unroll
   for (int i = 0; i < DYP; ++i) {
     const int v = (tid >> 3) + (NT / 8) * i;
-    dyoff[i] = p.upc ? (uint32_t)(((v >> 6) * p.dsd + ((v >> 3) & 7) * p.dsh + (v & 7) * p.dsw) * dpitch + pc_dy * 8) * 2u
+    dyoff[i] = UPC ? (uint32_t)(((v >> 6) * p.dsd + ((v >> 3) & 7) * p.dsh + (v & 7) * p.dsw) * dpitch + pc_dy * 8) * 2u
                      : (uint32_t)(((v >> 6) * p.sd + ((v >> 3) & 7) * p.sh + (v & 7) * p.sw) * p.Cu + pc_dy * 8) * 2u;
   }
 #pragma unroll
@@ -260,7 +267,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
       }                                                                                                      \
     }                                                                                                        \
     const int64_t base0 = (int64_t)n * p.D * p.H * p.W + (int64_t)d0 * p.sd + h0 * p.sh + w0 * p.sw;          \
-    dyb = p.upc ? reinterpret_cast<const char*>(p.dy + ((int64_t)n * p.dyn + (int64_t)d0 * p.dsd + h0 * p.dsh + w0 * p.dsw + p.phoff[uph]) * dpitch + uco) \
+    dyb = UPC ? reinterpret_cast<const char*>(p.dy + ((int64_t)n * p.dyn + (int64_t)d0 * p.dsd + h0 * p.dsh + w0 * p.dsw + p.phoff[uph]) * dpitch + uco) \
                 : reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                   \
     /* first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
     const int64_t xbase0 = p.up ? (((int64_t)n * p.D + d0) * Hs + (h0 >> 1)) * Ws + (w0 >> 1) : base0;       \
@@ -353,6 +360,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
         for (int f = 0; f < FA; ++f) fa[(kc + 1) & 1][f] = WB_A(kc + 1, f);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this step's MFMAs (hipcc sinks them next to their use otherwise)
+      if (UPC && !((tmask >> t) & 1u)) continue;   // composed up-conv: this in-plane tap is not one of the phase's 2 x 2 (block-uniform)
 #pragma unroll
       for (int f = 0; f < FA; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st % (PF + 1)], acc[t][f], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -487,13 +495,13 @@ BrickSplit plan3(int nbricks, int Cu, int Cv) {
   return (used_a < 230 && used_b > used_a) ? b : a;
 }
 
-template <int TCO, int TCI> void launch_cfg(dim3 grid, hipStream_t stream, const WBrickParams& p) {
+template <int TCO, int TCI, bool UPC = false> void launch_cfg(dim3 grid, hipStream_t stream, const WBrickParams& p) {
   static std::once_flag attr_once;   // hipFuncSetAttribute once per process and instantiation, race-free
   constexpr int lds = 2 * WCfg<TCO, TCI>::BUF_BYTES;
   std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel<TCO, TCI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel<TCO, TCI, UPC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
-  hipLaunchKernelGGL((wgrad_brick_kernel<TCO, TCI>), grid, dim3(NT), lds, stream, p);
+  hipLaunchKernelGGL((wgrad_brick_kernel<TCO, TCI, UPC>), grid, dim3(NT), lds, stream, p);
 }
 
 }  // namespace
@@ -563,19 +571,19 @@ int pcrl_wgrad_brick_upc_launch(const void* x, const void* dy0, float* ws, int N
   p.upc = Co;
   p.dyn = (int64_t)8 * D * H * W;
   for (int ph = 0; ph < 8; ++ph) p.phoff[ph] = (((ph >> 2) & 1) * (2 * H) + ((ph >> 1) & 1)) * (2 * W) + (ph & 1);
-  p.dsd = 8 * H * W; p.dsh = 4 * W; p.dsw = 2; p.pax = 2;       // brick d axis = memory d = bit 2 of the phase index
+  p.dsd = 8 * H * W; p.dsh = 4 * W; p.dsw = 2; p.pax = 2; p.pbh = 1; p.pbw = 0;   // brick axes = memory (d, h, w) = bits (2, 1, 0) of the phase index
   if (!wb_natural(D, H, W)) {   // memory (D, H, W) -> brick axes (W, D, H)
     p.D = W; p.H = D; p.W = H;
     p.sd = 1; p.sh = H * W; p.sw = W;
     p.td = 1; p.th = 9; p.tw = 3;
-    p.dsd = 2; p.dsh = 8 * H * W; p.dsw = 4 * W; p.pax = 0;    // brick d axis = memory w = bit 0
+    p.dsd = 2; p.dsh = 8 * H * W; p.dsw = 4 * W; p.pax = 0; p.pbh = 2; p.pbw = 1;   // brick (d, h, w) = memory (w, d, h) = bits (0, 2, 1)
   }
   dim3 grid((unsigned)sp.blocks);
   switch (sp.cfg) {
-    case 1: launch_cfg<128, 64>(grid, stream, p); break;
-    case 2: launch_cfg<64, 128>(grid, stream, p); break;
-    case 3: launch_cfg<64, 32>(grid, stream, p); break;
-    default: launch_cfg<64, 64>(grid, stream, p); break;
+    case 1: launch_cfg<128, 64, true>(grid, stream, p); break;
+    case 2: launch_cfg<64, 128, true>(grid, stream, p); break;
+    case 3: launch_cfg<64, 32, true>(grid, stream, p); break;
+    default: launch_cfg<64, 64, true>(grid, stream, p); break;
   }
   return pcrl_check_launch("wgrad_brick (composed up-conv)");
 }
