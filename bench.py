@@ -69,7 +69,7 @@ def upconv_key(name, args):
     else:                               # pcrl_upconv_wgrad_accum(x, dy0, dweff, dw3, box, first, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)
         N, D, H, W, Ci, Co, dt = args[8:15]
         brick = dt == 1 and Co % 64 == 0 and ((D % 2 == 0 and H % 8 == 0 and W % 8 == 0) or (W % 2 == 0 and D % 8 == 0 and H % 8 == 0))
-        key = "wgrad<%s,upconv,%s>(+reduce, class sums)" % ("bf16" if dt == 1 else "f32", "brick kernel, 18 of 27 taps" if brick else "gather kernel")
+        key = "wgrad<%s,upconv,%s>(+reduce, class sums)" % ("bf16" if dt == 1 else "f32", "brick kernel" if brick else "gather kernel")
     return key, 2.0 * N * D * H * W * 64 * Ci * Co
 
 
