@@ -66,8 +66,8 @@ def upconv_key(name, args):
     elif name == "pcrl_upconv_dgrad":   # (dy0, wd, dx, N, D, H, W, Ci, Co, dtype, stream)
         N, D, H, W, Ci, Co, dt = args[3:10]
         key = "igemm_kernel<%s,upconv_dgrad>" % ("bf16" if dt == 1 else "f32")
-    else:                               # pcrl_upconv_wgrad_accum(x, dy0, dweff, dw3, box, first, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)
-        N, D, H, W, Ci, Co, dt = args[8:15]
+    else:                               # pcrl_upconv_wgrad_accum(x, dy0, dweff, box, first, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)
+        N, D, H, W, Ci, Co, dt = args[7:14]
         brick = dt == 1 and Co % 64 == 0 and ((D % 2 == 0 and H % 8 == 0 and W % 8 == 0) or (W % 2 == 0 and D % 8 == 0 and H % 8 == 0))
         key = "wgrad<%s,upconv,%s>(+reduce, class sums)" % ("bf16" if dt == 1 else "f32", "brick kernel" if brick else "gather kernel")
     return key, 2.0 * N * D * H * W * 64 * Ci * Co

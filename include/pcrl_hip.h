@@ -325,11 +325,9 @@ int pcrl_relu_mask_bwd(const void* da, const void* a, void* g, int64_t n, int dt
  * Channels are multiples of 32.
  *   wgrad_accum / wgrad_finish: the same in two stages, both linear in their intermediates -- `accum` (once per backward pass) adds the pass's
  *             gradient of the composed weights and border-class sums of dy0 (box_acc, float32 [27][Co]) to caller-owned buffers; `finish` runs the
- *             chain rule to dw_up / db_up / dw0 once after the last pass.  The gradient of the composed weights has two accumulators because
- *             two kernels produce it: shapes the brick weight-gradient kernel tiles (pcrl_upconv_wgrad_uses_brick() != 0) add to dw3_acc
- *             (float32 [8*Co][Ci][27], the 3x3x3 form on the coarse grid: tap p+q per axis of phase p), the others to dweff_acc (float32
- *             [Co][Ci][64]); `first` bit 0: first pass into the accumulator this pass uses (store, not add), bit 1: the same for box_acc;
- *             `finish` sums whichever are non-NULL. */
+ *             chain rule to dw_up / db_up / dw0 once after the last pass.  dweff_acc: float32 [Co][Ci][64] (the gradient of the composed weights,
+ *             index p*8+q; from the brick weight-gradient kernel where it tiles the coarse grid, else from the gather kernel); first != 0: store
+ *             instead of add. */
 size_t pcrl_upconv_compose_ws_bytes(int Ci, int Cm, int Co, int dtype);
 int pcrl_upconv_compose(const float* w_up, const float* b_up, const float* w0, const float* b0, void* wf, void* wd, float* bias_tab,
                         void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream);
@@ -338,14 +336,13 @@ int pcrl_upconv_fwd(const void* x, const void* wf, const float* bias_tab, void* 
                     int Ci, int Co, int dtype, pcrl_stream_t stream);
 int pcrl_upconv_dgrad(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
                       pcrl_stream_t stream);
-int64_t pcrl_upconv_wgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   /* which accumulator a pass of this shape adds to */
+int64_t pcrl_upconv_wgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   /* informational: which kernel a shape gets */
 size_t pcrl_upconv_wgrad_accum_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype);
-int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* dw3_acc, float* box_acc, int first, void* ws, size_t ws_bytes,
-                            int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
+int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* box_acc, int first, void* ws, size_t ws_bytes, int N, int D,
+                            int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
 size_t pcrl_upconv_wgrad_finish_ws_bytes(int Ci, int Cm, int Co, int dtype);
-int pcrl_upconv_wgrad_finish(const float* dweff_acc, const float* dw3_acc, const float* box_acc, const float* w_up, const float* b_up, const float* w0,
-                             float* dw_up, float* db_up, float* dw0, void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype,
-                             pcrl_stream_t stream);
+int pcrl_upconv_wgrad_finish(const float* dweff_acc, const float* box_acc, const float* w_up, const float* b_up, const float* w0, float* dw_up,
+                             float* db_up, float* dw0, void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream);
 size_t pcrl_upconv_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype);
 int pcrl_upconv_wgrad(const void* x, const void* dy0, const float* w_up, const float* b_up, const float* w0, float* dw_up, float* db_up,
                       float* dw0, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype,

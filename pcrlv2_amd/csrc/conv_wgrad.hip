@@ -1122,8 +1122,7 @@ int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws
   return launch_wgrad_reduce((const float*)ws, dweff, sp.splits, 64, Co, Ci, Ci, stream, accumulate);
 }
 
-// the same gradient from the brick kernel (wgrad_brick.hip, composed up-conv mode): dw3[8 * Co][Ci][27], the zero-embedded 3x3x3 form on the
-// coarse grid (tap (p + q) per axis of phase p holds dWeff[p][q]; the other 19 taps of a phase are unwritten / meaningless)
+// the same gradient, dweff[co][ci][p * 8 + q], from the brick kernel (wgrad_brick.hip, composed up-conv mode) where it tiles the coarse grid
 bool pcrl_wgrad_brick_upc_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);
 int pcrl_wgrad_brick_upc_slabs(int N, int D, int H, int W, int Ci, int Co);
 int pcrl_wgrad_brick_upc_launch(const void* x, const void* dy0, float* ws, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
@@ -1133,13 +1132,46 @@ bool pcrl_upc_wgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int d
 size_t pcrl_upc_wgrad3_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
   return (size_t)pcrl_wgrad_brick_upc_slabs(N, D, H, W, Ci, Co) * 27 * 8 * Co * Ci * sizeof(float);
 }
-int pcrl_upc_wgrad3_launch(const void* dy0, const void* x, float* dw3, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
+// Second pass of the brick form: the slabs hold the zero-embedded 3x3x3 layout ws[z][27][8 * Co][Ci] of which a phase's rows carry 8
+// meaningful taps (tap (p + q) per axis; the planes a phase does not use were never written).  Sum those over z, in slab order, straight
+// into the compact layout of the gather form, out[co][ci][p * 8 + q] -- 8 / 27 of the slab bytes, no intermediate [8 * Co][Ci][27] array.
+// Block = one row i = p * Co + co and 64 columns ci: thread (q, lane) reads 128-byte runs, the tile is transposed through LDS so that the
+// eight q of a (co, ci) leave as one 32-byte run.
+__global__ void __launch_bounds__(256) wgrad_reduce_upc_kernel(const float* __restrict__ ws, float* __restrict__ out, int splits, int Co, int Ci,
+                                                               bool accumulate) {
+  __shared__ float tile[64][9];
+  const int i = blockIdx.y, p = i / Co, co = i - p * Co, j0 = blockIdx.x * 64;
+  const int q = threadIdx.x >> 5, jl = threadIdx.x & 31;
+  const int tap = (((p >> 2) & 1) + ((q >> 2) & 1)) * 9 + (((p >> 1) & 1) + ((q >> 1) & 1)) * 3 + ((p & 1) + (q & 1));
+  const int64_t per = (int64_t)8 * Co * Ci, zs = 27 * per;
+  const float* src = ws + (int64_t)tap * per + (int64_t)i * Ci + j0 + jl;
+  double a0 = 0.0, a1 = 0.0;
+  const bool ok0 = j0 + jl < Ci, ok1 = j0 + jl + 32 < Ci;
+  for (int z = 0; z < splits; ++z) {
+    if (ok0) a0 += (double)src[(int64_t)z * zs];
+    if (ok1) a1 += (double)src[(int64_t)z * zs + 32];
+  }
+  tile[jl][q] = (float)a0;
+  tile[jl + 32][q] = (float)a1;
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = h * 32 + (threadIdx.x >> 3), qq = threadIdx.x & 7;
+    if (j0 + j < Ci) {
+      float* dst = out + ((int64_t)co * Ci + j0 + j) * 64 + p * 8 + qq;
+      *dst = accumulate ? *dst + tile[j][qq] : tile[j][qq];
+    }
+  }
+}
+int pcrl_upc_wgrad3_launch(const void* dy0, const void* x, float* dweff, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
                            hipStream_t stream, bool accumulate) {
   const int splits = pcrl_wgrad_brick_upc_slabs(N, D, H, W, Ci, Co);
   const size_t need = (size_t)splits * 27 * 8 * Co * Ci * sizeof(float);
   if (!ws || ws_bytes < need) return pcrl_fail(PCRL_EWORKSPACE, "upconv wgrad (brick): workspace %zu < %zu", ws_bytes, need);
   if (int e = pcrl_wgrad_brick_upc_launch(x, dy0, (float*)ws, N, D, H, W, Ci, Co, stream)) return e;
-  return launch_wgrad_reduce((const float*)ws, dw3, splits, 27, 8 * Co, Ci, Ci, stream, accumulate);
+  hipLaunchKernelGGL(wgrad_reduce_upc_kernel, dim3((unsigned)((Ci + 63) / 64), (unsigned)(8 * Co)), dim3(256), 0, stream, (const float*)ws, dweff, splits, Co,
+                     Ci, accumulate);
+  return pcrl_check_launch("upconv wgrad (brick, reduce)");
 }
 
 extern "C" size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {

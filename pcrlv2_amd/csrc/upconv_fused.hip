@@ -34,7 +34,7 @@ int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws
                           int dtype, hipStream_t stream, bool accumulate);
 bool pcrl_upc_wgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);
 size_t pcrl_upc_wgrad3_ws_bytes(int N, int D, int H, int W, int Ci, int Co);
-int pcrl_upc_wgrad3_launch(const void* dy0, const void* x, float* dw3, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
+int pcrl_upc_wgrad3_launch(const void* dy0, const void* x, float* dweff, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
                            hipStream_t stream, bool accumulate);
 
 namespace {
@@ -144,11 +144,9 @@ __global__ void __launch_bounds__(256) upc_bias_kernel(const float* __restrict__
   }
 }
 
-// gradient of the composed weights -> a1[(t*Co+co)][(s*Ci+ci)] and a2[(s*Ci+ci)][(t*Co+co)], value dWeff[pq(t,s)][ci][co].  Two sources,
-// summed when both are present: dweff[co][ci][pq] (gather kernel) and dw3[(p*Co+co)][ci][27] (brick kernel: tap (p+q) per axis).
+// dweff[co][ci][pq] (float32) -> a1[(t*Co+co)][(s*Ci+ci)] and a2[(s*Ci+ci)][(t*Co+co)], value dWeff[pq(t,s)][ci][co]
 template <typename T>
-__global__ void __launch_bounds__(256) upc_chain_pack_kernel(const float* __restrict__ dweff, const float* __restrict__ dw3, T* __restrict__ a1,
-                                                             T* __restrict__ a2, int Ci, int Co) {
+__global__ void __launch_bounds__(256) upc_chain_pack_kernel(const float* __restrict__ dweff, T* __restrict__ a1, T* __restrict__ a2, int Ci, int Co) {
   const int64_t K1 = (int64_t)8 * Ci, K2 = (int64_t)27 * Co;
   const int64_t total = (int64_t)27 * 8 * Ci * Co;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -157,32 +155,10 @@ __global__ void __launch_bounds__(256) upc_chain_pack_kernel(const float* __rest
     pq_axis(t / 9, s >> 2, pd, qd);
     pq_axis((t / 3) % 3, (s >> 1) & 1, ph, qh);
     pq_axis(t % 3, s & 1, pw, qw);
-    const int p = pd * 4 + ph * 2 + pw, pq = p * 8 + (qd * 4 + qh * 2 + qw);
-    float g = 0.f;
-    if (dweff) g += dweff[((int64_t)co * Ci + ci) * 64 + pq];
-    if (dw3) g += dw3[(((int64_t)p * Co + co) * Ci + ci) * 27 + (pd + qd) * 9 + (ph + qh) * 3 + (pw + qw)];
-    const T v = cvt<T>(g);
+    const int pq = (pd * 4 + ph * 2 + pw) * 8 + (qd * 4 + qh * 2 + qw);
+    const T v = cvt<T>(dweff[((int64_t)co * Ci + ci) * 64 + pq]);
     a1[((int64_t)t * Co + co) * K1 + (int64_t)s * Ci + ci] = v;      // = index i: coalesced
     a2[((int64_t)s * Ci + ci) * K2 + (int64_t)t * Co + co] = v;
-  }
-}
-
-// dw3[(p*Co+co)][ci][27] (brick kernel) -> out[co][ci][p*8+q] = dw3[..][tap (p+q) per axis] (+ add[co][ci][pq] if given): a thread reads the 27
-// contiguous taps of one (phase, co, ci) -- the chain-rule pack reading dw3 directly strode 108 bytes per lane (399 us at up_tr256)
-__global__ void __launch_bounds__(256) upc_compact_kernel(const float* __restrict__ dw3, const float* __restrict__ add, float* __restrict__ out, int Ci,
-                                                          int Co) {
-  const int64_t total = (int64_t)8 * Co * Ci;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int ci = (int)(i % Ci), co = (int)((i / Ci) % Co), p = (int)(i / ((int64_t)Ci * Co));
-    const float* src = dw3 + i * 27;
-    const int pd = (p >> 2) & 1, ph = (p >> 1) & 1, pw = p & 1;
-    float* dst = out + ((int64_t)co * Ci + ci) * 64 + p * 8;
-    const float* ad = add ? add + ((int64_t)co * Ci + ci) * 64 + p * 8 : nullptr;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float v = src[(pd + ((q >> 2) & 1)) * 9 + (ph + ((q >> 1) & 1)) * 3 + (pw + (q & 1))];
-      dst[q] = ad ? v + ad[q] : v;
-    }
   }
 }
 
@@ -361,7 +337,7 @@ extern "C" int pcrl_upconv_dgrad(const void* dy0, const void* wd, void* dx, int 
 // parameters once, after the last pass (three passes share the weights in a pre-training step: the weight-sized GEMMs run once).
 namespace {
 struct FinLayout {
-  size_t a1, a2, b1, b2, z1, z2, dwc, total;
+  size_t a1, a2, b1, b2, z1, z2, total;
 };
 FinLayout fin_layout(int Ci, int Cm, int Co, int dtype) {
   FinLayout L;
@@ -372,7 +348,6 @@ FinLayout fin_layout(int Ci, int Cm, int Co, int dtype) {
   L.b2 = o;    o += al((size_t)Cm * 27 * Co * esz(dtype));
   L.z1 = o;    o += al((size_t)Cm * 27 * Co * sizeof(float));
   L.z2 = o;    o += al((size_t)Cm * 8 * Ci * sizeof(float));
-  L.dwc = o;   o += al((size_t)64 * Co * Ci * sizeof(float));
   L.total = o;
   return L;
 }
@@ -390,22 +365,20 @@ extern "C" size_t pcrl_upconv_wgrad_accum_ws_bytes(int N, int D, int H, int W, i
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
   return al(acc_wg_bytes(N, D, H, W, Ci, Co, dtype)) + al((size_t)N * 2 * D * 9 * Co * sizeof(float)) + al((size_t)27 * Co * sizeof(float));
 }
-// Which accumulator a pass adds to depends on its shape: pcrl_upconv_wgrad_uses_brick() != 0 -> dw3_acc (float32 [8*Co][Ci][27], the brick
-// weight-gradient kernel on the coarse grid), else dweff_acc (float32 [Co][Ci][64], the gather kernel); box_acc: float32 [27][Co].
-// first: bit 0 = this is the first pass into the accumulator it uses (store instead of add), bit 1 = first pass into box_acc.
-extern "C" int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* dw3_acc, float* box_acc, int first, void* ws,
-                                       size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+// dweff_acc: float32 [Co][Ci][64]; box_acc: float32 [27][Co]; first != 0: store, else add.  The gradient of the composed weights comes from the
+// brick weight-gradient kernel where it tiles the coarse grid (pcrl_upconv_wgrad_uses_brick() != 0), else from the gather kernel: same layout.
+extern "C" int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* box_acc, int first, void* ws, size_t ws_bytes, int N,
+                                       int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_upc("upconv_wgrad_accum", N, D, H, W, Ci, 32, Co, dtype)) return e;
-  const bool brick = pcrl_upc_wgrad_uses_brick(N, D, H, W, Ci, Co, dtype);
-  PCRL_REQUIRE(x && dy0 && box_acc && (brick ? dw3_acc != nullptr : dweff_acc != nullptr), "upconv_wgrad_accum: null pointer");
+  PCRL_REQUIRE(x && dy0 && dweff_acc && box_acc, "upconv_wgrad_accum: null pointer");
   if (!ws || ws_bytes < pcrl_upconv_wgrad_accum_ws_bytes(N, D, H, W, Ci, Co, dtype)) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad_accum: workspace too small");
   hipStream_t st = as_stream(stream);
   char* w = (char*)ws;
   const size_t wgb = al(acc_wg_bytes(N, D, H, W, Ci, Co, dtype));
-  if (brick) {
-    if (int e = pcrl_upc_wgrad3_launch(dy0, x, dw3_acc, w, wgb, N, D, H, W, Ci, Co, st, (first & 1) == 0)) return e;
+  if (pcrl_upc_wgrad_uses_brick(N, D, H, W, Ci, Co, dtype)) {
+    if (int e = pcrl_upc_wgrad3_launch(dy0, x, dweff_acc, w, wgb, N, D, H, W, Ci, Co, st, first == 0)) return e;
   } else {
-    if (int e = pcrl_upc_wgrad_launch(dy0, x, dweff_acc, w, wgb, N, D, H, W, Ci, Co, dtype, st, (first & 1) == 0)) return e;
+    if (int e = pcrl_upc_wgrad_launch(dy0, x, dweff_acc, w, wgb, N, D, H, W, Ci, Co, dtype, st, first == 0)) return e;
   }
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
   if (Co % vec != 0 || (Co / vec) > 256 || 256 % (Co / vec) != 0) return pcrl_fail(PCRL_EINVAL, "upconv_wgrad_accum: Co=%d not supported by the class-sum kernel", Co);
@@ -415,33 +388,28 @@ extern "C" int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dw
   if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_class_sums_kernel<bf16>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const bf16*)dy0, part, 2 * H, 2 * W, Co);
   else hipLaunchKernelGGL(upc_class_sums_kernel<float>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const float*)dy0, part, 2 * H, 2 * W, Co);
   hipLaunchKernelGGL(upc_class_total_kernel, dim3((unsigned)(9 * ((Co + 63) / 64)), 3), dim3(1024), 0, st, (const float*)part, S, N, 2 * D, Co);
-  hipLaunchKernelGGL(upc_box_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)S, box_acc, Co, (first & 2) == 0);
+  hipLaunchKernelGGL(upc_box_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)S, box_acc, Co, first == 0);
   return pcrl_check_launch("upconv_wgrad_accum");
 }
 extern "C" size_t pcrl_upconv_wgrad_finish_ws_bytes(int Ci, int Cm, int Co, int dtype) {
   if (Ci <= 0 || Cm <= 0 || Co <= 0) return 0;
   return fin_layout(Ci, Cm, Co, dtype).total;
 }
-extern "C" int pcrl_upconv_wgrad_finish(const float* dweff_acc, const float* dw3_acc, const float* box_acc, const float* w_up, const float* b_up,
-                                        const float* w0, float* dw_up, float* db_up, float* dw0, void* ws, size_t ws_bytes, int Ci, int Cm, int Co,
-                                        int dtype, pcrl_stream_t stream) {
+extern "C" int pcrl_upconv_wgrad_finish(const float* dweff_acc, const float* box_acc, const float* w_up, const float* b_up, const float* w0, float* dw_up,
+                                        float* db_up, float* dw0, void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_upc("upconv_wgrad_finish", 1, 1, 1, 1, Ci, Cm, Co, dtype)) return e;
-  PCRL_REQUIRE((dweff_acc || dw3_acc) && box_acc && w_up && b_up && w0 && dw_up && db_up && dw0, "upconv_wgrad_finish: null pointer");
+  PCRL_REQUIRE(dweff_acc && box_acc && w_up && b_up && w0 && dw_up && db_up && dw0, "upconv_wgrad_finish: null pointer");
   const FinLayout L = fin_layout(Ci, Cm, Co, dtype);
   if (!ws || ws_bytes < L.total) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad_finish: workspace %zu < %zu", ws_bytes, L.total);
   hipStream_t st = as_stream(stream);
   char* w = (char*)ws;
   const unsigned gpre = blocks_for((int64_t)27 * Co * Cm + (int64_t)8 * Ci * Cm), gpk = blocks_for((int64_t)216 * Ci * Co);
-  if (dw3_acc) {   // brick-kernel layout -> the compact one (summed with the gather kernel's accumulator when both were used)
-    hipLaunchKernelGGL(upc_compact_kernel, dim3(blocks_for((int64_t)8 * Co * Ci)), dim3(256), 0, st, dw3_acc, dweff_acc, (float*)(w + L.dwc), Ci, Co);
-    dweff_acc = (const float*)(w + L.dwc);
-  }
   if (dtype == PCRL_BF16) {
     hipLaunchKernelGGL(upc_prep_kernel<bf16>, dim3(gpre), dim3(256), 0, st, w_up, w0, (bf16*)nullptr, (bf16*)nullptr, (bf16*)(w + L.b1), (bf16*)(w + L.b2), Ci, Cm, Co);
-    hipLaunchKernelGGL(upc_chain_pack_kernel<bf16>, dim3(gpk), dim3(256), 0, st, dweff_acc, (const float*)nullptr, (bf16*)(w + L.a1), (bf16*)(w + L.a2), Ci, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<bf16>, dim3(gpk), dim3(256), 0, st, dweff_acc, (bf16*)(w + L.a1), (bf16*)(w + L.a2), Ci, Co);
   } else {
     hipLaunchKernelGGL(upc_prep_kernel<float>, dim3(gpre), dim3(256), 0, st, w_up, w0, (float*)nullptr, (float*)nullptr, (float*)(w + L.b1), (float*)(w + L.b2), Ci, Cm, Co);
-    hipLaunchKernelGGL(upc_chain_pack_kernel<float>, dim3(gpk), dim3(256), 0, st, dweff_acc, (const float*)nullptr, (float*)(w + L.a1), (float*)(w + L.a2), Ci, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<float>, dim3(gpk), dim3(256), 0, st, dweff_acc, (float*)(w + L.a1), (float*)(w + L.a2), Ci, Co);
   }
   if (int e = pcrl_check_launch("upconv_wgrad_finish (pack)")) return e;
   if (int e = pcrl_gemm_planes_launch(w + L.a1, w + L.b1, (float*)(w + L.z1), (int64_t)27 * Co, 8 * Ci, Cm, dtype, st)) return e;   // z1[cm][(t,co)]
@@ -455,7 +423,7 @@ extern "C" int pcrl_upconv_wgrad_finish(const float* dweff_acc, const float* dw3
 extern "C" size_t pcrl_upconv_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Cm <= 0 || Co <= 0) return 0;
   const size_t a = pcrl_upconv_wgrad_accum_ws_bytes(N, D, H, W, Ci, Co, dtype), f = fin_layout(Ci, Cm, Co, dtype).total;
-  return al((size_t)27 * 8 * Co * Ci * sizeof(float)) + al((size_t)27 * Co * sizeof(float)) + (a > f ? a : f);
+  return al((size_t)64 * Co * Ci * sizeof(float)) + al((size_t)27 * Co * sizeof(float)) + (a > f ? a : f);
 }
 extern "C" int pcrl_upconv_wgrad(const void* x, const void* dy0, const float* w_up, const float* b_up, const float* w0, float* dw_up, float* db_up,
                                  float* dw0, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Cm, int Co, int dtype,
@@ -463,12 +431,10 @@ extern "C" int pcrl_upconv_wgrad(const void* x, const void* dy0, const float* w_
   if (int e = check_upc("upconv_wgrad", N, D, H, W, Ci, Cm, Co, dtype)) return e;
   if (!ws || ws_bytes < pcrl_upconv_wgrad_ws_bytes(N, D, H, W, Ci, Cm, Co, dtype)) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad: workspace too small");
   char* w = (char*)ws;
-  float* acc = (float*)w;     // either layout fits
-  float* box = (float*)(w + al((size_t)27 * 8 * Co * Ci * sizeof(float)));
+  float* dweff = (float*)w;
+  float* box = (float*)(w + al((size_t)64 * Co * Ci * sizeof(float)));
   char* rest = (char*)box + al((size_t)27 * Co * sizeof(float));
   const size_t rest_bytes = ws_bytes - (size_t)(rest - w);
-  const bool brick = pcrl_upc_wgrad_uses_brick(N, D, H, W, Ci, Co, dtype);
-  if (int e = pcrl_upconv_wgrad_accum(x, dy0, brick ? nullptr : acc, brick ? acc : nullptr, box, 3, rest, rest_bytes, N, D, H, W, Ci, Co, dtype, stream)) return e;
-  return pcrl_upconv_wgrad_finish(brick ? nullptr : acc, brick ? acc : nullptr, box, w_up, b_up, w0, dw_up, db_up, dw0, rest, rest_bytes, Ci, Cm, Co, dtype,
-                                  stream);
+  if (int e = pcrl_upconv_wgrad_accum(x, dy0, dweff, box, 1, rest, rest_bytes, N, D, H, W, Ci, Co, dtype, stream)) return e;
+  return pcrl_upconv_wgrad_finish(dweff, box, w_up, b_up, w0, dw_up, db_up, dw0, rest, rest_bytes, Ci, Cm, Co, dtype, stream);
 }

@@ -495,8 +495,7 @@ class ComposedUpConv:
     def __init__(self):
         self.key = None
         self.wf = self.wd = self.bias_tab = None
-        self.dweff = self.dw3 = self.box = None
-        self.have = [False, False, False]
+        self.dweff = self.box = None
         self.pending = None     # (w_up, b_up, w0, dtype) while accumulated gradients wait for delivery
 
     def get(self, w_up, b_up, w0, b0, dtype):
@@ -516,28 +515,19 @@ class ComposedUpConv:
         return self.wf, self.wd, self.bias_tab
 
     def accumulate(self, x, dy, geom, w_up, b_up, w0, dtype):
-        """One backward pass: the gradient of the composed weights goes to dw3 (shapes the brick weight-gradient kernel tiles) or dweff (the
-        gather kernel), the border-class sums of dy to box (pcrl_upconv_wgrad_accum)."""
+        """One backward pass: dweff += d(composed weights), box += border-class sums of dy (pcrl_upconv_wgrad_accum)."""
         L, dev = lib(), x.device
         N, D, H, W, Ci, Co = geom
-        if self.pending is None:
+        first = self.pending is None
+        if first:
+            if self.dweff is None or self.dweff.numel() != 64 * Ci * Co or self.dweff.device != dev:
+                self.dweff, self.box = _f32(64 * Ci * Co, dev), _f32(27 * Co, dev)
             self.pending = (w_up, b_up, w0, dtype)
-            self.have = [False, False, False]       # dweff, dw3, box hold something
             _pending_composed.append(self)
-        brick = bool(L.call("pcrl_upconv_wgrad_uses_brick", N, D, H, W, Ci, Co, dtype_code(dtype)))
-        if brick and (self.dw3 is None or self.dw3.numel() != 216 * Ci * Co or self.dw3.device != dev):
-            self.dw3 = _f32(216 * Ci * Co, dev)
-        if not brick and (self.dweff is None or self.dweff.numel() != 64 * Ci * Co or self.dweff.device != dev):
-            self.dweff = _f32(64 * Ci * Co, dev)
-        if self.box is None or self.box.numel() != 27 * Co or self.box.device != dev:
-            self.box = _f32(27 * Co, dev)
-        k = 1 if brick else 0
-        first = (0 if self.have[k] else 1) | (0 if self.have[2] else 2)
-        self.have[k] = self.have[2] = True
         nb = L.call("pcrl_upconv_wgrad_accum_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
         with side_wgrad(dev, x, dy) as ws:
-            L.call("pcrl_upconv_wgrad_accum", x, dy, None if brick else self.dweff, self.dw3 if brick else None, self.box, first, ws(nb), nb,
-                   N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
+            L.call("pcrl_upconv_wgrad_accum", x, dy, self.dweff, self.box, 1 if first else 0, ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype),
+                   stream_handle())
 
     def finish(self):
         """-> (w_up, b_up, w0, dw_up, db_up, dw0) for everything accumulated since the last delivery."""
@@ -549,8 +539,8 @@ class ComposedUpConv:
         dw0 = torch.empty_like(w0, dtype=torch.float32, memory_format=torch.contiguous_format)
         db_up = _f32(Cm, dev)
         nb = L.call("pcrl_upconv_wgrad_finish_ws_bytes", Ci, Cm, Co, dtype_code(dtype))
-        L.call("pcrl_upconv_wgrad_finish", self.dweff if self.have[0] else None, self.dw3 if self.have[1] else None, self.box, w_up.detach(),
-               b_up.detach(), w0.detach(), dw_up, db_up, dw0, workspace(nb, dev), nb, Ci, Cm, Co, dtype_code(dtype), stream_handle())
+        L.call("pcrl_upconv_wgrad_finish", self.dweff, self.box, w_up.detach(), b_up.detach(), w0.detach(), dw_up, db_up, dw0, workspace(nb, dev), nb,
+               Ci, Cm, Co, dtype_code(dtype), stream_handle())
         return w_up, b_up, w0, dw_up, db_up, dw0
 
 
