@@ -144,10 +144,9 @@ __global__ void __launch_bounds__(256) upc_bias_kernel(const float* __restrict__
   }
 }
 
-// dweff[co][ci][pq] (float32) -> a1[(t*Co+co)][(s*Ci+ci)] and a2[(s*Ci+ci)][(t*Co+co)], value dWeff[pq(t,s)][ci][co]
+// dweff[co][ci][pq] (float32) -> a1[(t*Co+co)][(s*Ci+ci)], value dWeff[pq(t,s)][ci][co]   (a2 = a1 transposed: transpose_kernel)
 template <typename T>
-__global__ void __launch_bounds__(256) upc_chain_pack_kernel(const float* __restrict__ dweff, T* __restrict__ a1, T* __restrict__ a2, int Ci, int Co) {
-  const int64_t K1 = (int64_t)8 * Ci, K2 = (int64_t)27 * Co;
+__global__ void __launch_bounds__(256) upc_chain_pack_kernel(const float* __restrict__ dweff, T* __restrict__ a1, int Ci, int Co) {
   const int64_t total = (int64_t)27 * 8 * Ci * Co;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ci = (int)(i % Ci), s = (int)((i / Ci) % 8), co = (int)((i / ((int64_t)8 * Ci)) % Co), t = (int)(i / ((int64_t)8 * Ci * Co));
@@ -156,10 +155,20 @@ __global__ void __launch_bounds__(256) upc_chain_pack_kernel(const float* __rest
     pq_axis((t / 3) % 3, (s >> 1) & 1, ph, qh);
     pq_axis(t % 3, s & 1, pw, qw);
     const int pq = (pd * 4 + ph * 2 + pw) * 8 + (qd * 4 + qh * 2 + qw);
-    const T v = cvt<T>(dweff[((int64_t)co * Ci + ci) * 64 + pq]);
-    a1[((int64_t)t * Co + co) * K1 + (int64_t)s * Ci + ci] = v;      // = index i: coalesced
-    a2[((int64_t)s * Ci + ci) * K2 + (int64_t)t * Co + co] = v;
+    a1[i] = cvt<T>(dweff[((int64_t)co * Ci + ci) * 64 + pq]);   // a1 index ((t*Co+co) * 8*Ci + s*Ci + ci) == i
   }
+}
+// out[c][r] = in[r][c] for an R x C matrix (both multiples of 32), 32 x 32 tiles through LDS: both sides coalesced (the pack kernel writing
+// the transposed copy itself strode 2-byte stores by 27*Co elements: 228 us at up_tr256)
+template <typename T>
+__global__ void __launch_bounds__(256) transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int R, int C) {
+  __shared__ T tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) tile[ty + 8 * k][tx] = in[(int64_t)(r0 + ty + 8 * k) * C + c0 + tx];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[(int64_t)(c0 + ty + 8 * k) * R + r0 + tx] = tile[tx][ty + 8 * k];
 }
 
 // z1[cm][(t*Co+co)] -> dw0[co][cm][t];   z2[cm][(s*Ci+ci)] -> dwup[ci][cm][s]
@@ -406,10 +415,12 @@ extern "C" int pcrl_upconv_wgrad_finish(const float* dweff_acc, const float* box
   const unsigned gpre = blocks_for((int64_t)27 * Co * Cm + (int64_t)8 * Ci * Cm), gpk = blocks_for((int64_t)216 * Ci * Co);
   if (dtype == PCRL_BF16) {
     hipLaunchKernelGGL(upc_prep_kernel<bf16>, dim3(gpre), dim3(256), 0, st, w_up, w0, (bf16*)nullptr, (bf16*)nullptr, (bf16*)(w + L.b1), (bf16*)(w + L.b2), Ci, Cm, Co);
-    hipLaunchKernelGGL(upc_chain_pack_kernel<bf16>, dim3(gpk), dim3(256), 0, st, dweff_acc, (bf16*)(w + L.a1), (bf16*)(w + L.a2), Ci, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<bf16>, dim3(gpk), dim3(256), 0, st, dweff_acc, (bf16*)(w + L.a1), Ci, Co);
+    hipLaunchKernelGGL(transpose_kernel<bf16>, dim3((unsigned)(8 * Ci / 32), (unsigned)(27 * Co / 32)), dim3(256), 0, st, (const bf16*)(w + L.a1), (bf16*)(w + L.a2), 27 * Co, 8 * Ci);
   } else {
     hipLaunchKernelGGL(upc_prep_kernel<float>, dim3(gpre), dim3(256), 0, st, w_up, w0, (float*)nullptr, (float*)nullptr, (float*)(w + L.b1), (float*)(w + L.b2), Ci, Cm, Co);
-    hipLaunchKernelGGL(upc_chain_pack_kernel<float>, dim3(gpk), dim3(256), 0, st, dweff_acc, (float*)(w + L.a1), (float*)(w + L.a2), Ci, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<float>, dim3(gpk), dim3(256), 0, st, dweff_acc, (float*)(w + L.a1), Ci, Co);
+    hipLaunchKernelGGL(transpose_kernel<float>, dim3((unsigned)(8 * Ci / 32), (unsigned)(27 * Co / 32)), dim3(256), 0, st, (const float*)(w + L.a1), (float*)(w + L.a2), 27 * Co, 8 * Ci);
   }
   if (int e = pcrl_check_launch("upconv_wgrad_finish (pack)")) return e;
   if (int e = pcrl_gemm_planes_launch(w + L.a1, w + L.b1, (float*)(w + L.z1), (int64_t)27 * Co, 8 * Ci, Cm, dtype, st)) return e;   // z1[cm][(t,co)]

@@ -38,16 +38,20 @@ def set_ddp_callbacks(final_callback, finalize_hook):
     _final_callback, _finalize_hook = final_callback, finalize_hook
 
 
-def _end_of_backward():
-    global _callback_queued
-    _callback_queued = False
-    # composed up-conv stages (ops.ComposedUpConv): the chain rule from the accumulated gradient of the composed weights to
-    # up_conv.weight / up_conv.bias / ops.0.conv1.weight runs once per backward() call, here
-    for p, g in ops.deliver_composed():
+def _deliver_composed(only=None):
+    """Composed up-conv stages (ops.ComposedUpConv): the chain rule from the accumulated gradient of the composed weights to
+    up_conv.weight / up_conv.bias / ops.0.conv1.weight, once per backward() call."""
+    for p, g in ops.deliver_composed(only):
         if p.requires_grad:
             _parked.setdefault(id(p), (p, []))[1].append(g)
             if _final_callback is not None:
                 _final_callback(p)
+
+
+def _end_of_backward():
+    global _callback_queued
+    _callback_queued = False
+    _deliver_composed()
     if _finalize_hook is not None:
         _finalize_hook()
     else:
@@ -319,9 +323,13 @@ class UpStageFn(Function):
             dx, g_upw, g_upb, gw0, gb0, gg0, gbe0 = ops.upconv_luconv_backward(ctx.sv0, d_a0, up_w, ctx.plist[1], w0, ctx.plist[3], g0,
                                                                                mod._composed_up, dt, need_dx=ctx.needs_input_grad[0],
                                                                                defer=defer)
-            if defer:                 # delivered (and marked final) by _end_of_backward
+            if defer:                 # delivered (and marked final) by _end_of_backward ...
                 deferred = (0, 1, 2)
                 _queue_end_of_backward()
+                if _final_callback is not None and getattr(ctx, "pass_idx", 1) == 0:
+                    # ... or, under the data-parallel wrapper, right here when this is the step's first forward pass (its backward runs
+                    # last -- the assumption mark_final already makes): the bucket's all-reduce overlaps the rest of the backward
+                    _deliver_composed(mod._composed_up)
         else:
             g_upb = torch.empty(up_w.shape[1], dtype=torch.float32, device=d_a0.device)
             d_up, gw0, gb0, gg0, gbe0 = ops.luconv_backward(ctx.sv0, d_a0, w0, g0, l0._packed, dt, need_dx=True, dx_colsum=g_upb)

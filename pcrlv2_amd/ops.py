@@ -547,17 +547,18 @@ class ComposedUpConv:
 _pending_composed: list = []
 
 
-def deliver_composed():
-    """End of a backward() call: run the chain rule of every composed up-conv that accumulated gradients in it.
-    -> [(parameter, gradient), ...] for up_conv.weight, up_conv.bias and ops.0.conv1.weight of each."""
+def deliver_composed(only=None):
+    """End of a backward() call (or, `only` = one ComposedUpConv, the moment its last pass has accumulated): run the chain rule of every
+    composed up-conv that accumulated gradients.  -> [(parameter, gradient), ...] for up_conv.weight, up_conv.bias and ops.0.conv1.weight."""
     out = []
-    if _pending_composed:
+    todo = [c for c in _pending_composed if only is None or c is only]
+    if todo:
         join_side_stream()        # the accumulations may have run on the weight-gradient side stream
-        for c in _pending_composed:
+        for c in todo:
             if c.pending is not None:
                 w_up, b_up, w0, dw_up, db_up, dw0 = c.finish()
                 out += [(w_up, dw_up), (b_up, db_up), (w0, dw0)]
-        _pending_composed.clear()
+            _pending_composed.remove(c)
     return out
 
 
