@@ -59,6 +59,13 @@ struct Brick16Params {
   int N, D, H, W;
   int K, Nc;
   int ny;             // > 0: 1-D grid of bricks x ny ids (channel tiles of a brick on one XCD, see conv_brick.hip); 0: 2-D grid
+  // UPCF instantiations only (forward of the composed ConvTranspose3d -> Conv3d operator, upconv_fused.hip): x is the COARSE tensor, the
+  // Nc = 8 * upc output channels are 8 phases x upc channels, w the zero-embedded 3x3x3 weights [8 * upc][27][K] in which a phase holds
+  // its 2 x 2 x 2 taps at (p + q) per axis.  A block (one 64-channel tile = one phase, or part of one) walks only the 4 of 9 (kd, kh) stages
+  // its phase uses (the unused kw tap of a stage multiplies zeros), writes its voxels to the phase's FINE positions of y [N][2D][2H][2W][upc]
+  // and adds bias_tab[border class of the fine voxel][channel]; the statistics rows are [bricks][8 * upc][2] = [bricks * 8][upc][2].
+  int upc;
+  const float* bias_tab;
 };
 
 __device__ __forceinline__ int key_w(int hw) { return ((0xFC30 >> hw) & 1) << 1; }   // hw in [0, 18)
@@ -81,9 +88,10 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
                : "memory");
 }
 
-template <int BN>
+template <int BN, bool UPCF = false>
 __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Params p) {
   constexpr int FN = BN / 16;
+  constexpr int NSK = UPCF ? 4 : NS;   // stages per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* wbuf = smem + HALO_BYTES;
@@ -109,6 +117,8 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
   }
   const int n0 = ytile * BN;
+  const int uph = UPCF ? n0 / p.upc : 0, ukd0 = (uph >> 2) & 1, ukh0 = (uph >> 1) & 1;
+#define SID(s_) (UPCF ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) : (s_))   /* stage number -> (kd * 3 + kh) */
   const int brick_id = b;
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
@@ -218,14 +228,14 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
 #define STAGE(P_)                                                                                          \
   do {                                                                                                     \
     int cn = c, sn = s9 + 1;                                                                               \
-    if (sn == NS) { sn = 0; cn = c + 1; }                                                                  \
+    if (sn == NSK) { sn = 0; cn = c + 1; }                                                                 \
     const bool last = (cn == nchunk);                                                                      \
     if (last) { cn = c; sn = s9; }                                                                         \
-    if (!(B16_ABL & 1)) LOAD_W(cn, sn);                                                                    \
-    const bool halo_next = (s9 == NS - 1) && !last && !(B16_ABL & 2); /* block-uniform */                  \
+    if (!(B16_ABL & 1)) LOAD_W(cn, SID(sn));                                                               \
+    const bool halo_next = (s9 == NSK - 1) && !last && !(B16_ABL & 2); /* block-uniform */                 \
     const bool more_chunks = c + 1 < nchunk && !(B16_ABL & 2);                                             \
-    const int tap64 = ((s9 / 3) * HH + (s9 % 3)) * (HP * 64);                                              \
-    const int ntap64 = ((sn / 3) * HH + (sn % 3)) * (HP * 64);                                             \
+    const int tap64 = ((SID(s9) / 3) * HH + (SID(s9) % 3)) * (HP * 64);                                    \
+    const int ntap64 = ((SID(sn) / 3) * HH + (SID(sn) % 3)) * (HP * 64);                                   \
     /* ht0: kw 0, half 0 */                                                                                \
     LOADA(1, akw[0] + tap64, 1);                                                                           \
     MFMA_HALF(0, P_, 0, 0, 4);                                                                             \
@@ -274,14 +284,14 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   } while (0)
 
   DMA_HALO(0, 0, NDMA);
-  LOAD_W(0, 0);
+  LOAD_W(0, SID(0));
   STORE_W();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  LOADA(0, akw[0], 0);
+  LOADA(0, akw[0] + ((SID(0) / 3) * HH + (SID(0) % 3)) * (HP * 64), 0);
   LOADB(0, wbuf);
 
-  const int nstage = NS * nchunk;
+  const int nstage = NSK * nchunk;
   for (int S = 0; S + 1 < nstage; S += 2) {
     STAGE(0);
     STAGE(1);
@@ -289,6 +299,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   if (nstage & 1) STAGE(0);
   __syncthreads();   // the epilogue reuses the LDS
 #undef STAGE
+#undef SID
 #undef SB
 #undef MFMA_HALF
 #undef LOADA
@@ -306,17 +317,27 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   for (int j = 0; j < FN; ++j) {
     s1[j] = 0.f;
     s2[j] = 0.f;
-    bv[j] = p.bias ? p.bias[n0 + j * 16 + lr] : 0.f;
+    bv[j] = (!UPCF && p.bias) ? p.bias[n0 + j * 16 + lr] : 0.f;
   }
+  const int uch0 = UPCF ? n0 - uph * p.upc : 0;                       // first channel of this tile inside its phase
+  const int ypitch = UPCF ? p.upc : p.Nc;
 #pragma unroll
   for (int fm = 0; fm < 8; ++fm) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t row = (((int64_t)n * p.D + d0 + wid) * p.H + h0 + fm) * p.W + w0 + lg * 4 + r;
+      int64_t row = (((int64_t)n * p.D + d0 + wid) * p.H + h0 + fm) * p.W + w0 + lg * 4 + r;
+      if (UPCF) {   // the phase's fine voxel, and the bias of its border class (0 first, 1 inside, 2 last per axis)
+        const int fd = 2 * (d0 + wid) + ((uph >> 2) & 1), fh = 2 * (h0 + fm) + ((uph >> 1) & 1), fw = 2 * (w0 + lg * 4 + r) + (uph & 1);
+        row = (((int64_t)n * (2 * p.D) + fd) * (2 * p.H) + fh) * (2 * p.W) + fw;
+        const int cls = ((fd == 0 ? 0 : (fd == 2 * p.D - 1 ? 2 : 1)) * 3 + (fh == 0 ? 0 : (fh == 2 * p.H - 1 ? 2 : 1))) * 3 +
+                        (fw == 0 ? 0 : (fw == 2 * p.W - 1 ? 2 : 1));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bv[j] = p.bias_tab[cls * p.upc + uch0 + j * 16 + lr];
+      }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const float val = acc[fm][j][r] + bv[j];
-        p.y[row * p.Nc + n0 + j * 16 + lr] = (bf16)val;
+        p.y[row * ypitch + (UPCF ? uch0 : n0) + j * 16 + lr] = (bf16)val;
         s1[j] += val;
         s2[j] += val * val;
       }
@@ -382,4 +403,24 @@ int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, v
   if (BN == 64) hipLaunchKernelGGL((brick16_conv_kernel<64>), grid, dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
   else hipLaunchKernelGGL((brick16_conv_kernel<32>), grid, dim3(256), HALO_BYTES + 3 * 32 * 64, stream, p);
   return pcrl_check_launch("brick16_conv");
+}
+
+// ---- forward of the composed ConvTranspose3d -> Conv3d operator on the wide-brick kernel (see Brick16Params::upc) ----
+// x: coarse [N][D][H][W][Ci]; w3: zero-embedded weights [8 * Co][27][Ci]; y0: fine [N][2D][2H][2W][Co]; stats [bricks * 8][Co][2]
+bool pcrl_brick16_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return pcrl_brick16_conv_eligible(N, D, H, W, Ci, 8 * Co, dtype) && Co % 64 == 0 && (int64_t)N * D * H * W * 8 < ((int64_t)1 << 29);
+}
+int pcrl_brick16_upc_fwd_launch(const void* x, const void* w3, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
+                                hipStream_t stream) {
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
+  });
+  Brick16Params p{(const bf16*)x, (const bf16*)w3, nullptr, (bf16*)y0, stats, N, D, H, W, Ci, 8 * Co, 0, Co, bias_tab};
+  const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
+  const int ny = 8 * Co / 64;
+  if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16 (composed up-conv): grid too large");
+  p.ny = ny;
+  hipLaunchKernelGGL((brick16_conv_kernel<64, true>), dim3((unsigned)(bricks * ny)), dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
+  return pcrl_check_launch("brick16_conv (composed up-conv forward)");
 }

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "mma_tile.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace {
 
@@ -607,6 +608,11 @@ int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, vo
                         int dtype, hipStream_t stream) {
   IgemmParams p{x, wf, bias_tab, y0, stats, Dims{N, D, H, W}, (int64_t)N * D * H * W, Ci, Co, 8, nullptr, 0};
   return launch_upc<GEOM_UPC_FWD>(p, 8, dtype, stream);
+}
+bool pcrl_brick16_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_brick16.hip
+bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  static const bool gather_only = [] { const char* e = getenv("PCRL_UPC_FWD_GATHER"); return e && e[0] == '1'; }();   // A/B switch
+  return g_conv_impl == 0 && !gather_only && pcrl_brick16_upc_fwd_eligible(N, D, H, W, Ci, Co, dtype);
 }
 int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype, hipStream_t stream) {
   // rows = coarse voxels, K per tap = Co (channels of dy0), 64 taps, output channels = Ci

@@ -28,6 +28,10 @@
 int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
                         int dtype, hipStream_t stream);
 int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype, hipStream_t stream);
+bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_igemm.hip: the wide-brick kernel takes this shape
+int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W);
+int pcrl_brick16_upc_fwd_launch(const void* x, const void* w3, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
+                                hipStream_t stream);
 int pcrl_gemm_planes_launch(const void* a, const void* b, float* z, int64_t M, int K, int Nc, int dtype, hipStream_t stream);
 size_t pcrl_upc_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co);
 int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
@@ -86,8 +90,10 @@ __global__ void __launch_bounds__(256) upc_prep_kernel(const float* __restrict__
 // P[(s*Ci+ci)][(t*Co+co)] (float32, row length M27 = 27*Co) -> Weff, stored as
 //   wd[(ci*64 + e)*Co + co]            e = the fine offset triple of (p, q)        (threads: co fastest -> coalesced both ways)
 //   wf[((p*Co + co)*8 + q)*Ci + ci]
+//   w3[((p*Co + co)*27 + tap)*Ci + ci]  tap = (p + q) per axis: the zero-embedded 3x3x3 form the brick kernels read (optional; pre-zeroed)
 template <typename T>
-__global__ void __launch_bounds__(256) upc_pack_kernel(const float* __restrict__ P, T* __restrict__ wf, T* __restrict__ wd, int Ci, int Co) {
+__global__ void __launch_bounds__(256) upc_pack_kernel(const float* __restrict__ P, T* __restrict__ wf, T* __restrict__ wd, T* __restrict__ w3, int Ci,
+                                                       int Co) {
   const int64_t M27 = (int64_t)27 * Co;
   const int64_t total = (int64_t)64 * Ci * Co;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -114,6 +120,7 @@ __global__ void __launch_bounds__(256) upc_pack_kernel(const float* __restrict__
     wd[i] = v;
     const int p = pd * 4 + ph * 2 + pw, q = qd * 4 + qh * 2 + qw;
     wf[(((int64_t)p * Co + co) * 8 + q) * Ci + ci] = v;
+    if (w3) w3[(((int64_t)p * Co + co) * 27 + (pd + qd) * 9 + (ph + qh) * 3 + (pw + qw)) * Ci + ci] = v;
   }
 }
 
@@ -300,8 +307,8 @@ extern "C" size_t pcrl_upconv_compose_ws_bytes(int Ci, int Cm, int Co, int dtype
   if (Ci <= 0 || Cm <= 0 || Co <= 0) return 0;
   return al((size_t)27 * Co * Cm * esz(dtype)) + al((size_t)8 * Ci * Cm * esz(dtype)) + al((size_t)27 * Co * 8 * Ci * sizeof(float));
 }
-extern "C" int pcrl_upconv_compose(const float* w_up, const float* b_up, const float* w0, const float* b0, void* wf, void* wd, float* bias_tab,
-                                   void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream) {
+extern "C" int pcrl_upconv_compose(const float* w_up, const float* b_up, const float* w0, const float* b0, void* wf, void* wd, void* w3f,
+                                   float* bias_tab, void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_upc("upconv_compose", 1, 1, 1, 1, Ci, Cm, Co, dtype)) return e;
   PCRL_REQUIRE(w_up && b_up && w0 && wf && wd && bias_tab, "upconv_compose: null pointer");
   if (!ws || ws_bytes < pcrl_upconv_compose_ws_bytes(Ci, Cm, Co, dtype)) return pcrl_fail(PCRL_EWORKSPACE, "upconv_compose: workspace too small");
@@ -316,21 +323,30 @@ extern "C" int pcrl_upconv_compose(const float* w_up, const float* b_up, const f
   // P[(s,ci)][(t,co)] = sum_cm w0[co][cm][t] * wup[ci][cm][s]
   if (int e = pcrl_gemm_planes_launch(a0, bu, P, (int64_t)27 * Co, Cm, 8 * Ci, dtype, st)) return e;
   const unsigned gp = blocks_for((int64_t)64 * Ci * Co);
-  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_pack_kernel<bf16>, dim3(gp), dim3(256), 0, st, (const float*)P, (bf16*)wf, (bf16*)wd, Ci, Co);
-  else hipLaunchKernelGGL(upc_pack_kernel<float>, dim3(gp), dim3(256), 0, st, (const float*)P, (float*)wf, (float*)wd, Ci, Co);
+  if (w3f) (void)hipMemsetAsync(w3f, 0, (size_t)216 * Ci * Co * esz(dtype), st);   // 19 of a phase's 27 taps stay zero
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_pack_kernel<bf16>, dim3(gp), dim3(256), 0, st, (const float*)P, (bf16*)wf, (bf16*)wd, (bf16*)w3f, Ci, Co);
+  else hipLaunchKernelGGL(upc_pack_kernel<float>, dim3(gp), dim3(256), 0, st, (const float*)P, (float*)wf, (float*)wd, (float*)w3f, Ci, Co);
   if (int e = pcrl_check_launch("upconv_compose (pack)")) return e;
   hipLaunchKernelGGL(upc_bias_kernel, dim3(Co), dim3(256), 0, st, w0, b_up, b0, bias_tab, Cm, Co);
   return pcrl_check_launch("upconv_compose (bias)");
 }
 
 // ---- forward / data gradient ----
-extern "C" int64_t pcrl_upconv_stats_rows(int N, int D, int H, int W) {
+extern "C" int64_t pcrl_upconv_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return pcrl_upc_fwd_uses_brick(N, D, H, W, Ci, Co, dtype) ? 1 : 0;
+}
+extern "C" int64_t pcrl_upconv_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  if (pcrl_upc_fwd_uses_brick(N, D, H, W, Ci, Co, dtype)) return 8 * pcrl_brick16_conv_rows(N, D, H, W);
   return 8 * (((int64_t)N * D * H * W + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
 }
-extern "C" int pcrl_upconv_fwd(const void* x, const void* wf, const float* bias_tab, void* y0, float* stats_partial, int N, int D, int H, int W,
-                               int Ci, int Co, int dtype, pcrl_stream_t stream) {
+extern "C" int pcrl_upconv_fwd(const void* x, const void* wf, const void* w3f, const float* bias_tab, void* y0, float* stats_partial, int N, int D, int H,
+                               int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_upc("upconv_fwd", N, D, H, W, Ci, 32, Co, dtype)) return e;
   PCRL_REQUIRE(x && wf && bias_tab && y0, "upconv_fwd: null pointer");
+  if (pcrl_upc_fwd_uses_brick(N, D, H, W, Ci, Co, dtype)) {
+    PCRL_REQUIRE(w3f, "upconv_fwd: this shape runs on the wide-brick kernel and needs the 3x3x3 form of the composed weights (w3f)");
+    return pcrl_brick16_upc_fwd_launch(x, w3f, bias_tab, y0, stats_partial, N, D, H, W, Ci, Co, as_stream(stream));
+  }
   return pcrl_upc_fwd_launch(x, wf, bias_tab, y0, stats_partial, N, D, H, W, Ci, Co, dtype, as_stream(stream));
 }
 extern "C" int pcrl_upconv_dgrad(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,

@@ -494,7 +494,7 @@ class ComposedUpConv:
 
     def __init__(self):
         self.key = None
-        self.wf = self.wd = self.bias_tab = None
+        self.wf = self.wd = self.w3f = self.bias_tab = None
         self.dweff = self.box = None
         self.pending = None     # (w_up, b_up, w0, dtype) while accumulated gradients wait for delivery
 
@@ -507,9 +507,10 @@ class ComposedUpConv:
                 raise PcrlError(f"composed up-conv: up_conv has {Cm} output channels, conv1 expects {w0.shape[1]}")
             self.wf = torch.empty(64 * Ci * Co, dtype=dtype, device=dev)
             self.wd = torch.empty(64 * Ci * Co, dtype=dtype, device=dev)
+            self.w3f = torch.empty(216 * Ci * Co, dtype=dtype, device=dev) if (dtype == torch.bfloat16 and Co % 64 == 0) else None
             self.bias_tab = _f32(27 * Co, dev)
             nb = L.call("pcrl_upconv_compose_ws_bytes", Ci, Cm, Co, dtype_code(dtype))
-            L.call("pcrl_upconv_compose", w_up.detach(), b_up.detach(), w0.detach(), b0.detach(), self.wf, self.wd, self.bias_tab,
+            L.call("pcrl_upconv_compose", w_up.detach(), b_up.detach(), w0.detach(), b0.detach(), self.wf, self.wd, self.w3f, self.bias_tab,
                    workspace(nb, dev), nb, Ci, Cm, Co, dtype_code(dtype), s)
             self.key = key
         return self.wf, self.wd, self.bias_tab
@@ -579,10 +580,10 @@ def upconv_luconv_forward(x, w_up, b_up, conv_w, conv_b, gamma, beta, running_me
         raise PcrlError(f"up_conv: input has {Ci} channels, weight expects {w_up.shape[0]}")
     wf, _, bias_tab = composed.get(w_up, b_up, conv_w, conv_b, dtype)
     M = N * D * H * W * 8
-    rows = L.call("pcrl_upconv_stats_rows", N, D, H, W)
+    rows = L.call("pcrl_upconv_stats_rows", N, D, H, W, Ci, Co, dtype_code(dtype))
     y = new_act(N, 2 * D, 2 * H, 2 * W, Co, dtype, dev)
     partial = _f32(rows * Co * 2, dev)
-    L.call("pcrl_upconv_fwd", x, wf, bias_tab, y, partial, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    L.call("pcrl_upconv_fwd", x, wf, composed.w3f, bias_tab, y, partial, N, D, H, W, Ci, Co, dtype_code(dtype), s)
     mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, True)
     a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
     sv = LUConvSaved()

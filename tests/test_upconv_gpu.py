@@ -48,6 +48,10 @@ SHAPES = [  # N, D, H, W (coarse), Ci, Cm, Co
     (1, 2, 8, 16, 64, 64, 128),     # 128 x 64 tiles inside a phase
     (1, 8, 8, 2, 64, 64, 64),       # innermost extent 2: permuted brick axes
     (3, 2, 8, 8, 32, 64, 64),       # Ci = 32 tiles
+    # shapes whose forward runs on the wide-brick kernel in bf16 (coarse D % 4 == H % 8 == W % 16 == 0, Co % 64 == 0): stage window + fine-voxel scatter
+    (1, 4, 8, 16, 64, 64, 64),      # one brick: every fine border class on its faces
+    (2, 8, 16, 32, 128, 128, 64),   # up_tr64's channels, several bricks in every direction
+    (1, 4, 8, 16, 32, 32, 128),     # two 64-channel tiles per phase
 ]
 
 
@@ -73,10 +77,10 @@ def test_composed_upconv_matches_the_two_aten_calls(shape, dt):
     xa = ops.to_act(xq.to(dt).to(DEV), dt)
     comp = ops.ComposedUpConv()
     wf, wd, tab = comp.get(wu, bu, wc, bc, dt)
-    rows = L.call("pcrl_upconv_stats_rows", N, D, H, W)
+    rows = L.call("pcrl_upconv_stats_rows", N, D, H, W, Ci, Co, dtype_code(dt))
     y = ops.new_act(N, 2 * D, 2 * H, 2 * W, Co, dt, torch.device(DEV))
     part = torch.full((rows, Co, 2), float("nan"), dtype=torch.float32, device=DEV)
-    L.call("pcrl_upconv_fwd", xa, wf, tab, y, part, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    L.call("pcrl_upconv_fwd", xa, wf, comp.w3f, tab, y, part, N, D, H, W, Ci, Co, dtype_code(dt), s)
     close(y, y_ref.detach(), 2e-2 if bf else 1e-4, "y0")
     # statistics rows: (sum, sum^2) of the unrounded accumulators -- against the reference tensor
     got = part.double().sum(0).cpu()
