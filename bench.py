@@ -63,9 +63,7 @@ def upconv_key(name, args):
     if name == "pcrl_upconv_fwd":       # (x, wf, w3f, tab, y0, stats, N, D, H, W, Ci, Co, dtype, stream)
         N, D, H, W, Ci, Co, dt = args[6:13]
         brick = dt == 1 and Co % 64 == 0 and D % 4 == 0 and H % 8 == 0 and W % 16 == 0 and os.environ.get("PCRL_DEBUG_CONV_IMPL", "0") == "0"
-        key = "brick16_conv_kernel<upconv_fwd: 12 of 27 taps>" if brick else "igemm_kernel<%s,upconv_fwd>" % ("bf16" if dt == 1 else "f32")
-        if brick:
-            return key, 2.0 * N * D * H * W * 96 * Ci * Co      # executed: 8 phases x 4 stages x 3 kw taps (one of them zero weights)
+        key = "brick16_conv_kernel<upconv_fwd>" if brick else "igemm_kernel<%s,upconv_fwd>" % ("bf16" if dt == 1 else "f32")
     elif name == "pcrl_upconv_dgrad":   # (dy0, wd, dx, N, D, H, W, Ci, Co, dtype, stream)
         N, D, H, W, Ci, Co, dt = args[3:10]
         key = "igemm_kernel<%s,upconv_dgrad>" % ("bf16" if dt == 1 else "f32")

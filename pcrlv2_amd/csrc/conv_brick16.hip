@@ -62,7 +62,7 @@ struct Brick16Params {
   // UPCF instantiations only (forward of the composed ConvTranspose3d -> Conv3d operator, upconv_fused.hip): x is the COARSE tensor, the
   // Nc = 8 * upc output channels are 8 phases x upc channels, w the zero-embedded 3x3x3 weights [8 * upc][27][K] in which a phase holds
   // its 2 x 2 x 2 taps at (p + q) per axis.  A block (one 64-channel tile = one phase, or part of one) walks only the 4 of 9 (kd, kh) stages
-  // its phase uses (the unused kw tap of a stage multiplies zeros), writes its voxels to the phase's FINE positions of y [N][2D][2H][2W][upc]
+  // its phase uses (the MFMAs of a stage's unused kw tap are skipped), writes its voxels to the phase's FINE positions of y [N][2D][2H][2W][upc]
   // and adds bias_tab[border class of the fine voxel][channel]; the statistics rows are [bricks][8 * upc][2] = [bricks * 8][upc][2].
   int upc;
   const float* bias_tab;
@@ -119,6 +119,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   const int n0 = ytile * BN;
   const int uph = UPCF ? n0 / p.upc : 0, ukd0 = (uph >> 2) & 1, ukh0 = (uph >> 1) & 1;
 #define SID(s_) (UPCF ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) : (s_))   /* stage number -> (kd * 3 + kh) */
+  const bool kw0_on = !UPCF || (uph & 1) == 0, kw2_on = !UPCF || (uph & 1) == 1;   // UPCF: the phase uses kw = pw, pw + 1 (the third tap's weights are zero)
   const int brick_id = b;
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
@@ -238,13 +239,13 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     const int ntap64 = ((SID(sn) / 3) * HH + (SID(sn) % 3)) * (HP * 64);                                   \
     /* ht0: kw 0, half 0 */                                                                                \
     LOADA(1, akw[0] + tap64, 1);                                                                           \
-    MFMA_HALF(0, P_, 0, 0, 4);                                                                             \
+    if (kw0_on) MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \
     /* ht1: kw 0, half 1 */                                                                                \
     LOADA(0, akw[1] + tap64, 0);                                                                           \
     LOADB((P_) ^ 1, wbuf + 1 * (BN * 64));                                                                 \
-    MFMA_HALF(1, P_, 1, 0, 4);                                                                             \
+    if (kw0_on) MFMA_HALF(1, P_, 1, 0, 4);                                                                 \
     PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
     SB();                                                                                                  \
     /* ht2: kw 1, half 0 */                                                                                \
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     SB();                                                                                                  \
     /* ht4: kw 2, half 0 */                                                                                \
     LOADA(1, akw[2] + tap64, 1);                                                                           \
-    MFMA_HALF(0, P_, 0, 0, 4);                                                                             \
+    if (kw2_on) MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \
     /* ht5: kw 2, half 1 -- every LDS read of this stage (and, in a chunk's last stage, of this chunk's halo) is complete */ \
@@ -269,14 +270,14 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     if (B16_EARLY && more_chunks && s9 == 2) DMA_HALO(c + 1, 0, PA);                                        \
     if (B16_EARLY && more_chunks && s9 == 5) DMA_HALO(c + 1, PA, PB);                                       \
     if (halo_next) DMA_HALO(c + 1, B16_EARLY ? PB : 0, NDMA);                                               \
-    MFMA_HALF(1, P_, 1, 0, 2);                                                                             \
+    if (kw2_on) MFMA_HALF(1, P_, 1, 0, 2);                                                                 \
     PIPE_WRITES(3, FN / 2);                                                                                     \
     SB();                                                                                                  \
     if (halo_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
     __syncthreads();                                                                                       \
     LOADA(0, akw[0] + ntap64, 0);                                                                          \
     LOADB((P_) ^ 1, wbuf);                                                                                 \
-    MFMA_HALF(1, P_, 1, 2, 4);                                                                             \
+    if (kw2_on) MFMA_HALF(1, P_, 1, 2, 4);                                                                 \
     PIPE_READS(4 + FN, 1);                                                                                 \
     SB();                                                                                                  \
     c = cn;                                                                                                \
