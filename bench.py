@@ -63,7 +63,9 @@ def upconv_key(name, args):
     if name == "pcrl_upconv_fwd":       # (x, wf, w3f, tab, y0, stats, N, D, H, W, Ci, Co, dtype, stream)
         N, D, H, W, Ci, Co, dt = args[6:13]
         brick = dt == 1 and Co % 64 == 0 and D % 4 == 0 and H % 8 == 0 and W % 16 == 0 and os.environ.get("PCRL_DEBUG_CONV_IMPL", "0") == "0"
-        key = "brick16_conv_kernel<upconv_fwd>" if brick else "igemm_kernel<%s,upconv_fwd>" % ("bf16" if dt == 1 else "f32")
+        # the wide-brick kernel's composed-forward instantiation is the same kernel (rocprofv3 lists both under brick16_conv_kernel):
+        # one key, each launch with its own EXECUTED flops
+        key = "brick16_conv_kernel" if brick else "igemm_kernel<%s,upconv_fwd>" % ("bf16" if dt == 1 else "f32")
     elif name == "pcrl_upconv_dgrad":   # (dy0, wd, dx, N, D, H, W, Ci, Co, dtype, stream)
         N, D, H, W, Ci, Co, dt = args[3:10]
         key = "igemm_kernel<%s,upconv_dgrad>" % ("bf16" if dt == 1 else "f32")
