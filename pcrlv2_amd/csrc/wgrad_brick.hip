@@ -418,6 +418,225 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Composed up-conv, weight gradient, TWO PHASES PER BLOCK (upconv_fused.hip; replaces the UPC mode of the kernel above for the launch).
+// A phase needs 2 x 2 x 2 of the 27 taps: in the 3x3x3 kernel's decomposition that is two kd-plane blocks per phase, each staging its own
+// dy image and x halo for 4 useful taps -- 92 KB staged per phase, brick and 64 input channels.  Here a block owns the two phases that
+// differ in the brick-w bit (they use the same kd and kh taps and kw = {0,1} / {1,2}): ONE x halo of three d planes (46 KB) serves both
+// kd planes of both phases, wave group g multiplies phase g's dy image against it: 39 KB per phase.  8 waves: group g = phase, wave =
+// 16-ci block; a wave holds 8 taps x 4 co fragments.  K chunk, step order, staging by LDS-DMA, transpose reads and swizzles as above.
+// Slabs ws[split][27][8 * Co][Ci] (the taps of a phase at (p + q) per axis; everything else unwritten) -> wgrad_reduce_upc_kernel.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int XPL2 = BD + 1;                        // halo planes
+constexpr int XR2 = XPL2 * XH * XW;                 // 360 rows
+constexpr int X2_BYTES = XR2 * 128;                 // 45 KiB
+constexpr int XP2 = (XR2 * 8 + NT - 1) / NT;        // 6 pieces per thread
+constexpr int BUF2_BYTES = 2 * DY_BYTES + X2_BYTES; // 77 KiB per brick buffer
+constexpr int NPIECE2 = 2 * DYP + XP2;              // 10 requests per brick and wave
+constexpr int NSTEP2 = 32;                          // 4 K chunks x 8 taps
+
+struct WBrick2Params {
+  const bf16* dy;   // fine gradient [N][2D][2H][2W][Co]
+  const bf16* x;    // coarse [N][D][H][W][Cv]
+  float* ws;
+  int N, D, H, W;   // extents of the BRICK axes (coarse)
+  int Co, Cv;
+  int nbricks, per_split, nsplit;
+  int sd, sh, sw, td, th, tw;       // brick-axis strides (coarse voxels) and tap-index strides, as in WBrickParams
+  int dsd, dsh, dsw;                // brick-axis strides in fine voxels
+  int64_t dyn;                      // fine voxels per sample
+  int phoff[8];                     // fine-voxel offset of phase (memory bit order d, h, w)
+  int bd, bh, bw;                   // bit of the memory phase index that belongs to the brick d / h / w axis
+  int order;
+};
+
+__global__ void __launch_bounds__(NT, 1) wgrad_brick_upc2_kernel(const WBrick2Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // two brick buffers: [dy image phase 0][dy image phase 1][x halo, 3 planes]
+  const int tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, grp = tid >> 8;
+  const int lg = lane >> 4, jr = (lane & 15) >> 2, cq = lane & 3;
+  const int ntj = (p.Cv + 63) / 64, nco = p.Co / 64, ntile = 4 * nco * ntj;
+  // block -> (tile, split): the tiles of one split walk the same bricks -- ids congruent mod 8 (one XCD), consecutive there
+  int member, split;
+  if ((p.nsplit & 7) == 0) {
+    const int k = blockIdx.x >> 3;
+    member = k % ntile;
+    split = (k / ntile) * 8 + (blockIdx.x & 7);
+  } else {
+    member = blockIdx.x % ntile;
+    split = blockIdx.x / ntile;
+  }
+  const int tj = member % ntj, cot = (member / ntj) % nco, pp = member / (ntj * nco);
+  const int pbd = pp >> 1, pbh = pp & 1;                            // phase bits along the brick d and h axes; group g = the brick w bit
+  const int uph0 = (pbd << p.bd) | (pbh << p.bh), uph1 = uph0 | (1 << p.bw), uphg = grp ? uph1 : uph0;
+  const int j0 = tj * 64, uco = cot * 64;
+  const int cib = wid;
+  const int b_beg = split * p.per_split;
+  const int b_end = min(b_beg + p.per_split, p.nbricks);
+  const int bw = p.W / BW, bh = p.H / BH, bd = p.D / BD;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pcp = tid & 7, srow = tid >> 3;
+  const int key_dy = ((srow >> 1) & 1) | (((srow >> 3) & 1) << 1), key_x = (srow >> 1) & 3;
+  const int pc_dy = ((((pcp >> 1) ^ key_dy) & 3) << 1) | (pcp & 1), pc = ((((pcp >> 1) ^ key_x) & 3) << 1) | (pcp & 1);
+  const bool jok = (j0 + pc * 8) < p.Cv;
+  const int xcol = j0 + pc * 8;
+  uint32_t dyoff[DYP], xoff[XP2], xedge[XP2];
+#pragma unroll
+  for (int i = 0; i < DYP; ++i) {
+    const int v = (tid >> 3) + (NT / 8) * i;
+    dyoff[i] = (uint32_t)(((v >> 6) * p.dsd + ((v >> 3) & 7) * p.dsh + (v & 7) * p.dsw) * p.Co + pc_dy * 8) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < XP2; ++i) {
+    const int r = (tid >> 3) + (NT / 8) * i;
+    const int hd = r / (XH * XW), hh = (r / XW) % XH, hw = r % XW;
+    const bool row_ok = r < XR2 && hw < BW + 2;
+    xoff[i] = row_ok ? (uint32_t)((hd * p.sd + hh * p.sh + hw * p.sw) * p.Cv + xcol) * 2u : 0u;
+    xedge[i] = (hd == 0 ? 1u : 0u) | (hd == XPL2 - 1 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == XH - 1 ? 8u : 0u) | (hw == 0 ? 16u : 0u) |
+               (hw == BW + 1 ? 32u : 0u) | (row_ok ? 0u : 64u);
+  }
+  const int dyimg1 = (p.phoff[uph1] - p.phoff[uph0]) * p.Co * 2;   // byte distance of phase 1's image from phase 0's
+  const char* zpage = reinterpret_cast<const char*>(g_wb_zero);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const char* dyb = nullptr;
+  const char* xb = nullptr;
+  uint32_t xout = 0;
+  int ob = b_beg, ow0, oh0, od0, on;
+  {
+    int t_ = b_beg;
+    ow0 = (t_ % bw) * BW; t_ /= bw;
+    if (p.order) {
+      od0 = (t_ % bd) * BD; t_ /= bd;
+      oh0 = (t_ % bh) * BH; t_ /= bh;
+    } else {
+      oh0 = (t_ % bh) * BH; t_ /= bh;
+      od0 = (t_ % bd) * BD; t_ /= bd;
+    }
+    on = t_;
+  }
+#define W2_ORIGIN_NEXT()                                                                                     \
+  do {                                                                                                       \
+    const int w0 = ow0, h0 = oh0, d0 = od0, n = on;                                                          \
+    if (ob + 1 < b_end) {                                                                                    \
+      ++ob;                                                                                                  \
+      ow0 += BW;                                                                                             \
+      if (ow0 == p.W) {                                                                                      \
+        ow0 = 0;                                                                                             \
+        if (p.order) {                                                                                       \
+          od0 += BD;                                                                                         \
+          if (od0 == p.D) { od0 = 0; oh0 += BH; if (oh0 == p.H) { oh0 = 0; ++on; } }                         \
+        } else {                                                                                             \
+          oh0 += BH;                                                                                         \
+          if (oh0 == p.H) { oh0 = 0; od0 += BD; if (od0 == p.D) { od0 = 0; ++on; } }                         \
+        }                                                                                                    \
+      }                                                                                                      \
+    }                                                                                                        \
+    const int64_t base0 = (int64_t)n * p.D * p.H * p.W + (int64_t)d0 * p.sd + h0 * p.sh + w0 * p.sw;          \
+    dyb = reinterpret_cast<const char*>(p.dy + ((int64_t)n * p.dyn + (int64_t)d0 * p.dsd + h0 * p.dsh + w0 * p.dsw + p.phoff[uph0]) * p.Co + uco); \
+    /* first halo voxel (d0 + pbd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
+    xb = reinterpret_cast<const char*>(p.x + (base0 + (int64_t)(pbd - 1) * p.sd - p.sh - p.sw) * p.Cv);      \
+    xout = (d0 + pbd - 1 < 0 ? 1u : 0u) | (d0 + pbd + 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |            \
+           (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;            \
+  } while (0)
+#define W2_DMA_PIECE(i_, buf_)                                                                               \
+  do {                                                                                                       \
+    if ((i_) < 2 * DYP) {                                                                                    \
+      const int m_ = ((i_) < 2 * DYP ? (i_) : 0) / DYP, k_ = ((i_) < 2 * DYP ? (i_) : 0) % DYP;              \
+      lds_dma16(dyb + dyoff[k_] + m_ * dyimg1, lds_base + (uint32_t)((buf_)-smem) + m_ * DY_BYTES + wv * 1024 + k_ * (NT * 16)); \
+    } else {                                                                                                 \
+      const int k_ = (i_) < 2 * DYP ? 0 : (i_) - 2 * DYP;                                                    \
+      if (8 * wv + (NT / 8) * k_ < XR2) {                                                                    \
+        const bool ok = (xedge[k_] & xout) == 0 && jok;                                                      \
+        lds_dma16(ok ? xb + xoff[k_] : zpage, lds_base + (uint32_t)((buf_)-smem) + 2 * DY_BYTES + wv * 1024 + k_ * (NT * 16)); \
+      }                                                                                                      \
+    }                                                                                                        \
+  } while (0)
+
+  // lane parts of the fragment addresses; the phase's in-plane tap origin (kh0 = pbh, kw0 = group) is a row offset folded into them
+  const int offrt = pbh * XW + grp;
+  int abase[4], xbase[6];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) abase[f] = dy_off(8 * lg + jr, f * 16 + 4 * cq);
+#pragma unroll
+  for (int ci = 0; ci < 6; ++ci) {
+    const int c = ci < 3 ? ci : ci + 1;
+    const int lrow = lg * XW + jr + offrt, col = cib * 16 + 4 * cq;
+    xbase[ci] = lrow * 128 + ((((col >> 4) ^ ((c + lrow) >> 1)) & 3) << 5) + ((col & 15) << 1);
+  }
+
+  if (b_beg < b_end) {
+    W2_ORIGIN_NEXT();
+#pragma unroll
+    for (int i = 0; i < NPIECE2; ++i) W2_DMA_PIECE(i, smem);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int b = b_beg; b < b_end; ++b) {
+    const char* dys = smem + ((b - b_beg) & 1) * BUF2_BYTES + grp * DY_BYTES;
+    const char* xs = smem + ((b - b_beg) & 1) * BUF2_BYTES + 2 * DY_BYTES;
+    char* nxt = smem + (((b - b_beg) & 1) ^ 1) * BUF2_BYTES;
+    const bool more = b + 1 < b_end;
+    W2_ORIGIN_NEXT();
+    __builtin_amdgcn_sched_barrier(0);
+    // K chunk kc = brick d plane kc >> 1, h half kc & 1 (32 voxels); tap t8 = (kd, kh, kw) offsets from the phase's origin
+#define W2_A(kc_, f_) tr_frag(dys + abase[f_] + (kc_)*4096, dys + abase[f_] + (kc_)*4096 + 512)
+#define W2_XR(kc_, t_) (((((kc_) >> 1) + ((t_) >> 2)) * XH + ((kc_)&1) * 4 + (((t_) >> 1) & 1)) * XW + ((t_)&1))
+#define W2_XADDR(r_) (xs + xbase[((r_)&7) < 3 ? ((r_)&7) : ((r_)&7) - 1] + (r_)*128)
+#define W2_B(kc_, t_) tr_frag(W2_XADDR(W2_XR(kc_, t_)), W2_XADDR(W2_XR(kc_, t_) + 4))
+    bf16x8 fa[2][4], fbr[2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fa[0][f] = W2_A(0, f);
+    fbr[0] = W2_B(0, 0);
+#pragma unroll
+    for (int st = 0; st < NSTEP2; ++st) {
+      const int kc = st / 8, t = st % 8;
+      if (st < NPIECE2) {
+        if (more) W2_DMA_PIECE(st < NPIECE2 ? st : 0, nxt);
+      }
+      if (st + 1 < NSTEP2) fbr[(st + 1) & 1] = W2_B((st + 1) / 8, (st + 1) % 8);
+      if (t == 3 && kc < 3) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) fa[(kc + 1) & 1][f] = W2_A(kc + 1, f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st & 1], acc[t][f], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef W2_A
+#undef W2_XR
+#undef W2_XADDR
+#undef W2_B
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef W2_ORIGIN_NEXT
+#undef W2_DMA_PIECE
+
+  // D[i][j]: lane holds i = 16 f + 4 lg + r, j = lane & 15 of the wave's ci block; rows of phase uphg in the [27][8 * Co][Cv] slab
+  float* out = p.ws + (int64_t)split * 27 * (8 * p.Co) * p.Cv;
+  const int j = j0 + cib * 16 + (lane & 15);
+  if (j < p.Cv) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int tap = (pbd + (t >> 2)) * p.td + (pbh + ((t >> 1) & 1)) * p.th + (grp + (t & 1)) * p.tw;
+      float* ot = out + (int64_t)tap * (8 * p.Co) * p.Cv;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[(int64_t)(uphg * p.Co + uco + f * 16 + lg * 4 + r) * p.Cv + j] = acc[t][f][r];
+    }
+  }
+}
+
 struct BrickSplit {
   int splits, per_split;
   int xcd_map, G, Q, gpc, ngroups, ntg, pair, blocks;   // co-located launch (see WBrickParams); blocks = grid size
@@ -560,32 +779,44 @@ static int upc_cfg(int Ci, int Co) {
 bool pcrl_wgrad_brick_upc_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
   return pcrl_wgrad_brick_eligible(N, D, H, W, Ci, 8 * Co, dtype) && Co % 64 == 0 && (int64_t)N * D * H * W * 8 * Co < ((int64_t)1 << 31);
 }
+// split plan of the two-phases-per-block kernel: 4 x (Co / 64) x ceil(Ci / 64) tiles per brick range; whole rounds of the eight XCDs
+static void upc2_plan(int nbricks, int Ci, int Co, int& splits, int& per) {
+  const int ntile = 4 * (Co / 64) * ((Ci + 63) / 64);
+  int s = 512 / ntile;
+  if (s < 1) s = 1;
+  if (s > nbricks / 16) s = nbricks / 16;
+  if (s < 1) s = 1;
+  if (s >= 8) s &= ~7;
+  per = (nbricks + s - 1) / s;
+  const int used = (nbricks + per - 1) / per;
+  splits = (s >= 8 && (used & 7)) ? s : used;
+}
 int pcrl_wgrad_brick_upc_slabs(int N, int D, int H, int W, int Ci, int Co) {
-  return plan_xcd((int)((int64_t)N * D * H * W / BV), 8 * Co, Ci, upc_cfg(Ci, Co)).splits;
+  int splits, per;
+  upc2_plan((int)((int64_t)N * D * H * W / BV), Ci, Co, splits, per);
+  return splits;
 }
 int pcrl_wgrad_brick_upc_launch(const void* x, const void* dy0, float* ws, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
   const int nbricks = (int)((int64_t)N * D * H * W / BV);
-  const BrickSplit sp = plan_xcd(nbricks, 8 * Co, Ci, upc_cfg(Ci, Co));
-  WBrickParams p{(const bf16*)dy0, (const bf16*)x, ws, N, D, H, W, 8 * Co, Ci, nbricks, sp.per_split, 0, 3, H * W, W, 1, 9, 3, 1};
-  p.xcd_map = sp.xcd_map; p.order = g_wb_order; p.G = sp.G; p.Q = sp.Q; p.gpc = sp.gpc; p.ngroups = sp.ngroups; p.ntg = sp.ntg; p.pair = sp.pair;
-  p.upc = Co;
-  p.dyn = (int64_t)8 * D * H * W;
+  int splits, per;
+  upc2_plan(nbricks, Ci, Co, splits, per);
+  WBrick2Params p{(const bf16*)dy0, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, per, splits, H * W, W, 1, 9, 3, 1, 8 * H * W, 4 * W, 2,
+                  (int64_t)8 * D * H * W, {0, 0, 0, 0, 0, 0, 0, 0}, 2, 1, 0, g_wb_order};
   for (int ph = 0; ph < 8; ++ph) p.phoff[ph] = (((ph >> 2) & 1) * (2 * H) + ((ph >> 1) & 1)) * (2 * W) + (ph & 1);
-  p.dsd = 8 * H * W; p.dsh = 4 * W; p.dsw = 2; p.pax = 2; p.pbh = 1; p.pbw = 0;   // brick axes = memory (d, h, w) = bits (2, 1, 0) of the phase index
   if (!wb_natural(D, H, W)) {   // memory (D, H, W) -> brick axes (W, D, H)
     p.D = W; p.H = D; p.W = H;
     p.sd = 1; p.sh = H * W; p.sw = W;
     p.td = 1; p.th = 9; p.tw = 3;
-    p.dsd = 2; p.dsh = 8 * H * W; p.dsw = 4 * W; p.pax = 0; p.pbh = 2; p.pbw = 1;   // brick (d, h, w) = memory (w, d, h) = bits (0, 2, 1)
+    p.dsd = 2; p.dsh = 8 * H * W; p.dsw = 4 * W;
+    p.bd = 0; p.bh = 2; p.bw = 1;          // brick (d, h, w) = memory (w, d, h) = phase bits (0, 2, 1)
   }
-  dim3 grid((unsigned)sp.blocks);
-  switch (sp.cfg) {
-    case 1: launch_cfg<128, 64, true>(grid, stream, p); break;
-    case 2: launch_cfg<64, 128, true>(grid, stream, p); break;
-    case 3: launch_cfg<64, 32, true>(grid, stream, p); break;
-    default: launch_cfg<64, 64, true>(grid, stream, p); break;
-  }
-  return pcrl_check_launch("wgrad_brick (composed up-conv)");
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_upc2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF2_BYTES);
+  });
+  const int ntile = 4 * (Co / 64) * ((Ci + 63) / 64);
+  hipLaunchKernelGGL(wgrad_brick_upc2_kernel, dim3((unsigned)(ntile * splits)), dim3(NT), 2 * BUF2_BYTES, stream, p);
+  return pcrl_check_launch("wgrad_brick (composed up-conv, two phases per block)");
 }
 
 // ---- 2D path: weight gradient of a 3x3 / stride 1 / pad 1 convolution over N images (N % 2 == 0): the image index is the depth ----
