@@ -77,14 +77,6 @@ struct WBrickParams {
   int xcd_map;
   int order;        // brick walk order: 0 = w, h, d, n ; 1 = w, d, h, n
   int G, Q, gpc, ngroups, ntg, pair;   // group size, groups per XCD and chunk, groups per chunk, groups, tile groups per range, 0 none / 1 pair over j / 2 pair over i
-  // Composed up-conv mode (upc > 0; conv_wgrad.hip / upconv_fused.hip): x is the COARSE tensor [N][D][H][W][Cv] and "dy" the fine gradient
-  // dy0 [N][2D][2H][2W][upc] seen as 8 * upc channels on the coarse grid -- tile i0 belongs to phase i0 / upc and reads the fine voxels
-  // 2v + phase: dsd / dsh / dsw are the strides of the BRICK axes in fine voxels, dyn the fine voxels per sample, phoff[8] the phase's
-  // voxel offset.  A phase needs only 2 of the 3 taps along every axis: blocks whose kd plane is the unused one exit (pax = the bit of the
-  // phase index that belongs to the brick d axis); their slab entries stay unwritten and are never read (upc_chain_pack_kernel).
-  int upc, dsd, dsh, dsw, pax, pbh, pbw;   // pbh / pbw: phase-index bits of the brick h / w axes (in-plane taps a phase uses)
-  int64_t dyn;
-  int phoff[8];
 };
 
 __device__ __forceinline__ int dy_off(int v, int col) {   // 128-byte rows, 32-byte quads XOR-swizzled (see conv_wgrad.hip)
@@ -116,7 +108,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* p0, const char* p1) {
   return u.f;
 }
 
-template <int TCO, int TCI, bool UPC = false>   // UPC: composed up-conv mode (compile-time: the 3x3x3 instantiations carry none of its branches)
+template <int TCO, int TCI>
 __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p) {
   using C = WCfg<TCO, TCI>;
   constexpr int FA = C::FA, NSTEP = C::NSTEP, BUF_BYTES = C::BUF_BYTES, NPIECE = C::NPIECE, KSPLIT = C::KSPLIT;
@@ -150,16 +142,6 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     split = blockIdx.x;
   }
   const int i0 = (tile / ntj) * TCO, j0 = (tile % ntj) * TCI;
-  const int uph = UPC ? i0 / p.upc : 0, uco = UPC ? i0 % p.upc : i0;   // composed up-conv: phase and channel offset inside the phase
-  if (UPC && kd == (((uph >> p.pax) & 1) ? 0 : 2)) return;                 // this phase has no tap in that plane
-  const int dpitch = UPC ? p.upc : p.Cu;
-  uint32_t tmask = 0x1FFu;   // in-plane taps (kh * 3 + kw) to multiply
-  if (UPC) {
-    const int bh_ = (uph >> p.pbh) & 1, bw_ = (uph >> p.pbw) & 1;
-    tmask = 0;
-    for (int a = 0; a < 2; ++a)
-      for (int b = 0; b < 2; ++b) tmask |= 1u << ((bh_ + a) * 3 + bw_ + b);
-  }
   // roles of this wave: dy image / x image of its group, its 16-ci block and (TCI = 32) its co half
   const int dyimg = C::IMG_DY == 2 ? grp : 0, ximg = C::IMG_X == 2 ? grp : 0;
   const int cib = C::HALFCI ? (wid & 1) : wid, cobase = C::HALFCI ? (wid >> 1) * 32 : 0;
@@ -196,8 +178,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #pragma unroll
   for (int i = 0; i < DYP; ++i) {
     const int v = (tid >> 3) + (NT / 8) * i;
-    dyoff[i] = UPC ? (uint32_t)(((v >> 6) * p.dsd + ((v >> 3) & 7) * p.dsh + (v & 7) * p.dsw) * dpitch + pc_dy * 8) * 2u
-                     : (uint32_t)(((v >> 6) * p.sd + ((v >> 3) & 7) * p.sh + (v & 7) * p.sw) * p.Cu + pc_dy * 8) * 2u;
+    dyoff[i] = (uint32_t)(((v >> 6) * p.sd + ((v >> 3) & 7) * p.sh + (v & 7) * p.sw) * p.Cu + pc_dy * 8) * 2u;
   }
 #pragma unroll
   for (int i = 0; i < XP; ++i) {
@@ -267,8 +248,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
       }                                                                                                      \
     }                                                                                                        \
     const int64_t base0 = (int64_t)n * p.D * p.H * p.W + (int64_t)d0 * p.sd + h0 * p.sh + w0 * p.sw;          \
-    dyb = UPC ? reinterpret_cast<const char*>(p.dy + ((int64_t)n * p.dyn + (int64_t)d0 * p.dsd + h0 * p.dsh + w0 * p.dsw + p.phoff[uph]) * dpitch + uco) \
-                : reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                   \
+    dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                           \
     /* first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
     const int64_t xbase0 = p.up ? (((int64_t)n * p.D + d0) * Hs + (h0 >> 1)) * Ws + (w0 >> 1) : base0;       \
     xb = reinterpret_cast<const char*>(p.x + (xbase0 + (p.up ? ((int64_t)(kd - 1) * Hs - 1) * Ws - 1 : (int64_t)(kd - 1) * p.sd - p.sh - p.sw)) * p.Cv); \
@@ -360,7 +340,6 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
         for (int f = 0; f < FA; ++f) fa[(kc + 1) & 1][f] = WB_A(kc + 1, f);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch reads AHEAD of this step's MFMAs (hipcc sinks them next to their use otherwise)
-      if (UPC && !((tmask >> t) & 1u)) continue;   // composed up-conv: this in-plane tap is not one of the phase's 2 x 2 (block-uniform)
 #pragma unroll
       for (int f = 0; f < FA; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st % (PF + 1)], acc[t][f], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -419,7 +398,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Composed up-conv, weight gradient, TWO PHASES PER BLOCK (upconv_fused.hip; replaces the UPC mode of the kernel above for the launch).
+// Composed up-conv, weight gradient, TWO PHASES PER BLOCK (upconv_fused.hip).
 // A phase needs 2 x 2 x 2 of the 27 taps: in the 3x3x3 kernel's decomposition that is two kd-plane blocks per phase, each staging its own
 // dy image and x halo for 4 useful taps -- 92 KB staged per phase, brick and 64 input channels.  Here a block owns the two phases that
 // differ in the brick-w bit (they use the same kd and kh taps and kw = {0,1} / {1,2}): ONE x halo of three d planes (46 KB) serves both
@@ -714,13 +693,13 @@ BrickSplit plan3(int nbricks, int Cu, int Cv) {
   return (used_a < 230 && used_b > used_a) ? b : a;
 }
 
-template <int TCO, int TCI, bool UPC = false> void launch_cfg(dim3 grid, hipStream_t stream, const WBrickParams& p) {
+template <int TCO, int TCI> void launch_cfg(dim3 grid, hipStream_t stream, const WBrickParams& p) {
   static std::once_flag attr_once;   // hipFuncSetAttribute once per process and instantiation, race-free
   constexpr int lds = 2 * WCfg<TCO, TCI>::BUF_BYTES;
   std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel<TCO, TCI, UPC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick_kernel<TCO, TCI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
-  hipLaunchKernelGGL((wgrad_brick_kernel<TCO, TCI, UPC>), grid, dim3(NT), lds, stream, p);
+  hipLaunchKernelGGL((wgrad_brick_kernel<TCO, TCI>), grid, dim3(NT), lds, stream, p);
 }
 
 }  // namespace
@@ -769,13 +748,8 @@ int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int
 }
 
 
-// ---- composed up-conv (upconv_fused.hip): gradient of the zero-embedded 3x3x3 weights W3[8 * Co][Ci][27] on the COARSE grid ----
-// x: coarse [N][D][H][W][Ci]; dy0: fine [N][2D][2H][2W][Co]; slabs ws[split][27][8 * Co][Ci] (entries of a phase's unused planes unwritten)
-static int upc_cfg(int Ci, int Co) {
-  if (Co % 128 == 0) return 1;          // 128 x 64 tiles inside a phase
-  if (Ci % 128 == 0) return 2;          // Co == 64: 64 x 128
-  return Ci == 32 ? 3 : 0;
-}
+// ---- composed up-conv (upconv_fused.hip): gradient of the composed weights on the COARSE grid (wgrad_brick_upc2_kernel) ----
+// x: coarse [N][D][H][W][Ci]; dy0: fine [N][2D][2H][2W][Co]; slabs ws[split][27][8 * Co][Ci] (only a phase's 8 taps written)
 bool pcrl_wgrad_brick_upc_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
   return pcrl_wgrad_brick_eligible(N, D, H, W, Ci, 8 * Co, dtype) && Co % 64 == 0 && (int64_t)N * D * H * W * 8 * Co < ((int64_t)1 << 31);
 }
