@@ -14,7 +14,7 @@ find $R/gpurun_out/$TAG -name "*.csv" | grep -v agent_info | xargs ls -la | awk 
 for d in fetch write sq; do
   f=$(find $R/gpurun_out/$TAG/$d -name "*counter_collection.csv")
   head -1 $f > $R/gpurun_out/$TAG/$d.csv
-  grep "brick16_conv_kernel\|brick_conv_kernel\|wgrad_brick_kernel\|wgrad_upc8_kernel\|igemm_kernelIDF16bLi[0-9]*ELi[34]E\|bn_bwd_apply_rc_kernel\|bn_bwd_reduce_kernel\|bn_apply_rc_kernel\|bn_apply_gap_kernel\|bn_apply_pool_kernel\|bn_bwd_apply_pool_kernel\|bn_bwd_reduce_pool_kernel\|maxpool_\|gap_bwd_kernel\|coltile_sum_kernel" $f >> $R/gpurun_out/$TAG/$d.csv
+  grep "brick16_conv_kernel\|brick_conv_kernel\|wgrad_brick_kernel\|wgrad_brick_upc2_kernel\|wgrad_upc8_kernel\|igemm_kernelIDF16bLi[0-9]*ELi[34]E\|bn_bwd_apply_rc_kernel\|bn_bwd_reduce_kernel\|bn_apply_rc_kernel\|bn_apply_gap_kernel\|bn_apply_pool_kernel\|bn_bwd_apply_pool_kernel\|bn_bwd_reduce_pool_kernel\|maxpool_\|gap_bwd_kernel\|coltile_sum_kernel" $f >> $R/gpurun_out/$TAG/$d.csv
   rm -f $f $(find $R/gpurun_out/$TAG/$d -name "*kernel_trace.csv")
 done
 cd $R && python tools/summarize_profiles.py $TAG $(find gpurun_out/$TAG/stats -name "*kernel_stats.csv") 8 gpurun_out/$TAG/fetch.csv gpurun_out/$TAG/write.csv gpurun_out/$TAG/sq.csv > gpurun_out/$TAG.summary.txt 2>&1
