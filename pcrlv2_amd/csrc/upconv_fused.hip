@@ -195,42 +195,50 @@ __global__ void __launch_bounds__(256) upc_chain_unpack_kernel(const float* __re
   }
 }
 
-// Border-class sums of dy0 for the gradient of the transposed convolution's bias.  Block = one (n, fine d) plane of dy0 [2H][2W][C];
-// thread = (channel vector, row slot) keeps 9 accumulators (h class x w class); part[plane][9][C].
+// Border-class sums of dy0 for the gradient of the transposed convolution's bias.  Block = one (n, fine d) plane of dy0 [FH][FW][C];
+// thread = (channel vector, w slot).  The class of a voxel is fixed by the loop it is visited in -- rows h = 0 / inside / FH - 1, and inside
+// a row the columns w = 0 / inside / FW - 1 -- so the streaming loop is one 16-byte load and VEC adds (a per-element class select over
+// nine accumulators made the first version VALU-bound: 183 us for 268 MB).  part[plane][9][C], k = h class * 3 + w class.
 template <typename T>
 __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict__ dy, float* __restrict__ part, int FH, int FW, int C) {
   constexpr int VEC = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [slots][C]
   const int tid = threadIdx.x, nvec = C / VEC, cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
-  const int64_t rows = (int64_t)FH * FW;
-  const T* base = dy + (int64_t)blockIdx.x * rows * C;
+  const T* base = dy + (int64_t)blockIdx.x * FH * FW * C + cv * VEC;
   float acc[9][VEC];
 #pragma unroll
   for (int k = 0; k < 9; ++k)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[k][j] = 0.f;
-  for (int64_t r = slot; r < rows; r += nslots) {
-    const int h = (int)(r / FW), w = (int)(r % FW);
-    const int k = (h == 0 ? 0 : (h == FH - 1 ? 2 : 1)) * 3 + (w == 0 ? 0 : (w == FW - 1 ? 2 : 1));
-    const Vec16<T> v = ld16(base + (r * nvec + cv) * VEC);
-#pragma unroll
-    for (int q = 0; q < 9; ++q)
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[q][j] += (q == k) ? to_f(v.v[j]) : 0.f;
+  // a row (or a run of rows) of one h class: columns 1 .. FW - 2 over the slots, the two border columns by slot 0
+#define ROWS(h0_, h1_, K_)                                                                      \
+  for (int h = (h0_); h < (h1_); ++h) {                                                         \
+    const T* row = base + (int64_t)h * FW * C;                                                  \
+    for (int w = 1 + slot; w < FW - 1; w += nslots) {                                           \
+      const Vec16<T> v = ld16(row + (int64_t)w * C);                                            \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[(K_)*3 + 1][j] += to_f(v.v[j]);       \
+    }                                                                                           \
+    if (slot == 0) {                                                                            \
+      const Vec16<T> v0 = ld16(row), v1 = ld16(row + (int64_t)(FW - 1) * C);                    \
+      _Pragma("unroll") for (int j = 0; j < VEC; ++j) {                                         \
+        acc[(K_)*3 + 0][j] += to_f(v0.v[j]);                                                    \
+        acc[(K_)*3 + 2][j] += to_f(v1.v[j]);                                                    \
+      }                                                                                         \
+    }                                                                                           \
   }
+  ROWS(0, 1, 0)
+  ROWS(1, FH - 1, 1)
+  ROWS(FH - 1, FH, 2)
+#undef ROWS
+#pragma unroll
   for (int q = 0; q < 9; ++q) {
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      float v = 0.f;
-#pragma unroll
-      for (int qq = 0; qq < 9; ++qq) v = (qq == q) ? acc[qq][j] : v;
-      sm[slot * C + cv * VEC + j] = v;
-    }
+    for (int j = 0; j < VEC; ++j) sm[slot * C + cv * VEC + j] = acc[q][j];
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
       float a = 0.f;
-      for (int s = 0; s < nslots; ++s) a += sm[s * C + c];
+      for (int s2 = 0; s2 < nslots; ++s2) a += sm[s2 * C + c];
       part[((int64_t)blockIdx.x * 9 + q) * C + c] = a;
     }
   }
