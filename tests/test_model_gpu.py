@@ -309,6 +309,45 @@ def test_fused_cosine_terms_equal_the_26_separate_launches():
             assert d < 1e-4 or float(gb[n].abs().max()) < 1e-7, (n, d)
 
 
+@pytest.mark.parametrize("switch", ["COMPOSE_UPCONV", "FOLD_POOL_GRAD", "FOLD_GAP_GRAD", "FUSE_APPLY_CONSUMERS"])
+def test_round2_fusions_leave_the_step_unchanged_fp32(switch):
+    """Each memory-pass fusion of round 2 (config.py) against the separate kernels it replaces, on a whole training step in the exact-fp32
+    mode: same losses, same gradient for every parameter (float32 summation order -- and, for the composed up-conv, the association of
+    two nested sums -- aside).  COMPOSE_UPCONV: UpTransition's ConvTranspose3d -> Conv3d as one operator, gradients of up_conv.weight /
+    up_conv.bias / ops.0.conv1.weight through the composed weights, accumulated over the three passes and delivered once per backward()."""
+    from pcrlv2_amd import config, train_3d as T
+    batch = O.fill_batch(4, (32, 32, 16), dtype=torch.float32, seed=12)
+    res = []
+    for on in (True, False):
+        old = getattr(config, switch)
+        setattr(config, switch, on)
+        try:
+            model = build(torch.float32)
+            random.seed(7)
+            T.begin_step()
+            losses = T.step_losses(model, batch, 3, MSELoss(), CosineSimilarityMean())
+            losses[0].backward()
+            res.append(([float(l) for l in losses], {n: (None if p.grad is None else p.grad.clone()) for n, p in model.named_parameters()}))
+        finally:
+            setattr(config, switch, old)
+    (la, ga), (lb, gb) = res
+    for a, b in zip(la, lb):
+        assert abs(a - b) < 5e-6, (switch, la, lb)
+    worst = ("", 0.0)
+    for n in ga:
+        assert (ga[n] is None) == (gb[n] is None), (switch, n)
+        if ga[n] is not None:
+            d = float((ga[n] - gb[n]).norm()) / max(float(gb[n].norm()), 1e-12)
+            if float(gb[n].abs().max()) >= 1e-7 and d > worst[1]:
+                worst = (n, d)
+    print(f"  {switch}: worst relative gradient difference {worst[1]:.2e} ({worst[0]})")
+    # The three folds change no arithmetic (measured 0 .. 2e-6).  The composed up-conv changes the association of two nested float32 sums:
+    # y0 moves by ~1e-6 relative, and the backward through 17 batch-statistics normalisations and the cosine terms amplifies float32
+    # round-off to ~1e-2 against the float64 golden on EITHER route (test_fp32_step_matches_reference_golden: 0.6e-2 .. 1.05e-2; stock
+    # PyTorch float32: 7e-3) -- the two routes differ from each other by 4e-4 .. 4e-3, uniformly over all layers.
+    assert worst[1] < (1e-2 if switch == "COMPOSE_UPCONV" else 2e-5), (switch, worst)
+
+
 def test_optional_groupnorm_silu_mode_vs_torch_definition():
     """PCRLv23d(norm='gn', act='silu') -- an OPTIONAL, NON-REFERENCE mode (BASELINE.json's north_star names GroupNorm + SiLU; the
     reference's own norm='gn' crashes at construction and it rejects 'silu').  Checked against the oracle's torch
