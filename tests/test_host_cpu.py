@@ -340,3 +340,42 @@ def test_c1_plumbing_2d_oracle_cpu():
             for k, v in so.items():
                 sd[k] = v
     assert losses[-1] < losses[0], losses
+
+
+def test_composed_upconv_algebra_in_float64():
+    """The identity csrc/upconv_fused.hip builds on, restated in torch float64 on the CPU (no library call): ConvTranspose3d(k2,s2) followed
+    by Conv3d(3x3x3, pad 1) equals, phase by phase, an 8-tap operator on the zero-padded coarse tensor with
+    Weff[p][q] = sum over the (t, s) pairs of (p, q) of Wup[:, :, s] W0[:, :, t]^T   (per axis: (0,0): (0,1); (0,1): (1,0),(2,1); (1,0): (0,0),(1,1); (1,1): (2,0))
+    plus a bias that depends on the border class of the fine voxel (the inner convolution zero-pads the UPSAMPLED tensor)."""
+    import itertools
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    N, D, H, W, Ci, Cm, Co = 2, 2, 3, 2, 3, 4, 5
+    x = torch.randn(N, Ci, D, H, W, generator=g, dtype=torch.float64)
+    wup, bup = torch.randn(Ci, Cm, 2, 2, 2, generator=g, dtype=torch.float64), torch.randn(Cm, generator=g, dtype=torch.float64)
+    w0, b0 = torch.randn(Co, Cm, 3, 3, 3, generator=g, dtype=torch.float64), torch.randn(Co, generator=g, dtype=torch.float64)
+    ref = F.conv3d(F.conv_transpose3d(x, wup, bup, stride=2), w0, b0, padding=1)
+    pairs = {(0, 0): [(0, 1)], (0, 1): [(1, 0), (2, 1)], (1, 0): [(0, 0), (1, 1)], (1, 1): [(2, 0)]}
+    xp = F.pad(x, (1, 1, 1, 1, 1, 1))                       # zero padding of the COARSE tensor
+    out = torch.zeros_like(ref)
+    for p in itertools.product((0, 1), repeat=3):
+        acc = torch.zeros(N, Co, D, H, W, dtype=torch.float64)
+        for q in itertools.product((0, 1), repeat=3):
+            weff = torch.zeros(Ci, Co, dtype=torch.float64)
+            for (td, sd), (th, sh), (tw, sw) in itertools.product(pairs[p[0], q[0]], pairs[p[1], q[1]], pairs[p[2], q[2]]):
+                weff += wup[:, :, sd, sh, sw] @ w0[:, :, td, th, tw].t()
+            # coarse voxel v + p - 1 + q  ->  index v + p + q in the padded tensor
+            sl = xp[:, :, p[0] + q[0]:p[0] + q[0] + D, p[1] + q[1]:p[1] + q[1] + H, p[2] + q[2]:p[2] + q[2] + W]
+            acc += torch.einsum("ncdhw,co->nodhw", sl, weff)
+        out[:, :, p[0]::2, p[1]::2, p[2]::2] = acc
+    # bias: b0 + the taps of w0 that stay inside the fine grid applied to b_up
+    FD, FH, FW = 2 * D, 2 * H, 2 * W
+    ok = lambda t, f, n: 0 <= f + t - 1 < n
+    for fd, fh, fw in itertools.product(range(FD), range(FH), range(FW)):
+        bias = b0.clone()
+        for td, th, tw in itertools.product(range(3), repeat=3):
+            if ok(td, fd, FD) and ok(th, fh, FH) and ok(tw, fw, FW):
+                bias += w0[:, :, td, th, tw] @ bup
+        out[:, :, fd, fh, fw] += bias
+    assert torch.allclose(out, ref, rtol=1e-12, atol=1e-12), float((out - ref).abs().max())
