@@ -24,6 +24,9 @@
 // weight staging -13 %, without both -22 % (1 560 TFLOP/s); requesting the dead planes early changes nothing.  What is left on the
 // table is bytes staged per MFMA, not latency.  (Also tried: weight fragments straight from global memory into registers, no weight stage
 // in LDS and no per-stage barriers -- 16 x 64-byte segments per load instruction, L1 / address-path bound: -30 %.)
+// The epilogue (128 two-byte stores per lane) costs 7 % (64 -> 64 channels) to 16 % (32 -> 64: one K chunk per block) by the same kind of
+// ablation; storing 4-byte channel pairs after a lane-pair exchange (64 stores, 2 DPP moves and 6 selects per fragment) measured equal
+// or 3 % worse, 8-byte quads through a transposed accumulator layout 4 % worse (spills): the stores stay as they are.
 //
 // LDS: halo 68 KiB (single buffer: 1080 rows x 64 B, rounded up to whole 1 KiB DMA pieces) + one weight stage 12 KiB = 80 KiB -> two
 // blocks (eight waves) per CU.  The next chunk's halo is requested as soon as every wave holds the last fragments of the current one
