@@ -7,7 +7,9 @@
   step     : one pass of train_3d.train_step over one batch.
   roofline : the dominant kernel (bf16 LDS-halo implicit-GEMM 3x3x3 convolution, forward + data-gradient launches): algorithmic
              FLOPs (2*M*27*Ci*Co per launch) / launch duration measured with HIP events on the launch stream, against
-             the dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).
+             the dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).  The weight-gradient kernels run on a
+             side stream next to these launches, so the timed-region figure is the kernel under that contention (it agrees with the
+             rocprofv3 summary of the same command); roofline.alone is the same kernel over 10 extra steps with the side stream off.
   cpu_baseline : the CPU oracle (a port of the reference step, oracle/pcrlv2_oracle.py) timed on this box's host cores on
              a bounded sample (b=8, <= 3 steps or ~35 s), rank 0, N=1 only.
 
@@ -135,6 +137,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dhw", default="64,64,32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alone", action="store_true", help="skip the extra roofline.alone steps (rocprofv3 runs: the trace then holds the timed configuration only)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -237,6 +240,24 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # Weight gradients run on a side stream next to the data-gradient / BatchNorm chain (config.WGRAD_SIDE_STREAM_3D), so the per-launch
+    # times above are times under that contention.  A few extra steps with the side stream off (after the timed region, one GPU only)
+    # give the dominant kernel's time with the chip to itself: reported as roofline.alone, never as `value`.
+    from pcrlv2_amd import config as _cfg
+    alone = None
+    if world == 1 and _cfg.WGRAD_SIDE_STREAM_3D and not args.no_alone:
+        _cfg.WGRAD_SIDE_STREAM_3D = False
+        for _ in range(2):
+            train_step(model, opt, batch, 0, crit, cosine, guard=False)
+        alone = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_upconv_fwd"}, keyfn)
+        torch.cuda.synchronize()
+        L.profiler = alone
+        for _ in range(min(10, args.steps)):
+            train_step(model, opt, batch, 0, crit, cosine, guard=False)
+        torch.cuda.synchronize()
+        L.profiler = None
+        _cfg.WGRAD_SIDE_STREAM_3D = True
+
     if rank != 0:
         return
     res = prof.results()
@@ -274,7 +295,8 @@ def main():
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
                      "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
                      "avg_launch_ms": round(ms / n, 4), "launches": n, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
-                     "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(work / n)},
+                     "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(work / n),
+                     "concurrent": "weight-gradient kernels on a side stream" if alone is not None else None},
         "step_mfma_frac": round(flop_per_crop * args.b * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4) if flop_per_crop else None,
         "kernels": detail, "final_loss": round(loss, 5),
         "diag": {"gpu_ms_per_step": per_step,
@@ -282,6 +304,11 @@ def main():
                  "alloc_retries": ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
                  "reserved_GB": round(ms1.get("reserved_bytes.all.peak", 0) / 2**30, 1)},
     }
+    if alone is not None and dom in alone.results():
+        n1, ms1_, work1 = alone.results()[dom]
+        a1 = work1 / (ms1_ * 1e-3) / 1e12
+        line["roofline"]["alone"] = {"achieved": round(a1, 1), "frac": round(a1 / line["roofline"]["peak"], 4), "avg_launch_ms": round(ms1_ / n1, 4),
+                                     "launches": n1, "note": "same kernel, extra steps after the timed region with PCRL_WGRAD_STREAM=0 semantics"}
     if dist_info is not None:
         line["distributed"] = dist_info
         line["per_gpu_value"] = round(crops / world, 2)

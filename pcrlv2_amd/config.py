@@ -28,11 +28,11 @@ DIRECT_PARAM_GRADS = os.environ.get("PCRL_AUTOGRAD_PARAM_GRADS", "0") != "1"
 
 # Weight-gradient kernels on a side stream, concurrently with the data-gradient / BatchNorm-backward chain of the layers below
 # (MFMA-bound next to HBM-bound work); joined before the parameter gradients are summed (ops.side_wgrad).
-#   PCRL_WGRAD_STREAM unset: on for the 2D path (+3.6 % at C5), off for the 3D path -- there it gains 1.5 % of step time but every
-#   kernel then shares the chip with a neighbour, so the per-launch HIP-event times that bench.py's roofline reports (and that must
-#   agree with the rocprofv3 summary) stop describing the kernel alone;  =1: on everywhere;  =0: off everywhere.
+#   PCRL_WGRAD_STREAM unset or 1: on (2D: +3.6 % at C5; 3D: +4 % at C2, 38.45 -> 36.95 ms same box);  =0: off everywhere.
+#   With a neighbour on the chip a kernel's per-launch time is its time UNDER that contention (brick16 0.333 -> 0.346 ms): bench.py's
+#   `roofline` reports the timed region as it ran and adds `roofline.alone` from a few extra steps with the side stream off.
 _ws = os.environ.get("PCRL_WGRAD_STREAM", "")
-WGRAD_SIDE_STREAM_3D = _ws == "1"
+WGRAD_SIDE_STREAM_3D = _ws != "0"
 WGRAD_SIDE_STREAM_2D = _ws != "0"
 
 # The global-average-pool branch of UpTransition (pcrlv2_model_3d.py:67) sends d_g[n][c] / S back to every voxel of a1: folded into the

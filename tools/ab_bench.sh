@@ -3,8 +3,8 @@
 A="$1"; B="$2"; R=${3:-2}; S=${4:-15}
 mkdir -p gpurun_out/ab
 for i in $(seq 1 $R); do
-  env $A python bench.py --steps $S --warmup 4 --no-cpu-baseline > gpurun_out/ab/a_$i.json 2> gpurun_out/ab/a_$i.err
-  env $B python bench.py --steps $S --warmup 4 --no-cpu-baseline > gpurun_out/ab/b_$i.json 2> gpurun_out/ab/b_$i.err
+  env $A python bench.py --steps $S --warmup 4 --no-cpu-baseline --no-alone > gpurun_out/ab/a_$i.json 2> gpurun_out/ab/a_$i.err
+  env $B python bench.py --steps $S --warmup 4 --no-cpu-baseline --no-alone > gpurun_out/ab/b_$i.json 2> gpurun_out/ab/b_$i.err
 done
 python - <<PY
 import json, glob
