@@ -62,15 +62,17 @@ def wgrad_key(name, args):
 def upconv_key(name, args):
     """The composed ConvTranspose3d -> Conv3d operator (csrc/upconv_fused.hip): EXECUTED flops = 8 phases x 8 coarse taps per coarse voxel
     (the 27-tap convolution over the upsampled tensor it replaces would be 27/8 of that, plus the transposed convolution)."""
+    from pcrlv2_amd import _lib
+    L = _lib.lib()
     if name == "pcrl_upconv_fwd":       # (x, wf, w3f, tab, y0, stats, N, D, H, W, Ci, Co, dtype, stream)
         N, D, H, W, Ci, Co, dt = args[6:13]
-        brick = dt == 1 and Co % 64 == 0 and D % 4 == 0 and H % 8 == 0 and W % 16 == 0 and os.environ.get("PCRL_DEBUG_CONV_IMPL", "0") == "0"
-        # the wide-brick kernel's composed-forward instantiation is the same kernel (rocprofv3 lists both under brick16_conv_kernel):
-        # one key, each launch with its own EXECUTED flops
-        key = "brick16_conv_kernel" if brick else "igemm_kernel<%s,upconv_fwd>" % ("bf16" if dt == 1 else "f32")
-    elif name == "pcrl_upconv_dgrad":   # (dy0, wd, dx, N, D, H, W, Ci, Co, dtype, stream)
-        N, D, H, W, Ci, Co, dt = args[3:10]
-        key = "igemm_kernel<%s,upconv_dgrad>" % ("bf16" if dt == 1 else "f32")
+        # the wide-brick kernel's composed instantiations are separate kernels (template arguments <64, 1> forward, <64, 2> data gradient)
+        brick = L.call("pcrl_upconv_fwd_uses_brick", N, D, H, W, Ci, Co, dt)
+        key = "brick16_conv_kernel<upconv_fwd>" if brick else "igemm_kernel<%s,upconv_fwd>" % ("bf16" if dt == 1 else "f32")
+    elif name == "pcrl_upconv_dgrad":   # (dy0, wd, wd3, dx, N, D, H, W, Ci, Co, dtype, stream)
+        N, D, H, W, Ci, Co, dt = args[4:11]
+        brick = L.call("pcrl_upconv_dgrad_uses_brick", N, D, H, W, Ci, Co, dt)
+        key = "brick16_conv_kernel<upconv_dgrad>" if brick else "igemm_kernel<%s,upconv_dgrad>" % ("bf16" if dt == 1 else "f32")
     else:                               # pcrl_upconv_wgrad_accum(x, dy0, dweff, box, first, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)
         N, D, H, W, Ci, Co, dt = args[7:14]
         brick = dt == 1 and Co % 64 == 0 and ((D % 2 == 0 and H % 8 == 0 and W % 8 == 0) or (W % 2 == 0 and D % 8 == 0 and H % 8 == 0))
@@ -264,7 +266,7 @@ def main():
     detail = {}
     for k, (n, ms, work) in sorted(res.items()):
         detail[k] = {"launches": n, "avg_ms": round(ms / n, 4), "tflops": round(work / (ms * 1e-3) / 1e12, 1)}
-    conv = {k: v for k, v in res.items() if k.startswith(("igemm", "brick"))}
+    conv = {k: v for k, v in res.items() if k.startswith(("igemm", "brick"))}   # forward / data-gradient convolution kernels
     dom = max(conv, key=lambda k: conv[k][1])
     n, ms, work = conv[dom]
     achieved = work / (ms * 1e-3) / 1e12

@@ -317,11 +317,14 @@ int pcrl_relu_mask_bwd(const void* da, const void* a, void* g, int64_t n, int dt
  * 2x-upsampled tensor (and its gradient) never exists.  See csrc/upconv_fused.hip for the algebra.
  *   compose : wf (dtype [8][Co][8][Ci]), wd (dtype [Ci][64][Co]), optionally w3f (dtype [8*Co][27][Ci]: the same composed weights zero-embedded
  *             in 3x3x3 form, read by the wide-brick kernel on the shapes it tiles: coarse D % 4 == H % 8 == W % 16 == 0, bf16, Co % 64 == 0;
+ *             NULL: not produced), optionally wd3 (dtype [Ci][27][8*Co]: the data-gradient weights zero-embedded in 3x3x3 form over the
+ *             space-to-depth view of dy0 -- channel = parity * Co + co -- read by the wide-brick kernel where pcrl_upconv_dgrad_uses_brick();
  *             NULL: not produced), bias_tab (float32 [27][Co]: border classes of the fine voxel) from the four parameters; once per
  *             optimizer step.  ws: pcrl_upconv_compose_ws_bytes().
  *   fwd     : x dtype [N][D][H][W][Ci] -> y0 dtype [N][2D][2H][2W][Co];  stats_partial: [pcrl_upconv_stats_rows()][Co][2] (sum, sum^2)
  *             for the BatchNorm that follows (or NULL).
- *   dgrad   : dy0 -> dx (dtype [N][D][H][W][Ci]).
+ *   dgrad   : dy0 -> dx (dtype [N][D][H][W][Ci]); wd3 may be NULL unless pcrl_upconv_dgrad_uses_brick() (bf16, coarse D % 4 == H % 8 ==
+ *             W % 16 == 0, Ci % 64 == 0, Co = 32 * 2^k).
  *   wgrad   : x, dy0 -> dw_up, db_up, dw0 (float32, reference layouts; db0 is the column sum of dy0 -- identically cancelled by the
  *             BatchNorm that follows in the reference model and not produced here).  ws: pcrl_upconv_wgrad_ws_bytes().
  * Channels are multiples of 32.
@@ -331,13 +334,14 @@ int pcrl_relu_mask_bwd(const void* da, const void* a, void* g, int64_t n, int dt
  *             index p*8+q; from the brick weight-gradient kernel where it tiles the coarse grid, else from the gather kernel); first != 0: store
  *             instead of add. */
 size_t pcrl_upconv_compose_ws_bytes(int Ci, int Cm, int Co, int dtype);
-int pcrl_upconv_compose(const float* w_up, const float* b_up, const float* w0, const float* b0, void* wf, void* wd, void* w3f, float* bias_tab,
-                        void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream);
+int pcrl_upconv_compose(const float* w_up, const float* b_up, const float* w0, const float* b0, void* wf, void* wd, void* w3f, void* wd3,
+                        float* bias_tab, void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream);
 int64_t pcrl_upconv_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   /* informational: which kernel a shape gets */
 int64_t pcrl_upconv_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype);
 int pcrl_upconv_fwd(const void* x, const void* wf, const void* w3f, const float* bias_tab, void* y0, float* stats_partial, int N, int D, int H, int W,
                     int Ci, int Co, int dtype, pcrl_stream_t stream);
-int pcrl_upconv_dgrad(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
+int64_t pcrl_upconv_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   /* informational: which kernel a shape gets */
+int pcrl_upconv_dgrad(const void* dy0, const void* wd, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
                       pcrl_stream_t stream);
 int64_t pcrl_upconv_wgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   /* informational: which kernel a shape gets */
 size_t pcrl_upconv_wgrad_accum_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype);

@@ -69,6 +69,12 @@ struct Brick16Params {
   // and adds bias_tab[border class of the fine voxel][channel]; the statistics rows are [bricks][8 * upc][2] = [bricks * 8][upc][2].
   int upc;
   const float* bias_tab;
+  // MODE 2 (data gradient of the composed operator): x is the FINE gradient dy0 [N][2D][2H][2W][upc] read as its space-to-depth view on the
+  // coarse grid, K = 8 * upc channels = 8 parities x upc (chunk c of 32 channels lies in parity c >> cshift, cshift = log2(upc / 32)); w the
+  // zero-embedded 3x3x3 weights [Nc = Ci][27][8 * upc] in which parity `par` holds the taps e = 2 k - 1 + par per axis (dx[v] = sum_e
+  // dy0[2 v + e - 1] wd[e]: parity 0 uses k in {1, 2}, parity 1 uses k in {0, 1}).  A chunk walks the 4 of 9 (kd, kh) stages and the two kw
+  // taps of ITS parity; the output is an ordinary coarse tensor [N][D][H][W][Nc].
+  int cshift;
 };
 
 __device__ __forceinline__ int key_w(int hw) { return ((0xFC30 >> hw) & 1) << 1; }   // hw in [0, 18)
@@ -91,10 +97,11 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
                : "memory");
 }
 
-template <int BN, bool UPCF = false>
+template <int BN, int MODE = 0>   // 0: 3x3x3 convolution; 1: composed up-conv forward; 2: composed up-conv data gradient (Brick16Params)
 __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Params p) {
   constexpr int FN = BN / 16;
-  constexpr int NSK = UPCF ? 4 : NS;   // stages per chunk
+  constexpr bool UPCF = MODE == 1, UPCD = MODE == 2;
+  constexpr int NSK = MODE ? 4 : NS;   // stages per chunk
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* wbuf = smem + HALO_BYTES;
@@ -121,8 +128,12 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   }
   const int n0 = ytile * BN;
   const int uph = UPCF ? n0 / p.upc : 0, ukd0 = (uph >> 2) & 1, ukh0 = (uph >> 1) & 1;
-#define SID(s_) (UPCF ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) : (s_))   /* stage number -> (kd * 3 + kh) */
-  const bool kw0_on = !UPCF || (uph & 1) == 0, kw2_on = !UPCF || (uph & 1) == 1;   // UPCF: the phase uses kw = pw, pw + 1 (the third tap's weights are zero)
+  // stage number -> (kd * 3 + kh).  UPCF: the block's phase uses k = p, p + 1 per axis; UPCD: chunk c's parity uses k = 1 - par, 2 - par.
+#define PARC(c_) ((c_) >> p.cshift)
+#define SID(c_, s_) (MODE == 0 ? (s_) : MODE == 1 ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) \
+                                                 : ((1 - ((PARC(c_) >> 2) & 1) + ((s_) >> 1)) * 3 + 1 - ((PARC(c_) >> 1) & 1) + ((s_)&1)))
+#define KW0_ON(c_) (MODE == 0 ? true : MODE == 1 ? (uph & 1) == 0 : (PARC(c_) & 1) == 1)   /* the third kw tap's weights are zero: its MFMAs are skipped */
+#define KW2_ON(c_) (MODE == 0 ? true : MODE == 1 ? (uph & 1) == 1 : (PARC(c_) & 1) == 0)
   const int brick_id = b;
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
@@ -149,8 +160,15 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
       const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                         \
       const bool ok = row < ROWS && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W; \
       const int ls = (lo & 3) ^ key_w(hw);                                                                 \
-      const int64_t vox = (((int64_t)n * p.D + d) * p.H + h) * p.W + w;                                    \
-      const char* src = ok ? xb + ((vox * K + (c_)*32 + ls * 8) << 1) : zp;                                \
+      int64_t el;                                                                                          \
+      if (UPCD) { /* fine voxel 2 v + par of the coarse halo voxel, channel chunk inside the parity */     \
+        const int par = PARC(c_), co0 = ((c_) - (par << p.cshift)) * 32;                                   \
+        const int64_t fv = (((int64_t)n * (2 * p.D) + 2 * d + ((par >> 2) & 1)) * (2 * p.H) + 2 * h + ((par >> 1) & 1)) * (2 * p.W) + 2 * w + (par & 1); \
+        el = fv * p.upc + co0 + ls * 8;                                                                    \
+      } else {                                                                                             \
+        el = ((((int64_t)n * p.D + d) * p.H + h) * p.W + w) * K + (c_)*32 + ls * 8;                        \
+      }                                                                                                    \
+      const char* src = ok ? xb + (el << 1) : zp;                                                          \
       lds_dma16(src, lds_base + (wid + 4 * i) * 1024);                                                     \
     }                                                                                                      \
   } while (0)
@@ -235,11 +253,12 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     if (sn == NSK) { sn = 0; cn = c + 1; }                                                                 \
     const bool last = (cn == nchunk);                                                                      \
     if (last) { cn = c; sn = s9; }                                                                         \
-    if (!(B16_ABL & 1)) LOAD_W(cn, SID(sn));                                                               \
+    const bool kw0_on = KW0_ON(c), kw2_on = KW2_ON(c);                                                     \
+    if (!(B16_ABL & 1)) LOAD_W(cn, SID(cn, sn));                                                           \
     const bool halo_next = (s9 == NSK - 1) && !last && !(B16_ABL & 2); /* block-uniform */                 \
     const bool more_chunks = c + 1 < nchunk && !(B16_ABL & 2);                                             \
-    const int tap64 = ((SID(s9) / 3) * HH + (SID(s9) % 3)) * (HP * 64);                                    \
-    const int ntap64 = ((SID(sn) / 3) * HH + (SID(sn) % 3)) * (HP * 64);                                   \
+    const int tap64 = ((SID(c, s9) / 3) * HH + (SID(c, s9) % 3)) * (HP * 64);                              \
+    const int ntap64 = ((SID(cn, sn) / 3) * HH + (SID(cn, sn) % 3)) * (HP * 64);                           \
     /* ht0: kw 0, half 0 */                                                                                \
     LOADA(1, akw[0] + tap64, 1);                                                                           \
     if (kw0_on) MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
@@ -288,11 +307,11 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   } while (0)
 
   DMA_HALO(0, 0, NDMA);
-  LOAD_W(0, SID(0));
+  LOAD_W(0, SID(0, 0));
   STORE_W();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  LOADA(0, akw[0] + ((SID(0) / 3) * HH + (SID(0) % 3)) * (HP * 64), 0);
+  LOADA(0, akw[0] + ((SID(0, 0) / 3) * HH + (SID(0, 0) % 3)) * (HP * 64), 0);
   LOADB(0, wbuf);
 
   const int nstage = NSK * nchunk;
@@ -304,6 +323,9 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   __syncthreads();   // the epilogue reuses the LDS
 #undef STAGE
 #undef SID
+#undef PARC
+#undef KW0_ON
+#undef KW2_ON
 #undef SB
 #undef MFMA_HALF
 #undef LOADA
@@ -395,7 +417,7 @@ int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, v
     hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
     hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 32 * 64);
   });
-  Brick16Params p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0};
+  Brick16Params p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0, 0, nullptr, 0};
   const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
   const int BN = Co % 64 == 0 ? 64 : 32, ny = Co / BN;
   if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16_conv: grid too large");
@@ -418,13 +440,37 @@ int pcrl_brick16_upc_fwd_launch(const void* x, const void* w3, const float* bias
                                 hipStream_t stream) {
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
   });
-  Brick16Params p{(const bf16*)x, (const bf16*)w3, nullptr, (bf16*)y0, stats, N, D, H, W, Ci, 8 * Co, 0, Co, bias_tab};
+  Brick16Params p{(const bf16*)x, (const bf16*)w3, nullptr, (bf16*)y0, stats, N, D, H, W, Ci, 8 * Co, 0, Co, bias_tab, 0};
   const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
   const int ny = 8 * Co / 64;
   if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16 (composed up-conv): grid too large");
   p.ny = ny;
-  hipLaunchKernelGGL((brick16_conv_kernel<64, true>), dim3((unsigned)(bricks * ny)), dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
+  hipLaunchKernelGGL((brick16_conv_kernel<64, 1>), dim3((unsigned)(bricks * ny)), dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
   return pcrl_check_launch("brick16_conv (composed up-conv forward)");
+}
+
+// ---- data gradient of the composed operator on the wide-brick kernel (see Brick16Params::cshift) ----
+// dy0: fine [N][2D][2H][2W][Co]; wd3: zero-embedded weights [Ci][27][8 * Co]; dx: coarse [N][D][H][W][Ci]
+static int upc_cshift(int Co) {
+  for (int k = 0; k < 8; ++k)
+    if (Co == (32 << k)) return k;
+  return -1;
+}
+bool pcrl_brick16_upc_dgrad_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return upc_cshift(Co) >= 0 && Ci % 64 == 0 && pcrl_brick16_conv_eligible(N, D, H, W, 8 * Co, Ci, dtype) && (int64_t)N * D * H * W * 8 < ((int64_t)1 << 29);
+}
+int pcrl_brick16_upc_dgrad_launch(const void* dy0, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
+  });
+  Brick16Params p{(const bf16*)dy0, (const bf16*)wd3, nullptr, (bf16*)dx, nullptr, N, D, H, W, 8 * Co, Ci, 0, Co, nullptr, upc_cshift(Co)};
+  const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
+  const int ny = Ci / 64;
+  if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16 (composed up-conv data gradient): grid too large");
+  p.ny = ny;
+  hipLaunchKernelGGL((brick16_conv_kernel<64, 2>), dim3((unsigned)(bricks * ny)), dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
+  return pcrl_check_launch("brick16_conv (composed up-conv data gradient)");
 }

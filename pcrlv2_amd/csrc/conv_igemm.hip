@@ -614,6 +614,11 @@ bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dty
   static const bool gather_only = [] { const char* e = getenv("PCRL_UPC_FWD_GATHER"); return e && e[0] == '1'; }();   // A/B switch
   return g_conv_impl == 0 && !gather_only && pcrl_brick16_upc_fwd_eligible(N, D, H, W, Ci, Co, dtype);
 }
+bool pcrl_brick16_upc_dgrad_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_brick16.hip
+bool pcrl_upc_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  static const bool gather_only = [] { const char* e = getenv("PCRL_UPC_DGRAD_GATHER"); return e && e[0] == '1'; }();   // A/B switch
+  return g_conv_impl == 0 && !gather_only && pcrl_brick16_upc_dgrad_eligible(N, D, H, W, Ci, Co, dtype);
+}
 int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype, hipStream_t stream) {
   // rows = coarse voxels, K per tap = Co (channels of dy0), 64 taps, output channels = Ci
   IgemmParams p{dy0, wd, nullptr, dx, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Co, Ci, 64, nullptr, 0};

@@ -32,6 +32,8 @@ bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dty
 int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W);
 int pcrl_brick16_upc_fwd_launch(const void* x, const void* w3, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
                                 hipStream_t stream);
+bool pcrl_upc_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);
+int pcrl_brick16_upc_dgrad_launch(const void* dy0, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
 int pcrl_gemm_planes_launch(const void* a, const void* b, float* z, int64_t M, int K, int Nc, int dtype, hipStream_t stream);
 size_t pcrl_upc_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co);
 int pcrl_upc_wgrad_launch(const void* dy0, const void* x, float* dweff, void* ws, size_t ws_bytes, int N, int D, int H, int W, int Ci, int Co,
@@ -92,8 +94,8 @@ __global__ void __launch_bounds__(256) upc_prep_kernel(const float* __restrict__
 //   wf[((p*Co + co)*8 + q)*Ci + ci]
 //   w3[((p*Co + co)*27 + tap)*Ci + ci]  tap = (p + q) per axis: the zero-embedded 3x3x3 form the brick kernels read (optional; pre-zeroed)
 template <typename T>
-__global__ void __launch_bounds__(256) upc_pack_kernel(const float* __restrict__ P, T* __restrict__ wf, T* __restrict__ wd, T* __restrict__ w3, int Ci,
-                                                       int Co) {
+__global__ void __launch_bounds__(256) upc_pack_kernel(const float* __restrict__ P, T* __restrict__ wf, T* __restrict__ wd, T* __restrict__ w3, T* __restrict__ wd3,
+                                                       int Ci, int Co) {
   const int64_t M27 = (int64_t)27 * Co;
   const int64_t total = (int64_t)64 * Ci * Co;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -121,6 +123,11 @@ __global__ void __launch_bounds__(256) upc_pack_kernel(const float* __restrict__
     const int p = pd * 4 + ph * 2 + pw, q = qd * 4 + qh * 2 + qw;
     wf[(((int64_t)p * Co + co) * 8 + q) * Ci + ci] = v;
     if (w3) w3[(((int64_t)p * Co + co) * 27 + (pd + qd) * 9 + (ph + qh) * 3 + (pw + qw)) * Ci + ci] = v;
+    if (wd3) {   // data-gradient tap e = 2 k - 1 + par per axis: k = (e + 1) >> 1 on the coarse grid, parity (e + 1) & 1 of the fine voxel
+      const int ed = e >> 4, eh = (e >> 2) & 3, ew = e & 3;
+      const int k = ((ed + 1) >> 1) * 9 + ((eh + 1) >> 1) * 3 + ((ew + 1) >> 1), par = (((ed + 1) & 1) << 2) | (((eh + 1) & 1) << 1) | ((ew + 1) & 1);
+      wd3[(((int64_t)ci * 27 + k) * 8 + par) * Co + co] = v;
+    }
   }
 }
 
@@ -316,7 +323,7 @@ extern "C" size_t pcrl_upconv_compose_ws_bytes(int Ci, int Cm, int Co, int dtype
   return al((size_t)27 * Co * Cm * esz(dtype)) + al((size_t)8 * Ci * Cm * esz(dtype)) + al((size_t)27 * Co * 8 * Ci * sizeof(float));
 }
 extern "C" int pcrl_upconv_compose(const float* w_up, const float* b_up, const float* w0, const float* b0, void* wf, void* wd, void* w3f,
-                                   float* bias_tab, void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream) {
+                                   void* wd3, float* bias_tab, void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_upc("upconv_compose", 1, 1, 1, 1, Ci, Cm, Co, dtype)) return e;
   PCRL_REQUIRE(w_up && b_up && w0 && wf && wd && bias_tab, "upconv_compose: null pointer");
   if (!ws || ws_bytes < pcrl_upconv_compose_ws_bytes(Ci, Cm, Co, dtype)) return pcrl_fail(PCRL_EWORKSPACE, "upconv_compose: workspace too small");
@@ -332,8 +339,9 @@ extern "C" int pcrl_upconv_compose(const float* w_up, const float* b_up, const f
   if (int e = pcrl_gemm_planes_launch(a0, bu, P, (int64_t)27 * Co, Cm, 8 * Ci, dtype, st)) return e;
   const unsigned gp = blocks_for((int64_t)64 * Ci * Co);
   if (w3f) (void)hipMemsetAsync(w3f, 0, (size_t)216 * Ci * Co * esz(dtype), st);   // 19 of a phase's 27 taps stay zero
-  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_pack_kernel<bf16>, dim3(gp), dim3(256), 0, st, (const float*)P, (bf16*)wf, (bf16*)wd, (bf16*)w3f, Ci, Co);
-  else hipLaunchKernelGGL(upc_pack_kernel<float>, dim3(gp), dim3(256), 0, st, (const float*)P, (float*)wf, (float*)wd, (float*)w3f, Ci, Co);
+  if (wd3) (void)hipMemsetAsync(wd3, 0, (size_t)216 * Ci * Co * esz(dtype), st);   // a parity holds 8 of the 27 taps
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_pack_kernel<bf16>, dim3(gp), dim3(256), 0, st, (const float*)P, (bf16*)wf, (bf16*)wd, (bf16*)w3f, (bf16*)wd3, Ci, Co);
+  else hipLaunchKernelGGL(upc_pack_kernel<float>, dim3(gp), dim3(256), 0, st, (const float*)P, (float*)wf, (float*)wd, (float*)w3f, (float*)wd3, Ci, Co);
   if (int e = pcrl_check_launch("upconv_compose (pack)")) return e;
   hipLaunchKernelGGL(upc_bias_kernel, dim3(Co), dim3(256), 0, st, w0, b_up, b0, bias_tab, Cm, Co);
   return pcrl_check_launch("upconv_compose (bias)");
@@ -357,10 +365,17 @@ extern "C" int pcrl_upconv_fwd(const void* x, const void* wf, const void* w3f, c
   }
   return pcrl_upc_fwd_launch(x, wf, bias_tab, y0, stats_partial, N, D, H, W, Ci, Co, dtype, as_stream(stream));
 }
-extern "C" int pcrl_upconv_dgrad(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
+extern "C" int64_t pcrl_upconv_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return pcrl_upc_dgrad_uses_brick(N, D, H, W, Ci, Co, dtype) ? 1 : 0;
+}
+extern "C" int pcrl_upconv_dgrad(const void* dy0, const void* wd, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
                                  pcrl_stream_t stream) {
   if (int e = check_upc("upconv_dgrad", N, D, H, W, Ci, 32, Co, dtype)) return e;
   PCRL_REQUIRE(dy0 && wd && dx, "upconv_dgrad: null pointer");
+  if (pcrl_upc_dgrad_uses_brick(N, D, H, W, Ci, Co, dtype)) {
+    PCRL_REQUIRE(wd3, "upconv_dgrad: this shape runs on the wide-brick kernel and needs the 3x3x3 form of the composed weights (wd3)");
+    return pcrl_brick16_upc_dgrad_launch(dy0, wd3, dx, N, D, H, W, Ci, Co, as_stream(stream));
+  }
   return pcrl_upc_dgrad_launch(dy0, wd, dx, N, D, H, W, Ci, Co, dtype, as_stream(stream));
 }
 

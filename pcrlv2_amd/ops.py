@@ -494,12 +494,20 @@ class ComposedUpConv:
 
     def __init__(self):
         self.key = None
-        self.wf = self.wd = self.w3f = self.bias_tab = None
+        self.wf = self.wd = self.w3f = self.wd3 = self.bias_tab = None
+        self.want = (False, False)      # sticky: some pass of the step runs forward / data gradient on the wide-brick kernel (3x3x3 weight forms)
         self.dweff = self.box = None
         self.pending = None     # (w_up, b_up, w0, dtype) while accumulated gradients wait for delivery
 
-    def get(self, w_up, b_up, w0, b0, dtype):
-        key = (_weights_epoch, w_up._version, w_up.data_ptr(), b_up._version, w0._version, w0.data_ptr(), b0._version, dtype)
+    def get(self, w_up, b_up, w0, b0, dtype, geom=None):
+        """-> (wf, wd, bias_tab); .w3f / .wd3 hold the 3x3x3 forms for the wide-brick kernels.  geom = (N, D, H, W) of a forward pass: the
+        3x3x3 forms are produced from then on if that shape runs on the brick kernels (passes of other shapes share the same weights)."""
+        if geom is not None:
+            Ci, Co, L = w_up.shape[0], w0.shape[0], lib()
+            f = bool(L.call("pcrl_upconv_fwd_uses_brick", *geom, Ci, Co, dtype_code(dtype)))
+            d = bool(L.call("pcrl_upconv_dgrad_uses_brick", *geom, Ci, Co, dtype_code(dtype)))
+            self.want = (self.want[0] or f, self.want[1] or d)
+        key = (_weights_epoch, w_up._version, w_up.data_ptr(), b_up._version, w0._version, w0.data_ptr(), b0._version, dtype, self.want)
         if key != self.key:
             L, s, dev = lib(), stream_handle(), w_up.device
             Ci, Cm, Co = w_up.shape[0], w_up.shape[1], w0.shape[0]
@@ -507,10 +515,11 @@ class ComposedUpConv:
                 raise PcrlError(f"composed up-conv: up_conv has {Cm} output channels, conv1 expects {w0.shape[1]}")
             self.wf = torch.empty(64 * Ci * Co, dtype=dtype, device=dev)
             self.wd = torch.empty(64 * Ci * Co, dtype=dtype, device=dev)
-            self.w3f = torch.empty(216 * Ci * Co, dtype=dtype, device=dev) if (dtype == torch.bfloat16 and Co % 64 == 0) else None
+            self.w3f = torch.empty(216 * Ci * Co, dtype=dtype, device=dev) if self.want[0] else None
+            self.wd3 = torch.empty(216 * Ci * Co, dtype=dtype, device=dev) if self.want[1] else None
             self.bias_tab = _f32(27 * Co, dev)
             nb = L.call("pcrl_upconv_compose_ws_bytes", Ci, Cm, Co, dtype_code(dtype))
-            L.call("pcrl_upconv_compose", w_up.detach(), b_up.detach(), w0.detach(), b0.detach(), self.wf, self.wd, self.w3f, self.bias_tab,
+            L.call("pcrl_upconv_compose", w_up.detach(), b_up.detach(), w0.detach(), b0.detach(), self.wf, self.wd, self.w3f, self.wd3, self.bias_tab,
                    workspace(nb, dev), nb, Ci, Cm, Co, dtype_code(dtype), s)
             self.key = key
         return self.wf, self.wd, self.bias_tab
@@ -578,7 +587,7 @@ def upconv_luconv_forward(x, w_up, b_up, conv_w, conv_b, gamma, beta, running_me
     Co = conv_w.shape[0]
     if w_up.shape[0] != Ci:
         raise PcrlError(f"up_conv: input has {Ci} channels, weight expects {w_up.shape[0]}")
-    wf, _, bias_tab = composed.get(w_up, b_up, conv_w, conv_b, dtype)
+    wf, _, bias_tab = composed.get(w_up, b_up, conv_w, conv_b, dtype, geom=(N, D, H, W))
     M = N * D * H * W * 8
     rows = L.call("pcrl_upconv_stats_rows", N, D, H, W, Ci, Co, dtype_code(dtype))
     y = new_act(N, 2 * D, 2 * H, 2 * W, Co, dtype, dev)
@@ -611,7 +620,7 @@ def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamm
     if need_dx:
         _, wd, _ = composed.get(w_up, b_up, conv_w, conv_b, dtype)
         dx = new_act(N, D, H, W, Ci, dtype, dev)
-        L.call("pcrl_upconv_dgrad", dy, wd, dx, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+        L.call("pcrl_upconv_dgrad", dy, wd, composed.wd3, dx, N, D, H, W, Ci, Co, dtype_code(dtype), s)
     return dx, dw_up, db_up, dw0, zero_grad_vector(Co, dev), dgamma, dbeta
 
 

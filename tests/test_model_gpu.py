@@ -348,6 +348,34 @@ def test_round2_fusions_leave_the_step_unchanged_fp32(switch):
     assert worst[1] < (1e-2 if switch == "COMPOSE_UPCONV" else 2e-5), (switch, worst)
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_weight_gradients_on_the_side_stream_are_bit_identical(dt):
+    """config.WGRAD_SIDE_STREAM_3D (default on): the weight-gradient kernels run on a second stream next to the data-gradient / BatchNorm
+    chain.  Same kernels, same operands, only the ordering between streams differs -> the parameters after two SGD steps and the
+    BatchNorm running statistics must be BIT-identical to the one-stream run."""
+    from pcrlv2_amd import config
+    batches = [O.fill_batch(4, (32, 32, 16), dtype=torch.float32, seed=21 + s) for s in range(2)]
+    finals = []
+    old = config.WGRAD_SIDE_STREAM_3D
+    try:
+        for on in (True, False):
+            config.WGRAD_SIDE_STREAM_3D = on
+            model = build(dt)
+            opt = FusedSGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+            random.seed(5)
+            for bt in batches:
+                losses = train_step(model, opt, bt, 3, MSELoss(), CosineSimilarityMean())
+            torch.cuda.synchronize()
+            finals.append(([float(l) for l in losses], opt.flat_p.clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
+    finally:
+        config.WGRAD_SIDE_STREAM_3D = old
+    (la, pa, ra), (lb, pb, rb) = finals
+    assert la == lb, (la, lb)
+    assert torch.equal(pa, pb), float((pa - pb).abs().max())
+    for k in ra:
+        assert torch.equal(ra[k], rb[k]), k
+
+
 def test_optional_groupnorm_silu_mode_vs_torch_definition():
     """PCRLv23d(norm='gn', act='silu') -- an OPTIONAL, NON-REFERENCE mode (BASELINE.json's north_star names GroupNorm + SiLU; the
     reference's own norm='gn' crashes at construction and it rejects 'silu').  Checked against the oracle's torch

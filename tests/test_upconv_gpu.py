@@ -52,6 +52,9 @@ SHAPES = [  # N, D, H, W (coarse), Ci, Cm, Co
     (1, 4, 8, 16, 64, 64, 64),      # one brick: every fine border class on its faces
     (2, 8, 16, 32, 128, 128, 64),   # up_tr64's channels, several bricks in every direction
     (1, 4, 8, 16, 32, 32, 128),     # two 64-channel tiles per phase
+    # the data gradient of the three shapes above with Ci % 64 == 0 also runs on the wide-brick kernel (space-to-depth view of dy0); plus:
+    (1, 4, 8, 16, 64, 64, 32),      # Co = 32: one 32-channel chunk per parity (forward on the gather kernel)
+    (2, 4, 16, 16, 128, 64, 128),   # Co = 128: four chunks per parity, two 64-channel output tiles
 ]
 
 
@@ -76,7 +79,7 @@ def test_composed_upconv_matches_the_two_aten_calls(shape, dt):
     wu, bu, wc, bc = (to_dev(t) for t in (w_up, b_up, w0, b0))
     xa = ops.to_act(xq.to(dt).to(DEV), dt)
     comp = ops.ComposedUpConv()
-    wf, wd, tab = comp.get(wu, bu, wc, bc, dt)
+    wf, wd, tab = comp.get(wu, bu, wc, bc, dt, geom=(N, D, H, W))
     rows = L.call("pcrl_upconv_stats_rows", N, D, H, W, Ci, Co, dtype_code(dt))
     y = ops.new_act(N, 2 * D, 2 * H, 2 * W, Co, dt, torch.device(DEV))
     part = torch.full((rows, Co, 2), float("nan"), dtype=torch.float32, device=DEV)
@@ -90,7 +93,7 @@ def test_composed_upconv_matches_the_two_aten_calls(shape, dt):
 
     dya = ops.to_act(dyq.to(dt).to(DEV), dt)
     dx = ops.new_act(N, D, H, W, Ci, dt, torch.device(DEV))
-    L.call("pcrl_upconv_dgrad", dya, wd, dx, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    L.call("pcrl_upconv_dgrad", dya, wd, comp.wd3, dx, N, D, H, W, Ci, Co, dtype_code(dt), s)
     close(dx, xr.grad, 2e-2 if bf else 1e-4, "dx")
 
     dwu, dbu, dwc = torch.empty_like(wu), torch.empty_like(bu), torch.empty_like(wc)

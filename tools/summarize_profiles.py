@@ -17,6 +17,11 @@ def short(name):
                 "to1_fwd_kernel", "bn_finalize_kernel", "bn_bwd_finalize_kernel", "coltile_finish_kernel", "sgd_kernel", "tri_fwd_kernel",
                 "tri_bwd_kernel", "cosine_fwd_kernel", "cosine_bwd_kernel", "bn1d_fwd_kernel", "bn1d_bwd_kernel", "pack_conv3_kernel"):
         if key in name:
+            if key == "brick16_conv_kernel":      # template arguments <BN, MODE>: MODE 1 / 2 = the composed up-conv's forward / data gradient
+                import re
+                m = re.search(r"brick16_conv_kernel(?:ILi\d+ELi(\d)E|<\d+, (\d)>)", name)
+                mode = (m.group(1) or m.group(2)) if m else "0"
+                return key + {"1": "<upconv_fwd>", "2": "<upconv_dgrad>"}.get(mode, "")
             if key == "igemm_kernel":
                 import re
                 m = re.search(r"igemm_kernelI(DF16b|f)Li(\d+)ELi(\d)ELb(\d)", name)
@@ -70,7 +75,7 @@ def main():
                 "# SQ counters are sampled on ONE XCD (SQ_BUSY_CU_CYCLES / GRBM_GUI_ACTIVE ~ 30 of its 32 CUs): MFMA busy fraction =\n"
                 "# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 32 CUs * 4 SIMDs).\n")
         traffic = {}
-        mfma_kernels = ["brick16_conv_kernel", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_brick_upc2_kernel", "wgrad_upc8_kernel"] + sorted(k for k in fd if k.startswith("igemm_kernel<") and "upconv" in k)
+        mfma_kernels = ["brick16_conv_kernel", "brick16_conv_kernel<upconv_fwd>", "brick16_conv_kernel<upconv_dgrad>", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_brick_upc2_kernel", "wgrad_upc8_kernel"] + sorted(k for k in fd if k.startswith("igemm_kernel<") and "upconv" in k)
         for k in mfma_kernels:
             if k not in fd or k not in wd or k not in md:
                 continue
