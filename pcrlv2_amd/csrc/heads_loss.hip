@@ -126,6 +126,107 @@ __global__ void __launch_bounds__(256) sgemm_small_kernel(const float* __restric
       if (m < M && n < N) Cm[(int64_t)m * N + n] = acc[i][j] + (bias ? bias[n] : 0.f);
     }
 }
+// ---- the same three products for the usual head sizes (rows = 32 .. 192, channels 64 .. 512, all multiples of 4): the tiled kernel above
+// has 16 .. 32 blocks walking K in serial LDS chunks (30 us a launch, 54 launches a step); here every output group owns its whole
+// contraction with independent 16-byte loads -- one global round trip -- and the parallelism comes from the outputs (128+ blocks).
+// y[r][o] = sum_k x[r][k] w[o][k] + b[o].  Wave = one output column o and 32 rows; lanes split k in float4 groups; 32 wave reductions.
+__global__ void __launch_bounds__(256) linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int rows, int Cin, int Cout) {
+  const int lane = threadIdx.x & 63, o = blockIdx.x * 4 + (threadIdx.x >> 6), r0 = blockIdx.y * 32;
+  if (o >= Cout) return;
+  float acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = 0.f;
+  for (int k = lane * 4; k < Cin; k += 256) {
+    const float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)o * Cin + k);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      if (r0 + i < rows) {   // wave-uniform
+        const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)(r0 + i) * Cin + k);
+        acc[i] = fmaf(xv.x, wv.x, fmaf(xv.y, wv.y, fmaf(xv.z, wv.z, fmaf(xv.w, wv.w, acc[i]))));
+      }
+    }
+  }
+  // 32 sums over 64 lanes as a halving butterfly (32 exchanges instead of 32 x 6): at distance 32, 16, .., 2 a lane keeps the half of its
+  // values selected by that bit of its index and adds the partner's copy of them; lane l ends with row l >> 1 (distance 1: same row twice).
+#define HALVE(n_, dist_)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < (n_); ++i) {                                       \
+    const bool hi = (lane & (dist_)) != 0;                                                 \
+    const float keep = hi ? acc[(n_) + i] : acc[i], send = hi ? acc[i] : acc[(n_) + i];    \
+    acc[i] = keep + __shfl_xor(send, (dist_), 64);                                         \
+  }
+  HALVE(16, 32)
+  HALVE(8, 16)
+  HALVE(4, 8)
+  HALVE(2, 4)
+  HALVE(1, 2)
+#undef HALVE
+  const float tot = acc[0] + __shfl_xor(acc[0], 1, 64);
+  const int r = r0 + (lane >> 1);
+  if ((lane & 1) == 0 && r < rows) y[(int64_t)r * Cout + o] = tot + (bias ? bias[o] : 0.f);
+}
+// dx[r][k] = sum_o dy[r][o] w[o][k].  Block = 4 rows x 256 columns; lane owns 4 consecutive k, the four waves split o, LDS combine.
+__global__ void __launch_bounds__(256) linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int rows, int Cin,
+                                                        int Cout) {
+  __shared__ float4 red[3][4][64];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = (blockIdx.x * 64 + lane) * 4, r0 = blockIdx.y * 4;
+  const bool kin = k < Cin;
+  float4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = float4{0.f, 0.f, 0.f, 0.f};
+  const int per = (Cout + 3) / 4, o0 = wv * per, o1 = min(Cout, o0 + per);
+  const float* dyr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dyr[i] = dy + (int64_t)min(r0 + i, rows - 1) * Cout;
+#pragma unroll 4
+  for (int o = o0; o < o1; ++o) {
+    const float4 t = kin ? *reinterpret_cast<const float4*>(w + (int64_t)o * Cin + k) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float d = dyr[i][o];   // wave-uniform
+      acc[i].x = fmaf(d, t.x, acc[i].x);
+      acc[i].y = fmaf(d, t.y, acc[i].y);
+      acc[i].z = fmaf(d, t.z, acc[i].z);
+      acc[i].w = fmaf(d, t.w, acc[i].w);
+    }
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) red[wv - 1][i][lane] = acc[i];
+  }
+  __syncthreads();
+  if (wv == 0 && kin) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 a = acc[i];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const float4 t = red[q][i][lane];
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+      }
+      if (r0 + i < rows) *reinterpret_cast<float4*>(dx + (int64_t)(r0 + i) * Cin + k) = a;
+    }
+  }
+}
+// dw[o][k] = sum_r dy[r][o] x[r][k].  Wave = one output row o, lane owns 4 consecutive k; the rows are walked with independent loads.
+__global__ void __launch_bounds__(256) linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, int rows, int Cin,
+                                                        int Cout) {
+  const int lane = threadIdx.x & 63, o = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int k = (blockIdx.x * 64 + lane) * 4;
+  if (o >= Cout || k >= Cin) return;
+  float4 acc{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int r = 0; r < rows; ++r) {
+    const float d = dy[(int64_t)r * Cout + o];   // wave-uniform
+    const float4 t = *reinterpret_cast<const float4*>(x + (int64_t)r * Cin + k);
+    acc.x = fmaf(d, t.x, acc.x);
+    acc.y = fmaf(d, t.y, acc.y);
+    acc.z = fmaf(d, t.z, acc.z);
+    acc.w = fmaf(d, t.w, acc.w);
+  }
+  *reinterpret_cast<float4*>(dw + (int64_t)o * Cin + k) = acc;
+}
 __global__ void __launch_bounds__(256) colsum_small_kernel(const float* __restrict__ v, float* __restrict__ out, int rows, int C) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -566,23 +667,34 @@ extern "C" int pcrl_bn1d_bwd(const float* dy, const float* x, const float* y, co
   hipLaunchKernelGGL(bn1d_bwd_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), dy, x, y, gamma, mean, rstd, dx, dgamma, dbeta, rows, C, relu);
   return pcrl_check_launch("bn1d_bwd");
 }
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 extern "C" int pcrl_linear_fwd(const float* x, const float* w, const float* b, float* y, int rows, int Cin, int Cout, pcrl_stream_t stream) {
   PCRL_REQUIRE(x && w && y && rows > 0 && Cin > 0 && Cout > 0, "linear_fwd: bad arguments");
   // y[r][o] = sum_k x[r][k] * w[o][k] + b[o]
-  hipLaunchKernelGGL(sgemm_small_kernel, dim3((Cout + 31) / 32, (rows + 31) / 32), dim3(256), 0, as_stream(stream),
-                     x, (int64_t)Cin, (int64_t)1, w, (int64_t)1, (int64_t)Cin, b, y, rows, Cout, Cin);
+  if (Cin % 4 == 0 && al16(x) && al16(w))
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((Cout + 3) / 4, (rows + 31) / 32), dim3(256), 0, as_stream(stream), x, w, b, y, rows, Cin, Cout);
+  else
+    hipLaunchKernelGGL(sgemm_small_kernel, dim3((Cout + 31) / 32, (rows + 31) / 32), dim3(256), 0, as_stream(stream),
+                       x, (int64_t)Cin, (int64_t)1, w, (int64_t)1, (int64_t)Cin, b, y, rows, Cout, Cin);
   return pcrl_check_launch("linear_fwd");
 }
 extern "C" int pcrl_linear_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
                                int rows, int Cin, int Cout, pcrl_stream_t stream) {
   PCRL_REQUIRE(dy && x && w && dx && dw, "linear_bwd: null pointer");
   // dx[r][k] = sum_o dy[r][o] * w[o][k]
-  hipLaunchKernelGGL(sgemm_small_kernel, dim3((Cin + 31) / 32, (rows + 31) / 32), dim3(256), 0, as_stream(stream),
-                     dy, (int64_t)Cout, (int64_t)1, w, (int64_t)Cin, (int64_t)1, (const float*)nullptr, dx, rows, Cin, Cout);
+  const bool fast = Cin % 4 == 0 && al16(x) && al16(w) && al16(dx) && al16(dw);
+  if (fast)
+    hipLaunchKernelGGL(linear_dx_kernel, dim3((Cin + 255) / 256, (rows + 3) / 4), dim3(256), 0, as_stream(stream), dy, w, dx, rows, Cin, Cout);
+  else
+    hipLaunchKernelGGL(sgemm_small_kernel, dim3((Cin + 31) / 32, (rows + 31) / 32), dim3(256), 0, as_stream(stream),
+                       dy, (int64_t)Cout, (int64_t)1, w, (int64_t)Cin, (int64_t)1, (const float*)nullptr, dx, rows, Cin, Cout);
   if (int e = pcrl_check_launch("linear_dx")) return e;
   // dw[o][k] = sum_r dy[r][o] * x[r][k]
-  hipLaunchKernelGGL(sgemm_small_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32), dim3(256), 0, as_stream(stream),
-                     dy, (int64_t)1, (int64_t)Cout, x, (int64_t)Cin, (int64_t)1, (const float*)nullptr, dw, Cout, Cin, rows);
+  if (fast)
+    hipLaunchKernelGGL(linear_dw_kernel, dim3((Cin + 255) / 256, (Cout + 3) / 4), dim3(256), 0, as_stream(stream), dy, x, dw, rows, Cin, Cout);
+  else
+    hipLaunchKernelGGL(sgemm_small_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32), dim3(256), 0, as_stream(stream),
+                       dy, (int64_t)1, (int64_t)Cout, x, (int64_t)Cin, (int64_t)1, (const float*)nullptr, dw, Cout, Cin, rows);
   if (int e = pcrl_check_launch("linear_dw")) return e;
   if (db) {
     hipLaunchKernelGGL(colsum_small_kernel, dim3((Cout + 3) / 4), dim3(256), 0, as_stream(stream), dy, db, rows, Cout);

@@ -103,7 +103,7 @@ class DataParallel:
         self.strict_flags = strict_flags
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._active = self.world > 1 or (force_collectives and dist.is_initialized())   # 1-rank groups: test hook only
-        sizes = [p.numel() for p in optimizer._plist]
+        sizes = list(getattr(optimizer, "_slot_sizes", None) or [p.numel() for p in optimizer._plist])   # arena slots (FusedSGD pads to 16 bytes)
         self.reducer = BucketedAllReduce(optimizer.flat_g, sizes, group, bucket_mb)
         self.overlap = (os.environ.get("PCRL_DDP_OVERLAP", "1") == "1") if overlap is None else overlap
         optimizer.grad_scale = 1.0 / self.world

@@ -30,12 +30,16 @@ class FusedSGD(torch.optim.SGD):
         if dev.type != "cuda":
             raise RuntimeError("FusedSGD needs parameters on the GPU (no CPU fallback)")
         sizes = [p.numel() for p in self._plist]
+        # every parameter starts on a 16-byte boundary of the arena (slots rounded up to 4 floats; the padding stays zero in all three
+        # arenas): the kernels that read weights with 16-byte loads (the heads' Linear products) take them as they lie -- the model has
+        # 1-element parameters (the deep-supervision heads' 1-channel convolutions and norms) in front of them
+        self._slot_sizes = [(n + 3) // 4 * 4 for n in sizes]
         offs = [0]
-        for n in sizes:
+        for n in self._slot_sizes:
             offs.append(offs[-1] + n)
         self._offsets_host = offs
         self._total = offs[-1]
-        self.flat_p = torch.empty(self._total, dtype=torch.float32, device=dev)
+        self.flat_p = torch.zeros(self._total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(self._total, dtype=torch.float32, device=dev)
         self.flat_buf = torch.zeros(self._total, dtype=torch.float32, device=dev)
         with torch.no_grad():

@@ -597,6 +597,22 @@ def test_heads_bn1d_linear(rows, C):
         ops.bn1d_forward(xd[:1].contiguous(), wd[0].contiguous(), wd[1].contiguous(), None, None, False)
 
 
+@pytest.mark.parametrize("rows,Cin,Cout", [(32, 64, 128), (32, 512, 256), (192, 256, 512), (192, 128, 64), (5, 36, 10), (33, 260, 7), (7, 30, 12)])
+def test_linear_products(rows, Cin, Cout):
+    """pcrl_linear_fwd / _bwd (nn.Linear of the predictor heads, pcrlv2_model_3d.py:57-58): y = x W^T + b, dx = dy W, dW = dy^T x, db = colsum(dy)
+    against float64.  Head sizes and ragged ones (partial row groups, channel counts not a multiple of 64 or 4 -- the last takes the tiled
+    fallback kernel), contiguous float32 operands."""
+    x, w, b = rnd(rows, Cin, seed=1), rnd(Cout, Cin, seed=2, scale=0.1), rnd(Cout, seed=3)
+    dy = rnd(rows, Cout, seed=4)
+    xd, wd, bd, dyd = (t.float().to(DEV) for t in (x, w, b, dy))
+    x64, w64, dy64 = (t.float().double() for t in (x, w, dy))
+    check(ops.linear_forward(xd, wd, bd), x64 @ w64.T + b.float().double(), torch.float32, "linear fwd", f32_tol=2e-6)
+    dx, dw, db = ops.linear_backward(dyd, xd, wd)
+    check(dx, dy64 @ w64, torch.float32, "linear dx", f32_tol=2e-6)
+    check(dw, dy64.T @ x64, torch.float32, "linear dw", f32_tol=2e-6)
+    check(db, dy64.sum(0), torch.float32, "linear db", f32_tol=2e-6)
+
+
 @pytest.mark.parametrize("scale", [2, 4])
 def test_trilinear(scale):
     N, D, H, W = 2, 4, 6, 3
