@@ -39,9 +39,11 @@ def conv_key(name, args):
     return its algorithmic FLOPs (2 * voxels * 27 * Ci * Co)."""
     # pcrl_conv3d_k3_fwd_ws(x, wp, bias, y, stats, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)   [_fwd: without ws, ws_bytes]
     N, D, H, W, Ci, Co, dt = args[7:14] if name == "pcrl_conv3d_k3_fwd_ws" else args[5:12]
-    if dt == 1 and D % 4 == 0 and H % 8 == 0 and W % 16 == 0 and Co % 32 == 0 and os.environ.get("PCRL_DEBUG_CONV_IMPL", "0") == "0":
+    from pcrlv2_amd import _lib
+    kid = _lib.lib().call("pcrl_conv3d_k3_fwd_kernel", N, D, H, W, Ci, Co, dt)
+    if kid == 2:
         key = "brick16_conv_kernel"
-    elif dt == 1 and Co % 32 == 0 and ((D % 4 == 0 and H % 8 == 0 and W % 8 == 0) or (W % 4 == 0 and D % 8 == 0 and H % 8 == 0)):
+    elif kid == 1:
         key = "brick_conv_kernel"
     else:
         bn = 128 if Co % 128 == 0 else (64 if Co % 64 == 0 else 32)

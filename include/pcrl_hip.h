@@ -64,6 +64,7 @@ int pcrl_pack_convt_weight(const float* w_ref, void* w_fwd, void* w_dgrad, int C
  * The data gradient (aten::convolution_backward, input half) is the same call with wp = w_dgrad,
  * Ci/Co exchanged, bias = NULL, stats_partial = NULL. */
 int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype);
+int64_t pcrl_conv3d_k3_fwd_kernel(int N, int D, int H, int W, int Ci, int Co, int dtype);   /* informational: 2 wide-brick, 1 brick, 0 gather kernel */
 int pcrl_conv3d_k3_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial,
                        int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
 /* Same operation with a caller-provided workspace: volumes too small to fill the chip with 128-voxel tiles (the 8x8x4 bottleneck

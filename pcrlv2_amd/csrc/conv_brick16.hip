@@ -97,7 +97,12 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
                : "memory");
 }
 
-template <int BN, int MODE = 0>   // 0: 3x3x3 convolution; 1: composed up-conv forward; 2: composed up-conv data gradient (Brick16Params)
+// MODE 0: 3x3x3 convolution; 1: composed up-conv forward; 2: composed up-conv data gradient (Brick16Params).
+// PERM 1: the brick's (d, h, w) axes run along the volume's (D, W, H) -- p.D, p.H, p.W are then the extents along the BRICK axes (D, W, H of the
+// volume) -- for volumes whose H, not W, is a multiple of 16 (the 16 x 16 x 8 level).  A convolution commutes with a permutation of the axes
+// applied to volume, taps and phases alike: only the voxel index (VOX / FVOX), the tap number of a weight row (WTAP), the phase / parity bit of
+// an axis (BITH / BITW) and the border class (CLS) know the difference; rows still go through LDS one 64-byte slice per voxel.
+template <int BN, int MODE = 0, int PERM = 0>
 __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Params p) {
   constexpr int FN = BN / 16;
   constexpr bool UPCF = MODE == 1, UPCD = MODE == 2;
@@ -127,13 +132,20 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
   }
   const int n0 = ytile * BN;
-  const int uph = UPCF ? n0 / p.upc : 0, ukd0 = (uph >> 2) & 1, ukh0 = (uph >> 1) & 1;
+#define BITD(x_) (((x_) >> 2) & 1)
+#define BITH(x_) (PERM ? ((x_)&1) : (((x_) >> 1) & 1))      /* bit of the volume axis the brick's h axis runs along */
+#define BITW(x_) (PERM ? (((x_) >> 1) & 1) : ((x_)&1))
+#define VOX(n_, d_, h_, w_) (PERM ? (((int64_t)(n_)*p.D + (d_)) * p.W + (w_)) * p.H + (h_) : (((int64_t)(n_)*p.D + (d_)) * p.H + (h_)) * p.W + (w_))
+#define FVOX(n_, d_, h_, w_) (PERM ? (((int64_t)(n_) * (2 * p.D) + (d_)) * (2 * p.W) + (w_)) * (2 * p.H) + (h_) \
+                                   : (((int64_t)(n_) * (2 * p.D) + (d_)) * (2 * p.H) + (h_)) * (2 * p.W) + (w_))
+#define WTAP(s9_, j_) (PERM ? ((s9_) / 3) * 9 + (j_)*3 + (s9_) % 3 : (s9_)*3 + (j_))   /* (kd, kh, kw) of the brick -> tap number of the volume */
+  const int uph = UPCF ? n0 / p.upc : 0, ukd0 = BITD(uph), ukh0 = BITH(uph);
   // stage number -> (kd * 3 + kh).  UPCF: the block's phase uses k = p, p + 1 per axis; UPCD: chunk c's parity uses k = 1 - par, 2 - par.
 #define PARC(c_) ((c_) >> p.cshift)
 #define SID(c_, s_) (MODE == 0 ? (s_) : MODE == 1 ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) \
-                                                 : ((1 - ((PARC(c_) >> 2) & 1) + ((s_) >> 1)) * 3 + 1 - ((PARC(c_) >> 1) & 1) + ((s_)&1)))
-#define KW0_ON(c_) (MODE == 0 ? true : MODE == 1 ? (uph & 1) == 0 : (PARC(c_) & 1) == 1)   /* the third kw tap's weights are zero: its MFMAs are skipped */
-#define KW2_ON(c_) (MODE == 0 ? true : MODE == 1 ? (uph & 1) == 1 : (PARC(c_) & 1) == 0)
+                                                 : ((1 - BITD(PARC(c_)) + ((s_) >> 1)) * 3 + 1 - BITH(PARC(c_)) + ((s_)&1)))
+#define KW0_ON(c_) (MODE == 0 ? true : MODE == 1 ? BITW(uph) == 0 : BITW(PARC(c_)) == 1)   /* the third kw tap's weights are zero: its MFMAs are skipped */
+#define KW2_ON(c_) (MODE == 0 ? true : MODE == 1 ? BITW(uph) == 1 : BITW(PARC(c_)) == 0)
   const int brick_id = b;
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
@@ -163,10 +175,10 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
       int64_t el;                                                                                          \
       if (UPCD) { /* fine voxel 2 v + par of the coarse halo voxel, channel chunk inside the parity */     \
         const int par = PARC(c_), co0 = ((c_) - (par << p.cshift)) * 32;                                   \
-        const int64_t fv = (((int64_t)n * (2 * p.D) + 2 * d + ((par >> 2) & 1)) * (2 * p.H) + 2 * h + ((par >> 1) & 1)) * (2 * p.W) + 2 * w + (par & 1); \
+        const int64_t fv = FVOX(n, 2 * d + BITD(par), 2 * h + BITH(par), 2 * w + BITW(par));               \
         el = fv * p.upc + co0 + ls * 8;                                                                    \
       } else {                                                                                             \
-        el = ((((int64_t)n * p.D + d) * p.H + h) * p.W + w) * K + (c_)*32 + ls * 8;                        \
+        el = VOX(n, d, h, w) * K + (c_)*32 + ls * 8;                                                       \
       }                                                                                                    \
       const char* src = ok ? xb + (el << 1) : zp;                                                          \
       lds_dma16(src, lds_base + (wid + 4 * i) * 1024);                                                     \
@@ -186,7 +198,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
 #define LOAD_W(c_, s9_)                                                                                    \
   do {                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                          \
-      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)((s9_)*3 + j) * K + (c_)*32);                \
+      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)WTAP(s9_, j) * K + (c_)*32);                 \
   } while (0)
 #define STORE_W()                                                                                          \
   do {                                                                                                     \
@@ -326,6 +338,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
 #undef PARC
 #undef KW0_ON
 #undef KW2_ON
+#undef WTAP
 #undef SB
 #undef MFMA_HALF
 #undef LOADA
@@ -351,12 +364,12 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   for (int fm = 0; fm < 8; ++fm) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      int64_t row = (((int64_t)n * p.D + d0 + wid) * p.H + h0 + fm) * p.W + w0 + lg * 4 + r;
-      if (UPCF) {   // the phase's fine voxel, and the bias of its border class (0 first, 1 inside, 2 last per axis)
-        const int fd = 2 * (d0 + wid) + ((uph >> 2) & 1), fh = 2 * (h0 + fm) + ((uph >> 1) & 1), fw = 2 * (w0 + lg * 4 + r) + (uph & 1);
-        row = (((int64_t)n * (2 * p.D) + fd) * (2 * p.H) + fh) * (2 * p.W) + fw;
-        const int cls = ((fd == 0 ? 0 : (fd == 2 * p.D - 1 ? 2 : 1)) * 3 + (fh == 0 ? 0 : (fh == 2 * p.H - 1 ? 2 : 1))) * 3 +
-                        (fw == 0 ? 0 : (fw == 2 * p.W - 1 ? 2 : 1));
+      int64_t row = VOX(n, d0 + wid, h0 + fm, w0 + lg * 4 + r);
+      if (UPCF) {   // the phase's fine voxel, and the bias of its border class (0 first, 1 inside, 2 last per axis; class number in volume order)
+        const int fd = 2 * (d0 + wid) + BITD(uph), fh = 2 * (h0 + fm) + BITH(uph), fw = 2 * (w0 + lg * 4 + r) + BITW(uph);
+        row = FVOX(n, fd, fh, fw);
+        const int cd = fd == 0 ? 0 : (fd == 2 * p.D - 1 ? 2 : 1), ch = fh == 0 ? 0 : (fh == 2 * p.H - 1 ? 2 : 1), cw = fw == 0 ? 0 : (fw == 2 * p.W - 1 ? 2 : 1);
+        const int cls = PERM ? (cd * 3 + cw) * 3 + ch : (cd * 3 + ch) * 3 + cw;
 #pragma unroll
         for (int j = 0; j < FN; ++j) bv[j] = p.bias_tab[cls * p.upc + uch0 + j * 16 + lr];
       }
@@ -398,25 +411,50 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   }
 }
 
+#undef BITD
+#undef BITH
+#undef BITW
+#undef VOX
+#undef FVOX
+
 std::atomic<int> g_brick16_on{1};
+// 0: no brick tiling; 1: (4, 8, 16) bricks along (D, H, W); 2: along (D, W, H) (PERM instantiations)
+int brick16_perm(int D, int H, int W) {
+  if (D % TD == 0 && H % TH == 0 && W % TW == 0) return 1;
+  static const bool perm_on = [] { const char* e = getenv("PCRL_B16_PERM"); return !(e && e[0] == '0'); }();   // A/B switch
+  if (perm_on && D % TD == 0 && W % TH == 0 && H % TW == 0) return 2;
+  return 0;
+}
 
 }  // namespace
 
 // ---- internal interface used by conv_igemm.hip's dispatcher -------------------------------------------------------
 void pcrl_brick16_set(int on) { g_brick16_on = on; }
 bool pcrl_brick16_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  return g_brick16_on && dtype == PCRL_BF16 && D % TD == 0 && H % TH == 0 && W % TW == 0 && Ci % 32 == 0 && Co % 32 == 0 &&
-         (int64_t)N * D * H * W < ((int64_t)1 << 29);
+  return g_brick16_on && dtype == PCRL_BF16 && brick16_perm(D, H, W) != 0 && Ci % 32 == 0 && Co % 32 == 0 && (int64_t)N * D * H * W < ((int64_t)1 << 29);
 }
-int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W) { return (int64_t)N * (D / TD) * (H / TH) * (W / TW); }
+int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W) { return (int64_t)N * D * H * W / (TD * TH * TW); }
+
+// p.D / p.H / p.W arrive as the volume's extents; perm == 2: handed to the PERM instantiation as the extents along the brick axes (D, W, H)
+template <int BN, int MODE>
+static int launch16(Brick16Params p, dim3 grid, hipStream_t stream, const char* what) {
+  constexpr size_t lds = HALO_BYTES + 3 * BN * 64;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  });
+  if (brick16_perm(p.D, p.H, p.W) == 2) {
+    std::swap(p.H, p.W);
+    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 1>), grid, dim3(256), lds, stream, p);
+  } else {
+    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 0>), grid, dim3(256), lds, stream, p);
+  }
+  return pcrl_check_launch(what);
+}
 
 int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                              int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 32 * 64);
-  });
   Brick16Params p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0, 0, nullptr, 0};
   const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
   const int BN = Co % 64 == 0 ? 64 : 32, ny = Co / BN;
@@ -426,9 +464,7 @@ int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, v
     p.ny = ny;
     grid = dim3((unsigned)(bricks * ny));
   }
-  if (BN == 64) hipLaunchKernelGGL((brick16_conv_kernel<64>), grid, dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
-  else hipLaunchKernelGGL((brick16_conv_kernel<32>), grid, dim3(256), HALO_BYTES + 3 * 32 * 64, stream, p);
-  return pcrl_check_launch("brick16_conv");
+  return BN == 64 ? launch16<64, 0>(p, grid, stream, "brick16_conv") : launch16<32, 0>(p, grid, stream, "brick16_conv");
 }
 
 // ---- forward of the composed ConvTranspose3d -> Conv3d operator on the wide-brick kernel (see Brick16Params::upc) ----
@@ -438,17 +474,12 @@ bool pcrl_brick16_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, i
 }
 int pcrl_brick16_upc_fwd_launch(const void* x, const void* w3, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
                                 hipStream_t stream) {
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<64, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
-  });
   Brick16Params p{(const bf16*)x, (const bf16*)w3, nullptr, (bf16*)y0, stats, N, D, H, W, Ci, 8 * Co, 0, Co, bias_tab, 0};
   const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
   const int ny = 8 * Co / 64;
   if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16 (composed up-conv): grid too large");
   p.ny = ny;
-  hipLaunchKernelGGL((brick16_conv_kernel<64, 1>), dim3((unsigned)(bricks * ny)), dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
-  return pcrl_check_launch("brick16_conv (composed up-conv forward)");
+  return launch16<64, 1>(p, dim3((unsigned)(bricks * ny)), stream, "brick16_conv (composed up-conv forward)");
 }
 
 // ---- data gradient of the composed operator on the wide-brick kernel (see Brick16Params::cshift) ----
@@ -462,15 +493,10 @@ bool pcrl_brick16_upc_dgrad_eligible(int N, int D, int H, int W, int Ci, int Co,
   return upc_cshift(Co) >= 0 && Ci % 64 == 0 && pcrl_brick16_conv_eligible(N, D, H, W, 8 * Co, Ci, dtype) && (int64_t)N * D * H * W * 8 < ((int64_t)1 << 29);
 }
 int pcrl_brick16_upc_dgrad_launch(const void* dy0, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, HALO_BYTES + 3 * 64 * 64);
-  });
   Brick16Params p{(const bf16*)dy0, (const bf16*)wd3, nullptr, (bf16*)dx, nullptr, N, D, H, W, 8 * Co, Ci, 0, Co, nullptr, upc_cshift(Co)};
   const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
   const int ny = Ci / 64;
   if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16 (composed up-conv data gradient): grid too large");
   p.ny = ny;
-  hipLaunchKernelGGL((brick16_conv_kernel<64, 2>), dim3((unsigned)(bricks * ny)), dim3(256), HALO_BYTES + 3 * 64 * 64, stream, p);
-  return pcrl_check_launch("brick16_conv (composed up-conv data gradient)");
+  return launch16<64, 2>(p, dim3((unsigned)(bricks * ny)), stream, "brick16_conv (composed up-conv data gradient)");
 }

@@ -520,6 +520,13 @@ extern "C" int64_t pcrl_conv3d_k3_stats_rows(int N, int D, int H, int W, int Ci,
   return ((int64_t)N * D * H * W + PCRL_CONV_BM - 1) / PCRL_CONV_BM;
 }
 
+// informational: which kernel pcrl_conv3d_k3_fwd gives this shape -- 2: wide-brick (conv_brick16.hip), 1: brick (conv_brick.hip), 0: gather
+extern "C" int64_t pcrl_conv3d_k3_fwd_kernel(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  if (g_conv_impl == 0 && pcrl_brick16_conv_eligible(N, D, H, W, Ci, Co, dtype)) return 2;
+  if (g_conv_impl == 0 && pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype)) return 1;
+  return 0;
+}
+
 static int conv3d_k3_fwd_impl(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, void* ws, int64_t ws_bytes,
                              int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_dims("conv3d_k3_fwd", N, D, H, W, Ci, Co)) return e;

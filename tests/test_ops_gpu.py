@@ -60,6 +60,8 @@ SHAPES3 = [  # N, D, H, W, Ci, Co   (M deliberately not a multiple of 128 in the
     (1, 4, 16, 16, 256, 128),
     # 4x8x16-brick kernel (conv_brick16.hip): edge bricks in d, h, w; one and several bricks per direction; BN = 32 (Co = 32), Co = 96
     (1, 8, 16, 32, 32, 64), (2, 4, 8, 16, 64, 32), (1, 12, 24, 48, 32, 96), (2, 8, 8, 32, 96, 64),
+    # the same kernel with its brick axes along (D, W, H): H % 16 == 0, W % 8 == 0 but not W % 16 (the 16 x 16 x 8 level)
+    (3, 4, 16, 8, 64, 64), (1, 4, 32, 8, 64, 128), (2, 8, 16, 24, 32, 96), (1, 16, 16, 8, 128, 32),
     # brick kernels with the innermost extent as the 4-deep brick axis (the 8 x 8 x 4 bottleneck level; W = 12: three bricks along W)
     (2, 8, 8, 4, 64, 128), (3, 16, 8, 4, 32, 64), (1, 8, 16, 12, 64, 64),
 ]

@@ -55,6 +55,10 @@ SHAPES = [  # N, D, H, W (coarse), Ci, Cm, Co
     # the data gradient of the three shapes above with Ci % 64 == 0 also runs on the wide-brick kernel (space-to-depth view of dy0); plus:
     (1, 4, 8, 16, 64, 64, 32),      # Co = 32: one 32-channel chunk per parity (forward on the gather kernel)
     (2, 4, 16, 16, 128, 64, 128),   # Co = 128: four chunks per parity, two 64-channel output tiles
+    # wide-brick kernel with its axes along (D, W, H) (coarse H % 16 == 0, W % 8 == 0, not W % 16): phases, parities and border classes permuted
+    (1, 4, 16, 8, 64, 64, 64),
+    (2, 8, 16, 8, 128, 128, 64),
+    (1, 4, 32, 24, 64, 64, 32),
 ]
 
 
