@@ -65,7 +65,7 @@ struct Brick16Params {
   // UPCF instantiations only (forward of the composed ConvTranspose3d -> Conv3d operator, upconv_fused.hip): x is the COARSE tensor, the
   // Nc = 8 * upc output channels are 8 phases x upc channels, w the zero-embedded 3x3x3 weights [8 * upc][27][K] in which a phase holds
   // its 2 x 2 x 2 taps at (p + q) per axis.  A block (one 64-channel tile = one phase, or part of one) walks only the 4 of 9 (kd, kh) stages
-  // its phase uses (the MFMAs of a stage's unused kw tap are skipped), writes its voxels to the phase's FINE positions of y [N][2D][2H][2W][upc]
+  // its phase uses, each with the two kw taps in use (STAGE2: the unused tap is neither staged nor read; 900 -> 960 TFLOP/s), writes its voxels to the phase's FINE positions of y [N][2D][2H][2W][upc]
   // and adds bias_tab[border class of the fine voxel][channel]; the statistics rows are [bricks][8 * upc][2] = [bricks * 8][upc][2].
   int upc;
   const float* bias_tab;
@@ -144,8 +144,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
 #define PARC(c_) ((c_) >> p.cshift)
 #define SID(c_, s_) (MODE == 0 ? (s_) : MODE == 1 ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) \
                                                  : ((1 - BITD(PARC(c_)) + ((s_) >> 1)) * 3 + 1 - BITH(PARC(c_)) + ((s_)&1)))
-#define KW0_ON(c_) (MODE == 0 ? true : MODE == 1 ? BITW(uph) == 0 : BITW(PARC(c_)) == 1)   /* the third kw tap's weights are zero: its MFMAs are skipped */
-#define KW2_ON(c_) (MODE == 0 ? true : MODE == 1 ? BITW(uph) == 1 : BITW(PARC(c_)) == 0)
+#define KWB(c_) (MODE == 0 ? 0 : MODE == 1 ? BITW(uph) : 1 - BITW(PARC(c_)))   /* first of the kw taps in use (composed modes: two, the third tap's weights are zero) */
   const int brick_id = b;
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
@@ -195,15 +194,16 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   const bf16* wrow = p.w + ((int64_t)(n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8;
   const int wdst = woff(tid >> 2, tid & 3);
   u32x4 rw[3];
-#define LOAD_W(c_, s9_)                                                                                    \
+  constexpr int NKW = MODE ? 2 : 3;   // kw taps per stage: the composed modes stage and multiply only the two taps their phase / parity uses
+#define LOAD_W(c_, s9_, kwb_) /* taps kwb_ .. kwb_ + NKW - 1 of stage (kd, kh) */                          \
   do {                                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                          \
-      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)WTAP(s9_, j) * K + (c_)*32);                 \
+    _Pragma("unroll") for (int j = 0; j < NKW; ++j)                                                        \
+      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)WTAP(s9_, (kwb_) + j) * K + (c_)*32);        \
   } while (0)
 #define STORE_W()                                                                                          \
   do {                                                                                                     \
     if (wthread) {                                                                                         \
-      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                        \
+      _Pragma("unroll") for (int j = 0; j < NKW; ++j)                                                      \
         *reinterpret_cast<u32x4*>(wbuf + j * (BN * 64) + wdst) = rw[j];                                    \
     }                                                                                                      \
   } while (0)
@@ -265,21 +265,20 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     if (sn == NSK) { sn = 0; cn = c + 1; }                                                                 \
     const bool last = (cn == nchunk);                                                                      \
     if (last) { cn = c; sn = s9; }                                                                         \
-    const bool kw0_on = KW0_ON(c), kw2_on = KW2_ON(c);                                                     \
-    if (!(B16_ABL & 1)) LOAD_W(cn, SID(cn, sn));                                                           \
+    if (!(B16_ABL & 1)) LOAD_W(cn, SID(cn, sn), 0);                                                        \
     const bool halo_next = (s9 == NSK - 1) && !last && !(B16_ABL & 2); /* block-uniform */                 \
     const bool more_chunks = c + 1 < nchunk && !(B16_ABL & 2);                                             \
     const int tap64 = ((SID(c, s9) / 3) * HH + (SID(c, s9) % 3)) * (HP * 64);                              \
     const int ntap64 = ((SID(cn, sn) / 3) * HH + (SID(cn, sn) % 3)) * (HP * 64);                           \
     /* ht0: kw 0, half 0 */                                                                                \
     LOADA(1, akw[0] + tap64, 1);                                                                           \
-    if (kw0_on) MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
+    MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \
     /* ht1: kw 0, half 1 */                                                                                \
     LOADA(0, akw[1] + tap64, 0);                                                                           \
     LOADB((P_) ^ 1, wbuf + 1 * (BN * 64));                                                                 \
-    if (kw0_on) MFMA_HALF(1, P_, 1, 0, 4);                                                                 \
+    MFMA_HALF(1, P_, 1, 0, 4);                                                                 \
     PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
     SB();                                                                                                  \
     /* ht2: kw 1, half 0 */                                                                                \
@@ -295,7 +294,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     SB();                                                                                                  \
     /* ht4: kw 2, half 0 */                                                                                \
     LOADA(1, akw[2] + tap64, 1);                                                                           \
-    if (kw2_on) MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
+    MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \
     /* ht5: kw 2, half 1 -- every LDS read of this stage (and, in a chunk's last stage, of this chunk's halo) is complete */ \
@@ -304,14 +303,61 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     if (B16_EARLY && more_chunks && s9 == 2) DMA_HALO(c + 1, 0, PA);                                        \
     if (B16_EARLY && more_chunks && s9 == 5) DMA_HALO(c + 1, PA, PB);                                       \
     if (halo_next) DMA_HALO(c + 1, B16_EARLY ? PB : 0, NDMA);                                               \
-    if (kw2_on) MFMA_HALF(1, P_, 1, 0, 2);                                                                 \
+    MFMA_HALF(1, P_, 1, 0, 2);                                                                 \
     PIPE_WRITES(3, FN / 2);                                                                                     \
     SB();                                                                                                  \
     if (halo_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
     __syncthreads();                                                                                       \
     LOADA(0, akw[0] + ntap64, 0);                                                                          \
     LOADB((P_) ^ 1, wbuf);                                                                                 \
-    if (kw2_on) MFMA_HALF(1, P_, 1, 2, 4);                                                                 \
+    MFMA_HALF(1, P_, 1, 2, 4);                                                                 \
+    PIPE_READS(4 + FN, 1);                                                                                 \
+    SB();                                                                                                  \
+    c = cn;                                                                                                \
+    s9 = sn;                                                                                               \
+  } while (0)
+
+  // Composed modes: a stage = the TWO kw taps in use (four half-taps); same pipeline, the B sets no longer flip between stages.
+#define STAGE2()                                                                                           \
+  do {                                                                                                     \
+    int cn = c, sn = s9 + 1;                                                                               \
+    if (sn == NSK) { sn = 0; cn = c + 1; }                                                                 \
+    const bool last = (cn == nchunk);                                                                      \
+    if (last) { cn = c; sn = s9; }                                                                         \
+    const int kwb = KWB(c), kwbn = KWB(cn);                                                                \
+    LOAD_W(cn, SID(cn, sn), kwbn);                                                                         \
+    const bool halo_next = (s9 == NSK - 1) && !last; /* block-uniform */                                   \
+    const int tap64 = ((SID(c, s9) / 3) * HH + (SID(c, s9) % 3)) * (HP * 64);                              \
+    const int ntap64 = ((SID(cn, sn) / 3) * HH + (SID(cn, sn) % 3)) * (HP * 64);                           \
+    const int a0 = kwb ? akw[1] : akw[0], a1 = kwb ? akw[2] : akw[1], an0 = kwbn ? akw[1] : akw[0];        \
+    /* ht0: first tap, half 0 */                                                                           \
+    LOADA(1, a0 + tap64, 1);                                                                               \
+    MFMA_HALF(0, 0, 0, 0, 4);                                                                              \
+    PIPE_READS(4, FN);                                                                                     \
+    SB();                                                                                                  \
+    /* ht1: first tap, half 1 */                                                                           \
+    LOADA(0, a1 + tap64, 0);                                                                               \
+    LOADB(1, wbuf + 1 * (BN * 64));                                                                        \
+    MFMA_HALF(1, 0, 1, 0, 4);                                                                              \
+    PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                               \
+    SB();                                                                                                  \
+    /* ht2: second tap, half 0 */                                                                          \
+    LOADA(1, a1 + tap64, 1);                                                                               \
+    MFMA_HALF(0, 1, 0, 0, 4);                                                                              \
+    PIPE_READS(4, FN);                                                                                     \
+    SB();                                                                                                  \
+    /* ht3: second tap, half 1 -- every LDS read of this stage (and, in a chunk's last stage, of this chunk's halo) is complete */ \
+    __syncthreads();                                                                                       \
+    STORE_W();                                                                                             \
+    if (halo_next) DMA_HALO(c + 1, 0, NDMA);                                                               \
+    MFMA_HALF(1, 1, 1, 0, 2);                                                                              \
+    PIPE_WRITES(2, FN / 2);                                                                                \
+    SB();                                                                                                  \
+    if (halo_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
+    __syncthreads();                                                                                       \
+    LOADA(0, an0 + ntap64, 0);                                                                             \
+    LOADB(0, wbuf);                                                                                        \
+    MFMA_HALF(1, 1, 1, 2, 4);                                                                              \
     PIPE_READS(4 + FN, 1);                                                                                 \
     SB();                                                                                                  \
     c = cn;                                                                                                \
@@ -319,25 +365,29 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   } while (0)
 
   DMA_HALO(0, 0, NDMA);
-  LOAD_W(0, SID(0, 0));
+  LOAD_W(0, SID(0, 0), KWB(0));
   STORE_W();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  LOADA(0, akw[0] + ((SID(0, 0) / 3) * HH + (SID(0, 0) % 3)) * (HP * 64), 0);
+  LOADA(0, (KWB(0) ? akw[1] : akw[0]) + ((SID(0, 0) / 3) * HH + (SID(0, 0) % 3)) * (HP * 64), 0);
   LOADB(0, wbuf);
 
   const int nstage = NSK * nchunk;
-  for (int S = 0; S + 1 < nstage; S += 2) {
-    STAGE(0);
-    STAGE(1);
+  if constexpr (MODE == 0) {
+    for (int S = 0; S + 1 < nstage; S += 2) {
+      STAGE(0);
+      STAGE(1);
+    }
+    if (nstage & 1) STAGE(0);
+  } else {
+    for (int S = 0; S < nstage; ++S) STAGE2();
   }
-  if (nstage & 1) STAGE(0);
   __syncthreads();   // the epilogue reuses the LDS
 #undef STAGE
+#undef STAGE2
 #undef SID
 #undef PARC
-#undef KW0_ON
-#undef KW2_ON
+#undef KWB
 #undef WTAP
 #undef SB
 #undef MFMA_HALF

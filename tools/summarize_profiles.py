@@ -19,7 +19,7 @@ def short(name):
         if key in name:
             if key == "brick16_conv_kernel":      # template arguments <BN, MODE>: MODE 1 / 2 = the composed up-conv's forward / data gradient
                 import re
-                m = re.search(r"brick16_conv_kernel(?:ILi\d+ELi(\d)E|<\d+, (\d)>)", name)
+                m = re.search(r"brick16_conv_kernel(?:ILi\d+ELi(\d)E|<\d+, (\d)[,>])", name)     # <BN, MODE, PERM>
                 mode = (m.group(1) or m.group(2)) if m else "0"
                 return key + {"1": "<upconv_fwd>", "2": "<upconv_dgrad>"}.get(mode, "")
             if key == "igemm_kernel":
