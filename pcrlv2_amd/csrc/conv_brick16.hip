@@ -27,6 +27,8 @@
 // The epilogue (128 two-byte stores per lane) costs 7 % (64 -> 64 channels) to 16 % (32 -> 64: one K chunk per block) by the same kind of
 // ablation; storing 4-byte channel pairs after a lane-pair exchange (64 stores, 2 DPP moves and 6 selects per fragment) measured equal
 // or 3 % worse, 8-byte quads through a transposed accumulator layout 4 % worse (spills): the stores stay as they are.
+// Composed modes: sourcing the halo planes a phase / parity never reads (one of T + 2 per axis, 30 % of the rows) from the zero page instead of
+// the tensor measured 4 % SLOWER (960 -> 915 TFLOP/s: every lane of those rows then hits one 16-byte line): the full halo is requested.
 //
 // LDS: halo 68 KiB (single buffer: 1080 rows x 64 B, rounded up to whole 1 KiB DMA pieces) + one weight stage 12 KiB = 80 KiB -> two
 // blocks (eight waves) per CU.  The next chunk's halo is requested as soon as every wave holds the last fragments of the current one
