@@ -28,7 +28,9 @@
 // ablation; storing 4-byte channel pairs after a lane-pair exchange (64 stores, 2 DPP moves and 6 selects per fragment) measured equal
 // or 3 % worse, 8-byte quads through a transposed accumulator layout 4 % worse (spills): the stores stay as they are.
 // Composed modes: sourcing the halo planes a phase / parity never reads (one of T + 2 per axis, 30 % of the rows) from the zero page instead of
-// the tensor measured 4 % SLOWER (960 -> 915 TFLOP/s: every lane of those rows then hits one 16-byte line): the full halo is requested.
+// the tensor measured 4 % SLOWER (960 -> 915 TFLOP/s), and not requesting them at all (exec-masked lanes; rows outside the volume zeroed once per
+// block instead of read from the zero page) 1-2 % slower than the plain request, in every mode: what the halo request costs is its issue
+// (address arithmetic per piece at the chunk boundary), not the bytes -- the full halo is requested, branch-free.
 //
 // LDS: halo 68 KiB (single buffer: 1080 rows x 64 B, rounded up to whole 1 KiB DMA pieces) + one weight stage 12 KiB = 80 KiB -> two
 // blocks (eight waves) per CU.  The next chunk's halo is requested as soon as every wave holds the last fragments of the current one
