@@ -35,6 +35,12 @@ _ws = os.environ.get("PCRL_WGRAD_STREAM", "")
 WGRAD_SIDE_STREAM_3D = _ws != "0"
 WGRAD_SIDE_STREAM_2D = _ws != "0"
 
+# Forward: the side branches of a decoder stage -- projection / predictor heads and the deep-supervision map (pcrlv2_model_3d.py:67-71), small
+# HBM- and latency-bound kernels whose results nothing in the forward consumes -- run on the side stream next to the next stage's convolutions;
+# the main stream joins at the end of model.forward (train_3d.step_losses: once, before the losses).  PCRL_BRANCH_STREAM=0: off (A/B switch;
+# results are bit-identical).
+FWD_BRANCH_STREAM = os.environ.get("PCRL_BRANCH_STREAM", "1") != "0"
+
 # The global-average-pool branch of UpTransition (pcrlv2_model_3d.py:67) sends d_g[n][c] / S back to every voxel of a1: folded into the
 # two passes of ops.1's BatchNorm backward (pcrl_bn_act_bwd_*_rowadd) instead of materialised (pcrl_gap_bwd).  PCRL_FOLD_GAP_GRAD=0:
 # materialise (A/B switch; the folded form skips one bf16 rounding of the summed gradient).

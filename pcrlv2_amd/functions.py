@@ -256,12 +256,15 @@ class UpStageFn(Function):
             g = ops.gap_forward(a1, dt)
         else:   # activation and its global average pool (:67) from one pass over the convolution output
             (a1, g), sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gap=True)
-        x_pro, m_pro, r_pro = ops.bn1d_forward(g, bn_g, bn_b, mod.bn.running_mean, mod.bn.running_var, relu=False)
-        h0 = ops.linear_forward(x_pro, p0_w, p0_b)
-        ph1 = mod.predictor_head[1]
-        h1, m_h, r_h = ops.bn1d_forward(h0, p1_g, p1_b, ph1.running_mean, ph1.running_var, relu=True)
-        x_pre = ops.linear_forward(h1, p3_w, p3_b)
-        x_mask, svd = ops.luconv_forward(a1, dw_, db_, dg_, dbe_, ld.bn1.running_mean, ld.bn1.running_var, ld._packed, ACT_SIGMOID, dt)
+        # The stage's side branches -- nothing in the forward consumes them -- on the side stream, next to the next stage's convolutions
+        # (config.FWD_BRANCH_STREAM; the main stream joins at the end of the forward).  Backward runs on the main stream as before.
+        with ops.side_branch(a1.device, a1, g):
+            x_pro, m_pro, r_pro = ops.bn1d_forward(g, bn_g, bn_b, mod.bn.running_mean, mod.bn.running_var, relu=False)
+            h0 = ops.linear_forward(x_pro, p0_w, p0_b)
+            ph1 = mod.predictor_head[1]
+            h1, m_h, r_h = ops.bn1d_forward(h0, p1_g, p1_b, ph1.running_mean, ph1.running_var, relu=True)
+            x_pre = ops.linear_forward(h1, p3_w, p3_b)
+            x_mask, svd = ops.luconv_forward(a1, dw_, db_, dg_, dbe_, ld.bn1.running_mean, ld.bn1.running_var, ld._packed, ACT_SIGMOID, dt)
         for m in (l0, l1, ld):
             m._count_batch()
         mod._count_batch_heads()
@@ -351,7 +354,8 @@ class OutFn(Function):
     def forward(ctx, x, w, b, mod):
         dt = mod.compute_dtype
         x = ops.to_act(x, dt)
-        out = ops.conv1x1_to1_forward(x, w, b, dt)
+        with ops.side_branch(x.device, x):      # nothing in the forward consumes the reconstruction: next to the next pass's encoder
+            out = ops.conv1x1_to1_forward(x, w, b, dt)
         ctx.x, ctx.w, ctx.dt = x, w, dt
         ctx.pass_idx = getattr(mod, "_pass_idx", 1)
         ctx.plist = (w, b)
@@ -376,7 +380,8 @@ class TrilinearFn(Function):
     def forward(ctx, x, scale):
         ctx.shape, ctx.scale = tuple(x.shape), scale
         ctx.set_materialize_grads(False)
-        return ops.upsample_forward(x, scale)
+        with ops.side_branch(x.device, x):      # behind the deep-supervision branch that produced x (UpStageFn.forward)
+            return ops.upsample_forward(x, scale)
 
     @staticmethod
     def backward(ctx, dy):

@@ -273,4 +273,6 @@ class PCRLv23d(nn.Module):
             middle_features.append([pro, pre])
             if not local:
                 middle_masks.append(mask if factor == 1 else Fn.TrilinearFn.apply(mask, factor))
-        return self.out_tr(h), middle_features, middle_masks
+        out = self.out_tr(h)
+        ops.end_of_forward_join()           # the stages' side branches (config.FWD_BRANCH_STREAM) are complete when the outputs are handed out
+        return out, middle_features, middle_masks

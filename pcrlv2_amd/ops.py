@@ -76,6 +76,39 @@ class side_wgrad:
         return False
 
 
+class side_branch(side_wgrad):
+    """`with side_branch(device, a, g):` -- a forward side branch (config.FWD_BRANCH_STREAM) on the same side stream; joined by
+    join_side_stream() at the end of the forward (or, inside `deferred_join()`, when the caller asks)."""
+
+    def __init__(self, device, *operands):
+        self.device, self.operands = device, operands
+        self.active = config.FWD_BRANCH_STREAM and device.type == "cuda"
+
+
+_defer_join = 0
+
+
+class deferred_join:
+    """Inside this context model.forward leaves the side stream un-joined (its branch outputs are NOT safe to read on the main stream);
+    leaving the context joins.  train_3d.step_losses wraps its three forwards in it: a stage's branch then also runs under the next pass."""
+
+    def __enter__(self):
+        global _defer_join
+        _defer_join += 1
+
+    def __exit__(self, *exc):
+        global _defer_join
+        _defer_join -= 1
+        if _defer_join == 0:
+            join_side_stream()
+        return False
+
+
+def end_of_forward_join():
+    if _defer_join == 0:
+        join_side_stream()
+
+
 def join_side_stream(device=None):
     """The current stream waits for every weight gradient launched so far (no-op when none is outstanding)."""
     for key, pending in list(_side_pending.items()):

@@ -116,10 +116,13 @@ def step_losses(model, batch, epoch, criterion, cosine):
     view1, view2, target, _unused_gt2, local_views = batch              # gt2 is never used by the reference either (Q3)
     n = view1.size(0)
     target = _to_gpu(target)
-    out1, feats1, masks1 = model(_to_gpu(view1))
-    _out2, feats2, _ = model(_to_gpu(view2))                            # mask2 / its deep-supervision maps stay unused (Q3)
-    if getattr(cosine, "fusable", False) and FUSED_COS_LOSSES:
-        _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
+    fused = getattr(cosine, "fusable", False) and FUSED_COS_LOSSES
+    with _ops.deferred_join():     # the decoder stages' side branches (heads, deep-supervision maps) also run under the NEXT forward; joined on exit
+        out1, feats1, masks1 = model(_to_gpu(view1))
+        _out2, feats2, _ = model(_to_gpu(view2))                        # mask2 / its deep-supervision maps stay unused (Q3)
+        if fused:
+            _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
+    if fused:
         l_global, l_local, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
         l_restore = criterion(out1, target)
         beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))

@@ -355,18 +355,20 @@ def test_round2_fusions_leave_the_step_unchanged_fp32(switch):
     assert worst[1] < (1e-2 if switch == "COMPOSE_UPCONV" else 2e-5), (switch, worst)
 
 
+@pytest.mark.parametrize("switch", ["WGRAD_SIDE_STREAM_3D", "FWD_BRANCH_STREAM"])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-def test_weight_gradients_on_the_side_stream_are_bit_identical(dt):
+def test_weight_gradients_on_the_side_stream_are_bit_identical(dt, switch):
     """config.WGRAD_SIDE_STREAM_3D (default on): the weight-gradient kernels run on a second stream next to the data-gradient / BatchNorm
-    chain.  Same kernels, same operands, only the ordering between streams differs -> the parameters after two SGD steps and the
-    BatchNorm running statistics must be BIT-identical to the one-stream run."""
+    chain; config.FWD_BRANCH_STREAM (default on): the decoder stages' heads and deep-supervision maps run there in forward.  Same kernels,
+    same operands, only the ordering between streams differs -> the parameters after two SGD steps and the BatchNorm running statistics
+    must be BIT-identical to the one-stream run."""
     from pcrlv2_amd import config
     batches = [O.fill_batch(4, (32, 32, 16), dtype=torch.float32, seed=21 + s) for s in range(2)]
     finals = []
-    old = config.WGRAD_SIDE_STREAM_3D
+    old = getattr(config, switch)
     try:
         for on in (True, False):
-            config.WGRAD_SIDE_STREAM_3D = on
+            setattr(config, switch, on)
             model = build(dt)
             opt = FusedSGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
             random.seed(5)
@@ -375,7 +377,7 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical(dt):
             torch.cuda.synchronize()
             finals.append(([float(l) for l in losses], opt.flat_p.clone(), {k: v.clone() for k, v in model.state_dict().items() if "running" in k}))
     finally:
-        config.WGRAD_SIDE_STREAM_3D = old
+        setattr(config, switch, old)
     (la, pa, ra), (lb, pb, rb) = finals
     assert la == lb, (la, lb)
     assert torch.equal(pa, pb), float((pa - pb).abs().max())
