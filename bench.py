@@ -7,9 +7,11 @@
   step     : one pass of train_3d.train_step over one batch.
   roofline : the dominant kernel (bf16 LDS-halo implicit-GEMM 3x3x3 convolution, forward + data-gradient launches): algorithmic
              FLOPs (2*M*27*Ci*Co per launch) / launch duration measured with HIP events on the launch stream, against
-             the dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).  The weight-gradient kernels run on a
-             side stream next to these launches, so the timed-region figure is the kernel under that contention (it agrees with the
-             rocprofv3 summary of the same command); roofline.alone is the same kernel over 10 extra steps with the side stream off.
+             the dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).  The step runs on three streams (the
+             second global view; weight gradients and the decoder's side branches), so in the timed region this kernel SHARES the chip --
+             two convolutions side by side each see about half of it -- and roofline.frac is its share (it agrees with the rocprofv3
+             summary of the same command, profiles/*_overlap_*); roofline.alone is the same kernel over 10 extra one-stream steps: its
+             rate with the chip to itself, the kernel-quality figure (profiles/*_kernel_stats.txt is the one-stream profile).
   cpu_baseline : the CPU oracle (a port of the reference step, oracle/pcrlv2_oracle.py) timed on this box's host cores on
              a bounded sample (b=8, <= 3 steps or ~35 s), rank 0, N=1 only.
 
@@ -244,13 +246,15 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # Weight gradients run on a side stream next to the data-gradient / BatchNorm chain (config.WGRAD_SIDE_STREAM_3D), so the per-launch
-    # times above are times under that contention.  A few extra steps with the side stream off (after the timed region, one GPU only)
-    # give the dominant kernel's time with the chip to itself: reported as roofline.alone, never as `value`.
+    # The step runs on three streams (config.py: the second global view on its own stream, weight gradients and the decoder's side branches on
+    # a side stream), so the per-launch times above are times of kernels SHARING the chip -- two convolutions side by side each see about half
+    # of it.  A few extra steps on one stream (after the timed region, one GPU only) give the dominant kernel's time with the chip to itself:
+    # reported as roofline.alone (the kernel-quality figure; the one-stream rocprofv3 summary agrees with it), never as `value`.
     from pcrlv2_amd import config as _cfg
     alone = None
     if world == 1 and _cfg.WGRAD_SIDE_STREAM_3D and not args.no_alone:
-        _cfg.WGRAD_SIDE_STREAM_3D = False
+        _cfg.WGRAD_SIDE_STREAM_3D = False     # also turns the second view's stream off (it needs the side stream)
+        _branch, _cfg.FWD_BRANCH_STREAM = _cfg.FWD_BRANCH_STREAM, False
         for _ in range(2):
             train_step(model, opt, batch, 0, crit, cosine, guard=False)
         alone = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_upconv_fwd"}, keyfn)
@@ -260,7 +264,7 @@ def main():
             train_step(model, opt, batch, 0, crit, cosine, guard=False)
         torch.cuda.synchronize()
         L.profiler = None
-        _cfg.WGRAD_SIDE_STREAM_3D = True
+        _cfg.WGRAD_SIDE_STREAM_3D, _cfg.FWD_BRANCH_STREAM = True, _branch
 
     if rank != 0:
         return
@@ -300,7 +304,7 @@ def main():
                      "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
                      "avg_launch_ms": round(ms / n, 4), "launches": n, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
                      "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(work / n),
-                     "concurrent": "weight-gradient kernels on a side stream" if alone is not None else None},
+                     "concurrent": "kernels of three streams share the chip in the timed region (second view, weight gradients + side branches): frac is the kernel's share, roofline.alone its rate with the chip to itself" if alone is not None else None},
         "step_mfma_frac": round(flop_per_crop * args.b * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4) if flop_per_crop else None,
         "kernels": detail, "final_loss": round(loss, 5),
         "diag": {"gpu_ms_per_step": per_step,
@@ -311,8 +315,9 @@ def main():
     if alone is not None and dom in alone.results():
         n1, ms1_, work1 = alone.results()[dom]
         a1 = work1 / (ms1_ * 1e-3) / 1e12
+        line["roofline"]["frac_alone"] = round(a1 / line["roofline"]["peak"], 4)     # next to `frac`: the kernel with the chip to itself
         line["roofline"]["alone"] = {"achieved": round(a1, 1), "frac": round(a1 / line["roofline"]["peak"], 4), "avg_launch_ms": round(ms1_ / n1, 4),
-                                     "launches": n1, "note": "same kernel, extra steps after the timed region with PCRL_WGRAD_STREAM=0 semantics"}
+                                     "launches": n1, "note": "same kernel, extra steps after the timed region on ONE stream (PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 semantics)"}
     if dist_info is not None:
         line["distributed"] = dist_info
         line["per_gpu_value"] = round(crops / world, 2)

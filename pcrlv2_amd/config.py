@@ -41,6 +41,13 @@ WGRAD_SIDE_STREAM_2D = _ws != "0"
 # results are bit-identical).
 FWD_BRANCH_STREAM = os.environ.get("PCRL_BRANCH_STREAM", "1") != "0"
 
+# Forward + backward of the SECOND global view on its own stream (train_3d.step_losses): the two global views share nothing but the
+# parameters, the packed-weight caches (built by the first view: guarded by an event) and the BatchNorm running statistics (updated in the
+# reference's order: the second view's update of a layer waits for the first view's, ops.order_rmw).  HBM-bound passes and launch gaps of one
+# view then run under the other's MFMA work.  Needs the weight-gradient side stream (the composed up-conv's accumulators are ordered there).
+# Same-box A/B 36.0 -> 34.67 ms (+3.8 %).  PCRL_VIEW_STREAMS=0: off (A/B switch; results are bit-identical).
+VIEW_STREAMS = os.environ.get("PCRL_VIEW_STREAMS", "1") != "0"
+
 # The global-average-pool branch of UpTransition (pcrlv2_model_3d.py:67) sends d_g[n][c] / S back to every voxel of a1: folded into the
 # two passes of ops.1's BatchNorm backward (pcrl_bn_act_bwd_*_rowadd) instead of materialised (pcrl_gap_bwd).  PCRL_FOLD_GAP_GRAD=0:
 # materialise (A/B switch; the folded form skips one bf16 rounding of the summed gradient).

@@ -110,12 +110,107 @@ def end_of_forward_join():
 
 
 def join_side_stream(device=None):
-    """The current stream waits for every weight gradient launched so far (no-op when none is outstanding)."""
+    """The current stream waits for everything launched so far on the side stream and on the second view's stream (no-op when nothing is
+    outstanding)."""
     for key, pending in list(_side_pending.items()):
         if pending and (device is None or (device.type, device.index) == key):
             dev = torch.device(key[0], key[1])
             torch.cuda.current_stream(dev).wait_stream(_side_streams[key])
             _side_pending[key] = False
+    if _views_active:
+        # the second view's autograd nodes run their backward on the view stream without passing through view_pass: while a step uses the
+        # stream every join waits for it (a wait on an idle stream costs nothing)
+        for key, vs in _view_streams.items():
+            if device is None or (device.type, device.index) == key:
+                cur = torch.cuda.current_stream(torch.device(key[0], key[1]))
+                if cur.cuda_stream != vs.cuda_stream:
+                    cur.wait_stream(vs)
+
+
+# ---- the second global view on its own stream (config.VIEW_STREAMS) ----
+_view_streams: dict = {}
+_views_active = False        # set while a step uses the view stream: the cross-stream guards below are then live
+_rmw_events: dict = {}
+
+
+def view_streams_on(device) -> bool:
+    return config.VIEW_STREAMS and config.WGRAD_SIDE_STREAM_3D and device.type == "cuda"
+
+
+def fork_views(device):
+    """Start of a step, BEFORE the first view is queued: the view stream waits for what the main stream holds now (the optimizer step)."""
+    global _views_active
+    if not view_streams_on(device):
+        return
+    key = (device.type, device.index)
+    vs = _view_streams.get(key)
+    if vs is None:
+        vs = _view_streams[key] = torch.cuda.Stream(device=device)
+    vs.wait_stream(torch.cuda.current_stream(device))
+    _views_active = True
+
+
+class view_pass:
+    """`with view_pass(device, x):` -- the forward queued inside runs on the view stream (its autograd nodes run their backward there)."""
+
+    def __init__(self, device, *operands):
+        self.device, self.operands = device, operands
+        self.active = _views_active and view_streams_on(device)
+
+    def __enter__(self):
+        if self.active:
+            key = (self.device.type, self.device.index)
+            vs = _view_streams[key]
+            for t in self.operands:
+                t.record_stream(vs)
+            self._cm = torch.cuda.stream(vs)
+            self._cm.__enter__()
+
+    def __exit__(self, *exc):
+        if self.active:
+            self._cm.__exit__(*exc)
+        return False
+
+
+def order_rmw(t):
+    """Before a read-modify-write of a tensor the passes share (BatchNorm running statistics): wait for the last update made on another stream."""
+    if not _views_active or t is None:
+        return
+    e = _rmw_events.get(t.data_ptr())
+    if e is not None:
+        cur = torch.cuda.current_stream(t.device)
+        if e[1] != cur.cuda_stream:
+            cur.wait_event(e[0])
+
+
+def mark_rmw(t):
+    if not _views_active or t is None:
+        return
+    cur = torch.cuda.current_stream(t.device)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _rmw_events[t.data_ptr()] = (ev, cur.cuda_stream)
+
+
+class _CacheGuard:
+    """Mixin of the packed-weight caches: built on one stream, read on another -> the reader waits for the build."""
+    _ev = None
+    _ev_stream = None
+
+    def _built(self, device):
+        if _views_active:
+            cur = torch.cuda.current_stream(device)
+            self._ev = torch.cuda.Event()
+            self._ev.record(cur)
+            self._ev_stream = cur.cuda_stream
+        else:
+            self._ev = None
+
+    def _reading(self, device):
+        if _views_active and self._ev is not None:
+            cur = torch.cuda.current_stream(device)
+            if cur.cuda_stream != self._ev_stream:
+                cur.wait_event(self._ev)
 
 
 def new_act(N, D, H, W, C, dtype, device) -> torch.Tensor:
@@ -185,8 +280,9 @@ _pass_index = 0
 
 
 def begin_step():
-    global _pass_index
+    global _pass_index, _views_active
     _pass_index = 0
+    _views_active = False
     drop_pending_composed()
 
 
@@ -197,7 +293,7 @@ def next_pass() -> int:
     return i
 
 
-class PackedWeights:
+class PackedWeights(_CacheGuard):
     """Packed (K-contiguous, activation-dtype) copies of one conv / transposed-conv weight."""
 
     def __init__(self, kind: str):
@@ -219,6 +315,9 @@ class PackedWeights:
                 Ci, Co = w.shape[0], w.shape[1]
                 L.call("pcrl_pack_convt_weight", w.detach(), self.fwd, self.dgrad, Ci, Co, dtype_code(dtype), s)
             self.key = key
+            self._built(w.device)
+        else:
+            self._reading(w.device)
         return self.fwd, self.dgrad
 
 
@@ -248,8 +347,10 @@ def bn_finalize(partial, rows, C, count, gamma, beta, running_mean, running_var,
         partial, rows = both, 1
     coef = _f32(4 * C, dev)
     mean, rstd, scale, shift = coef[:C], coef[C:2 * C], coef[2 * C:3 * C], coef[3 * C:]
+    order_rmw(running_mean)      # the passes of a step update the running statistics in the reference's order, whatever stream they run on
     lib().call("pcrl_bn_finalize", partial, rows, C, float(count), gamma, beta, running_mean, running_var,
                BN_MOMENTUM, BN_EPS, mean, rstd, scale, shift, stream_handle())
+    mark_rmw(running_mean)
     return mean, rstd, scale, shift
 
 
@@ -519,7 +620,7 @@ def convt_backward(x, dy, w, packed: PackedWeights, dtype, need_dx=True, db=None
 # ----------------------------------------------------------------------------------------------
 # UpTransition: ConvTranspose3d(k2,s2) -> conv1 of ops.0 as one operator on the coarse grid   (models/pcrlv2_model_3d.py:64; csrc/upconv_fused.hip)
 # ----------------------------------------------------------------------------------------------
-class ComposedUpConv:
+class ComposedUpConv(_CacheGuard):
     """Composed weights of (up_conv, ops.0.conv1), rebuilt when either parameter changed (once per optimizer step), and the
     accumulators of their gradients: every backward pass adds its gradient of the COMPOSED weights (and the border-class sums of dy0)
     here; the chain rule to the two reference parameters is linear in those, so it runs once per backward() call, from the engine's
@@ -555,6 +656,9 @@ class ComposedUpConv:
             L.call("pcrl_upconv_compose", w_up.detach(), b_up.detach(), w0.detach(), b0.detach(), self.wf, self.wd, self.w3f, self.wd3, self.bias_tab,
                    workspace(nb, dev), nb, Ci, Cm, Co, dtype_code(dtype), s)
             self.key = key
+            self._built(dev)
+        else:
+            self._reading(w_up.device)
         return self.wf, self.wd, self.bias_tab
 
     def accumulate(self, x, dy, geom, w_up, b_up, w0, dtype):
@@ -689,8 +793,10 @@ def bn1d_forward(x, gamma, beta, running_mean, running_var, relu: bool):
     rows, C = x.shape
     y = torch.empty_like(x)
     st = _f32(2 * C, x.device)
+    order_rmw(running_mean)
     lib().call("pcrl_bn1d_fwd", x, y, gamma.detach(), beta.detach(), running_mean, running_var, BN_MOMENTUM, BN_EPS,
                st[:C], st[C:], rows, C, int(relu), stream_handle())
+    mark_rmw(running_mean)
     return y, st[:C], st[C:]
 
 

@@ -117,9 +117,12 @@ def step_losses(model, batch, epoch, criterion, cosine):
     n = view1.size(0)
     target = _to_gpu(target)
     fused = getattr(cosine, "fusable", False) and FUSED_COS_LOSSES
+    view1, view2 = _to_gpu(view1), _to_gpu(view2)
+    _ops.fork_views(view1.device)  # config.VIEW_STREAMS: the second view's forward (and backward) on its own stream, next to the first's
     with _ops.deferred_join():     # the decoder stages' side branches (heads, deep-supervision maps) also run under the NEXT forward; joined on exit
-        out1, feats1, masks1 = model(_to_gpu(view1))
-        _out2, feats2, _ = model(_to_gpu(view2))                        # mask2 / its deep-supervision maps stay unused (Q3)
+        out1, feats1, masks1 = model(view1)
+        with _ops.view_pass(view2.device, view2):
+            _out2, feats2, _ = model(view2)                             # mask2 / its deep-supervision maps stay unused (Q3)
         if fused:
             _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
     if fused:
