@@ -8,6 +8,8 @@ Every function launches on torch's current stream and returns immediately.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import config
@@ -120,15 +122,16 @@ def join_side_stream(device=None):
     if _views_active:
         # the second view's autograd nodes run their backward on the view stream without passing through view_pass: while a step uses the
         # stream every join waits for it (a wait on an idle stream costs nothing)
-        for key, vs in _view_streams.items():
-            if device is None or (device.type, device.index) == key:
-                cur = torch.cuda.current_stream(torch.device(key[0], key[1]))
+        for (dt_, di_, _name), vs in _view_streams.items():
+            if device is None or (device.type, device.index) == (dt_, di_):
+                cur = torch.cuda.current_stream(torch.device(dt_, di_))
                 if cur.cuda_stream != vs.cuda_stream:
                     cur.wait_stream(vs)
 
 
 # ---- the second global view on its own stream (config.VIEW_STREAMS) ----
 _view_streams: dict = {}
+VIEW_STREAM_NAMES = tuple(n for n in os.environ.get("PCRL_VIEW_STREAM_NAMES", "view2").split(",") if n)   # "view2,local": the local views' pass too (experiment)
 _views_active = False        # set while a step uses the view stream: the cross-stream guards below are then live
 _rmw_events: dict = {}
 
@@ -142,24 +145,25 @@ def fork_views(device):
     global _views_active
     if not view_streams_on(device):
         return
-    key = (device.type, device.index)
-    vs = _view_streams.get(key)
-    if vs is None:
-        vs = _view_streams[key] = torch.cuda.Stream(device=device)
-    vs.wait_stream(torch.cuda.current_stream(device))
+    for name in VIEW_STREAM_NAMES:
+        key = (device.type, device.index, name)
+        vs = _view_streams.get(key)
+        if vs is None:
+            vs = _view_streams[key] = torch.cuda.Stream(device=device)
+        vs.wait_stream(torch.cuda.current_stream(device))
     _views_active = True
 
 
 class view_pass:
-    """`with view_pass(device, x):` -- the forward queued inside runs on the view stream (its autograd nodes run their backward there)."""
+    """`with view_pass(device, x, name="view2"):` -- the forward queued inside runs on that view stream (its autograd nodes run their backward there)."""
 
-    def __init__(self, device, *operands):
-        self.device, self.operands = device, operands
-        self.active = _views_active and view_streams_on(device)
+    def __init__(self, device, *operands, name="view2"):
+        self.device, self.operands, self.name = device, operands, name
+        self.active = _views_active and view_streams_on(device) and name in VIEW_STREAM_NAMES
 
     def __enter__(self):
         if self.active:
-            key = (self.device.type, self.device.index)
+            key = (self.device.type, self.device.index, self.name)
             vs = _view_streams[key]
             for t in self.operands:
                 t.record_stream(vs)

@@ -124,7 +124,9 @@ def step_losses(model, batch, epoch, criterion, cosine):
         with _ops.view_pass(view2.device, view2):
             _out2, feats2, _ = model(view2)                             # mask2 / its deep-supervision maps stay unused (Q3)
         if fused:
-            _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
+            loc = torch.cat([_to_gpu(v) for v in local_views], dim=0)
+            with _ops.view_pass(loc.device, loc, name="local"):
+                _, feats_loc, _ = model(loc, local=True)
     if fused:
         l_global, l_local, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
         l_restore = criterion(out1, target)
