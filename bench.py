@@ -9,9 +9,11 @@
              FLOPs (2*M*27*Ci*Co per launch) / launch duration measured with HIP events on the launch stream, against
              the dense bf16 MFMA peak (2.5 PFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md).  The step runs on three streams (the
              second global view; weight gradients and the decoder's side branches), so in the timed region this kernel SHARES the chip --
-             two convolutions side by side each see about half of it -- and roofline.frac is its share (it agrees with the rocprofv3
-             summary of the same command, profiles/*_overlap_*); roofline.alone is the same kernel over 10 extra one-stream steps: its
-             rate with the chip to itself, the kernel-quality figure (profiles/*_kernel_stats.txt is the one-stream profile).
+             two convolutions side by side each see about half of it, and how much depends on how the streams line up.  The roofline figure
+             is therefore taken over 10 extra ONE-STREAM steps run right after the timed region (same process, model, batch): the kernel's
+             rate with the chip to itself, which the one-stream rocprofv3 summary (profiles/*_kernel_stats.txt) reproduces to < 1 %; its
+             per-launch time inside the timed region is kept as roofline.in_timed_region (profiles/*_overlap_* is the three-stream trace).
+             `value` is always the three-stream timed region.  With --no-alone or N > 1 the roofline is the timed region's.
   cpu_baseline : the CPU oracle (a port of the reference step, oracle/pcrlv2_oracle.py) timed on this box's host cores on
              a bounded sample (b=8, <= 3 steps or ~35 s), rank 0, N=1 only.
 
@@ -303,21 +305,30 @@ def main():
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3,
                      "unit": "TFLOP/s", "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
                      "avg_launch_ms": round(ms / n, 4), "launches": n, "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC)",
-                     "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(work / n),
-                     "concurrent": "kernels of three streams share the chip in the timed region (second view, weight gradients + side branches): frac is the kernel's share, roofline.alone its rate with the chip to itself" if alone is not None else None},
+                     "traffic_source": traffic_src, "algorithmic_flops_per_launch": round(work / n)},
         "step_mfma_frac": round(flop_per_crop * args.b * args.steps / elapsed / 1e12 / PEAK_BF16_TFLOPS, 4) if flop_per_crop else None,
-        "kernels": detail, "final_loss": round(loss, 5),
+        "kernels": detail, "kernels_note": "per-launch times inside the timed region, where kernels of three streams share the chip",
+        "final_loss": round(loss, 5),
         "diag": {"gpu_ms_per_step": per_step,
                  "device_mallocs_in_timed_region": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
                  "alloc_retries": ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
                  "reserved_GB": round(ms1.get("reserved_bytes.all.peak", 0) / 2**30, 1)},
     }
     if alone is not None and dom in alone.results():
+        # The roofline figure of the dominant kernel is its rate with the chip to itself (the one-stream steps): reproducible, and what the
+        # one-stream rocprofv3 summary under profiles/ shows (244.3 vs 244.8 us per launch on one box).  Its per-launch time inside the
+        # three-stream timed region is kept beside it: there it shares the chip, and how much depends on how the streams happen to line up
+        # (the overlapped rocprofv3 run, whose instrumentation slows the launches, saw 376 us where the timed region saw 471).
         n1, ms1_, work1 = alone.results()[dom]
         a1 = work1 / (ms1_ * 1e-3) / 1e12
-        line["roofline"]["frac_alone"] = round(a1 / line["roofline"]["peak"], 4)     # next to `frac`: the kernel with the chip to itself
-        line["roofline"]["alone"] = {"achieved": round(a1, 1), "frac": round(a1 / line["roofline"]["peak"], 4), "avg_launch_ms": round(ms1_ / n1, 4),
-                                     "launches": n1, "note": "same kernel, extra steps after the timed region on ONE stream (PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 semantics)"}
+        rf = line["roofline"]
+        rf["in_timed_region"] = {"achieved": rf["achieved"], "frac": rf["frac"], "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"],
+                                 "note": "three streams share the chip (second view; weight gradients + side branches): the kernel's share, not its rate"}
+        rf.update({"achieved": round(a1, 1), "frac": round(a1 / rf["peak"], 4), "avg_launch_ms": round(ms1_ / n1, 4), "launches": n1,
+                   "measured": "HIP events over %d one-stream steps run right after the timed region (same process, model and batch; "
+                               "PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 PCRL_VIEW_STREAMS=0 semantics)" % min(10, args.steps)})
+    else:
+        line["roofline"]["measured"] = "HIP events over the timed region"
     if dist_info is not None:
         line["distributed"] = dist_info
         line["per_gpu_value"] = round(crops / world, 2)
