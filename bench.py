@@ -31,6 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # up to five streams per rank (pcrlv2_amd/__init__.py)
 
 import torch  # noqa: E402
 
