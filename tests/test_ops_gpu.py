@@ -599,6 +599,33 @@ def test_heads_bn1d_linear(rows, C):
         ops.bn1d_forward(xd[:1].contiguous(), wd[0].contiguous(), wd[1].contiguous(), None, None, False)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ratio", [10.0, 100.0])
+def test_batch_statistics_on_badly_centred_channels(ratio, dt):
+    """Training-mode BatchNorm statistics come from per-tile (sum, sum of squares) of the float32 accumulators, reduced in float64 -- the
+    variance is E[y^2] - mean^2, which cancels when |mean| >> std (aten uses Welford).  Measured here on a convolution whose
+    bias puts every channel's mean at `ratio` standard deviations: the per-tile float32 rounding is unbiased and averages out over the tiles
+    (512-voxel bricks / 128-row tiles), so rstd stays within 2e-5 (ratio 10; measured 3e-6) / 2e-3 (ratio 100; measured 3.5e-4) of the float64 value -- far inside what the
+    activations' own rounding moves -- instead of the worst case (mean/std)^2 * 1e-7 per tile times no averaging."""
+    N, D, H, W, Ci, Co = 2, 8, 16, 32, 32, 64
+    x = rnd(N, Ci, D, H, W, seed=1)
+    w = rnd(Co, Ci, 3, 3, 3, seed=2, scale=0.05)
+    y0 = F.conv3d(q(x, dt), q(w, dt), None, padding=1)
+    std = y0.std(dim=(0, 2, 3, 4))
+    bias = ratio * std * (1 + 0.1 * rnd(Co, seed=3))
+    y = y0 + bias.view(1, -1, 1, 1, 1)
+    mean_ref, var_ref = y.mean(dim=(0, 2, 3, 4)), y.var(dim=(0, 2, 3, 4), unbiased=False)
+    g, b = torch.ones(Co), torch.zeros(Co)
+    rm, rv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+    packed = ops.PackedWeights("conv3")
+    a, sv = ops.luconv_forward(ops.to_act(x.to(DEV), dt), w.float().to(DEV), bias.float().to(DEV), g.to(DEV), b.to(DEV), rm, rv, packed, 0, dt)
+    rstd_ref = 1.0 / torch.sqrt(var_ref + 1e-5)
+    e_mean = float(((back(sv.mean) - mean_ref).abs() / std).max())
+    e_rstd = float(((back(sv.rstd) - rstd_ref).abs() / rstd_ref).max())
+    print(f"  mean/std = {ratio:g} [{dt}]: max |mean - ref| / std = {e_mean:.2e}, max relative rstd error = {e_rstd:.2e}")
+    assert e_mean < 1e-4 and e_rstd < (2e-5 if ratio <= 10 else 2e-3)
+
+
 @pytest.mark.parametrize("rows,Cin,Cout", [(32, 64, 128), (32, 512, 256), (192, 256, 512), (192, 128, 64), (5, 36, 10), (33, 260, 7), (7, 30, 12)])
 def test_linear_products(rows, Cin, Cout):
     """pcrl_linear_fwd / _bwd (nn.Linear of the predictor heads, pcrlv2_model_3d.py:57-58): y = x W^T + b, dx = dy W, dW = dy^T x, db = colsum(dy)
