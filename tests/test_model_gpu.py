@@ -385,6 +385,38 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical(dt, switch):
         assert torch.equal(ra[k], rb[k]), k
 
 
+def test_three_stream_step_is_bit_identical_at_the_bench_size():
+    """The same check at BASELINE's size (b = 32, 64x64x32 + 6 local views: other launch timing, every kernel at full occupancy): four steps
+    with the second view's stream, the side branches and the side-stream weight gradients all on, twice, against the one-stream run --
+    parameters, momentum buffers and running statistics bit for bit (tools/stream_stress.py is the longer form)."""
+    from bench import synthetic_batch
+    from pcrlv2_amd import config
+    batch = synthetic_batch(32, (64, 64, 32), 16, torch.device(DEV), 7)
+    keep = (config.WGRAD_SIDE_STREAM_3D, config.FWD_BRANCH_STREAM, config.VIEW_STREAMS)
+
+    def run(on):
+        config.WGRAD_SIDE_STREAM_3D = config.FWD_BRANCH_STREAM = config.VIEW_STREAMS = on
+        torch.manual_seed(0)
+        random.seed(0)
+        model = PCRLv23d().to(DEV).train().set_compute_dtype(torch.bfloat16)
+        opt = FusedSGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+        for _ in range(4):
+            out = train_step(model, opt, batch, 0, MSELoss(), CosineSimilarityMean(), guard=False)
+        torch.cuda.synchronize()
+        rs = torch.cat([v.flatten().float() for k, v in sorted(model.state_dict().items()) if "running" in k])
+        return [float(o) for o in out], opt.flat_p.clone(), opt.flat_buf.clone(), rs
+
+    try:
+        ref = run(False)
+        for _ in range(2):
+            got = run(True)
+            assert got[0] == ref[0], (got[0], ref[0])
+            for a, b, what in zip(got[1:], ref[1:], ("parameters", "momentum buffers", "running statistics")):
+                assert torch.equal(a, b), what
+    finally:
+        config.WGRAD_SIDE_STREAM_3D, config.FWD_BRANCH_STREAM, config.VIEW_STREAMS = keep
+
+
 def test_optional_groupnorm_silu_mode_vs_torch_definition():
     """PCRLv23d(norm='gn', act='silu') -- an OPTIONAL, NON-REFERENCE mode (BASELINE.json's north_star names GroupNorm + SiLU; the
     reference's own norm='gn' crashes at construction and it rejects 'silu').  Checked against the oracle's torch
