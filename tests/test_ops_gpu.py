@@ -599,6 +599,45 @@ def test_heads_bn1d_linear(rows, C):
         ops.bn1d_forward(xd[:1].contiguous(), wd[0].contiguous(), wd[1].contiguous(), None, None, False)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 16, 32, 64, 64), (1, 4, 8, 16, 32, 96), (3, 4, 16, 8, 64, 64), (1, 16, 16, 8, 128, 32), (2, 8, 16, 24, 32, 96),
+                                   (2, 8, 8, 4, 64, 128), (2, 4, 8, 8, 64, 64)])
+def test_brick_convolution_kernels_equal_the_gather_kernel_to_an_ulp(shape):
+    """bf16 3x3x3 convolution: the wide-brick kernel (bricks along (D, H, W) and along (D, W, H)) and the 4x8x8-brick kernel against the gather
+    kernel (`pcrl_debug_set_conv_impl(1)`, the one the exact-float32 mode pins against float64) on the same operands -- the same bf16 products
+    summed in float32 in another order: outputs differ by at most one bf16 ulp on a fraction of a percent of the elements, the float32
+    statistics rows agree to 1e-5.  A wrong tap or border anywhere in a brick kernel is an O(1) difference here."""
+    N, D, H, W, Ci, Co = shape
+    dt = torch.bfloat16
+    L, s = lib(), stream_handle()
+    g = torch.Generator(device=DEV).manual_seed(9)
+    x = ops.new_act(N, D, H, W, Ci, dt, DEV)
+    x.normal_(generator=g)
+    w = torch.randn(Co, Ci, 3, 3, 3, device=DEV, generator=g) * 0.05
+    b = torch.randn(Co, device=DEV, generator=g) * 0.2
+    wf, _ = ops.PackedWeights("conv3").get(w, dt)
+    outs, kinds = [], []
+    try:
+        for impl in (0, 1):
+            L.debug_set_conv_impl(impl)
+            code = dtype_code(dt)
+            kinds.append(L.call("pcrl_conv3d_k3_fwd_kernel", N, D, H, W, Ci, Co, code))
+            rows = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Ci, Co, code)
+            y = ops.new_act(N, D, H, W, Co, dt, DEV)
+            part = torch.zeros(rows, Co, 2, device=DEV)
+            nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Ci, Co, code)
+            L.call("pcrl_conv3d_k3_fwd_ws", x, wf, b, y, part, ops.workspace(nb, torch.device(DEV)) if nb else None, nb, N, D, H, W, Ci, Co, code, s)
+            outs.append((y.float(), part.double().sum(0)))
+    finally:
+        L.debug_set_conv_impl(0)
+    assert kinds[0] in (1, 2) and kinds[1] == 0, kinds
+    (ya, pa), (yb, pb) = outs
+    d = (ya - yb).abs()
+    assert float((d > 0).float().mean()) < 5e-3 and float((d / yb.abs().clamp_min(1e-2)).max()) <= 2.0 ** -7 + 1e-6, (kinds, float(d.max()))
+    # (sum, sum of squares) per channel: float32 partial sums in another order -- 1e-6 of sum|y| <= sqrt(count * sum y^2), resp. of sum y^2
+    s2 = pb[:, 1]
+    assert bool(((pa[:, 0] - pb[:, 0]).abs() <= 1e-6 * torch.sqrt(N * D * H * W * s2)).all()) and bool(((pa[:, 1] - s2).abs() <= 1e-6 * s2).all())
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ratio", [10.0, 100.0])
 def test_batch_statistics_on_badly_centred_channels(ratio, dt):

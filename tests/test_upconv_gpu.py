@@ -144,3 +144,110 @@ def test_composed_stage_head_through_ops(dt):
     close(dg, pr[4].grad, tol, "dgamma")
     close(dbe, pr[5].grad, tol, "dbeta")
     assert float(dbc.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("geom", [(32, 32, 32, 16, 128, 128, 64), (32, 16, 16, 8, 256, 256, 128), (32, 8, 8, 4, 512, 512, 256)])
+def test_full_size_composed_operator_adjoint_identities_bf16(geom):
+    """BASELINE C2 sizes (b = 32: up_tr64 / up_tr128 / up_tr256 of a global view), bf16 -- no CPU reference is affordable there, but the
+    composed operator's four kernels must be mutually adjoint.  y = A(w_up, w0) x + B(b_up, w0) + b0 is linear in x, in w0 and in
+    (w_up, b_up) jointly, so with dy arbitrary
+        <y - y|x=0, dy> == <x, dgrad(dy)>,   <y - b0, dy> == <w0, dw0> == <w_up, dw_up> + <b_up, db_up>
+    up to the bf16 rounding of y, dx and of the composed weights (a size-independent property; the wide-brick instantiations -- along
+    (D, H, W) and (D, W, H) -- and the gather kernels each serve one of the three shapes)."""
+    N, D, H, W, Ci, Cm, Co = geom
+    dt = torch.bfloat16
+    L, s = lib(), stream_handle()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = ops.new_act(N, D, H, W, Ci, dt, DEV)
+    dy = ops.new_act(N, 2 * D, 2 * H, 2 * W, Co, dt, DEV)
+    x.normal_(generator=g)
+    dy.normal_(generator=g)
+    w_up = torch.randn(Ci, Cm, 2, 2, 2, device=DEV, generator=g) * 0.05
+    b_up = torch.randn(Cm, device=DEV, generator=g) * 0.5
+    w0 = torch.randn(Co, Cm, 3, 3, 3, device=DEV, generator=g) * 0.03
+    b0 = torch.zeros(Co, device=DEV)
+    comp = ops.ComposedUpConv()
+    wf, wd, tab = comp.get(w_up, b_up, w0, b0, dt, geom=(N, D, H, W))
+
+    def fwd(xin):
+        y = ops.new_act(N, 2 * D, 2 * H, 2 * W, Co, dt, DEV)
+        L.call("pcrl_upconv_fwd", xin, wf, comp.w3f, tab, y, None, N, D, H, W, Ci, Co, dtype_code(dt), s)
+        return y
+    y = fwd(x)
+    y_bias = fwd(torch.zeros_like(x))                      # B(b_up, w0): the bias table over the border classes
+    # dy correlated with y (cosine ~0.9): with an independent random dy the inner products are ~1e-4 of |y||dy| and the identities would hold
+    # to the tolerance below whatever the kernels did
+    dy = ((y.float() / y.float().std()) + 0.5 * dy.float()).to(dt)
+    dx = ops.new_act(N, D, H, W, Ci, dt, DEV)
+    L.call("pcrl_upconv_dgrad", dy, wd, comp.wd3, dx, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    dwu, dbu, dw0 = torch.empty_like(w_up), torch.empty_like(b_up), torch.empty_like(w0)
+    nb = L.call("pcrl_upconv_wgrad_ws_bytes", N, D, H, W, Ci, Cm, Co, dtype_code(dt))
+    L.call("pcrl_upconv_wgrad", x, dy, w_up, b_up, w0, dwu, dbu, dw0, ops.workspace(nb, torch.device(DEV)), nb, N, D, H, W, Ci, Cm, Co, dtype_code(dt), s)
+    dyd = dy.double()
+    a_lin = float(((y.double() - y_bias.double()) * dyd).sum())
+    a_all = float((y.double() * dyd).sum())
+    b_x = float((x.double() * dx.double()).sum())
+    c_w0 = float((w0.double() * dw0.double()).sum())
+    c_up = float((w_up.double() * dwu.double()).sum() + (b_up.double() * dbu.double()).sum())
+    scale = float(y.double().norm() * dyd.norm())
+    print(f"  composed adjoint {geom}: <Ax,dy>={a_lin:.6e} <x,dx>={b_x:.6e} | <y,dy>={a_all:.6e} <w0,dw0>={c_w0:.6e} <w_up,dw_up>+<b_up,db_up>={c_up:.6e} "
+          f"(|y||dy|={scale:.3e}: {abs(a_lin - b_x) / scale:.1e} {abs(a_all - c_w0) / scale:.1e} {abs(a_all - c_up) / scale:.1e})")
+    assert abs(a_all) > 0.5 * scale
+    assert abs(a_lin - b_x) < 5e-4 * scale
+    assert abs(a_all - c_w0) < 2e-3 * scale and abs(a_all - c_up) < 2e-3 * scale
+
+
+@pytest.mark.parametrize("geom", [(2, 4, 8, 16, 64, 64, 64), (3, 8, 16, 32, 128, 128, 64), (2, 4, 16, 8, 64, 64, 64), (1, 8, 32, 8, 128, 64, 128),
+                                  (2, 4, 32, 24, 64, 64, 32), (1, 4, 8, 16, 64, 64, 256)])
+def test_brick_instantiations_equal_the_gather_kernels_to_an_ulp(geom):
+    """bf16: the composed operator's wide-brick instantiations (forward <64, 1>, data gradient <64, 2>, along (D, H, W) and (D, W, H)) and the
+    brick weight-gradient kernel against the GATHER kernels on the same operands (`pcrl_debug_set_conv_impl(1)` / `_wgrad_impl(1)`).  Both
+    sides add the same bf16 products in float32, in another order: after the output rounding at most a fraction of a percent of the elements
+    differ, by one bf16 ulp; the float32 results (statistics rows, gradient of the composed weights) agree to 1e-5.  The gather kernels are the
+    ones the exact-float32 mode pins to 1e-4 against float64 above -- a wrong tap, phase, parity or border class in a brick instantiation
+    would be an O(1) difference here, which the 2e-2 bf16 tolerance of the float64 comparison could hide on a thin border."""
+    N, D, H, W, Ci, Cm, Co = geom
+    dt = torch.bfloat16
+    L, s = lib(), stream_handle()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = ops.new_act(N, D, H, W, Ci, dt, DEV)
+    dy = ops.new_act(N, 2 * D, 2 * H, 2 * W, Co, dt, DEV)
+    x.normal_(generator=g)
+    dy.normal_(generator=g)
+    w_up = torch.randn(Ci, Cm, 2, 2, 2, device=DEV, generator=g) * 0.05
+    b_up = torch.randn(Cm, device=DEV, generator=g) * 0.5
+    w0 = torch.randn(Co, Cm, 3, 3, 3, device=DEV, generator=g) * 0.03
+    b0 = torch.randn(Co, device=DEV, generator=g) * 0.1
+    comp = ops.ComposedUpConv()
+    wf, wd, tab = comp.get(w_up, b_up, w0, b0, dt, geom=(N, D, H, W))
+    outs, used = [], []
+    try:
+        for impl in (0, 1):
+            L.debug_set_conv_impl(impl)
+            L.debug_set_wgrad_impl(impl)
+            code = dtype_code(dt)
+            used.append((L.call("pcrl_upconv_fwd_uses_brick", N, D, H, W, Ci, Co, code), L.call("pcrl_upconv_dgrad_uses_brick", N, D, H, W, Ci, Co, code),
+                         L.call("pcrl_upconv_wgrad_uses_brick", N, D, H, W, Ci, Co, code)))
+            rows = L.call("pcrl_upconv_stats_rows", N, D, H, W, Ci, Co, code)
+            y = ops.new_act(N, 2 * D, 2 * H, 2 * W, Co, dt, DEV)
+            part = torch.zeros(rows, Co, 2, device=DEV)
+            L.call("pcrl_upconv_fwd", x, wf, comp.w3f, tab, y, part, N, D, H, W, Ci, Co, code, s)
+            dx = ops.new_act(N, D, H, W, Ci, dt, DEV)
+            L.call("pcrl_upconv_dgrad", dy, wd, comp.wd3, dx, N, D, H, W, Ci, Co, code, s)
+            dweff, box = torch.empty(64 * Ci * Co, device=DEV), torch.empty(27 * Co, device=DEV)
+            nb = L.call("pcrl_upconv_wgrad_accum_ws_bytes", N, D, H, W, Ci, Co, code)
+            L.call("pcrl_upconv_wgrad_accum", x, dy, dweff, box, 1, ops.workspace(nb, torch.device(DEV)), nb, N, D, H, W, Ci, Co, code, s)
+            outs.append((y.float(), dx.float(), part.double().sum(0), dweff.double(), box.double()))
+    finally:
+        L.debug_set_conv_impl(0)
+        L.debug_set_wgrad_impl(0)
+    assert used[1] == (0, 0, 0) and any(used[0]), used      # every shape here runs at least one brick kernel by default
+    (ya, dxa, pa, wa, ba), (yb, dxb, pb, wb, bb) = outs
+    for name, a, b in (("y0", ya, yb), ("dx", dxa, dxb)):
+        d = (a - b).abs()
+        frac = float((d > 0).float().mean())
+        ulp = float((d / b.abs().clamp_min(1e-2)).max())
+        assert frac < 5e-3 and ulp <= 2.0 ** -7 + 1e-6, (name, used, frac, ulp)
+    assert float(((pa - pb).abs() / pb.abs().clamp_min(1e-3)).max()) < 1e-5
+    assert float((wa - wb).abs().max()) < 1e-5 * float(wb.abs().max())
+    assert float((ba - bb).abs().max()) < 1e-5 * max(float(bb.abs().max()), 1e-3)
