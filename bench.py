@@ -13,7 +13,7 @@
              is therefore taken over 10 extra ONE-STREAM steps run right after the timed region (same process, model, batch): the kernel's
              rate with the chip to itself, which the one-stream rocprofv3 summary (profiles/*_kernel_stats.txt) reproduces to < 1 %; its
              per-launch time inside the timed region is kept as roofline.in_timed_region (profiles/*_overlap_* is the three-stream trace).
-             `value` is always the three-stream timed region.  With --no-alone or N > 1 the roofline is the timed region's.
+             `value` is always the three-stream timed region.  With --no-alone the roofline is the timed region's.
   cpu_baseline : the CPU oracle (a port of the reference step, oracle/pcrlv2_oracle.py) timed on this box's host cores on
              a bounded sample (b=8, <= 3 steps or ~35 s), rank 0, N=1 only.
 
@@ -251,11 +251,11 @@ def main():
 
     # The step runs on three streams (config.py: the second global view on its own stream, weight gradients and the decoder's side branches on
     # a side stream), so the per-launch times above are times of kernels SHARING the chip -- two convolutions side by side each see about half
-    # of it.  A few extra steps on one stream (after the timed region, one GPU only) give the dominant kernel's time with the chip to itself:
-    # reported as roofline.alone (the kernel-quality figure; the one-stream rocprofv3 summary agrees with it), never as `value`.
+    # of it.  A few extra steps on one stream (after the timed region, on every rank) give the dominant kernel's time with the chip to itself:
+    # the roofline figure (the one-stream rocprofv3 summary agrees with it), never `value`; the timed region's share stays in roofline.in_timed_region.
     from pcrlv2_amd import config as _cfg
     alone = None
-    if world == 1 and _cfg.WGRAD_SIDE_STREAM_3D and not args.no_alone:
+    if _cfg.WGRAD_SIDE_STREAM_3D and not args.no_alone:      # every rank runs them (the optimizer step holds a collective)
         _cfg.WGRAD_SIDE_STREAM_3D = False     # also turns the second view's stream off (it needs the side stream)
         _branch, _cfg.FWD_BRANCH_STREAM = _cfg.FWD_BRANCH_STREAM, False
         for _ in range(2):
