@@ -22,6 +22,7 @@ Launch: python bench.py [--gpus 1 --steps K --warmup W]   or, for N>1,
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import collections
 import json
 import os
 import random
@@ -39,6 +40,9 @@ PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md "Peak BF16/FP
 FLOP_PER_CROP = 1.2707e12   # fwd+bwd of one crop (2 global + 6 local views), SURVEY 8(d) [torch flop counter on the reference]
 
 
+ALG_BYTES = collections.Counter()   # key -> algorithmic HBM bytes of the launches seen (input + output + packed weights, each once)
+
+
 def conv_key(name, args):
     """Classify a pcrl_conv3d_k3_fwd launch the way the library's dispatcher does (conv_igemm.hip / conv_brick.hip) and
     return its algorithmic FLOPs (2 * voxels * 27 * Ci * Co)."""
@@ -53,6 +57,7 @@ def conv_key(name, args):
     else:
         bn = 128 if Co % 128 == 0 else (64 if Co % 64 == 0 else 32)
         key = "igemm_kernel<%s,%d,conv3>(+split-K finish)" % ("bf16" if dt == 1 else "f32", bn)
+    ALG_BYTES[key] += 2.0 * (N * D * H * W * (Ci + Co) + 27 * Ci * Co)
     return key, 2.0 * N * D * H * W * 27 * Ci * Co
 
 
@@ -230,6 +235,7 @@ def main():
     if os.environ.get("PCRL_BENCH_NOGC", "0") == "1":
         gc.disable()
     barrier()
+    ALG_BYTES.clear()
     L.profiler = prof
     ms0 = torch.cuda.memory_stats(dev)
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -261,6 +267,7 @@ def main():
         for _ in range(2):
             train_step(model, opt, batch, 0, crit, cosine, guard=False)
         alone = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_upconv_fwd"}, keyfn)
+        ALG_BYTES.clear()
         torch.cuda.synchronize()
         L.profiler = alone
         for _ in range(min(10, args.steps)):
@@ -330,6 +337,11 @@ def main():
                                "PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 PCRL_VIEW_STREAMS=0 semantics)" % min(10, args.steps)})
     else:
         line["roofline"]["measured"] = "HIP events over the timed region"
+    if ALG_BYTES.get(dom) and line["roofline"]["launches"]:
+        ab = ALG_BYTES[dom] / line["roofline"]["launches"]
+        line["roofline"]["algorithmic_bytes_per_launch"] = round(ab)
+        if line["roofline"]["traffic"]:
+            line["roofline"]["traffic_over_algorithmic"] = round(line["roofline"]["traffic"] / ab, 3)
     if dist_info is not None:
         line["distributed"] = dist_info
         line["per_gpu_value"] = round(crops / world, 2)
