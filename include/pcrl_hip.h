@@ -332,8 +332,10 @@ int pcrl_relu_mask_bwd(const void* da, const void* a, void* g, int64_t n, int dt
  *   wgrad_accum / wgrad_finish: the same in two stages, both linear in their intermediates -- `accum` (once per backward pass) adds the pass's
  *             gradient of the composed weights and border-class sums of dy0 (box_acc, float32 [27][Co]) to caller-owned buffers; `finish` runs the
  *             chain rule to dw_up / db_up / dw0 once after the last pass.  dweff_acc: float32 [Co][Ci][64] (the gradient of the composed weights,
- *             index p*8+q; from the brick weight-gradient kernel where it tiles the coarse grid, else from the gather kernel); first != 0: store
- *             instead of add. */
+ *             index p*8+q; from the brick weight-gradient kernel where it tiles the coarse grid, else from the gather kernel); flags bit 0: store
+ *             instead of add (first pass); bit 1: the caller states that dy0 sums to ZERO over all voxels per channel -- true when it is the output of
+ *             the training-mode BatchNorm backward that follows conv1 in the reference -- so the border-class sums read only the border voxels and the
+ *             interior class is minus the rest (exact arithmetic's value, free of the rounding of dy0). */
 size_t pcrl_upconv_compose_ws_bytes(int Ci, int Cm, int Co, int dtype);
 int pcrl_upconv_compose(const float* w_up, const float* b_up, const float* w0, const float* b0, void* wf, void* wd, void* w3f, void* wd3,
                         float* bias_tab, void* ws, size_t ws_bytes, int Ci, int Cm, int Co, int dtype, pcrl_stream_t stream);
@@ -346,7 +348,7 @@ int pcrl_upconv_dgrad(const void* dy0, const void* wd, const void* wd3, void* dx
                       pcrl_stream_t stream);
 int64_t pcrl_upconv_wgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   /* informational: which kernel a shape gets */
 size_t pcrl_upconv_wgrad_accum_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype);
-int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* box_acc, int first, void* ws, size_t ws_bytes, int N, int D,
+int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* box_acc, int flags, void* ws, size_t ws_bytes, int N, int D,
                             int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
 size_t pcrl_upconv_wgrad_finish_ws_bytes(int Ci, int Cm, int Co, int dtype);
 int pcrl_upconv_wgrad_finish(const float* dweff_acc, const float* box_acc, const float* w_up, const float* b_up, const float* w0, float* dw_up,

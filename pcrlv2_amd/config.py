@@ -41,6 +41,11 @@ WGRAD_SIDE_STREAM_2D = _ws != "0"
 # results are bit-identical).
 FWD_BRANCH_STREAM = os.environ.get("PCRL_BRANCH_STREAM", "1") != "0"
 
+# Composed up-conv, bias gradients: the border-class sums of dy0 (the gradient entering conv1 = the output of its training-mode BatchNorm's
+# backward, whose per-channel sum over the batch is zero in exact arithmetic) read only the border voxels; the interior class is minus the
+# rest (pcrl_upconv_wgrad_accum flags bit 1).  PCRL_UPC_ZERO_SUM=0: sum every voxel (A/B switch; differs by the rounding of dy0).
+UPC_ZERO_SUM = os.environ.get("PCRL_UPC_ZERO_SUM", "1") != "0"
+
 # Forward + backward of the SECOND global view on its own stream (train_3d.step_losses): the two global views share nothing but the
 # parameters, the packed-weight caches (built by the first view: guarded by an event) and the BatchNorm running statistics (updated in the
 # reference's order: the second view's update of a layer waits for the first view's, ops.order_rmw).  HBM-bound passes and launch gaps of one

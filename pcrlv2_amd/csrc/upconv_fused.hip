@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) upc_chain_unpack_kernel(const float* __re
 // a row the columns w = 0 / inside / FW - 1 -- so the streaming loop is one 16-byte load and VEC adds (a per-element class select over
 // nine accumulators made the first version VALU-bound: 183 us for 268 MB).  part[plane][9][C], k = h class * 3 + w class.
 template <typename T>
-__global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict__ dy, float* __restrict__ part, int FH, int FW, int C) {
+__global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict__ dy, float* __restrict__ part, int FD, int FH, int FW, int C, bool zsum) {
   constexpr int VEC = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [slots][C]
   const int tid = threadIdx.x, nvec = C / VEC, cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
@@ -233,9 +233,27 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
       }                                                                                         \
     }                                                                                           \
   }
-  ROWS(0, 1, 0)
-  ROWS(1, FH - 1, 1)
-  ROWS(FH - 1, FH, 2)
+  // zsum: dy sums to zero over all voxels per channel (it is the output of a training-mode BatchNorm backward over exactly these voxels), so the
+  // fully interior class is minus the sum of the other 26 (upc_box_kernel) and a plane inside the volume only contributes its border: two
+  // rows and two columns instead of FH x FW voxels (9 % at 64 x 32) -- and the result is the exact-arithmetic one, free of the rounding of dy.
+  const int fd = blockIdx.x % FD;
+  if (zsum && fd > 0 && fd < FD - 1) {
+    ROWS(0, 1, 0)
+    ROWS(FH - 1, FH, 2)
+    for (int h = 1 + slot; h < FH - 1; h += nslots) {
+      const T* row = base + (int64_t)h * FW * C;
+      const Vec16<T> v0 = ld16(row), v1 = ld16(row + (int64_t)(FW - 1) * C);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        acc[3][j] += to_f(v0.v[j]);
+        acc[5][j] += to_f(v1.v[j]);
+      }
+    }
+  } else {
+    ROWS(0, 1, 0)
+    ROWS(1, FH - 1, 1)
+    ROWS(FH - 1, FH, 2)
+  }
 #undef ROWS
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
@@ -276,13 +294,19 @@ __global__ void __launch_bounds__(1024) upc_class_total_kernel(const float* __re
   }
 }
 // box[t][co] = sum over the classes for which tap t is inside the grid of S[cls][co]
-__global__ void __launch_bounds__(256) upc_box_kernel(const float* __restrict__ S, float* __restrict__ box, int Co, bool accumulate) {
+__global__ void __launch_bounds__(256) upc_box_kernel(const float* __restrict__ S, float* __restrict__ box, int Co, bool accumulate, bool zsum) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= 27 * Co) return;
   const int co = i % Co, t = i / Co;
+  double inner = (double)S[13 * Co + co];
+  if (zsum) {   // the fully interior class from the zero total (its entry of S is zero then: the planes inside the volume skipped it)
+    inner = 0.0;
+    for (int cls = 0; cls < 27; ++cls)
+      if (cls != 13) inner -= (double)S[cls * Co + co];
+  }
   double st = 0.0;
   for (int cls = 0; cls < 27; ++cls)
-    if (tap_in(t / 9, cls / 9) && tap_in((t / 3) % 3, (cls / 3) % 3) && tap_in(t % 3, cls % 3)) st += (double)S[cls * Co + co];
+    if (tap_in(t / 9, cls / 9) && tap_in((t / 3) % 3, (cls / 3) % 3) && tap_in(t % 3, cls % 3)) st += cls == 13 ? inner : (double)S[cls * Co + co];
   box[i] = accumulate ? box[i] + (float)st : (float)st;
 }
 // db_up[cm] = sum_t sum_co w0[co][cm][t] * box[t][co];  block = cm
@@ -415,8 +439,10 @@ extern "C" size_t pcrl_upconv_wgrad_accum_ws_bytes(int N, int D, int H, int W, i
 }
 // dweff_acc: float32 [Co][Ci][64]; box_acc: float32 [27][Co]; first != 0: store, else add.  The gradient of the composed weights comes from the
 // brick weight-gradient kernel where it tiles the coarse grid (pcrl_upconv_wgrad_uses_brick() != 0), else from the gather kernel: same layout.
-extern "C" int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* box_acc, int first, void* ws, size_t ws_bytes, int N,
+extern "C" int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* box_acc, int flags, void* ws, size_t ws_bytes, int N,
                                        int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  const int first = flags & 1;        // store instead of add
+  const bool zsum = (flags & 2) != 0;  // the caller states that dy0 sums to zero over all voxels per channel (see upc_class_sums_kernel)
   if (int e = check_upc("upconv_wgrad_accum", N, D, H, W, Ci, 32, Co, dtype)) return e;
   PCRL_REQUIRE(x && dy0 && dweff_acc && box_acc, "upconv_wgrad_accum: null pointer");
   if (!ws || ws_bytes < pcrl_upconv_wgrad_accum_ws_bytes(N, D, H, W, Ci, Co, dtype)) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad_accum: workspace too small");
@@ -433,10 +459,10 @@ extern "C" int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dw
   const size_t lds = (size_t)(256 / (Co / vec)) * Co * sizeof(float);
   float* part = (float*)(w + wgb);
   float* S = (float*)(w + wgb + al((size_t)N * 2 * D * 9 * Co * sizeof(float)));
-  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_class_sums_kernel<bf16>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const bf16*)dy0, part, 2 * H, 2 * W, Co);
-  else hipLaunchKernelGGL(upc_class_sums_kernel<float>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const float*)dy0, part, 2 * H, 2 * W, Co);
+  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_class_sums_kernel<bf16>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const bf16*)dy0, part, 2 * D, 2 * H, 2 * W, Co, zsum);
+  else hipLaunchKernelGGL(upc_class_sums_kernel<float>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const float*)dy0, part, 2 * D, 2 * H, 2 * W, Co, zsum);
   hipLaunchKernelGGL(upc_class_total_kernel, dim3((unsigned)(9 * ((Co + 63) / 64)), 3), dim3(1024), 0, st, (const float*)part, S, N, 2 * D, Co);
-  hipLaunchKernelGGL(upc_box_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)S, box_acc, Co, first == 0);
+  hipLaunchKernelGGL(upc_box_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)S, box_acc, Co, first == 0, zsum);
   return pcrl_check_launch("upconv_wgrad_accum");
 }
 extern "C" size_t pcrl_upconv_wgrad_finish_ws_bytes(int Ci, int Cm, int Co, int dtype) {

@@ -665,8 +665,9 @@ class ComposedUpConv(_CacheGuard):
             self._reading(w_up.device)
         return self.wf, self.wd, self.bias_tab
 
-    def accumulate(self, x, dy, geom, w_up, b_up, w0, dtype):
-        """One backward pass: dweff += d(composed weights), box += border-class sums of dy (pcrl_upconv_wgrad_accum)."""
+    def accumulate(self, x, dy, geom, w_up, b_up, w0, dtype, zero_sum=False):
+        """One backward pass: dweff += d(composed weights), box += border-class sums of dy (pcrl_upconv_wgrad_accum).  zero_sum: dy is the
+        output of a training-mode BatchNorm backward over exactly these voxels (its per-channel sum is zero in exact arithmetic)."""
         L, dev = lib(), x.device
         N, D, H, W, Ci, Co = geom
         first = self.pending is None
@@ -677,7 +678,7 @@ class ComposedUpConv(_CacheGuard):
             _pending_composed.append(self)
         nb = L.call("pcrl_upconv_wgrad_accum_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
         with side_wgrad(dev, x, dy) as ws:
-            L.call("pcrl_upconv_wgrad_accum", x, dy, self.dweff, self.box, 1 if first else 0, ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype),
+            L.call("pcrl_upconv_wgrad_accum", x, dy, self.dweff, self.box, (1 if first else 0) | (2 if zero_sum else 0), ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype),
                    stream_handle())
 
     def finish(self):
@@ -751,7 +752,7 @@ def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamm
     N, D, H, W, Ci, Co = sv.geom
     M = N * D * H * W * 8
     dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype)
-    composed.accumulate(sv.x, dy, sv.geom, w_up, b_up, conv_w, dtype)
+    composed.accumulate(sv.x, dy, sv.geom, w_up, b_up, conv_w, dtype, zero_sum=config.UPC_ZERO_SUM)   # dy: output of the BatchNorm backward just above
     dw_up = db_up = dw0 = None
     if not defer:
         join_side_stream()

@@ -251,3 +251,40 @@ def test_brick_instantiations_equal_the_gather_kernels_to_an_ulp(geom):
     assert float(((pa - pb).abs() / pb.abs().clamp_min(1e-3)).max()) < 1e-5
     assert float((wa - wb).abs().max()) < 1e-5 * float(wb.abs().max())
     assert float((ba - bb).abs().max()) < 1e-5 * max(float(bb.abs().max()), 1e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("geom", [(2, 3, 4, 5, 32, 32), (3, 1, 2, 3, 32, 64), (1, 4, 8, 16, 64, 64), (2, 8, 8, 4, 64, 32)])
+def test_border_class_sums_from_the_border_when_dy_sums_to_zero(geom, dt):
+    """pcrl_upconv_wgrad_accum flags bit 1: dy0 sums to zero per channel (the output of a training-mode BatchNorm backward), so the class sums
+    read only the border voxels and the interior class is minus the rest.  On a dy0 made zero-sum in float64 before the rounding to the
+    activation dtype, both routes give the same box sums up to the rounding of dy0 (float32: 1e-5 of the largest; bfloat16: the full sum
+    carries the rounding noise of every voxel, the border route does not -- they agree to 2^-9 * sqrt(#voxels) * rms); the gradient of the
+    composed weights is untouched by the flag."""
+    N, D, H, W, Ci, Co = geom
+    L, s = lib(), stream_handle()
+    x = ops.to_act(rnd(N, Ci, D, H, W, seed=1).to(dt).to(DEV), dt)
+    dy = rnd(N, Co, 2 * D, 2 * H, 2 * W, seed=2)
+    dy = dy - dy.mean(dim=(0, 2, 3, 4), keepdim=True)
+    dya = ops.to_act(dy.to(dt).to(DEV), dt)
+    outs = []
+    for flags in (1, 3):
+        dweff, box = torch.empty(64 * Ci * Co, device=DEV), torch.empty(27 * Co, device=DEV)
+        nb = L.call("pcrl_upconv_wgrad_accum_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dt))
+        L.call("pcrl_upconv_wgrad_accum", x, dya, dweff, box, flags, ops.workspace(nb, torch.device(DEV)), nb, N, D, H, W, Ci, Co, dtype_code(dt), s)
+        outs.append((back(dweff), back(box)))
+    (wa, ba), (wb, bb) = outs
+    assert torch.equal(wa, wb)
+    M = N * 8 * D * H * W
+    noise = (2.0 ** -9 if dt == torch.bfloat16 else 2.0 ** -24) * (M ** 0.5) * float(dy.std()) * 4 + 1e-5 * float(ba.abs().max())
+    assert float((ba - bb).abs().max()) <= noise, (float((ba - bb).abs().max()), noise)
+    # and against float64: box[t] = sum of dy over the fine voxels from which tap t stays inside the grid
+    dq = dy.to(dt).double()
+    FD, FH, FW = 2 * D, 2 * H, 2 * W
+    ref = torch.zeros(27, Co, dtype=torch.float64)
+    for t in range(27):
+        td, th, tw = t // 9 - 1, (t // 3) % 3 - 1, t % 3 - 1
+        sl = lambda k, n_: slice(max(0, -k), n_ - max(0, k))
+        ref[t] = dq[:, :, sl(td, FD), sl(th, FH), sl(tw, FW)].sum(dim=(0, 2, 3, 4))
+    for got, what in ((ba, "all voxels"), (bb, "border voxels")):
+        assert float((got.view(27, Co) - ref).abs().max()) <= noise, what
