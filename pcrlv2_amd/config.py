@@ -46,6 +46,12 @@ FWD_BRANCH_STREAM = os.environ.get("PCRL_BRANCH_STREAM", "1") != "0"
 # rest (pcrl_upconv_wgrad_accum flags bit 1).  PCRL_UPC_ZERO_SUM=0: sum every voxel (A/B switch; differs by the rounding of dy0).
 UPC_ZERO_SUM = os.environ.get("PCRL_UPC_ZERO_SUM", "1") != "0"
 
+# Composed up-conv: the chain rule from the accumulated gradient of the composed weights to the reference parameters (weight-sized GEMMs and
+# re-layouts, ~0.3 ms per stage) is queued on the side stream as soon as the stage's LAST backward pass has accumulated (the step's first
+# forward pass) -- next to the rest of the backward -- instead of on the main stream at the end of backward(), where it was a serial tail on
+# an idle chip.  PCRL_EARLY_COMPOSED=0: at the end of backward(), on the main stream (A/B switch; bit-identical).
+EARLY_COMPOSED = os.environ.get("PCRL_EARLY_COMPOSED", "1") != "0"
+
 # Forward + backward of the SECOND global view on its own stream (train_3d.step_losses): the two global views share nothing but the
 # parameters, the packed-weight caches (built by the first view: guarded by an event) and the BatchNorm running statistics (updated in the
 # reference's order: the second view's update of a layer waits for the first view's, ops.order_rmw).  HBM-bound passes and launch gaps of one

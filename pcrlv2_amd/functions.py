@@ -329,9 +329,10 @@ class UpStageFn(Function):
             if defer:                 # delivered (and marked final) by _end_of_backward ...
                 deferred = (0, 1, 2)
                 _queue_end_of_backward()
-                if _final_callback is not None and getattr(ctx, "pass_idx", 1) == 0:
-                    # ... or, under the data-parallel wrapper, right here when this is the step's first forward pass (its backward runs
-                    # last -- the assumption mark_final already makes): the bucket's all-reduce overlaps the rest of the backward
+                if getattr(ctx, "pass_idx", 1) == 0 and (config.EARLY_COMPOSED or _final_callback is not None):
+                    # ... or right here when this is the step's first forward pass (its backward runs last -- the assumption mark_final
+                    # already makes): the chain rule runs on the side stream next to the rest of the backward instead of as a serial tail at
+                    # its end, and under the data-parallel wrapper the bucket's all-reduce overlaps the rest of the backward
                     _deliver_composed(mod._composed_up)
         else:
             g_upb = torch.empty(up_w.shape[1], dtype=torch.float32, device=d_a0.device)

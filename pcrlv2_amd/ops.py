@@ -701,14 +701,27 @@ _pending_composed: list = []
 
 def deliver_composed(only=None):
     """End of a backward() call (or, `only` = one ComposedUpConv, the moment its last pass has accumulated): run the chain rule of every
-    composed up-conv that accumulated gradients.  -> [(parameter, gradient), ...] for up_conv.weight, up_conv.bias and ops.0.conv1.weight."""
+    composed up-conv that accumulated gradients.  -> [(parameter, gradient), ...] for up_conv.weight, up_conv.bias and ops.0.conv1.weight.
+    With the weight-gradient side stream on, the chain rule is queued THERE, behind the accumulations it consumes (same stream: no join) and
+    next to whatever the other streams still have to do -- at the end of a backward() it would otherwise be a serial tail on an idle chip;
+    its results are parked like every side-stream gradient (the join before they are summed covers them)."""
     out = []
     todo = [c for c in _pending_composed if only is None or c is only]
     if todo:
-        join_side_stream()        # the accumulations may have run on the weight-gradient side stream
+        dev = None
         for c in todo:
             if c.pending is not None:
-                w_up, b_up, w0, dw_up, db_up, dw0 = c.finish()
+                dev = c.pending[0].device
+        side = config.EARLY_COMPOSED and dev is not None and side_wgrad(dev).active
+        if not side:
+            join_side_stream()        # one-stream mode: nothing to wait for, kept for the 2D / CPU-less paths' symmetry
+        for c in todo:
+            if c.pending is not None:
+                if side:
+                    with side_wgrad(dev):
+                        w_up, b_up, w0, dw_up, db_up, dw0 = c.finish()
+                else:
+                    w_up, b_up, w0, dw_up, db_up, dw0 = c.finish()
                 out += [(w_up, dw_up), (b_up, db_up), (w0, dw0)]
             _pending_composed.remove(c)
     return out
