@@ -614,6 +614,52 @@ __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const f
   }
 }
 
+// Four elements per thread: one table search and 16-byte accesses per group when the group lies inside one tensor (FusedSGD pads its slots to
+// 4 floats, so every group does); a group that straddles tensors falls back to the scalar update.  0.16 -> 0.07 ms for 17.1 M parameters.
+__global__ void __launch_bounds__(256) sgd4_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                   const int64_t* __restrict__ offsets, const int32_t* __restrict__ flags, int ntensors,
+                                                   int64_t total, float lr, float momentum, float wd, float gscale) {
+  const int64_t ngroups = (total + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < ngroups; q += (int64_t)gridDim.x * 256) {
+    const int64_t i = q << 2;
+    int lo = 0, hi = ntensors;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    if (i + 4 <= total && offsets[lo + 1] >= i + 4) {
+      const int f = flags[lo];
+      if (!(f & 1)) continue;
+      float4 pv = *reinterpret_cast<const float4*>(p + i);
+      const float4 gv = *reinterpret_cast<const float4*>(g + i);
+      float4 bv = (f & 2) ? *reinterpret_cast<const float4*>(buf + i) : float4{0.f, 0.f, 0.f, 0.f};
+#define SGD1(c_)                                        \
+      {                                                 \
+        const float gg = gv.c_ * gscale + wd * pv.c_;   \
+        const float b = (f & 2) ? momentum * bv.c_ + gg : gg; \
+        bv.c_ = b;                                      \
+        pv.c_ = pv.c_ - lr * b;                         \
+      }
+      SGD1(x) SGD1(y) SGD1(z) SGD1(w)
+#undef SGD1
+      *reinterpret_cast<float4*>(buf + i) = bv;
+      *reinterpret_cast<float4*>(p + i) = pv;
+    } else {
+      for (int64_t e = i; e < i + 4 && e < total; ++e) {
+        int t = lo;
+        while (t + 1 < ntensors && offsets[t + 1] <= e) ++t;
+        const int f = flags[t];
+        if (!(f & 1)) continue;
+        const float pv = p[e];
+        const float gv = g[e] * gscale + wd * pv;
+        const float b = (f & 2) ? momentum * buf[e] + gv : gv;
+        buf[e] = b;
+        p[e] = pv - lr * b;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Weight packing
 // ---------------------------------------------------------------------------------------------
@@ -806,8 +852,12 @@ extern "C" int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y,
 extern "C" int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
                              int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream) {
   PCRL_REQUIRE(p && g && buf && offsets && flags && ntensors > 0 && total > 0, "sgd_step: bad arguments");
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), p, g, buf, offsets, flags, ntensors, total, lr, momentum,
-                     weight_decay, grad_scale);
+  if (al16(p) && al16(g) && al16(buf))
+    hipLaunchKernelGGL(sgd4_kernel, dim3(grid_for((total + 3) / 4)), dim3(256), 0, as_stream(stream), p, g, buf, offsets, flags, ntensors, total, lr,
+                       momentum, weight_decay, grad_scale);
+  else
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), p, g, buf, offsets, flags, ntensors, total, lr, momentum,
+                       weight_decay, grad_scale);
   return pcrl_check_launch("sgd");
 }
 

@@ -736,6 +736,35 @@ def test_fused_sgd_matches_torch_sgd():
     assert set(sd["state"][0].keys()) == {"momentum_buffer"} and sd["param_groups"][0]["momentum"] == 0.9
 
 
+def test_sgd_kernel_on_an_unpadded_arena():
+    """pcrl_sgd_step on a flat arena whose tensors start anywhere (FusedSGD pads its slots to 4 floats; a caller of the C ABI need not): groups
+    of four elements that straddle two tensors -- with different has-gradient / has-momentum flags -- take the scalar path of the kernel."""
+    L, s = lib(), stream_handle()
+    sizes = [5, 1, 7, 64, 3, 130, 2]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    total = offs[-1]
+    flags = [1, 3, 0, 3, 1, 2, 3]          # bit 0: has a gradient, bit 1: momentum buffer initialised
+    g = torch.Generator().manual_seed(4)
+    p0, gr, b0 = (torch.randn(total, generator=g, dtype=torch.float64) for _ in range(3))
+    lr, mom, wd, gs = 0.05, 0.9, 1e-2, 0.5
+    ep, eb = p0.clone(), b0.clone()
+    for t, (o, n) in enumerate(zip(offs, sizes)):
+        if not flags[t] & 1:
+            continue
+        sl = slice(o, o + n)
+        gg = gr[sl] * gs + wd * p0[sl]
+        bb = mom * b0[sl] + gg if flags[t] & 2 else gg
+        eb[sl] = bb
+        ep[sl] = p0[sl] - lr * bb
+    pd, gd, bd = (t.float().to(DEV) for t in (p0, gr, b0))
+    L.call("pcrl_sgd_step", pd, gd, bd, torch.tensor(offs, dtype=torch.int64, device=DEV), torch.tensor(flags, dtype=torch.int32, device=DEV),
+           len(sizes), total, lr, mom, wd, gs, s)
+    check(pd, ep, torch.float32, "sgd parameters", f32_tol=2e-6)
+    check(bd, eb, torch.float32, "sgd momentum buffers", f32_tol=2e-6)
+
+
 @pytest.mark.parametrize("N,C,tau", [(32, 64, 0.5), (96, 256, 0.1), (2, 8, 1.0)])
 def test_ntxent_optional_extra(N, C, tau):
     """NT-Xent (named in north_star, absent from the reference) against its PyTorch float64 definition:
