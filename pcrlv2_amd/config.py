@@ -41,6 +41,10 @@ WGRAD_SIDE_STREAM_2D = _ws != "0"
 # results are bit-identical).
 FWD_BRANCH_STREAM = os.environ.get("PCRL_BRANCH_STREAM", "1") != "0"
 
+# The same for the 2D path (train_2d.step_losses: view 2 next to view 1; the global cosine term sits between the second view and the local
+# views, so the join comes before it).  PCRL_VIEW_STREAMS_2D=0: off.
+VIEW_STREAMS_2D = os.environ.get("PCRL_VIEW_STREAMS_2D", "1") != "0"
+
 # Composed up-conv, bias gradients: the border-class sums of dy0 (the gradient entering conv1 = the output of its training-mode BatchNorm's
 # backward, whose per-channel sum over the batch is zero in exact arithmetic) read only the border voxels; the interior class is minus the
 # rest (pcrl_upconv_wgrad_accum flags bit 1).  PCRL_UPC_ZERO_SUM=0: sum every voxel (A/B switch; differs by the rounding of dy0).

@@ -136,14 +136,16 @@ _views_active = False        # set while a step uses the view stream: the cross-
 _rmw_events: dict = {}
 
 
-def view_streams_on(device) -> bool:
+def view_streams_on(device, path2d=False) -> bool:
+    if path2d:      # the 2D path has no accumulators shared between passes: no need for the side stream
+        return config.VIEW_STREAMS_2D and device.type == "cuda"
     return config.VIEW_STREAMS and config.WGRAD_SIDE_STREAM_3D and device.type == "cuda"
 
 
-def fork_views(device):
+def fork_views(device, path2d=False):
     """Start of a step, BEFORE the first view is queued: the view stream waits for what the main stream holds now (the optimizer step)."""
     global _views_active
-    if not view_streams_on(device):
+    if not view_streams_on(device, path2d):
         return
     for name in VIEW_STREAM_NAMES:
         key = (device.type, device.index, name)
@@ -157,9 +159,9 @@ def fork_views(device):
 class view_pass:
     """`with view_pass(device, x, name="view2"):` -- the forward queued inside runs on that view stream (its autograd nodes run their backward there)."""
 
-    def __init__(self, device, *operands, name="view2"):
+    def __init__(self, device, *operands, name="view2", path2d=False):
         self.device, self.operands, self.name = device, operands, name
-        self.active = _views_active and view_streams_on(device) and name in VIEW_STREAM_NAMES
+        self.active = _views_active and view_streams_on(device, path2d) and name in VIEW_STREAM_NAMES
 
     def __enter__(self):
         if self.active:

@@ -56,6 +56,7 @@ class PackedConv2d:
         self.dgrad = None
         self.s2_key = None
         self.s2 = None        # stride-2 data gradient: {(a, b): parity-class pack}
+        self._guard, self._guard_s2 = ops._CacheGuard(), ops._CacheGuard()   # built on one stream, read on another (config.VIEW_STREAMS_2D)
 
     def get_s2(self, w: torch.Tensor, dtype):
         """Parity-class packs of the stride-2 data gradient (pcrl_conv2d_dgrad_s2): 3x3 -> four classes, 1x1 -> class (0, 0)."""
@@ -71,6 +72,9 @@ class PackedConv2d:
                 L.call("pcrl_conv2d_pack_s2", w.detach(), t, Co, Ci, KH, KW, CoP, a, b, dtype_code(dtype), s)
                 self.s2[(a, b)] = t
             self.s2_key = key
+            self._guard_s2._built(w.device)
+        else:
+            self._guard_s2._reading(w.device)
         return self.s2
 
     def get(self, w: torch.Tensor, dtype, CiP: int):
@@ -84,6 +88,9 @@ class PackedConv2d:
             L.call("pcrl_conv2d_pack", w.detach(), self.fwd, Co, Ci, KH, KW, CiP, 0, dtype_code(dtype), s)
             L.call("pcrl_conv2d_pack", w.detach(), self.dgrad, Co, Ci, KH, KW, CoP, 1, dtype_code(dtype), s)
             self.key = key
+            self._guard._built(w.device)
+        else:
+            self._guard._reading(w.device)
         return self.fwd, self.dgrad
 
 

@@ -18,6 +18,7 @@ import time
 import torch
 
 from . import ddp as _ddp
+from . import ops as _ops
 from .functions2d import mse_loss2d
 from .models.pcrlv2_model import PCRLv2
 from .optim import FusedSGD
@@ -40,8 +41,12 @@ def step_losses(model, batch, epoch, criterion, cosine):
     view1, view2, target, _unused_gt2, local_views = batch
     n = view1.size(0)
     target = _to_gpu(target)
-    feats1, mask1, masks1 = model(_to_gpu(view1))
-    feats2, _mask2, _ = model(_to_gpu(view2))
+    view1, view2 = _to_gpu(view1), _to_gpu(view2)
+    _ops.fork_views(view1.device, path2d=True)     # config.VIEW_STREAMS_2D: the second view's forward (and backward) on its own stream
+    feats1, mask1, masks1 = model(view1)
+    with _ops.view_pass(view2.device, view2, path2d=True):
+        feats2, _mask2, _ = model(view2)
+    _ops.join_side_stream()                        # the cosine term below reads both views' features on the main stream
     l_global, scale = cos_loss(cosine, feats1, feats2)
     feats_loc, _, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
     stacked = [torch.stack(pair) for pair in feats_loc]                 # [2, 6n, C] per scale

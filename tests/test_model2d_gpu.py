@@ -134,6 +134,36 @@ def test_training_steps_reduce_loss(dtype):
     assert n_none >= 1    # view-2 / unselected deep-supervision heads get no gradient in a step (autograd semantics of the reference)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_second_view_on_its_own_stream_is_bit_identical_2d(dtype):
+    """config.VIEW_STREAMS_2D (default on): the second global view's forward and backward run on their own stream next to the first's; the
+    packed-weight caches and the BatchNorm running statistics are ordered by events.  Same kernels, same operands -> parameters, momentum
+    buffers and running statistics after three steps are BIT-identical to the one-stream run."""
+    import pcrlv2_2d_oracle as O
+    from pcrlv2_amd import config, train_2d
+    from pcrlv2_amd.optim import FusedSGD
+    from pcrlv2_amd.train_3d import CosineSimilarityMean
+    batches = [O.synthetic_batch(4, 64, 32, seed=11 + k) for k in range(3)]
+    keep, finals = config.VIEW_STREAMS_2D, []
+    try:
+        for on in (True, False):
+            config.VIEW_STREAMS_2D = on
+            model = _build(seed=5, dtype=dtype)
+            opt = FusedSGD(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+            random.seed(2)
+            for bt in batches:
+                out = train_2d.train_step(model, opt, bt, 0, train_2d.MSELoss2d(), CosineSimilarityMean())
+            torch.cuda.synchronize()
+            rs = torch.cat([v.flatten().float() for k, v in sorted(model.state_dict().items()) if "running" in k])
+            finals.append(([float(o) for o in out], opt.flat_p.clone(), opt.flat_buf.clone(), rs))
+    finally:
+        config.VIEW_STREAMS_2D = keep
+    a, b = finals
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y, what in zip(a[1:], b[1:], ("parameters", "momentum buffers", "running statistics")):
+        assert torch.equal(x, y), what
+
+
 def test_bf16_step_close_to_fp32():
     import pcrlv2_2d_oracle as O
     from pcrlv2_amd import train_2d
