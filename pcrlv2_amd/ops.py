@@ -117,8 +117,12 @@ def join_side_stream(device=None):
     for key, pending in list(_side_pending.items()):
         if pending and (device is None or (device.type, device.index) == key):
             dev = torch.device(key[0], key[1])
-            torch.cuda.current_stream(dev).wait_stream(_side_streams[key])
-            _side_pending[key] = False
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_stream(_side_streams[key])
+            # "nothing outstanding" is a statement about the MAIN stream: a join issued while a view stream is current (a forward of the second
+            # view outside deferred_join) makes that stream wait, but the main stream still has to
+            if not any(cur.cuda_stream == vs.cuda_stream for vs in _view_streams.values()):
+                _side_pending[key] = False
     if _views_active:
         # the second view's autograd nodes run their backward on the view stream without passing through view_pass: while a step uses the
         # stream every join waits for it (a wait on an idle stream costs nothing)
