@@ -56,6 +56,13 @@ UPC_ZERO_SUM = os.environ.get("PCRL_UPC_ZERO_SUM", "1") != "0"
 # an idle chip.  PCRL_EARLY_COMPOSED=0: at the end of backward(), on the main stream (A/B switch; bit-identical).
 EARLY_COMPOSED = os.environ.get("PCRL_EARLY_COMPOSED", "1") != "0"
 
+# The host enqueues a step in ~14 ms, the GPU runs it in ~34: left alone the host runs as far ahead as the launch queue lets it, and every
+# block whose last use was recorded on another stream (the side / view streams: record_stream) stays unavailable to the caching allocator
+# until the GPU gets there -- the reserved footprint grew to 8x the peak allocation (97 GB for 12.6 GB at b = 32) with device mallocs inside
+# the timed steps.  train_step therefore waits, before enqueueing step k, for the END of step k - MAX_STEPS_AHEAD (an event, not a device
+# synchronize): the GPU always has at least one whole step queued, the footprint stays at a few times the peak.  0: unlimited.
+MAX_STEPS_AHEAD = int(os.environ.get("PCRL_MAX_STEPS_AHEAD", "2"))
+
 # Forward + backward of the SECOND global view on its own stream (train_3d.step_losses): the two global views share nothing but the
 # parameters, the packed-weight caches (built by the first view: guarded by an event) and the BatchNorm running statistics (updated in the
 # reference's order: the second view's update of a layer waits for the first view's, ops.order_rmw).  HBM-bound passes and launch gaps of one

@@ -8,6 +8,7 @@ Every function launches on torch's current stream and returns immediately.
 """
 from __future__ import annotations
 
+import collections
 import os
 
 import torch
@@ -131,6 +132,26 @@ def join_side_stream(device=None):
                 cur = torch.cuda.current_stream(torch.device(dt_, di_))
                 if cur.cuda_stream != vs.cuda_stream:
                     cur.wait_stream(vs)
+
+
+# ---- host run-ahead (config.MAX_STEPS_AHEAD) ----
+_step_ends: dict = {}      # device index -> deque of events recorded at the end of the last steps
+
+
+def throttle_host(device, step_done=False):
+    """config.MAX_STEPS_AHEAD: keep the host at most that many steps ahead of the GPU.  Called with step_done=True after optimizer.step()
+    (records the step's end) and with False before a step is enqueued (waits for the end of the step MAX_STEPS_AHEAD back)."""
+    lag = config.MAX_STEPS_AHEAD
+    if lag <= 0 or device.type != "cuda":
+        return
+    q = _step_ends.setdefault(device.index, collections.deque())
+    if step_done:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        q.append(ev)
+    else:
+        while len(q) >= lag:
+            q.popleft().synchronize()
 
 
 # ---- the second global view on its own stream (config.VIEW_STREAMS) ----

@@ -63,10 +63,13 @@ def step_losses(model, batch, epoch, criterion, cosine):
 
 
 def train_step(model, optimizer, batch, epoch, criterion, cosine):
+    dev = next(model.parameters()).device
+    _ops.throttle_host(dev)      # at most config.MAX_STEPS_AHEAD steps of host run-ahead (allocator footprint, see config.py)
     losses = step_losses(model, batch, epoch, criterion, cosine)
     optimizer.zero_grad()
     losses[0].backward()
     optimizer.step()
+    _ops.throttle_host(dev, step_done=True)
     return tuple(l.detach() for l in losses)
 
 

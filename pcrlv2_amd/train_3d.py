@@ -158,6 +158,8 @@ def train_step(model, optimizer, batch, epoch, criterion, cosine, guard=True):
     """One iteration of train_3d.py:113-151.  Returns (loss, loss1, loss2, loss4, local_loss) as detached device
     scalars, or None when the divergence guard skipped the update."""
     begin_step()            # forward-pass numbering / parked-gradient state start clean even after a skipped or failed step
+    dev = next(model.parameters()).device
+    _ops.throttle_host(dev)      # at most config.MAX_STEPS_AHEAD steps of run-ahead (allocator footprint, see config.py)
     losses = step_losses(model, batch, epoch, criterion, cosine)
     if guard and epoch > 10:
         # The reference is one process (nn.DataParallel): one loss, one decision.  With one process per GPU the decision must be
@@ -171,6 +173,7 @@ def train_step(model, optimizer, batch, epoch, criterion, cosine, guard=True):
     optimizer.zero_grad()
     losses[0].backward()
     optimizer.step()
+    _ops.throttle_host(dev, step_done=True)
     return tuple(l.detach() for l in losses)
 
 
