@@ -380,6 +380,14 @@ int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y, void* cons
  * g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
 int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
                   int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream);
+/* The divergence guard of train_3d.py:140-142 (`if loss > 1000 and epoch > 10: continue`) decided ON THE DEVICE, so that epochs 11..240 run
+ * without a forward -> backward host synchronisation: pcrl_guard_flag writes out[0] = (loss[0] > threshold) ? 1 : 0 (under data parallelism
+ * the caller MAX-all-reduces it: one process, one decision in the reference), pcrl_sgd_step_guarded is pcrl_sgd_step that does NOTHING when
+ * skip[0] != 0 -- parameters and momentum buffers stay bit-unchanged, which is what the reference's `continue` leaves behind. */
+int pcrl_guard_flag(const float* loss, float threshold, float* out, pcrl_stream_t stream);
+int pcrl_sgd_step_guarded(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
+                          int64_t total, float lr, float momentum, float weight_decay, float grad_scale, const float* skip,
+                          pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Input pipeline: the torchio transforms of data.py:73-89 / datasets/lunaDataset.py:28-81 on float32 volumes

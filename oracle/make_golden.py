@@ -287,6 +287,104 @@ def make_eval(tag, b, dhw, refmod, ref_train, ref_utils):
             fx[f"mask{i}/{k}"] = v
     np.savez_compressed(os.path.join(OUT, tag + ".npz"), **fx)
     print(f"[{tag}] oracle eval == reference eval; wrote fixture")
+class chunked_convs:
+    """Run every F.conv3d / F.conv_transpose3d call in batch chunks.  ATen's float64 CPU convolution (slow_conv3d) materialises the im2col
+    matrix of the WHOLE batch (27*Ci x voxels x 8 B per sample: 3.6 GB per sample for up_tr64.ops.0 at 64x64x32, 29 GB at 128x128x64); a
+    convolution treats the samples of a batch independently, so chunking changes no arithmetic -- `make_forward` asserts bit-identity
+    against the unchunked call on a small batch before it relies on it.  The module tree, forward code, BatchNorm and losses stay the
+    reference's own."""
+
+    def __init__(self, budget_bytes=12 << 30):
+        self.budget = budget_bytes
+
+    def _wrap(self, fn, taps_of):
+        budget = self.budget
+
+        def run(x, weight, *a, **kw):
+            n = x.shape[0]
+            vox = x[0, 0].numel()
+            per = weight.shape[1] * taps_of(weight) * vox * x.element_size()   # im2col / col2im matrix of one sample
+            c = max(1, min(n, budget // max(per, 1)))
+            if c >= n:
+                return fn(x, weight, *a, **kw)
+            return torch.cat([fn(x[i:i + c], weight, *a, **kw) for i in range(0, n, c)], 0)
+        return run
+
+    def __enter__(self):
+        import torch.nn.functional as Fn
+        self.Fn = Fn
+        self.f_conv, self.f_convt = Fn.conv3d, Fn.conv_transpose3d
+        Fn.conv3d = self._wrap(self.f_conv, lambda w: w[0, 0].numel())
+        Fn.conv_transpose3d = self._wrap(self.f_convt, lambda w: w[0, 0].numel())
+        return self
+
+    def __exit__(self, *exc):
+        self.Fn.conv3d, self.Fn.conv_transpose3d = self.f_conv, self.f_convt
+
+
+def make_forward(tag, b, dhw, refmod, ref_train, ref_utils, epoch=3, seed=0):
+    """Forward-only pin at the exact BASELINE batch (C2: b = 32 at 64x64x32; C4: b = 8 at 128x128x64): float64 backward does not fit this
+    container's 62 GB at those sizes, the three forwards of train_3d.py:116-138 under torch.no_grad() do.  The REAL reference model in train
+    mode (batch statistics, running statistics moved by the three passes), the imported cos_loss, float64, oneDNN off: `out`, the six feature
+    tensors of view 1, the three deep-supervision maps, all five losses and the BatchNorm buffers after the step's three forwards."""
+    torch.set_num_threads(8)
+    dt = torch.float64
+    st0 = O.fill_state(dt)
+    model = refmod.PCRLv23d().double()
+    model.load_state_dict(st0, strict=True)
+    model.train()
+    criterion, cosine = torch.nn.MSELoss(), torch.nn.CosineSimilarity()
+    # chunked convolutions are the same arithmetic: bit-identical to the unchunked reference on a small batch
+    with torch.backends.mkldnn.flags(enabled=False), torch.no_grad():
+        xs = O.fill_batch(4, (16, 16, 16), dtype=dt, seed=3)[0]
+        a = model(xs)
+        model.load_state_dict(st0, strict=True)
+        with chunked_convs(budget_bytes=1):
+            c = model(xs)
+        model.load_state_dict(st0, strict=True)
+    assert torch.equal(a[0], c[0]) and all(torch.equal(u, v) for fa, fc in zip(a[1], c[1]) for u, v in zip(fa, fc)), "chunking changed bits"
+    del a, c, xs
+    batch = O.fill_batch(b, dhw, dtype=dt, seed=7)
+    random.seed(seed)
+    with torch.backends.mkldnn.flags(enabled=False), torch.no_grad(), chunked_convs():
+        r = reference_step(model, ref_train, batch, epoch, criterion, cosine)
+    bufs = {k: v.detach().clone() for k, v in model.state_dict().items() if O.is_buffer(k)}
+    # drop the activations the reference model stashes on itself before the oracle runs (memory)
+    for a in ("skip_out64", "skip_out128", "skip_out256", "out512"):
+        if hasattr(model, a):
+            setattr(model, a, None)
+    with torch.backends.mkldnn.flags(enabled=False), torch.no_grad(), chunked_convs():
+        nb = {}
+        o = O.step_losses(st0, batch, epoch, random.Random(seed), nb)
+    for k in ("loss", "loss1", "loss2", "loss4", "local_loss"):
+        assert abs(float(o[k]) - float(r[k])) < 1e-10, (k, float(o[k]), float(r[k]))
+    assert o["index2"] == r["index2"]
+    worst = close(o["mask1"], r["mask1"], 1e-10, "out")
+    for i in range(3):
+        worst = max(worst, close(o["dec1"][i][0], r["dec1"][i][0], 1e-9, f"pro{i}"))
+        worst = max(worst, close(o["dec1"][i][1], r["dec1"][i][1], 1e-9, f"pre{i}"))
+        worst = max(worst, close(o["mid1"][i], r["mid1"][i], 1e-10, f"mid{i}"))
+    for k, v in bufs.items():
+        close(nb[k].double(), v.double(), 1e-10, k)
+    fx = OrderedDict()
+    fx["meta/b"], fx["meta/dhw"], fx["meta/epoch"], fx["meta/seed"], fx["meta/batch_seed"] = np.int64(b), np.array(dhw), np.int64(epoch), np.int64(seed), np.int64(7)
+    for k in ("loss", "loss1", "loss2", "loss4", "local_loss"):
+        fx[f"step0/{k}"] = np.float64(float(r[k]))
+    fx["step0/index2"] = np.float64(r["index2"])
+    for k, v in summarize(r["mask1"], 1024).items():
+        fx[f"fwd/out/{k}"] = v
+    for i in range(3):
+        fx[f"fwd/pro{i}"] = r["dec1"][i][0].detach().numpy().copy()
+        fx[f"fwd/pre{i}"] = r["dec1"][i][1].detach().numpy().copy()
+        for k, v in summarize(r["mid1"][i], 1024).items():
+            fx[f"fwd/mid{i}/{k}"] = v
+    for name, v in bufs.items():
+        fx[f"buf1/{name}"] = v.double().numpy().copy()
+    path = os.path.join(OUT, f"{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{tag}] oracle == reference forward-only (worst fwd |d| {worst:.2e}); losses "
+          f"{ {k: float(r[k]) for k in ('loss', 'loss1', 'loss2', 'loss4', 'local_loss')} }; wrote {path} "
+          f"({os.path.getsize(path) / 1024:.0f} KiB, {len(fx)} arrays)", flush=True)
 
 
 def make_init(tag, refmod, seed=7):
@@ -307,6 +405,11 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be regenerated in the authoring container")
     refmod, ref_train, ref_utils = load_reference()
+    if "--forward-only" in sys.argv:
+        # the exact BASELINE batches (C2, C4), forward-only (float64 backward does not fit at these sizes)
+        make_forward("f_c2_b32_64x64x32", 32, (64, 64, 32), refmod, ref_train, ref_utils)
+        make_forward("f_c4_b8_128x128x64", 8, (128, 128, 64), refmod, ref_train, ref_utils)
+        return
     make_init("init_seed7", refmod)
     if "--init-only" in sys.argv:
         return

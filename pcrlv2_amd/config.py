@@ -89,3 +89,9 @@ FUSE_APPLY_CONSUMERS = os.environ.get("PCRL_FUSE_APPLY_CONSUMERS", "1") != "0"
 # one 8-tap operator on the coarse grid (csrc/upconv_fused.hip): 0.30 of the multiply-adds of the 27-tap convolution over the upsampled
 # tensor, which is never formed.  Training-mode BatchNorm route only.  PCRL_COMPOSE_UPCONV=0: the two separate kernels (A/B switch).
 COMPOSE_UPCONV = os.environ.get("PCRL_COMPOSE_UPCONV", "1") != "0"
+
+# Allocator provisioning (ops.provision_allocator): after the first complete training step the per-stream pools of torch's caching
+# allocator are grown to PROVISION_FACTOR times what that step left in them, once, so that the multi-stream steady state (blocks in flight
+# across the two-step run-ahead window) needs no hipMalloc later -- the timed region of a short benchmark run (`--warmup 5`) otherwise holds
+# a few device mallocs per step.  1: off.
+PROVISION_FACTOR = int(os.environ.get("PCRL_PROVISION_FACTOR", "3"))

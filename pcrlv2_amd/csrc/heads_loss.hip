@@ -595,9 +595,12 @@ __global__ void __launch_bounds__(256) ntx_denorm_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 // SGD over a flat arena; per-tensor flags looked up by binary search on the offsets table.
 // ---------------------------------------------------------------------------------------------
+// `skip` (may be null): device flag of the divergence guard (train_3d.py:140-142 decided on the device); non-zero = the whole update is
+// skipped -- parameters and momentum buffers stay bit-unchanged, exactly what the reference's `continue` leaves behind.
 __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                   const int64_t* __restrict__ offsets, const int32_t* __restrict__ flags, int ntensors,
-                                                  int64_t total, float lr, float momentum, float wd, float gscale) {
+                                                  int64_t total, float lr, float momentum, float wd, float gscale, const float* __restrict__ skip) {
+  if (skip && *skip != 0.f) return;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int lo = 0, hi = ntensors;  // find t with offsets[t] <= i < offsets[t+1]
     while (hi - lo > 1) {
@@ -618,7 +621,8 @@ __global__ void __launch_bounds__(256) sgd_kernel(float* __restrict__ p, const f
 // 4 floats, so every group does); a group that straddles tensors falls back to the scalar update.  0.16 -> 0.07 ms for 17.1 M parameters.
 __global__ void __launch_bounds__(256) sgd4_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                    const int64_t* __restrict__ offsets, const int32_t* __restrict__ flags, int ntensors,
-                                                   int64_t total, float lr, float momentum, float wd, float gscale) {
+                                                   int64_t total, float lr, float momentum, float wd, float gscale, const float* __restrict__ skip) {
+  if (skip && *skip != 0.f) return;
   const int64_t ngroups = (total + 3) >> 2;
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < ngroups; q += (int64_t)gridDim.x * 256) {
     const int64_t i = q << 2;
@@ -849,16 +853,39 @@ extern "C" int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y,
   return pcrl_check_launch("cosine_terms_bwd");
 }
 
-extern "C" int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
-                             int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream) {
+static int sgd_launch(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors, int64_t total, float lr,
+                      float momentum, float weight_decay, float grad_scale, const float* skip, pcrl_stream_t stream) {
   PCRL_REQUIRE(p && g && buf && offsets && flags && ntensors > 0 && total > 0, "sgd_step: bad arguments");
   if (al16(p) && al16(g) && al16(buf))
     hipLaunchKernelGGL(sgd4_kernel, dim3(grid_for((total + 3) / 4)), dim3(256), 0, as_stream(stream), p, g, buf, offsets, flags, ntensors, total, lr,
-                       momentum, weight_decay, grad_scale);
+                       momentum, weight_decay, grad_scale, skip);
   else
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), p, g, buf, offsets, flags, ntensors, total, lr, momentum,
-                       weight_decay, grad_scale);
+                       weight_decay, grad_scale, skip);
   return pcrl_check_launch("sgd");
+}
+
+extern "C" int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
+                             int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream) {
+  return sgd_launch(p, g, buf, offsets, flags, ntensors, total, lr, momentum, weight_decay, grad_scale, nullptr, stream);
+}
+
+extern "C" int pcrl_sgd_step_guarded(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
+                                     int64_t total, float lr, float momentum, float weight_decay, float grad_scale, const float* skip,
+                                     pcrl_stream_t stream) {
+  PCRL_REQUIRE(skip, "sgd_step_guarded: null skip flag");
+  return sgd_launch(p, g, buf, offsets, flags, ntensors, total, lr, momentum, weight_decay, grad_scale, skip, stream);
+}
+
+// out[0] = (loss > threshold) ? 1 : 0, NaN counts as diverged exactly when the reference's `loss > 1000` would (it would not: NaN > x is false).
+__global__ void guard_flag_kernel(const float* __restrict__ loss, float threshold, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = (loss[0] > threshold) ? 1.f : 0.f;
+}
+
+extern "C" int pcrl_guard_flag(const float* loss, float threshold, float* out, pcrl_stream_t stream) {
+  PCRL_REQUIRE(loss && out, "guard_flag: bad arguments");
+  hipLaunchKernelGGL(guard_flag_kernel, dim3(1), dim3(64), 0, as_stream(stream), loss, threshold, out);
+  return pcrl_check_launch("guard_flag");
 }
 
 extern "C" int pcrl_pack_conv3_weight(const float* w_ref, void* w_fwd, void* w_dgrad, int Co, int Ci, int dtype, pcrl_stream_t stream) {

@@ -96,16 +96,32 @@ def draw_spatial(gen, B, device, p_flip=0.5, scales=0.1, degrees=10.0):
     flip = (torch.rand(B, generator=gen, device=device) < p_flip).to(torch.int32)
     sc = _u(gen, B * 3, 1.0 - scales, 1.0 + scales, device).view(B, 3)
     rot = _rotation(_u(gen, B * 3, -degrees, degrees, device).view(B, 3))
-    inv = torch.linalg.inv(rot @ torch.diag_embed(sc)).to(torch.float32).contiguous()
+    # (rot . diag(sc))^-1 = diag(1 / sc) . rot^T in closed form: torch.linalg.inv on the device synchronises the host (it reads the LU
+    # status back), which would stall the enqueue of the next training step behind the whole previous one
+    inv = (rot.transpose(1, 2) / sc.unsqueeze(2)).to(torch.float32).contiguous()
     return flip, inv
 
 
-def draw_intensity(gen, B, device, max_blur=2.0, max_noise=0.25, log_gamma=0.3):
-    """RandomBlur / RandomNoise / RandomGamma parameters -> (sigma [3,B], noise_std [B], gamma [B], seed)."""
+_host_rngs: dict = {}
+
+
+def _host_rng_of(gen):
+    """The host-side companion of a device generator (seeded from it once): scalars the kernels take BY VALUE -- the noise seed -- are drawn
+    here, never read back from the device (an .item() between two training steps makes the host wait for the whole previous step)."""
+    import random
+    r = _host_rngs.get(id(gen))
+    if r is None:
+        r = _host_rngs[id(gen)] = random.Random(gen.initial_seed())
+    return r
+
+
+def draw_intensity(gen, B, device, max_blur=2.0, max_noise=0.25, log_gamma=0.3, host_rng=None):
+    """RandomBlur / RandomNoise / RandomGamma parameters -> (sigma [3,B], noise_std [B], gamma [B], seed).  The per-volume parameters stay on
+    the device; the noise seed (a kernel argument) comes from `host_rng` (default: the generator's host companion) -- no device read-back."""
     sigma = _u(gen, 3 * B, 0.0, max_blur, device).view(3, B).contiguous()
     noise_std = _u(gen, B, 0.0, max_noise, device)
     gamma = torch.exp(_u(gen, B, -log_gamma, log_gamma, device))
-    seed = int(torch.randint(0, 2 ** 62, (1,), generator=gen, device=device).item())
+    seed = (host_rng if host_rng is not None else _host_rng_of(gen)).getrandbits(62)
     return sigma, noise_std, gamma, seed
 
 
@@ -162,13 +178,15 @@ class GpuLunaAugment:
         if self.device.type != "cuda":
             raise RuntimeError("GpuLunaAugment runs on the GPU (libpcrl_hip.so); there is no CPU fallback")
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
+        import random
+        self.host_rng = random.Random(seed)       # by-value kernel arguments (the noise seed): drawn on the host, no device read-back
 
     def spatial(self, v):
         flip, inv = draw_spatial(self.gen, v.shape[0], self.device)
         return apply_spatial(v, flip, inv)
 
     def intensity(self, v, swap):
-        sigma, noise_std, gamma, seed = draw_intensity(self.gen, v.shape[0], self.device)
+        sigma, noise_std, gamma, seed = draw_intensity(self.gen, v.shape[0], self.device, host_rng=self.host_rng)
         origins = draw_swap(self.gen, v.shape[0], tuple(v.shape[1:]), self.device) if swap else None
         return apply_intensity(v, sigma, noise_std, gamma, seed, origins)
 

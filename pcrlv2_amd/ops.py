@@ -39,6 +39,50 @@ def workspace(nbytes: int, device, arena=None) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------------------
+# roctx ranges (PCRL_TRACE_RANGES=1): forward / backward / optimizer / bucket all-reduce show up as named ranges in a
+# `rocprofv3 --kernel-trace --marker-trace` run (the reference has only wall-clock BT/DT meters, train_3d.py:102-103).  Off by default:
+# a range costs two library calls per use.
+# ----------------------------------------------------------------------------------------------
+TRACE_RANGES = os.environ.get("PCRL_TRACE_RANGES", "0") == "1"
+_roctx = None
+
+
+def _roctx_lib():
+    global _roctx
+    if _roctx is None:
+        import ctypes
+        _roctx = False
+        for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):      # the SDK's library is the one rocprofv3 listens to
+            try:
+                lib_ = ctypes.CDLL(name)
+                lib_.roctxRangePushA.argtypes = [ctypes.c_char_p]
+                lib_.roctxRangePushA.restype = ctypes.c_int
+                lib_.roctxRangePop.restype = ctypes.c_int
+                _roctx = lib_
+                break
+            except OSError:
+                continue
+    return _roctx
+
+
+class trace_range:
+    """`with trace_range("backward"):` -- a roctx range around the enqueue of a phase (no-op unless PCRL_TRACE_RANGES=1)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        self.on = TRACE_RANGES and _roctx_lib()
+        if self.on:
+            _roctx.roctxRangePushA(("pcrl:" + self.name).encode())
+
+    def __exit__(self, *exc):
+        if self.on:
+            _roctx.roctxRangePop()
+        return False
+
+
+# ----------------------------------------------------------------------------------------------
 # side stream for the weight gradients
 # ----------------------------------------------------------------------------------------------
 # In backward a layer's weight gradient (MFMA-bound) has no consumer until the optimizer step, while the chain that everything else
@@ -152,6 +196,71 @@ def throttle_host(device, step_done=False):
     else:
         while len(q) >= lag:
             q.popleft().synchronize()
+
+
+# ---- allocator provisioning (config.PROVISION_FACTOR) ----
+# The step runs on three streams and the host runs up to MAX_STEPS_AHEAD steps ahead of the GPU.  torch's caching allocator keeps a pool PER
+# STREAM, and a block whose last use was recorded on another stream (record_stream: the operands of side-stream weight gradients, the second
+# view's inputs) only returns to its pool when the GPU has got there -- up to two steps later.  Left alone the pools grow by a few hipMalloc
+# per step (each a device-wide stall) for the first 15-25 steps until every stream's pool holds enough blocks for the whole run-ahead window:
+# with the driver's `--warmup 5` that growth was inside the timed region (23 mallocs in 20 steps, 31-36 ms step times).  Instead the engine
+# sizes the pools ONCE, after the first complete step of a (model, batch shape): every segment the first step left in a stream's pool is
+# duplicated PROVISION_FACTOR - 1 times on the same stream (288 GB of HBM: the 3x of a 13 GB peak is nothing), so the steady state is there
+# from step 2.  One device synchronisation, once.
+_provisioned: set = set()
+_provisioned_segments: set = set()     # (device, address) of the segments that existed after the last provisioning: only NEW ones are duplicated
+
+
+def provision_allocator(device, key=None):
+    f = config.PROVISION_FACTOR
+    if f <= 1 or device.type != "cuda" or (device.index, key) in _provisioned:
+        return
+    _provisioned.add((device.index, key))
+    torch.cuda.synchronize(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    segs = [s for s in torch.cuda.memory_snapshot() if s["device"] == idx and (idx, s["address"]) not in _provisioned_segments]
+    free_b, total_b = torch.cuda.mem_get_info(device)
+    want = sum(s["total_size"] for s in segs) * (f - 1)
+    if want > 0.5 * free_b:           # never provision a box into memory pressure: scale the copies down
+        f = 1 + int((f - 1) * 0.5 * free_b / max(want, 1))
+        if f <= 1:
+            return
+    streams = {}
+    for st in [torch.cuda.current_stream(device)] + list(_side_streams.values()) + list(_view_streams.values()):
+        streams[st.cuda_stream] = st
+    hold = []
+    by_stream = collections.defaultdict(list)
+    for s in segs:
+        by_stream[s["stream"]].append(s)
+    for sid, lst in by_stream.items():
+        st = streams.get(sid)
+        if st is None:          # the null stream / a stream this module does not own (RCCL, data-parallel wrapper): leave its pool alone
+            continue
+        with torch.cuda.stream(st):
+            # (1) occupy what the pool holds now, so that (2) has to come from the device
+            for s in lst:
+                for blk in s["blocks"]:
+                    if blk["state"] == "inactive" and blk["size"] >= 512:
+                        try:
+                            hold.append(torch.empty(blk["size"], dtype=torch.uint8, device=device))
+                        except RuntimeError:
+                            pass
+            # (2) f - 1 more segments of every size.  Small-pool segments (2 MB) are filled with two 1 MB - 512 B requests each.
+            for s in lst:
+                for _ in range(f - 1):
+                    try:
+                        if s["segment_type"] == "small":
+                            hold.append(torch.empty((1 << 20) - 512, dtype=torch.uint8, device=device))
+                            hold.append(torch.empty((1 << 20) - 512, dtype=torch.uint8, device=device))
+                        else:
+                            hold.append(torch.empty(s["total_size"], dtype=torch.uint8, device=device))
+                    except RuntimeError:
+                        break
+    del hold
+    torch.cuda.synchronize(device)
+    for s in torch.cuda.memory_snapshot():
+        if s["device"] == idx:
+            _provisioned_segments.add((idx, s["address"]))
 
 
 # ---- the second global view on its own stream (config.VIEW_STREAMS) ----
@@ -676,6 +785,13 @@ class ComposedUpConv(_CacheGuard):
         if key != self.key:
             L, s, dev = lib(), stream_handle(), w_up.device
             Ci, Cm, Co = w_up.shape[0], w_up.shape[1], w0.shape[0]
+            if self.key is not None and key[:-1] == self.key[:-1]:
+                # same weights, a later pass of the step (another shape) needs more weight forms: a pass on another stream may still be READING
+                # the tensors this rebuild drops -- keep the allocator from recycling them under it
+                for t in (self.wf, self.wd, self.w3f, self.wd3, self.bias_tab):
+                    if t is not None:
+                        for st in list(_side_streams.values()) + list(_view_streams.values()):
+                            t.record_stream(st)
             if w0.shape[1] != Cm:
                 raise PcrlError(f"composed up-conv: up_conv has {Cm} output channels, conv1 expects {w0.shape[1]}")
             self.wf = torch.empty(64 * Ci * Co, dtype=dtype, device=dev)

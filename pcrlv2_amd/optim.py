@@ -56,6 +56,7 @@ class FusedSGD(torch.optim.SGD):
         self._flag_cache = {}
         self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
         self.pre_step = None           # optional callable(self, None) -> has-grad list: replaces the gradient gather (ddp.DataParallel)
+        self.skip_flag = None          # float32[1] on the device, consumed by the NEXT step(): non-zero = leave parameters and momentum untouched
         ops.bump_weights_epoch()
 
     # ------------------------------------------------------------------
@@ -113,9 +114,18 @@ class FusedSGD(torch.optim.SGD):
         else:
             has = self.gather_grads()
         flags = self._flags(has)
-        lib().call("pcrl_sgd_step", self.flat_p, self.flat_g, self.flat_buf, self._offsets, flags, len(self._plist),
-                   self._total, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(self.grad_scale),
-                   stream_handle())
+        skip, self.skip_flag = self.skip_flag, None
+        if skip is None:
+            lib().call("pcrl_sgd_step", self.flat_p, self.flat_g, self.flat_buf, self._offsets, flags, len(self._plist),
+                       self._total, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(self.grad_scale),
+                       stream_handle())
+        else:
+            # the divergence guard decided on the device (train_3d.train_step): a skipped update leaves the arenas bit-unchanged.  The host-side
+            # "momentum initialised" marks below are set either way; the buffers start as zeros, so momentum * 0 + g == g and a first update
+            # that happens one step later is the same arithmetic.
+            lib().call("pcrl_sgd_step_guarded", self.flat_p, self.flat_g, self.flat_buf, self._offsets, flags, len(self._plist),
+                       self._total, float(g["lr"]), float(g["momentum"]), float(g["weight_decay"]), float(self.grad_scale), skip,
+                       stream_handle())
         for i, (p, h) in enumerate(zip(self._plist, has)):
             if h and not self._initialised[i]:
                 self._initialised[i] = True

@@ -88,19 +88,20 @@ def train_pcrlv2(args, data_loader, out_channel=3):
     if getattr(args, "amp", False):
         model.set_compute_dtype(torch.bfloat16)
     optimizer = FusedSGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
-    if distributed:
-        _ddp.DataParallel(model, optimizer)
-    criterion, cosine = MSELoss2d().cuda(), CosineSimilarityMean().cuda()
     first_epoch = 0
     if getattr(args, "resume", None):
+        # BEFORE the data-parallel wrapper is built: its initial broadcast then carries the resumed state from rank 0 to every rank
         ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
         model.model.encoder.load_state_dict(ckpt["state_dict"])
         try:
             optimizer.load_state_dict(ckpt["optimizer"])
-        except Exception as e:       # a checkpoint of another parameter list: keep fresh momentum
-            if chatty:
-                print("==> optimizer state not restored:", e)
+        except (ValueError, KeyError) as e:       # a checkpoint of another parameter list (group / size mismatch): keep fresh momentum, say so on EVERY rank
+            print("==> [rank {}] optimizer state not restored: {}".format(rank, e))
         first_epoch = int(ckpt.get("epoch", -1)) + 1
+    if distributed:
+        _ddp.DataParallel(model, optimizer)
+    criterion, cosine = MSELoss2d().cuda(), CosineSimilarityMean().cuda()
+    if getattr(args, "resume", None):
         if chatty:
             print("==> resumed the ENCODER from {} (the 2D checkpoint layout holds nothing else); continuing with epoch {}".format(args.resume, first_epoch))
     for epoch in range(first_epoch, args.epochs + 1):

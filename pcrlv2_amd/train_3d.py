@@ -10,8 +10,13 @@ assembly, LR schedule, log line, checkpoint dict and file name.  Differences, al
     or plain `python main.py ...` for one GPU.  `--b` is the PER-PROCESS batch (the reference splits a global batch);
   * meters hold device scalars and are read only when the log line is printed: a step does not synchronise the GPU
     (the reference calls .item() twice and cuda.synchronize() every iteration);
-  * the divergence guard (train_3d.py:140-142) is evaluated as `epoch > 10 and loss > 1000`, so the device->host read
-    happens only when the reference would act on it;
+  * the divergence guard (train_3d.py:140-142, `loss > 1000 and epoch > 10`) is decided ON THE DEVICE by default: a flag kernel,
+    MAX-all-reduced under data parallelism, consumed by the SGD kernel (parameters and momentum stay bit-unchanged when it is set) --
+    epochs 11..240 run without the forward -> backward host synchronisation the reference's `if loss > 1000` implies.  A skipped
+    step still runs its backward (wasted work on a rare event) and its `.grad`s are this step's instead of the previous step's
+    (nobody reads them: the next step starts with zero_grad); meters and the "skip the step" line are settled when the log line is
+    printed.  PCRL_GUARD_SYNC=1 (or train_step(guard="sync")) restores the reference's host-side decision: the step returns None
+    before zero_grad / backward / step;
   * `--seed`, ignored by the reference (SURVEY Q5), seeds python `random` (the scale draws) and torch;
   * `--resume CKPT` (not in the reference, which only saves): restores model, momentum buffers and epoch from a checkpoint of
     the layout above -- written by this engine or by the reference -- and continues with the next epoch.
@@ -48,6 +53,7 @@ class MSELoss:
         return mse_loss(pred, target)
 
 
+COS_MAX_TERMS = 32   # csrc/heads_loss.hip
 FUSED_COS_LOSSES = os.environ.get("PCRL_FUSED_COS", "1") != "0"   # all 26 cosine means of a step in one launch (0: one launch per mean)
 
 
@@ -116,7 +122,9 @@ def step_losses(model, batch, epoch, criterion, cosine):
     view1, view2, target, _unused_gt2, local_views = batch              # gt2 is never used by the reference either (Q3)
     n = view1.size(0)
     target = _to_gpu(target)
-    fused = getattr(cosine, "fusable", False) and FUSED_COS_LOSSES
+    # all cosine means of the step in one launch -- pcrl_cosine_terms_* takes up to 32 terms (2 + 4 per local view: up to 7 local views; the
+    # reference's loop accepts any number): beyond that the step falls back to one launch per mean, same arithmetic
+    fused = getattr(cosine, "fusable", False) and FUSED_COS_LOSSES and 2 + 4 * len(local_views) <= COS_MAX_TERMS
     view1, view2 = _to_gpu(view1), _to_gpu(view2)
     _ops.fork_views(view1.device)  # config.VIEW_STREAMS: the second view's forward (and backward) on its own stream, next to the first's
     with _ops.deferred_join():     # the decoder stages' side branches (heads, deep-supervision maps) also run under the NEXT forward; joined on exit
@@ -154,27 +162,60 @@ def begin_step():
     _fn.reset_parked()
 
 
+GUARD_THRESHOLD = 1000.0   # train_3d.py:140
+GUARD_FIRST_EPOCH = 11     # `epoch > 10`
+GUARD_SYNC = os.environ.get("PCRL_GUARD_SYNC", "0") == "1"
+
+
+class StepLosses(tuple):
+    """(loss, loss1, loss2, loss4, local_loss) as detached device scalars, plus `.skipped`: None, or the device flag (float32[1]) of the
+    divergence guard -- 1 when the update of this step was skipped on the device."""
+    skipped = None
+
+
+def divergence_flag(loss, group=None):
+    """float32[1] on loss's device: 1 if loss > 1000 on ANY rank (the reference is one process with one loss and one decision; with one
+    process per GPU the decision must be collective -- a rank that skipped alone would leave its peers waiting in the gradient all-reduce)."""
+    flag = torch.empty(1, dtype=torch.float32, device=loss.device)
+    if loss.is_cuda:
+        _ops.lib().call("pcrl_guard_flag", loss.detach().float().reshape(1), GUARD_THRESHOLD, flag, _ops.stream_handle())
+    else:       # host tensors (the gloo tests of the collective form): same predicate
+        flag[0] = 1.0 if float(loss) > GUARD_THRESHOLD else 0.0
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return flag
+
+
 def train_step(model, optimizer, batch, epoch, criterion, cosine, guard=True):
-    """One iteration of train_3d.py:113-151.  Returns (loss, loss1, loss2, loss4, local_loss) as detached device
-    scalars, or None when the divergence guard skipped the update."""
+    """One iteration of train_3d.py:113-151.  Returns StepLosses (loss, loss1, loss2, loss4, local_loss: detached device scalars).
+    Divergence guard (epoch > 10, loss > 1000): by default decided on the device -- the returned `.skipped` flag says whether the SGD
+    kernel left the parameters alone; with guard="sync" (PCRL_GUARD_SYNC=1) on the host like the reference -- None is returned before
+    zero_grad / backward / step.  guard=False: no guard."""
     begin_step()            # forward-pass numbering / parked-gradient state start clean even after a skipped or failed step
     dev = next(model.parameters()).device
     _ops.throttle_host(dev)      # at most config.MAX_STEPS_AHEAD steps of run-ahead (allocator footprint, see config.py)
-    losses = step_losses(model, batch, epoch, criterion, cosine)
-    if guard and epoch > 10:
-        # The reference is one process (nn.DataParallel): one loss, one decision.  With one process per GPU the decision must be
-        # COLLECTIVE -- a rank that skipped alone would never enter the gradient all-reduce its peers wait in.
-        diverged = (losses[0].detach() > 1000).to(torch.float32)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(diverged, op=dist.ReduceOp.MAX)
-        if bool(diverged):
-            print('skip the step')
-            return None
+    with _ops.trace_range("forward"):
+        losses = step_losses(model, batch, epoch, criterion, cosine)
+    flag = None
+    if guard and epoch >= GUARD_FIRST_EPOCH:
+        flag = divergence_flag(losses[0])
+        if guard == "sync" or GUARD_SYNC:
+            if bool(flag):       # device -> host read: the reference's semantics, and its synchronisation
+                print('skip the step')
+                return None
+            flag = None
     optimizer.zero_grad()
-    losses[0].backward()
-    optimizer.step()
+    with _ops.trace_range("backward"):
+        losses[0].backward()
+    optimizer.skip_flag = flag
+    with _ops.trace_range("optimizer"):
+        optimizer.step()
     _ops.throttle_host(dev, step_done=True)
-    return tuple(l.detach() for l in losses)
+    # first complete step of this batch shape: size the allocator's per-stream pools for the steady state, once (ops.provision_allocator)
+    _ops.provision_allocator(dev, key=("3d", tuple(batch[0].shape), len(batch[4])))
+    out = StepLosses(l.detach() for l in losses)
+    out.skipped = flag
+    return out
 
 
 def _checkpoint_name(args, epoch):
@@ -203,15 +244,15 @@ def train_pcrlv2_3d(args, data_loader, out_channel=3):
     if getattr(args, "amp", False):
         model.set_compute_dtype(torch.bfloat16)
     optimizer = FusedSGD(model.parameters(), lr=args.lr, momentum=args.momentum, weight_decay=args.weight_decay)
-    if distributed:
-        _ddp.DataParallel(model, optimizer)          # hooks itself into optimizer.step()
-    criterion, cosine = MSELoss().cuda(), CosineSimilarityMean().cuda()
     chatty = rank == 0
     first_epoch = 0
-    if getattr(args, "resume", None):
+    if getattr(args, "resume", None):       # before the data-parallel wrapper: its initial broadcast carries rank 0's resumed state to every rank
         first_epoch = load_checkpoint(args.resume, model, optimizer) + 1
         if chatty:
             print("==> resumed from {} (continuing with epoch {})".format(args.resume, first_epoch))
+    if distributed:
+        _ddp.DataParallel(model, optimizer)          # hooks itself into optimizer.step()
+    criterion, cosine = MSELoss().cuda(), CosineSimilarityMean().cuda()
 
     for epoch in range(first_epoch, args.epochs + 1):          # inclusive upper bound, like the reference (Q1): lr reaches 0 in the last epoch
         adjust_learning_rate(epoch, args, optimizer)
@@ -233,19 +274,29 @@ def train_pcrlv2_inner(args, epoch, train_loader, model, optimizer, criterion, c
     """One epoch (train_3d.py:95-173).  Returns (mean restoration loss, mean local loss)."""
     model.train()
     meters = {k: AverageMeter() for k in ("bt", "dt", "cos", "mg", "local")}
+    skipped_flags = []
     tick = time.time()
     for it, batch in enumerate(train_loader, start=1):
         meters["dt"].update(time.time() - tick)
         out = train_step(model, optimizer, batch, epoch, criterion, cosine)
-        if out is None:
+        if out is None:         # host-side guard (PCRL_GUARD_SYNC=1): the reference's `continue`
             continue
         n = batch[0].size(0)
+        if out.skipped is not None:
+            # guard decided on the device: a skipped step must not enter the meters (the reference `continue`s before them) -- its weight is
+            # n * (1 - skipped), a device scalar; the "skip the step" lines are printed when the flags are read, with the log line
+            n = n * (1.0 - out.skipped.reshape(()))
+            skipped_flags.append(out.skipped)
         meters["mg"].update(out[1], n)
         meters["cos"].update(out[2], n)
         meters["local"].update(out[4], n)
         log_now = it % 10 == 0
         if log_now:
             torch.cuda.synchronize()
+            if skipped_flags and verbose:
+                for _ in range(int(torch.cat(skipped_flags).sum().item())):
+                    print('skip the step')
+            skipped_flags.clear()
         meters["bt"].update(time.time() - tick)
         tick = time.time()
         if log_now and verbose:

@@ -10,20 +10,51 @@ def adjust_learning_rate(epoch, args, optimizer):
 
 
 class AverageMeter(object):
-    """Running value / average, utils.py:117-137.  Values may be python numbers or 0-d device tensors;
-    tensors are only converted when read (`float(meter.val)`), so updating never synchronises the GPU."""
+    """Running value / average, utils.py:117-137 (`val`, `avg`, `sum`, `count`).  Values and weights may be python numbers or 0-d device
+    tensors.  Device values are only QUEUED by update(): the running sum is formed when `avg` / `sum` / `count` is read (one stack + one
+    weighted sum for everything queued), so a training step launches nothing for its meters and never synchronises the GPU."""
 
     def __init__(self):
         self.reset()
 
     def reset(self):
         self.val = 0
-        self.avg = 0
-        self.sum = 0
-        self.count = 0
+        self._sum = 0
+        self._count = 0
+        self._queue = []
 
     def update(self, val, n=1):
         self.val = val
-        self.sum = self.sum + val * n
-        self.count += n
-        self.avg = self.sum / self.count
+        if hasattr(val, "is_cuda") or hasattr(n, "is_cuda"):
+            self._queue.append((val, n))
+        else:
+            self._sum = self._sum + val * n
+            self._count += n
+
+    def _settle(self):
+        if self._queue:
+            import torch
+            dev = next(t.device for pair in self._queue for t in pair if hasattr(t, "is_cuda"))
+            as_t = lambda v: v.detach().reshape(()).to(torch.float32) if hasattr(v, "is_cuda") else torch.tensor(float(v), device=dev)
+            vals = torch.stack([as_t(v) for v, _ in self._queue])
+            ns = torch.stack([as_t(n) for _, n in self._queue])
+            self._sum = self._sum + (vals * ns).sum()
+            self._count = self._count + ns.sum()
+            self._queue = []
+
+    @property
+    def sum(self):
+        self._settle()
+        return self._sum
+
+    @property
+    def count(self):
+        self._settle()
+        return self._count
+
+    @property
+    def avg(self):
+        self._settle()
+        if isinstance(self._count, (int, float)) and not self._count:
+            return 0
+        return self._sum / self._count

@@ -384,3 +384,46 @@ def test_composed_upconv_algebra_in_float64():
                 bias += w0[:, :, td, th, tw] @ bup
         out[:, :, fd, fh, fw] += bias
     assert torch.allclose(out, ref, rtol=1e-12, atol=1e-12), float((out - ref).abs().max())
+
+
+GUARD_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from pcrlv2_amd.ddp import init_process_group_from_env
+from pcrlv2_amd.train_3d import divergence_flag
+rank, world, _ = init_process_group_from_env("gloo")
+# only rank 1 diverges (loss > 1000): the decision is collective, both ranks hold flag 1 and would skip together
+f = divergence_flag(torch.tensor(2.5e3 if rank == 1 else 0.7))
+assert f.shape == (1,) and float(f) == 1.0, (rank, f)
+# nobody diverges: flag 0 on both; exactly 1000 is not "> 1000" (train_3d.py:140)
+assert float(divergence_flag(torch.tensor(1000.0))) == 0.0
+# NaN > 1000 is False in the reference as well: a NaN loss does not trip the guard
+assert float(divergence_flag(torch.tensor(float("nan")))) == 0.0
+dist.barrier()
+print("OK", rank)
+'''
+
+
+def test_divergence_guard_decision_is_collective_gloo_world2(tmp_path):
+    """train_3d.py:140-142 under one process per GPU: a rank that skipped alone would leave its peers in the gradient all-reduce."""
+    script = tmp_path / "g.py"
+    script.write_text(GUARD_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29735", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("OK" in o for o in outs)
+
+
+def test_rank_cpu_binding_helpers():
+    """ddp.bind_rank_to_numa's pure parts: sysfs cpulist parsing and the even split of a NUMA node's CPUs among the ranks on it."""
+    from pcrlv2_amd.ddp import cpu_share, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert parse_cpulist("5") == [5]
+    node = list(range(0, 64)) + list(range(128, 192))           # one socket of a 2 x 64-core SMT box
+    allowed = set(range(256))
+    shares = [cpu_share(node, allowed, 4, k) for k in range(4)]
+    assert all(len(s) == 32 for s in shares) and len(set(c for s in shares for c in s)) == 128      # disjoint, whole node
+    assert cpu_share(node, {1, 2, 3}, 4, 3) == [1, 2, 3]        # fewer CPUs than ranks: share the pool rather than starve a rank
+    assert cpu_share([], {4, 5, 6, 7}, 2, 1) == [6, 7]          # unknown node: even split of what is allowed

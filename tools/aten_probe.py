@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Which host lines still launch ATen / runtime kernels inside a training step (everything else goes through libpcrl_hip.so).
+
+    python tools/aten_probe.py [--b 32]
+
+Runs a few warm steps, then one step under torch.profiler (CPU activity with python stacks) and prints every aten:: operator that
+launched a device kernel or copy, with its count and the innermost pcrlv2_amd frame."""
+import argparse
+import collections
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--b", type=int, default=32)
+    args = ap.parse_args()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from pcrlv2_amd.models import PCRLv23d
+    from pcrlv2_amd.optim import FusedSGD
+    from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    random.seed(0)
+    model = PCRLv23d().to(dev).train()
+    model.set_compute_dtype(torch.bfloat16)
+    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    batch = bench.synthetic_batch(args.b, (64, 64, 32), 16, dev, 1234)
+    crit, cosine = MSELoss(), CosineSimilarityMean()
+    for _ in range(4):
+        train_step(model, opt, batch, 0, crit, cosine, guard=False)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        train_step(model, opt, batch, 0, crit, cosine, guard=False)
+        torch.cuda.synchronize()
+    agg = collections.Counter()
+    for ev in prof.events():
+        if not ev.name.startswith("aten::") or not ev.kernels:
+            continue
+        site = "?"
+        for fr in ev.stack:
+            if "pcrlv2_amd" in fr or "bench.py" in fr:
+                site = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr
+                break
+        agg[(ev.name, site, ev.kernels[0].name[:50])] += 1
+    tot = 0
+    for (name, site, k), n in sorted(agg.items(), key=lambda kv: -kv[1]):
+        print(f"{n:4d}  {name:28s} {k:52s} {site}")
+        tot += n
+    print("total ATen ops that launched device work in one step:", tot)
+
+
+if __name__ == "__main__":
+    main()
