@@ -95,3 +95,19 @@ COMPOSE_UPCONV = os.environ.get("PCRL_COMPOSE_UPCONV", "1") != "0"
 # across the two-step run-ahead window) needs no hipMalloc later -- the timed region of a short benchmark run (`--warmup 5`) otherwise holds
 # a few device mallocs per step.  1: off.
 PROVISION_FACTOR = int(os.environ.get("PCRL_PROVISION_FACTOR", "3"))
+
+# EXPERIMENT, measured and NOT kept (default off; kept as switches because the result is instructive -- DESIGN.md section 5).
+# Idea: two streams that run the SAME layer sequence from the same start fall into lockstep -- both convolutions side by side, then both
+# BatchNorm passes side by side -- so HBM-bound passes never run under the other pass's matrix work (rocprofv3 timeline: 7.6 ms per step with
+# only HBM-bound kernels in flight).  INTERLEAVE_VIEWS: the three forwards are enqueued stage by stage in rotation (PCRLv23d.forward_views:
+# view 1, view 2, local views, each on its own stream), so the backward replays in the same rotation.  MFMA_TOKEN: every large matrix kernel
+# (>= MFMA_TOKEN_MIN_GF GFLOP) waits for the previous large matrix kernel of another stream (ops.mfma_turn): one matrix kernel at a time, in
+# enqueue order, HBM-bound passes under it.  Results bit-identical (tests).  Same-box A/B, 15 steps x 2 rounds: baseline 33.53 ms; interleave
+# alone 34.39; interleave + token 37.13; token alone 38.54; token only >= 60 GFLOP 35.59.  Why: (a) a cross-stream event wait in front of
+# ~150 kernels per step exposes the queue-to-queue signalling latency each time; (b) two matrix kernels side by side are ~10 % FASTER than
+# back to back (the co-scheduled blocks fill each other's barrier / staging stalls: one kernel alone keeps the MFMA pipe 56 % busy), so
+# serialising them gives up more than the hidden BatchNorm passes return; (c) step time tracks the SUM of kernel time (a step whose
+# draws leave view 2's 64-channel scale without a gradient skips 3.4 ms of kernels and is 3 ms shorter), i.e. the chip is throughput-bound.
+INTERLEAVE_VIEWS = os.environ.get("PCRL_INTERLEAVE", "0") == "1"
+MFMA_TOKEN = os.environ.get("PCRL_MFMA_TOKEN", "0") == "1"
+MFMA_TOKEN_MIN_GF = float(os.environ.get("PCRL_MFMA_TOKEN_MIN_GF", "20"))

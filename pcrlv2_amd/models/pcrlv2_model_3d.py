@@ -247,32 +247,87 @@ class PCRLv23d(nn.Module):
                 masks.append(mask if factor == 1 else ops.upsample_forward(mask, factor))
         return ops.conv1x1_to1_forward(ops.to_act(h, dt), self.out_tr.final_conv.weight, self.out_tr.final_conv.bias, dt), feats, masks
 
+    def _train_stages(self, x, local, pass_idx):
+        """The training-mode forward as a generator: yields after every stage's kernels are enqueued (eleven stops), returns the forward's
+        result.  `forward` runs it to the end; `forward_views` advances several of them in rotation, each under its own stream."""
+        mods = self._stage_modules()
+
+        def mine():          # the stage Functions read the pass number off their module at forward time
+            for m in mods:
+                m._pass_idx = pass_idx
+
+        h, pooled = x, None
+        for i, ((name, _, _), attr) in enumerate(zip(_ENCODER, _SKIPS)):
+            stage = getattr(self, name)
+            mine()
+            h = h if i == 0 else (pooled if pooled is not None else self.maxpool(h))
+            last = stage.ops[1]
+            if config.FOLD_POOL_GRAD and i + 1 < len(_ENCODER) and not last._gn_groups:
+                # stage output and `self.maxpool` of it (:115-117) as one node: the pool's backward folds into the BatchNorm backward
+                a = stage.ops[0](h)
+                yield
+                mine()
+                h, pooled = last.forward_pooled(a)
+            else:
+                h, pooled = stage(h), None
+            setattr(self, attr, h)          # the reference keeps these alive as attributes; the skips are never consumed (D6)
+            yield
+        middle_features, middle_masks = [], []
+        for (name, _, _), factor in zip(_DECODER, _UPSAMPLE):
+            mine()
+            h, pro, pre, mask = getattr(self, name)(h)
+            middle_features.append([pro, pre])
+            if not local:
+                middle_masks.append(mask if factor == 1 else Fn.TrilinearFn.apply(mask, factor))
+            yield
+        mine()
+        out = self.out_tr(h)
+        return out, middle_features, middle_masks
+
     def forward(self, x, local=False):
         """-> (out [b,1,D,H,W], [[pro, pre] x 3 scales], [mask x 3] or [] when local)"""
         if not x.is_cuda:
             raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
         if not self.training:
             return self._forward_eval(x, local)
-        pass_idx = ops.next_pass()          # 0 = first forward since the last optimizer step (its backward runs last)
-        for m in self._stage_modules():
-            m._pass_idx = pass_idx
-        h, pooled = x, None
-        for i, ((name, _, _), attr) in enumerate(zip(_ENCODER, _SKIPS)):
-            stage = getattr(self, name)
-            h = h if i == 0 else (pooled if pooled is not None else self.maxpool(h))
-            last = stage.ops[1]
-            if config.FOLD_POOL_GRAD and i + 1 < len(_ENCODER) and not last._gn_groups:
-                # stage output and `self.maxpool` of it (:115-117) as one node: the pool's backward folds into the BatchNorm backward
-                h, pooled = last.forward_pooled(stage.ops[0](h))
-            else:
-                h, pooled = stage(h), None
-            setattr(self, attr, h)          # the reference keeps these alive as attributes; the skips are never consumed (D6)
-        middle_features, middle_masks = [], []
-        for (name, _, _), factor in zip(_DECODER, _UPSAMPLE):
-            h, pro, pre, mask = getattr(self, name)(h)
-            middle_features.append([pro, pre])
-            if not local:
-                middle_masks.append(mask if factor == 1 else Fn.TrilinearFn.apply(mask, factor))
-        out = self.out_tr(h)
+        gen = self._train_stages(x, local, ops.next_pass())     # pass 0 = first forward since the last optimizer step (its backward runs last)
+        try:
+            while True:
+                next(gen)
+        except StopIteration as done:
+            result = done.value
         ops.end_of_forward_join()           # the stages' side branches (config.FWD_BRANCH_STREAM) are complete when the outputs are handed out
-        return out, middle_features, middle_masks
+        return result
+
+    def forward_views(self, views):
+        """Several training-mode forwards enqueued stage by stage in rotation (engine API, not in the reference): `views` = [(x, local, stream
+        name | None), ...] -> [forward(x, local) for each], as if called one after the other in that order -- same kernels, same results, same
+        order of the running-statistics updates (ops.order_rmw) -- but the autograd graphs interleave, so the backward replays the passes in
+        rotation too, and each pass runs on the view stream of its name (ops.fork_views must have been called; None = the current stream).
+        With config.MFMA_TOKEN the HBM-bound passes of one view then run under the convolutions of the others (config.py)."""
+        if not self.training:
+            return [self.forward(x, local) for x, local, _ in views]
+        runs = []
+        for x, local, name in views:
+            if not x.is_cuda:
+                raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
+            st = ops.view_stream(x.device, name) if name else None
+            if st is not None:
+                x.record_stream(st)
+            runs.append([self._train_stages(x, local, ops.next_pass()), st, None, False])
+        alive = len(runs)
+        while alive:
+            for r in runs:
+                if r[3]:
+                    continue
+                try:
+                    if r[1] is not None:
+                        with torch.cuda.stream(r[1]):
+                            next(r[0])
+                    else:
+                        next(r[0])
+                except StopIteration as done:
+                    r[2], r[3] = done.value, True
+                    alive -= 1
+        ops.end_of_forward_join()
+        return [r[2] for r in runs]

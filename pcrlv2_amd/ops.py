@@ -198,6 +198,37 @@ def throttle_host(device, step_done=False):
             q.popleft().synchronize()
 
 
+# ---- one large matrix kernel at a time (config.MFMA_TOKEN) ----
+_mfma_last: dict = {}      # device index -> (event recorded behind the last large matrix kernel, stream it ran on)
+
+
+class mfma_turn:
+    """`with mfma_turn(device, flops):` around the launch of a matrix kernel on the CURRENT stream.  If the kernel is large it first waits
+    for the previous large matrix kernel launched on another stream (an event wait on the device, nothing on the host) and leaves its own
+    event behind: large matrix kernels of all streams run one at a time, in enqueue order (config.MFMA_TOKEN explains why)."""
+    __slots__ = ("dev", "on")
+
+    def __init__(self, device, flops):
+        self.dev = device
+        self.on = config.MFMA_TOKEN and _views_active and device.type == "cuda" and flops >= config.MFMA_TOKEN_MIN_GF * 1e9
+
+    def __enter__(self):
+        if self.on:
+            last = _mfma_last.get(self.dev.index)
+            if last is not None:
+                cur = torch.cuda.current_stream(self.dev)
+                if last[1] != cur.cuda_stream:
+                    cur.wait_event(last[0])
+
+    def __exit__(self, *exc):
+        if self.on:
+            cur = torch.cuda.current_stream(self.dev)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            _mfma_last[self.dev.index] = (ev, cur.cuda_stream)
+        return False
+
+
 # ---- allocator provisioning (config.PROVISION_FACTOR) ----
 # The step runs on three streams and the host runs up to MAX_STEPS_AHEAD steps ahead of the GPU.  torch's caching allocator keeps a pool PER
 # STREAM, and a block whose last use was recorded on another stream (record_stream: the operands of side-stream weight gradients, the second
@@ -265,7 +296,8 @@ def provision_allocator(device, key=None):
 
 # ---- the second global view on its own stream (config.VIEW_STREAMS) ----
 _view_streams: dict = {}
-VIEW_STREAM_NAMES = tuple(n for n in os.environ.get("PCRL_VIEW_STREAM_NAMES", "view2").split(",") if n)   # "view2,local": the local views' pass too (experiment)
+# "view2,local" with config.INTERLEAVE_VIEWS (every pass of the round-robin on its own stream), else "view2" (the local views' pass on the main stream)
+VIEW_STREAM_NAMES = tuple(n for n in os.environ.get("PCRL_VIEW_STREAM_NAMES", "view2,local" if config.INTERLEAVE_VIEWS else "view2").split(",") if n)
 _views_active = False        # set while a step uses the view stream: the cross-stream guards below are then live
 _rmw_events: dict = {}
 
@@ -288,6 +320,13 @@ def fork_views(device, path2d=False):
             vs = _view_streams[key] = torch.cuda.Stream(device=device)
         vs.wait_stream(torch.cuda.current_stream(device))
     _views_active = True
+
+
+def view_stream(device, name, path2d=False):
+    """The stream of pass `name` while a step uses view streams (fork_views was called), else None (= the current stream)."""
+    if not (_views_active and view_streams_on(device, path2d) and name in VIEW_STREAM_NAMES):
+        return None
+    return _view_streams[(device.type, device.index, name)]
 
 
 class view_pass:
@@ -617,8 +656,9 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         y = new_act(N, D, H, W, Co, dtype, dev)
         partial = _f32(rows * Co * 2, dev) if training else None
         nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
-        L.call("pcrl_conv3d_k3_fwd_ws", x, wf, conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb, N, D, H, W, Ci, Co,
-               dtype_code(dtype), s)
+        with mfma_turn(dev, 54.0 * M * Ci * Co):
+            L.call("pcrl_conv3d_k3_fwd_ws", x, wf, conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb, N, D, H, W, Ci, Co,
+                   dtype_code(dtype), s)
         mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, training)
         if pooled and config.FUSE_APPLY_CONSUMERS and bn_pool_ok(D, H, W, Co, dtype):
             a, p = torch.empty_like(y), new_act(N, D // 2, H // 2, W // 2, Co, dtype, dev)
@@ -688,7 +728,8 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
         return None, dw, db, dgamma, dbeta
     nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
     with side_wgrad(dev, sv.x, dy) as ws:
-        L.call("pcrl_conv3d_k3_wgrad", sv.x, dy, dw, ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
+        with mfma_turn(dev, 54.0 * M * Ci * Co):
+            L.call("pcrl_conv3d_k3_wgrad", sv.x, dy, dw, ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
     dx = None
     if need_dx:
         _, wd = packed.get(conv_w, dtype)
@@ -698,7 +739,8 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
         if dx_colsum is not None:
             rows = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Co, Ci, dtype_code(dtype))
             part = _f32(rows * Ci * 2, dev)
-        L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, part, workspace(nb, dev) if nb else None, nb, N, D, H, W, Co, Ci, dtype_code(dtype), s)
+        with mfma_turn(dev, 54.0 * M * Ci * Co):
+            L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, part, workspace(nb, dev) if nb else None, nb, N, D, H, W, Co, Ci, dtype_code(dtype), s)
         if part is not None:   # [rows][Ci][2] -> column sums; the (sum) entries are the even columns
             both = _f32(Ci * 2, dev)
             nb2 = L.call("pcrl_colsum_ws_bytes", rows, Ci * 2)
@@ -821,8 +863,9 @@ class ComposedUpConv(_CacheGuard):
             _pending_composed.append(self)
         nb = L.call("pcrl_upconv_wgrad_accum_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
         with side_wgrad(dev, x, dy) as ws:
-            L.call("pcrl_upconv_wgrad_accum", x, dy, self.dweff, self.box, (1 if first else 0) | (2 if zero_sum else 0), ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype),
-                   stream_handle())
+            with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
+                L.call("pcrl_upconv_wgrad_accum", x, dy, self.dweff, self.box, (1 if first else 0) | (2 if zero_sum else 0), ws(nb), nb, N, D, H, W, Ci, Co,
+                       dtype_code(dtype), stream_handle())
 
     def finish(self):
         """-> (w_up, b_up, w0, dw_up, db_up, dw0) for everything accumulated since the last delivery."""
@@ -890,7 +933,8 @@ def upconv_luconv_forward(x, w_up, b_up, conv_w, conv_b, gamma, beta, running_me
     rows = L.call("pcrl_upconv_stats_rows", N, D, H, W, Ci, Co, dtype_code(dtype))
     y = new_act(N, 2 * D, 2 * H, 2 * W, Co, dtype, dev)
     partial = _f32(rows * Co * 2, dev)
-    L.call("pcrl_upconv_fwd", x, wf, composed.w3f, bias_tab, y, partial, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
+        L.call("pcrl_upconv_fwd", x, wf, composed.w3f, bias_tab, y, partial, N, D, H, W, Ci, Co, dtype_code(dtype), s)
     mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, True)
     a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
     sv = LUConvSaved()
@@ -918,7 +962,8 @@ def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamm
     if need_dx:
         _, wd, _ = composed.get(w_up, b_up, conv_w, conv_b, dtype)
         dx = new_act(N, D, H, W, Ci, dtype, dev)
-        L.call("pcrl_upconv_dgrad", dy, wd, composed.wd3, dx, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+        with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
+            L.call("pcrl_upconv_dgrad", dy, wd, composed.wd3, dx, N, D, H, W, Ci, Co, dtype_code(dtype), s)
     return dx, dw_up, db_up, dw0, zero_grad_vector(Co, dev), dgamma, dbeta
 
 

@@ -32,6 +32,7 @@ import time
 import torch
 import torch.distributed as dist
 
+from . import config as _cfg
 from . import ddp as _ddp
 from . import functions as _fn
 from . import ops as _ops
@@ -127,6 +128,17 @@ def step_losses(model, batch, epoch, criterion, cosine):
     fused = getattr(cosine, "fusable", False) and FUSED_COS_LOSSES and 2 + 4 * len(local_views) <= COS_MAX_TERMS
     view1, view2 = _to_gpu(view1), _to_gpu(view2)
     _ops.fork_views(view1.device)  # config.VIEW_STREAMS: the second view's forward (and backward) on its own stream, next to the first's
+    if fused and _cfg.INTERLEAVE_VIEWS and hasattr(model, "forward_views") and _ops.view_streams_on(view1.device):
+        # the three forwards enqueued stage by stage in rotation, each pass on its own stream (config.INTERLEAVE_VIEWS / MFMA_TOKEN)
+        loc = torch.cat([_to_gpu(v) for v in local_views], dim=0)
+        with _ops.deferred_join():
+            (out1, feats1, masks1), (_out2, feats2, _), (_, feats_loc, _) = model.forward_views(
+                [(view1, False, None), (view2, False, "view2"), (loc, True, "local")])
+        l_global, l_local, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
+        l_restore = criterion(out1, target)
+        beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
+        l_deep = beta * criterion(masks1[scale], target)
+        return l_restore + l_global + l_deep + l_local, l_restore, l_global, l_deep, l_local
     with _ops.deferred_join():     # the decoder stages' side branches (heads, deep-supervision maps) also run under the NEXT forward; joined on exit
         out1, feats1, masks1 = model(view1)
         with _ops.view_pass(view2.device, view2):
