@@ -346,6 +346,12 @@ int pcrl_upconv_fwd(const void* x, const void* wf, const void* w3f, const float*
 int64_t pcrl_upconv_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   /* informational: which kernel a shape gets */
 int pcrl_upconv_dgrad(const void* dy0, const void* wd, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
                       pcrl_stream_t stream);
+/* The same with a caller-owned workspace (convolution_backward(input) of :9,33 through :52,64 on SMALL coarse grids -- up_tr256's 8x8x4 and
+ * the local views' 2^3 / 4^3): the 64-tap reduction of the gather form is split over the grid's third dimension into float partial sums and
+ * summed by a fixed-order finish pass (deterministic), like pcrl_conv3d_k3_fwd_ws.  ws_bytes() == 0: no workspace needed, ws may be NULL. */
+int64_t pcrl_upconv_dgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype);
+int pcrl_upconv_dgrad_ws(const void* dy0, const void* wd, const void* wd3, void* dx, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
+                         int Ci, int Co, int dtype, pcrl_stream_t stream);
 int64_t pcrl_upconv_wgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   /* informational: which kernel a shape gets */
 size_t pcrl_upconv_wgrad_accum_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype);
 int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dweff_acc, float* box_acc, int flags, void* ws, size_t ws_bytes, int N, int D,

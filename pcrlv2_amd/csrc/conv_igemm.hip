@@ -46,7 +46,7 @@ struct IgemmParams {
   int K;              // channels per tap
   int Nc;             // output channels
   int taps;           // taps accumulated inside one GEMM (27, 1 or 8)
-  float* ws;          // split-K (GEOM_CONV3 only): [gridDim.z][M][Nc] float partial sums, or null
+  float* ws;          // split-K (GEOM_CONV3 and GEOM_UPC_DGRAD): [gridDim.z][M][Nc] float partial sums, or null
   int steps_per_split;
   // GEOM_UPC_* only.  1-D grid over (row tile, phase): the phases of a tile run back to back on ONE XCD and every XCD owns a contiguous
   // range of tiles (the eight phases gather the same x rows, neighbouring tiles share faces: one L2 serves them; with the phase as the
@@ -176,8 +176,9 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nchunk = K / 32;
-  const int s_off = (GEOM == GEOM_CONV3 && p.ws) ? blockIdx.z * p.steps_per_split : 0;   // first K-step of this split
-  const int S = (GEOM == GEOM_CONV3 && p.ws) ? min(p.steps_per_split, p.taps * nchunk - s_off) : p.taps * nchunk;
+  constexpr bool CAN_SPLIT = GEOM == GEOM_CONV3 || GEOM == GEOM_UPC_DGRAD;
+  const int s_off = (CAN_SPLIT && p.ws) ? blockIdx.z * p.steps_per_split : 0;   // first K-step of this split
+  const int S = (CAN_SPLIT && p.ws) ? min(p.steps_per_split, p.taps * nchunk - s_off) : p.taps * nchunk;
   // Two staging register sets: the loads of K-step s+2 are issued while step s is multiplied and step s+1 waits in the
   // other set, so a load has two MFMA phases to land.
   u32x4 raA[AP], rbA[BP], raB[AP], rbB[BP];
@@ -295,7 +296,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
     }
     return;
   }
-  if (GEOM == GEOM_CONV3 && p.ws) {   // split-K: raw float partial sums; bias, rounding and statistics happen in the finish pass
+  if (CAN_SPLIT && p.ws) {   // split-K: raw float partial sums; bias, rounding and statistics happen in the finish pass
     float* __restrict__ Z = p.ws + (int64_t)blockIdx.z * p.M * p.Nc;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -303,8 +304,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + wm * 64 + i * 16 + lg * 4 + r;
         if (m < p.M) {
+          int64_t orow = m;
+          if (GEOM == GEOM_UPC_DGRAD) {   // box-ordered rows -> the voxel's row in the output tensor
+            int n, d, h, w;
+            row_voxel(m, n, d, h, w);
+            orow = (((int64_t)n * g.D + d) * g.H + h) * g.W + w;
+          }
 #pragma unroll
-          for (int j = 0; j < FN; ++j) Z[m * p.Nc + n0 + wn * (BN / 2) + j * 16 + lr] = acc[i][j][r];
+          for (int j = 0; j < FN; ++j) Z[orow * p.Nc + n0 + wn * (BN / 2) + j * 16 + lr] = acc[i][j][r];
         }
       }
     return;
@@ -385,7 +392,7 @@ int launch_igemm(const IgemmParams& p, int zdim, hipStream_t stream) {
   using TL = Tile<T>;
   const size_t lds = 2 * (size_t)(PCRL_CONV_BM + BN) * TL::ROWB;
   dim3 grid((unsigned)((p.M + PCRL_CONV_BM - 1) / PCRL_CONV_BM), (unsigned)(p.Nc / BN), (unsigned)zdim);
-  if (GEOM == GEOM_UPC_FWD || GEOM == GEOM_UPC_DGRAD) grid = dim3((unsigned)(p.nt * p.zdim), (unsigned)(p.Nc / BN), 1);
+  if (GEOM == GEOM_UPC_FWD || GEOM == GEOM_UPC_DGRAD) grid = dim3((unsigned)(p.nt * p.zdim), (unsigned)(p.Nc / BN), (unsigned)(GEOM == GEOM_UPC_DGRAD ? zdim : 1));
   hipLaunchKernelGGL((igemm_kernel<T, BN, GEOM>), grid, dim3(256), lds, stream, p);
   return pcrl_check_launch("igemm");
 }
@@ -604,12 +611,12 @@ static void upc_box(int D, int H, int W, IgemmParams& p) {
       return;
     }
 }
-template <int GEOM> static int launch_upc(IgemmParams& p, int zdim, int dtype, hipStream_t stream) {
+template <int GEOM> static int launch_upc(IgemmParams& p, int zdim, int dtype, hipStream_t stream, int splits = 1) {
   upc_box(p.g.D, p.g.H, p.g.W, p);
   p.nt = (int)((p.M + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
   p.zdim = zdim;
   if ((int64_t)p.nt * zdim >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "upconv: grid too large");
-  return dispatch<GEOM>(p, 1, dtype, stream);
+  return dispatch<GEOM>(p, splits, dtype, stream);      // the third grid dimension: K splits (data gradient only)
 }
 int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
                         int dtype, hipStream_t stream) {
@@ -626,9 +633,47 @@ bool pcrl_upc_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int d
   static const bool gather_only = [] { const char* e = getenv("PCRL_UPC_DGRAD_GATHER"); return e && e[0] == '1'; }();   // A/B switch
   return g_conv_impl == 0 && !gather_only && pcrl_brick16_upc_dgrad_eligible(N, D, H, W, Ci, Co, dtype);
 }
-int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype, hipStream_t stream) {
+// Split-K plan of the composed data gradient on the gather kernel: K = 64 taps x Co / 32 chunks (512 steps at up_tr256) over row tiles that
+// are few on the coarse grids it serves -- the 8 x 8 x 4 grid of up_tr256 (64 tiles x 4 channel tiles = one block per CU, four waves: 319 us,
+// 430 TFLOP/s) and the 2^3 / 4^3 grids of the local views (12 tiles: 287 us, 90 TFLOP/s).  Splits bring the grid to ~4 blocks per CU.
+static SplitPlan upc_dgrad_plan(int64_t M, int Ci, int Co) {
+  const int bn = Ci % 128 == 0 ? 128 : (Ci % 64 == 0 ? 64 : 32);
+  const int64_t blocks = ((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM) * (Ci / bn);
+  const int steps = 64 * (Co / 32);
+  static const bool off = [] { const char* e = getenv("PCRL_UPC_DGRAD_SPLITK"); return e && e[0] == '0'; }();   // A/B switch
+  if (off || blocks >= 512) return SplitPlan{1, steps};
+  int splits = (int)((1024 + blocks - 1) / blocks);
+  if (splits > 16) splits = 16;
+  if (splits > steps / 16) splits = steps / 16;   // at least 16 K-steps per split
+  if (splits < 2) return SplitPlan{1, steps};
+  const int per = (steps + splits - 1) / splits;
+  return SplitPlan{(steps + per - 1) / per, per};
+}
+int64_t pcrl_upc_dgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co) {
+  const int64_t M = (int64_t)N * D * H * W;
+  const SplitPlan sp = upc_dgrad_plan(M, Ci, Co);
+  return sp.splits > 1 ? (int64_t)sp.splits * M * Ci * 4 : 0;
+}
+int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Ci, int Co, int dtype,
+                          hipStream_t stream) {
   // rows = coarse voxels, K per tap = Co (channels of dy0), 64 taps, output channels = Ci
-  IgemmParams p{dy0, wd, nullptr, dx, nullptr, Dims{N, D, H, W}, (int64_t)N * D * H * W, Co, Ci, 64, nullptr, 0};
+  const int64_t M = (int64_t)N * D * H * W;
+  IgemmParams p{dy0, wd, nullptr, dx, nullptr, Dims{N, D, H, W}, M, Co, Ci, 64, nullptr, 0};
+  const SplitPlan sp = upc_dgrad_plan(M, Ci, Co);
+  if (ws && sp.splits > 1 && ws_bytes >= (int64_t)sp.splits * M * Ci * 4) {
+    p.ws = static_cast<float*>(ws);
+    p.steps_per_split = sp.steps_per_split;
+    if (int e = launch_upc<GEOM_UPC_DGRAD>(p, 1, dtype, stream, sp.splits)) return e;
+    const int64_t row_tiles = (M + PCRL_CONV_BM - 1) / PCRL_CONV_BM;
+    int cw = Ci < 64 ? Ci : 64;
+    while (cw > 16 && row_tiles * (Ci / cw) < 512) cw >>= 1;
+    const dim3 grid((unsigned)row_tiles, (unsigned)(Ci / cw));
+    if (dtype == PCRL_BF16)
+      hipLaunchKernelGGL(igemm_splitk_finish_kernel<bf16>, grid, dim3(256), 0, stream, p.ws, (const float*)nullptr, (bf16*)dx, (float*)nullptr, M, Ci, sp.splits);
+    else
+      hipLaunchKernelGGL(igemm_splitk_finish_kernel<float>, grid, dim3(256), 0, stream, p.ws, (const float*)nullptr, (float*)dx, (float*)nullptr, M, Ci, sp.splits);
+    return pcrl_check_launch("upconv_dgrad (split-K finish)");
+  }
   return launch_upc<GEOM_UPC_DGRAD>(p, 1, dtype, stream);
 }
 // Plain GEMM with a float32 plane-major result: z[col * M + m] = sum_k a[m][k] * b[col][k]   (M % 4 == 0, K % 32 == 0, Nc % 32 == 0)

@@ -27,7 +27,9 @@
 // conv_igemm.hip / conv_wgrad.hip
 int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
                         int dtype, hipStream_t stream);
-int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype, hipStream_t stream);
+int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Ci, int Co, int dtype,
+                          hipStream_t stream);
+int64_t pcrl_upc_dgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co);   // split-K workspace of the gather form (0: none)
 bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_igemm.hip: the wide-brick kernel takes this shape
 int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W);
 int pcrl_brick16_upc_fwd_launch(const void* x, const void* w3, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
@@ -159,17 +161,31 @@ __global__ void __launch_bounds__(256) upc_bias_kernel(const float* __restrict__
 }
 
 // dweff[co][ci][pq] (float32) -> a1[(t*Co+co)][(s*Ci+ci)], value dWeff[pq(t,s)][ci][co]   (a2 = a1 transposed: transpose_kernel)
+// Block = (co, 32 consecutive ci): the [32 ci][64 pq] slab of dweff (8 KB, contiguous) goes through LDS once, then every one of the 216
+// (t, s) rows of a1 gets its 32 consecutive ci as one 64 / 128-byte run.  (The first version read dweff at a stride of 64 floats per
+// thread -- one element per 256-byte line: 250 us for up_tr256's 28 M outputs; this one moves 33 MB in and 57 MB out in ~25 us.)
 template <typename T>
 __global__ void __launch_bounds__(256) upc_chain_pack_kernel(const float* __restrict__ dweff, T* __restrict__ a1, int Ci, int Co) {
-  const int64_t total = (int64_t)27 * 8 * Ci * Co;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int ci = (int)(i % Ci), s = (int)((i / Ci) % 8), co = (int)((i / ((int64_t)8 * Ci)) % Co), t = (int)(i / ((int64_t)8 * Ci * Co));
+  __shared__ float slab[32][65];
+  const int co = blockIdx.y, ci0 = blockIdx.x * 32, tid = threadIdx.x;
+  const float* src = dweff + ((int64_t)co * Ci + ci0) * 64;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = (k * 256 + tid) * 4;      // float index into the 2048-float slab
+    const float4 v = *reinterpret_cast<const float4*>(src + e);
+    const int r = e >> 6, c = e & 63;
+    slab[r][c] = v.x; slab[r][c + 1] = v.y; slab[r][c + 2] = v.z; slab[r][c + 3] = v.w;
+  }
+  __syncthreads();
+  const int ci = tid & 31;
+  for (int ts = tid >> 5; ts < 216; ts += 8) {
+    const int t = ts >> 3, sidx = ts & 7;
     int pd, qd, ph, qh, pw, qw;
-    pq_axis(t / 9, s >> 2, pd, qd);
-    pq_axis((t / 3) % 3, (s >> 1) & 1, ph, qh);
-    pq_axis(t % 3, s & 1, pw, qw);
+    pq_axis(t / 9, sidx >> 2, pd, qd);
+    pq_axis((t / 3) % 3, (sidx >> 1) & 1, ph, qh);
+    pq_axis(t % 3, sidx & 1, pw, qw);
     const int pq = (pd * 4 + ph * 2 + pw) * 8 + (qd * 4 + qh * 2 + qw);
-    a1[i] = cvt<T>(dweff[((int64_t)co * Ci + ci) * 64 + pq]);   // a1 index ((t*Co+co) * 8*Ci + s*Ci + ci) == i
+    a1[((int64_t)t * Co + co) * (8 * (int64_t)Ci) + (int64_t)sidx * Ci + ci0 + ci] = cvt<T>(slab[ci][pq]);
   }
 }
 // out[c][r] = in[r][c] for an R x C matrix (both multiples of 32), 32 x 32 tiles through LDS: both sides coalesced (the pack kernel writing
@@ -392,15 +408,30 @@ extern "C" int pcrl_upconv_fwd(const void* x, const void* wf, const void* w3f, c
 extern "C" int64_t pcrl_upconv_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) {
   return pcrl_upc_dgrad_uses_brick(N, D, H, W, Ci, Co, dtype) ? 1 : 0;
 }
-extern "C" int pcrl_upconv_dgrad(const void* dy0, const void* wd, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
-                                 pcrl_stream_t stream) {
+static int upconv_dgrad_impl(const void* dy0, const void* wd, const void* wd3, void* dx, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Ci,
+                             int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_upc("upconv_dgrad", N, D, H, W, Ci, 32, Co, dtype)) return e;
   PCRL_REQUIRE(dy0 && wd && dx, "upconv_dgrad: null pointer");
   if (pcrl_upc_dgrad_uses_brick(N, D, H, W, Ci, Co, dtype)) {
     PCRL_REQUIRE(wd3, "upconv_dgrad: this shape runs on the wide-brick kernel and needs the 3x3x3 form of the composed weights (wd3)");
     return pcrl_brick16_upc_dgrad_launch(dy0, wd3, dx, N, D, H, W, Ci, Co, as_stream(stream));
   }
-  return pcrl_upc_dgrad_launch(dy0, wd, dx, N, D, H, W, Ci, Co, dtype, as_stream(stream));
+  return pcrl_upc_dgrad_launch(dy0, wd, dx, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, as_stream(stream));
+}
+extern "C" int pcrl_upconv_dgrad(const void* dy0, const void* wd, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, int dtype,
+                                 pcrl_stream_t stream) {
+  return upconv_dgrad_impl(dy0, wd, wd3, dx, nullptr, 0, N, D, H, W, Ci, Co, dtype, stream);
+}
+// The same with a caller-owned workspace: small coarse grids (few row tiles) split the 64-tap reduction over blockIdx.z into float partial
+// sums and a finish pass, like pcrl_conv3d_k3_fwd_ws.  pcrl_upconv_dgrad_ws_bytes() == 0: no workspace needed (ws may be null).
+extern "C" int64_t pcrl_upconv_dgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 32 || Co % 32) return 0;
+  if (pcrl_upc_dgrad_uses_brick(N, D, H, W, Ci, Co, dtype)) return 0;
+  return pcrl_upc_dgrad_ws_bytes(N, D, H, W, Ci, Co);
+}
+extern "C" int pcrl_upconv_dgrad_ws(const void* dy0, const void* wd, const void* wd3, void* dx, void* ws, int64_t ws_bytes, int N, int D, int H, int W,
+                                    int Ci, int Co, int dtype, pcrl_stream_t stream) {
+  return upconv_dgrad_impl(dy0, wd, wd3, dx, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream);
 }
 
 // ---- parameter gradients ----
@@ -477,14 +508,14 @@ extern "C" int pcrl_upconv_wgrad_finish(const float* dweff_acc, const float* box
   if (!ws || ws_bytes < L.total) return pcrl_fail(PCRL_EWORKSPACE, "upconv_wgrad_finish: workspace %zu < %zu", ws_bytes, L.total);
   hipStream_t st = as_stream(stream);
   char* w = (char*)ws;
-  const unsigned gpre = blocks_for((int64_t)27 * Co * Cm + (int64_t)8 * Ci * Cm), gpk = blocks_for((int64_t)216 * Ci * Co);
+  const unsigned gpre = blocks_for((int64_t)27 * Co * Cm + (int64_t)8 * Ci * Cm);
   if (dtype == PCRL_BF16) {
     hipLaunchKernelGGL(upc_prep_kernel<bf16>, dim3(gpre), dim3(256), 0, st, w_up, w0, (bf16*)nullptr, (bf16*)nullptr, (bf16*)(w + L.b1), (bf16*)(w + L.b2), Ci, Cm, Co);
-    hipLaunchKernelGGL(upc_chain_pack_kernel<bf16>, dim3(gpk), dim3(256), 0, st, dweff_acc, (bf16*)(w + L.a1), Ci, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<bf16>, dim3((unsigned)(Ci / 32), (unsigned)Co), dim3(256), 0, st, dweff_acc, (bf16*)(w + L.a1), Ci, Co);
     hipLaunchKernelGGL(transpose_kernel<bf16>, dim3((unsigned)(8 * Ci / 32), (unsigned)(27 * Co / 32)), dim3(256), 0, st, (const bf16*)(w + L.a1), (bf16*)(w + L.a2), 27 * Co, 8 * Ci);
   } else {
     hipLaunchKernelGGL(upc_prep_kernel<float>, dim3(gpre), dim3(256), 0, st, w_up, w0, (float*)nullptr, (float*)nullptr, (float*)(w + L.b1), (float*)(w + L.b2), Ci, Cm, Co);
-    hipLaunchKernelGGL(upc_chain_pack_kernel<float>, dim3(gpk), dim3(256), 0, st, dweff_acc, (float*)(w + L.a1), Ci, Co);
+    hipLaunchKernelGGL(upc_chain_pack_kernel<float>, dim3((unsigned)(Ci / 32), (unsigned)Co), dim3(256), 0, st, dweff_acc, (float*)(w + L.a1), Ci, Co);
     hipLaunchKernelGGL(transpose_kernel<float>, dim3((unsigned)(8 * Ci / 32), (unsigned)(27 * Co / 32)), dim3(256), 0, st, (const float*)(w + L.a1), (float*)(w + L.a2), 27 * Co, 8 * Ci);
   }
   if (int e = pcrl_check_launch("upconv_wgrad_finish (pack)")) return e;

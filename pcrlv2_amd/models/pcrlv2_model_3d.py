@@ -247,9 +247,12 @@ class PCRLv23d(nn.Module):
                 masks.append(mask if factor == 1 else ops.upsample_forward(mask, factor))
         return ops.conv1x1_to1_forward(ops.to_act(h, dt), self.out_tr.final_conv.weight, self.out_tr.final_conv.bias, dt), feats, masks
 
-    def _train_stages(self, x, local, pass_idx):
+    def _train_stages(self, x, local, pass_idx, features_only=False):
         """The training-mode forward as a generator: yields after every stage's kernels are enqueued (eleven stops), returns the forward's
-        result.  `forward` runs it to the end; `forward_views` advances several of them in rotation, each under its own stream."""
+        result.  `forward` runs it to the end; `forward_views` advances several of them in rotation, each under its own stream.
+        features_only: the caller discards the reconstruction and the deep-supervision maps (the second view and the local views of a
+        training step, train_3d.py:117,123 -- SURVEY Q3): `out_tr` (no state) and the trilinear upsampling are skipped and None / [] are
+        returned in their place; everything that has STATE -- the deep-supervision heads' BatchNorm running statistics -- still runs."""
         mods = self._stage_modules()
 
         def mine():          # the stage Functions read the pass number off their module at forward time
@@ -277,20 +280,23 @@ class PCRLv23d(nn.Module):
             mine()
             h, pro, pre, mask = getattr(self, name)(h)
             middle_features.append([pro, pre])
-            if not local:
+            if not local and not features_only:
                 middle_masks.append(mask if factor == 1 else Fn.TrilinearFn.apply(mask, factor))
             yield
+        if features_only:
+            return None, middle_features, middle_masks
         mine()
         out = self.out_tr(h)
         return out, middle_features, middle_masks
 
-    def forward(self, x, local=False):
-        """-> (out [b,1,D,H,W], [[pro, pre] x 3 scales], [mask x 3] or [] when local)"""
+    def forward(self, x, local=False, *, features_only=False):
+        """-> (out [b,1,D,H,W], [[pro, pre] x 3 scales], [mask x 3] or [] when local).  `features_only` (engine extension, keyword only):
+        (None, features, []) -- see _train_stages."""
         if not x.is_cuda:
             raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
         if not self.training:
             return self._forward_eval(x, local)
-        gen = self._train_stages(x, local, ops.next_pass())     # pass 0 = first forward since the last optimizer step (its backward runs last)
+        gen = self._train_stages(x, local, ops.next_pass(), features_only)     # pass 0 = first forward since the last optimizer step (its backward runs last)
         try:
             while True:
                 next(gen)
@@ -300,21 +306,22 @@ class PCRLv23d(nn.Module):
         return result
 
     def forward_views(self, views):
-        """Several training-mode forwards enqueued stage by stage in rotation (engine API, not in the reference): `views` = [(x, local, stream
-        name | None), ...] -> [forward(x, local) for each], as if called one after the other in that order -- same kernels, same results, same
+        """Several training-mode forwards enqueued stage by stage in rotation (engine API, not in the reference; an experiment that is off by
+        default, config.INTERLEAVE_VIEWS): `views` = [(x, local, stream name | None), ...] -> [forward(x, local) for the first,
+        forward(x, local, features_only=True) for the others], as if called one after the other in that order -- same kernels, same results, same
         order of the running-statistics updates (ops.order_rmw) -- but the autograd graphs interleave, so the backward replays the passes in
         rotation too, and each pass runs on the view stream of its name (ops.fork_views must have been called; None = the current stream).
         With config.MFMA_TOKEN the HBM-bound passes of one view then run under the convolutions of the others (config.py)."""
         if not self.training:
             return [self.forward(x, local) for x, local, _ in views]
         runs = []
-        for x, local, name in views:
+        for k, (x, local, name) in enumerate(views):
             if not x.is_cuda:
                 raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
             st = ops.view_stream(x.device, name) if name else None
             if st is not None:
                 x.record_stream(st)
-            runs.append([self._train_stages(x, local, ops.next_pass()), st, None, False])
+            runs.append([self._train_stages(x, local, ops.next_pass(), features_only=k > 0), st, None, False])   # only the first view's maps are used
         alive = len(runs)
         while alive:
             for r in runs:

@@ -962,8 +962,9 @@ def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamm
     if need_dx:
         _, wd, _ = composed.get(w_up, b_up, conv_w, conv_b, dtype)
         dx = new_act(N, D, H, W, Ci, dtype, dev)
+        nbd = L.call("pcrl_upconv_dgrad_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))      # split-K scratch on the small coarse grids
         with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
-            L.call("pcrl_upconv_dgrad", dy, wd, composed.wd3, dx, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+            L.call("pcrl_upconv_dgrad_ws", dy, wd, composed.wd3, dx, workspace(nbd, dev) if nbd else None, nbd, N, D, H, W, Ci, Co, dtype_code(dtype), s)
     return dx, dw_up, db_up, dw0, zero_grad_vector(Co, dev), dgamma, dbeta
 
 

@@ -54,6 +54,7 @@ class MSELoss:
         return mse_loss(pred, target)
 
 
+SKIP_UNUSED_OUTPUTS = os.environ.get("PCRL_SKIP_UNUSED_OUTPUTS", "1") != "0"   # A/B switch (results are bit-identical)
 COS_MAX_TERMS = 32   # csrc/heads_loss.hip
 FUSED_COS_LOSSES = os.environ.get("PCRL_FUSED_COS", "1") != "0"   # all 26 cosine means of a step in one launch (0: one launch per mean)
 
@@ -141,12 +142,15 @@ def step_losses(model, batch, epoch, criterion, cosine):
         return l_restore + l_global + l_deep + l_local, l_restore, l_global, l_deep, l_local
     with _ops.deferred_join():     # the decoder stages' side branches (heads, deep-supervision maps) also run under the NEXT forward; joined on exit
         out1, feats1, masks1 = model(view1)
+        # mask2, the local views' reconstruction and their deep-supervision maps are never used (train_3d.py:117,123): the engine's
+        # model skips what has no state (out_tr, the trilinear upsampling) when asked for the features only; a plain nn.Module computes them
+        fo = dict(features_only=True) if SKIP_UNUSED_OUTPUTS and isinstance(model, PCRLv23d) else {}
         with _ops.view_pass(view2.device, view2):
-            _out2, feats2, _ = model(view2)                             # mask2 / its deep-supervision maps stay unused (Q3)
+            _out2, feats2, _ = model(view2, **fo)
         if fused:
             loc = torch.cat([_to_gpu(v) for v in local_views], dim=0)
             with _ops.view_pass(loc.device, loc, name="local"):
-                _, feats_loc, _ = model(loc, local=True)
+                _, feats_loc, _ = model(loc, local=True, **fo)
     if fused:
         l_global, l_local, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
         l_restore = criterion(out1, target)
@@ -154,7 +158,7 @@ def step_losses(model, batch, epoch, criterion, cosine):
         l_deep = beta * criterion(masks1[scale], target)
         return l_restore + l_global + l_deep + l_local, l_restore, l_global, l_deep, l_local
     l_global, scale = cos_loss(cosine, feats1, feats2)
-    _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
+    _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True, **fo)
     stacked = [torch.stack(pair) for pair in feats_loc]                 # [2, 6n, C] per scale
     l_local = 0.0
     for i in range(len(local_views)):

@@ -97,7 +97,14 @@ def test_composed_upconv_matches_the_two_aten_calls(shape, dt):
 
     dya = ops.to_act(dyq.to(dt).to(DEV), dt)
     dx = ops.new_act(N, D, H, W, Ci, dt, torch.device(DEV))
-    L.call("pcrl_upconv_dgrad", dya, wd, comp.wd3, dx, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    # the workspace form (what ops.upconv_luconv_backward calls): small coarse grids split the 64-tap reduction over K (deterministic finish pass)
+    nbd = L.call("pcrl_upconv_dgrad_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dt))
+    wsd = torch.empty(max(nbd, 16), dtype=torch.uint8, device=DEV)
+    L.call("pcrl_upconv_dgrad_ws", dya, wd, comp.wd3, dx, wsd if nbd else None, nbd, N, D, H, W, Ci, Co, dtype_code(dt), s)
+    if nbd:     # ... and agrees with the one-pass form to the rounding of its float32 partial sums
+        dx1 = torch.empty_like(dx)
+        L.call("pcrl_upconv_dgrad", dya, wd, comp.wd3, dx1, N, D, H, W, Ci, Co, dtype_code(dt), s)
+        assert (dx.float() - dx1.float()).abs().max().item() <= (2e-2 if dt == torch.bfloat16 else 1e-4) * max(dx1.float().abs().max().item(), 1e-6)
     close(dx, xr.grad, 2e-2 if bf else 1e-4, "dx")
 
     dwu, dbu, dwc = torch.empty_like(wu), torch.empty_like(bu), torch.empty_like(wc)

@@ -64,10 +64,12 @@ def main():
             dweff, box = torch.zeros(64 * Ci * Co, device=dev), torch.zeros(27 * Co, device=dev)
             nb = L.call("pcrl_upconv_wgrad_accum_ws_bytes", N, D, H, W, Ci, Co, dc)
             ws = ops.workspace(nb, dev)
+            nbd = L.call("pcrl_upconv_dgrad_ws_bytes", N, D, H, W, Ci, Co, dc)
+            wsd = torch.empty(max(nbd, 16), dtype=torch.uint8, device=dev) if nbd else None
             fb = bool(L.call("pcrl_upconv_fwd_uses_brick", N, D, H, W, Ci, Co, dc))
             db = bool(L.call("pcrl_upconv_dgrad_uses_brick", N, D, H, W, Ci, Co, dc))
             fns = {"fwd": lambda: L.call("pcrl_upconv_fwd", x, wf, comp.w3f, tab, y, st, N, D, H, W, Ci, Co, dc, s),
-                   "dgrad": lambda: L.call("pcrl_upconv_dgrad", dy, wd, comp.wd3, dx, N, D, H, W, Ci, Co, dc, s),
+                   "dgrad": lambda: L.call("pcrl_upconv_dgrad_ws", dy, wd, comp.wd3, dx, wsd, nbd, N, D, H, W, Ci, Co, dc, s),
                    "wgrad": lambda: L.call("pcrl_upconv_wgrad_accum", x, dy, dweff, box, 3, ws, nb, N, D, H, W, Ci, Co, dc, s)}
             line = f"{name:6s}{' local' if local else ' global'} N={N:3d} {D}x{H}x{W} Ci={Ci} Co={Co} {flops / 1e9:7.1f} GF (brick fwd {int(fb)} dgrad {int(db)}) |"
             for k in args.what.split(","):
