@@ -98,14 +98,14 @@ def keyfn(name, args):
     return conv_key(name, args) if name.startswith("pcrl_conv3d_k3_fwd") else wgrad_key(name, args)
 
 
-def synthetic_batch(b, dhw, local, device, seed):
+def synthetic_batch(b, dhw, local, device, seed, nlocal=6):
     """x1 ~ N(0,1), x2 = x1 + 0.1 N(0,1) (correlated views), gt ~ U(0,1), 6 local N(0,1) crops."""
     g = torch.Generator().manual_seed(seed)
     D, H, W = dhw
     x1 = torch.randn(b, 1, D, H, W, generator=g)
     x2 = x1 + 0.1 * torch.randn(b, 1, D, H, W, generator=g)
     gt = torch.rand(b, 1, D, H, W, generator=g)
-    loc = [torch.randn(b, 1, local, local, local, generator=g) for _ in range(6)]
+    loc = [torch.randn(b, 1, local, local, local, generator=g) for _ in range(nlocal)]
     to = lambda t: t.to(device)
     return to(x1), to(x2), to(gt), None, [to(t) for t in loc]
 
@@ -152,6 +152,7 @@ def main():
     ap.add_argument("--dhw", default="64,64,32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alone", action="store_true", help="skip the extra roofline.alone steps (rocprofv3 runs: the trace then holds the timed configuration only)")
+    ap.add_argument("--nlocal", type=int, default=6, help="local views per crop (the reference's loader delivers 6; other values are a probe, labelled custom)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the 5 extra steps of BASELINE config C4 (128x128x64, b=8) reported as `secondary`")
     args = ap.parse_args()
 
@@ -213,7 +214,7 @@ def main():
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
     dp = ddp.DataParallel(model, opt) if world > 1 else None  # noqa: F841
     crit, cosine = MSELoss(), CosineSimilarityMean()
-    batch = synthetic_batch(args.b, dhw, 16, dev, 1234 + rank)
+    batch = synthetic_batch(args.b, dhw, 16, dev, 1234 + rank, args.nlocal)
 
     def barrier():
         torch.cuda.synchronize()
@@ -280,7 +281,7 @@ def main():
     # BASELINE config C4 (128x128x64 crops, b = 8: the large-crop stress case) on the same model, after everything that feeds `value` and
     # `roofline`: 2 warm-up + 5 timed steps (~0.5 s), reported as `secondary` -- never part of `value`.
     secondary = None
-    if world == 1 and not args.no_secondary and dhw == (64, 64, 32) and args.b == 32 and args.dtype == "bf16":
+    if world == 1 and not args.no_secondary and dhw == (64, 64, 32) and args.b == 32 and args.dtype == "bf16" and args.nlocal == 6:
         try:
             c4 = synthetic_batch(8, (128, 128, 64), 16, dev, 4321)
             for _ in range(2):
@@ -325,6 +326,8 @@ def main():
         pass
     # BASELINE configs: C2 = 64x64x32 b=32 (the metric), C4 = 128x128x64 b=8 (9.42 TFLOP per crop); anything else is labelled as such
     cfg_name = {((64, 64, 32), 32): "C2", ((128, 128, 64), 8): "C4"}.get((dhw, args.b), "custom (not a BASELINE config)")
+    if args.nlocal != 6:
+        cfg_name = "custom (not a BASELINE config: %d local views)" % args.nlocal
     flop_per_crop = {"C2": FLOP_PER_CROP, "C4": 9.42e12}.get(cfg_name)
     line = {
         "metric": "3D crops/sec (64x64x32, b=32) pretrain step" if cfg_name == "C2" else f"3D crops/sec ({dhw[0]}x{dhw[1]}x{dhw[2]}, b={args.b}) pretrain step", "value": round(crops, 2), "unit": "crops/s",

@@ -616,6 +616,226 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_upc2_kernel(const WBrick2Pa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// ALL 27 TAPS PER BLOCK, 64 (co) x 32 (ci) tiles -- the layers with 64 output channels (down_tr64.ops.1 32 -> 64, down_tr128.ops.0 and
+// up_tr64.ops.1 64 -> 64: a third of the weight-gradient FLOPs of a step, and its least efficient third).
+// The one-kd-plane kernel above stages per brick a dy image (16 KB) and an x halo of two planes for ITS kd (30 KB) and multiplies 9 taps
+// out of them: 80 bytes staged per MFMA with 64 x 64 tiles, 160 with the 64 x 32 tiles of the Ci = 32 layer (half of whose x image is
+// padding) -- and staging, L2 -> LDS, is what this kernel spends its time on (1 840 vs 1 250 TFLOP/s without it).  With only 64 output
+// channels there is no wider tile to amortise it over (128 x 64 needs Co % 128 == 0).  Here a block multiplies ALL 27 taps from one staging:
+// the x halo is the brick's FOUR d planes x 32 channels, stored in the same 240-row x 128-byte image -- halo planes 0 / 1 in the rows'
+// first 64 bytes, planes 2 / 3 in their second 64 bytes (logical "channel" = 32 * (plane >> 1) + ci), so the transpose-read layout, its
+// swizzle and the LDS-DMA piece map are the ones above -- 46 KB per brick for 27 x 4 x 8 = 864 MFMAs: 53 bytes per MFMA.
+// Eight waves = 2 ci blocks of 16 x 4 tap groups (taps t = g, g + 4, ...: 7, 7, 7, 6); a wave holds 7 taps x 4 co fragments (112
+// accumulator registers), reads the 4 dy fragments of a K chunk once and one x fragment per tap: 28 steps of 4 MFMAs per brick.
+// Slabs ws[split][27][Cu][Cv] as above -> the same second pass.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int NPIECE27 = DYP + XP;   // 6 requests per brick and wave
+constexpr int NSTEP27 = 28;          // 4 K chunks x 7 taps
+constexpr int BUF27_BYTES = DY_BYTES + X_BYTES;
+
+struct WBrick27Params {
+  const bf16* dy;   // [M][Cu]
+  const bf16* x;    // [M][Cv]
+  float* ws;        // [splits][27][Cu][Cv]
+  int N, D, H, W;   // extents of the brick axes
+  int Cu, Cv;
+  int nbricks, per_split, nsplit;
+  int sd, sh, sw, td, th, tw;
+  int order;
+};
+
+__global__ void __launch_bounds__(NT, 1) wgrad_brick27_kernel(const WBrick27Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // two brick buffers: [dy image][x image (four planes x 32 ch)]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int lg = lane >> 4, jr = (lane & 15) >> 2, cq = lane & 3;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave 0 .. 7
+  const int cib = wv & 1, tg = wv >> 1;                          // 16-ci block, tap group
+  const int ntj = p.Cv / 32, ntile = (p.Cu / 64) * ntj;
+  int member, split;   // tiles of one split walk the same bricks: ids congruent mod 8 (one XCD), consecutive there
+  if ((p.nsplit & 7) == 0) {
+    const int k = blockIdx.x >> 3;
+    member = k % ntile;
+    split = (k / ntile) * 8 + (blockIdx.x & 7);
+  } else {
+    member = blockIdx.x % ntile;
+    split = blockIdx.x / ntile;
+  }
+  const int i0 = (member / ntj) * 64, j0 = (member % ntj) * 32;
+  const int b_beg = split * p.per_split;
+  const int b_end = min(b_beg + p.per_split, p.nbricks);
+  const int bw = p.W / BW, bh = p.H / BH, bd = p.D / BD;
+
+  f32x4 acc[7][4];
+#pragma unroll
+  for (int t = 0; t < 7; ++t)
+#pragma unroll
+    for (int f = 0; f < 4; ++f) acc[t][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging roles (see wgrad_brick_kernel): lane -> row tid >> 3 (+ 64 per round), physical 16-byte position tid & 7; the swizzle is applied
+  // to the source.  Logical piece pc of an x row: half = pc >> 2 selects the halo plane pair, pc & 3 the 8-channel group of the 32.
+  const int pp = tid & 7, srow = tid >> 3;
+  const int key_dy = ((srow >> 1) & 1) | (((srow >> 3) & 1) << 1), key_x = (srow >> 1) & 3;
+  const int pc_dy = ((((pp >> 1) ^ key_dy) & 3) << 1) | (pp & 1), pc = ((((pp >> 1) ^ key_x) & 3) << 1) | (pp & 1);
+  const int xhalf = pc >> 2, xcol = j0 + (pc & 3) * 8;
+  uint32_t dyoff[DYP], xoff[XP], xedge[XP];
+#pragma unroll
+  for (int i = 0; i < DYP; ++i) {
+    const int v = (tid >> 3) + (NT / 8) * i;
+    dyoff[i] = (uint32_t)(((v >> 6) * p.sd + ((v >> 3) & 7) * p.sh + (v & 7) * p.sw) * p.Cu + pc_dy * 8) * 2u;
+  }
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    const int r = (tid >> 3) + (NT / 8) * i;
+    const int hd2 = r / (XH * XW), hh = (r / XW) % XH, hw = r % XW;
+    const int pl = hd2 + 2 * xhalf;                         // halo plane 0 .. 3 (d0 - 1 .. d0 + 2)
+    const bool row_ok = r < XROWS && hw < BW + 2;
+    xoff[i] = row_ok ? (uint32_t)((pl * p.sd + hh * p.sh + hw * p.sw) * p.Cv + xcol) * 2u : 0u;
+    xedge[i] = (pl == 0 ? 1u : 0u) | (pl == 3 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == XH - 1 ? 8u : 0u) | (hw == 0 ? 16u : 0u) |
+               (hw == BW + 1 ? 32u : 0u) | (row_ok ? 0u : 64u);
+  }
+  const char* zpage = reinterpret_cast<const char*>(g_wb_zero);
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const char* dyb = nullptr;
+  const char* xb = nullptr;
+  uint32_t xout = 0;
+  int ob = b_beg, ow0, oh0, od0, on;
+  {
+    int t_ = b_beg;
+    ow0 = (t_ % bw) * BW; t_ /= bw;
+    if (p.order) {
+      od0 = (t_ % bd) * BD; t_ /= bd;
+      oh0 = (t_ % bh) * BH; t_ /= bh;
+    } else {
+      oh0 = (t_ % bh) * BH; t_ /= bh;
+      od0 = (t_ % bd) * BD; t_ /= bd;
+    }
+    on = t_;
+  }
+#define W27_ORIGIN_NEXT()                                                                                    \
+  do {                                                                                                       \
+    const int w0 = ow0, h0 = oh0, d0 = od0, n = on;                                                          \
+    if (ob + 1 < b_end) {                                                                                    \
+      ++ob;                                                                                                  \
+      ow0 += BW;                                                                                             \
+      if (ow0 == p.W) {                                                                                      \
+        ow0 = 0;                                                                                             \
+        if (p.order) {                                                                                       \
+          od0 += BD;                                                                                         \
+          if (od0 == p.D) { od0 = 0; oh0 += BH; if (oh0 == p.H) { oh0 = 0; ++on; } }                         \
+        } else {                                                                                             \
+          oh0 += BH;                                                                                         \
+          if (oh0 == p.H) { oh0 = 0; od0 += BD; if (od0 == p.D) { od0 = 0; ++on; } }                         \
+        }                                                                                                    \
+      }                                                                                                      \
+    }                                                                                                        \
+    const int64_t base0 = (int64_t)n * p.D * p.H * p.W + (int64_t)d0 * p.sd + h0 * p.sh + w0 * p.sw;          \
+    dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                           \
+    /* first halo voxel (d0 - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */      \
+    xb = reinterpret_cast<const char*>(p.x + (base0 - (int64_t)p.sd - p.sh - p.sw) * p.Cv);                  \
+    xout = (d0 == 0 ? 1u : 0u) | (d0 + BD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + BH == p.H ? 8u : 0u) | \
+           (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;                                         \
+  } while (0)
+#define W27_DMA_PIECE(i_, buf_)                                                                              \
+  do {                                                                                                       \
+    if ((i_) < DYP) {                                                                                        \
+      const int k_ = (i_) < DYP ? (i_) : 0;                                                                  \
+      lds_dma16(dyb + dyoff[k_], lds_base + (uint32_t)((buf_)-smem) + wv * 1024 + k_ * (NT * 16));           \
+    } else {                                                                                                 \
+      const int k_ = (i_) < DYP ? 0 : (i_) - DYP;                                                            \
+      if (8 * wv + (NT / 8) * k_ < XROWS) {                                                                  \
+        const bool ok = (xedge[k_] & xout) == 0;                                                             \
+        lds_dma16(ok ? xb + xoff[k_] : zpage, lds_base + (uint32_t)((buf_)-smem) + DY_BYTES + wv * 1024 + k_ * (NT * 16)); \
+      }                                                                                                      \
+    }                                                                                                        \
+  } while (0)
+
+  // lane parts of the fragment addresses.  dy as above.  x: a wave's 7 taps are t = tg + 4 k; tap (kd, kh, kw) of a voxel in brick d plane
+  // vd reads halo plane vd + kd -- row block (plane & 1), row half (plane >> 1: logical column 32 * half + 16 * cib + 4 * cq) -- at row
+  // R = ((plane & 1) * XH + kh) * XW + kw (+ 4 * XW for the upper h half of the plane: a multiple of 8 rows, i.e. an immediate that leaves
+  // the swizzle alone).  The two transpose reads of a fragment (rows R and R + 4) get their complete lane address here, once: 28 registers
+  // instead of a four-way copy of the step loop (the tap group is a run-time, wave-uniform value).
+  int abase[4], xa0[2][7], xa1[2][7];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) abase[f] = dy_off(8 * lg + jr, f * 16 + 4 * cq);
+#pragma unroll
+  for (int vd = 0; vd < 2; ++vd)
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+      const int t = min(tg + 4 * k, 26);                    // group 3 has six taps: its seventh slot re-reads tap 26
+      const int pl = vd + t / 9, R = ((pl & 1) * XH + (t / 3) % 3) * XW + t % 3;
+      const int lrow = lg * XW + jr, col = (pl >> 1) * 32 + cib * 16 + 4 * cq;
+      xa0[vd][k] = (R + lrow) * 128 + ((((col >> 4) ^ ((R + lrow) >> 1)) & 3) << 5) + ((col & 15) << 1);
+      xa1[vd][k] = (R + 4 + lrow) * 128 + ((((col >> 4) ^ ((R + 4 + lrow) >> 1)) & 3) << 5) + ((col & 15) << 1);
+    }
+  // (group 3's seventh slot multiplies tap 26 once more into an accumulator that is never written: 4 of 112 MFMAs per K chunk of two of
+  // the eight waves, cheaper than a branch around them -- a conditional MFMA cost 30 spilled registers)
+
+  if (b_beg < b_end) {
+    W27_ORIGIN_NEXT();
+#pragma unroll
+    for (int i = 0; i < NPIECE27; ++i) W27_DMA_PIECE(i, smem);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // K chunk kc = brick d plane kc >> 1, h half kc & 1 (32 voxels); tap t = (kd, kh, kw) reads halo plane (kc >> 1) + kd:
+  // row block (plane & 1), row half (plane >> 1)
+#define W27_A(kc_, f_) tr_frag(dys + abase[f_] + (kc_)*4096, dys + abase[f_] + (kc_)*4096 + 512)
+#define W27_B(kc_, k_) tr_frag(xs + xa0[(kc_) >> 1][k_] + ((kc_)&1) * (4 * XW * 128), xs + xa1[(kc_) >> 1][k_] + ((kc_)&1) * (4 * XW * 128))
+
+  for (int b = b_beg; b < b_end; ++b) {
+    const char* dys = smem + ((b - b_beg) & 1) * BUF27_BYTES;
+    const char* xs = dys + DY_BYTES;
+    char* nxt = smem + (((b - b_beg) & 1) ^ 1) * BUF27_BYTES;
+    const bool more = b + 1 < b_end;
+    W27_ORIGIN_NEXT();
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 fa[2][4], fbr[2];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fa[0][f] = W27_A(0, f);
+    fbr[0] = W27_B(0, 0);
+#pragma unroll
+    for (int st = 0; st < NSTEP27; ++st) {
+      const int kc = st / 7, k = st % 7;
+      if (st < NPIECE27) {
+        if (more) W27_DMA_PIECE(st < NPIECE27 ? st : 0, nxt);
+      }
+      if (st + 1 < NSTEP27) fbr[(st + 1) & 1] = W27_B((st + 1) / 7, (st + 1) % 7);
+      if (k == 3 && kc < 3) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f) fa[(kc + 1) & 1][f] = W27_A(kc + 1, f);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) acc[k][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st & 1], acc[k][f], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef W27_A
+#undef W27_B
+#undef W27_ORIGIN_NEXT
+#undef W27_DMA_PIECE
+
+  // D[i][j]: lane holds i = 16 f + 4 lg + r (co), j = lane & 15 of the wave's ci block
+  float* out = p.ws + (int64_t)split * 27 * p.Cu * p.Cv;
+  const int j = j0 + cib * 16 + (lane & 15);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    const int t = tg + 4 * k;
+    if (t < 27) {
+      float* ot = out + (int64_t)((t / 9) * p.td + ((t / 3) % 3) * p.th + (t % 3) * p.tw) * p.Cu * p.Cv;
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ot[(int64_t)(i0 + f * 16 + lg * 4 + r) * p.Cv + j] = acc[k][f][r];
+    }
+  }
+}
+
 struct BrickSplit {
   int splits, per_split;
   int xcd_map, G, Q, gpc, ngroups, ntg, pair, blocks;   // co-located launch (see WBrickParams); blocks = grid size
@@ -712,6 +932,26 @@ bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int d
   return dtype == PCRL_BF16 && (wb_natural(D, H, W) || wb_permuted(D, H, W)) && Co % 64 == 0 && Ci % 32 == 0 &&
          (int64_t)N * D * H * W / BV < (1 << 30) && (int64_t)N * D * H * W * (Ci > Co ? Ci : Co) < ((int64_t)1 << 31);
 }
+// 27-taps-per-block kernel (wgrad_brick27_kernel): layers with 64 output channels and 32 or 64 input channels.  PCRL_WGRAD27=0: off (A/B switch).
+// Measured (same box, isolated, b = 32): 32 -> 64 at 64x64x32  752 -> 965 TFLOP/s (0.617 -> 0.480 ms: the 64 x 32 tile of the one-plane kernel
+// staged a half-empty x image for 9 taps); 64 -> 64 at 64x64x32  1 162 -> 1 198; 64 -> 64 at 32x32x16 (4 096 bricks)  895 -> 851: with Ci = 64
+// the one-plane kernel is no longer bound by its staging (both forms sit at ~0.8 transpose reads per MFMA), and on small volumes the
+// larger tile count of the one-plane form fills the chip better -- so: Ci = 32 always, Ci = 64 from 8 192 bricks on.
+static bool wb27_on(int Ci, int Co, int nbricks) {
+  static const bool off = [] { const char* e = getenv("PCRL_WGRAD27"); return e && e[0] == '0'; }();
+  return !off && g_wb_tiles && Co == 64 && (Ci == 32 || (Ci == 64 && nbricks >= 8192));
+}
+static void wb27_plan(int nbricks, int Ci, int Co, int& splits, int& per) {
+  const int ntile = (Co / 64) * (Ci / 32);
+  int s = 256 / ntile;                       // one block per CU: one round of 256 blocks
+  if (s > nbricks / 16) s = nbricks / 16;    // at least 16 bricks per block
+  if (s < 1) s = 1;
+  if (s >= 8) s &= ~7;
+  per = (nbricks + s - 1) / s;
+  const int used = (nbricks + per - 1) / per;
+  splits = (s >= 8 && (used & 7)) ? s : used;   // keep the split count a multiple of 8 (the XCD map) unless the tail would be empty
+  if (splits != used && (int64_t)(splits - 1) * per >= nbricks) splits = used;
+}
 int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co) {
   // the workspace must hold the partial slabs of every launch form
   const int nb = (int)((int64_t)N * D * H * W / BV);
@@ -721,13 +961,43 @@ int pcrl_wgrad_brick_splits(int N, int D, int H, int W, int Ci, int Co) {
     const int b = plan_xcd(nb, Co, Ci, cfg).splits;
     if (b > m) m = b;
   }
+  if (Co == 64 && (Ci == 32 || Ci == 64)) {
+    int s27, per27;
+    wb27_plan(nb, Ci, Co, s27, per27);
+    if (s27 > m) m = s27;
+  }
   return m;
 }
-int pcrl_wgrad_brick_slabs(int N, int D, int H, int W, int Ci, int Co) { return plan3((int)((int64_t)N * D * H * W / BV), Co, Ci).splits; }
+int pcrl_wgrad_brick_slabs(int N, int D, int H, int W, int Ci, int Co) {
+  const int nb = (int)((int64_t)N * D * H * W / BV);
+  if (wb27_on(Ci, Co, nb)) {
+    int s27, per27;
+    wb27_plan(nb, Ci, Co, s27, per27);
+    return s27;
+  }
+  return plan3(nb, Co, Ci).splits;
+}
 void pcrl_wgrad_brick_set_xcd(int on, int order, int tiles) { g_wb_xcd = on; g_wb_order = order; g_wb_tiles = tiles; }
 int pcrl_wgrad_brick_launch(const void* x, const void* dy, float* ws, int N, int D, int H, int W, int Ci, int Co,
                             hipStream_t stream) {
   const int nbricks = (int)((int64_t)N * D * H * W / BV);
+  if (wb27_on(Ci, Co, nbricks)) {
+    int splits, per;
+    wb27_plan(nbricks, Ci, Co, splits, per);
+    WBrick27Params q{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, per, splits, H * W, W, 1, 9, 3, 1, g_wb_order};
+    if (!wb_natural(D, H, W)) {   // memory (D, H, W) -> brick axes (W, D, H)
+      q.D = W; q.H = D; q.W = H;
+      q.sd = 1; q.sh = H * W; q.sw = W;
+      q.td = 1; q.th = 9; q.tw = 3;
+    }
+    static std::once_flag attr27;
+    std::call_once(attr27, [&] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_brick27_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF27_BYTES);
+    });
+    const int ntile = (Co / 64) * (Ci / 32);
+    hipLaunchKernelGGL(wgrad_brick27_kernel, dim3((unsigned)(ntile * splits)), dim3(NT), 2 * BUF27_BYTES, stream, q);
+    return pcrl_check_launch("wgrad_brick (27 taps per block)");
+  }
   const BrickSplit sp = plan3(nbricks, Co, Ci);
   WBrickParams p{(const bf16*)dy, (const bf16*)x, ws, N, D, H, W, Co, Ci, nbricks, sp.per_split, 0, 3, H * W, W, 1, 9, 3, 1,
                  sp.xcd_map, g_wb_order, sp.G, sp.Q, sp.gpc, sp.ngroups, sp.ntg, sp.pair};
