@@ -244,6 +244,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rc_kernel(const T* __restric
   else bn_bwd_apply_rc_kernel_body<T, ACT, false>(da, y, dy, scale, shift, k1, kB, kA, M, C, ra);
 }
 
+#ifndef BN_RED_U
+#define BN_RED_U 4
+#endif
 // First-stage reduction of the backward: per 1024-row tile, per channel: (sum dz, sum dz*xhat).
 // Thread = (channel vector, row slot); LDS combine over row slots.  nvec = C/VEC divides 256.
 template <typename T, int ACT, bool NT>
@@ -285,19 +288,20 @@ __device__ __forceinline__ void bn_bwd_reduce_kernel_body(const T* __restrict__ 
       n_have = n_;                                                                               \
     }                                                                                            \
   }
-  // four rows in flight per thread (eight 16-byte loads): the tile is streamed once and nothing else hides HBM latency
+  // BN_RED_U rows in flight per thread (2 x BN_RED_U 16-byte loads): the tile is streamed once and nothing else hides HBM latency
+  constexpr int U = BN_RED_U;
   int64_t r = rbeg + slot;
   if (!ra.g || ra_tile) {
-    for (; r + 3 * (int64_t)nslots < rend; r += 4 * (int64_t)nslots) {
-      Vec16<T> g[4], v[4];
+    for (; r + (U - 1) * (int64_t)nslots < rend; r += U * (int64_t)nslots) {
+      Vec16<T> g[U], v[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int64_t off = ((r + u * (int64_t)nslots) * nvec + cv) * VEC;
         if (da) g[u] = ld16_sel<NT>(da + off);
         v[u] = ld16_sel<NT>(y + off);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           const float yv = to_f(v[u].v[j]);

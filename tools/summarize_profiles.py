@@ -10,7 +10,7 @@ import sys
 
 
 def short(name):
-    for key in ("brick16_conv_kernel", "brick_conv_kernel", "wgrad_brick_upc2_kernel", "wgrad_brick_kernel", "wgrad_upc8_kernel", "wgrad_reduce_upc_kernel", "wgrad_reduce_kernel", "bn_bwd_reduce_pool_kernel",
+    for key in ("brick16_conv_kernel", "brick_conv_kernel", "wgrad_brick_upc2_kernel", "wgrad_brick27_kernel", "wgrad_brick_kernel", "wgrad_upc8_kernel", "wgrad_reduce_upc_kernel", "wgrad_reduce_kernel", "bn_bwd_reduce_pool_kernel",
                 "bn_bwd_apply_pool_kernel", "bn_apply_pool_kernel", "bn_apply_gap_kernel", "bn_bwd_reduce_kernel", "bn_bwd_apply_rc_kernel",
                 "bn_apply_rc_kernel", "igemm_kernel", "wgrad_kernel", "coltile_sum_kernel", "sgemm_small_kernel", "shift_sum27_kernel",
                 "c1_fwd_kernel", "maxpool_bwd_kernel", "maxpool_fwd_kernel", "im2col27_kernel", "gap_bwd_kernel", "to1_dgrad_kernel",
@@ -75,7 +75,7 @@ def main():
                 "# SQ counters are sampled on ONE XCD (SQ_BUSY_CU_CYCLES / GRBM_GUI_ACTIVE ~ 30 of its 32 CUs): MFMA busy fraction =\n"
                 "# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 32 CUs * 4 SIMDs).\n")
         traffic = {}
-        mfma_kernels = ["brick16_conv_kernel", "brick16_conv_kernel<upconv_fwd>", "brick16_conv_kernel<upconv_dgrad>", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_brick_upc2_kernel", "wgrad_upc8_kernel"] + sorted(k for k in fd if k.startswith("igemm_kernel<") and "upconv" in k)
+        mfma_kernels = ["brick16_conv_kernel", "brick16_conv_kernel<upconv_fwd>", "brick16_conv_kernel<upconv_dgrad>", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_brick27_kernel", "wgrad_brick_upc2_kernel", "wgrad_upc8_kernel"] + sorted(k for k in fd if k.startswith("igemm_kernel<") and "upconv" in k)
         for k in mfma_kernels:
             if k not in fd or k not in wd or k not in md:
                 continue
