@@ -25,9 +25,9 @@ CASES = {"e_b16_32x32x16": (16, (32, 32, 16)), "e_luna_b8_64x64x32": (8, (64, 64
 LOSSES = ("loss", "loss1", "loss2", "loss4", "local_loss")
 
 
-def run(mod, st32, batch, epoch, seed):
+def run(mod, st32, batch, epoch, seed, track_bufs=True):
     st = OrderedDict((k, (v.double().requires_grad_(True) if not O.is_buffer(k) else v.double() if v.is_floating_point() else v)) for k, v in st32.items())
-    nb = {}
+    nb = {} if track_bufs else None
     with torch.backends.mkldnn.flags(enabled=False):
         r = mod.step_losses(st, batch, epoch, random.Random(seed), nb)
         names = [k for k in st if not O.is_buffer(k)]
@@ -60,7 +60,12 @@ def make(tag, epoch=3, seed=0):
     torch.set_num_threads(8)
     st32 = O.fill_state(torch.float32)                      # the engine's float32 master weights
     batch = tuple(t.double() if torch.is_tensor(t) else [u.double() for u in t] for t in O.fill_batch(b, dhw, dtype=torch.float32, seed=7))
-    r, grads, nb = run(E, st32, batch, epoch, seed)
+    big = b * dhw[0] * dhw[1] * dhw[2] > 400000       # the 64x64x32, b = 8 case: recompute stages in backward (memory), no buffer tracking
+    E.CHECKPOINT = big
+    try:
+        r, grads, nb = run(E, st32, batch, epoch, seed, track_bufs=not big)
+    finally:
+        E.CHECKPOINT = False
     fx = OrderedDict()
     fx["meta/b"], fx["meta/dhw"], fx["meta/epoch"], fx["meta/seed"], fx["meta/batch_seed"] = np.int64(b), np.array(dhw), np.int64(epoch), np.int64(seed), np.int64(7)
     for k in LOSSES:
@@ -79,7 +84,7 @@ def make(tag, epoch=3, seed=0):
             fx[f"grad/{name}/none"] = np.int64(1)
         else:
             fx[f"grad/{name}/l2"], fx[f"grad/{name}/samples"] = summ(g, 2048)
-    for name, v in nb.items():
+    for name, v in (nb or {}).items():
         fx["buf1/" + name] = v.double().numpy().copy()
     path = os.path.join(OUT, tag + ".npz")
     np.savez_compressed(path, **fx)

@@ -56,6 +56,18 @@ class _RoundValue(torch.autograd.Function):
 
 rb, rv = _RoundBoth.apply, _RoundValue.apply
 
+# Memory: float64 autograd keeps ~6 full tensors per layer; with CHECKPOINT on every LUConv / decoder stage is recomputed in backward
+# (torch.utils.checkpoint, non-reentrant) and only its input is kept -- what lets the b = 8, 64x64x32 case fit a 62 GB host.  The running
+# statistics are not tracked then (new_bufs must be None: a recomputation would update them twice).
+CHECKPOINT = False
+
+
+def _ckpt(fn, *args):
+    if not CHECKPOINT:
+        return fn(*args)
+    from torch.utils.checkpoint import checkpoint
+    return checkpoint(fn, *args, use_reentrant=False)
+
 _PAIRS = {(0, 0): [(0, 1)], (0, 1): [(1, 0), (2, 1)], (1, 0): [(0, 0), (1, 1)], (1, 1): [(2, 0)]}   # per axis: (p, q) -> [(t, s)]
 
 
@@ -134,10 +146,11 @@ def forward(st, x, local=False, new_bufs=None):
     for i, (p, _, _) in enumerate(O.ENCODER):
         if i in (2, 4, 6):
             h = F.max_pool3d(h, 2)
-        h = _luconv(h, st, p, new_bufs, first=(i == 0))
+        assert not (CHECKPOINT and new_bufs is not None), "running statistics cannot be tracked under checkpointing"
+        h = _ckpt(lambda t, p=p, i=i: _luconv(t, st, p, new_bufs, first=(i == 0)), h)
     feats, masks_raw = [], []
     for name, _, _ in O.DECODER:
-        h, pro, pre, mk = _up_transition(h, st, name, new_bufs)
+        h, pro, pre, mk = _ckpt(lambda t, name=name: _up_transition(t, st, name, new_bufs), h)
         feats.append([pro, pre])
         masks_raw.append(mk)
     masks = []
