@@ -238,17 +238,25 @@ class mfma_turn:
 # sizes the pools ONCE, after the first complete step of a (model, batch shape): every segment the first step left in a stream's pool is
 # duplicated PROVISION_FACTOR - 1 times on the same stream (288 GB of HBM: the 3x of a 13 GB peak is nothing), so the steady state is there
 # from step 2.  One device synchronisation, once.
-_provisioned: set = set()
+_provisioned: dict = {}                # (device index, key) -> bytes reserved right after the pools were sized for that key
 _provisioned_segments: set = set()     # (device, address) of the segments that existed after the last provisioning: only NEW ones are duplicated
 
 
 def provision_allocator(device, key=None):
     f = config.PROVISION_FACTOR
-    if f <= 1 or device.type != "cuda" or (device.index, key) in _provisioned:
+    if f <= 1 or device.type != "cuda":
         return
-    _provisioned.add((device.index, key))
-    torch.cuda.synchronize(device)
     idx = device.index if device.index is not None else torch.cuda.current_device()
+    done = _provisioned.get((idx, key))
+    if done is not None:
+        if torch.cuda.memory_reserved(device) >= 0.7 * done:      # a host-side counter: no synchronisation
+            return
+        # the pools were emptied since (torch.cuda.empty_cache() at the end of an epoch, train_3d.py:83): size them again
+        for k in [k for k in _provisioned if k[0] == idx]:
+            del _provisioned[k]
+        _provisioned_segments.difference_update({e for e in _provisioned_segments if e[0] == idx})
+    _provisioned[(idx, key)] = 0
+    torch.cuda.synchronize(device)
     segs = [s for s in torch.cuda.memory_snapshot() if s["device"] == idx and (idx, s["address"]) not in _provisioned_segments]
     free_b, total_b = torch.cuda.mem_get_info(device)
     want = sum(s["total_size"] for s in segs) * (f - 1)
@@ -292,6 +300,7 @@ def provision_allocator(device, key=None):
     for s in torch.cuda.memory_snapshot():
         if s["device"] == idx:
             _provisioned_segments.add((idx, s["address"]))
+    _provisioned[(idx, key)] = torch.cuda.memory_reserved(device)
 
 
 # ---- the second global view on its own stream (config.VIEW_STREAMS) ----
