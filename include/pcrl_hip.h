@@ -386,6 +386,12 @@ int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y, void* cons
  * g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
 int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
                   int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream);
+/* torch.cat(local_views, dim=0) (train_3d.py:121) as one launch: dst = the n <= 8 contiguous pieces src[k] (nbytes[k] bytes each, multiples
+ * of 16, 16-byte aligned) one after the other.  src / nbytes are HOST arrays, read before the call returns. */
+int pcrl_concat(const void* const* src, const int64_t* nbytes, int n, void* dst, pcrl_stream_t stream);
+/* loss = loss1 + loss2 + loss4 + local_loss with loss4 = beta * l4 (train_3d.py:136-138) from four device scalars in one launch:
+ * out[0] = total (the reference's order of additions), out[1] = beta * l4. */
+int pcrl_loss_total(const float* l1, const float* l2, const float* l4, const float* l5, float beta, float* out, pcrl_stream_t stream);
 /* The divergence guard of train_3d.py:140-142 (`if loss > 1000 and epoch > 10: continue`) decided ON THE DEVICE, so that epochs 11..240 run
  * without a forward -> backward host synchronisation: pcrl_guard_flag writes out[0] = (loss[0] > threshold) ? 1 : 0 (under data parallelism
  * the caller MAX-all-reduces it: one process, one decision in the reference), pcrl_sgd_step_guarded is pcrl_sgd_step that does NOTHING when

@@ -853,6 +853,56 @@ extern "C" int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y,
   return pcrl_check_launch("cosine_terms_bwd");
 }
 
+// dst = the concatenation of up to 8 contiguous buffers (torch.cat of the six local views, train_3d.py:121): ONE launch instead of one
+// device copy per piece.  Sizes in bytes, multiples of 16; 16-byte vectors.
+struct CatParams {
+  const uint4* src[8];
+  int64_t vec_end[8];   // exclusive end of piece k in 16-byte vectors of dst
+  int n;
+};
+__global__ void __launch_bounds__(256) concat_kernel(const CatParams c, uint4* __restrict__ dst) {
+  const int64_t total = c.vec_end[c.n - 1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q)
+      if (q + 1 < c.n && i >= c.vec_end[q]) k = q + 1;
+    dst[i] = c.src[k][i - (k ? c.vec_end[k - 1] : 0)];
+  }
+}
+extern "C" int pcrl_concat(const void* const* src, const int64_t* nbytes, int n, void* dst, pcrl_stream_t stream) {
+  PCRL_REQUIRE(src && nbytes && dst && n >= 1 && n <= 8, "concat: 1..8 pieces");
+  CatParams c;
+  int64_t end = 0;
+  for (int k = 0; k < 8; ++k) {
+    if (k < n) {
+      PCRL_REQUIRE(src[k] && nbytes[k] > 0 && nbytes[k] % 16 == 0 && al16(src[k]), "concat: piece %d must be a non-empty 16-byte multiple, 16-byte aligned", k);
+      end += nbytes[k] / 16;
+    }
+    c.src[k] = k < n ? static_cast<const uint4*>(src[k]) : nullptr;
+    c.vec_end[k] = end;
+  }
+  c.n = n;
+  PCRL_REQUIRE(al16(dst), "concat: destination not 16-byte aligned");
+  hipLaunchKernelGGL(concat_kernel, dim3(grid_for(end)), dim3(256), 0, as_stream(stream), c, static_cast<uint4*>(dst));
+  return pcrl_check_launch("concat");
+}
+
+// total = l1 + l2 + beta * l4 + l5 and scaled = beta * l4 in one launch (train_3d.py:136-138): out[0] = total, out[1] = scaled
+__global__ void loss_total_kernel(const float* __restrict__ l1, const float* __restrict__ l2, const float* __restrict__ l4, const float* __restrict__ l5,
+                                  float beta, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float s = beta * l4[0];
+    out[1] = s;
+    out[0] = ((l1[0] + l2[0]) + s) + l5[0];      // the reference's order of additions: loss1 + loss2 + loss4 + local_loss
+  }
+}
+extern "C" int pcrl_loss_total(const float* l1, const float* l2, const float* l4, const float* l5, float beta, float* out, pcrl_stream_t stream) {
+  PCRL_REQUIRE(l1 && l2 && l4 && l5 && out, "loss_total: null pointer");
+  hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, as_stream(stream), l1, l2, l4, l5, beta, out);
+  return pcrl_check_launch("loss_total");
+}
+
 static int sgd_launch(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors, int64_t total, float lr,
                       float momentum, float weight_decay, float grad_scale, const float* skip, pcrl_stream_t stream) {
   PCRL_REQUIRE(p && g && buf && offsets && flags && ntensors > 0 && total > 0, "sgd_step: bad arguments");

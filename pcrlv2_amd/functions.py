@@ -455,17 +455,22 @@ class CosineTermsFn(Function):
         grads, seen = [None] * len(ts), set()
         first = []
         for s in spec:
-            if grads[s[0]] is None:
-                grads[s[0]] = torch.empty_like(ts[s[0]])
             key = (s[0], s[1])                      # a row block of a tensor: the first term that touches it stores, later ones add
             first.append(0 if key in seen else 1)
             seen.add(key)
-        # row blocks of a multi-block tensor (the local views) that no term wrote stay undefined: zero them
-        for i, g in enumerate(grads):
-            if g is not None and g.shape[0] != ctx.rows:
-                blocks = {r0 for (xi, r0) in seen if xi == i}
-                if len(blocks) * ctx.rows != g.shape[0]:
-                    g.zero_()
+        # row blocks of a multi-block tensor (the local views) that no term writes must read as zero: those tensors are carved out of ONE
+        # zero-filled buffer (one fill launch for all of them instead of one per tensor)
+        used = sorted({s[0] for s in spec})
+        holes = [i for i in used if ts[i].shape[0] != ctx.rows and len({r0 for (xi, r0) in seen if xi == i}) * ctx.rows != ts[i].shape[0]]
+        if holes:
+            flat = torch.zeros(sum(ts[i].numel() for i in holes), dtype=torch.float32, device=ts[0].device)
+            o = 0
+            for i in holes:
+                grads[i] = flat[o:o + ts[i].numel()].view_as(ts[i])
+                o += ts[i].numel()
+        for i in used:
+            if grads[i] is None:
+                grads[i] = torch.empty_like(ts[i])
         P, I32 = ctypes.c_void_p * n, ctypes.c_int * n
         dx = P(*[grads[s[0]].data_ptr() + 4 * s[1] * ts[s[0]].shape[1] for s in spec])
         fst = I32(*first)
@@ -473,6 +478,29 @@ class CosineTermsFn(Function):
         ops.lib().call("pcrl_cosine_terms_bwd", adr(x), adr(y), adr(dx), adr(w), adr(C), adr(grp), adr(fst), n, ctx.rows, ctx.ngroups, 1e-8,
                        dout.contiguous().float(), ops.stream_handle())
         return (None, None, None) + tuple(grads)
+
+
+class LossTotalFn(Function):
+    """loss = loss1 + loss2 + beta * l4 + local_loss (train_3d.py:136-138) from four device scalars in one launch -> (total, beta * l4).
+    Backward: the four incoming scalars get g, g, beta * g, g (g = d total + nothing through the second output, which is only reported)."""
+
+    @staticmethod
+    def forward(ctx, l1, l2, l4, l5, beta):
+        out = torch.empty(2, dtype=torch.float32, device=l1.device)
+        f = lambda t: t.detach().reshape(1).float()
+        ops.lib().call("pcrl_loss_total", f(l1), f(l2), f(l4), f(l5), float(beta), out, ops.stream_handle())
+        ctx.beta = float(beta)
+        total, scaled = out[0], out[1]
+        ctx.mark_non_differentiable(scaled)
+        return total, scaled
+
+    @staticmethod
+    def backward(ctx, g, _g_scaled):
+        return g, g, g * ctx.beta, g, None
+
+
+def loss_total(l1, l2, l4, l5, beta):
+    return LossTotalFn.apply(l1, l2, l4, l5, beta)
 
 
 def cosine_terms(spec, rows, ngroups, tensors):

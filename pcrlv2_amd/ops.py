@@ -1088,6 +1088,23 @@ def conv1x1_to1_backward(x, out, dout, w, dtype, need_dx=True):
     return dx, dw, db
 
 
+def concat_batch(tensors):
+    """torch.cat(tensors, dim=0) of contiguous tensors of one shape / dtype / device as ONE launch (pcrl_concat: up to 8 pieces; the six local
+    views of a step, train_3d.py:121) instead of one device copy per piece.  Falls back to torch.cat for what the kernel does not take."""
+    t0 = tensors[0]
+    ok = (1 <= len(tensors) <= 8 and t0.is_cuda and all(t.is_contiguous() and t.shape == t0.shape and t.dtype == t0.dtype and t.device == t0.device for t in tensors)
+          and (t0.numel() * t0.element_size()) % 16 == 0 and all(t.data_ptr() % 16 == 0 for t in tensors))
+    if not ok:
+        return torch.cat(tensors, dim=0)
+    import ctypes
+    n = len(tensors)
+    out = torch.empty((n * t0.shape[0],) + tuple(t0.shape[1:]), dtype=t0.dtype, device=t0.device)
+    src = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    nb = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in tensors])
+    lib().call("pcrl_concat", ctypes.addressof(src), ctypes.addressof(nb), n, out, stream_handle())
+    return out
+
+
 def mse_forward(p, gt):
     L = lib()
     n = p.numel()

@@ -131,15 +131,15 @@ def step_losses(model, batch, epoch, criterion, cosine):
     _ops.fork_views(view1.device)  # config.VIEW_STREAMS: the second view's forward (and backward) on its own stream, next to the first's
     if fused and _cfg.INTERLEAVE_VIEWS and hasattr(model, "forward_views") and _ops.view_streams_on(view1.device):
         # the three forwards enqueued stage by stage in rotation, each pass on its own stream (config.INTERLEAVE_VIEWS / MFMA_TOKEN)
-        loc = torch.cat([_to_gpu(v) for v in local_views], dim=0)
+        loc = _ops.concat_batch([_to_gpu(v) for v in local_views])
         with _ops.deferred_join():
             (out1, feats1, masks1), (_out2, feats2, _), (_, feats_loc, _) = model.forward_views(
                 [(view1, False, None), (view2, False, "view2"), (loc, True, "local")])
         l_global, l_local, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
         l_restore = criterion(out1, target)
         beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
-        l_deep = beta * criterion(masks1[scale], target)
-        return l_restore + l_global + l_deep + l_local, l_restore, l_global, l_deep, l_local
+        total, l_deep = _fn.loss_total(l_restore, l_global, criterion(masks1[scale], target), l_local, beta)
+        return total, l_restore, l_global, l_deep, l_local
     with _ops.deferred_join():     # the decoder stages' side branches (heads, deep-supervision maps) also run under the NEXT forward; joined on exit
         out1, feats1, masks1 = model(view1)
         # mask2, the local views' reconstruction and their deep-supervision maps are never used (train_3d.py:117,123): the engine's
@@ -148,15 +148,15 @@ def step_losses(model, batch, epoch, criterion, cosine):
         with _ops.view_pass(view2.device, view2):
             _out2, feats2, _ = model(view2, **fo)
         if fused:
-            loc = torch.cat([_to_gpu(v) for v in local_views], dim=0)
+            loc = _ops.concat_batch([_to_gpu(v) for v in local_views])
             with _ops.view_pass(loc.device, loc, name="local"):
                 _, feats_loc, _ = model(loc, local=True, **fo)
     if fused:
         l_global, l_local, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
         l_restore = criterion(out1, target)
         beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
-        l_deep = beta * criterion(masks1[scale], target)
-        return l_restore + l_global + l_deep + l_local, l_restore, l_global, l_deep, l_local
+        total, l_deep = _fn.loss_total(l_restore, l_global, criterion(masks1[scale], target), l_local, beta)   # one launch: the sum and beta * MSE
+        return total, l_restore, l_global, l_deep, l_local
     l_global, scale = cos_loss(cosine, feats1, feats2)
     _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True, **fo)
     stacked = [torch.stack(pair) for pair in feats_loc]                 # [2, 6n, C] per scale

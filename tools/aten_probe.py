@@ -39,7 +39,7 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
         train_step(model, opt, batch, 0, crit, cosine, guard=False)
         torch.cuda.synchronize()
-    agg = collections.Counter()
+    agg, nk = collections.Counter(), collections.Counter()
     for ev in prof.events():
         if not ev.name.startswith("aten::") or not ev.kernels:
             continue
@@ -49,11 +49,20 @@ def main():
                 site = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr
                 break
         agg[(ev.name, site, ev.kernels[0].name[:50])] += 1
-    tot = 0
+        nk[(ev.name, site, ev.kernels[0].name[:50])] += len(ev.kernels)
+    tot = totk = 0
     for (name, site, k), n in sorted(agg.items(), key=lambda kv: -kv[1]):
-        print(f"{n:4d}  {name:28s} {k:52s} {site}")
+        print(f"{n:4d} ops {nk[(name, site, k)]:4d} device launches  {name:28s} {k:52s} {site}")
         tot += n
-    print("total ATen ops that launched device work in one step:", tot)
+        totk += nk[(name, site, k)]
+    print("total ATen ops that launched device work in one step:", tot, "-- device launches (kernels + copies) behind them:", totk)
+    # everything on the device that is NOT one of ours: runtime copies / fills / ATen kernels, by name
+    dev = collections.Counter()
+    for ev in prof.events():
+        if ev.device_type == torch.autograd.DeviceType.CUDA and not ev.name.startswith(("void (anonymous namespace)", "(anonymous namespace)")) and "_kernel" not in ev.name:
+            dev[ev.name[:70]] += 1
+    for k, n in dev.most_common(12):
+        print(f"   device-side event {n:4d} x {k}")
 
 
 if __name__ == "__main__":
