@@ -32,7 +32,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # up to five streams per rank (pcrlv2_amd/__init__.py)
+# GPU_MAX_HW_QUEUES stays at ROCm's default (4): see pcrlv2_amd/__init__.py (8 costs 7.5 ms per step once RCCL is initialised)
 
 import torch  # noqa: E402
 
@@ -213,6 +213,21 @@ def main():
     model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
     dp = ddp.DataParallel(model, opt) if world > 1 else None  # noqa: F841
+    if world == 1 and os.environ.get("PCRL_FORCE_DDP", "0") == "2":     # bisect probe: the process group alone, no wrapper
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("gloo" if os.environ.get("PCRL_DIST_PROBE_GLOO") == "1" else "nccl", rank=0, world_size=1)
+        dist.all_reduce(torch.zeros(4, device=dev))
+    if world == 1 and os.environ.get("PCRL_FORCE_DDP", "0") == "1":
+        # probe, not a BASELINE configuration: the data-parallel wrapper on a ONE-rank RCCL group (bucket sums on the communication stream,
+        # the collectives, the guarded hooks all run for real) -- what the multi-rank code path costs on one GPU, labelled in the JSON line
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        dp = ddp.DataParallel(model, opt, force_collectives=True)  # noqa: F841
+        dist_info = {"backend": "nccl (RCCL)", "world_size": 1, "forced_one_rank_probe": True}
     crit, cosine = MSELoss(), CosineSimilarityMean()
     batch = synthetic_batch(args.b, dhw, 16, dev, 1234 + rank, args.nlocal)
 
@@ -381,7 +396,12 @@ def main():
             pass
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline()
-    print(json.dumps(line))
+    try:        # RCCL's version banner sits in the C stdio buffer of a redirected stdout and would land BEHIND the JSON line at exit: flush it first
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

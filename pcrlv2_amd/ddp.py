@@ -18,6 +18,11 @@ import torch
 import torch.distributed as dist
 
 
+_PROBE_SKIP_COLLECTIVE = os.environ.get("PCRL_DDP_PROBE_SKIP_COLLECTIVE", "0") == "1"   # tools/ddp_overlap_probe.sh only: everything but the collective itself
+_PROBE_DEFER = os.environ.get("PCRL_DDP_PROBE_DEFER", "0") == "1"                       # ... callbacks on, bucket launches left to optimizer.step()
+_PROBE_SKIP_FLUSH = os.environ.get("PCRL_DDP_PROBE_SKIP_FLUSH", "0") == "1"             # ... only the callbacks' bookkeeping (wrong results)
+
+
 def init_process_group_from_env(backend: str | None = None):
     """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
     if dist.is_initialized():
@@ -151,7 +156,17 @@ class DataParallel:
     on the side stream -- while the rest of backward (earlier layers) is still running.  Whatever is not final by then
     (parameters without a pass-0 gradient, e.g. the unused deep-supervision heads) is swept up in optimizer.step().
     A gradient that arrives for a bucket already sent ("late"; cannot happen with the reference's step) is all-reduced on its
-    own and added.  `overlap=False` (or PCRL_DDP_OVERLAP=0) does everything in optimizer.step().
+    own and added.
+
+    Default: `overlap=False` (PCRL_DDP_OVERLAP=1 turns it on) -- a MEASURED choice (tools/ddp_overlap_probe.sh: the wrapper on a one-rank
+    RCCL group on one MI355X, where the collectives themselves cost nothing): launching buckets from inside backward costs 1.2-1.7 ms
+    per step (34.2-34.6 vs 32.4-32.7 ms), launching them all from optimizer.step() costs nothing measurable (33.1-33.3 vs 33.3 without a
+    wrapper).  The reason is structural: a bucket is made of WEIGHT gradients, those are produced on the side stream, and the side stream is
+    the one that finishes last (it carries the ~10 ms backlog of weight-gradient kernels that run next to the data-gradient chain) -- in the
+    rocprofv3 trace the first bucket's sums execute at 34.2 ms of a 38 ms step however early they were queued.  There is nothing to overlap
+    the 68 MB all-reduce with except that backlog, and all-reducing at the end costs its own time only (~0.7 ms on 8 GPUs at RCCL's
+    large-message rate).  Either way the collectives and the bucket sums run on the side stream, behind the weight gradients they
+    consume, so they start the moment those are done.
     """
 
     def __init__(self, model: torch.nn.Module, optimizer, group=None, bucket_mb: float = 24.0, strict_flags: bool = False,
@@ -164,7 +179,13 @@ class DataParallel:
         self._active = self.world > 1 or (force_collectives and dist.is_initialized())   # 1-rank groups: test hook only
         sizes = list(getattr(optimizer, "_slot_sizes", None) or [p.numel() for p in optimizer._plist])   # arena slots (FusedSGD pads to 16 bytes)
         self.reducer = BucketedAllReduce(optimizer.flat_g, sizes, group, bucket_mb)
-        self.overlap = (os.environ.get("PCRL_DDP_OVERLAP", "1") == "1") if overlap is None else overlap
+        if optimizer.flat_g.is_cuda and os.environ.get("PCRL_DDP_COMM_STREAM", "side") == "side":
+            # bucket sums and collectives on the engine's side stream rather than on a stream of their own: main, view, side and RCCL's
+            # internal stream are then the four streams of a rank -- as many as ROCm's default hardware queues (measured on one GPU with a
+            # one-rank RCCL group: a fifth stream costs 1.7 ms per step; GPU_MAX_HW_QUEUES=8 costs 7.5 ms once RCCL is initialised)
+            from . import ops
+            self.reducer.comm_stream = ops.side_stream(optimizer.flat_g.device)
+        self.overlap = (os.environ.get("PCRL_DDP_OVERLAP", "0") == "1") if overlap is None else overlap
         optimizer.grad_scale = 1.0 / self.world
         optimizer.pre_step = self._pre_step
         # bucket bookkeeping: which parameters live in which bucket
@@ -205,7 +226,7 @@ class DataParallel:
         self._final[i] = True
         bi = self._param_bucket[i]
         self._ready[bi] += 1
-        if self._ready[bi] == len(self._bucket_params[bi]) and not self._launched[bi]:
+        if self._ready[bi] == len(self._bucket_params[bi]) and not self._launched[bi] and not _PROBE_DEFER:
             self._launch_bucket(bi)
 
     @torch.no_grad()
@@ -233,27 +254,35 @@ class DataParallel:
         """Sum the bucket's gradients into the flat arena (zeros for parameters without one) and start its all-reduce."""
         opt = self.opt
         idxs = self._bucket_params[bi]
-        self._fn.flush_param_grads([opt._plist[i] for i in idxs])
-        miss = [i for i in idxs if opt._plist[i].grad is None]
-        copy = [i for i in idxs if opt._plist[i].grad is not None and opt._plist[i].grad.data_ptr() != opt._gviews[i].data_ptr()]
-        if copy:
-            torch._foreach_copy_([opt._gviews[i] for i in copy], [opt._plist[i].grad for i in copy])
-        if miss:
-            torch._foreach_zero_([opt._gviews[i] for i in miss])
+        cs = self.reducer.comm_stream
+        b, e = self.reducer.buckets[bi]
+        seg = opt.flat_g[b:e]
+        from . import ops
+        import contextlib
+        with ops.trace_range("all_reduce bucket %d (%.1f MB)" % (bi, (e - b) * 4 / 2**20)):
+            # On the GPU everything a bucket needs -- summing its parked gradients into the arena, zero-filling parameters without a gradient,
+            # the collective -- runs on the COMMUNICATION stream, which waits for the producers; the main stream is never joined here, so the
+            # weight gradients queued on the side stream keep overlapping the data-gradient chain while buckets go out.
+            if _PROBE_SKIP_FLUSH:
+                for i in idxs:
+                    self._gathered[i] = True
+                self._launched[bi] = True
+                return
+            self._fn.flush_param_grads([opt._plist[i] for i in idxs], on_stream=cs)
+            if cs is not None:
+                cs.wait_stream(torch.cuda.current_stream())
+            with (torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext()):
+                miss = [i for i in idxs if opt._plist[i].grad is None]
+                copy = [i for i in idxs if opt._plist[i].grad is not None and opt._plist[i].grad.data_ptr() != opt._gviews[i].data_ptr()]
+                if copy:
+                    torch._foreach_copy_([opt._gviews[i] for i in copy], [opt._plist[i].grad for i in copy])
+                if miss:
+                    torch._foreach_zero_([opt._gviews[i] for i in miss])
+                if not _PROBE_SKIP_COLLECTIVE:
+                    self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for i in idxs:
             self._gathered[i] = True
         self._launched[bi] = True
-        b, e = self.reducer.buckets[bi]
-        seg = opt.flat_g[b:e]
-        cs = self.reducer.comm_stream
-        from . import ops
-        with ops.trace_range("all_reduce bucket %d (%.1f MB)" % (bi, (e - b) * 4 / 2**20)):
-            if cs is not None:
-                cs.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(cs):
-                    self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            else:
-                self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def broadcast_state(self):
         if not self._active:

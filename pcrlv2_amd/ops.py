@@ -178,6 +178,30 @@ def join_side_stream(device=None):
                     cur.wait_stream(vs)
 
 
+def side_stream(device):
+    """The side stream of `device` (created on first use): weight gradients, forward side branches -- and, under data parallelism, the
+    bucket sums and collectives (ddp.DataParallel), so that a rank never drives more than four streams (ROCm's default number of
+    hardware queues per process: a fifth stream shares a queue with another one and serialises with it)."""
+    key = (device.type, device.index)
+    side = _side_streams.get(key)
+    if side is None:
+        side = _side_streams[key] = torch.cuda.Stream(device=device)
+    return side
+
+
+def producer_streams(device):
+    """The streams other than the current one that a step launches gradient producers on (side stream, view streams) -- what a consumer on
+    yet another stream (the data-parallel wrapper's communication stream) has to wait for."""
+    out = []
+    s = _side_streams.get((device.type, device.index))
+    if s is not None:
+        out.append(s)
+    for (dt_, di_, _name), vs in _view_streams.items():
+        if (dt_, di_) == (device.type, device.index):
+            out.append(vs)
+    return out
+
+
 # ---- host run-ahead (config.MAX_STEPS_AHEAD) ----
 _step_ends: dict = {}      # device index -> deque of events recorded at the end of the last steps
 
