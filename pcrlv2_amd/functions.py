@@ -183,7 +183,7 @@ def mark_final(ctx, params):
         return
     ev = None
     for p in params:
-        if id(p) in _parked:
+        if id(p) in _parked and p.is_cuda:       # (the CPU tests of the wrapper's bookkeeping have no streams)
             if ev is None:
                 ev = torch.cuda.Event()
                 ev.record()

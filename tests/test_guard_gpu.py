@@ -154,7 +154,8 @@ both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
 dist.all_gather(both, mine)
 assert both[0].item() == both[1].item(), both
 dist.barrier()
-print("OK", rank)
+print("OK", rank, flush=True)
+dist.destroy_process_group()      # tear the group down before the interpreter exits (gloo threads alive at exit abort the process now and then)
 '''
 
 

@@ -128,7 +128,8 @@ r.reduce()
 exp = torch.arange(sum(sizes), dtype=torch.float32) * sum(range(1, world + 1))
 assert torch.equal(flat, exp), (flat[:5], exp[:5])
 dist.barrier()
-print("OK", rank)
+print("OK", rank, flush=True)
+dist.destroy_process_group()      # tear the group down before the interpreter exits (gloo threads alive at exit abort the process now and then)
 '''
 
 
@@ -200,7 +201,8 @@ for step in range(3):
         mult = {0: 2, 1: 1, 2: 2, 3: 0, 4: 2}[i]
         assert torch.allclose(v, torch.full_like(v, float(mult * tot))), (step, i, v.flatten()[:3], mult * tot)
 dist.barrier()
-print("OK", rank)
+print("OK", rank, flush=True)
+dist.destroy_process_group()      # tear the group down before the interpreter exits (gloo threads alive at exit abort the process now and then)
 '''
 
 
@@ -400,7 +402,8 @@ assert float(divergence_flag(torch.tensor(1000.0))) == 0.0
 # NaN > 1000 is False in the reference as well: a NaN loss does not trip the guard
 assert float(divergence_flag(torch.tensor(float("nan")))) == 0.0
 dist.barrier()
-print("OK", rank)
+print("OK", rank, flush=True)
+dist.destroy_process_group()      # tear the group down before the interpreter exits (gloo threads alive at exit abort the process now and then)
 '''
 
 

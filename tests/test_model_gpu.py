@@ -834,7 +834,8 @@ for bt in batches:
     train_step(model, opt, bt, 3, MSELoss(), CosineSimilarityMean())
 assert not torch.equal(opt.flat_p, finals[0])
 dist.barrier()
-print("OK", rank)
+print("OK", rank, flush=True)
+dist.destroy_process_group()      # tear the group down before the interpreter exits (gloo threads alive at exit abort the process now and then)
 '''
 
 
