@@ -111,3 +111,15 @@ PROVISION_FACTOR = int(os.environ.get("PCRL_PROVISION_FACTOR", "3"))
 INTERLEAVE_VIEWS = os.environ.get("PCRL_INTERLEAVE", "0") == "1"
 MFMA_TOKEN = os.environ.get("PCRL_MFMA_TOKEN", "0") == "1"
 MFMA_TOKEN_MIN_GF = float(os.environ.get("PCRL_MFMA_TOKEN_MIN_GF", "20"))
+
+# Weight gradients of the second view's backward on the view stream itself (ops.side_wgrad) instead of the side stream.  Measured without a
+# profiler (tools/stream_balance_probe.py: events at the tail of every stream): the view stream ran dry 24.2 ms into a 31.6 ms step -- it
+# carries one pass, the main stream two (view 1 + local views) and the side stream the weight gradients of all three -- so for a quarter of
+# the step only two streams fed the chip.  With the second view's plain weight gradients inline (the composed up-conv's accumulations stay on
+# the side stream: they add into buffers the passes share, ordered by that stream) the view stream ends at 29.4 ms and the step goes
+# 32.36 -> 31.84 ms (same box, three interleaved runs each).  PCRL_VIEW_WGRAD_INLINE=0: off (A/B switch; results are bit-identical).
+VIEW_WGRAD_INLINE = os.environ.get("PCRL_VIEW_WGRAD_INLINE", "1") != "0"
+
+# EXPERIMENT: the second view's forward side branches (heads, deep-supervision map) on the view stream itself instead of the side stream
+# (the view stream is idle for the last 2 ms of the forward phase).  PCRL_VIEW_BRANCH_INLINE=1: on.
+VIEW_BRANCH_INLINE = os.environ.get("PCRL_VIEW_BRANCH_INLINE", "0") == "1"

@@ -98,9 +98,16 @@ _side_pending: dict = {}
 class side_wgrad:
     """`with side_wgrad(device, x, dy) as ws:` -- launches inside run on the side stream; ws(nbytes) is its scratch arena."""
 
-    def __init__(self, device, *operands, path2d=False):
+    def __init__(self, device, *operands, path2d=False, shared_accumulator=False):
         self.device, self.operands = device, operands
         self.active = (config.WGRAD_SIDE_STREAM_2D if path2d else config.WGRAD_SIDE_STREAM_3D) and device.type == "cuda"
+        if self.active and config.VIEW_WGRAD_INLINE and not shared_accumulator and not path2d and _views_active:
+            # config.VIEW_WGRAD_INLINE: a weight gradient of the SECOND VIEW's backward stays on the view stream (which otherwise runs dry a
+            # quarter of the step before the others) instead of queueing behind everybody's on the side stream.  Not for launches that add
+            # into an accumulator the passes share (the composed up-conv's: those are ordered by the side stream).
+            cur = torch.cuda.current_stream(device).cuda_stream
+            if any(cur == vs.cuda_stream for vs in _view_streams.values()):
+                self.active = False
 
     def __enter__(self):
         if not self.active:
@@ -130,6 +137,10 @@ class side_branch(side_wgrad):
     def __init__(self, device, *operands):
         self.device, self.operands = device, operands
         self.active = config.FWD_BRANCH_STREAM and device.type == "cuda"
+        if self.active and config.VIEW_BRANCH_INLINE and _views_active:
+            cur = torch.cuda.current_stream(device).cuda_stream
+            if any(cur == vs.cuda_stream for vs in _view_streams.values()):
+                self.active = False       # the second view's side branches stay on its own stream (config.VIEW_BRANCH_INLINE)
 
 
 _defer_join = 0
@@ -895,7 +906,7 @@ class ComposedUpConv(_CacheGuard):
             self.pending = (w_up, b_up, w0, dtype)
             _pending_composed.append(self)
         nb = L.call("pcrl_upconv_wgrad_accum_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
-        with side_wgrad(dev, x, dy) as ws:
+        with side_wgrad(dev, x, dy, shared_accumulator=True) as ws:
             with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
                 L.call("pcrl_upconv_wgrad_accum", x, dy, self.dweff, self.box, (1 if first else 0) | (2 if zero_sum else 0), ws(nb), nb, N, D, H, W, Ci, Co,
                        dtype_code(dtype), stream_handle())
