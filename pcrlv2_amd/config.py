@@ -123,3 +123,8 @@ VIEW_WGRAD_INLINE = os.environ.get("PCRL_VIEW_WGRAD_INLINE", "1") != "0"
 # EXPERIMENT: the second view's forward side branches (heads, deep-supervision map) on the view stream itself instead of the side stream
 # (the view stream is idle for the last 2 ms of the forward phase).  PCRL_VIEW_BRANCH_INLINE=1: on.
 VIEW_BRANCH_INLINE = os.environ.get("PCRL_VIEW_BRANCH_INLINE", "0") == "1"
+
+# Experiment: the second view's forward starts only when the first view's forward has passed its VIEW_SKEW-th stage stop (1..11; 0: off --
+# both views start together and run their identical layer sequences in lockstep, convolution next to convolution and BatchNorm next to
+# BatchNorm).  One event wait per step, nothing else changes; results bit-identical.
+VIEW_SKEW = int(os.environ.get("PCRL_VIEW_SKEW", "0"))

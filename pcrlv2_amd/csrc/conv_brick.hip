@@ -52,6 +52,17 @@ struct BrickParams {
   // strides (in voxels) of those axes in memory and td, th, tw the tap-index strides (a permutation of 9, 3, 1), so a volume whose
   // innermost extent is 4 (the 8 x 8 x 4 bottleneck level) runs with its W as the 4-deep brick axis.  Identity: (H*W, W, 1), (9, 3, 1).
   int sd, sh, sw, td, th, tw;
+  // Composed modes (MODE 1 / 2, KD = 3; the operator and its weight forms are described at conv_brick16.hip's Brick16Params -- this kernel takes
+  // the coarse grids the wide brick does not tile: the 8 x 8 x 4 grid of up_tr256 and the 8^3 grid of the local views' up_tr64).
+  // MODE 1 (forward): x coarse, Nc = 8 * upc = 8 phases x upc channels, w the zero-embedded weights [8 * upc][27][K]; a block (one phase) walks the
+  // 4 of 9 (kd, kh) stages x 2 kw taps of its phase, writes the phase's FINE voxels of y [N][2D][2H][2W][upc] and adds bias_tab[border class].
+  // MODE 2 (data gradient): x = dy0 on the fine grid read as its space-to-depth view, K = 8 parities x upc (chunk c lies in parity c >> cshift),
+  // w = [Nc = Ci][27][8 * upc]; a chunk walks the stages / taps of its parity; the output is an ordinary coarse tensor.
+  int upc;
+  const float* bias_tab;
+  int cshift;
+  int bd, bh, bw;        // bit of the phase / parity number (d = 4, h = 2, w = 1 of the MEMORY axes) that belongs to the brick's d, h, w axis: 2, 1, 0
+  int fsd, fsh, fsw;     // strides, in fine voxels, of the brick's axes on the fine grid: 4 H W, 2 W, 1
 };
 
 // Weight tile [64 co][32 k]: a fragment read takes 16 CONSECUTIVE rows -> same swizzle as conv_igemm.hip's Tile<bf16>.
@@ -69,10 +80,13 @@ __device__ __forceinline__ int hoff_h(int row, int slot) {
   return row * 64 + ((slot ^ (((row >> 2) & 1) << 1)) << 4);
 }
 
-template <int BN, int KD>   // BN = output channels per block: 64, or 32 for the Co = 32 data gradient (wave tile 64 voxels x BN)
+template <int BN, int KD, int MODE = 0>   // BN = output channels per block: 64, or 32 for the Co = 32 data gradient (wave tile 64 voxels x BN)
 __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p) {
   using BG = BrickGeom<KD>;
-  constexpr int HPT = BG::HPT, HALO_BYTES = BG::HALO_BYTES, NS = BG::NS;
+  static_assert(MODE == 0 || KD == 3, "the composed modes are 3-D");
+  constexpr bool UPCF = MODE == 1, UPCD = MODE == 2;
+  constexpr int HPT = BG::HPT, HALO_BYTES = BG::HALO_BYTES, NS = MODE ? 4 : BG::NS;
+  constexpr int NKW = MODE ? 2 : 3;   // kw taps per stage
   constexpr int FN = BN / 16;
   constexpr int WT_BYTES = 3 * BN * 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,6 +116,15 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
     b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
   }
   const int n0 = ytile * BN;
+  // composed modes: phase of the block (forward) / parity of a chunk (data gradient), per BRICK axis
+  const int uph = UPCF ? n0 / p.upc : 0;
+  const int upd = (uph >> p.bd) & 1, uphh = (uph >> p.bh) & 1, upw = (uph >> p.bw) & 1;
+#define PARC(c_) ((c_) >> p.cshift)
+#define PBIT(c_, b_) ((PARC(c_) >> (b_)) & 1)
+  // stage number -> kd * 3 + kh of the brick axes.  Forward: the phase uses k = p, p + 1 per axis; data gradient: the parity uses k = 1 - par, 2 - par.
+#define SID(c_, s_) (MODE == 0 ? (s_) : MODE == 1 ? ((upd + ((s_) >> 1)) * 3 + uphh + ((s_)&1)) \
+                                                 : ((1 - PBIT(c_, p.bd) + ((s_) >> 1)) * 3 + 1 - PBIT(c_, p.bh) + ((s_)&1)))
+#define KWB(c_) (MODE == 0 ? 0 : MODE == 1 ? upw : 1 - PBIT(c_, p.bw))   /* first of the kw taps in use */
   const int brick_id = b;
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
@@ -124,6 +147,8 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
     if (KD == 1 && p.up) {
       const int Hs = p.H >> 1, Ws = p.W >> 1;
       grow[i] = ok ? ((n * p.D + d) * Hs + (h >> 1)) * Ws + (w >> 1) : ((n * p.D + d0) * Hs + (h0 >> 1)) * Ws + (w0 >> 1);
+    } else if (UPCD) {   // fine voxel 2 v (+ the chunk's parity) of the coarse halo voxel v
+      grow[i] = n * (8 * p.D * p.H * p.W) + (ok ? 2 * d * p.fsd + 2 * h * p.fsh + 2 * w * p.fsw : 2 * d0 * p.fsd + 2 * h0 * p.fsh + 2 * w0 * p.fsw);
     } else {
       grow[i] = n * (p.D * p.H * p.W) + (ok ? d * p.sd + h * p.sh + w * p.sw : d0 * p.sd + h0 * p.sh + w0 * p.sw);
     }
@@ -146,8 +171,15 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 
 #define LOAD_HALO(c_)                                                                                     \
   do {                                                                                                    \
-    _Pragma("unroll") for (int i = 0; i < HPT; ++i)                                                       \
-      rh[i] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)grow[i] * K + (c_)*32 + hslot * 8);          \
+    if (UPCD) {                                                                                           \
+      const int poff = PBIT(c_, p.bd) * p.fsd + PBIT(c_, p.bh) * p.fsh + PBIT(c_, p.bw) * p.fsw;          \
+      const int co0 = ((c_) - (PARC(c_) << p.cshift)) * 32 + hslot * 8;                                   \
+      _Pragma("unroll") for (int i = 0; i < HPT; ++i)                                                     \
+        rh[i] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)(grow[i] + poff) * p.upc + co0);           \
+    } else {                                                                                              \
+      _Pragma("unroll") for (int i = 0; i < HPT; ++i)                                                     \
+        rh[i] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)grow[i] * K + (c_)*32 + hslot * 8);        \
+    }                                                                                                     \
   } while (0)
 #define STORE_HALO()                                                                                      \
   do {                                                                                                    \
@@ -155,15 +187,15 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
       *reinterpret_cast<u32x4*>(halo + hdst0 + i * (6 * HW * 64)) = keep_if((hvalid >> i) & 1u, rh[i]);       \
     }                                                                                                     \
   } while (0)
-#define LOAD_W(c_, s9_)                                                                                   \
+#define LOAD_W(c_, s9_, kwb_) /* taps kwb_ .. kwb_ + NKW - 1 of stage (kd, kh) = s9_ */                    \
   do {                                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                         \
-      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)(KD == 3 ? ((s9_) / 3) * p.td + ((s9_) % 3) * p.th + j * p.tw : (s9_)*3 + j) * K + (c_)*32); \
+    _Pragma("unroll") for (int j = 0; j < NKW; ++j)                                                       \
+      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)(KD == 3 ? ((s9_) / 3) * p.td + ((s9_) % 3) * p.th + ((kwb_) + j) * p.tw : (s9_)*3 + j) * K + (c_)*32); \
   } while (0)
 #define STORE_W()                                                                                         \
   do {                                                                                                    \
     if (wthread) {                                                                                        \
-      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                       \
+      _Pragma("unroll") for (int j = 0; j < NKW; ++j)                                                     \
         *reinterpret_cast<u32x4*>(wbuf + j * (BN * 64) + wdst) = rw[j];                                   \
     }                                                                                                     \
   } while (0)
@@ -219,7 +251,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
     if (sn == NS) { sn = 0; cn = c + 1; }                                                                  \
     const bool last = (cn == nchunk);                                                                     \
     if (last) { cn = c; sn = s9; }                                                                        \
-    LOAD_W(cn, sn);                                                                                       \
+    LOAD_W(cn, sn, 0);                                                                                    \
     const bool halo_next = (s9 == NS - 1) && !last; /* block-uniform */                                        \
     if (halo_next) LOAD_HALO(c + 1);                                                                      \
     const int tap64 = ((s9 / 3) * HH + (s9 % 3)) * (HW * 64);                                             \
@@ -252,21 +284,69 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
     s9 = sn;                                                                                              \
   } while (0)
 
+  // Composed modes: a stage = the TWO kw taps its phase / parity uses (fragment set 0 = first tap, set 1 = second); same barriers, the
+  // sets no longer flip between stages.
+#define STAGE2()                                                                                          \
+  do {                                                                                                    \
+    int cn = c, sn = s9 + 1;                                                                              \
+    if (sn == NS) { sn = 0; cn = c + 1; }                                                                  \
+    const bool last = (cn == nchunk);                                                                     \
+    if (last) { cn = c; sn = s9; }                                                                        \
+    const int kwb = KWB(c), kwbn = KWB(cn);                                                               \
+    LOAD_W(cn, SID(cn, sn), kwbn);                                                                        \
+    const bool halo_next = (s9 == NS - 1) && !last; /* block-uniform */                                   \
+    if (halo_next) LOAD_HALO(c + 1);                                                                      \
+    const int tap64 = ((SID(c, s9) / 3) * HH + (SID(c, s9) % 3)) * (HW * 64);                             \
+    const int ntap64 = ((SID(cn, sn) / 3) * HH + (SID(cn, sn) % 3)) * (HW * 64);                          \
+    const int a1 = kwb ? akw[2] : akw[1], an0 = kwbn ? akw[1] : akw[0];                                   \
+    LOADF(1, a1 + tap64, wbuf + 1 * (BN * 64));                                                           \
+    MFMA_ROWS(0, 0, 4);                                                                                   \
+    PIPE_READS(4 + FN, 16 / (4 + FN));                                                                    \
+    SB();                                                                                                 \
+    __syncthreads(); /* every wave holds its second-tap fragments: weight stage (and halo) may be replaced */ \
+    STORE_W();                                                                                            \
+    if (halo_next) {                                                                                      \
+      STORE_HALO();                                                                                       \
+      MFMA_ROWS(1, 0, 2);                                                                                 \
+      PIPE_WRITES(2 * FN, 1);                                                                             \
+    } else {                                                                                              \
+      MFMA_ROWS(1, 0, 2);                                                                                 \
+      PIPE_WRITES(2, 2);                                                                                  \
+    }                                                                                                     \
+    SB();                                                                                                 \
+    __syncthreads();                                                                                      \
+    LOADF(0, an0 + ntap64, wbuf);                                                                         \
+    MFMA_ROWS(1, 2, 4);                                                                                   \
+    PIPE_READS(4 + FN, 1);                                                                                \
+    SB();                                                                                                 \
+    c = cn;                                                                                               \
+    s9 = sn;                                                                                              \
+  } while (0)
+
   LOAD_HALO(0);
-  LOAD_W(0, 0);
+  LOAD_W(0, SID(0, 0), KWB(0));
   STORE_HALO();
   STORE_W();
   __syncthreads();
-  LOADF(0, akw[0], wbuf);
+  LOADF(0, (KWB(0) ? akw[1] : akw[0]) + ((SID(0, 0) / 3) * HH + (SID(0, 0) % 3)) * (HW * 64), wbuf);
 
   const int nstage = NS * nchunk;
-  for (int S = 0; S + 1 < nstage; S += 2) {
-    STAGE(0);
-    STAGE(1);
+  if constexpr (MODE == 0) {
+    for (int S = 0; S + 1 < nstage; S += 2) {
+      STAGE(0);
+      STAGE(1);
+    }
+    if (nstage & 1) STAGE(0);
+  } else {
+    for (int S = 0; S < nstage; ++S) STAGE2();
   }
-  if (nstage & 1) STAGE(0);
   __syncthreads();   // the epilogue reuses the LDS
 #undef STAGE
+#undef STAGE2
+#undef SID
+#undef KWB
+#undef PARC
+#undef PBIT
 #undef SB
 #undef MFMA_ROWS
 #undef LOADF
@@ -283,18 +363,28 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   for (int j = 0; j < FN; ++j) {
     s1[j] = 0.f;
     s2[j] = 0.f;
-    bv[j] = p.bias ? p.bias[n0 + j * 16 + lr] : 0.f;
+    bv[j] = (!UPCF && p.bias) ? p.bias[n0 + j * 16 + lr] : 0.f;
   }
+  const int uch0 = UPCF ? n0 - uph * p.upc : n0;   // first channel of this tile (inside its phase)
+  const int ypitch = UPCF ? p.upc : p.Nc;
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int v = wid * 64 + fm * 16 + lg * 4 + r;
-      const int64_t row = (int64_t)n * p.D * p.H * p.W + (int64_t)(d0 + (v >> 6)) * p.sd + (h0 + ((v >> 3) & 7)) * p.sh + (w0 + (v & 7)) * p.sw;
+      int64_t row = (int64_t)n * p.D * p.H * p.W + (int64_t)(d0 + (v >> 6)) * p.sd + (h0 + ((v >> 3) & 7)) * p.sh + (w0 + (v & 7)) * p.sw;
+      if (UPCF) {   // the phase's fine voxel, and the bias of its border class (0 first, 1 inside, 2 last per axis; class number in memory order = tap strides)
+        const int fd = 2 * (d0 + (v >> 6)) + upd, fh = 2 * (h0 + ((v >> 3) & 7)) + uphh, fw = 2 * (w0 + (v & 7)) + upw;
+        row = (int64_t)n * (8 * p.D * p.H * p.W) + (int64_t)fd * p.fsd + fh * p.fsh + fw * p.fsw;
+        const int cd = fd == 0 ? 0 : (fd == 2 * p.D - 1 ? 2 : 1), ch = fh == 0 ? 0 : (fh == 2 * p.H - 1 ? 2 : 1), cw = fw == 0 ? 0 : (fw == 2 * p.W - 1 ? 2 : 1);
+        const int cls = cd * p.td + ch * p.th + cw * p.tw;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bv[j] = p.bias_tab[cls * p.upc + uch0 + j * 16 + lr];
+      }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const float val = acc[fm][j][r] + bv[j];
-        p.y[row * p.Nc + n0 + j * 16 + lr] = (bf16)val;
+        p.y[row * ypitch + uch0 + j * 16 + lr] = (bf16)val;
         s1[j] += val;
         s2[j] += val * val;
       }
@@ -386,4 +476,59 @@ int pcrl_brick_conv2d_launch(const void* x, const void* wp, const float* bias, v
   if (Co % 64 == 0) hipLaunchKernelGGL((brick_conv_kernel<64, 1>), dim3(bricks, Co / 64), dim3(256), HB + 3 * 64 * 64, stream, p);
   else hipLaunchKernelGGL((brick_conv_kernel<32, 1>), dim3(bricks, Co / 32), dim3(256), HB + 3 * 32 * 64, stream, p);
   return pcrl_check_launch("brick_conv2d");
+}
+
+// ---- composed ConvTranspose3d -> Conv3d operator (upconv_fused.hip) on the 4 x 8 x 8 brick: forward and data gradient ----
+// x: coarse [N][D][H][W][Ci]; w3: zero-embedded weights [8 * Co][27][Ci]; y0: fine [N][2D][2H][2W][Co]; stats [bricks * 8][Co][2]
+static void upc_axes(BrickParams& p, int D, int H, int W) {
+  p.sd = H * W; p.sh = W; p.sw = 1; p.td = 9; p.th = 3; p.tw = 1;
+  p.bd = 2; p.bh = 1; p.bw = 0;
+  p.fsd = 4 * H * W; p.fsh = 2 * W; p.fsw = 1;
+  if (!brick_natural(D, H, W)) {   // memory (D, H, W) -> brick axes (W, D, H), as in pcrl_brick_conv_launch
+    p.D = W; p.H = D; p.W = H;
+    p.sd = 1; p.sh = H * W; p.sw = W;
+    p.td = 1; p.th = 9; p.tw = 3;
+    p.bd = 0; p.bh = 2; p.bw = 1;
+    p.fsd = 1; p.fsh = 4 * H * W; p.fsw = 2 * W;
+  }
+}
+template <int BN, int MODE> static void launch_upc8(const BrickParams& p, unsigned nblocks, hipStream_t stream) {
+  constexpr int HB = BrickGeom<3>::HALO_BYTES;
+  static std::once_flag attr_once;
+  std::call_once(attr_once, [&] {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(brick_conv_kernel<BN, 3, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, HB + 3 * BN * 64);
+  });
+  hipLaunchKernelGGL((brick_conv_kernel<BN, 3, MODE>), dim3(nblocks), dim3(256), HB + 3 * BN * 64, stream, p);
+}
+bool pcrl_brick8_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return pcrl_brick_conv_eligible(N, D, H, W, Ci, 8 * Co, dtype) && Co % 64 == 0 && (int64_t)N * D * H * W * 8 < ((int64_t)1 << 29);
+}
+int pcrl_brick8_upc_fwd_launch(const void* x, const void* w3, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
+                               hipStream_t stream) {
+  BrickParams p{(const bf16*)x, (const bf16*)w3, nullptr, (bf16*)y0, stats, N, D, H, W, Ci, 8 * Co, 0, 8 * Co / 64, 0, 0, 0, 0, 0, 0, Co, bias_tab, 0};
+  upc_axes(p, D, H, W);
+  const int64_t blocks = pcrl_brick_conv_rows(N, D, H, W) * p.ny;
+  if (blocks >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick (composed up-conv): grid too large");
+  launch_upc8<64, 1>(p, (unsigned)blocks, stream);
+  return pcrl_check_launch("brick_conv (composed up-conv forward)");
+}
+// dy0: fine [N][2D][2H][2W][Co]; wd3: zero-embedded weights [Ci][27][8 * Co]; dx: coarse [N][D][H][W][Ci]
+static int upc8_cshift(int Co) {
+  for (int k = 0; k < 8; ++k)
+    if (Co == (32 << k)) return k;
+  return -1;
+}
+bool pcrl_brick8_upc_dgrad_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+  return upc8_cshift(Co) >= 0 && pcrl_brick_conv_eligible(N, D, H, W, 8 * Co, Ci, dtype) && (int64_t)N * D * H * W * 8 < ((int64_t)1 << 29);
+}
+int pcrl_brick8_upc_dgrad_launch(const void* dy0, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
+  const int64_t bricks = pcrl_brick_conv_rows(N, D, H, W);
+  const int BN = (Ci % 64 == 0 && bricks * (Ci / 64) > 192) ? 64 : 32;
+  BrickParams p{(const bf16*)dy0, (const bf16*)wd3, nullptr, (bf16*)dx, nullptr, N, D, H, W, 8 * Co, Ci, 0, Ci / BN, 0, 0, 0, 0, 0, 0, Co, nullptr, upc8_cshift(Co)};
+  upc_axes(p, D, H, W);
+  const int64_t blocks = bricks * p.ny;
+  if (blocks >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick (composed up-conv data gradient): grid too large");
+  if (BN == 64) launch_upc8<64, 2>(p, (unsigned)blocks, stream);
+  else launch_upc8<32, 2>(p, (unsigned)blocks, stream);
+  return pcrl_check_launch("brick_conv (composed up-conv data gradient)");
 }

@@ -624,15 +624,29 @@ int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, vo
   return launch_upc<GEOM_UPC_FWD>(p, 8, dtype, stream);
 }
 bool pcrl_brick16_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_brick16.hip
-bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+bool pcrl_brick8_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);    // conv_brick.hip
+// PCRL_UPC_BRICK8=0: the coarse grids only the 4 x 8 x 8 brick tiles (8 x 8 x 4 of up_tr256, 8^3 of the local views' up_tr64) stay on the gather kernel (A/B switch)
+static bool upc_brick8_on() {
+  static const bool on = [] { const char* e = getenv("PCRL_UPC_BRICK8"); return !(e && e[0] == '0'); }();
+  return on;
+}
+// 0: gather kernel; 1: wide-brick kernel (conv_brick16.hip); 2: 4 x 8 x 8-brick kernel (conv_brick.hip)
+int pcrl_upc_fwd_impl(int N, int D, int H, int W, int Ci, int Co, int dtype) {
   static const bool gather_only = [] { const char* e = getenv("PCRL_UPC_FWD_GATHER"); return e && e[0] == '1'; }();   // A/B switch
-  return g_conv_impl == 0 && !gather_only && pcrl_brick16_upc_fwd_eligible(N, D, H, W, Ci, Co, dtype);
+  if (g_conv_impl != 0 || gather_only) return 0;
+  if (pcrl_brick16_upc_fwd_eligible(N, D, H, W, Ci, Co, dtype)) return 1;
+  return upc_brick8_on() && pcrl_brick8_upc_fwd_eligible(N, D, H, W, Ci, Co, dtype) ? 2 : 0;
 }
+bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) { return pcrl_upc_fwd_impl(N, D, H, W, Ci, Co, dtype) != 0; }
 bool pcrl_brick16_upc_dgrad_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_brick16.hip
-bool pcrl_upc_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) {
+bool pcrl_brick8_upc_dgrad_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);    // conv_brick.hip
+int pcrl_upc_dgrad_impl(int N, int D, int H, int W, int Ci, int Co, int dtype) {
   static const bool gather_only = [] { const char* e = getenv("PCRL_UPC_DGRAD_GATHER"); return e && e[0] == '1'; }();   // A/B switch
-  return g_conv_impl == 0 && !gather_only && pcrl_brick16_upc_dgrad_eligible(N, D, H, W, Ci, Co, dtype);
+  if (g_conv_impl != 0 || gather_only) return 0;
+  if (pcrl_brick16_upc_dgrad_eligible(N, D, H, W, Ci, Co, dtype)) return 1;
+  return upc_brick8_on() && pcrl_brick8_upc_dgrad_eligible(N, D, H, W, Ci, Co, dtype) ? 2 : 0;
 }
+bool pcrl_upc_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) { return pcrl_upc_dgrad_impl(N, D, H, W, Ci, Co, dtype) != 0; }
 // Split-K plan of the composed data gradient on the gather kernel: K = 64 taps x Co / 32 chunks (512 steps at up_tr256) over row tiles that
 // are few on the coarse grids it serves -- the 8 x 8 x 4 grid of up_tr256 (64 tiles x 4 channel tiles = one block per CU, four waves: 319 us,
 // 430 TFLOP/s) and the 2^3 / 4^3 grids of the local views (12 tiles: 287 us, 90 TFLOP/s).  Splits bring the grid to ~4 blocks per CU.

@@ -30,8 +30,14 @@ int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, vo
 int pcrl_upc_dgrad_launch(const void* dy0, const void* wd, void* dx, void* ws, int64_t ws_bytes, int N, int D, int H, int W, int Ci, int Co, int dtype,
                           hipStream_t stream);
 int64_t pcrl_upc_dgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co);   // split-K workspace of the gather form (0: none)
-bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_igemm.hip: the wide-brick kernel takes this shape
+bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_igemm.hip: a brick kernel takes this shape
+int pcrl_upc_fwd_impl(int N, int D, int H, int W, int Ci, int Co, int dtype);           // 0 gather, 1 wide brick (conv_brick16.hip), 2 4 x 8 x 8 brick (conv_brick.hip)
+int pcrl_upc_dgrad_impl(int N, int D, int H, int W, int Ci, int Co, int dtype);
 int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W);
+int64_t pcrl_brick_conv_rows(int N, int D, int H, int W);
+int pcrl_brick8_upc_fwd_launch(const void* x, const void* w3, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
+                               hipStream_t stream);
+int pcrl_brick8_upc_dgrad_launch(const void* dy0, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
 int pcrl_brick16_upc_fwd_launch(const void* x, const void* w3, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
                                 hipStream_t stream);
 bool pcrl_upc_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype);
@@ -392,15 +398,18 @@ extern "C" int64_t pcrl_upconv_fwd_uses_brick(int N, int D, int H, int W, int Ci
   return pcrl_upc_fwd_uses_brick(N, D, H, W, Ci, Co, dtype) ? 1 : 0;
 }
 extern "C" int64_t pcrl_upconv_stats_rows(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  if (pcrl_upc_fwd_uses_brick(N, D, H, W, Ci, Co, dtype)) return 8 * pcrl_brick16_conv_rows(N, D, H, W);
+  const int impl = pcrl_upc_fwd_impl(N, D, H, W, Ci, Co, dtype);
+  if (impl == 1) return 8 * pcrl_brick16_conv_rows(N, D, H, W);
+  if (impl == 2) return 8 * pcrl_brick_conv_rows(N, D, H, W);
   return 8 * (((int64_t)N * D * H * W + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
 }
 extern "C" int pcrl_upconv_fwd(const void* x, const void* wf, const void* w3f, const float* bias_tab, void* y0, float* stats_partial, int N, int D, int H,
                                int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_upc("upconv_fwd", N, D, H, W, Ci, 32, Co, dtype)) return e;
   PCRL_REQUIRE(x && wf && bias_tab && y0, "upconv_fwd: null pointer");
-  if (pcrl_upc_fwd_uses_brick(N, D, H, W, Ci, Co, dtype)) {
-    PCRL_REQUIRE(w3f, "upconv_fwd: this shape runs on the wide-brick kernel and needs the 3x3x3 form of the composed weights (w3f)");
+  if (const int impl = pcrl_upc_fwd_impl(N, D, H, W, Ci, Co, dtype)) {
+    PCRL_REQUIRE(w3f, "upconv_fwd: this shape runs on a brick kernel and needs the 3x3x3 form of the composed weights (w3f)");
+    if (impl == 2) return pcrl_brick8_upc_fwd_launch(x, w3f, bias_tab, y0, stats_partial, N, D, H, W, Ci, Co, as_stream(stream));
     return pcrl_brick16_upc_fwd_launch(x, w3f, bias_tab, y0, stats_partial, N, D, H, W, Ci, Co, as_stream(stream));
   }
   return pcrl_upc_fwd_launch(x, wf, bias_tab, y0, stats_partial, N, D, H, W, Ci, Co, dtype, as_stream(stream));
@@ -412,8 +421,9 @@ static int upconv_dgrad_impl(const void* dy0, const void* wd, const void* wd3, v
                              int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_upc("upconv_dgrad", N, D, H, W, Ci, 32, Co, dtype)) return e;
   PCRL_REQUIRE(dy0 && wd && dx, "upconv_dgrad: null pointer");
-  if (pcrl_upc_dgrad_uses_brick(N, D, H, W, Ci, Co, dtype)) {
-    PCRL_REQUIRE(wd3, "upconv_dgrad: this shape runs on the wide-brick kernel and needs the 3x3x3 form of the composed weights (wd3)");
+  if (const int impl = pcrl_upc_dgrad_impl(N, D, H, W, Ci, Co, dtype)) {
+    PCRL_REQUIRE(wd3, "upconv_dgrad: this shape runs on a brick kernel and needs the 3x3x3 form of the composed weights (wd3)");
+    if (impl == 2) return pcrl_brick8_upc_dgrad_launch(dy0, wd3, dx, N, D, H, W, Ci, Co, as_stream(stream));
     return pcrl_brick16_upc_dgrad_launch(dy0, wd3, dx, N, D, H, W, Ci, Co, as_stream(stream));
   }
   return pcrl_upc_dgrad_launch(dy0, wd, dx, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, as_stream(stream));

@@ -259,6 +259,13 @@ class PCRLv23d(nn.Module):
             for m in mods:
                 m._pass_idx = pass_idx
 
+        stops = [0]
+
+        def stop():          # config.VIEW_SKEW: the second view's stream starts when the first view has enqueued this many stages
+            stops[0] += 1
+            if pass_idx == 0 and stops[0] == config.VIEW_SKEW:
+                ops.skew_mark(x.device)
+
         h, pooled = x, None
         for i, ((name, _, _), attr) in enumerate(zip(_ENCODER, _SKIPS)):
             stage = getattr(self, name)
@@ -268,12 +275,14 @@ class PCRLv23d(nn.Module):
             if config.FOLD_POOL_GRAD and i + 1 < len(_ENCODER) and not last._gn_groups:
                 # stage output and `self.maxpool` of it (:115-117) as one node: the pool's backward folds into the BatchNorm backward
                 a = stage.ops[0](h)
+                stop()
                 yield
                 mine()
                 h, pooled = last.forward_pooled(a)
             else:
                 h, pooled = stage(h), None
             setattr(self, attr, h)          # the reference keeps these alive as attributes; the skips are never consumed (D6)
+            stop()
             yield
         middle_features, middle_masks = [], []
         for (name, _, _), factor in zip(_DECODER, _UPSAMPLE):
@@ -282,6 +291,7 @@ class PCRLv23d(nn.Module):
             middle_features.append([pro, pre])
             if not local and not features_only:
                 middle_masks.append(mask if factor == 1 else Fn.TrilinearFn.apply(mask, factor))
+            stop()
             yield
         if features_only:
             return None, middle_features, middle_masks

@@ -346,6 +346,17 @@ _views_active = False        # set while a step uses the view stream: the cross-
 _rmw_events: dict = {}
 
 
+_skew_event = None
+
+
+def skew_mark(device):
+    """config.VIEW_SKEW: the first view's forward has enqueued the stage the second view waits for."""
+    global _skew_event
+    if _views_active and _skew_event is None:
+        _skew_event = torch.cuda.Event()
+        _skew_event.record(torch.cuda.current_stream(device))
+
+
 def view_streams_on(device, path2d=False) -> bool:
     if path2d:      # the 2D path has no accumulators shared between passes: no need for the side stream
         return config.VIEW_STREAMS_2D and device.type == "cuda"
@@ -386,6 +397,8 @@ class view_pass:
             vs = _view_streams[key]
             for t in self.operands:
                 t.record_stream(vs)
+            if _skew_event is not None and self.name == "view2":
+                vs.wait_event(_skew_event)
             self._cm = torch.cuda.stream(vs)
             self._cm.__enter__()
 
@@ -503,9 +516,10 @@ _pass_index = 0
 
 
 def begin_step():
-    global _pass_index, _views_active
+    global _pass_index, _views_active, _skew_event
     _pass_index = 0
     _views_active = False
+    _skew_event = None
     drop_pending_composed()
 
 

@@ -59,6 +59,11 @@ SHAPES = [  # N, D, H, W (coarse), Ci, Cm, Co
     (1, 4, 16, 8, 64, 64, 64),
     (2, 8, 16, 8, 128, 128, 64),
     (1, 4, 32, 24, 64, 64, 32),
+    # coarse grids only the 4 x 8 x 8 brick tiles (conv_brick.hip's composed modes): the local views' 8^3 grid, up_tr256's 8 x 8 x 4 grid (permuted axes)
+    (2, 8, 8, 8, 128, 128, 64),
+    (1, 8, 8, 4, 64, 64, 64),
+    (3, 4, 8, 8, 32, 64, 128),      # two 64-channel tiles per phase; one brick per sample: every border class on its faces
+    (1, 16, 8, 4, 64, 32, 32),      # Co = 32: forward on the gather kernel, data gradient on the brick (one chunk per parity, 32-channel output tiles)
 ]
 
 
@@ -205,7 +210,10 @@ def test_full_size_composed_operator_adjoint_identities_bf16(geom):
 
 
 @pytest.mark.parametrize("geom", [(2, 4, 8, 16, 64, 64, 64), (3, 8, 16, 32, 128, 128, 64), (2, 4, 16, 8, 64, 64, 64), (1, 8, 32, 8, 128, 64, 128),
-                                  (2, 4, 32, 24, 64, 64, 32), (1, 4, 8, 16, 64, 64, 256)])
+                                  (2, 4, 32, 24, 64, 64, 32), (1, 4, 8, 16, 64, 64, 256),
+                                  # the 4 x 8 x 8-brick instantiations: natural and permuted axes, 64- and 32-channel output tiles of the data gradient
+                                  (2, 8, 8, 8, 128, 128, 64), (3, 8, 8, 4, 64, 64, 64), (2, 16, 8, 4, 64, 64, 128), (25, 8, 8, 8, 256, 32, 32),
+                                  (2, 8, 8, 4, 512, 64, 256)])
 def test_brick_instantiations_equal_the_gather_kernels_to_an_ulp(geom):
     """bf16: the composed operator's wide-brick instantiations (forward <64, 1>, data gradient <64, 2>, along (D, H, W) and (D, W, H)) and the
     brick weight-gradient kernel against the GATHER kernels on the same operands (`pcrl_debug_set_conv_impl(1)` / `_wgrad_impl(1)`).  Both
