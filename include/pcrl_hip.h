@@ -427,7 +427,8 @@ int pcrl_aug_swap(float* x, const int* origins, int B, int D, int H, int W, int 
  * of the kernels behind one entry point runs, so that tests can check every kernel against the same reference and probes can
  * time them against each other inside one process (tools/conv_probe.py).
  *   conv  impl: 0 auto (LDS-halo brick kernel where eligible, co-located launch), 1 gather kernel, 2 gather kernel without
- *               split-K, 3 brick kernel on its plain 2-D grid, 4 the 4x8x8-brick kernel also where the 4x8x16-brick one is eligible
+ *               split-K, 3 brick kernel on its plain 2-D grid, 4 the 4x8x8-brick kernel also where the 4x8x16-brick one is eligible,
+ *               5 / 6 auto with the wide-brick kernel on 4 x 8 x 16 bricks only / on 8 x 8 x 16 bricks wherever they tile
  *   wgrad impl: 0 auto (brick kernel where eligible, XCD co-located launch), 1 gather kernel, 2 brick kernel on its plain 2-D grid,
  *               4 / 5 co-located launch with the old walk order / plain grid with the new walk order (experiments),
  *               6 co-located launch with 64 x 64 tiles only (0 also uses 128 x 64, 64 x 128 and 64 x 32 tiles)

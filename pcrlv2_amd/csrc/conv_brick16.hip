@@ -43,16 +43,26 @@
 #define B16_EARLY 0   // 1: request the dead planes of the halo early (measured equal to 0, the whole halo at the end of the chunk: the co-resident block covers the latency)
 #endif
 #ifndef B16_ABL
-#define B16_ABL 0   // timing ablations (wrong results): bit 0 no weight staging after the first stage, bit 1 no halo requests after the first chunk
+#define B16_ABL 0   // timing ablations (wrong results): bit 0 no weight staging after the first stage, bit 1 no halo requests after the first chunk,
+                    // bit 2 a BatchNorm + ReLU pass over the landed halo in LDS (what applying the PREVIOUS layer's normalisation inside this kernel
+                    // would cost: VERDICT r2 item 3; measured +9..17 % on the layers it would serve, see DESIGN 4.3 -- not built)
 #endif
 
 namespace {
 
 constexpr int TD = 4, TH = 8, TW = 16;
-constexpr int HD = TD + 2, HH = TH + 2, HP = TW + 2;   // halo extents; w pitch = natural 18
-constexpr int ROWS = HD * HH * HP;                     // 1080 rows of 64 B
-constexpr int NDMA = (ROWS + 15) / 16;                 // 68 wave-instructions of 16 rows (1 KiB)
-constexpr int HALO_BYTES = NDMA * 1024;                // 69632
+constexpr int HH = TH + 2, HP = TW + 2;                // halo extents in h, w; w pitch = natural 18
+// NW = waves per block = d-planes per brick: 4 (4 x 8 x 16 bricks, two blocks per CU) or 8 (8 x 8 x 16 bricks, one block of eight waves per CU:
+// the 27 weight tiles of a chunk serve 1024 voxels and the halo is 10 / 8 instead of 6 / 4 planes per output plane -- 33 instead of 52 staged
+// bytes per MFMA; see pcrl_brick16_conv_launch for where it is used)
+template <int NW> struct B16Geom {
+  static constexpr int HD = NW + 2;
+  static constexpr int ROWS = HD * HH * HP;            // 1080 / 1800 rows of 64 B
+  static constexpr int NDMA = (ROWS + 15) / 16;        // 68 / 113 wave-instructions of 16 rows (1 KiB)
+  static constexpr int HALO_BYTES = NDMA * 1024;       // 69632 / 115712
+  static constexpr int PPW = (NDMA + NW - 1) / NW;     // pieces per wave: 17 / 15
+};
+constexpr int HALO_BYTES = B16Geom<4>::HALO_BYTES;
 constexpr int NS = 9;                                  // stages per chunk: (kd, kh); a stage = three kw taps
 
 __device__ uint4 g_zero_page[4];                       // source of halo rows outside the volume (zero-initialised device memory)
@@ -106,8 +116,10 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
 // volume) -- for volumes whose H, not W, is a multiple of 16 (the 16 x 16 x 8 level).  A convolution commutes with a permutation of the axes
 // applied to volume, taps and phases alike: only the voxel index (VOX / FVOX), the tap number of a weight row (WTAP), the phase / parity bit of
 // an axis (BITH / BITW) and the border class (CLS) know the difference; rows still go through LDS one 64-byte slice per voxel.
-template <int BN, int MODE = 0, int PERM = 0>
-__global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Params p) {
+template <int BN, int MODE = 0, int PERM = 0, int NW = 4>
+__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(const Brick16Params p) {
+  using G = B16Geom<NW>;
+  constexpr int ROWS = G::ROWS, NDMA = G::NDMA, HALO_BYTES = G::HALO_BYTES;
   constexpr int FN = BN / 16;
   constexpr bool UPCF = MODE == 1, UPCD = MODE == 2;
   constexpr int NSK = MODE ? 4 : NS;   // stages per chunk
@@ -120,7 +132,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   const int K = p.K, nchunk = K / 32;
 
   // ---- brick origin (XCD-contiguous brick ranges; the channel tiles of a brick adjacent on one XCD) ----
-  const int bw = p.W / TW, bh = p.H / TH, bd = p.D / TD;
+  const int bw = p.W / TW, bh = p.H / TH, bd = p.D / NW;
   int b = blockIdx.x, ytile = blockIdx.y;
   if (p.ny > 0) {
     const int nbr = gridDim.x / p.ny;
@@ -149,15 +161,14 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
 #define SID(c_, s_) (MODE == 0 ? (s_) : MODE == 1 ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) \
                                                  : ((1 - BITD(PARC(c_)) + ((s_) >> 1)) * 3 + 1 - BITH(PARC(c_)) + ((s_)&1)))
 #define KWB(c_) (MODE == 0 ? 0 : MODE == 1 ? BITW(uph) : 1 - BITW(PARC(c_)))   /* first of the kw taps in use (composed modes: two, the third tap's weights are zero) */
-  const int brick_id = b;
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
-  const int d0 = (b % bd) * TD; b /= bd;
+  const int d0 = (b % bd) * NW; b /= bd;
   const int n = b;
 
   // ---- halo DMA: wave `wid` issues pieces wid, wid + 4, ...; a piece = 16 rows, lane -> (row = piece * 16 + lane / 4, slot lane & 3).
   //      The source voxel of a row is fixed for the block: element offsets are computed once (17 registers), -1 = outside. ----
-  constexpr int PPW = NDMA / 4;   // 17 pieces per wave
+  constexpr int PPW = G::PPW;
   const char* xb = reinterpret_cast<const char*>(p.x);
   const char* zp = reinterpret_cast<const char*>(g_zero_page);
   // The source address of a piece is recomputed per request (a few dozen VALU operations per piece and chunk, nothing next to a chunk's
@@ -168,9 +179,9 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     int lo = lane;                                                                                         \
     asm volatile("" : "+v"(lo));                                                                           \
     _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                      \
-      if (4 * i + 3 < (P0_) || 4 * i >= (P1_)) continue;         /* compile time */                        \
-      if (wid + 4 * i < (P0_) || wid + 4 * i >= (P1_)) continue; /* wave-uniform */                        \
-      const int row = (wid + 4 * i) * 16 + (lo >> 2);                                                      \
+      if (NW * i + NW - 1 < (P0_) || NW * i >= (P1_)) continue;    /* compile time */                        \
+      if (wid + NW * i < (P0_) || wid + NW * i >= (P1_)) continue; /* wave-uniform */                      \
+      const int row = (wid + NW * i) * 16 + (lo >> 2);                                                     \
       const int hd = row / (HH * HP), rem = row % (HH * HP), hh = rem / HP, hw = rem % HP;                 \
       const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                         \
       const bool ok = row < ROWS && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W; \
@@ -184,7 +195,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
         el = VOX(n, d, h, w) * K + (c_)*32 + ls * 8;                                                       \
       }                                                                                                    \
       const char* src = ok ? xb + (el << 1) : zp;                                                          \
-      lds_dma16(src, lds_base + (wid + 4 * i) * 1024);                                                     \
+      lds_dma16(src, lds_base + (wid + NW * i) * 1024);                                                    \
     }                                                                                                      \
   } while (0)
   // Rows of the halo die plane by plane: stage (kd, kh) reads planes kd .. kd + 3, so plane 0 is dead after the three kd = 0 stages and
@@ -194,7 +205,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   // ---- weight staging through registers: 3 pieces per thread (taps kw = 0,1,2 of the stage), row co = tid >> 2, slot tid & 3 ----
-  const bool wthread = BN == 64 || (tid >> 2) < BN;
+  const bool wthread = (tid >> 2) < BN;
   const bf16* wrow = p.w + ((int64_t)(n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8;
   const int wdst = woff(tid >> 2, tid & 3);
   u32x4 rw[3];
@@ -258,6 +269,34 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
   } while (0)
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
+  // B16_ABL bit 2 (timing only): a = max(y * scale[ci] + shift[ci], 0) over the 4 352 16-byte pieces of the landed halo, 17 per thread: the
+  // thread owns one LOGICAL 8-channel slot (one coefficient set) of rows tid / 4 + 64 i; rows outside the volume stay 0.
+#define HALO_XFORM(c_)                                                                                     \
+  do {                                                                                                     \
+    float sc[8], sh[8];                                                                                    \
+    const float* cf = reinterpret_cast<const float*>(p.w) + (((c_)*32 + (tid & 3) * 8) & 1016);            \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                        \
+      sc[e] = cf[e];                                                                                       \
+      sh[e] = cf[e + 8];                                                                                   \
+    }                                                                                                      \
+    _Pragma("unroll 1") for (int i = 0; i < NDMA / 4; ++i) {                                               \
+      const int row = (tid >> 2) + 64 * i;                                                                 \
+      const int hd = row / (HH * HP), rem = row % (HH * HP), hh = rem / HP, hw = rem % HP;                 \
+      const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                         \
+      const bool ok = row < ROWS && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W; \
+      char* at = halo + row * 64 + (((tid & 3) ^ key_w(hw)) << 4);   /* the thread's LOGICAL slot is fixed: one coefficient set */ \
+      u32x4 v = *reinterpret_cast<const u32x4*>(at);                                                       \
+      u32x4 o;                                                                                             \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+        const float lo = __uint_as_float(v[q] << 16), hi = __uint_as_float(v[q] & 0xffff0000u);            \
+        const float a0 = fmaxf(lo * sc[2 * q] + sh[2 * q], 0.f), a1 = fmaxf(hi * sc[2 * q + 1] + sh[2 * q + 1], 0.f); \
+        bf16 b0 = (bf16)a0, b1 = (bf16)a1;                                                                 \
+        o[q] = (uint32_t) * reinterpret_cast<uint16_t*>(&b0) | ((uint32_t) * reinterpret_cast<uint16_t*>(&b1) << 16); \
+      }                                                                                                    \
+      *reinterpret_cast<u32x4*>(at) = keep_if(ok, o);                                                      \
+    }                                                                                                      \
+  } while (0)
+
   // One stage = six half-taps (kw = 0,1,2 x voxel halves 0,1), 16 MFMAs each.  A sets alternate per half-tap (fa[0] = half 0,
   // fa[1] = half 1); B sets alternate per tap: P = the set that holds kw = 0 on entry (a stage has three taps, so P flips per stage).
   // The two barriers of a stage sit inside the LAST half-tap, whose operands are in registers: the next stage's weights are stored,
@@ -312,6 +351,10 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     SB();                                                                                                  \
     if (halo_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
     __syncthreads();                                                                                       \
+    if ((B16_ABL & 4) && halo_next) {                                                                      \
+      HALO_XFORM(c + 1);                                                                                   \
+      __syncthreads();                                                                                     \
+    }                                                                                                      \
     LOADA(0, akw[0] + ntap64, 0);                                                                          \
     LOADB((P_) ^ 1, wbuf);                                                                                 \
     MFMA_HALF(1, P_, 1, 2, 4);                                                                 \
@@ -400,6 +443,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
 #undef PIPE_READS
 #undef PIPE_WRITES
 #undef DMA_HALO
+#undef HALO_XFORM
 #undef LOAD_W
 #undef STORE_W
 
@@ -437,7 +481,8 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
     }
   }
   if (p.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [4 waves][64 ch][2]; the loop ended with a barrier
+    // one statistics row per 4-plane half of the brick: row numbering and summation order are those of the 4 x 8 x 16 brick for either NW
+    float* red = reinterpret_cast<float*>(smem);  // [NW waves][64 ch][2]; the loop ended with a barrier
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       float a = s1[j], c2 = s2[j];
@@ -451,14 +496,16 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
       }
     }
     __syncthreads();
-    if (tid < BN) {
+    const int half = tid >> 6, ch = tid & 63;
+    if (half < NW / 4 && ch < BN) {
       float a = 0.f, c2 = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        a += red[(q * 64 + tid) * 2 + 0];
-        c2 += red[(q * 64 + tid) * 2 + 1];
+        a += red[((half * 4 + q) * 64 + ch) * 2 + 0];
+        c2 += red[((half * 4 + q) * 64 + ch) * 2 + 1];
       }
-      float* o = p.stats + ((int64_t)brick_id * p.Nc + n0 + tid) * 2;
+      const int64_t brick_id = (((int64_t)n * (p.D / 4) + (d0 >> 2) + half) * bh + h0 / TH) * bw + w0 / TW;
+      float* o = p.stats + (brick_id * p.Nc + n0 + ch) * 2;
       o[0] = a;
       o[1] = c2;
     }
@@ -472,6 +519,7 @@ __global__ void __launch_bounds__(256, 2) brick16_conv_kernel(const Brick16Param
 #undef FVOX
 
 std::atomic<int> g_brick16_on{1};
+std::atomic<int> g_brick16_planes{-1};   // -1: PCRL_B16_NW8 / the default rule; 0: 4-plane bricks only; 2: 8-plane bricks wherever they tile
 // 0: no brick tiling; 1: (4, 8, 16) bricks along (D, H, W); 2: along (D, W, H) (PERM instantiations)
 int brick16_perm(int D, int H, int W) {
   if (D % TD == 0 && H % TH == 0 && W % TW == 0) return 1;
@@ -484,25 +532,26 @@ int brick16_perm(int D, int H, int W) {
 
 // ---- internal interface used by conv_igemm.hip's dispatcher -------------------------------------------------------
 void pcrl_brick16_set(int on) { g_brick16_on = on; }
+void pcrl_brick16_set_planes(int mode) { g_brick16_planes = mode; }
 bool pcrl_brick16_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
   return g_brick16_on && dtype == PCRL_BF16 && brick16_perm(D, H, W) != 0 && Ci % 32 == 0 && Co % 32 == 0 && (int64_t)N * D * H * W < ((int64_t)1 << 29);
 }
 int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W) { return (int64_t)N * D * H * W / (TD * TH * TW); }
 
 // p.D / p.H / p.W arrive as the volume's extents; perm == 2: handed to the PERM instantiation as the extents along the brick axes (D, W, H)
-template <int BN, int MODE>
+template <int BN, int MODE, int NW = 4>
 static int launch16(Brick16Params p, dim3 grid, hipStream_t stream, const char* what) {
-  constexpr size_t lds = HALO_BYTES + 3 * BN * 64;
+  constexpr size_t lds = B16Geom<NW>::HALO_BYTES + 3 * BN * 64;
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 0, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 1, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   if (brick16_perm(p.D, p.H, p.W) == 2) {
     std::swap(p.H, p.W);
-    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 1>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 1, NW>), grid, dim3(NW * 64), lds, stream, p);
   } else {
-    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 0>), grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 0, NW>), grid, dim3(NW * 64), lds, stream, p);
   }
   return pcrl_check_launch(what);
 }
@@ -510,14 +559,23 @@ static int launch16(Brick16Params p, dim3 grid, hipStream_t stream, const char* 
 int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                              int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
   Brick16Params p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, N, D, H, W, Ci, Co, 0, 0, nullptr, 0};
-  const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
   const int BN = Co % 64 == 0 ? 64 : 32, ny = Co / BN;
+  // 8 x 8 x 16 bricks (one eight-wave block per CU) where there are two or more 64-channel tiles per brick, D % 8 == 0 and the grid still gives
+  // every CU a block.  Measured per layer (tools/conv_probe.py, same box): 512->256 at 16x16x8 1445 -> 1544 TFLOP/s, 256->256 1433 -> 1495,
+  // 256->128 at 32x32x16 1320 -> 1383, 128->128 1365 -> 1403; the 64-output-channel layers (one tile per brick) do not gain (128->64 at
+  // 64x64x32: 1330 -> 1300) and small grids lose (128->128 at 16x16x8, 64 blocks: 1105 -> 805).  PCRL_B16_NW8=0: off; =2: every eligible shape.
+  static const int nw8_env = [] { const char* e = getenv("PCRL_B16_NW8"); return e ? atoi(e) : 1; }();
+  const int nw8_mode = g_brick16_planes >= 0 ? (int)g_brick16_planes : nw8_env;   // test hook (pcrl_debug_set_conv_impl 5 / 6) over the environment
+  int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
+  const bool nw8 = nw8_mode > 0 && BN == 64 && D % 8 == 0 && (nw8_mode == 2 || (ny >= 2 && (bricks / 2) * ny >= 256));
+  if (nw8) bricks /= 2;
   if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16_conv: grid too large");
   dim3 grid((unsigned)bricks, ny);
   if (ny > 1) {
     p.ny = ny;
     grid = dim3((unsigned)(bricks * ny));
   }
+  if (nw8) return launch16<64, 0, 8>(p, grid, stream, "brick16_conv (8 planes)");
   return BN == 64 ? launch16<64, 0>(p, grid, stream, "brick16_conv") : launch16<32, 0>(p, grid, stream, "brick16_conv");
 }
 

@@ -506,6 +506,7 @@ int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W);
 int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                              int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
 void pcrl_brick16_set(int on);
+void pcrl_brick16_set_planes(int mode);
 
 bool pcrl_convt_up2_eligible(int Ci, int Co, int dtype);   // conv_up2.hip
 int pcrl_convt_up2_launch(const void* x, const void* wp, const float* bias, void* y, int N, int D, int H, int W, int Ci, int Co,
@@ -513,11 +514,13 @@ int pcrl_convt_up2_launch(const void* x, const void* wp, const float* bias, void
 static std::atomic<int> g_conv_impl{0};  // 0 = auto (brick kernel where eligible), 1 = always the gather kernel
 void pcrl_brick_conv_set_ymap(int on);
 // 0 = auto (brick kernel where eligible), 1 = always the gather kernel, 2 = gather kernel without split-K,
-// 3 = brick kernel on its 2-D grid (channel tiles of a brick not co-located), 4 = 4x8x8-brick kernel also where the 4x8x16 one is eligible
+// 3 = brick kernel on its 2-D grid (channel tiles of a brick not co-located), 4 = 4x8x8-brick kernel also where the 4x8x16 one is eligible,
+// 5 / 6 = auto with the wide-brick kernel on 4-plane bricks only / on 8-plane bricks wherever they tile (0: its own rule, conv_brick16.hip)
 extern "C" void pcrl_debug_set_conv_impl(int impl) {
-  g_conv_impl = (impl == 3 || impl == 4) ? 0 : impl;
+  g_conv_impl = (impl == 3 || impl == 4 || impl == 5 || impl == 6) ? 0 : impl;
   pcrl_brick_conv_set_ymap(impl != 3);
-  pcrl_brick16_set(impl == 0);
+  pcrl_brick16_set(impl == 0 || impl == 5 || impl == 6);
+  pcrl_brick16_set_planes(impl == 5 ? 0 : impl == 6 ? 2 : -1);
 }
 int pcrl_debug_conv_impl() { return g_conv_impl; }
 

@@ -131,6 +131,25 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
         check(y4, ref, dt, "conv3 fwd (4x8x8 bricks)")
         check(dx4, xr.grad, dt, "conv3 dgrad (4x8x8 bricks)")
         check(back(part4).view(rows4, Co, 2).sum(0)[:, 1], (ref * ref).sum(dim=(0, 2, 3, 4)), dt, "conv3 stats (4x8x8 bricks)", out_rounded=False, f32_tol=1e-4)
+    if dt == torch.bfloat16 and D % 8 == 0 and Co % 64 == 0 and (H % 8 == 0 and W % 16 == 0 or H % 16 == 0 and W % 8 == 0):
+        # wide-brick kernel on 8 x 8 x 16 bricks (one eight-wave block; impl 6) vs 4 x 8 x 16 bricks (impl 5): same accumulation order per voxel and
+        # the same statistics rows (one per 4-plane half) -> bit-identical output, data gradient and partial statistics
+        outs = []
+        for impl in (5, 6):
+            L.debug_set_conv_impl(impl)
+            rows5 = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Ci, Co, dtype_code(dt))
+            part5 = torch.zeros(rows5 * Co * 2, dtype=torch.float32, device=DEV)
+            y5 = ops.new_act(N, D, H, W, Co, dt, DEV)
+            L.call("pcrl_conv3d_k3_fwd", xa, wf, b.float().to(DEV), y5, part5, N, D, H, W, Ci, Co, dtype_code(dt), s)
+            dx5 = ops.new_act(N, D, H, W, Ci, dt, DEV)
+            if Ci % 64 == 0:
+                L.call("pcrl_conv3d_k3_fwd", dya, wd, None, dx5, None, N, D, H, W, Co, Ci, dtype_code(dt), s)
+            else:
+                dx5.zero_()
+            outs.append((y5, part5, dx5))
+        L.debug_set_conv_impl(0)
+        check(outs[1][0], ref, dt, "conv3 fwd (8x8x16 bricks)")
+        assert all(torch.equal(a, b_) for a, b_ in zip(outs[0], outs[1])), "8-plane bricks differ from 4-plane bricks"
     if dt == torch.bfloat16 and Co > 64:   # the brick kernel on its 2-D grid (impl 3): bit-identical to the co-located launch
         y3 = ops.new_act(N, D, H, W, Co, dt, DEV)
         part3 = torch.zeros(rows * Co * 2, dtype=torch.float32, device=DEV)
