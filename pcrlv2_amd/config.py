@@ -128,3 +128,10 @@ VIEW_BRANCH_INLINE = os.environ.get("PCRL_VIEW_BRANCH_INLINE", "0") == "1"
 # both views start together and run their identical layer sequences in lockstep, convolution next to convolution and BatchNorm next to
 # BatchNorm).  One event wait per step, nothing else changes; results bit-identical.
 VIEW_SKEW = int(os.environ.get("PCRL_VIEW_SKEW", "0"))
+
+# Weight packing off the forward's critical chain: the packed / composed weight forms a step needs (10 pack launches, 3 x the composed
+# operator's prep + GEMM + pack + bias: ~25 small kernels, 0.5 ms back to back) are rebuilt on the SIDE stream at the start of the step, in
+# first-use order, while the main stream already runs the first layers; every reader waits for its own cache's event (ops._CacheGuard).
+# Without it each pack launch sits in front of its convolution on the first view's chain and the second view waits for it too.  The first
+# step of a model records which caches it builds (ops.prepack).  PCRL_PREPACK=0: off (A/B switch; results are bit-identical).
+PREPACK = os.environ.get("PCRL_PREPACK", "1") != "0"

@@ -579,6 +579,13 @@ int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, v
   return BN == 64 ? launch16<64, 0>(p, grid, stream, "brick16_conv") : launch16<32, 0>(p, grid, stream, "brick16_conv");
 }
 
+// composed modes on 8 x 8 x 16 bricks (PCRL_B16_UPC_NW8=1; the test hook of the plain mode applies): D % 8 == 0 and a block for every CU
+static bool upc_planes8(int D, int64_t bricks, int ny) {
+  static const int env = [] { const char* e = getenv("PCRL_B16_UPC_NW8"); return e ? atoi(e) : 0; }();
+  const int mode = g_brick16_planes >= 0 ? (int)g_brick16_planes : env;
+  return mode > 0 && D % 8 == 0 && (mode == 2 || (bricks / 2) * ny >= 256);
+}
+
 // ---- forward of the composed ConvTranspose3d -> Conv3d operator on the wide-brick kernel (see Brick16Params::upc) ----
 // x: coarse [N][D][H][W][Ci]; w3: zero-embedded weights [8 * Co][27][Ci]; y0: fine [N][2D][2H][2W][Co]; stats [bricks * 8][Co][2]
 bool pcrl_brick16_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
@@ -591,6 +598,7 @@ int pcrl_brick16_upc_fwd_launch(const void* x, const void* w3, const float* bias
   const int ny = 8 * Co / 64;
   if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16 (composed up-conv): grid too large");
   p.ny = ny;
+  if (upc_planes8(D, bricks, ny)) return launch16<64, 1, 8>(p, dim3((unsigned)(bricks / 2 * ny)), stream, "brick16_conv (composed up-conv forward, 8 planes)");
   return launch16<64, 1>(p, dim3((unsigned)(bricks * ny)), stream, "brick16_conv (composed up-conv forward)");
 }
 
@@ -610,5 +618,6 @@ int pcrl_brick16_upc_dgrad_launch(const void* dy0, const void* wd3, void* dx, in
   const int ny = Ci / 64;
   if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16 (composed up-conv data gradient): grid too large");
   p.ny = ny;
+  if (upc_planes8(D, bricks, ny)) return launch16<64, 2, 8>(p, dim3((unsigned)(bricks / 2 * ny)), stream, "brick16_conv (composed up-conv data gradient, 8 planes)");
   return launch16<64, 2>(p, dim3((unsigned)(bricks * ny)), stream, "brick16_conv (composed up-conv data gradient)");
 }

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import collections
 import os
+import weakref
 
 import torch
 
@@ -516,10 +517,11 @@ _pass_index = 0
 
 
 def begin_step():
-    global _pass_index, _views_active, _skew_event
+    global _pass_index, _views_active, _skew_event, _pack_recording
     _pass_index = 0
     _views_active = False
     _skew_event = None
+    _pack_recording = None
     drop_pending_composed()
 
 
@@ -528,6 +530,37 @@ def next_pass() -> int:
     i = _pass_index
     _pass_index += 1
     return i
+
+
+# ---- config.PREPACK: the caches a step builds, rebuilt on the side stream at the start of the next steps ----
+_pack_plans = weakref.WeakKeyDictionary()     # model -> [(cache, args of its get())] in first-use order
+_pack_recording = None
+
+
+def _record_build(cache, args):
+    if _pack_recording is not None and not any(c is cache for c, _ in _pack_recording):
+        _pack_recording.append((cache, args))
+
+
+def prepack(model, device):
+    """Start of a step's forward (after fork_views): rebuild the weight forms the step will ask for on the side stream, ahead of their first
+    use.  A model's first step records them instead (every cache miss between this call and the next begin_step())."""
+    global _pack_recording
+    _pack_recording = None
+    if not (config.PREPACK and _views_active and device.type == "cuda"):
+        return
+    plan = _pack_plans.get(model)
+    if plan is None:
+        _pack_recording = _pack_plans[model] = []
+        return
+    if not plan:
+        return
+    ss, cur = side_stream(device), torch.cuda.current_stream(device)
+    ss.wait_stream(cur)          # the optimizer step that changed the weights; every reader of the old forms finished before it
+    with torch.cuda.stream(ss):
+        for cache, args in plan:
+            cache.get(*args)
+    _side_pending[(device.type, device.index)] = True
 
 
 class PackedWeights(_CacheGuard):
@@ -553,6 +586,7 @@ class PackedWeights(_CacheGuard):
                 L.call("pcrl_pack_convt_weight", w.detach(), self.fwd, self.dgrad, Ci, Co, dtype_code(dtype), s)
             self.key = key
             self._built(w.device)
+            _record_build(self, (w, dtype))
         else:
             self._reading(w.device)
         return self.fwd, self.dgrad
@@ -904,6 +938,7 @@ class ComposedUpConv(_CacheGuard):
                    workspace(nb, dev), nb, Ci, Cm, Co, dtype_code(dtype), s)
             self.key = key
             self._built(dev)
+            _record_build(self, (w_up, b_up, w0, b0, dtype))
         else:
             self._reading(w_up.device)
         return self.wf, self.wd, self.bias_tab

@@ -129,6 +129,7 @@ def step_losses(model, batch, epoch, criterion, cosine):
     fused = getattr(cosine, "fusable", False) and FUSED_COS_LOSSES and 2 + 4 * len(local_views) <= COS_MAX_TERMS
     view1, view2 = _to_gpu(view1), _to_gpu(view2)
     _ops.fork_views(view1.device)  # config.VIEW_STREAMS: the second view's forward (and backward) on its own stream, next to the first's
+    _ops.prepack(model, view1.device)   # config.PREPACK: this step's packed / composed weight forms on the side stream, ahead of their use
     if fused and _cfg.INTERLEAVE_VIEWS and hasattr(model, "forward_views") and _ops.view_streams_on(view1.device):
         # the three forwards enqueued stage by stage in rotation, each pass on its own stream (config.INTERLEAVE_VIEWS / MFMA_TOKEN)
         loc = _ops.concat_batch([_to_gpu(v) for v in local_views])
