@@ -386,6 +386,14 @@ int pcrl_cosine_terms_bwd(const void* const* x, const void* const* y, void* cons
  * g is multiplied by grad_scale first (1/world_size after an all-reduce sum). */
 int pcrl_sgd_step(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors,
                   int64_t total, float lr, float momentum, float weight_decay, float grad_scale, pcrl_stream_t stream);
+/* The sum of the gradients several forward passes produced for each parameter, written into the flat gradient arena -- autograd's
+ * AccumulateGrad behind `loss.backward()` (train_3d.py:149) for the tensors t0 .. t0 + cnt - 1 of the arena in one launch (per 480 / nsrc
+ * tensors): dst[offsets[t] + e] = ((src[t][0][e] + src[t][1][e]) + ...), e < numels[t].  offsets / numels: device arrays (int64[ntensors + 1]
+ * / int64[ntensors], slots padded to 4 floats); offsets_host: the same offsets on the host; srcs: HOST array [cnt][nsrc] of device pointers
+ * (contiguous float32; 16-byte aligned ones are read with 16-byte loads; NULL = no term; a tensor with no term is left untouched), read
+ * before the call returns. */
+int pcrl_grad_sum(float* dst, const int64_t* offsets, const int64_t* numels, const int64_t* offsets_host, const void* const* srcs, int t0, int cnt, int nsrc,
+                  pcrl_stream_t stream);
 /* torch.cat(local_views, dim=0) (train_3d.py:121) as one launch: dst = the n <= 8 contiguous pieces src[k] (nbytes[k] bytes each, multiples
  * of 16, 16-byte aligned) one after the other.  src / nbytes are HOST arrays, read before the call returns. */
 int pcrl_concat(const void* const* src, const int64_t* nbytes, int n, void* dst, pcrl_stream_t stream);

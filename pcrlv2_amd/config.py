@@ -135,3 +135,7 @@ VIEW_SKEW = int(os.environ.get("PCRL_VIEW_SKEW", "0"))
 # Without it each pack launch sits in front of its convolution on the first view's chain and the second view waits for it too.  The first
 # step of a model records which caches it builds (ops.prepack).  PCRL_PREPACK=0: off (A/B switch; results are bit-identical).
 PREPACK = os.environ.get("PCRL_PREPACK", "1") != "0"
+
+# The passes' parameter gradients summed into the optimizer's arena by ONE launch of our own (pcrl_grad_sum) instead of a multi-tensor copy
+# and two multi-tensor adds (four ATen launches on the serial tail of backward).  PCRL_FUSED_GRAD_SUM=0: off (bit-identical).
+FUSED_GRAD_SUM = os.environ.get("PCRL_FUSED_GRAD_SUM", "1") != "0"

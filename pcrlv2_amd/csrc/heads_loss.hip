@@ -888,6 +888,78 @@ extern "C" int pcrl_concat(const void* const* src, const int64_t* nbytes, int n,
   return pcrl_check_launch("concat");
 }
 
+// Sum of the gradients the passes of a step produced for each parameter, straight into the optimizer's flat gradient arena (what autograd's
+// AccumulateGrad does tensor by tensor behind train_3d.py:149): dst[offsets[t] + e] = ((src[t][0][e] + src[t][1][e]) + ...) for the tensors
+// t0 .. t0 + cnt - 1, sources in the order given, null sources skipped (a tensor whose sources are all null is left alone).  The source
+// pointers travel as kernel arguments (<= GS_MAX per launch), so nothing is staged through device memory and nothing waits for a copy.
+constexpr int GS_MAX = 480;
+struct GradSrc {
+  const float* s[GS_MAX];
+};
+__global__ void __launch_bounds__(256) grad_sum_kernel(float* __restrict__ dst, const int64_t* __restrict__ offsets, const int64_t* __restrict__ numels,
+                                                       const GradSrc src, int t0, int cnt, int nsrc) {
+  const int64_t base = offsets[t0], total = offsets[t0 + cnt] - base;
+  const int64_t ngroups = (total + 3) >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < ngroups; q += (int64_t)gridDim.x * 256) {
+    const int64_t i = base + (q << 2);      // slots are padded to 4 floats: a group never straddles two tensors
+    int lo = t0, hi = t0 + cnt;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int64_t e = i - offsets[lo], n = numels[lo];
+    if (e >= n) continue;
+    const float* const* sp = src.s + (lo - t0) * nsrc;
+    bool vec = e + 4 <= n;
+    for (int k = 0; k < nsrc; ++k) vec = vec && ((reinterpret_cast<uintptr_t>(sp[k]) & 15) == 0);   // e.g. a 1-element slice of a (gamma, beta) pair
+    if (vec) {
+      float4 a{0.f, 0.f, 0.f, 0.f};
+      bool any = false;
+      for (int k = 0; k < nsrc; ++k) {
+        const float* g = sp[k];
+        if (!g) continue;
+        const float4 v = *reinterpret_cast<const float4*>(g + e);
+        if (!any) { a = v; any = true; }
+        else { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+      }
+      if (any) *reinterpret_cast<float4*>(dst + i) = a;
+    } else {
+      for (int64_t r = e; r < n && r < e + 4; ++r) {
+        float a = 0.f;
+        bool any = false;
+        for (int k = 0; k < nsrc; ++k) {
+          const float* g = sp[k];
+          if (!g) continue;
+          if (!any) { a = g[r]; any = true; }
+          else a += g[r];
+        }
+        if (any) dst[i + (r - e)] = a;
+      }
+    }
+  }
+}
+extern "C" int pcrl_grad_sum(float* dst, const int64_t* offsets, const int64_t* numels, const int64_t* offsets_host, const void* const* srcs, int t0, int cnt,
+                             int nsrc, pcrl_stream_t stream) {
+  PCRL_REQUIRE(dst && offsets && numels && offsets_host && srcs && t0 >= 0 && cnt >= 1 && nsrc >= 1 && nsrc <= 8, "grad_sum: bad arguments");
+  PCRL_REQUIRE(al16(dst), "grad_sum: arena not 16-byte aligned");
+  const int per = GS_MAX / nsrc;
+  for (int c0 = 0; c0 < cnt; c0 += per) {
+    const int c = cnt - c0 < per ? cnt - c0 : per;
+    GradSrc gs;
+    bool any = false;
+    for (int k = 0; k < c * nsrc; ++k) {
+      gs.s[k] = static_cast<const float*>(srcs[(size_t)c0 * nsrc + k]);
+      PCRL_REQUIRE((reinterpret_cast<uintptr_t>(gs.s[k]) & 3) == 0, "grad_sum: source %d not 4-byte aligned", c0 * nsrc + k);
+      any = any || gs.s[k];
+    }
+    if (!any) continue;
+    const int64_t elems = offsets_host[t0 + c0 + c] - offsets_host[t0 + c0];
+    hipLaunchKernelGGL(grad_sum_kernel, dim3(grid_for((elems + 3) / 4)), dim3(256), 0, as_stream(stream), dst, offsets, numels, gs, t0 + c0, c, nsrc);
+    if (int e = pcrl_check_launch("grad_sum")) return e;
+  }
+  return 0;
+}
+
 // total = l1 + l2 + beta * l4 + l5 and scaled = beta * l4 in one launch (train_3d.py:136-138): out[0] = total, out[1] = scaled
 __global__ void loss_total_kernel(const float* __restrict__ l1, const float* __restrict__ l2, const float* __restrict__ l4, const float* __restrict__ l5,
                                   float beta, float* __restrict__ out) {

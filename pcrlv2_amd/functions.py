@@ -105,6 +105,39 @@ def take_parked(p):
     return _parked.pop(id(p), (p, []))[1]
 
 
+def _flush_fused(items):
+    """The common case in one launch (pcrl_grad_sum; config.FUSED_GRAD_SUM): every parameter lives in ONE FusedSGD arena, has no gradient yet
+    (no accumulation across backward() calls) and at most 8 contiguous float32 terms.  -> False: the caller's generic
+    path (multi-tensor copies and adds) runs instead.  Same additions in the same order: bit-identical."""
+    if not config.FUSED_GRAD_SUM:
+        return False
+    opt, idx = None, {}
+    nsrc = 1
+    for p, gs in items:
+        slot = getattr(p, "_pcrl_gslot", None)
+        if slot is None or p.grad is not None or (opt is not None and slot[0] is not opt) or len(gs) > 8:
+            return False
+        for g in gs:
+            if not ops.is_shared_zero(g) and (g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != p.numel() or g.data_ptr() % 4
+                                              or g.device != p.device):
+                return False
+        opt = slot[0]
+        idx[slot[1]] = (p, gs)
+        nsrc = max(nsrc, len(gs))
+    import ctypes
+    t0, t1 = min(idx), max(idx) + 1
+    srcs = (ctypes.c_void_p * ((t1 - t0) * nsrc))()
+    for i, (p, gs) in idx.items():
+        # the first term is copied even when it is the shared zero vector (a bias in front of a BatchNorm: its gradient IS zero), later zero terms add nothing
+        for k, g in enumerate(gs):
+            if k == 0 or not ops.is_shared_zero(g):
+                srcs[(i - t0) * nsrc + k] = g.data_ptr()
+        p.grad = p._pcrl_gview
+    ops.lib().call("pcrl_grad_sum", opt.flat_g, opt._offsets, opt._numels, ctypes.addressof(opt._offsets_c), ctypes.addressof(srcs), t0, t1 - t0, nsrc,
+                   ops.stream_handle())
+    return True
+
+
 @torch.no_grad()
 def flush_param_grads(params=None, on_stream=None):
     """Sum the parked gradients of `params` (default: all) into `.grad`, level by level with multi-tensor launches.
@@ -148,6 +181,8 @@ def flush_param_grads(params=None, on_stream=None):
                 g.record_stream(on_stream)      # allocated on a producer stream, read here: keep the allocator from recycling it under us
         ctx = torch.cuda.stream(on_stream)
     with ctx:
+        if _flush_fused(items):
+            return
         targets, level = [], 0
         copy_dst, copy_src = [], []
         for p, gs in items:

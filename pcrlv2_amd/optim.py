@@ -50,8 +50,12 @@ class FusedSGD(torch.optim.SGD):
                 p.data = self.flat_p[o:o + n].view(p.shape)
         self._offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
         self._gviews = [self.flat_g[o:o + n].view(p.shape) for p, o, n in zip(self._plist, offs, sizes)]
-        for p, v in zip(self._plist, self._gviews):
+        self._numels = torch.tensor(sizes, dtype=torch.int64, device=dev)
+        import ctypes
+        self._offsets_c = (ctypes.c_int64 * len(offs))(*offs)       # pcrl_grad_sum reads the offsets on the host as well
+        for i, (p, v) in enumerate(zip(self._plist, self._gviews)):
             p._pcrl_gview = v      # pcrlv2_amd.functions.flush_param_grads sums the step's gradients straight into the arena
+            p._pcrl_gslot = (self, i)
         self._initialised = [False] * len(self._plist)
         self._flag_cache = {}
         self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper

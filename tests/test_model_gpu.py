@@ -355,7 +355,7 @@ def test_round2_fusions_leave_the_step_unchanged_fp32(switch):
     assert worst[1] < (1e-2 if switch == "COMPOSE_UPCONV" else 2e-5), (switch, worst)
 
 
-@pytest.mark.parametrize("switch", ["WGRAD_SIDE_STREAM_3D", "FWD_BRANCH_STREAM", "VIEW_STREAMS", "EARLY_COMPOSED", "INTERLEAVE_VIEWS", "MFMA_TOKEN", "VIEW_WGRAD_INLINE", "PREPACK", "VIEW_SKEW"])
+@pytest.mark.parametrize("switch", ["WGRAD_SIDE_STREAM_3D", "FWD_BRANCH_STREAM", "VIEW_STREAMS", "EARLY_COMPOSED", "INTERLEAVE_VIEWS", "MFMA_TOKEN", "VIEW_WGRAD_INLINE", "PREPACK", "VIEW_SKEW", "FUSED_GRAD_SUM"])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 def test_weight_gradients_on_the_side_stream_are_bit_identical(dt, switch):
     """config.WGRAD_SIDE_STREAM_3D (default on): the weight-gradient kernels run on a second stream next to the data-gradient / BatchNorm

@@ -24,5 +24,21 @@ def gaps(path, skip=3):
     print(path, "step wall %.2f ms, idle total %.2f ms in %d gaps" % ((sel[-1][1] - sel[0][1]) / 1e6, sum(g[0] for g in out) / 1e6, len(out)))
     for g in out[:14]:
         print("   gap %6.1f us at t=%6.2f ms  after %-40s before %s" % (g[0] / 1e3, g[3], g[1][:40], g[2][:40]))
-for p in sys.argv[1:]:
-    gaps(p)
+if not (len(sys.argv) > 2 and sys.argv[1] == "--start"):
+    for p in sys.argv[1:]:
+        gaps(p)
+
+
+def step_start(path, skip, n=40):
+    """The first n kernels after the skip-th SGD launch: start / end relative to the SGD kernel's end (us), queue, name."""
+    rows = load(path)
+    sgd = [i for i, r in enumerate(rows) if r[2].startswith("sgd")]
+    i0 = sgd[skip]
+    t0 = rows[i0][1]
+    print("step start after SGD #%d (t = 0 at its end):" % skip)
+    for r in rows[i0 + 1:i0 + 1 + n]:
+        print("   %8.1f .. %8.1f us  q%-3s %s" % ((r[0] - t0) / 1e3, (r[1] - t0) / 1e3, r[3], r[2][:60]))
+
+
+if len(sys.argv) > 2 and sys.argv[1] == "--start":
+    step_start(sys.argv[3], int(sys.argv[2]))
