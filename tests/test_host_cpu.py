@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
     assert L.call("pcrl_conv3d_k3_fwd_kernel", 32, 16, 16, 8, 128, 128, 1) == 2 and L.call("pcrl_conv3d_k3_fwd_kernel", 32, 8, 8, 4, 256, 256, 1) == 1
     assert L.call("pcrl_conv3d_k3_fwd_kernel", 192, 4, 4, 4, 256, 256, 1) == 0 and L.call("pcrl_conv3d_k3_fwd_kernel", 32, 64, 64, 32, 64, 64, 0) == 0
     assert L.call("pcrl_upconv_dgrad_uses_brick", 32, 32, 32, 16, 128, 64, 1) == 1 and L.call("pcrl_upconv_dgrad_uses_brick", 32, 16, 16, 8, 256, 128, 1) == 1
-    assert L.call("pcrl_upconv_dgrad_uses_brick", 32, 8, 8, 4, 512, 256, 1) == 0 and L.call("pcrl_upconv_fwd_uses_brick", 32, 16, 16, 8, 256, 128, 1) == 1
+    assert L.call("pcrl_upconv_dgrad_uses_brick", 32, 8, 8, 4, 512, 256, 1) == 1 and L.call("pcrl_upconv_dgrad_uses_brick", 32, 8, 8, 4, 512, 256, 0) == 0 and L.call("pcrl_upconv_fwd_uses_brick", 32, 16, 16, 8, 256, 128, 1) == 1
     assert L.call("pcrl_conv3d_k3_fwd_ws_bytes", 32, 64, 64, 32, 64, 64, 1) == 0
 
 
