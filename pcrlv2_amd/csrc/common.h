@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/pcrl_hip.h"
 
@@ -73,7 +74,10 @@ template <bool NT, typename T> __device__ __forceinline__ void st16_sel(T* p, co
   if (NT) st16_nt(p, v);
   else st16(p, v);
 }
-inline bool pcrl_streaming(int64_t bytes) { return bytes >= ((int64_t)192 << 20); }
+inline bool pcrl_streaming(int64_t bytes) {
+  static const int64_t min_mb = [] { const char* e = getenv("PCRL_NT_MIN_MB"); return e ? (int64_t)atoll(e) : (int64_t)192; }();
+  return bytes >= (min_mb << 20);
+}
 
 // ---- wave / block reductions (wave = 64) ------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
