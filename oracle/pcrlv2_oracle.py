@@ -41,19 +41,28 @@ BN_EPS = 1e-5       # nn.BatchNorm3d / BatchNorm1d default, pcrlv2_model_3d.py:1
 BN_MOMENTUM = 0.1   # pcrlv2_model_3d.py:12
 
 
-def state_layout(n_class: int = 1, in_channels: int = 1) -> "OrderedDict[str, tuple]":
+def state_layout(n_class: int = 1, in_channels: int = 1, act: str = "relu", norm: str = "bn") -> "OrderedDict[str, tuple]":
     """Names and shapes of the 169 state_dict entries, in registration order.
 
-    Follows the module construction order of pcrlv2_model_3d.py:6-34 (LUConv: conv1, bn1),
+    Follows the module construction order of pcrlv2_model_3d.py:6-34 (LUConv: conv1, bn1, activation),
     :48-60 (UpTransition: up_conv, ops, bn, predictor_head, deep_supervision_head),
     :75-79 (OutputTransition) and :98-110 (PCRLv23d).
+    Constructor variants (never instantiated by train_3d.py:45, accepted by the constructor): norm='in' -- InstanceNorm3d(affine=True)
+    keeps weight and bias only (:16, no running statistics by default); act='prelu' -- nn.PReLU(out_chan) adds `activation.weight` after
+    bn1 in every LUConv except the sigmoid heads (:22-23).
     """
     lay: "OrderedDict[str, tuple]" = OrderedDict()
 
-    def luconv(p, ci, co):
+    def luconv(p, ci, co, head=False):
         lay[p + ".conv1.weight"] = (co, ci, 3, 3, 3)
         lay[p + ".conv1.bias"] = (co,)
-        bn(p + ".bn1", co)
+        if norm == "in":
+            lay[p + ".bn1.weight"] = (co,)
+            lay[p + ".bn1.bias"] = (co,)
+        else:
+            bn(p + ".bn1", co)
+        if act == "prelu" and not head:
+            lay[p + ".activation.weight"] = (co,)
 
     def bn(p, c):
         lay[p + ".weight"] = (c,)
@@ -75,7 +84,7 @@ def state_layout(n_class: int = 1, in_channels: int = 1) -> "OrderedDict[str, tu
         bn(name + ".predictor_head.1", 2 * c)
         lay[name + ".predictor_head.3.weight"] = (c, 2 * c)
         lay[name + ".predictor_head.3.bias"] = (c,)
-        luconv(name + ".deep_supervision_head", c, 1)
+        luconv(name + ".deep_supervision_head", c, 1, head=True)
     lay["out_tr.final_conv.weight"] = (n_class, 64, 1, 1, 1)
     lay["out_tr.final_conv.bias"] = (n_class,)
     return lay
@@ -105,12 +114,12 @@ def _name_seed(name: str) -> int:
     return s >> 8
 
 
-def fill_state(dtype=torch.float64, n_class: int = 1, in_channels: int = 1) -> "OrderedDict[str, torch.Tensor]":
+def fill_state(dtype=torch.float64, n_class: int = 1, in_channels: int = 1, act: str = "relu", norm: str = "bn") -> "OrderedDict[str, torch.Tensor]":
     """Deterministic stand-in for PyTorch's default init (kaiming-uniform(a=sqrt 5) bounds:
     U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for conv/linear weight and bias; BN weight near 1,
     bias near 0 but not exactly so that their gradients are exercised)."""
     st: "OrderedDict[str, torch.Tensor]" = OrderedDict()
-    for name, shape in state_layout(n_class, in_channels).items():
+    for name, shape in state_layout(n_class, in_channels, act, norm).items():
         n = int(np.prod(shape)) if shape else 1
         u = _hash_uniform(n, _name_seed(name))
         if name.endswith("num_batches_tracked"):
@@ -120,6 +129,8 @@ def fill_state(dtype=torch.float64, n_class: int = 1, in_channels: int = 1) -> "
             v = np.zeros(n)
         elif name.endswith("running_var"):
             v = np.ones(n)
+        elif name.endswith("activation.weight"):
+            v = 0.25 + 0.1 * u          # nn.PReLU initialises its slopes to 0.25
         elif ".bn" in name or "predictor_head.1" in name:
             v = (1.0 + 0.1 * u) if name.endswith("weight") else 0.1 * u
         else:
@@ -128,7 +139,7 @@ def fill_state(dtype=torch.float64, n_class: int = 1, in_channels: int = 1) -> "
                 if "up_conv" in name:  # ConvTranspose3d: fan_in computed from dim 1 * k^3 as well
                     fan_in = shape[1] * 8
             else:
-                wshape = state_layout(n_class, in_channels)[name[:-4] + "weight"]
+                wshape = state_layout(n_class, in_channels, act, norm)[name[:-4] + "weight"]
                 fan_in = int(np.prod(wshape[1:]))
                 if "up_conv" in name:
                     fan_in = wshape[1] * 8
@@ -160,6 +171,7 @@ def fill_batch(b: int, dhw=(32, 32, 16), local=16, dtype=torch.float64, seed: in
 # ----------------------------------------------------------------------------------------
 # Forward pass
 # ----------------------------------------------------------------------------------------
+_CFG = {"act": "relu", "norm": "bn"}   # constructor variant in force (forward(act=, norm=)); the default is what train_3d.py:45 instantiates
 _EVAL = False   # set by forward(training=False): batch norms use the running statistics (nn.Module.eval() semantics)
 
 
@@ -191,12 +203,30 @@ def _bn_train(x, st, p, new_bufs):
 def _luconv(x, st, p, new_bufs, act="relu"):
     """LUConv.forward, pcrlv2_model_3d.py:32-34: act(bn1(conv1(x))); conv 3x3x3 pad 1 with bias (:9)."""
     y = F.conv3d(x, st[p + ".conv1.weight"], st[p + ".conv1.bias"], padding=1)
+    if _CFG["norm"] == "in":
+        # norm='in' (pcrlv2_model_3d.py:15-16): InstanceNorm3d(affine=True), per-(sample, channel) statistics in train and eval mode alike
+        y = F.instance_norm(y, weight=st[p + ".bn1.weight"], bias=st[p + ".bn1.bias"], eps=1e-5)
+        return _activation(y, st, p, act)
     if (p + ".bn1.running_mean") not in st:
         # OPTIONAL non-reference mode of the engine (PCRLv23d(norm='gn', act='silu'), north_star's GroupNorm + SiLU): the state has
         # no running statistics for this layer -> GroupNorm(8) + SiLU.  Checked against torch's own F.group_norm / F.silu only.
         return F.silu(F.group_norm(y, 8, st[p + ".bn1.weight"], st[p + ".bn1.bias"], eps=1e-5))
     y = _bn_train(y, st, p + ".bn1", new_bufs)
-    return torch.relu(y) if act == "relu" else torch.sigmoid(y)
+    return _activation(y, st, p, act)
+
+
+def _activation(y, st, p, act):
+    """LUConv's activation, pcrlv2_model_3d.py:20-30: the sigmoid heads keep their sigmoid; every other LUConv takes the constructor's `act`."""
+    if act == "sigmoid":
+        return torch.sigmoid(y)
+    a = _CFG["act"]
+    if a == "relu":
+        return torch.relu(y)
+    if a == "elu":
+        return F.elu(y)                                   # nn.ELU(): alpha = 1 (:25)
+    if a == "prelu":
+        return F.prelu(y, st[p + ".activation.weight"])   # nn.PReLU(out_chan): one slope per channel (:23)
+    raise ValueError(a)
 
 
 def _up_transition(x, st, name, new_bufs):
@@ -213,16 +243,23 @@ def _up_transition(x, st, name, new_bufs):
     return x, x_pro, x_pre, x_mask
 
 
-def forward(st, x, local: bool = False, new_bufs=None, training: bool = True):
+def forward(st, x, local: bool = False, new_bufs=None, training: bool = True, act: str = "relu", norm: str = "bn"):
     """PCRLv23d.forward, pcrlv2_model_3d.py:112-133.  `st` maps state_dict names to tensors
     (parameters may require grad).  Returns (out, [[pro,pre]x3], [mask x3] or []).
     `new_bufs` (dict) receives the updated BN running statistics, in call order.
     training=False: the module in .eval() mode (what a consumer of the checkpoint runs for validation, README.md:48-55)."""
     global _EVAL
+    if (act, norm) != (_CFG["act"], _CFG["norm"]):
+        keep = dict(_CFG)
+        _CFG.update(act=act, norm=norm)
+        try:
+            return forward(st, x, local, new_bufs, training, act, norm)
+        finally:
+            _CFG.update(keep)
     if not training:
         _EVAL = True
         try:
-            return forward(st, x, local, None, True)
+            return forward(st, x, local, None, True, act, norm)
         finally:
             _EVAL = False
     h = x

@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
 #define SID(c_, s_) (MODE == 0 ? (s_) : MODE == 1 ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) \
                                                  : ((1 - BITD(PARC(c_)) + ((s_) >> 1)) * 3 + 1 - BITH(PARC(c_)) + ((s_)&1)))
 #define KWB(c_) (MODE == 0 ? 0 : MODE == 1 ? BITW(uph) : 1 - BITW(PARC(c_)))   /* first of the kw taps in use (composed modes: two, the third tap's weights are zero) */
+  const int brick_lin = b;   // NW == 4: the statistics row of this brick (kept instead of re-derived in the epilogue: seven fewer live scalars)
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
   const int d0 = (b % bd) * NW; b /= bd;
@@ -205,7 +206,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
   // ---- weight staging through registers: 3 pieces per thread (taps kw = 0,1,2 of the stage), row co = tid >> 2, slot tid & 3 ----
-  const bool wthread = (tid >> 2) < BN;
+  const bool wthread = NW * 16 <= BN || (tid >> 2) < BN;   // compile-time true for four waves x 64 channels: no exec mask around the weight stores
   const bf16* wrow = p.w + ((int64_t)(n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8;
   const int wdst = woff(tid >> 2, tid & 3);
   u32x4 rw[3];
@@ -504,7 +505,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
         a += red[((half * 4 + q) * 64 + ch) * 2 + 0];
         c2 += red[((half * 4 + q) * 64 + ch) * 2 + 1];
       }
-      const int64_t brick_id = (((int64_t)n * (p.D / 4) + (d0 >> 2) + half) * bh + h0 / TH) * bw + w0 / TW;
+      const int64_t brick_id = NW == 4 ? (int64_t)brick_lin : (((int64_t)n * (p.D / 4) + (d0 >> 2) + half) * bh + h0 / TH) * bw + w0 / TW;
       float* o = p.stats + (brick_id * p.Nc + n0 + ch) * 2;
       o[0] = a;
       o[1] = c2;
