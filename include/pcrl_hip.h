@@ -33,7 +33,8 @@ extern "C" {
 typedef void* pcrl_stream_t; /* hipStream_t */
 
 enum { PCRL_F32 = 0, PCRL_BF16 = 1 };
-enum { PCRL_ACT_NONE = 0, PCRL_ACT_RELU = 1, PCRL_ACT_SIGMOID = 2, PCRL_ACT_SILU = 3 /* optional extra, not used by the reference path */ };
+enum { PCRL_ACT_NONE = 0, PCRL_ACT_RELU = 1, PCRL_ACT_SIGMOID = 2, PCRL_ACT_SILU = 3 /* optional extra, not used by the reference path */,
+       PCRL_ACT_ELU = 4 /* LUConv(act='elu'), models/pcrlv2_model_3d.py:24-25: a constructor variant train_3d.py never instantiates */ };
 enum { PCRL_OK = 0, PCRL_EINVAL = -1, PCRL_ELAUNCH = -2, PCRL_EWORKSPACE = -3 };
 
 #define PCRL_CONV_BM 128 /* rows (voxels) per conv tile == rows per BN-statistics partial */
@@ -264,6 +265,18 @@ int pcrl_gn_finalize(const float* partial, int tiles, int N, int64_t S, int C, i
                      float* mean_c, float* rstd_c, float* scale, float* shift, pcrl_stream_t stream);
 int pcrl_gn_bwd_finalize(const float* partial_b, int rows_b, int N, int64_t S, int C, int G, const float* gamma, const float* mean_c,
                          const float* rstd_c, float* k1, float* kB, float* kA, float* dgamma_n, float* dbeta_n, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LUConv constructor variants (models/pcrlv2_model_3d.py:15-16,22-25; accepted by the reference's constructor, never instantiated by
+ * train_3d.py:45): act='elu' is PCRL_ACT_ELU of the fused BatchNorm kernels; norm='in' (InstanceNorm3d, affine) is the GroupNorm
+ * machinery above with G == C; act='prelu' (nn.PReLU(out_chan), aten::prelu / prelu_backward) is a streaming pass behind the
+ * normalisation, which then runs with PCRL_ACT_NONE:
+ *   prelu_fwd:  a[m][c] = z > 0 ? z : w[c] * z                                   (z, a: [M][C] activations; w: float32 [C])
+ *   prelu_bwd:  dz = da * (z > 0 ? 1 : w[c]);  partial[tile][c] = sum_m da * z * [z <= 0] over the tile's rows
+ *               (pcrl_prelu_bwd_partial_rows(M) tiles; dw = column sums of `partial`, e.g. pcrl_colsum). */
+int pcrl_prelu_fwd(const void* z, const float* w, void* a, int64_t M, int C, int dtype, pcrl_stream_t stream);
+int64_t pcrl_prelu_bwd_partial_rows(int64_t M);
+int pcrl_prelu_bwd(const void* da, const void* z, const float* w, void* dz, float* partial, int64_t M, int C, int dtype, pcrl_stream_t stream);
 
 /* =======================================================================================
  * 2D path: the PCRLv2 ResNet-18 U-Net of models/pcrlv2_model.py:68-209 (decoder) and the smp/torchvision ResNet-18

@@ -387,6 +387,77 @@ def make_forward(tag, b, dhw, refmod, ref_train, ref_utils, epoch=3, seed=0):
           f"({os.path.getsize(path) / 1024:.0f} KiB, {len(fx)} arrays)", flush=True)
 
 
+def make_variant(tag, refmod, b=3, dhw=(32, 32, 16), **kw):
+    """Constructor variants the reference accepts but train_3d.py:45 never instantiates (pcrlv2_model_3d.py:15-16,22-25,98): one
+    train-mode forward of the REAL model built with `kw` (act / norm / in_channels / n_class), float64, oneDNN off, and the gradients
+    of O.variant_loss w.r.t. every parameter; the oracle is asserted equal first."""
+    torch.set_num_threads(8)
+    dt = torch.float64
+    okw = dict(n_class=kw.get("n_class", 1), in_channels=kw.get("in_channels", 1), act=kw.get("act", "relu"), norm=kw.get("norm", "bn"))
+    st0 = O.fill_state(dt, **okw)
+    model = refmod.PCRLv23d(**kw).double()
+    assert list(model.state_dict().keys()) == list(st0.keys()), "state_dict order differs from the oracle layout for " + tag
+    model.load_state_dict(st0, strict=True)
+    model.train()
+    x = O.variant_input(b, dhw, okw["in_channels"], dt)
+    with torch.backends.mkldnn.flags(enabled=False):
+        out, feats, masks = model(x)
+        L = O.variant_loss(out, feats, masks)
+        L.backward()
+        ref_grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in model.named_parameters()}
+        ref_bufs = {k: v.detach().clone() for k, v in model.state_dict().items() if O.is_buffer(k)}
+        st = OrderedDict((k, (v.clone().requires_grad_(True) if not O.is_buffer(k) else v.clone())) for k, v in st0.items())
+        nb = {}
+        o_out, o_feats, o_masks = O.forward(st, x, new_bufs=nb, act=okw["act"], norm=okw["norm"])
+        oL = O.variant_loss(o_out, o_feats, o_masks)
+        pn = [k for k in st if not O.is_buffer(k)]
+        og = dict(zip(pn, torch.autograd.grad(oL, [st[k] for k in pn], allow_unused=True)))
+    assert abs(float(oL) - float(L)) < 1e-12, (float(oL), float(L))
+    worst = close(o_out, out, 1e-10, "out")
+    for i in range(3):
+        worst = max(worst, close(o_feats[i][0], feats[i][0], 1e-9, f"pro{i}"), close(o_feats[i][1], feats[i][1], 1e-9, f"pre{i}"),
+                    close(o_masks[i], masks[i], 1e-10, f"mask{i}"))
+    for k, g in ref_grads.items():
+        assert (g is None) == (og[k] is None), f"grad None-ness differs for {k}"
+        if g is not None:
+            assert (g - og[k]).abs().max().item() <= 1e-9 * g.abs().max().item() + 1e-11, f"grad {k}"
+    for k, v in ref_bufs.items():
+        close(nb[k].double(), v.double(), 1e-10, k)
+    fx = OrderedDict()
+    fx["meta/b"], fx["meta/dhw"] = np.int64(b), np.array(dhw)
+    fx["meta/n_class"], fx["meta/in_channels"] = np.int64(okw["n_class"]), np.int64(okw["in_channels"])
+    fx["meta/act"], fx["meta/norm"] = np.array(okw["act"]), np.array(okw["norm"])
+    fx["loss"] = np.float64(float(L))
+    for k, v in summarize(out, 512).items():
+        fx[f"fwd/out/{k}"] = v
+    for i in range(3):
+        fx[f"fwd/pro{i}"], fx[f"fwd/pre{i}"] = feats[i][0].detach().numpy().copy(), feats[i][1].detach().numpy().copy()
+        for k, v in summarize(masks[i], 256).items():
+            fx[f"fwd/mask{i}/{k}"] = v
+    for name, g in ref_grads.items():
+        if g is None:
+            fx[f"grad/{name}/none"] = np.int64(1)
+            continue
+        for k, v in summarize(g, 64).items():
+            fx[f"grad/{name}/{k}"] = v
+    for name, v in ref_bufs.items():
+        fx[f"buf1/{name}"] = v.double().numpy().copy()
+    path = os.path.join(OUT, f"{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{tag}] {kw}: oracle == reference (worst fwd |d| {worst:.2e}, loss {float(L):+.6f}); wrote {path} "
+          f"({os.path.getsize(path) / 1024:.0f} KiB, {len(fx)} arrays)", flush=True)
+
+
+VARIANTS = OrderedDict([
+    ("v_elu", dict(act="elu")),
+    ("v_prelu", dict(act="prelu")),
+    ("v_in", dict(norm="in")),
+    ("v_inch3", dict(in_channels=3)),
+    ("v_ncls2", dict(n_class=2)),
+    ("v_all", dict(act="prelu", norm="in", in_channels=2, n_class=3)),
+])
+
+
 def make_init(tag, refmod, seed=7):
     """Freshly constructed reference model under torch.manual_seed(seed): per-tensor sum, |sum| and leading entries.
     A drop-in model class must consume the RNG in the same order to start from the same point (models/pcrlv2_model_3d.py:85-104)."""
@@ -405,6 +476,10 @@ def main():
     if not os.path.isdir(REF):
         sys.exit("reference not present: fixtures can only be regenerated in the authoring container")
     refmod, ref_train, ref_utils = load_reference()
+    if "--variants" in sys.argv:
+        for tag, kw in VARIANTS.items():
+            make_variant(tag, refmod, **kw)
+        return
     if "--forward-only" in sys.argv:
         # the exact BASELINE batches (C2, C4), forward-only (float64 backward does not fit at these sizes)
         make_forward("f_c2_b32_64x64x32", 32, (64, 64, 32), refmod, ref_train, ref_utils)

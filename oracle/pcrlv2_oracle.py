@@ -281,6 +281,27 @@ def forward(st, x, local: bool = False, new_bufs=None, training: bool = True, ac
     return out, feats, masks
 
 
+def variant_input(b: int, dhw, in_channels: int, dtype=torch.float64, seed: int = 41):
+    """[b, in_channels, D, H, W] closed-form input for the constructor-variant fixtures (tests/golden/v_*.npz)."""
+    D, H, W = dhw
+    x = _hash_uniform(b * in_channels * D * H * W, seed).reshape(b, in_channels, D, H, W) * 1.7
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dtype)
+
+
+def variant_loss(out, feats, masks, seed: int = 97):
+    """A scalar that reaches every output of PCRLv23d.forward with fixed closed-form weights: sum over outputs of mean(output * R).
+    Used by the constructor-variant fixtures (make_golden.make_variant) and their GPU tests to compare gradients of every parameter."""
+    def term(t, k):
+        r = torch.from_numpy(_hash_uniform(t.numel(), seed + k).reshape(tuple(t.shape))).to(device=t.device, dtype=t.dtype)
+        return (t * r).mean()
+    L = term(out, 0)
+    for i, (pro, pre) in enumerate(feats):
+        L = L + term(pro, 1 + 3 * i) + term(pre, 2 + 3 * i)
+    for i, m in enumerate(masks):
+        L = L + term(m, 3 + 3 * i)
+    return L
+
+
 # ----------------------------------------------------------------------------------------
 # Losses and the training step
 # ----------------------------------------------------------------------------------------

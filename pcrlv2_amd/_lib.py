@@ -21,6 +21,7 @@ LIBPATH = os.environ.get("PCRL_LIB") or os.path.join(_PKG, "lib", "libpcrl_hip.s
 
 PCRL_F32, PCRL_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU = 0, 1, 2, 3   # ACT_SILU: optional extra (GroupNorm+SiLU), not on the reference path
+ACT_ELU = 4       # LUConv(act='elu'): a constructor variant of the reference (models/pcrlv2_model_3d.py:24-25)
 CONV_BM = 128
 
 _CTYPES = {

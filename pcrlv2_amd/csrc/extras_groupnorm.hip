@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
                                                           float* __restrict__ mean_c, float* __restrict__ rstd_c, float* __restrict__ scale,
                                                           float* __restrict__ shift) {
   __shared__ double cs[1024][2];
-  __shared__ float gm[64], gr[64];
+  __shared__ float gm[1024], gr[1024];
   const int n = blockIdx.x, cpg = C / G;
   for (int c = threadIdx.x; c < C; c += 256) {
     double a = 0.0, b = 0.0;
@@ -74,17 +74,17 @@ __global__ void __launch_bounds__(256) gn_finalize_kernel(const float* __restric
     cs[c][1] = b;
   }
   __syncthreads();
-  if ((int)threadIdx.x < G) {
+  for (int g = threadIdx.x; g < G; g += 256) {   // G == C: InstanceNorm3d (models/pcrlv2_model_3d.py:15-16)
     double a = 0.0, b = 0.0;
-    for (int c = threadIdx.x * cpg; c < (int)(threadIdx.x + 1) * cpg; ++c) {
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
       a += cs[c][0];
       b += cs[c][1];
     }
     const double cnt = (double)S * cpg, mu = a / cnt;
-    double var = b / cnt - mu * mu;   // biased, as torch.nn.GroupNorm
+    double var = b / cnt - mu * mu;   // biased, as torch.nn.GroupNorm / InstanceNorm3d
     if (var < 0.0) var = 0.0;
-    gm[threadIdx.x] = (float)mu;
-    gr[threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+    gm[g] = (float)mu;
+    gr[g] = (float)(1.0 / sqrt(var + (double)eps));
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ rstd_c, float* __restrict__ k1, float* __restrict__ kB,
                                                               float* __restrict__ kA, float* __restrict__ dgamma_n, float* __restrict__ dbeta_n) {
   __shared__ double cs[1024][2];
-  __shared__ float m1[64], m2[64];
+  __shared__ float m1[1024], m2[1024];
   const int n = blockIdx.x, cpg = C / G;
   for (int c = threadIdx.x; c < C; c += 256) {
     double a = 0.0, b = 0.0;
@@ -117,15 +117,15 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
     dgamma_n[(int64_t)n * C + c] = (float)b;
   }
   __syncthreads();
-  if ((int)threadIdx.x < G) {
+  for (int g = threadIdx.x; g < G; g += 256) {
     double a = 0.0, b = 0.0;
-    for (int c = threadIdx.x * cpg; c < (int)(threadIdx.x + 1) * cpg; ++c) {
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
       a += (double)gamma[c] * cs[c][0];
       b += (double)gamma[c] * cs[c][1];
     }
     const double cnt = (double)S * cpg;
-    m1[threadIdx.x] = (float)(a / cnt);
-    m2[threadIdx.x] = (float)(b / cnt);
+    m1[g] = (float)(a / cnt);
+    m2[g] = (float)(b / cnt);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -138,8 +138,8 @@ __global__ void __launch_bounds__(256) gn_bwd_finalize_kernel(const float* __res
 }
 
 int gn_check(const char* what, int N, int64_t S, int C, int G) {
-  if (N <= 0 || S <= 0 || C <= 0 || C > 1024 || G <= 0 || G > 64 || C % G != 0)
-    return pcrl_fail(PCRL_EINVAL, "%s: bad sizes N=%d S=%lld C=%d G=%d (C <= 1024, G <= 64, G | C)", what, N, (long long)S, C, G);
+  if (N <= 0 || S <= 0 || C <= 0 || C > 1024 || G <= 0 || C % G != 0)
+    return pcrl_fail(PCRL_EINVAL, "%s: bad sizes N=%d S=%lld C=%d G=%d (C <= 1024, G | C)", what, N, (long long)S, C, G);
   return 0;
 }
 

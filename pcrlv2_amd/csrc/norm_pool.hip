@@ -17,6 +17,7 @@ template <int ACT> __device__ __forceinline__ float act_fwd(float z) {
   if (ACT == PCRL_ACT_RELU) return z > 0.f ? z : 0.f;
   if (ACT == PCRL_ACT_SIGMOID) return 1.f / (1.f + expf(-z));
   if (ACT == PCRL_ACT_SILU) return z / (1.f + expf(-z));
+  if (ACT == PCRL_ACT_ELU) return z > 0.f ? z : expm1f(z);   // nn.ELU(): alpha = 1 (models/pcrlv2_model_3d.py:25)
   return z;
 }
 template <int ACT> __device__ __forceinline__ float act_bwd(float z, float da) {
@@ -29,6 +30,7 @@ template <int ACT> __device__ __forceinline__ float act_bwd(float z, float da) {
     const float a = 1.f / (1.f + expf(-z));
     return da * a * (1.f + z * (1.f - a));
   }
+  if (ACT == PCRL_ACT_ELU) return z > 0.f ? da : da * expf(z);
   return da;
 }
 
@@ -791,6 +793,7 @@ extern "C" int pcrl_bn_finalize(const float* partial, int rows, int C, double co
     if (act == PCRL_ACT_RELU) hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_RELU>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__); \
     else if (act == PCRL_ACT_SIGMOID) hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_SIGMOID>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__); \
     else if (act == PCRL_ACT_SILU) hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_SILU>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__); \
+    else if (act == PCRL_ACT_ELU) hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_ELU>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<T, PCRL_ACT_NONE>), GRID, dim3(256), LDS, as_stream(stream), __VA_ARGS__);                    \
   } while (0)
 

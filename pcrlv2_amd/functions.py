@@ -228,6 +228,22 @@ def mark_final(ctx, params):
             _final_callback(p)
 
 
+def _slope(mod):
+    """nn.PReLU's slope vector of a LUConv built with act='prelu' (constructor variant), else None."""
+    return mod.activation.weight if getattr(mod, "_prelu", False) else None
+
+
+def _park_slope(mod, sv):
+    """The PReLU slope's gradient does not travel through autograd (the slope is not an input of the stage Functions): parked like every
+    other parameter gradient.  Needs the engine-delivered gradients (config.DIRECT_PARAM_GRADS)."""
+    if sv.prelu is None or sv.dslope is None:
+        return
+    if not config.DIRECT_PARAM_GRADS:
+        raise RuntimeError("act='prelu' needs config.DIRECT_PARAM_GRADS (the slope gradient is delivered by the engine, not by autograd)")
+    _park(mod.activation.weight, sv.dslope)
+    sv.dslope = None
+
+
 class LUConvFn(Function):
     """act(bn1(conv1(x)))  --  models/pcrlv2_model_3d.py:32-34."""
 
@@ -235,11 +251,15 @@ class LUConvFn(Function):
     def forward(ctx, x, w, b, gamma, beta, mod):
         dt = mod.compute_dtype
         gn = getattr(mod, "_gn_groups", 0)
-        a, sv = ops.luconv_forward(x, w, b, gamma, beta, None if gn else mod.bn1.running_mean, None if gn else mod.bn1.running_var,
-                                   mod._packed, mod._act, dt, gn_groups=gn)
+        w_eff, ctx.ci = w, 0
+        if getattr(mod, "_ci_pad", 0):         # in_channels != 1 (constructor variant): zero-padded to the implicit-GEMM kernels' channel granule
+            ctx.ci = w.shape[1]
+            x, w_eff = ops.pad_first_layer(x, w, mod._ci_pad, dt)
+        a, sv = ops.luconv_forward(x, w_eff, b, gamma, beta, None if gn else mod.bn1.running_mean, None if gn else mod.bn1.running_var,
+                                   mod._packed, mod._act, dt, gn_groups=gn, prelu=_slope(mod), inorm=getattr(mod, "_inorm", False))
         mod._count_batch()
         ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
-        ctx.wref, ctx.gref = w, gamma
+        ctx.wref, ctx.gref = w_eff, gamma
         ctx.pass_idx = getattr(mod, "_pass_idx", 1)
         ctx.plist = (w, b, gamma, beta)
         ctx.set_materialize_grads(False)
@@ -253,6 +273,11 @@ class LUConvFn(Function):
         da = da.contiguous() if sv.kind == "to1" else _act_grad(da, ctx.dt)
         dx, dw, db, dg, dbeta = ops.luconv_backward(sv, da, ctx.wref, ctx.gref, ctx.mod._packed, ctx.dt,
                                                     need_dx=ctx.needs_input_grad[0] and sv.kind != "c1")
+        if ctx.ci:                              # padded first layer: the real input channels' share
+            ops.join_side_stream()              # the weight gradient was produced on the side stream; the slice below runs on this one
+            dw = dw[:, :ctx.ci].contiguous()
+            dx = None if dx is None else dx[:, :ctx.ci]
+        _park_slope(ctx.mod, sv)
         w, b, gamma, beta = ctx.plist
         out = dx, _park(w, dw), _park(b, db), _park(gamma, dg), _park(beta, dbeta), None
         mark_final(ctx, ctx.plist)
@@ -268,7 +293,8 @@ class LUConvPoolFn(Function):
     @staticmethod
     def forward(ctx, x, w, b, gamma, beta, mod):
         dt = mod.compute_dtype
-        (a, p), sv = ops.luconv_forward(x, w, b, gamma, beta, mod.bn1.running_mean, mod.bn1.running_var, mod._packed, mod._act, dt, pooled=True)
+        (a, p), sv = ops.luconv_forward(x, w, b, gamma, beta, mod.bn1.running_mean, mod.bn1.running_var, mod._packed, mod._act, dt, pooled=True,
+                                        prelu=_slope(mod))
         mod._count_batch()
         ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
         ctx.wref, ctx.gref = w, gamma
@@ -286,16 +312,17 @@ class LUConvPoolFn(Function):
         pool_dp = None
         if dp is not None:
             dp = _act_grad(dp, dt)
-            if da is None and ops.bn_pool_ok(D, H, W, Co, dt):
+            if da is None and sv.prelu is None and ops.bn_pool_ok(D, H, W, Co, dt):
                 pool_dp = dp
             else:   # somebody consumed the full-resolution activation too: materialise max_pool3d_backward and add
-                a = ops.bn_act_apply(sv.y, sv.scale, sv.shift, N * D * H * W, Co, sv.act, dt)
+                a = ops.prelu_forward(sv.z, sv.prelu, dt) if sv.prelu is not None else ops.bn_act_apply(sv.y, sv.scale, sv.shift, N * D * H * W, Co, sv.act, dt)
                 dfull = ops.maxpool_backward(a, dp, dt)
                 da = dfull if da is None else _act_grad(da, dt) + dfull
         elif da is not None:
             da = _act_grad(da, dt)
         dx, dw, db, dg, dbeta = ops.luconv_backward(sv, da, ctx.wref, ctx.gref, ctx.mod._packed, dt, need_dx=ctx.needs_input_grad[0],
                                                     pool_dp=pool_dp)
+        _park_slope(ctx.mod, sv)
         w, b, gamma, beta = ctx.plist
         out = dx, _park(w, dw), _park(b, db), _park(gamma, dg), _park(beta, dbeta), None
         mark_final(ctx, ctx.plist)
@@ -334,18 +361,19 @@ class UpStageFn(Function):
         l0, l1, ld = mod.ops[0], mod.ops[1], mod.deep_supervision_head
         gn = getattr(l0, "_gn_groups", 0)
         rs = lambda m: (None, None) if gn else (m.bn1.running_mean, m.bn1.running_var)
-        if config.COMPOSE_UPCONV and not gn:
+        s0, s1 = _slope(l0), _slope(l1)
+        if config.COMPOSE_UPCONV and not gn and s0 is None:
             # up_conv and ops.0's conv1 are two linear maps with nothing in between (:64): one 8-tap operator on the coarse grid,
             # the upsampled tensor is never formed (ops.upconv_luconv_forward, csrc/upconv_fused.hip)
             a0, sv0 = ops.upconv_luconv_forward(x, up_w, up_b, w0, b0, g0, be0, *rs(l0), mod._composed_up, l0._act, dt)
         else:
             up = ops.convt_forward(x, up_w, up_b, mod._packed_up, dt)
-            a0, sv0 = ops.luconv_forward(up, w0, b0, g0, be0, *rs(l0), l0._packed, l0._act, dt, gn_groups=gn)
+            a0, sv0 = ops.luconv_forward(up, w0, b0, g0, be0, *rs(l0), l0._packed, l0._act, dt, gn_groups=gn, prelu=s0)
         if gn:
-            a1, sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gn_groups=gn)
+            a1, sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gn_groups=gn, prelu=s1)
             g = ops.gap_forward(a1, dt)
         else:   # activation and its global average pool (:67) from one pass over the convolution output
-            (a1, g), sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gap=True)
+            (a1, g), sv1 = ops.luconv_forward(a0, w1, b1, g1, be1, *rs(l1), l1._packed, l1._act, dt, gap=True, prelu=s1)
         # The stage's side branches -- nothing in the forward consumes them -- on the side stream, next to the next stage's convolutions
         # (config.FWD_BRANCH_STREAM; the main stream joins at the end of the forward).  Backward runs on the main stream as before.
         with ops.side_branch(a1.device, a1, g):
@@ -354,7 +382,8 @@ class UpStageFn(Function):
             ph1 = mod.predictor_head[1]
             h1, m_h, r_h = ops.bn1d_forward(h0, p1_g, p1_b, ph1.running_mean, ph1.running_var, relu=True)
             x_pre = ops.linear_forward(h1, p3_w, p3_b)
-            x_mask, svd = ops.luconv_forward(a1, dw_, db_, dg_, dbe_, ld.bn1.running_mean, ld.bn1.running_var, ld._packed, ACT_SIGMOID, dt)
+            x_mask, svd = ops.luconv_forward(a1, dw_, db_, dg_, dbe_, ld.bn1.running_mean, ld.bn1.running_var, ld._packed, ACT_SIGMOID, dt,
+                                             inorm=getattr(ld, "_inorm", False))
         for m in (l0, l1, ld):
             m._count_batch()
         mod._count_batch_heads()
@@ -398,7 +427,7 @@ class UpStageFn(Function):
                 grads[13], grads[14], grads[15], grads[16], grads[17], grads[18] = g_p0w, g_p0b, g_p1g, g_p1b, g_p3w, g_p3b
             d_g, g_bng, g_bnb = ops.bn1d_backward(d_xpro, g, x_pro, bn_g, m_pro, r_pro, relu=False)
             grads[11], grads[12] = g_bng, g_bnb
-            if config.FOLD_GAP_GRAD and ctx.sv1.gn is None and ops.bn_rowadd_ok(a1.shape[1], dt):
+            if config.FOLD_GAP_GRAD and ctx.sv1.gn is None and ctx.sv1.prelu is None and ops.bn_rowadd_ok(a1.shape[1], dt):
                 row_g = d_g        # d a1 += d_g[n][c] / S: folded into the BatchNorm backward of ops.1, never materialised
             else:
                 d_a1 = ops.gap_backward(d_g, a1, d_a1, dt)
@@ -409,6 +438,7 @@ class UpStageFn(Function):
             grads[19], grads[20], grads[21], grads[22] = g_dw, g_db, g_dg, g_dbe
         # ---- ops.1, ops.0 ----
         d_a0, gw1, gb1, gg1, gbe1 = ops.luconv_backward(ctx.sv1, d_a1, w1, g1, l1._packed, dt, need_dx=True, da_row_g=row_g)
+        _park_slope(l1, ctx.sv1)
         grads[7], grads[8], grads[9], grads[10] = gw1, gb1, gg1, gbe1
         deferred = ()
         if ctx.sv0.kind == "upc":     # composed up_conv + conv1: both layers' gradients from one set of coarse-grid passes
@@ -427,6 +457,7 @@ class UpStageFn(Function):
         else:
             g_upb = torch.empty(up_w.shape[1], dtype=torch.float32, device=d_a0.device)
             d_up, gw0, gb0, gg0, gbe0 = ops.luconv_backward(ctx.sv0, d_a0, w0, g0, l0._packed, dt, need_dx=True, dx_colsum=g_upb)
+            _park_slope(l0, ctx.sv0)
             # ---- up_conv ----
             dx, g_upw, g_upb = ops.convt_backward(ctx.x, d_up, up_w, mod._packed_up, dt, need_dx=ctx.needs_input_grad[0], db=g_upb)
         grads[3], grads[4], grads[5], grads[6] = gw0, gb0, gg0, gbe0

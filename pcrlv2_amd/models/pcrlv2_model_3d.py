@@ -7,8 +7,13 @@ parameter names / shapes / default initialisation (so an identical `torch.manual
 weights); their forward() is never called.  There is no CPU / eager fallback: non-GPU inputs raise.
 `model.eval()` runs the same kernels on the running statistics (inference; `_forward_eval`).
 
-Unsupported on purpose (NotImplementedError at construction): norm in {'gn','in'} and act in {'prelu','elu'} -- accepted
-as strings by the reference but never instantiated ('gn' crashes there) -- in_channels != 1, n_class != 1.
+Constructor variants the reference accepts but train_3d.py:45 never instantiates -- act in {'elu','prelu'}, norm='in',
+in_channels != 1, n_class != 1 (models/pcrlv2_model_3d.py:15-16,22-25,98) -- run on the same library through general-purpose routes
+(ELU as an activation code of the fused BatchNorm kernels; PReLU as a streaming pass behind the normalisation; InstanceNorm3d as
+GroupNorm with one channel per group; the first layer zero-padded to 32 input channels; one C -> 1 pass per output class) and are
+pinned against the real reference built with the same arguments (tests/golden/v_*.npz, tests/test_variants_gpu.py).  They are not
+tuned: the pre-training path is PCRLv23d() with its defaults.  norm='gn' crashes in the reference; here it is the optional
+GroupNorm + SiLU mode described below.
 """
 from __future__ import annotations
 
@@ -16,14 +21,12 @@ import torch
 import torch.nn as nn
 
 from .. import config, functions as Fn, ops
-from .._lib import ACT_RELU, ACT_SIGMOID, ACT_SILU
+from .._lib import ACT_ELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU
 
 # 'silu' and norm='gn' are OPTIONAL, NON-REFERENCE modes (BASELINE.json's north_star names GroupNorm + SiLU; the reference rejects
 # 'silu' and crashes on 'gn'): PCRLv23d(norm='gn', act='silu') runs conv -> GroupNorm(8) -> SiLU in every LUConv except
 # the 1-channel deep-supervision heads, which keep BatchNorm + sigmoid (GroupNorm(8, 1) cannot exist).  Default = the reference.
-_ACTS = {"relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "silu": ACT_SILU}
-_NO_KERNEL_ACTS = ("prelu", "elu")
-_NO_KERNEL_NORMS = ("in",)
+_ACTS = {"relu": ACT_RELU, "sigmoid": ACT_SIGMOID, "silu": ACT_SILU, "elu": ACT_ELU, "prelu": ACT_NONE}   # prelu: a pass of its own behind the normalisation
 
 
 class _Counted:
@@ -48,27 +51,36 @@ class LUConv(nn.Module, _Counted):
 
     def __init__(self, in_chan, out_chan, act, norm):
         super().__init__()
-        if norm in _NO_KERNEL_NORMS:
-            raise NotImplementedError(f"normalization type {norm} has no gfx950 kernel ('bn' is the reference default and its only working setting)")
-        if norm not in ("bn", "gn"):
+        if norm not in ("bn", "gn", "in"):
             raise ValueError('normalization type {} is not supported'.format(norm))
-        if act in _NO_KERNEL_ACTS:
-            raise NotImplementedError(f"activation type {act} has no gfx950 kernel")
         if act not in _ACTS or (act == "silu" and norm != "gn"):    # the reference rejects 'silu' (:30); only the optional 'gn' mode takes it
             raise ValueError('activation type {} is not supported'.format(act))
         self.conv1 = nn.Conv3d(in_chan, out_chan, 3, padding=1)               # container: weight [Co,Ci,3,3,3], bias [Co]
-        self._gn_groups = 8 if (norm == "gn" and out_chan > 1) else 0
-        if self._gn_groups:
+        self._inorm = norm == "in"
+        # per-sample statistics pooled over channel groups: GroupNorm(8) (optional mode) or one channel per group = InstanceNorm3d (:15-16);
+        # the 1-channel heads keep BatchNorm in 'gn' mode (GroupNorm(8, 1) cannot exist) and take ops.luconv_forward's InstanceNorm route in 'in' mode
+        self._gn_groups = (8 if norm == "gn" else out_chan) if (norm in ("gn", "in") and out_chan > 1) else 0
+        if norm == "in":
+            self.bn1 = nn.InstanceNorm3d(out_chan, momentum=ops.BN_MOMENTUM, affine=True)   # container: affine only (no running statistics, :16)
+        elif self._gn_groups:
             self.bn1 = nn.GroupNorm(8, out_chan)                              # the reference's attribute name for either norm (:13-14)
         else:
             self.bn1 = nn.BatchNorm3d(out_chan, momentum=ops.BN_MOMENTUM)      # container: affine + running statistics
+        self._prelu = act == "prelu"
+        if self._prelu:
+            self.activation = nn.PReLU(out_chan)                              # container: the slope vector, registered after bn1 like the reference (:23)
+        # first layer of a multi-channel model (in_channels != 1, :98): zero-padded to the implicit-GEMM kernels' 32-channel granule
+        self._ci_pad = 32 * ((in_chan + 31) // 32) if (in_chan != 1 and in_chan % 32) else 0
         self._act = _ACTS[act]
         self.compute_dtype = config.default_compute_dtype()
         self._packed = ops.PackedWeights("conv3")
-        self._init_counter([] if self._gn_groups else [self.bn1])
+        self._init_counter([] if (self._gn_groups or self._inorm) else [self.bn1])
 
     def forward(self, x):
-        x = x.float().contiguous() if self.conv1.in_channels == 1 else ops.to_act(x, self.compute_dtype)
+        if self._ci_pad:
+            x = x.float()
+        else:
+            x = x.float().contiguous() if self.conv1.in_channels == 1 else ops.to_act(x, self.compute_dtype)
         c, n = self.conv1, self.bn1
         return Fn.LUConvFn.apply(x, c.weight, c.bias, n.weight, n.bias, self)
 
@@ -91,8 +103,6 @@ class UpTransition(nn.Module, _Counted):
 
     def __init__(self, inChans, outChans, depth, act, norm):
         super().__init__()
-        if act not in ("relu", "silu"):
-            raise NotImplementedError("UpTransition is implemented for act='relu' (the reference default) and the optional 'silu'")
         c = 64 << depth
         self.depth = depth
         self.up_conv = nn.ConvTranspose3d(inChans, outChans, 2, stride=2)
@@ -125,8 +135,6 @@ class OutputTransition(nn.Module):
 
     def __init__(self, inChans, n_labels):
         super().__init__()
-        if n_labels != 1:
-            raise NotImplementedError("n_class != 1 has no gfx950 kernel (pre-training uses n_class=1)")
         self.final_conv = nn.Conv3d(inChans, n_labels, 1)
         self.sigmoid = nn.Sigmoid()   # kept for attribute parity; the sigmoid is fused into the kernel path
         self.compute_dtype = config.default_compute_dtype()
@@ -168,8 +176,6 @@ class PCRLv23d(nn.Module):
 
     def __init__(self, n_class=1, act='relu', norm='bn', in_channels=1, low_dim=128, student=False):
         super().__init__()
-        if in_channels != 1:
-            raise NotImplementedError("in_channels != 1 has no gfx950 first-layer kernel (LUNA volumes are 1-channel)")
         self.compute_dtype = config.default_compute_dtype()
         # registration order == the reference's, so state_dict() enumerates the same 169 keys in the same order
         self.maxpool = _MaxPool3d2()
@@ -224,8 +230,11 @@ class PCRLv23d(nn.Module):
 
         def lu(m, h):
             c, n, gn = m.conv1, m.bn1, m._gn_groups
-            return ops.luconv_forward(h, c.weight, c.bias, n.weight, n.bias, None if gn else n.running_mean, None if gn else n.running_var,
-                                      m._packed, m._act, dt, training=False, gn_groups=gn)[0]
+            w = c.weight
+            if m._ci_pad:
+                h, w = ops.pad_first_layer(h, w, m._ci_pad, dt)
+            return ops.luconv_forward(h, w, c.bias, n.weight, n.bias, None if gn else n.running_mean, None if gn else n.running_var,
+                                      m._packed, m._act, dt, training=False, gn_groups=gn, prelu=Fn._slope(m), inorm=m._inorm)[0]
 
         h = x.float().contiguous()
         for i, ((name, _, _), attr) in enumerate(zip(_ENCODER, _SKIPS)):

@@ -677,11 +677,45 @@ def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, ro
 # LUConv = conv3x3x3 + BatchNorm3d(train) + activation      (models/pcrlv2_model_3d.py:6-34)
 # ----------------------------------------------------------------------------------------------
 class LUConvSaved:
-    __slots__ = ("kind", "x", "y", "mean", "rstd", "scale", "shift", "geom", "act", "gn")
+    __slots__ = ("kind", "x", "y", "mean", "rstd", "scale", "shift", "geom", "act", "gn", "prelu", "z", "dslope", "in_head")
+
+
+def prelu_forward(z, slope, dtype):
+    """nn.PReLU(C) on an activation (constructor variant act='prelu', models/pcrlv2_model_3d.py:22-23)."""
+    N, D, H, W, C = dims(z)
+    a = torch.empty_like(z)
+    lib().call("pcrl_prelu_fwd", z, slope.detach(), a, N * D * H * W, C, dtype_code(dtype), stream_handle())
+    return a
+
+
+def prelu_backward(da, z, slope, dtype):
+    """-> (dz, dslope [C] float32)."""
+    L, s, dev = lib(), stream_handle(), z.device
+    N, D, H, W, C = dims(z)
+    M = N * D * H * W
+    rows = L.call("pcrl_prelu_bwd_partial_rows", M)
+    partial = _f32(rows * C, dev)
+    dz = torch.empty_like(z)
+    L.call("pcrl_prelu_bwd", da, z, slope.detach(), dz, partial, M, C, dtype_code(dtype), s)
+    dslope = _f32(C, dev)
+    nb = L.call("pcrl_colsum_ws_bytes", rows, C)
+    L.call("pcrl_colsum", partial, dslope, workspace(nb, dev), nb, rows, C, dtype_code(torch.float32), s)
+    return dz, dslope
+
+
+def pad_first_layer(x, conv_w, ci_pad, dtype):
+    """in_channels != 1 (constructor variant, models/pcrlv2_model_3d.py:98,102): the input and the first convolution's weight zero-padded
+    to `ci_pad` input channels so that the layer runs on the Ci % 32 == 0 implicit-GEMM kernels.  Data movement only."""
+    N, Ci, D, H, W = x.shape
+    xp = torch.zeros((N, D, H, W, ci_pad), dtype=dtype, device=x.device).permute(0, 4, 1, 2, 3)
+    xp[:, :Ci] = x
+    wp = torch.zeros((conv_w.shape[0], ci_pad, 3, 3, 3), dtype=torch.float32, device=conv_w.device)
+    wp[:, :Ci] = conv_w.detach()
+    return xp, wp
 
 
 def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, packed: PackedWeights, act: int, dtype, training=True, gn_groups=0,
-                   pooled=False, gap=False):
+                   pooled=False, gap=False, prelu=None, inorm=False):
     """x: activation (or float32 [N,1,D,H,W] for the first layer).  Returns (a, saved); with `pooled` ((a, MaxPool3d(2)(a)), saved) --
     one pass where bn_pool_ok (BatchNorm layers of the MFMA path), else the separate pool; with `gap` ((a, global average pool [N, C]
     float32 of a), saved), likewise in one pass where bn_rowadd_ok.
@@ -689,8 +723,30 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
     L, s, dev = lib(), stream_handle(), x.device
     Co, Ci = conv_w.shape[0], conv_w.shape[1]
     sv = LUConvSaved()
+    # prelu (a float32 [Co] slope vector; constructor variant act='prelu'): the normalisation runs without an activation and
+    # pcrl_prelu_fwd follows as its own pass -- none of the fused apply kernels applies
+    if prelu is not None:
+        act = ACT_NONE
     sv.act = act
     sv.gn = None
+    sv.prelu, sv.z, sv.dslope, sv.in_head = prelu, None, None, False
+    if inorm and Co == 1:
+        # norm='in' deep-supervision head (InstanceNorm3d(1), models/pcrlv2_model_3d.py:15-16,60): per-sample statistics of a 1-channel
+        # float32 map -- the GroupNorm machinery on the map viewed as [N][S / 4][4] with ONE group over its four pseudo-channels
+        N, D, H, W, C = dims(x)
+        M, S = N * D * H * W, D * H * W
+        if S % 4:
+            raise PcrlError("InstanceNorm head: D*H*W must be a multiple of 4")
+        y = _f32(M, dev)
+        nb = L.call("pcrl_conv3d_to1_fwd_ws_bytes", N, D, H, W, C, 27)
+        L.call("pcrl_conv3d_to1_fwd", x, conv_w.detach(), conv_b.detach(), y, None, workspace(nb, dev) if nb else None, nb,
+               N, D, H, W, C, 27, dtype_code(dtype), s)
+        g4, b4 = gamma.detach().expand(4).contiguous(), beta.detach().expand(4).contiguous()
+        a, saved = gn_forward_rows(y.view(N, S // 4, 4), g4, b4, 1, act, torch.float32)
+        sv.gn, sv.in_head, sv.kind = (saved, 1), True, "to1"
+        sv.x, sv.y, sv.mean, sv.rstd, sv.scale, sv.shift = x, y, None, None, None, None
+        sv.geom = (N, D, H, W, Ci, Co)
+        return a.view(N, 1, D, H, W), sv
     if gn_groups and Co > 1:
         # OPTIONAL, NOT IN THE REFERENCE (north_star's GroupNorm + SiLU; the reference's own norm='gn' crashes):
         # conv -> GroupNorm(groups) -> activation.  Per-sample statistics: the same in train and eval mode, no running buffers.
@@ -709,6 +765,12 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         sv.gn = (saved, gn_groups)
         sv.x, sv.y, sv.mean, sv.rstd, sv.scale, sv.shift = x, y, None, None, None, None
         sv.geom = (N, D, H, W, Ci, Co)
+        if prelu is not None:
+            sv.z, a = a, prelu_forward(a, prelu, dtype)
+        if pooled:
+            a = (a, maxpool_forward(a, dtype))
+        elif gap:
+            a = (a, gap_forward(a, dtype))
         return a, sv
     if Co == 1:  # deep-supervision head: C -> 1, float32 map out
         N, D, H, W, C = dims(x)
@@ -752,11 +814,11 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
             L.call("pcrl_conv3d_k3_fwd_ws", x, wf, conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb, N, D, H, W, Ci, Co,
                    dtype_code(dtype), s)
         mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, training)
-        if pooled and config.FUSE_APPLY_CONSUMERS and bn_pool_ok(D, H, W, Co, dtype):
+        if pooled and prelu is None and config.FUSE_APPLY_CONSUMERS and bn_pool_ok(D, H, W, Co, dtype):
             a, p = torch.empty_like(y), new_act(N, D // 2, H // 2, W // 2, Co, dtype, dev)
             L.call("pcrl_bn_act_apply_pool", y, a, p, scale, shift, N, D, H, W, Co, act, dtype_code(dtype), s)
             a, pooled = (a, p), False
-        elif gap and config.FUSE_APPLY_CONSUMERS and bn_rowadd_ok(Co, dtype):
+        elif gap and prelu is None and config.FUSE_APPLY_CONSUMERS and bn_rowadd_ok(Co, dtype):
             a, g = torch.empty_like(y), _f32(N * Co, dev).view(N, Co)
             nbg = L.call("pcrl_gap_ws_bytes", N, D * H * W, Co)
             L.call("pcrl_bn_act_apply_gap", y, a, g, scale, shift, workspace(nbg, dev), nbg, N, D * H * W, Co, act, dtype_code(dtype), s)
@@ -766,6 +828,8 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         sv.kind = "gemm"
     sv.x, sv.y, sv.mean, sv.rstd, sv.scale, sv.shift = x, y, mean, rstd, scale, shift
     sv.geom = (N, D, H, W, Ci, Co)
+    if prelu is not None:
+        sv.z, a = a, prelu_forward(a, prelu, dtype)
     if pooled:
         a = (a, maxpool_forward(a, dtype))
     elif gap:
@@ -793,9 +857,18 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
     dev = sv.y.device
     dw = torch.empty_like(conv_w, dtype=torch.float32, memory_format=torch.contiguous_format)
     db = zero_grad_vector(Co, dev)
+    if sv.prelu is not None:      # act='prelu': through the PReLU pass first (the callers fold nothing into `da` in this mode)
+        if da is None or da_row_g is not None or pool_dp is not None:
+            raise PcrlError("luconv_backward: the PReLU variant takes the complete gradient of the activation as a tensor")
+        da, sv.dslope = prelu_backward(da, sv.z, sv.prelu, dtype)
     if sv.kind == "to1":
         da = da.contiguous()
-        dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, 1, sv.act, torch.float32)
+        if sv.in_head:
+            S = D * H * W
+            dy, dg4, db4 = gn_backward_rows(da.view(N, S // 4, 4), sv.gn[0], gamma.detach().expand(4).contiguous(), 1, sv.act, torch.float32)
+            dy, dgamma, dbeta = dy.view(-1), dg4.sum().view(1), db4.sum().view(1)
+        else:
+            dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, 1, sv.act, torch.float32)
         nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, Ci, 27)
         dbias_unused = _f32(1, dev)
         L.call("pcrl_conv3d_to1_wgrad", sv.x, dy, dw, dbias_unused, workspace(nb, dev), nb, N, D, H, W, Ci, 27, dtype_code(dtype), s)
@@ -1148,6 +1221,17 @@ def conv1x1_to1_forward(x, w, b, dtype):
     L, s = lib(), stream_handle()
     N, D, H, W, C = dims(x)
     M = N * D * H * W
+    K = w.shape[0]
+    if K != 1:
+        # n_class != 1 (constructor variant, models/pcrlv2_model_3d.py:78,109): one C -> 1 pass per class into a class-major buffer,
+        # handed out as its [N, K, D, H, W] view
+        wd, bd = w.detach(), b.detach()
+        out = torch.empty((K, N, D, H, W), dtype=torch.float32, device=x.device)
+        pre = _f32(M, x.device)
+        for k in range(K):
+            L.call("pcrl_conv3d_to1_fwd", x, wd[k], bd[k:k + 1], pre, None, None, 0, N, D, H, W, C, 1, dtype_code(dtype), s)
+            L.call("pcrl_sigmoid_fwd", pre, out[k], M, s)
+        return out.permute(1, 0, 2, 3, 4)
     pre = _f32(M, x.device)
     L.call("pcrl_conv3d_to1_fwd", x, w.detach(), b.detach(), pre, None, None, 0, N, D, H, W, C, 1, dtype_code(dtype), s)
     out = torch.empty((N, 1, D, H, W), dtype=torch.float32, device=x.device)
@@ -1159,6 +1243,22 @@ def conv1x1_to1_backward(x, out, dout, w, dtype, need_dx=True):
     L, s, dev = lib(), stream_handle(), x.device
     N, D, H, W, C = dims(x)
     M = N * D * H * W
+    K = w.shape[0]
+    if K != 1:
+        outk, doutk = out.permute(1, 0, 2, 3, 4).contiguous(), dout.permute(1, 0, 2, 3, 4).contiguous()     # class-major, like the forward's buffer
+        dw = torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format)
+        db = _f32(K, dev)
+        dwk = dw.view(K, C)
+        nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, C, 1)
+        dpre, dx, wd = _f32(M, dev), None, w.detach()
+        for k in range(K):
+            L.call("pcrl_sigmoid_bwd", doutk[k], outk[k], dpre, M, s)
+            L.call("pcrl_conv3d_to1_wgrad", x, dpre, dwk[k], db[k:k + 1], workspace(nb, dev), nb, N, D, H, W, C, 1, dtype_code(dtype), s)
+            if need_dx:
+                nxt = torch.empty_like(x)
+                L.call("pcrl_conv3d_to1_dgrad", dpre, wd[k], dx, nxt, N, D, H, W, C, 1, dtype_code(dtype), s)     # dx = sum over the classes
+                dx = nxt
+        return dx, dw, db
     dpre = _f32(M, dev)
     L.call("pcrl_sigmoid_bwd", dout.contiguous(), out, dpre, M, s)
     dw = torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format)
@@ -1245,9 +1345,22 @@ def ntxent_backward(z, dloss, ws, tau, eps=1e-8):
 # ----------------------------------------------------------------------------------------------
 def gn_act_forward(y, gamma, beta, groups, act, dtype, eps=1e-5):
     """a = act(GroupNorm(groups)(y)); y, a: activations [N, C, D, H, W] in NDHWC storage.  -> (a, saved tuple for the backward)."""
-    L, s, dev = lib(), stream_handle(), y.device
     N, D, H, W, C = dims(y)
-    S = D * H * W
+    a, saved = gn_forward_rows(y.permute(0, 2, 3, 4, 1).view(N, D * H * W, C), gamma, beta, groups, act, dtype, eps)
+    return a.view(N, D, H, W, C).permute(0, 4, 1, 2, 3), saved
+
+
+def gn_act_backward(da, saved, gamma, groups, act, dtype):
+    """-> (dy, dgamma [C], dbeta [C])."""
+    N, D, H, W, C = dims(da)
+    dy, dg, db = gn_backward_rows(da.permute(0, 2, 3, 4, 1).view(N, D * H * W, C), saved, gamma, groups, act, dtype)
+    return dy.view(N, D, H, W, C).permute(0, 4, 1, 2, 3), dg, db
+
+
+def gn_forward_rows(y, gamma, beta, groups, act, dtype, eps=1e-5):
+    """GroupNorm(groups) + activation on a contiguous [N, S, C] tensor (S rows of C channels per sample).  groups == C: InstanceNorm."""
+    L, s, dev = lib(), stream_handle(), y.device
+    N, S, C = y.shape
     tiles = L.call("pcrl_gn_stats_tiles", S)
     partial = _f32(N * tiles * C * 2, dev)
     L.call("pcrl_gn_stats", y, partial, N, S, C, dtype_code(dtype), s)
@@ -1259,12 +1372,11 @@ def gn_act_forward(y, gamma, beta, groups, act, dtype, eps=1e-5):
     return a, (y, mean_c, rstd_c, scale, shift)
 
 
-def gn_act_backward(da, saved, gamma, groups, act, dtype):
-    """-> (dy, dgamma [C], dbeta [C])."""
+def gn_backward_rows(da, saved, gamma, groups, act, dtype):
+    """-> (dy [N, S, C], dgamma [C], dbeta [C]) for gn_forward_rows."""
     y, mean_c, rstd_c, scale, shift = saved
     L, s, dev = lib(), stream_handle(), y.device
-    N, D, H, W, C = dims(y)
-    S = D * H * W
+    N, S, C = y.shape
     rows_b = L.call("pcrl_bn_bwd_partial_rows", S)
     partial_b = _f32(N * rows_b * C * 2, dev)
     for n in range(N):

@@ -117,3 +117,36 @@ def test_eval_mode_forward_matches_reference(golden_dir):
     # eval mode leaves the state alone
     out2, _, _ = O.forward(st1, x, training=False)
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("tag", ["v_elu", "v_prelu", "v_in", "v_inch3", "v_ncls2", "v_all"])
+def test_constructor_variants_match_reference(tag, golden_dir):
+    """The oracle built like PCRLv23d(act=..., norm=..., in_channels=..., n_class=...) against the REAL reference built with the same
+    arguments (tests/golden/v_*.npz from make_golden.py --variants; models/pcrlv2_model_3d.py:15-16,22-25,98): forward outputs, the
+    scalar O.variant_loss and the gradient of every parameter."""
+    fx = _load(golden_dir, tag)
+    kw = dict(n_class=int(fx["meta/n_class"]), in_channels=int(fx["meta/in_channels"]), act=str(fx["meta/act"]), norm=str(fx["meta/norm"]))
+    dt = torch.float64
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    st0 = O.fill_state(dt, **kw)
+    st = {k: (v.clone().requires_grad_(True) if not O.is_buffer(k) else v.clone()) for k, v in st0.items()}
+    x = O.variant_input(int(fx["meta/b"]), tuple(int(v) for v in fx["meta/dhw"]), kw["in_channels"], dt)
+    with torch.backends.mkldnn.flags(enabled=False):
+        nb = {}
+        out, feats, masks = O.forward(st, x, new_bufs=nb, act=kw["act"], norm=kw["norm"])
+        L = O.variant_loss(out, feats, masks)
+        pn = [k for k in st if not O.is_buffer(k)]
+        grads = dict(zip(pn, torch.autograd.grad(L, [st[k] for k in pn], allow_unused=True)))
+    assert abs(float(L) - float(fx["loss"])) < 1e-12
+    np.testing.assert_allclose(_samples(out, 512), fx["fwd/out/samples"], rtol=0, atol=1e-10)
+    for i in range(3):
+        np.testing.assert_allclose(feats[i][0].detach().numpy(), fx[f"fwd/pro{i}"], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(_samples(masks[i], 256), fx[f"fwd/mask{i}/samples"], rtol=0, atol=1e-10)
+    for name, g in grads.items():
+        if f"grad/{name}/none" in fx.files:
+            assert g is None, name
+            continue
+        np.testing.assert_allclose(_samples(g, 64), fx[f"grad/{name}/samples"], rtol=0, atol=1e-9 * max(float(fx[f"grad/{name}/l2"]), 1e-3), err_msg=name)
+    for key in fx.files:
+        if key.startswith("buf1/"):
+            np.testing.assert_allclose(nb[key[5:]].double().numpy(), fx[key], rtol=0, atol=1e-10, err_msg=key)
