@@ -253,7 +253,8 @@ def main():
         gc.disable()
     barrier()
     ALG_BYTES.clear()
-    L.profiler = prof
+    if os.environ.get("PCRL_BENCH_NO_INREGION", "0") != "1":     # A/B probe of what the event pairs inside the timed region cost
+        L.profiler = prof
     ms0 = torch.cuda.memory_stats(dev)
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
@@ -313,10 +314,44 @@ def main():
             del c4
         except Exception as e:      # the secondary figure must never cost the primary line
             secondary = {"C4": {"error": repr(e)[:200]}}
+        # BASELINE config C5's per-GPU workload (2D ResNet-18 U-Net, 512x512, b = 64; SURVEY 8f N1 -- parity unpinned): 2 warm-up +
+        # 3 timed steps of train_2d.train_step on synthetic batches (tools/bench_2d.py is the stand-alone form), so that the driver's record
+        # holds the 2D path's rate as well.  Never part of `value`.
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from bench_2d import conv_flops_fwd
+            from pcrlv2_amd import train_2d
+            from pcrlv2_amd.models import PCRLv2
+            m2 = PCRLv2().to(dev).set_compute_dtype("bf16")
+            o2 = FusedSGD(m2.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+            g2 = torch.Generator(device=dev).manual_seed(1234)
+            kw2 = dict(generator=g2, device=dev)
+            b2, sz = 64, 512
+            x1 = torch.randn(b2, 3, sz, sz, **kw2)
+            batch2 = (x1, x1 + 0.1 * torch.randn(b2, 3, sz, sz, **kw2), torch.rand(b2, 3, sz, sz, **kw2), None,
+                      [torch.randn(b2, 3, 96, 96, **kw2) for _ in range(6)])
+            crit2 = train_2d.MSELoss2d()
+            for _ in range(2):
+                train_2d.train_step(m2, o2, batch2, 0, crit2, cosine)
+            torch.cuda.synchronize()
+            t_c5 = time.perf_counter()
+            for _ in range(3):
+                train_2d.train_step(m2, o2, batch2, 0, crit2, cosine)
+            torch.cuda.synchronize()
+            t_c5 = (time.perf_counter() - t_c5) / 3
+            flop2 = 3 * b2 * (2 * conv_flops_fwd(sz) + 6 * conv_flops_fwd(96))
+            secondary["C5_2d"] = {"workload": "C5 per-GPU: PCRLv2 ResNet-18 U-Net, 512x512 x2 + 6 local 96x96, b=64, fwd+bwd+SGD (3 timed steps after 2 warm-up; 2D parity unpinned)",
+                                  "value": round(b2 / t_c5, 2), "unit": "crops/s", "ms_per_step": round(1e3 * t_c5, 3),
+                                  "step_mfma_frac": round(flop2 / t_c5 / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            del m2, o2, batch2, x1
+        except Exception as e:
+            secondary["C5_2d"] = {"error": repr(e)[:200]}
 
     if rank != 0:
         return
     res = prof.results()
+    if not res and alone is not None:        # PCRL_BENCH_NO_INREGION=1 (probe): no event pairs inside the timed region -- the one-stream steps stand in
+        res = alone.results()
     detail = {}
     for k, (n, ms, work) in sorted(res.items()):
         detail[k] = {"launches": n, "avg_ms": round(ms / n, 4), "tflops": round(work / (ms * 1e-3) / 1e12, 1)}

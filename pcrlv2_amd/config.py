@@ -129,6 +129,12 @@ VIEW_BRANCH_INLINE = os.environ.get("PCRL_VIEW_BRANCH_INLINE", "0") == "1"
 # BatchNorm).  One event wait per step, nothing else changes; results bit-identical.
 VIEW_SKEW = int(os.environ.get("PCRL_VIEW_SKEW", "0"))
 
+# Experiment: HIP stream priorities (0 = normal, -1 = high).  When two streams hold ready kernels the dispatcher takes the higher-priority
+# queue's workgroups first, so a favoured view finishes its convolution earlier and its BatchNorm passes run under the other view's
+# convolution instead of next to its BatchNorm passes (the two views run identical layer sequences).  Results bit-identical.
+VIEW_STREAM_PRIORITY = int(os.environ.get("PCRL_VIEW_PRIO", "0"))
+SIDE_STREAM_PRIORITY = int(os.environ.get("PCRL_SIDE_PRIO", "0"))
+
 # Weight packing off the forward's critical chain: the packed / composed weight forms a step needs (10 pack launches, 3 x the composed
 # operator's prep + GEMM + pack + bias: ~25 small kernels, 0.5 ms back to back) are rebuilt on the SIDE stream at the start of the step, in
 # first-use order, while the main stream already runs the first layers; every reader waits for its own cache's event (ops._CacheGuard).

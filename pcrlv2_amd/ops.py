@@ -116,7 +116,7 @@ class side_wgrad:
         key = (self.device.type, self.device.index)
         side = _side_streams.get(key)
         if side is None:
-            side = _side_streams[key] = torch.cuda.Stream(device=self.device)
+            side = _side_streams[key] = torch.cuda.Stream(device=self.device, priority=config.SIDE_STREAM_PRIORITY)
         side.wait_stream(torch.cuda.current_stream(self.device))
         for t in self.operands:
             t.record_stream(side)
@@ -197,7 +197,7 @@ def side_stream(device):
     key = (device.type, device.index)
     side = _side_streams.get(key)
     if side is None:
-        side = _side_streams[key] = torch.cuda.Stream(device=device)
+        side = _side_streams[key] = torch.cuda.Stream(device=device, priority=config.SIDE_STREAM_PRIORITY)
     return side
 
 
@@ -373,7 +373,7 @@ def fork_views(device, path2d=False):
         key = (device.type, device.index, name)
         vs = _view_streams.get(key)
         if vs is None:
-            vs = _view_streams[key] = torch.cuda.Stream(device=device)
+            vs = _view_streams[key] = torch.cuda.Stream(device=device, priority=config.VIEW_STREAM_PRIORITY)
         vs.wait_stream(torch.cuda.current_stream(device))
     _views_active = True
 
