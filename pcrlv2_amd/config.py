@@ -145,3 +145,8 @@ PREPACK = os.environ.get("PCRL_PREPACK", "1") != "0"
 # The passes' parameter gradients summed into the optimizer's arena by ONE launch of our own (pcrl_grad_sum) instead of a multi-tensor copy
 # and two multi-tensor adds (four ATen launches on the serial tail of backward).  PCRL_FUSED_GRAD_SUM=0: off (bit-identical).
 FUSED_GRAD_SUM = os.environ.get("PCRL_FUSED_GRAD_SUM", "1") != "0"
+
+# The reference returns the caching allocator's pools to the driver after every epoch (train_3d.py:83, "help release GPU memory").  It changes
+# no result; here it means releasing and re-reserving the provisioned pools (45 GB at C2) once per epoch, and about one such cycle in ten
+# stalls for ~3 s inside the driver (measured: `[provision] ... in 3.22 s`, PCRL_PROVISION_VERBOSE=1).  Off by default; =1: as the reference.
+EMPTY_CACHE_PER_EPOCH = os.environ.get("PCRL_EMPTY_CACHE_PER_EPOCH", "0") == "1"

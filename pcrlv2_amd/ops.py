@@ -293,6 +293,8 @@ def provision_allocator(device, key=None):
         _provisioned_segments.difference_update({e for e in _provisioned_segments if e[0] == idx})
     _provisioned[(idx, key)] = 0
     torch.cuda.synchronize(device)
+    import time as _time
+    _t0 = _time.perf_counter()
     segs = [s for s in torch.cuda.memory_snapshot() if s["device"] == idx and (idx, s["address"]) not in _provisioned_segments]
     free_b, total_b = torch.cuda.mem_get_info(device)
     want = sum(s["total_size"] for s in segs) * (f - 1)
@@ -337,6 +339,8 @@ def provision_allocator(device, key=None):
         if s["device"] == idx:
             _provisioned_segments.add((idx, s["address"]))
     _provisioned[(idx, key)] = torch.cuda.memory_reserved(device)
+    if os.environ.get("PCRL_PROVISION_VERBOSE", "0") == "1":
+        print("[provision] %d new segments x%d -> reserved %.1f GB in %.2f s" % (len(segs), f, _provisioned[(idx, key)] / 2**30, _time.perf_counter() - _t0), flush=True)
 
 
 # ---- the second global view on its own stream (config.VIEW_STREAMS) ----

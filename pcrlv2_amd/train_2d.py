@@ -17,6 +17,7 @@ import time
 
 import torch
 
+from . import config as _cfg
 from . import ddp as _ddp
 from . import ops as _ops
 from .functions2d import mse_loss2d
@@ -117,7 +118,8 @@ def train_pcrlv2(args, data_loader, out_channel=3):
                 model.flush_counters()
                 state = {'opt': args, 'state_dict': model.model.encoder.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch}
                 torch.save(state, os.path.join(args.output, "{}_{}_{}_{}_{}.pt".format(args.model, args.n, args.phase, args.ratio, epoch)))
-        torch.cuda.empty_cache()
+        if _cfg.EMPTY_CACHE_PER_EPOCH:           # train_2d.py's per-epoch empty_cache; off by default (config.py)
+            torch.cuda.empty_cache()
     return model
 
 
