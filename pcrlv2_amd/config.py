@@ -150,3 +150,9 @@ FUSED_GRAD_SUM = os.environ.get("PCRL_FUSED_GRAD_SUM", "1") != "0"
 # no result; here it means releasing and re-reserving the provisioned pools (45 GB at C2) once per epoch, and about one such cycle in ten
 # stalls for ~3 s inside the driver (measured: `[provision] ... in 3.22 s`, PCRL_PROVISION_VERBOSE=1).  Off by default; =1: as the reference.
 EMPTY_CACHE_PER_EPOCH = os.environ.get("PCRL_EMPTY_CACHE_PER_EPOCH", "0") == "1"
+
+# Experiment: a layer's weight gradient (side stream) is queued BEHIND its data gradient instead of in front of it.  Both need the same dy;
+# queued first, the weight gradient runs next to the data gradient (two matrix kernels sharing the chip) and the BatchNorm backward passes
+# of the layer below then run with nothing beside them; queued second, the side stream's wait covers the data gradient, and the weight
+# gradient runs next to those HBM-bound passes.  Same kernels, same results (bit-identical).  PCRL_WGRAD_AFTER_DGRAD=1: on.
+WGRAD_AFTER_DGRAD = os.environ.get("PCRL_WGRAD_AFTER_DGRAD", "0") == "1"

@@ -895,10 +895,17 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
         nb = L.call("pcrl_conv3d_k3_c1_wgrad_ws_bytes", N, D, H, W, Co)
         L.call("pcrl_conv3d_k3_c1_wgrad", sv.x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Co, dtype_code(dtype), s)
         return None, dw, db, dgamma, dbeta
-    nb = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
-    with side_wgrad(dev, sv.x, dy) as ws:
-        with mfma_turn(dev, 54.0 * M * Ci * Co):
-            L.call("pcrl_conv3d_k3_wgrad", sv.x, dy, dw, ws(nb), nb, N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
+    def weight_gradient():
+        nbw = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
+        with side_wgrad(dev, sv.x, dy) as ws:
+            with mfma_turn(dev, 54.0 * M * Ci * Co):
+                L.call("pcrl_conv3d_k3_wgrad", sv.x, dy, dw, ws(nbw), nbw, N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
+
+    # config.WGRAD_AFTER_DGRAD: the data gradient is queued first, so the side stream's wait for this stream covers it and the weight
+    # gradient runs behind it, next to the BatchNorm backward passes of the layer below, instead of next to the data gradient
+    late = config.WGRAD_AFTER_DGRAD and need_dx
+    if not late:
+        weight_gradient()
     dx = None
     if need_dx:
         _, wd = packed.get(conv_w, dtype)
@@ -915,6 +922,8 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
             nb2 = L.call("pcrl_colsum_ws_bytes", rows, Ci * 2)
             L.call("pcrl_colsum", part, both, workspace(nb2, dev), nb2, rows, Ci * 2, dtype_code(torch.float32), s)
             dx_colsum.copy_(both.view(Ci, 2)[:, 0])
+    if late:
+        weight_gradient()
     return dx, dw, db, dgamma, dbeta
 
 
@@ -1122,19 +1131,27 @@ def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamm
     N, D, H, W, Ci, Co = sv.geom
     M = N * D * H * W * 8
     dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype)
+    late = config.WGRAD_AFTER_DGRAD and need_dx and defer      # see luconv_backward
+    dx = None
+
+    def data_gradient():
+        _, wd, _ = composed.get(w_up, b_up, conv_w, conv_b, dtype)
+        dxx = new_act(N, D, H, W, Ci, dtype, dev)
+        nbd = L.call("pcrl_upconv_dgrad_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))      # split-K scratch on the small coarse grids
+        with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
+            L.call("pcrl_upconv_dgrad_ws", dy, wd, composed.wd3, dxx, workspace(nbd, dev) if nbd else None, nbd, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+        return dxx
+
+    if late:
+        dx = data_gradient()
     composed.accumulate(sv.x, dy, sv.geom, w_up, b_up, conv_w, dtype, zero_sum=config.UPC_ZERO_SUM)   # dy: output of the BatchNorm backward just above
     dw_up = db_up = dw0 = None
     if not defer:
         join_side_stream()
         _pending_composed.remove(composed)
         _, _, _, dw_up, db_up, dw0 = composed.finish()
-    dx = None
-    if need_dx:
-        _, wd, _ = composed.get(w_up, b_up, conv_w, conv_b, dtype)
-        dx = new_act(N, D, H, W, Ci, dtype, dev)
-        nbd = L.call("pcrl_upconv_dgrad_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))      # split-K scratch on the small coarse grids
-        with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
-            L.call("pcrl_upconv_dgrad_ws", dy, wd, composed.wd3, dx, workspace(nbd, dev) if nbd else None, nbd, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    if need_dx and not late:
+        dx = data_gradient()
     return dx, dw_up, db_up, dw0, zero_grad_vector(Co, dev), dgamma, dbeta
 
 
