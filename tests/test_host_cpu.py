@@ -430,3 +430,44 @@ def test_rank_cpu_binding_helpers():
     assert all(len(s) == 32 for s in shares) and len(set(c for s in shares for c in s)) == 128      # disjoint, whole node
     assert cpu_share(node, {1, 2, 3}, 4, 3) == [1, 2, 3]        # fewer CPUs than ranks: share the pool rather than starve a rank
     assert cpu_share([], {4, 5, 6, 7}, 2, 1) == [6, 7]          # unknown node: even split of what is allowed
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/pcrl_hip.h must compile as plain C (gcc -std=c99 -pedantic, no C++, no HIP headers), and a C
+    program linked against libpcrl_hip.so must be able to call it -- here the host-only entry points (version string, workspace-size and
+    dispatch queries, an argument error with its message); compute calls need a GPU and live in the -m gpu tests."""
+    import shutil
+    import subprocess
+    from pcrlv2_amd import _lib
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    if not os.path.exists(_lib.LIBPATH):
+        import __graft_entry__ as g
+        g.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "pcrl_hip.h"
+int main(void) {
+  const char* v = pcrl_version();
+  if (!v || !strstr(v, "gfx950")) return 1;
+  if (pcrl_conv3d_k3_wgrad_ws_bytes(2, 16, 16, 16, 64, 64) <= 0) return 2;
+  if (pcrl_bn_bwd_partial_rows((int64_t)1 << 22) != 4096) return 3;
+  if (pcrl_prelu_bwd_partial_rows(1000) != 4) return 4;
+  /* an argument error: negative code, message available, nothing thrown across the boundary */
+  int rc = pcrl_prelu_fwd(NULL, NULL, NULL, 16, 3, PCRL_BF16, NULL);
+  if (rc != PCRL_EINVAL || !strlen(pcrl_last_error())) return 5;
+  printf("%s\n", v);
+  return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_lib.LIBPATH)
+    r = subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                        "-L", libdir, "-lpcrl_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and "gfx950" in r.stdout, (r.returncode, r.stdout, r.stderr)
