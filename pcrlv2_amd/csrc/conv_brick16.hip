@@ -45,7 +45,10 @@
 #ifndef B16_ABL
 #define B16_ABL 0   // timing ablations (wrong results): bit 0 no weight staging after the first stage, bit 1 no halo requests after the first chunk,
                     // bit 2 a BatchNorm + ReLU pass over the landed halo in LDS (what applying the PREVIOUS layer's normalisation inside this kernel
-                    // would cost: VERDICT r2 item 3; measured +9..17 % on the layers it would serve, see DESIGN 4.3 -- not built)
+                    // would cost: VERDICT r2 item 3; measured +9..17 % on the layers it would serve, see DESIGN 4.3 -- not built),
+                    // bit 3 the first pass of the NEXT layer's BatchNorm backward in the data gradient's epilogue, its y tile through LDS-DMA into the
+                    // free halo buffer (measured: 64->64 at 64x64x32 +77 us against the 171 us pass it would replace, neutral or worse on every
+                    // smaller layer; ~200 spilled registers in the epilogue as written -- DESIGN 9, not built)
 #endif
 
 namespace {
@@ -448,6 +451,31 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
 #undef LOAD_W
 #undef STORE_W
 
+#if B16_ABL & 8
+  // B16_ABL bit 3 (timing only, wrong statistics): what taking the FIRST PASS OF THE NEXT BatchNorm BACKWARD in this epilogue would cost
+  // (the data gradient's output tile is that layer's da; its y tile comes through LDS-DMA into the free halo buffer, one 16 KiB region
+  // per wave = its d-plane as [voxel][64 channels], and every lane reads its 128 (voxel, channel) elements back as 2-byte LDS reads).
+  int opq = 0;
+  asm volatile("" : "+v"(opq));   // everything below depends on a value defined AFTER the main loop: nothing is hoisted into it
+  if (MODE == 0 && BN == 64) {
+    const char* ysrc = reinterpret_cast<const char*>(p.y) + opq;   // any tensor of the output's shape will do for the timing
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int fmv = i >> 1, wv = ((i & 1) << 3) + (lane >> 3);
+      const int64_t rowv = VOX(n, d0 + wid, h0 + fmv, w0 + wv);
+      lds_dma16(ysrc + ((rowv * p.Nc + n0) << 1) + ((lane & 7) << 4), lds_base + wid * 16384 + i * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  float s3[FN], s4[FN], csc[FN], csh[FN], cmu[FN], crs[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    s3[j] = s4[j] = 0.f;
+    const float* cf = reinterpret_cast<const float*>(p.w) + ((n0 + j * 16 + lr + opq) & 255);
+    csc[j] = cf[0]; csh[j] = cf[256]; cmu[j] = cf[512]; crs[j] = cf[768];
+  }
+#endif
   // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick).  acc[fm][j][r]: voxel (d0 + wid, h0 + fm,
   //      w0 + 4 lg + r), channel n0 + 16 j + lr ----
   float s1[FN], s2[FN], bv[FN];
@@ -478,8 +506,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
         p.y[row * ypitch + (UPCF ? uch0 : n0) + j * 16 + lr] = (bf16)val;
         s1[j] += val;
         s2[j] += val * val;
+#if B16_ABL & 8
+        if (MODE == 0 && BN == 64) {
+          const bf16 yb = *reinterpret_cast<const bf16*>(smem + wid * 16384 + (fm * 16 + lg * 4 + r) * 128 + (j * 16 + lr) * 2);
+          const float yv = (float)yb, g = (csc[j] * yv + csh[j] > 0.f) ? (float)(bf16)val : 0.f;
+          s3[j] += g;
+          s4[j] += g * (yv - cmu[j]) * crs[j];
+        }
+#endif
       }
     }
+#if B16_ABL & 8
+    __builtin_amdgcn_sched_barrier(0);   // keep one h line's LDS reads in flight at a time (hoisting all 128 spills 170 registers)
+#endif
   }
   if (p.stats) {
     // one statistics row per 4-plane half of the brick: row numbering and summation order are those of the 4 x 8 x 16 brick for either NW
@@ -491,6 +530,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
       c2 += __shfl_xor(c2, 16, 64);
       a += __shfl_xor(a, 32, 64);
       c2 += __shfl_xor(c2, 32, 64);
+#if B16_ABL & 8
+      a += s3[j] * 1e-30f;      // keep the ablation's sums alive
+      c2 += s4[j] * 1e-30f;
+#endif
       if (lg == 0) {
         red[(wid * 64 + j * 16 + lr) * 2 + 0] = a;
         red[(wid * 64 + j * 16 + lr) * 2 + 1] = c2;
