@@ -48,7 +48,8 @@
                     // would cost: VERDICT r2 item 3; measured +9..17 % on the layers it would serve, see DESIGN 4.3 -- not built),
                     // bit 3 the first pass of the NEXT layer's BatchNorm backward in the data gradient's epilogue, its y tile through LDS-DMA into the
                     // free halo buffer (measured: 64->64 at 64x64x32 +77 us against the 171 us pass it would replace, neutral or worse on every
-                    // smaller layer; ~200 spilled registers in the epilogue as written -- DESIGN 9, not built)
+                    // smaller layer; ~200 spilled registers in the epilogue as written -- DESIGN 9, not built),
+                    // bit 4 the output tile as coalesced 16-byte stores (upper bound of an LDS-transposed epilogue: -7 % on 32->64, <= 2.6 % elsewhere)
 #endif
 
 namespace {
@@ -503,6 +504,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const float val = acc[fm][j][r] + bv[j];
+#if B16_ABL & 16
+        if (MODE != 0 || BN != 64)   // bit 4 (timing only, wrong output): the plain mode's 64-channel tile is stored below as 16-byte pieces instead
+#endif
         p.y[row * ypitch + (UPCF ? uch0 : n0) + j * 16 + lr] = (bf16)val;
         s1[j] += val;
         s2[j] += val * val;
@@ -518,6 +522,20 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
     }
 #if B16_ABL & 8
     __builtin_amdgcn_sched_barrier(0);   // keep one h line's LDS reads in flight at a time (hoisting all 128 spills 170 registers)
+#endif
+#if B16_ABL & 16
+    // bit 4: the same bytes as 16-byte, fully coalesced stores (what an LDS-transposed epilogue would issue: 16 instead of 128 store
+    // instructions per lane), fed with accumulator bits so that nothing is optimised away -- the upper bound of what such an epilogue can gain
+    if (MODE == 0 && BN == 64) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int i = fm * 2 + q, wv = ((i & 1) << 3) + (lane >> 3);
+        const int64_t rowv = VOX(n, d0 + wid, h0 + fm, w0 + wv);
+        u32x4 o;
+        o.x = __float_as_uint(acc[fm][0][q]); o.y = __float_as_uint(acc[fm][1][q]); o.z = __float_as_uint(acc[fm][2][q + 2]); o.w = __float_as_uint(acc[fm][3][q + 2]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + ((rowv * p.Nc + n0) << 1) + ((lane & 7) << 4)) = o;
+      }
+    }
 #endif
   }
   if (p.stats) {
