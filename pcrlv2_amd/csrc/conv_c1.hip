@@ -404,8 +404,8 @@ int pcrl_pointwise_planes_launch(const void* x, const void* wt, float* z, int64_
 // LDS-halo brick kernel (conv_to1_brick.hip)
 bool pcrl_to1_brick_eligible(int N, int D, int H, int W, int C, int taps, int dtype);
 int64_t pcrl_to1_brick_rows(int N, int D, int H, int W);
-int pcrl_to1_brick_launch(const void* x, const float* w_ref, const float* bias, float* y, float* stats, int N, int D, int H, int W, int C,
-                          hipStream_t stream);
+int pcrl_to1_brick_launch(const void* x, const float* w_ref, const float* bias, float* y, float* stats, void* ws, size_t ws_bytes, int N, int D, int H,
+                          int W, int C, hipStream_t stream);
 
 extern "C" int64_t pcrl_conv3d_to1_stats_rows(int N, int D, int H, int W, int C, int taps, int dtype) {
   if (pcrl_debug_conv_impl() == 0 && pcrl_to1_brick_eligible(N, D, H, W, C, taps, dtype)) return pcrl_to1_brick_rows(N, D, H, W);
@@ -423,7 +423,7 @@ extern "C" int pcrl_conv3d_to1_fwd(const void* x, const float* w_ref, const floa
   if (int e = to1_check("conv3d_to1_fwd", C, taps, dtype)) return e;
   PCRL_REQUIRE(x && w_ref && y, "conv3d_to1_fwd: null pointer");
   if (pcrl_debug_conv_impl() == 0 && pcrl_to1_brick_eligible(N, D, H, W, C, taps, dtype))
-    return pcrl_to1_brick_launch(x, w_ref, bias, y, stats_partial, N, D, H, W, C, as_stream(stream));
+    return pcrl_to1_brick_launch(x, w_ref, bias, y, stats_partial, ws, ws_bytes, N, D, H, W, C, as_stream(stream));
   const Dims g{N, D, H, W};
   const int64_t M = (int64_t)N * D * H * W;
   if (taps == 27 && C % 32 == 0 && M % 4 == 0 && ws && ws_bytes >= pcrl_conv3d_to1_fwd_ws_bytes(N, D, H, W, C, taps)) {
