@@ -1,3 +1,4 @@
+"""Probe of the 1-channel layers: C -> 1 brick forward (deep-supervision heads) and 1 -> Co first layer, HIP-event timing at the C2 shapes."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
@@ -16,3 +17,9 @@ for (N,D,H,W,C) in ((32,64,64,32,64),(32,32,32,16,128),(32,16,16,8,256),(192,16,
     nb=L.call("pcrl_conv3d_to1_fwd_ws_bytes",N,D,H,W,C,27); ws=torch.empty(nb,dtype=torch.uint8,device=dev)
     t=timed(lambda: L.call("pcrl_conv3d_to1_fwd",x,w,b,y,st,ws,nb,N,D,H,W,C,27,dtype_code(dt),stream_handle()))
     print(f"to1 fwd N={N} {D}x{H}x{W} C={C}: {t*1e3:7.1f} us  ({M*C*2/1e9/t:.2f} TB/s of x)")
+for (N,D,H,W,Co) in ((32,64,64,32,32),(192,16,16,16,32)):
+    M=N*D*H*W
+    x=torch.randn(N,1,D,H,W,device=dev); w=torch.randn(Co,1,3,3,3,device=dev)*0.2; b=torch.zeros(Co,device=dev)
+    y=torch.empty(M,Co,device=dev,dtype=dt); rows=L.call("pcrl_conv3d_k3_c1_stats_rows",N,D,H,W,Co,dtype_code(dt)); st=torch.empty(rows*Co*2,device=dev)
+    t=timed(lambda: L.call("pcrl_conv3d_k3_c1_fwd",x,w,b,y,st,N,D,H,W,Co,dtype_code(dt),stream_handle()))
+    print(f"c1 fwd N={N} {D}x{H}x{W} Co={Co}: {t*1e3:7.1f} us  ({M*Co*2/1e9/t:.2f} TB/s of y)")
