@@ -95,8 +95,10 @@ __global__ void c1_fwd_kernel(const float* __restrict__ x, const float* __restri
 // volume); the B operand (taps x 16 channels) is the weight row w_ref[c][8 lg .. 8 lg + 7], contiguous in the reference layout.
 // A wave = one d-plane of the brick (4 fragments of 16 voxels).  x and w enter the MFMA rounded to bf16 (like every other
 // convolution in bf16 mode); bias, the bf16 store and the BatchNorm partials (one row per brick) come from the float sums.
+// six blocks per CU for the narrow forms (<= 80 registers): the kernel is a chain of latencies per block -- stage, im2col, MFMA, store -- (130 -> 116 us
+// at 64x64x32 with the batched halo loads; eight blocks per CU spill: 273 us)
 template <int CO>
-__global__ void __launch_bounds__(256) c1_brick_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_ref,
+__global__ void __launch_bounds__(256, CO <= 32 ? 6 : 1) c1_brick_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_ref,
                                                            const float* __restrict__ bias, bf16* __restrict__ y,
                                                            float* __restrict__ stats, Dims g) {
   constexpr int FN = CO / 16;
@@ -111,12 +113,22 @@ __global__ void __launch_bounds__(256) c1_brick_fwd_kernel(const float* __restri
   const int d0 = (b % bd) * 4; b /= bd;
   const int n = b;
   const int64_t base0 = (((int64_t)n * g.D + d0) * g.H + h0) * g.W + w0;
-  for (int q = tid; q < 600; q += 256) {
-    const int hd = q / 100, hh = (q / 10) % 10, hw = q % 10;
-    const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
-    const bool ok = (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-    const float v = x[ok ? (((int64_t)n * g.D + d) * g.H + h) * g.W + w : base0];
-    sh[q] = ok ? v : 0.f;
+  // halo staging: the (up to) three loads of a thread are issued together, then stored (one global-memory latency per block instead of
+  // three: by ablation the staging was 59 of the kernel's 130 us at 64x64x32)
+  {
+    float hv[3];
+    bool hok[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int q = tid + 256 * i;
+      const int hd = q / 100, hh = (q / 10) % 10, hw = q % 10;
+      const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
+      hok[i] = q < 600 && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+      hv[i] = x[hok[i] ? (((int64_t)n * g.D + d) * g.H + h) * g.W + w : base0];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (tid + 256 * i < 600) sh[tid + 256 * i] = hok[i] ? hv[i] : 0.f;
   }
   // weights: fragment j, lane (lr = channel, lg = taps 8 lg .. 8 lg + 7)
   bf16x8 fb[FN];
