@@ -240,9 +240,11 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[k][j] = 0.f;
   // a row (or a run of rows) of one h class: columns 1 .. FW - 2 over the slots, the two border columns by slot 0
-#define ROWS(h0_, h1_, K_)                                                                      \
-  for (int h = (h0_); h < (h1_); ++h) {                                                         \
-    const T* row = base + (int64_t)h * FW * C;                                                  \
+  /* four rows in flight per thread (eight measured no better): the two border planes of a sample read every voxel -- 62 rows of ONE load each were a chain of 62   */
+  /* memory latencies per thread, and those 2 N blocks set the kernel's duration (110-130 us at up_tr64 for 12 % of a 537 MB tensor).     */
+#define ROW1(h_, K_)                                                                            \
+  {                                                                                             \
+    const T* row = base + (int64_t)(h_) * FW * C;                                               \
     for (int w = 1 + slot; w < FW - 1; w += nslots) {                                           \
       const Vec16<T> v = ld16(row + (int64_t)w * C);                                            \
       _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[(K_)*3 + 1][j] += to_f(v.v[j]);       \
@@ -254,6 +256,34 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
         acc[(K_)*3 + 2][j] += to_f(v1.v[j]);                                                    \
       }                                                                                         \
     }                                                                                           \
+  }
+#define ROWS(h0_, h1_, K_)                                                                      \
+  {                                                                                             \
+    int h = (h0_);                                                                              \
+    for (; h + 3 < (h1_); h += 4) {                                                             \
+      const T* row = base + (int64_t)h * FW * C;                                                \
+      for (int w = 1 + slot; w < FW - 1; w += nslots) {                                         \
+        Vec16<T> v[4];                                                                          \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) v[u] = ld16(row + ((int64_t)u * FW + w) * C); \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+          _Pragma("unroll") for (int j = 0; j < VEC; ++j) acc[(K_)*3 + 1][j] += to_f(v[u].v[j]); \
+        }                                                                                       \
+      }                                                                                         \
+      if (slot == 0) {                                                                          \
+        Vec16<T> v0[4], v1[4];                                                                  \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+          v0[u] = ld16(row + (int64_t)u * FW * C);                                              \
+          v1[u] = ld16(row + ((int64_t)u * FW + FW - 1) * C);                                   \
+        }                                                                                       \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                         \
+          _Pragma("unroll") for (int j = 0; j < VEC; ++j) {                                     \
+            acc[(K_)*3 + 0][j] += to_f(v0[u].v[j]);                                             \
+            acc[(K_)*3 + 2][j] += to_f(v1[u].v[j]);                                             \
+          }                                                                                     \
+        }                                                                                       \
+      }                                                                                         \
+    }                                                                                           \
+    for (; h < (h1_); ++h) ROW1(h, K_)                                                          \
   }
   // zsum: dy sums to zero over all voxels per channel (it is the output of a training-mode BatchNorm backward over exactly these voxels), so the
   // fully interior class is minus the sum of the other 26 (upc_box_kernel) and a plane inside the volume only contributes its border: two
@@ -277,6 +307,26 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
     ROWS(FH - 1, FH, 2)
   }
 #undef ROWS
+#undef ROW1
+  if (nvec <= 64) {
+    // The slots of a wave are lanes nvec apart: a fixed xor tree inside the wave, then the four waves through LDS -- one barrier instead of
+    // the eighteen of the class-by-class reduction below (which was most of this kernel: a plane inside the volume reads 9 % of its voxels).
+    const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float a = acc[q][j];
+        for (int o = nvec; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+        if (ln < nvec) sm[(wv * 9 + q) * C + cv * VEC + j] = a;
+      }
+    __syncthreads();
+    for (int i = tid; i < 9 * C; i += 256) {
+      const int q = i / C, c = i - q * C;
+      part[((int64_t)blockIdx.x * 9 + q) * C + c] = (sm[q * C + c] + sm[(9 + q) * C + c]) + (sm[(18 + q) * C + c] + sm[(27 + q) * C + c]);
+    }
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
     __syncthreads();
@@ -293,17 +343,22 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
 // S[cls][co] = sum over the planes of class cd of part[plane][ch*3+cw][co]   (planes = N * FD, plane = n * FD + fd).
 // Block = (k9, 64 channels) x cd: 16 groups of 64 lanes walk the class's planes four at a time (the plane count reaches thousands: a
 // single chain of dependent loads took 320 us), combined in group order through LDS.
+// blockIdx.z = chunk of the class's planes (UPC_TOTAL_CHUNKS of them; upc_box_kernel adds the chunks in order): 27 blocks walked up to
+// 1 984 planes each (51 us at up_tr64).
+constexpr int UPC_TOTAL_CHUNKS = 8;
 __global__ void __launch_bounds__(1024) upc_class_total_kernel(const float* __restrict__ part, float* __restrict__ S, int N, int FD, int C) {
   __shared__ double red[16][64];
   const int cb = C / 64 > 0 ? (C + 63) / 64 : 1;
   const int k9 = blockIdx.x / cb, co = (blockIdx.x % cb) * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6, cd = blockIdx.y;
   const int f0 = cd == 0 ? 0 : (cd == 2 ? FD - 1 : 1), f1 = cd == 0 ? 1 : (cd == 2 ? FD : FD - 1);
   const int nf = f1 > f0 ? f1 - f0 : 0;
-  const int64_t cnt = (int64_t)N * nf;
+  const int64_t all = (int64_t)N * nf;
+  const int64_t jb = all * blockIdx.z / UPC_TOTAL_CHUNKS, cnt = all * (blockIdx.z + 1) / UPC_TOTAL_CHUNKS;
+  S += (int64_t)blockIdx.z * 27 * C;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   if (co < C) {
     auto at = [&](int64_t j) { return (double)part[((((j / nf) * FD) + f0 + (j % nf)) * 9 + k9) * C + co]; };
-    int64_t j = g;
+    int64_t j = jb + g;
     for (; j + 48 < cnt; j += 64) { a0 += at(j); a1 += at(j + 16); a2 += at(j + 32); a3 += at(j + 48); }
     for (; j < cnt; j += 16) a0 += at(j);
   }
@@ -314,6 +369,15 @@ __global__ void __launch_bounds__(1024) upc_class_total_kernel(const float* __re
     for (int k = 0; k < 16; ++k) v += red[k][threadIdx.x];
     S[(cd * 9 + k9) * C + co] = (float)v;
   }
+}
+// S[i] = sum over the plane chunks of Sk[k][i], in chunk order (i < 27 * C)
+__global__ void __launch_bounds__(256) upc_chunk_sum_kernel(const float* __restrict__ Sk, float* __restrict__ S, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double v = 0.0;
+#pragma unroll
+  for (int k = 0; k < UPC_TOTAL_CHUNKS; ++k) v += (double)Sk[(int64_t)k * n + i];
+  S[i] = (float)v;
 }
 // box[t][co] = sum over the classes for which tap t is inside the grid of S[cls][co]
 __global__ void __launch_bounds__(256) upc_box_kernel(const float* __restrict__ S, float* __restrict__ box, int Co, bool accumulate, bool zsum) {
@@ -476,7 +540,7 @@ static size_t acc_wg_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype
 }
 extern "C" size_t pcrl_upconv_wgrad_accum_ws_bytes(int N, int D, int H, int W, int Ci, int Co, int dtype) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
-  return al(acc_wg_bytes(N, D, H, W, Ci, Co, dtype)) + al((size_t)N * 2 * D * 9 * Co * sizeof(float)) + al((size_t)27 * Co * sizeof(float));
+  return al(acc_wg_bytes(N, D, H, W, Ci, Co, dtype)) + al((size_t)N * 2 * D * 9 * Co * sizeof(float)) + al((size_t)9 * 27 * Co * sizeof(float));   // [27][Co] + UPC_TOTAL_CHUNKS (8) chunk copies
 }
 // dweff_acc: float32 [Co][Ci][64]; box_acc: float32 [27][Co]; first != 0: store, else add.  The gradient of the composed weights comes from the
 // brick weight-gradient kernel where it tiles the coarse grid (pcrl_upconv_wgrad_uses_brick() != 0), else from the gather kernel: same layout.
@@ -497,12 +561,15 @@ extern "C" int pcrl_upconv_wgrad_accum(const void* x, const void* dy0, float* dw
   }
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
   if (Co % vec != 0 || (Co / vec) > 256 || 256 % (Co / vec) != 0) return pcrl_fail(PCRL_EINVAL, "upconv_wgrad_accum: Co=%d not supported by the class-sum kernel", Co);
-  const size_t lds = (size_t)(256 / (Co / vec)) * Co * sizeof(float);
+  const size_t lds_old = (size_t)(256 / (Co / vec)) * Co * sizeof(float), lds_new = (size_t)36 * Co * sizeof(float);
+  const size_t lds = (Co / vec) <= 64 ? (lds_new > lds_old ? lds_new : lds_old) : lds_old;
   float* part = (float*)(w + wgb);
   float* S = (float*)(w + wgb + al((size_t)N * 2 * D * 9 * Co * sizeof(float)));
   if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_class_sums_kernel<bf16>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const bf16*)dy0, part, 2 * D, 2 * H, 2 * W, Co, zsum);
   else hipLaunchKernelGGL(upc_class_sums_kernel<float>, dim3((unsigned)(N * 2 * D)), dim3(256), lds, st, (const float*)dy0, part, 2 * D, 2 * H, 2 * W, Co, zsum);
-  hipLaunchKernelGGL(upc_class_total_kernel, dim3((unsigned)(9 * ((Co + 63) / 64)), 3), dim3(1024), 0, st, (const float*)part, S, N, 2 * D, Co);
+  float* Sk = S + 27 * Co;   // [UPC_TOTAL_CHUNKS][27][Co] behind the combined [27][Co]
+  hipLaunchKernelGGL(upc_class_total_kernel, dim3((unsigned)(9 * ((Co + 63) / 64)), 3, UPC_TOTAL_CHUNKS), dim3(1024), 0, st, (const float*)part, Sk, N, 2 * D, Co);
+  hipLaunchKernelGGL(upc_chunk_sum_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)Sk, S, 27 * Co);
   hipLaunchKernelGGL(upc_box_kernel, dim3((27 * Co + 255) / 256), dim3(256), 0, st, (const float*)S, box_acc, Co, first == 0, zsum);
   return pcrl_check_launch("upconv_wgrad_accum");
 }
