@@ -156,3 +156,8 @@ EMPTY_CACHE_PER_EPOCH = os.environ.get("PCRL_EMPTY_CACHE_PER_EPOCH", "0") == "1"
 # of the layer below then run with nothing beside them; queued second, the side stream's wait covers the data gradient, and the weight
 # gradient runs next to those HBM-bound passes.  Same kernels, same results (bit-identical).  PCRL_WGRAD_AFTER_DGRAD=1: on.
 WGRAD_AFTER_DGRAD = os.environ.get("PCRL_WGRAD_AFTER_DGRAD", "0") == "1"
+
+# Experiment (measured, no gain, default off): weight gradients of the 1-output-channel layers (OutputTransition, the deep-supervision heads) on
+# the side stream like every other weight gradient instead of inline on the data-gradient chain, at whose head OutputTransition's column sums
+# are ~100 us.  Same box, 4 interleaved runs: 31.70 (inline) vs 31.80 ms.  PCRL_TO1_WGRAD_SIDE=1: on (bit-identical).
+TO1_WGRAD_SIDE = os.environ.get("PCRL_TO1_WGRAD_SIDE", "0") == "1"

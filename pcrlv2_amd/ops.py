@@ -875,7 +875,11 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
             dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, 1, sv.act, torch.float32)
         nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, Ci, 27)
         dbias_unused = _f32(1, dev)
-        L.call("pcrl_conv3d_to1_wgrad", sv.x, dy, dw, dbias_unused, workspace(nb, dev), nb, N, D, H, W, Ci, 27, dtype_code(dtype), s)
+        if config.TO1_WGRAD_SIDE:      # like every other weight gradient: off the data-gradient chain (the side stream is idle this early in the backward)
+            with side_wgrad(dev, sv.x, dy) as ws:
+                L.call("pcrl_conv3d_to1_wgrad", sv.x, dy, dw, dbias_unused, ws(nb), nb, N, D, H, W, Ci, 27, dtype_code(dtype), stream_handle())
+        else:
+            L.call("pcrl_conv3d_to1_wgrad", sv.x, dy, dw, dbias_unused, workspace(nb, dev), nb, N, D, H, W, Ci, 27, dtype_code(dtype), s)
         dx = None
         if need_dx:
             dx = new_act(N, D, H, W, Ci, dtype, dev)
@@ -1285,7 +1289,11 @@ def conv1x1_to1_backward(x, out, dout, w, dtype, need_dx=True):
     dw = torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format)
     db = _f32(1, dev)
     nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, C, 1)
-    L.call("pcrl_conv3d_to1_wgrad", x, dpre, dw, db, workspace(nb, dev), nb, N, D, H, W, C, 1, dtype_code(dtype), s)
+    if config.TO1_WGRAD_SIDE:          # 145 us of column sums over the full-resolution activation, at the very head of the backward's chain
+        with side_wgrad(dev, x, dpre) as ws:
+            L.call("pcrl_conv3d_to1_wgrad", x, dpre, dw, db, ws(nb), nb, N, D, H, W, C, 1, dtype_code(dtype), stream_handle())
+    else:
+        L.call("pcrl_conv3d_to1_wgrad", x, dpre, dw, db, workspace(nb, dev), nb, N, D, H, W, C, 1, dtype_code(dtype), s)
     dx = None
     if need_dx:
         dx = torch.empty_like(x)
