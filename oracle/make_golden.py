@@ -219,6 +219,103 @@ def make_case(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=3, base_l
     print(f"[{tag}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB, {len(fx)} arrays)")
 
 
+def make_dp(tag, b_rank, dhw, nsteps, world, refmod, ref_train, ref_utils, epoch=3, base_lr=1e-3, epochs=240, seed=0):
+    """The reference's multi-GPU semantics -- `nn.DataParallel(model)` (train_3d.py:54) -- run on the REAL model, on CPU: replica 0 is
+    the module itself (its BatchNorm buffers persist), replicas r >= 1 are `torch.func.functional_call`s of the same module with the SAME
+    parameter tensors and throw-away copies of the buffers (what `replicate` builds on every forward call); every replica normalises with
+    its own batch statistics; the losses of train_3d.py:119-138 are means over the gathered batch (= the mean of the replicas' losses for
+    equal chunks) with ONE scale draw per cos_loss call; one backward sums the replicas' gradients into the shared parameters; one SGD step.
+    The local views are partitioned by sample (see oracle.train_steps_data_parallel).  Asserts the oracle's restatement equal, writes
+    tests/golden/<tag>.npz: per-replica losses of every step, the gradient of step 0, the parameters and replica 0's buffers after `nsteps`."""
+    from torch.func import functional_call
+    torch.set_num_threads(8)
+    dt = torch.float64
+    st0 = O.fill_state(dt)
+    rank_batches = [[O.fill_batch(b_rank, dhw, dtype=dt, seed=7 + 100 * s + 1000 * r) for r in range(world)] for s in range(nsteps)]
+    model = refmod.PCRLv23d().double()
+    model.load_state_dict(st0, strict=True)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=1e-4)
+
+    class A:
+        pass
+    A.lr, A.epochs = base_lr, epochs
+    ref_utils.adjust_learning_rate(epoch, A, opt)
+    criterion, cosine = torch.nn.MSELoss(), torch.nn.CosineSimilarity()
+    params = dict(model.named_parameters())
+
+    def replica(r):
+        if r == 0:
+            return model
+        def call(x, local=False):
+            bufs = {k: v.clone() for k, v in model.named_buffers()}      # replicate(): copies of the buffers as they are at this forward call
+            return functional_call(model, {**params, **bufs}, (x,), {"local": local})
+        return call
+
+    random.seed(seed)
+    ref_log, ref_first_grads = [], None
+    with torch.backends.mkldnn.flags(enabled=False):
+        for s in range(nsteps):
+            draws = random.getstate()
+            total, entry = 0.0, []
+            for r in range(world):
+                random.setstate(draws)               # one draw per cos_loss call, for the whole gathered batch
+                res = reference_step(replica(r), ref_train, rank_batches[s][r], epoch, criterion, cosine)
+                total = total + res["loss"] / world
+                entry.append({k: float(res[k].detach()) for k in ("loss", "loss1", "loss2", "loss4", "local_loss")} | {"index2": res["index2"]})
+            opt.zero_grad()
+            total.backward()
+            if s == 0:
+                ref_first_grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in model.named_parameters()}
+            opt.step()
+            ref_log.append(entry)
+    ref_final = {k: v.detach().clone() for k, v in model.state_dict().items()}
+
+    with torch.backends.mkldnn.flags(enabled=False):
+        st_fin, _mom, log, g0 = O.train_steps_data_parallel(st0, rank_batches, epoch, base_lr, epochs, seed)
+    for s in range(nsteps):
+        for r in range(world):
+            for k in ("loss", "loss1", "loss2", "loss4", "local_loss"):
+                assert abs(log[s][r][k] - ref_log[s][r][k]) < 1e-10, (s, r, k, log[s][r][k], ref_log[s][r][k])
+            assert log[s][r]["index2"] == ref_log[s][r]["index2"]
+    for k, g in ref_first_grads.items():
+        assert (g is None) == (g0[k] is None), f"grad None-ness differs for {k}"
+        if g is not None:
+            assert (g - g0[k]).abs().max().item() <= 1e-9 * g.abs().max().item() + 1e-11, f"grad {k}"
+    for k, v in ref_final.items():
+        close(st_fin[k].double(), v.double(), 1e-9, "final " + k)
+    # the exchange matters: a single replica on replica 0's batches ends elsewhere
+    with torch.backends.mkldnn.flags(enabled=False):
+        st_single, *_ = O.train_steps(st0, [rb[0] for rb in rank_batches], epoch, base_lr, epochs, seed)
+    k_big = "up_tr64.ops.1.conv1.weight"
+    assert (st_single[k_big] - st_fin[k_big]).abs().max().item() > 1e-6
+    print(f"[{tag}] oracle (DataParallel semantics, world {world}) == reference; losses {ref_log}")
+
+    fx = OrderedDict()
+    fx["meta/b_rank"], fx["meta/dhw"], fx["meta/nsteps"], fx["meta/world"] = np.int64(b_rank), np.array(dhw), np.int64(nsteps), np.int64(world)
+    fx["meta/epoch"], fx["meta/base_lr"], fx["meta/epochs"], fx["meta/seed"] = np.int64(epoch), np.float64(base_lr), np.int64(epochs), np.int64(seed)
+    fx["meta/lr"] = np.float64(opt.param_groups[0]["lr"])
+    for s, entry in enumerate(ref_log):
+        for r, l in enumerate(entry):
+            for k, v in l.items():
+                fx[f"step{s}/rank{r}/{k}"] = np.float64(v)
+    for name, g in ref_first_grads.items():
+        if g is None:
+            fx[f"grad/{name}/none"] = np.int64(1)
+            continue
+        for k, v in summarize(g, 64).items():
+            fx[f"grad/{name}/{k}"] = v
+    for name, v in ref_final.items():
+        if O.is_buffer(name):
+            fx[f"final_buf/{name}"] = v.double().numpy().copy()
+            continue
+        for k, vv in summarize(v, 64).items():
+            fx[f"final/{name}/{k}"] = vv
+    path = os.path.join(OUT, f"{tag}.npz")
+    np.savez_compressed(path, **fx)
+    print(f"[{tag}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB, {len(fx)} arrays)")
+
+
 def make_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, base_lr=1e-3, epochs=240, seed=5):
     """Loss curve of the REAL reference (float64, oneDNN off) over `nsteps` SGD steps on correlated synthetic views:
     the fixture behind the "loss curve within 1e-3" test (SURVEY App. C scopes what can be asserted)."""
@@ -479,6 +576,10 @@ def main():
     if "--variants" in sys.argv:
         for tag, kw in VARIANTS.items():
             make_variant(tag, refmod, **kw)
+        return
+    if "--data-parallel" in sys.argv:
+        # nn.DataParallel semantics (train_3d.py:54) on two replicas of b = 4
+        make_dp("dp2_b4x2_32x32x16", 4, (32, 32, 16), 2, 2, refmod, ref_train, ref_utils)
         return
     if "--forward-only" in sys.argv:
         # the exact BASELINE batches (C2, C4), forward-only (float64 backward does not fit at these sizes)

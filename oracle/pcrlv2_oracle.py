@@ -394,3 +394,48 @@ def train_steps(st, batches, epoch=0, base_lr=1e-3, epochs=240, seed=0, momentum
         st.update(new_bufs)
         log.append({k: float(r[k].detach()) for k in ("loss", "loss1", "loss2", "loss4", "local_loss")} | {"index2": r["index2"]})
     return st, mom, log, first_grads
+
+
+def train_steps_data_parallel(st, rank_batches, epoch=0, base_lr=1e-3, epochs=240, seed=0, momentum=0.9, weight_decay=1e-4):
+    """k iterations under the reference's `nn.DataParallel` (train_3d.py:54), restated for `world` replicas.
+
+    rank_batches[s][r] = the batch of replica r in iteration s (DataParallel scatters the global batch along dim 0, one chunk per
+    replica).  Semantics followed (torch.nn.parallel.DataParallel as train_3d.py:54 uses it):
+      * every replica runs the whole module on its chunk with the SAME parameters -- BatchNorm3d / BatchNorm1d statistics are
+        per replica (pcrlv2_model_3d.py:12,55,57 in train mode);
+      * replica 0 is the module itself: only ITS running statistics persist (`replicate` hands device 0 the original buffers);
+      * the outputs are gathered and the losses (train_3d.py:119-138) are means over the gathered global batch -- with equal chunks
+        the mean of the replicas' losses; the scales are drawn ONCE per cos_loss call for the whole batch (every replica sees the
+        same draw);
+      * one backward, gradients of all replicas summed into the one parameter set, one SGD step (train_3d.py:143-151).
+    One deliberate difference, stated in DESIGN.md: the local views are partitioned BY SAMPLE (each replica holds all six local
+    views of its own crops, as one-process-per-GPU loaders deliver them), not by chunks of the concatenated [6b] tensor.
+    Returns (final state with replica 0's buffers, momentum, per-step list of per-replica loss dicts, gradients of the first step)."""
+    rng = random.Random(seed)
+    st = OrderedDict((k, v.clone()) for k, v in st.items())
+    mom, log, first_grads = {}, [], None
+    lr = lr_at(epoch, base_lr, epochs)
+    for per_rank in rank_batches:
+        pnames = [k for k in st if not is_buffer(k)]
+        for k in pnames:
+            st[k] = st[k].detach().requires_grad_(True)
+        draws = rng.getstate()
+        total, bufs0, entry = 0.0, None, []
+        for r, batch in enumerate(per_rank):
+            rng.setstate(draws)                     # one draw per cos_loss call for the whole gathered batch
+            new_bufs = {}
+            res = step_losses(st, batch, epoch, rng, new_bufs)
+            total = total + res["loss"] / len(per_rank)
+            entry.append({k: float(res[k].detach()) for k in ("loss", "loss1", "loss2", "loss4", "local_loss")} | {"index2": res["index2"]})
+            if r == 0:
+                bufs0 = new_bufs
+        gl = torch.autograd.grad(total, [st[k] for k in pnames], allow_unused=True)
+        grads = dict(zip(pnames, gl))
+        if first_grads is None:
+            first_grads = {k: (None if g is None else g.detach().clone()) for k, g in grads.items()}
+        for k in pnames:
+            st[k] = st[k].detach()
+        st, mom = sgd_step(st, grads, mom, lr, momentum, weight_decay)
+        st.update(bufs0)
+        log.append(entry)
+    return st, mom, log, first_grads

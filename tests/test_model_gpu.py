@@ -856,6 +856,75 @@ def test_data_parallel_two_ranks_one_gpu_gloo(tmp_path):
     assert all("OK" in o for o in outs)
 
 
+DDP_ORACLE_WORKER = r"""
+import os, sys, random, numpy as np, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "oracle"))
+import pcrlv2_oracle as O
+from make_golden import sample_idx
+from pcrlv2_amd import ddp
+from pcrlv2_amd.models import PCRLv23d
+from pcrlv2_amd.optim import FusedSGD
+from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step
+rank, world, _ = ddp.init_process_group_from_env("gloo")     # two processes, ONE GPU: gloo moves the CUDA buffers
+torch.cuda.set_device(0)
+fx = np.load(os.path.join(root, "tests", "golden", "dp2_b4x2_32x32x16.npz"))
+b, dhw, nsteps = int(fx["meta/b_rank"]), tuple(int(v) for v in fx["meta/dhw"]), int(fx["meta/nsteps"])
+assert world == int(fx["meta/world"])
+overlap = os.environ.get("TEST_OVERLAP", "0") == "1"
+random.seed(int(fx["meta/seed"]))        # every rank draws the scales of the ONE global cos_loss call sequence
+model = PCRLv23d().cuda()
+model.load_state_dict(O.fill_state(torch.float32))
+model.train().set_compute_dtype(torch.float32)
+opt = FusedSGD(model.parameters(), lr=float(fx["meta/lr"]), momentum=0.9, weight_decay=1e-4)
+dp = ddp.DataParallel(model, opt, bucket_mb=8.0, overlap=overlap)
+assert dp._active and opt.grad_scale == 1.0 / world
+for s in range(nsteps):
+    batch = O.fill_batch(b, dhw, dtype=torch.float32, seed=7 + 100 * s + 1000 * rank)       # make_golden.make_dp's rank batches
+    out = train_step(model, opt, batch, int(fx["meta/epoch"]), MSELoss(), CosineSimilarityMean())
+    for k, v in zip(("loss", "loss1", "loss2", "loss4", "local_loss"), out):
+        tol = 2e-5 if (s == 0 or k in ("loss1", "loss4")) else 5e-4
+        d = abs(float(v) - float(fx[f"step{s}/rank{rank}/{k}"]))
+        assert d < tol, (rank, s, k, float(v), float(fx[f"step{s}/rank{rank}/{k}"]))
+worst = 0.0
+for name, p in model.named_parameters():
+    f = p.detach().double().cpu().reshape(-1).numpy()
+    d = np.abs(f[sample_idx(f.size, 64, 3)] - fx[f"final/{name}/samples"]).max()
+    worst = max(worst, d)
+    assert d < 5e-5, (rank, name, d)
+if rank == 0:        # replica 0's running statistics are the ones that persist under nn.DataParallel
+    model.flush_counters()
+    sd = model.state_dict()
+    for name in sd:
+        if O.is_buffer(name):
+            np.testing.assert_allclose(sd[name].double().cpu().numpy(), fx[f"final_buf/{name}"], rtol=2e-5, atol=2e-6, err_msg=name)
+dist.barrier()
+print("OK", rank, "worst parameter |d| after %d data-parallel steps = %.2e" % (nsteps, worst), flush=True)
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_data_parallel_two_ranks_match_the_reference_dataparallel_oracle(tmp_path, overlap):
+    """a14 PINNED: two ranks (gloo, both on cuda:0, float32, b = 4 per rank, two iterations) against tests/golden/dp2_b4x2_32x32x16.npz --
+    the REAL reference model run with nn.DataParallel's semantics (train_3d.py:54,116-138: per-replica BatchNorm statistics, losses over
+    the gathered batch, replicas' gradients summed, one SGD step; oracle/make_golden.py::make_dp).  Every rank's losses of both
+    iterations, every parameter after the second update (5e-5, the single-process two-step tolerance) and rank 0's running statistics."""
+    import subprocess
+    import sys
+    script = tmp_path / "ddp_oracle.py"
+    script.write_text(DDP_ORACLE_WORKER)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29771" if overlap else "29769", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TEST_OVERLAP="1" if overlap else "0")
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert all("OK" in o for o in outs)
+    print("\n".join(l for o in outs for l in o.splitlines() if l.startswith("OK")))
+
+
 # ---- bf16 engine against the ROUNDING-AWARE comparator (oracle/pcrlv2_bf16_emulation.py) ----------------------------------------------
 # The float64 golden differs from a bf16 step by what the roundings do to it; the comparator is the same float64 algorithm WITH the engine's
 # roundings (weights, stored activations, stored gradients, composed weights), so what is left is float32-vs-float64 accumulation -- and any
