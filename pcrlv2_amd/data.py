@@ -102,17 +102,39 @@ def draw_spatial(gen, B, device, p_flip=0.5, scales=0.1, degrees=10.0):
     return flip, inv
 
 
-_host_rngs: dict = {}
+_host_rngs: "collections.OrderedDict" = None      # id(generator) -> (generator, random.Random); the entry HOLDS the generator
+_HOST_RNG_CAP = 64
 
 
 def _host_rng_of(gen):
     """The host-side companion of a device generator (seeded from it once): scalars the kernels take BY VALUE -- the noise seed -- are drawn
-    here, never read back from the device (an .item() between two training steps makes the host wait for the whole previous step)."""
+    here, never read back from the device (an .item() between two training steps makes the host wait for the whole previous step).
+    torch.Generator takes neither attributes nor weak references, so the table is keyed by id() and every entry keeps a strong reference to
+    its generator: an id can then never be recycled for another generator while its entry lives (a stale entry would hand a NEW generator
+    the old stream); the table is an LRU of 64 entries.  The companion's state is part of the augmentation stream: checkpoint it with
+    the generator's own state (`host_rng_state` / `set_host_rng_state`)."""
+    import collections
     import random
-    r = _host_rngs.get(id(gen))
-    if r is None:
-        r = _host_rngs[id(gen)] = random.Random(gen.initial_seed())
-    return r
+    global _host_rngs
+    if _host_rngs is None:
+        _host_rngs = collections.OrderedDict()
+    ent = _host_rngs.get(id(gen))
+    if ent is None or ent[0] is not gen:
+        ent = _host_rngs[id(gen)] = (gen, random.Random(gen.initial_seed()))
+        while len(_host_rngs) > _HOST_RNG_CAP:
+            _host_rngs.popitem(last=False)
+    else:
+        _host_rngs.move_to_end(id(gen))
+    return ent[1]
+
+
+def host_rng_state(gen):
+    """State of the generator's host companion (see _host_rng_of) -- save it next to `gen.get_state()` to reproduce an augmentation stream."""
+    return _host_rng_of(gen).getstate()
+
+
+def set_host_rng_state(gen, state):
+    _host_rng_of(gen).setstate(state)
 
 
 def draw_intensity(gen, B, device, max_blur=2.0, max_noise=0.25, log_gamma=0.3, host_rng=None):

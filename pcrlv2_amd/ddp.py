@@ -39,7 +39,8 @@ def init_process_group_from_env(backend: str | None = None):
         torch.cuda.set_device(local)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if world > 1:
-        bind_rank_to_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), verbose=os.environ.get("PCRL_BIND_VERBOSE", "0") == "1")
+        bind_rank_to_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), verbose=os.environ.get("PCRL_BIND_VERBOSE", "0") == "1",
+                          exchange=True)
     return rank, world, local
 
 
@@ -73,26 +74,47 @@ def _gpu_numa_node(index: int):
         return -1
 
 
-def bind_rank_to_numa(local_rank: int, local_world: int, verbose: bool = False):
+def bind_rank_to_numa(local_rank: int, local_world: int, verbose: bool = False, exchange: bool = False):
     """Pin this rank's host threads to CPUs of its GPU's NUMA node (at < 1 ms of communication per ~33 ms step the >= 6x target
     at 8 GPUs is bounded by host-side launch jitter, not by xGMI: eight launcher threads migrating across two sockets is that jitter).
-    PCRL_BIND_CPUS=0 turns it off.  -> the CPU list, or None when nothing was done."""
+    The node is that of the device this process has made CURRENT (`torch.cuda.current_device()` after `set_device`: correct under
+    HIP_VISIBLE_DEVICES remapping, where local device index != local rank); with `exchange` (a process group is up) the ranks tell each
+    other (host, node) so that ranks sharing a node split its CPUs -- without it the split assumes device i belongs to local rank i.
+    Side effects, logged ONCE on rank 0 (stderr): the process-wide affinity mask is narrowed -- DataLoader workers forked later inherit it
+    (a rank's share is node CPUs / ranks on the node, e.g. 32 of 128: `--workers` beyond that share time-slice) -- and
+    `torch.set_num_threads(<= 8)`.  PCRL_BIND_CPUS=0 turns the binding off.  -> the CPU list, or None when nothing was done."""
     if os.environ.get("PCRL_BIND_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
     try:
+        import socket
         allowed = os.sched_getaffinity(0)
-        nodes = [_gpu_numa_node(i) for i in range(local_world)] if torch.cuda.is_available() and torch.cuda.device_count() >= local_world else [-1] * local_world
-        node = nodes[local_rank]
-        peers = [r for r in range(local_world) if nodes[r] == node]
+        cuda = torch.cuda.is_available()
+        node = _gpu_numa_node(torch.cuda.current_device()) if cuda else -1
+        how = "current device"
+        if exchange and dist.is_available() and dist.is_initialized():
+            table = [None] * dist.get_world_size()
+            dist.all_gather_object(table, (socket.gethostname(), node, dist.get_rank()))
+            mates = sorted(r for (h, n, r) in table if h == socket.gethostname() and n == node)
+            peers, slot = len(mates), mates.index(dist.get_rank())
+        else:
+            nodes = [_gpu_numa_node(i) for i in range(local_world)] if cuda and torch.cuda.device_count() >= local_world else [-1] * local_world
+            if not cuda:
+                node = nodes[local_rank]
+            mates = [r for r in range(local_world) if nodes[r] == node] or [local_rank]
+            peers, slot = len(mates), (mates.index(local_rank) if local_rank in mates else 0)
+            how = "device index = local rank assumed for the peers"
         node_cpus = sorted(allowed)
         if node >= 0:
             with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
                 node_cpus = parse_cpulist(f.read())
-        mine = cpu_share(node_cpus, allowed, len(peers), peers.index(local_rank))
+        mine = cpu_share(node_cpus, allowed, peers, slot)
         os.sched_setaffinity(0, mine)
         torch.set_num_threads(max(1, min(8, len(mine))))
-        if verbose:
-            print(f"[pcrlv2_amd.ddp] local rank {local_rank}: GPU NUMA node {node}, {len(mine)} CPUs ({mine[0]}..{mine[-1]})", flush=True)
+        if verbose or (dist.is_available() and dist.is_initialized() and dist.get_rank() == 0):
+            import sys
+            print(f"[pcrlv2_amd.ddp] rank binding on ({how}): local rank {local_rank} -> GPU NUMA node {node}, {len(mine)} CPUs "
+                  f"({mine[0]}..{mine[-1]}), {torch.get_num_threads()} torch threads; DataLoader workers inherit this mask; PCRL_BIND_CPUS=0 disables",
+                  file=sys.stderr, flush=True)
         return mine
     except Exception as e:      # binding is an optimisation, never a reason to fail a run
         if verbose:
@@ -177,18 +199,30 @@ class DataParallel:
         self.strict_flags = strict_flags
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._active = self.world > 1 or (force_collectives and dist.is_initialized())   # 1-rank groups: test hook only
-        sizes = list(getattr(optimizer, "_slot_sizes", None) or [p.numel() for p in optimizer._plist])   # arena slots (FusedSGD pads to 16 bytes)
-        self.reducer = BucketedAllReduce(optimizer.flat_g, sizes, group, bucket_mb)
+        self._sizes = list(getattr(optimizer, "_slot_sizes", None) or [p.numel() for p in optimizer._plist])   # arena slots (FusedSGD pads to 16 bytes)
+        optimizer.grad_scale = 1.0 / self.world
+        optimizer.pre_step = self._pre_step
+        optimizer.data_parallel = self          # train_3d.train_step reduces the divergence flag on this wrapper's group
+        self._index = {id(p): i for i, p in enumerate(optimizer._plist)}
+        for p, v in zip(optimizer._plist, optimizer._gviews):
+            p._pcrl_gview = v
+        self.configure((os.environ.get("PCRL_DDP_OVERLAP", "0") == "1") if overlap is None else overlap, bucket_mb)
+        self.broadcast_state()
+
+    def configure(self, overlap: bool, bucket_mb: float = 24.0):
+        """(Re)plan the buckets and choose where they are launched from: inside backward as they become final (`overlap`) or all from
+        optimizer.step().  Callable between steps (bench.py's A/B of the four settings); the result of a step does not depend on it."""
+        optimizer = self.opt
+        self.bucket_mb = float(bucket_mb)
+        self.reducer = BucketedAllReduce(optimizer.flat_g, self._sizes, self.group, bucket_mb)
         if optimizer.flat_g.is_cuda and os.environ.get("PCRL_DDP_COMM_STREAM", "side") == "side":
             # bucket sums and collectives on the engine's side stream rather than on a stream of their own: main, view, side and RCCL's
             # internal stream are then the four streams of a rank -- as many as ROCm's default hardware queues (measured on one GPU with a
             # one-rank RCCL group: a fifth stream costs 1.7 ms per step; GPU_MAX_HW_QUEUES=8 costs 7.5 ms once RCCL is initialised)
             from . import ops
             self.reducer.comm_stream = ops.side_stream(optimizer.flat_g.device)
-        self.overlap = (os.environ.get("PCRL_DDP_OVERLAP", "0") == "1") if overlap is None else overlap
-        optimizer.grad_scale = 1.0 / self.world
-        optimizer.pre_step = self._pre_step
-        # bucket bookkeeping: which parameters live in which bucket
+        self.overlap = bool(overlap)
+        sizes = self._sizes
         offs = [0]
         for n in sizes:
             offs.append(offs[-1] + n)
@@ -199,15 +233,12 @@ class DataParallel:
         for bi, idxs in enumerate(self._bucket_params):
             for i in idxs:
                 self._param_bucket[i] = bi
-        self._index = {id(p): i for i, p in enumerate(optimizer._plist)}
-        for p, v in zip(optimizer._plist, optimizer._gviews):
-            p._pcrl_gview = v
         self._reset_step()
         if self._active and self.overlap:
-            Fn.set_ddp_callbacks(self._on_final, self._on_backward_end)
+            self._fn.set_ddp_callbacks(self._on_final, self._on_backward_end)
         else:
-            Fn.set_ddp_callbacks(None, None)     # a wrapper built earlier in this process must not keep receiving callbacks
-        self.broadcast_state()
+            self._fn.set_ddp_callbacks(None, None)     # a wrapper built earlier in this process must not keep receiving callbacks
+        return self
 
     # ------------------------------------------------------------------
     def _reset_step(self):

@@ -542,6 +542,8 @@ _pack_recording = None
 
 
 def _record_build(cache, args):
+    if any(getattr(a, "_pcrl_no_prepack", False) for a in args if torch.is_tensor(a)):
+        return          # derived tensors refreshed inside forward (pad_first_layer): packing them at step start would pack last step's values
     if _pack_recording is not None and not any(c is cache for c, _ in _pack_recording):
         _pack_recording.append((cache, args))
 
@@ -707,15 +709,33 @@ def prelu_backward(da, z, slope, dtype):
     return dz, dslope
 
 
+_padded_first = {}      # id(conv weight) -> [weakref to it, key, padded float32 copy]
+
+
 def pad_first_layer(x, conv_w, ci_pad, dtype):
     """in_channels != 1 (constructor variant, models/pcrlv2_model_3d.py:98,102): the input and the first convolution's weight zero-padded
-    to `ci_pad` input channels so that the layer runs on the Ci % 32 == 0 implicit-GEMM kernels.  Data movement only."""
+    to `ci_pad` input channels so that the layer runs on the Ci % 32 == 0 implicit-GEMM kernels.  Data movement only.
+    The padded weight is ONE persistent tensor per parameter, refreshed IN PLACE when the parameter changed -- keyed on the real parameter
+    (`_weights_epoch`, its version counter, its address), so that any way of updating it (FusedSGD's epoch bump, torch.optim's in-place
+    update, a manual copy_) is seen; the in-place refresh advances the padded tensor's own version counter, which is what the packed-weight
+    cache downstream keys on (a fresh temporary per call would come back at the same address with the same version and hit a stale pack:
+    ADVICE r3).  The padded copy is not a parameter and is excluded from the start-of-step prepack plan (it is refreshed here, in forward)."""
+    import weakref
     N, Ci, D, H, W = x.shape
     xp = torch.zeros((N, D, H, W, ci_pad), dtype=dtype, device=x.device).permute(0, 4, 1, 2, 3)
     xp[:, :Ci] = x
-    wp = torch.zeros((conv_w.shape[0], ci_pad, 3, 3, 3), dtype=torch.float32, device=conv_w.device)
-    wp[:, :Ci] = conv_w.detach()
-    return xp, wp
+    key = (_weights_epoch, conv_w._version, conv_w.data_ptr())
+    ent = _padded_first.get(id(conv_w))
+    if ent is None or ent[0]() is not conv_w or ent[2].shape[1] != ci_pad or ent[2].device != conv_w.device:
+        for k in [k for k, e in _padded_first.items() if e[0]() is None]:
+            del _padded_first[k]
+        wp = torch.zeros((conv_w.shape[0], ci_pad, 3, 3, 3), dtype=torch.float32, device=conv_w.device)
+        wp._pcrl_no_prepack = True
+        ent = _padded_first[id(conv_w)] = [weakref.ref(conv_w), None, wp]
+    if ent[1] != key:
+        ent[2][:, :Ci].copy_(conv_w.detach())       # in place: bumps ent[2]._version
+        ent[1] = key
+    return xp, ent[2]
 
 
 def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, packed: PackedWeights, act: int, dtype, training=True, gn_groups=0,

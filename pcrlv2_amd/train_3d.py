@@ -190,15 +190,16 @@ class StepLosses(tuple):
     skipped = None
 
 
-def divergence_flag(loss, group=None):
-    """float32[1] on loss's device: 1 if loss > 1000 on ANY rank (the reference is one process with one loss and one decision; with one
-    process per GPU the decision must be collective -- a rank that skipped alone would leave its peers waiting in the gradient all-reduce)."""
+def divergence_flag(loss, group=None, collective=True):
+    """float32[1] on loss's device: 1 if loss > 1000 on ANY rank of `group` (the reference is one process with one loss and one decision;
+    with one process per GPU the decision must be collective -- a rank that skipped alone would leave its peers waiting in the gradient
+    all-reduce).  `collective=False`: this process's own decision (no data-parallel wrapper: nobody to agree with)."""
     flag = torch.empty(1, dtype=torch.float32, device=loss.device)
     if loss.is_cuda:
         _ops.lib().call("pcrl_guard_flag", loss.detach().float().reshape(1), GUARD_THRESHOLD, flag, _ops.stream_handle())
     else:       # host tensors (the gloo tests of the collective form): same predicate
         flag[0] = 1.0 if float(loss) > GUARD_THRESHOLD else 0.0
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collective and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     return flag
 
@@ -215,7 +216,10 @@ def train_step(model, optimizer, batch, epoch, criterion, cosine, guard=True):
         losses = step_losses(model, batch, epoch, criterion, cosine)
     flag = None
     if guard and epoch >= GUARD_FIRST_EPOCH:
-        flag = divergence_flag(losses[0])
+        # the decision is taken by the ranks that share gradients: the data-parallel wrapper's group (a wrapper on a sub-group must not pull
+        # ranks outside it into this collective); without a wrapper the process decides alone
+        dp = getattr(optimizer, "data_parallel", None)
+        flag = divergence_flag(losses[0], group=getattr(dp, "group", None), collective=dp is not None and getattr(dp, "_active", False))
         if guard == "sync" or GUARD_SYNC:
             if bool(flag):       # device -> host read: the reference's semantics, and its synchronisation
                 print('skip the step')
@@ -300,14 +304,18 @@ def train_pcrlv2_inner(args, epoch, train_loader, model, optimizer, criterion, c
         if out is None:         # host-side guard (PCRL_GUARD_SYNC=1): the reference's `continue`
             continue
         n = batch[0].size(0)
+        vals = (out[1], out[2], out[4])
         if out.skipped is not None:
             # guard decided on the device: a skipped step must not enter the meters (the reference `continue`s before them) -- its weight is
-            # n * (1 - skipped), a device scalar; the "skip the step" lines are printed when the flags are read, with the log line
-            n = n * (1.0 - out.skipped.reshape(()))
+            # n * (1 - skipped), a device scalar, AND its values are masked to 0 (a diverged loss is often inf / NaN: inf * 0 would poison the
+            # running sums); the "skip the step" lines are printed when the flags are read, with the log line
+            live = 1.0 - out.skipped.reshape(())
+            n = n * live
+            vals = tuple(torch.where(live > 0, v, torch.zeros_like(v)) for v in vals)
             skipped_flags.append(out.skipped)
-        meters["mg"].update(out[1], n)
-        meters["cos"].update(out[2], n)
-        meters["local"].update(out[4], n)
+        meters["mg"].update(vals[0], n)
+        meters["cos"].update(vals[1], n)
+        meters["local"].update(vals[2], n)
         log_now = it % 10 == 0
         if log_now:
             torch.cuda.synchronize()
@@ -329,4 +337,7 @@ def train_pcrlv2_inner(args, epoch, train_loader, model, optimizer, criterion, c
                       float(m["cos"].val), float(m["cos"].avg), float(m["mg"].val), float(m["mg"].avg),
                       float(m["local"].val), float(m["local"].avg)))
             sys.stdout.flush()
+    if skipped_flags and verbose:       # steps skipped after the last log line of the epoch
+        for _ in range(int(torch.cat(skipped_flags).sum().item())):
+            print('skip the step')
     return float(meters["mg"].avg), float(meters["local"].avg)

@@ -55,6 +55,7 @@ class AverageMeter(object):
     @property
     def avg(self):
         self._settle()
-        if isinstance(self._count, (int, float)) and not self._count:
-            return 0
-        return self._sum / self._count
+        if isinstance(self._count, (int, float)):
+            return self._sum / self._count if self._count else 0
+        import torch        # device count: an epoch whose every step was skipped by the divergence guard has weight 0 -- report 0 like an empty meter, not 0/0
+        return torch.where(self._count > 0, self._sum / self._count.clamp_min(1e-30), torch.zeros_like(self._sum))

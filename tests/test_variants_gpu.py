@@ -110,3 +110,51 @@ def test_variant_eval_mode_runs_and_matches_oracle(golden_dir):
     for i in range(3):
         assert (feats[i][0].double().cpu() - r_feats[i][0]).abs().max() < 3e-4
         assert (masks[i].double().cpu() - r_masks[i]).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("how", ["torch_sgd", "manual_copy", "eval_between"])
+def test_padded_first_layer_follows_weight_updates_that_bypass_the_engine_optimizer(how):
+    """in_channels != 1 zero-pads the first convolution's weight; the packed-weight cache must follow the REAL parameter however
+    it is updated -- torch.optim.SGD's in-place update, a manual copy_ between two forwards (train or eval) -- not only FusedSGD's epoch bump.
+    Two forwards around an update of down_tr64.ops.0.conv1.weight, each against the float64 oracle on the state of that moment."""
+    kw = dict(in_channels=3)
+    k = okw(kw)
+    st = O.fill_state(torch.float32, **k)
+    model = PCRLv23d(**kw).to(DEV)
+    model.load_state_dict(st)
+    model.set_compute_dtype(torch.float32)
+    x = O.variant_input(3, (32, 32, 16), 3, torch.float32)
+    name = "down_tr64.ops.0.conv1.weight"
+
+    def check(train):
+        model.train(train)
+        out, _feats, _masks = model(x.to(DEV))
+        sd = {n: (v.detach().double().cpu() if v.is_floating_point() else v.detach().cpu()) for n, v in model.state_dict().items()}
+        return out, sd
+
+    def oracle_out(sd, train):
+        with torch.no_grad():
+            return O.forward(sd, x.double(), training=train, act=k["act"], norm=k["norm"])[0]
+
+    train = how != "eval_between"
+    model.train(train)
+    sd_before = {n: (v.detach().double().cpu() if v.is_floating_point() else v.detach().cpu()) for n, v in model.state_dict().items()}
+    out0, _ = check(train)
+    assert (out0.double().cpu() - oracle_out(sd_before, train)).abs().max() < 5e-5
+    w = dict(model.named_parameters())[name]
+    if how == "torch_sgd":
+        opt = torch.optim.SGD(model.parameters(), lr=0.5)
+        (out0 * out0).mean().backward()
+        torch.cuda.synchronize()
+        assert w.grad is not None and float(w.grad.abs().max()) > 0
+        opt.step()
+    else:
+        with torch.no_grad():
+            w.copy_(w * -0.5 + 0.01)
+    model.flush_counters()
+    sd_mid = {n: (v.detach().double().cpu() if v.is_floating_point() else v.detach().cpu()) for n, v in model.state_dict().items()}
+    assert (sd_mid[name] - sd_before[name]).abs().max() > 1e-4      # the parameter really moved
+    out1, _ = check(train)
+    ref1 = oracle_out(sd_mid, train)
+    assert (out1.double().cpu() - ref1).abs().max() < 5e-5, "the first layer kept the packed weights of the previous forward"
+    assert (out1.double().cpu() - out0.double().cpu()).abs().max() > 1e-4
