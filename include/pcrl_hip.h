@@ -189,6 +189,17 @@ int pcrl_bn_act_bwd_apply_rowadd(const void* da, const float* row_g, int N, int6
                                  const float* shift, const float* k1, const float* kB, const float* kA,
                                  int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
 
+/* The same two passes when the incoming gradient is a SUM of up to three parts: da + da2 + row_g[n][c] / S (each may be NULL, at least
+ * one given; N, S only read with row_g).  Replaces the aten::add launches autograd issues where one activation has several consumers:
+ * a 2D decoder block's output feeds the next block, its own deep-supervision head and the pooled projection head
+ * (models/pcrlv2_model.py:119-127), a BasicBlock's input feeds conv1 and the identity branch.  Same availability as the row term. */
+int pcrl_bn_act_bwd_reduce_sum(const void* da, const void* da2, const float* row_g, int N, int64_t S, const void* y, const float* scale,
+                               const float* shift, const float* mean, const float* rstd, float* partial,
+                               int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
+int pcrl_bn_act_bwd_apply_sum(const void* da, const void* da2, const float* row_g, int N, int64_t S, const void* y, void* dy,
+                              const float* scale, const float* shift, const float* k1, const float* kB, const float* kA,
+                              int64_t M, int C, int act, int dtype, pcrl_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * MaxPool3d(2) -- aten::max_pool3d_with_indices(+backward) at pcrlv2_model_3d.py:100,115-117.
  * N,D,H,W are the INPUT dims (even).  Backward recomputes the argmax from the saved input
@@ -459,6 +470,32 @@ void pcrl_debug_set_conv_impl(int impl);
 void pcrl_debug_set_wgrad_impl(int impl);
 void pcrl_debug_set_wgrad_tr(int on);
 void pcrl_debug_set_conv2d_impl(int impl);
+
+/* ---------------------------------------------------------------------------------------
+ * 2D path, the 3-channel ends of the step (csrc/heads2d.hip).
+ * pcrl_mse2d_fwd / _bwd_pad -- nn.MSELoss()(masks, gt) at train_2d.py:165,167 with the prediction in NHWC memory (float32 [N][HW][C], what
+ *   the segmentation / deep-supervision heads write) and the target as the loader delivers it (float32 NCHW [N][C][HW]): no layout copy of
+ *   the image.  The backward writes d loss / d masks as `dtype` [N*HW][CP] with zeros in channels C..CP-1 -- the form the convolution
+ *   backward kernels take (CP = 8), or unpadded float32 (CP = C) for the bilinear backward -- and leaves colpart[pcrl_rows1024(N*HW)][CP],
+ *   per-block column sums whose total (pcrl_colsum) is the bias gradient of the convolution that produced the masks
+ *   (aten::mse_loss_backward + the zero-pad copy + the sum over pixels of aten::convolution_backward's bias branch).
+ * pcrl_conv2d_1x1_small_bwd -- backward of deep_supervision_head[3] = nn.Conv2d(C, 3, kernel_size=1) (models/pcrlv2_model.py:106;
+ *   aten::convolution_backward): x `dtype` [M][Ci], dy float32 [M][3], w float32 [3][Ci] -> dx `dtype` [M][Ci] and
+ *   part[pcrl_rows1024(M)][PW] (per block: 3*Ci dw entries, 3 db entries, zeros up to the row pitch PW >= 3*Ci + 3; pcrl_colsum
+ *   finishes) in one pass over x and dy. */
+int64_t pcrl_rows1024(int64_t M);
+size_t pcrl_mse2d_ws_bytes(int64_t M);
+int pcrl_mse2d_fwd(const float* p, const float* gt, float* loss, void* ws, size_t ws_bytes, int N, int64_t HW, int C, pcrl_stream_t stream);
+int pcrl_mse2d_bwd_pad(const float* p, const float* gt, const float* dloss, void* dy, float* colpart, int N, int64_t HW, int C, int CP,
+                       int dtype, pcrl_stream_t stream);
+int pcrl_conv2d_1x1_small_bwd(const void* x, const float* dy, const float* w, void* dx, float* part, int64_t M, int Ci, int Co, int PW,
+                              int dtype, pcrl_stream_t stream);
+/* the network input (train_2d.py:139-141: `.float().cuda()` images, NCHW float32 [N][C][HW], C <= 8) as the `dtype` NHWC tensor [N*HW][CP]
+ * with zero padding channels the ResNet stem's convolution reads (aten::zeros + aten::copy_ of a permuted view) */
+int pcrl_nchw_to_nhwc_pad(const float* x, void* out, int N, int C, int64_t HW, int CP, int dtype, pcrl_stream_t stream);
+/* out = a + b on float32 vectors: the sum of the two gradients that reach x_pro = bn(avgpool(x)) -- directly (the projection is a cosine
+ * operand) and through the predictor head (pcrlv2_model.py:125-127, pcrlv2_model_3d.py:69-70) -- autograd's aten::add on a [N, C] matrix */
+int pcrl_add_f32(const float* a, const float* b, float* out, int64_t n, pcrl_stream_t stream);
 
 #ifdef __cplusplus
 }

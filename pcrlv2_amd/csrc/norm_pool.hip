@@ -188,6 +188,8 @@ struct RowAdd {
   const float* g;   // [N][C] or null
   int64_t S;        // rows per sample
   float inv_s;
+  const void* da2;  // a SECOND gradient tensor of da's shape and dtype added to da (two consumers of one activation: a 2D decoder block's
+                    // output feeds the next block and its own deep-supervision head, pcrlv2_model.py:119-127), or null
 };
 
 template <typename T, int ACT, bool NT>
@@ -216,8 +218,9 @@ __device__ __forceinline__ void bn_bwd_apply_rc_kernel_body(const T* __restrict_
     // back, so their tails are what the Infinity Cache still holds
     const int64_t rr = rev ? M - 1 - r : r;
     const int64_t off = (rr * nvec + cv) * VEC;
-    Vec16<T> g;
+    Vec16<T> g, g2;
     if (da) g = ld16_sel<NT>(da + off);
+    if (ra.da2) g2 = ld16_sel<NT>(reinterpret_cast<const T*>(ra.da2) + off);
     const Vec16<T> v = ld16_sel<NT>(y + off);
     if (ra.g && rev) {
       n = rr / ra.S;
@@ -239,7 +242,7 @@ __device__ __forceinline__ void bn_bwd_apply_rc_kernel_body(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float yv = to_f(v.v[j]);
-      const float gin = (da ? to_f(g.v[j]) : 0.f) + add[j];
+      const float gin = ((da ? to_f(g.v[j]) : 0.f) + (ra.da2 ? to_f(g2.v[j]) : 0.f)) + add[j];
       const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], gin);
       o.v[j] = from_f<T>(c1[j] * dz + cB[j] * yv + cA[j]);
     }
@@ -305,11 +308,12 @@ __device__ __forceinline__ void bn_bwd_reduce_kernel_body(const T* __restrict__ 
   int64_t r = rbeg + slot;
   if (!ra.g || ra_tile) {
     for (; r + (U - 1) * (int64_t)nslots < rend; r += U * (int64_t)nslots) {
-      Vec16<T> g[U], v[U];
+      Vec16<T> g[U], g2[U], v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int64_t off = ((r + u * (int64_t)nslots) * nvec + cv) * VEC;
         if (da) g[u] = ld16_sel<NT>(da + off);
+        if (ra.da2) g2[u] = ld16_sel<NT>(reinterpret_cast<const T*>(ra.da2) + off);
         v[u] = ld16_sel<NT>(y + off);
       }
 #pragma unroll
@@ -317,7 +321,7 @@ __device__ __forceinline__ void bn_bwd_reduce_kernel_body(const T* __restrict__ 
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           const float yv = to_f(v[u].v[j]);
-          const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], (da ? to_f(g[u].v[j]) : 0.f) + add[j]);
+          const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], ((da ? to_f(g[u].v[j]) : 0.f) + (ra.da2 ? to_f(g2[u].v[j]) : 0.f)) + add[j]);
           s1[j] += dz;
           s2[j] += dz * (yv - mu[j]) * rs[j];
         }
@@ -325,14 +329,15 @@ __device__ __forceinline__ void bn_bwd_reduce_kernel_body(const T* __restrict__ 
   }
   for (; r < rend; r += nslots) {
     const int64_t off = (r * nvec + cv) * VEC;
-    Vec16<T> g;
+    Vec16<T> g, g2;
     if (da) g = ld16_sel<NT>(da + off);
+    if (ra.da2) g2 = ld16_sel<NT>(reinterpret_cast<const T*>(ra.da2) + off);
     const Vec16<T> v = ld16_sel<NT>(y + off);
     BR_ROWADD(r)
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float yv = to_f(v.v[j]);
-      const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], (da ? to_f(g.v[j]) : 0.f) + add[j]);
+      const float dz = act_bwd<ACT>(sc[j] * yv + sh[j], ((da ? to_f(g.v[j]) : 0.f) + (ra.da2 ? to_f(g2.v[j]) : 0.f)) + add[j]);
       s1[j] += dz;
       s2[j] += dz * (yv - mu[j]) * rs[j];
     }
@@ -850,7 +855,7 @@ extern "C" int64_t pcrl_bn_act_bwd_rowadd_ok(int C, int dtype) { return rowadd_o
 static int bn_bwd_reduce_impl(const void* da, const void* y, const float* scale, const float* shift, const float* mean, const float* rstd,
                               float* partial, int64_t M, int C, int act, int dtype, RowAdd ra, pcrl_stream_t stream) {
   if (int e = check_tilevec("bn_act_bwd_reduce", C, dtype, true)) return e;
-  PCRL_REQUIRE((da || ra.g) && y && scale && shift && mean && rstd && partial, "bn_act_bwd_reduce: null pointer");
+  PCRL_REQUIRE((da || ra.g || ra.da2) && y && scale && shift && mean && rstd && partial, "bn_act_bwd_reduce: null pointer");
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
   PCRL_REQUIRE(C != 1 || M % vec == 0, "bn_act_bwd_reduce: M must be a multiple of %d for C == 1", vec);
   const dim3 grid((unsigned)pcrl_bn_bwd_partial_rows(M));
@@ -869,12 +874,12 @@ extern "C" int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float
                                       const float* mean, const float* rstd, float* partial,
                                       int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
   PCRL_REQUIRE(da, "bn_act_bwd_reduce: null pointer");
-  return bn_bwd_reduce_impl(da, y, scale, shift, mean, rstd, partial, M, C, act, dtype, RowAdd{nullptr, 1, 0.f}, stream);
+  return bn_bwd_reduce_impl(da, y, scale, shift, mean, rstd, partial, M, C, act, dtype, RowAdd{nullptr, 1, 0.f, nullptr}, stream);
 }
 static int rowadd_check(const char* what, const float* row_g, int N, int64_t S, int64_t M, int C, int dtype, RowAdd& ra) {
   PCRL_REQUIRE(row_g && N > 0 && S > 0 && (int64_t)N * S == M, "%s: the row term needs N * S == M (N=%d S=%lld M=%lld)", what, N, (long long)S, (long long)M);
   PCRL_REQUIRE(rowadd_ok(C, dtype), "%s: the row term is not available for C=%d (pcrl_bn_act_bwd_rowadd_ok)", what, C);
-  ra = RowAdd{row_g, S, (float)(1.0 / (double)S)};
+  ra = RowAdd{row_g, S, (float)(1.0 / (double)S), nullptr};
   return PCRL_OK;
 }
 extern "C" int pcrl_bn_act_bwd_reduce_rowadd(const void* da, const float* row_g, int N, int64_t S, const void* y, const float* scale,
@@ -904,13 +909,13 @@ static int bn_bwd_apply_impl(const void* da, const void* y, void* dy, const floa
                              const float* k1, const float* kB, const float* kA,
                              int64_t M, int C, int act, int dtype, RowAdd ra, pcrl_stream_t stream) {
   if (int e = check_vec("bn_act_bwd_apply", C, dtype, true)) return e;
-  PCRL_REQUIRE((da || ra.g) && y && dy && scale && shift && k1 && kB && kA, "bn_act_bwd_apply: null pointer");
+  PCRL_REQUIRE((da || ra.g || ra.da2) && y && dy && scale && shift && k1 && kB && kA, "bn_act_bwd_apply: null pointer");
   const int vec = dtype == PCRL_BF16 ? 8 : 4;
   PCRL_REQUIRE((M * C) % vec == 0, "bn_act_bwd_apply: M*C must be a multiple of %d", vec);
   const int64_t nvec = M * C / vec;
   const dim3 grid(grid_for(nvec));
   const bool rc = C % vec == 0 && (C / vec) <= 256 && 256 % (C / vec) == 0;
-  PCRL_REQUIRE(rc || !ra.g, "bn_act_bwd_apply: the row term needs the channel-vector kernel (C=%d)", C);
+  PCRL_REQUIRE(rc || (!ra.g && !ra.da2), "bn_act_bwd_apply: the row term / second gradient need the channel-vector kernel (C=%d)", C);
   const dim3 grid_rc(rc_grid(M, C / (C % vec == 0 ? vec : 1)));
   if (dtype == PCRL_BF16) {
     using T = bf16;
@@ -927,13 +932,41 @@ extern "C" int pcrl_bn_act_bwd_apply(const void* da, const void* y, void* dy, co
                                      const float* k1, const float* kB, const float* kA,
                                      int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
   PCRL_REQUIRE(da, "bn_act_bwd_apply: null pointer");
-  return bn_bwd_apply_impl(da, y, dy, scale, shift, k1, kB, kA, M, C, act, dtype, RowAdd{nullptr, 1, 0.f}, stream);
+  return bn_bwd_apply_impl(da, y, dy, scale, shift, k1, kB, kA, M, C, act, dtype, RowAdd{nullptr, 1, 0.f, nullptr}, stream);
 }
 extern "C" int pcrl_bn_act_bwd_apply_rowadd(const void* da, const float* row_g, int N, int64_t S, const void* y, void* dy, const float* scale,
                                             const float* shift, const float* k1, const float* kB, const float* kA,
                                             int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
   RowAdd ra;
   if (int e = rowadd_check("bn_act_bwd_apply_rowadd", row_g, N, S, M, C, dtype, ra)) return e;
+  return bn_bwd_apply_impl(da, y, dy, scale, shift, k1, kB, kA, M, C, act, dtype, ra, stream);
+}
+
+// ---- the incoming gradient is a SUM: da (+ da2) (+ row_g[n] / S broadcast over the sample) -- any subset, at least one ----
+// A 2D decoder block's output has three consumers (the next block, its own deep-supervision head, the pooled projection head:
+// pcrlv2_model.py:119-127); autograd would materialise their sum with two element-wise adds over the full-resolution tensor.
+static int sum_check(const char* what, const void* da, const void* da2, const float* row_g, int N, int64_t S, int64_t M, int C, int dtype, RowAdd& ra) {
+  PCRL_REQUIRE(da || da2 || row_g, "%s: no gradient at all", what);
+  PCRL_REQUIRE(rowadd_ok(C, dtype), "%s: not available for C=%d (pcrl_bn_act_bwd_rowadd_ok)", what, C);
+  ra = RowAdd{nullptr, 1, 0.f, da2};
+  if (row_g) {
+    PCRL_REQUIRE(N > 0 && S > 0 && (int64_t)N * S == M, "%s: the row term needs N * S == M (N=%d S=%lld M=%lld)", what, N, (long long)S, (long long)M);
+    ra.g = row_g; ra.S = S; ra.inv_s = (float)(1.0 / (double)S);
+  }
+  return PCRL_OK;
+}
+extern "C" int pcrl_bn_act_bwd_reduce_sum(const void* da, const void* da2, const float* row_g, int N, int64_t S, const void* y, const float* scale,
+                                          const float* shift, const float* mean, const float* rstd, float* partial,
+                                          int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+  RowAdd ra;
+  if (int e = sum_check("bn_act_bwd_reduce_sum", da, da2, row_g, N, S, M, C, dtype, ra)) return e;
+  return bn_bwd_reduce_impl(da, y, scale, shift, mean, rstd, partial, M, C, act, dtype, ra, stream);
+}
+extern "C" int pcrl_bn_act_bwd_apply_sum(const void* da, const void* da2, const float* row_g, int N, int64_t S, const void* y, void* dy,
+                                         const float* scale, const float* shift, const float* k1, const float* kB, const float* kA,
+                                         int64_t M, int C, int act, int dtype, pcrl_stream_t stream) {
+  RowAdd ra;
+  if (int e = sum_check("bn_act_bwd_apply_sum", da, da2, row_g, N, S, M, C, dtype, ra)) return e;
   return bn_bwd_apply_impl(da, y, dy, scale, shift, k1, kB, kA, M, C, act, dtype, ra, stream);
 }
 

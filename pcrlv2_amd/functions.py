@@ -423,7 +423,7 @@ class UpStageFn(Function):
                 d_h1, g_p3w, g_p3b = ops.linear_backward(d_pre, h1, p3_w)
                 d_h0, g_p1g, g_p1b = ops.bn1d_backward(d_h1, h0, h1, p1_g, m_h, r_h, relu=True)
                 d_xp, g_p0w, g_p0b = ops.linear_backward(d_h0, x_pro, p0_w)
-                d_xpro = d_xp if d_xpro is None else d_xpro + d_xp   # [N,C] float32: a few KB
+                d_xpro = d_xp if d_xpro is None else ops.add2_small(d_xpro, d_xp)   # [N,C] float32: a few KB
                 grads[13], grads[14], grads[15], grads[16], grads[17], grads[18] = g_p0w, g_p0b, g_p1g, g_p1b, g_p3w, g_p3b
             d_g, g_bng, g_bnb = ops.bn1d_backward(d_xpro, g, x_pro, bn_g, m_pro, r_pro, relu=False)
             grads[11], grads[12] = g_bng, g_bnb

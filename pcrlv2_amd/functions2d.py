@@ -8,7 +8,8 @@ from __future__ import annotations
 import torch
 from torch.autograd import Function
 
-from . import ops, ops2d
+from . import config, ops, ops2d
+from ._lib import ACT_RELU, dtype_code, lib, stream_handle
 from .functions import _park, mark_final
 
 
@@ -184,6 +185,181 @@ class ProjHeadFn(Function):
         out = (d_a,) + tuple(_park(p, gr) for p, gr in zip(ctx.plist, grads)) + (None,)
         mark_final(ctx, ctx.plist)
         return out
+
+
+def _heads_backward(d_pro, d_pre, heads, x_pro, params):
+    """Backward of x_pro = bn(gap); x_pre = predictor_head(x_pro) (pcrlv2_model.py:124-127) down to the pooled vector.
+    -> (d_g float32 [N, C], [grads of bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b])"""
+    bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b = params
+    g, m_pro, r_pro, h0, h1, m_h, r_h = heads
+    grads = [None] * 8
+    d_xpro = d_pro.contiguous() if d_pro is not None else None
+    if d_pre is not None:
+        d_h1, g_p3w, g_p3b = ops.linear_backward(d_pre, h1, p3_w)
+        d_h0, g_p1g, g_p1b = ops.bn1d_backward(d_h1, h0, h1, p1_g, m_h, r_h, relu=True)
+        d_xp, g_p0w, g_p0b = ops.linear_backward(d_h0, x_pro, p0_w)
+        d_xpro = d_xp if d_xpro is None else ops.add2_small(d_xpro, d_xp)
+        grads[2:8] = [g_p0w, g_p0b, g_p1g, g_p1b, g_p3w, g_p3b]
+    d_g, g_bng, g_bnb = ops.bn1d_backward(d_xpro, g, x_pro, bn_g, m_pro, r_pro, relu=False)
+    grads[0], grads[1] = g_bng, g_bnb
+    return d_g, grads
+
+
+class DecoderBlockFn(Function):
+    """DecoderBlock.forward (pcrlv2_model.py:113-128) as ONE autograd node: nearest x2 -> conv1 -> conv2 -> {pooled projection + predictor
+    heads, deep-supervision head}.  The block's output has three consumers (the next block, its own deep-supervision head, the pooled
+    heads); as separate nodes autograd summed their gradients with full-resolution element-wise adds (2.9 ms of ATen launches per C5
+    step) -- here the BatchNorm backward of conv2 takes the parts as they are (pcrl_bn_act_bwd_*_sum: two tensors + the pooled branch's
+    per-(sample, channel) term).
+    `want_mask` False: the deep-supervision head runs its convolution and the statistics update of its BatchNorm2d only (the module's
+    state after a step is the reference's); its activation, the 1x1 convolution to 3 channels and the map are not computed -- nothing
+    reads them for the second view, the local views and the scales the first cos_loss did not draw (train_2d.py:143-168).
+
+    inputs : x, [w, gamma, beta] of conv1, conv2; [w, b, gamma, beta] of deep_supervision_head[0..1], [w, b] of [3]; bn.(gamma, beta),
+             ph0.(w, b), ph1.(gamma, beta), ph3.(w, b); module, want_mask
+    outputs: a2 (activation), x_pro [N,C], x_pre [N,C], x_mask float32 [N,3,H,W] (NHWC memory) | None"""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, be1, w2, g2, be2, wd, bd, gd, bed, w3, b3, bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b, mod, want_mask):
+        dt = mod.compute_dtype
+        u1, u2, ud0, ud3 = mod._u1, mod._u2, mod._ud0, mod._ud3
+        dev, L = x.device, lib()
+
+        def conv_bn(xin, w, b, g, be, u):
+            y, partial, rows = ops2d.conv2d_forward(xin, w, b, u._packed, 1, 1, u.up, dt)
+            N, H, W, C = ops2d.dims2(y)
+            bn = u.bn_module
+            coef = ops.bn_finalize(partial, rows, C, N * H * W, g.detach(), be.detach(), bn.running_mean, bn.running_var)
+            u._count_batch()
+            return y, coef
+
+        y1, c1 = conv_bn(x, w1, None, g1, be1, u1)
+        N, H, W, C = ops2d.dims2(y1)
+        M = N * H * W
+        a1 = ops.bn_act_apply(y1, c1[2], c1[3], M, C, ACT_RELU, dt)
+        y2, c2 = conv_bn(a1, w2, None, g2, be2, u2)
+        if config.FUSE_APPLY_CONSUMERS and ops.bn_rowadd_ok(C, dt):      # the activation and its global average pool from one pass
+            a2, g = torch.empty_like(y2), ops._f32(N * C, dev).view(N, C)
+            nbg = L.call("pcrl_gap_ws_bytes", N, H * W, C)
+            L.call("pcrl_bn_act_apply_gap", y2, a2, g, c2[2], c2[3], ops.workspace(nbg, dev), nbg, N, H * W, C, ACT_RELU, dtype_code(dt), stream_handle())
+        else:
+            a2 = ops.bn_act_apply(y2, c2[2], c2[3], M, C, ACT_RELU, dt)
+            g = ops2d.gap_forward(a2, dt)
+        x_pro, m_pro, r_pro = ops.bn1d_forward(g, bn_g, bn_b, mod.bn.running_mean, mod.bn.running_var, relu=False)
+        h0 = ops.linear_forward(x_pro, p0_w, p0_b)
+        ph1 = mod.predictor_head[1]
+        h1, m_h, r_h = ops.bn1d_forward(h0, p1_g, p1_b, ph1.running_mean, ph1.running_var, relu=True)
+        x_pre = ops.linear_forward(h1, p3_w, p3_b)
+        mod._count_batch_heads()
+        yd, cd = conv_bn(a2, wd, bd, gd, bed, ud0)           # statistics (running_mean / running_var / num_batches_tracked) always
+        ad = x_mask = None
+        if want_mask:
+            ad = ops.bn_act_apply(yd, cd[2], cd[3], M, C, ACT_RELU, dt)
+            x_mask = ops2d.conv2d_forward(ad, w3, b3, ud3._packed, 1, 0, 0, dt, want_stats=False, out_f32=True)[0]
+        ctx.mod, ctx.dt, ctx.MC = mod, dt, (N, H * W, M, C)
+        ctx.x, ctx.l1, ctx.l2 = x, (y1, c1, a1), (y2, c2)
+        ctx.ld = (yd, cd, ad) if want_mask else None
+        ctx.heads = (g, m_pro, r_pro, h0, h1, m_h, r_h)
+        ctx.plist = (w1, g1, be1, w2, g2, be2, wd, bd, gd, bed, w3, b3, bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b)
+        ctx.pass_idx = getattr(mod, "_pass_idx", 1)
+        ctx.save_for_backward(a2, x_pro)      # OUTPUTS needed in backward: never stashed on ctx directly (reference cycle, see functions.UpStageFn)
+        ctx.set_materialize_grads(False)
+        return a2, x_pro, x_pre, x_mask
+
+    @staticmethod
+    def backward(ctx, d_a2, d_pro, d_pre, d_mask):
+        n_in = 23
+        if d_a2 is None and d_pro is None and d_pre is None and d_mask is None:
+            return (None,) * n_in
+        mod, dt = ctx.mod, ctx.dt
+        N, S, M, C = ctx.MC
+        w1, g1, be1, w2, g2, be2, wd, bd, gd, bed, w3, b3, bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b = ctx.plist
+        a2, x_pro = ctx.saved_tensors
+        u1, u2, ud0 = mod._u1, mod._u2, mod._ud0
+        pg = [None] * 20         # parameter gradients in ctx.plist order
+        row_g = None
+        if d_pro is not None or d_pre is not None:
+            row_g, hg = _heads_backward(d_pro, d_pre, ctx.heads, x_pro, ctx.plist[12:])
+            pg[12:20] = hg
+        dx_ds = None
+        if d_mask is not None:
+            if ctx.ld is None:
+                raise RuntimeError("DecoderBlockFn: a gradient arrived for a deep-supervision map that was not computed")
+            yd, cd, ad = ctx.ld
+            d_ad, g_w3, g_b3 = ops2d.conv1x1_small_backward(ad, ops2d.to_act2(d_mask, torch.float32), w3, dt)
+            dyd, g_gd, g_bed = ops.bn_act_backward(d_ad, yd, gd.detach(), cd[0], cd[1], cd[2], cd[3], M, C, ACT_RELU, dt)
+            dx_ds, g_wd = ops2d.conv2d_backward(a2, dyd, wd, ud0._packed, 1, 1, 0, dt, need_dx=True)
+            pg[6], pg[7], pg[8], pg[9], pg[10], pg[11] = g_wd, ops.zero_grad_vector(C, a2.device), g_gd, g_bed, g_w3, g_b3
+        da = ops2d.to_act2(d_a2, dt) if d_a2 is not None else None
+        da2 = dx_ds
+        if da is None:
+            da, da2 = da2, None
+        dx = None
+        if da is not None or row_g is not None:
+            y2, c2 = ctx.l2
+            y1, c1, a1 = ctx.l1
+            if row_g is not None and not ops.bn_rowadd_ok(C, dt):
+                da, row_g = ops2d.gap_backward(row_g, a2, dt, add_src=da), None
+            if da2 is not None and not ops.bn_rowadd_ok(C, dt):
+                da, da2 = da + da2, None
+            dy2, g_g2, g_be2 = ops.bn_act_backward(da, y2, g2.detach(), c2[0], c2[1], c2[2], c2[3], M, C, ACT_RELU, dt, row_g=row_g, da2=da2)
+            d_a1, g_w2 = ops2d.conv2d_backward(a1, dy2, w2, u2._packed, 1, 1, 0, dt, need_dx=True)
+            dy1, g_g1, g_be1 = ops.bn_act_backward(d_a1, y1, g1.detach(), c1[0], c1[1], c1[2], c1[3], M, C, ACT_RELU, dt)
+            dx, g_w1 = ops2d.conv2d_backward(ctx.x, dy1, w1, u1._packed, 1, 1, 1, dt, need_dx=ctx.needs_input_grad[0])
+            pg[0], pg[1], pg[2], pg[3], pg[4], pg[5] = g_w1, g_g1, g_be1, g_w2, g_g2, g_be2
+        out = (dx,) + tuple(_park(p, g) for p, g in zip(ctx.plist, pg)) + (None, None)
+        mark_final(ctx, ctx.plist)
+        return out
+
+
+class SegMSEFn(Function):
+    """criterion(self.model.segmentation_head(decoder_output), gt) -- pcrlv2_model.py:208 + train_2d.py:165 -- as one node: Conv2d(16, n_class,
+    3, padding=1) with float32 NHWC output, the MSE against the NCHW image read in place; the backward writes the 3-channel gradient
+    directly in the zero-padded form the convolution backward kernels take and its bias sums in the same pass."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, gt, unit):
+        dt = unit.compute_dtype
+        y = ops2d.conv2d_forward(h, w, b, unit._packed, unit.stride, unit.pad, 0, dt, want_stats=False, out_f32=True)[0]
+        gt = ops2d._nchw_f32(gt, h.device)
+        loss = ops2d.mse2d_forward(y, gt)
+        ctx.h, ctx.y, ctx.gt, ctx.unit, ctx.dt = h, y, gt, unit, dt
+        ctx.plist = (w, b)
+        ctx.pass_idx = getattr(unit, "_pass_idx", 1)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        unit, dt = ctx.unit, ctx.dt
+        w, b = ctx.plist
+        Co = w.shape[0]
+        CoP = ops2d._pow2_at_least_8(Co)
+        dy, colpart, rows = ops2d.mse2d_backward(ctx.y, ctx.gt, dloss, CoP, dt)
+        db = ops2d.colsum_f32(colpart, rows, CoP)[:Co] if b is not None else None
+        dx, dw = ops2d.conv2d_backward(ctx.h, dy, w, unit._packed, unit.stride, unit.pad, 0, dt, need_dx=ctx.needs_input_grad[0])
+        out = dx, _park(w, dw), (_park(b, db) if b is not None else None), None, None
+        mark_final(ctx, [p for p in ctx.plist if p is not None])
+        return out
+
+
+class MaskMSEFn(Function):
+    """criterion(F.interpolate(x_mask, scale_factor=s, mode='bilinear'), gt) -- pcrlv2_model.py:190 + train_2d.py:167 -- for the ONE
+    deep-supervision map a step uses: bilinear upsampling (skipped at s = 1), the MSE against the NCHW image, and back."""
+
+    @staticmethod
+    def forward(ctx, x_mask, gt, scale):
+        x = ops2d.to_act2(x_mask, torch.float32)
+        up = ops2d.bilinear_forward(x, scale) if scale != 1 else x
+        gt = ops2d._nchw_f32(gt, x.device)
+        ctx.in_dims, ctx.scale, ctx.up, ctx.gt = ops2d.dims2(x), scale, up, gt
+        return ops2d.mse2d_forward(up, gt)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        C = ctx.in_dims[3]
+        d_up, _colpart, _rows = ops2d.mse2d_backward(ctx.up, ctx.gt, dloss, C, torch.float32)
+        d = ops2d.bilinear_backward(d_up, ctx.in_dims, ctx.scale) if ctx.scale != 1 else d_up
+        return d, None, None
 
 
 def mse_loss2d(p, gt):

@@ -110,7 +110,7 @@ class ResNetEncoder(nn.Module):
     def forward(self, x):
         dt = self._stem.compute_dtype
         feats = [x]
-        h = self._stem(ops2d.to_act2(x, dt, pad_to=8))
+        h = self._stem(ops2d.image_to_act(x, dt, 8))
         feats.append(h)
         h = Fn2.MaxPool2dFn.apply(h, dt)
         for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
@@ -192,13 +192,14 @@ class DecoderBlock(nn.Module, _Counted):
     def _units(self):
         return [self._u1, self._u2, self._ud0, self._ud3]
 
-    def forward(self, x, skip=None):
-        x = self._u2(self._u1(x))
-        x_mask = self._ud3(self._ud0(x))
-        ph = self.predictor_head
-        x_pro, x_pre = Fn2.ProjHeadFn.apply(x, self.bn.weight, self.bn.bias, ph[0].weight, ph[0].bias, ph[1].weight, ph[1].bias,
-                                            ph[3].weight, ph[3].bias, self)
-        return x, x_pro, x_pre, x_mask
+    def forward(self, x, skip=None, want_mask=True):
+        """-> (x, x_pro, x_pre, x_mask).  `want_mask` (engine hint, not in the reference): False leaves x_mask None -- the head's
+        convolution and BatchNorm2d statistics still run (the module's state is the reference's), see functions2d.DecoderBlockFn."""
+        c1, c2, ds, ph = self.conv1, self.conv2, self.deep_supervision_head, self.predictor_head
+        return Fn2.DecoderBlockFn.apply(x, c1[0].weight, c1[1].weight, c1[1].bias, c2[0].weight, c2[1].weight, c2[1].bias,
+                                        ds[0].weight, ds[0].bias, ds[1].weight, ds[1].bias, ds[3].weight, ds[3].bias,
+                                        self.bn.weight, self.bn.bias, ph[0].weight, ph[0].bias, ph[1].weight, ph[1].bias,
+                                        ph[3].weight, ph[3].bias, self, bool(want_mask))
 
 
 class PCRLv2Decoder(nn.Module):
@@ -220,17 +221,22 @@ class PCRLv2Decoder(nn.Module):
                                      for i, s, o in zip(in_channels, skip_channels, decoder_channels)])
         initialize_decoder(self.blocks)
 
-    def forward(self, features, local=False):
+    def forward(self, features, local=False, _mask_scales=None, _upsample=True):
         # NOTE (reference quirk, kept): PCRLv2.forward never passes `local`, so the deep-supervision maps are upsampled for the
         # local views too (pcrlv2_model.py:205) -- `local=True` only skips the segmentation head.
+        # Engine hints (not in the reference; PCRLv2.forward_engine): `_mask_scales` -- the block indices whose deep-supervision map is
+        # wanted (None: all five); `_upsample` False returns the maps at their own resolution (None where not wanted).
         features = features[1:][::-1]
         x = self.center(features[0])
         decoder_outs, middle_masks = [], []
         for i, block in enumerate(self.blocks):
-            x, x_pro, x_pre, x_mask = block(x, None)
+            want = _mask_scales is None or i in _mask_scales
+            x, x_pro, x_pre, x_mask = block(x, None, want_mask=want)
             decoder_outs.append((x_pro, x_pre))
-            if not local:
-                middle_masks.append(Fn2.BilinearFn.apply(x_mask, 2 ** (4 - i)))
+            if not _upsample:
+                middle_masks.append(x_mask)
+            elif not local:
+                middle_masks.append(Fn2.BilinearFn.apply(x_mask, 2 ** (4 - i)) if x_mask is not None else None)
         return decoder_outs, x, middle_masks
 
 
@@ -298,8 +304,7 @@ class PCRLv2(nn.Module):
         ops.bump_weights_epoch()
         return out
 
-    def forward(self, x, local=False):
-        """-> ([(pro, pre) x 5], masks [b,n_class,H,W] | None, [mask x 5])"""
+    def _begin_pass(self, x):
         if not self.training:
             raise NotImplementedError("PCRLv2 on the MI355X engine implements the pre-training (train-mode) path only")
         if not x.is_cuda:
@@ -309,9 +314,25 @@ class PCRLv2(nn.Module):
             u._pass_idx = pass_idx
         for b in self.model.decoder.blocks:
             b._pass_idx = pass_idx
+
+    def forward(self, x, local=False):
+        """-> ([(pro, pre) x 5], masks [b,n_class,H,W] | None, [mask x 5])"""
+        self._begin_pass(x)
         features = self.model.encoder(x)
         decoder_outputs, h, middle_masks = self.model.decoder(features)
         masks = None
         if not local:
             masks = self._seg(h)
         return decoder_outputs, masks, middle_masks
+
+    def forward_engine(self, x, mask_scale=None):
+        """The training step's form of forward (train_2d.step_losses; not in the reference): everything with STATE runs exactly as in
+        forward() -- every convolution in front of a BatchNorm, every BatchNorm1d of the heads -- but what has neither state nor a consumer
+        in train_2d.py:139-168 is not computed: the segmentation head (its loss is taken by functions2d.SegMSEFn from the returned decoder
+        output), the bilinear upsampling, and the deep-supervision maps of every scale but `mask_scale` (the scale the first cos_loss
+        draws; None: no map at all -- the second view and the local views, whose maps the reference computes and never reads).
+        -> ([(pro, pre) x 5], decoder output (activation), deep-supervision map of `mask_scale` at its own resolution | None)"""
+        self._begin_pass(x)
+        features = self.model.encoder(x)
+        decoder_outputs, h, low = self.model.decoder(features, _mask_scales=() if mask_scale is None else (mask_scale,), _upsample=False)
+        return decoder_outputs, h, (low[mask_scale] if mask_scale is not None else None)

@@ -645,12 +645,13 @@ def bn_pool_ok(D, H, W, C, dtype) -> bool:
     return bool(lib().call("pcrl_bn_act_bwd_pool_ok", D, H, W, C, dtype_code(dtype)))
 
 
-def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, row_g=None, pool_dp=None):
+def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, row_g=None, pool_dp=None, da2=None):
     """-> (dy, dgamma, dbeta): gradient w.r.t. the pre-normalisation tensor and the affine parameters.
     `row_g` (float32 [N, C]): the incoming gradient is da + row_g[n] / S broadcast over the S = M / N voxels of a sample (the
     global-average-pool branch, folded into both passes instead of materialised by gap_backward); `da` may then be None.
     `pool_dp` (activation [N, C, D/2, H/2, W/2]): the activation was consumed through MaxPool3d(2) only and THIS is the gradient of
-    the pooled tensor (da must be None): max_pool3d_backward happens inside the two passes."""
+    the pooled tensor (da must be None): max_pool3d_backward happens inside the two passes.
+    `da2`: a second gradient tensor of da's shape added to it inside both passes (two consumers of the activation; pcrl_bn_act_bwd_*_sum)."""
     L, s, dev = lib(), stream_handle(), y.device
     if pool_dp is not None:
         N, D, H, W, _ = dims(y)
@@ -660,7 +661,10 @@ def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, ro
     else:
         rows = L.call("pcrl_bn_bwd_partial_rows", M)
         partial = _f32(rows * C * 2, dev)
-        if row_g is not None:
+        if da2 is not None:
+            N = row_g.shape[0] if row_g is not None else 1
+            L.call("pcrl_bn_act_bwd_reduce_sum", da, da2, row_g, N, M // N, y, scale, shift, mean, rstd, partial, M, C, act, dtype_code(dtype), s)
+        elif row_g is not None:
             N = row_g.shape[0]
             L.call("pcrl_bn_act_bwd_reduce_rowadd", da, row_g, N, M // N, y, scale, shift, mean, rstd, partial, M, C, act, dtype_code(dtype), s)
         else:
@@ -671,6 +675,8 @@ def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, ro
     dy = torch.empty_like(y)
     if pool_dp is not None:
         L.call("pcrl_bn_act_bwd_apply_pool", pool_dp, y, dy, scale, shift, k1, kB, kA, N, D, H, W, C, act, dtype_code(dtype), s)
+    elif da2 is not None:
+        L.call("pcrl_bn_act_bwd_apply_sum", da, da2, row_g, N, M // N, y, dy, scale, shift, k1, kB, kA, M, C, act, dtype_code(dtype), s)
     elif row_g is not None:
         L.call("pcrl_bn_act_bwd_apply_rowadd", da, row_g, row_g.shape[0], M // row_g.shape[0], y, dy, scale, shift, k1, kB, kA, M, C, act,
                dtype_code(dtype), s)
@@ -1232,6 +1238,14 @@ def linear_forward(x, w, b):
     y = _f32(rows * Cout, x.device).view(rows, Cout)
     lib().call("pcrl_linear_fwd", x, w.detach(), b.detach(), y, rows, Cin, Cout, stream_handle())
     return y
+
+
+def add2_small(a, b):
+    """a + b for two float32 tensors of one shape (head-sized matrices), on the library's kernel instead of aten::add."""
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty_like(a)
+    lib().call("pcrl_add_f32", a, b, out, a.numel(), stream_handle())
+    return out
 
 
 def linear_backward(dy, x, w):

@@ -213,8 +213,84 @@ def gap_forward(a, dtype):
     return g
 
 
-def gap_backward(dg, like, dtype):
+def gap_backward(dg, like, dtype, add_src=None):
+    """da = add_src + dg / (H*W) broadcast over the pixels (add_src may be None)."""
     N, H, W, C = dims2(like)
     da = torch.empty_like(like)
-    lib().call("pcrl_gap_bwd", dg.contiguous(), None, da, N, H * W, C, dtype_code(dtype), stream_handle())
+    lib().call("pcrl_gap_bwd", dg.contiguous(), add_src, da, N, H * W, C, dtype_code(dtype), stream_handle())
     return da
+
+
+# ----------------------------------------------------------------------------------------------
+# the 3-channel ends of the step (csrc/heads2d.hip)
+# ----------------------------------------------------------------------------------------------
+def _nhwc_f32(p):
+    """An [N,C,H,W] float32 tensor in NHWC memory (what the segmentation / deep-supervision heads write), as is or converted."""
+    return to_act2(p, torch.float32)
+
+
+def _nchw_f32(gt, device):
+    gt = gt.to(device=device, dtype=torch.float32)
+    return gt if gt.is_contiguous() else gt.contiguous()
+
+
+def mse2d_forward(p, gt):
+    """nn.MSELoss()(p, gt): p float32 [N,C,H,W] in NHWC memory, gt float32 [N,C,H,W] contiguous (the loader's layout).  -> 0-d loss"""
+    L = lib()
+    N, H, W, C = dims2(p)
+    loss = ops._f32(1, p.device)
+    nb = L.call("pcrl_mse2d_ws_bytes", N * H * W)
+    L.call("pcrl_mse2d_fwd", p, gt, loss, ops.workspace(nb, p.device), nb, N, H * W, C, stream_handle())
+    return loss.view(())
+
+
+def mse2d_backward(p, gt, dloss, CP, dtype):
+    """d loss / d p as `dtype` [N,CP,H,W] in NHWC memory (channels C..CP-1 zero) + its per-channel sums float32 [C] (the bias gradient of the
+    convolution that produced p)."""
+    L = lib()
+    N, H, W, C = dims2(p)
+    M = N * H * W
+    dy = new_act2(N, H, W, CP, dtype, p.device)
+    rows = L.call("pcrl_rows1024", M)
+    colpart = ops._f32(rows * CP, p.device)
+    L.call("pcrl_mse2d_bwd_pad", p, gt, dloss.detach().reshape(1).float(), dy, colpart, N, H * W, C, CP, dtype_code(dtype), stream_handle())
+    return dy, colpart, rows
+
+
+def colsum_f32(partial, rows, C):
+    """float32 [C] column sums of a float32 [rows][C] matrix (second stage of the block partials above)."""
+    L = lib()
+    out = ops._f32(C, partial.device)
+    nb = L.call("pcrl_colsum_ws_bytes", rows, C)
+    L.call("pcrl_colsum", partial, out, ops.workspace(nb, partial.device), nb, rows, C, dtype_code(torch.float32), stream_handle())
+    return out
+
+
+def conv1x1_small_backward(x, dy, w, dtype):
+    """Backward of nn.Conv2d(Ci, 3, 1) (deep_supervision_head[3], pcrlv2_model.py:106) in one pass: x `dtype` NHWC [N,Ci,H,W], dy float32 NHWC
+    [N,3,H,W], w float32 [3,Ci,1,1] -> (dx like x, dw float32 [3,Ci,1,1], db float32 [3])."""
+    L = lib()
+    N, H, W, Ci = dims2(x)
+    M = N * H * W
+    Co = w.shape[0]
+    rows = L.call("pcrl_rows1024", M)
+    width = Co * Ci + Co
+    PW = 4
+    while PW < width:       # pcrl_colsum takes float32 rows of 4 * 2^k columns
+        PW *= 2
+    part = ops._f32(rows * PW, x.device)
+    dx = torch.empty_like(x)
+    L.call("pcrl_conv2d_1x1_small_bwd", x, dy, w.detach(), dx, part, M, Ci, Co, PW, dtype_code(dtype), stream_handle())
+    tot = colsum_f32(part, rows, PW)
+    return dx, tot[:Co * Ci].view(Co, Ci, 1, 1), tot[Co * Ci:width]
+
+
+def image_to_act(x, dtype, CP=8):
+    """The network input: float32 NCHW [N,3,H,W] -> `dtype` NHWC [N,CP,H,W] with zero padding channels, one launch (the stem's gather wants a
+    power-of-two channel count; was torch.zeros + a strided copy)."""
+    N, C, H, W = x.shape
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C <= CP):
+        return to_act2(x, dtype, pad_to=CP)
+    out = new_act2(N, H, W, CP, dtype, x.device)
+    lib().call("pcrl_nchw_to_nhwc_pad", x, out, N, C, H * W, CP, dtype_code(dtype), stream_handle())
+    return out

@@ -58,6 +58,7 @@ class FusedSGD(torch.optim.SGD):
             p._pcrl_gslot = (self, i)
         self._initialised = [False] * len(self._plist)
         self._flag_cache = {}
+        self._flag_ring = None
         self.grad_scale = 1.0          # set to 1/world_size by the data-parallel wrapper
         self.pre_step = None           # optional callable(self, None) -> has-grad list: replaces the gradient gather (ddp.DataParallel)
         self.skip_flag = None          # float32[1] on the device, consumed by the NEXT step(): non-zero = leave parameters and momentum untouched
@@ -74,12 +75,28 @@ class FusedSGD(torch.optim.SGD):
         return has
 
     def _flags(self, has):
+        """int32 per parameter (bit 0: has a gradient, bit 1: momentum buffer initialised) on the device.  Patterns are cached; a NEW pattern
+        (the 2D step has 160 of them: which scales the 13 draws picked) is staged in a pinned host slot and copied asynchronously on the
+        current stream -- `torch.tensor(vals, device=...)` is a pageable-memory copy, which the runtime completes only after everything
+        queued before it: a host stall of the whole backward (14 ms per 2D step, tools/host_probe_2d.py).  A slot is reused after
+        `len(ring)` further misses; the host never runs more than config.MAX_STEPS_AHEAD steps ahead of the device, and the ring is deeper."""
         key = (tuple(has), tuple(self._initialised))
         t = self._flag_cache.get(key)
         if t is None:
             vals = [(1 if h else 0) | (2 if i else 0) for h, i in zip(has, self._initialised)]
-            t = torch.tensor(vals, dtype=torch.int32, device=self.flat_p.device)
-            if len(self._flag_cache) > 64:
+            if self._flag_ring is None:
+                self._flag_ring = [torch.empty(len(vals), dtype=torch.int32).pin_memory() for _ in range(8)]
+                self._flag_ring_ev = [None] * 8
+                self._flag_ring_pos = 0
+            k = self._flag_ring_pos = (self._flag_ring_pos + 1) % len(self._flag_ring)
+            if self._flag_ring_ev[k] is not None:
+                self._flag_ring_ev[k].synchronize()       # the copy that last read this slot (long done: 8 misses ago)
+            self._flag_ring[k].copy_(torch.tensor(vals, dtype=torch.int32))
+            t = self._flag_ring[k].to(self.flat_p.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._flag_ring_ev[k] = ev
+            if len(self._flag_cache) > 256:
                 self._flag_cache.clear()
             self._flag_cache[key] = t
         return t

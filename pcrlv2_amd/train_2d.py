@@ -12,6 +12,7 @@ from __future__ import print_function
 
 import math
 import os
+import random
 import sys
 import time
 
@@ -19,11 +20,12 @@ import torch
 
 from . import config as _cfg
 from . import ddp as _ddp
+from . import functions as _fn
 from . import ops as _ops
-from .functions2d import mse_loss2d
+from .functions2d import MaskMSEFn, SegMSEFn, mse_loss2d
 from .models.pcrlv2_model import PCRLv2
 from .optim import FusedSGD
-from .train_3d import BETA_PERIOD, CosineSimilarityMean, _to_gpu, cos_loss, seed_everything  # noqa: F401  (cos_loss: train_2d.py:111-117)
+from .train_3d import BETA_PERIOD, COS_MAX_TERMS, CosineSimilarityMean, _fused_cos_losses, _to_gpu, cos_loss, seed_everything  # noqa: F401  (cos_loss: train_2d.py:111-117)
 from .utils import AverageMeter, adjust_learning_rate
 
 
@@ -37,13 +39,42 @@ class MSELoss2d:
         return mse_loss2d(pred, target)
 
 
+FUSED_STEP_2D = os.environ.get("PCRL_FUSED_STEP_2D", "1") != "0"     # A/B switch: 0 = the round-3 step (one launch per cosine mean, every map computed)
+
+
 def step_losses(model, batch, epoch, criterion, cosine):
-    """Forward half of one iteration (train_2d.py:139-168).  -> (total, restoration, global-cosine, deep-supervision, local-cosine)"""
+    """Forward half of one iteration (train_2d.py:139-168).  -> (total, restoration, global-cosine, deep-supervision, local-cosine)
+
+    Engine form (our PCRLv2, our criterion / cosine objects): the 13 scale draws are taken from python's `random` FIRST -- the same 13
+    `randint(0, 4)` calls in the same order as the reference's cos_loss calls (global pair; then for every local view (view 1, local_i),
+    (view 2, local_i)); nothing in between consumes `random` -- so that the forwards know which deep-supervision map the step reads
+    (masks1[scale of the first draw]) and skip the stateless work nobody reads (PCRLv2.forward_engine); all 26 cosine means in one launch,
+    the local views concatenated in one launch, both restoration terms against the NCHW image without a layout copy, the total in one."""
     view1, view2, target, _unused_gt2, local_views = batch
     n = view1.size(0)
     target = _to_gpu(target)
     view1, view2 = _to_gpu(view1), _to_gpu(view2)
+    nl = len(local_views)
+    fused = (FUSED_STEP_2D and isinstance(model, PCRLv2) and isinstance(criterion, MSELoss2d) and getattr(cosine, "fusable", False)
+             and 2 + 4 * nl <= COS_MAX_TERMS)
     _ops.fork_views(view1.device, path2d=True)     # config.VIEW_STREAMS_2D: the second view's forward (and backward) on its own stream
+    if fused:
+        ns = len(model.model.decoder.blocks)
+        draws = [random.randint(0, ns - 1) for _ in range(1 + 2 * nl)]
+        scale = draws[0]
+        feats1, h1, low1 = model.forward_engine(view1, mask_scale=scale)
+        with _ops.view_pass(view2.device, view2, path2d=True):
+            feats2, _, _ = model.forward_engine(view2)
+        loc = _ops.concat_batch([_to_gpu(v) for v in local_views])
+        feats_loc, _, _ = model.forward_engine(loc)
+        _ops.join_side_stream()                    # the cosine terms read both views' features on the main stream
+        l_global, l_local, _ = _fused_cos_losses(feats1, feats2, feats_loc, n, nl, draws=draws)
+        seg = model.model.segmentation_head[0]
+        l_restore = SegMSEFn.apply(h1, seg.weight, seg.bias, target, model._seg)
+        l_deep_raw = MaskMSEFn.apply(low1, target, 2 ** (ns - 1 - scale))
+        beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
+        total, l_deep = _fn.loss_total(l_restore, l_global, l_deep_raw, l_local, beta)
+        return total, l_restore, l_global, l_deep, l_local
     feats1, mask1, masks1 = model(view1)
     with _ops.view_pass(view2.device, view2, path2d=True):
         feats2, _mask2, _ = model(view2)
@@ -64,6 +95,8 @@ def step_losses(model, batch, epoch, criterion, cosine):
 
 
 def train_step(model, optimizer, batch, epoch, criterion, cosine):
+    _ops.begin_step()
+    _fn.reset_parked()
     dev = next(model.parameters()).device
     _ops.throttle_host(dev)      # at most config.MAX_STEPS_AHEAD steps of host run-ahead (allocator footprint, see config.py)
     losses = step_losses(model, batch, epoch, criterion, cosine)
@@ -71,6 +104,8 @@ def train_step(model, optimizer, batch, epoch, criterion, cosine):
     losses[0].backward()
     optimizer.step()
     _ops.throttle_host(dev, step_done=True)
+    # first complete step of this batch shape: size the allocator's per-stream pools for the steady state, once (ops.provision_allocator)
+    _ops.provision_allocator(dev, key=("2d", tuple(batch[0].shape), len(batch[4])))
     return tuple(l.detach() for l in losses)
 
 

@@ -92,7 +92,7 @@ def _to_gpu(t):
     return t.float().cuda(non_blocking=True)
 
 
-def _fused_cos_losses(feats1, feats2, feats_loc, n, nlocal):
+def _fused_cos_losses(feats1, feats2, feats_loc, n, nlocal, draws=None):
     """The 13 cos_loss calls of train_3d.py:119-134 as ONE launch: the scales are drawn from python's `random` in the reference's
     order (global pair; then for every local view (view 1, local_i), (view 2, local_i)), the 26 cosine means and their weights
     (-1/2 per call; /(2 * nlocal) for the local group) go to pcrl_cosine_terms_*.  -> (global term, local term, first drawn scale)."""
@@ -108,12 +108,14 @@ def _fused_cos_losses(feats1, feats2, feats_loc, n, nlocal):
         spec.append((idx[a, k, 1], ra, idx[b, k, 0], rb, -0.5 * w, g))
         spec.append((idx[b, k, 1], rb, idx[a, k, 0], ra, -0.5 * w, g))
 
-    k0 = random.randint(0, ns - 1)
+    # `draws`: the 1 + 2 * nlocal scales already taken from `random` in this order (train_2d.step_losses draws before the forwards)
+    nxt = iter(draws).__next__ if draws is not None else (lambda: random.randint(0, ns - 1))
+    k0 = nxt()
     add("1", 0, "2", 0, k0, 1.0, 0)
     wl = 1.0 / (2 * nlocal)
     for i in range(nlocal):
-        add("1", 0, "L", n * i, random.randint(0, ns - 1), wl, 1)
-        add("2", 0, "L", n * i, random.randint(0, ns - 1), wl, 1)
+        add("1", 0, "L", n * i, nxt(), wl, 1)
+        add("2", 0, "L", n * i, nxt(), wl, 1)
     out = _fn.cosine_terms(spec, n, 2, tensors)
     return out[0], out[1], k0
 

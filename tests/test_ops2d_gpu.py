@@ -195,3 +195,110 @@ def test_conv2d_brick_path(Ci, Co, up, H, W, N):
         outs[impl] = (y.float().cpu(), dx.float().cpu())
     # same operands, same fp32 accumulation: the two kernels differ only in summation order
     assert (outs[0][0] - outs[1][0]).abs().max() <= 0.02 * outs[1][0].abs().max()
+
+
+# ---- round 4: the 3-channel ends of the step (csrc/heads2d.hip) and the summed-gradient BatchNorm backward ----------------------------
+@pytest.mark.parametrize("N,H,W", [(2, 16, 24), (3, 37, 29), (1, 64, 64)])
+def test_mse2d_against_torch(N, H, W):
+    """pcrl_mse2d_fwd / _bwd_pad: NHWC float32 prediction against the NCHW image -- loss, the padded gradient (bf16 / f32, CP = 8; f32 CP = 3)
+    and its per-channel sums."""
+    from pcrlv2_amd import ops2d
+    g = torch.Generator().manual_seed(N * H + W)
+    p = torch.randn(N, 3, H, W, generator=g, dtype=torch.float64)
+    gt = torch.rand(N, 3, H, W, generator=g, dtype=torch.float64)
+    pa = ops2d.to_act2(p.float().to(_dev()), torch.float32)
+    gd = gt.float().to(_dev())
+    loss = ops2d.mse2d_forward(pa, gd)
+    pr = p.float().double().requires_grad_(True)
+    ref = F.mse_loss(pr, gt.float().double())
+    assert abs(float(loss) - float(ref.detach())) < 1e-6 * max(1.0, float(ref.detach()))
+    dl = torch.tensor(0.7, device=_dev())
+    (ref * 0.7).backward()
+    for dt, CP, tol in ((torch.float32, 3, 2e-6), (torch.float32, 8, 2e-6), (torch.bfloat16, 8, 5e-3)):
+        dy, colpart, rows = ops2d.mse2d_backward(pa, gd, dl, CP, dt)
+        assert tuple(dy.shape) == (N, CP, H, W) and dy.dtype == dt
+        _close(dy[:, :3], pr.grad, torch.float32, f"mse2d bwd {dt} CP={CP}", f32_tol=tol)
+        if CP > 3:
+            assert float(dy[:, 3:].abs().max()) == 0.0
+            sums = ops2d.colsum_f32(colpart, rows, CP)
+            assert float(sums[3:].abs().max()) == 0.0
+            _close(sums[:3], dy[:, :3].double().sum((0, 2, 3)).cpu(), torch.float32, "bias sums = sums of the stored (rounded) gradient", f32_tol=2e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("Ci,N,H,W", [(16, 2, 32, 32), (32, 2, 24, 40), (64, 3, 16, 16), (256, 2, 8, 8), (128, 1, 5, 7)])
+def test_conv1x1_to3_backward_one_pass(Ci, N, H, W, dt):
+    """pcrl_conv2d_1x1_small_bwd: dx, dw, db of nn.Conv2d(Ci, 3, 1) from one pass, against float64 autograd."""
+    from pcrlv2_amd import ops2d
+    g = torch.Generator().manual_seed(Ci + H)
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(3, Ci, 1, 1, generator=g) / Ci ** 0.5
+    dy = torch.randn(N, 3, H, W, generator=g)
+    xa = ops2d.to_act2(x.to(_dev()), dt)
+    dya = ops2d.to_act2(dy.to(_dev()), torch.float32)
+    dx, dw, db = ops2d.conv1x1_small_backward(xa, dya, w.to(_dev()), dt)
+    xr, wr = _q(x, dt).requires_grad_(True), w.double().requires_grad_(True)
+    br = torch.zeros(3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xr, wr, br).backward(dy.double())
+    _close(dx, xr.grad, dt, "1x1 -> 3 dgrad", bf_tol=6e-3)
+    _close(dw, wr.grad, torch.float32, "1x1 -> 3 wgrad", f32_tol=2e-5)
+    _close(db, br.grad, torch.float32, "1x1 -> 3 bias grad", f32_tol=2e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_image_to_act_pads_and_transposes(dt):
+    from pcrlv2_amd import ops2d
+    x = torch.randn(3, 3, 20, 28)
+    got = ops2d.image_to_act(x.to(_dev()), dt, 8)
+    assert tuple(got.shape) == (3, 8, 20, 28) and got.dtype == dt
+    ops2d.dims2(got)     # NHWC memory
+    assert torch.equal(got[:, :3].float().cpu(), x.to(dt).float())
+    assert float(got[:, 3:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("parts", ["da+da2", "da+da2+row", "da2+row", "da+row"])
+@pytest.mark.parametrize("C,N,S", [(16, 4, 96), (64, 3, 40), (256, 2, 64)])
+def test_bn_backward_of_a_summed_gradient(C, N, S, parts, dt):
+    """pcrl_bn_act_bwd_{reduce,apply}_sum: the BatchNorm backward fed with da + da2 + row_g / S in parts equals the backward fed with the
+    materialised sum (same kernels, one tensor): dy to one ulp of the storage type, dgamma / dbeta to float32 round-off."""
+    from pcrlv2_amd import ops
+    from pcrlv2_amd._lib import ACT_RELU
+    g = torch.Generator().manual_seed(C + S)
+    M = N * S
+    dev = _dev()
+    y = torch.randn(M, C, generator=g).to(dev).to(dt)
+    da = torch.randn(M, C, generator=g).to(dev).to(dt)
+    da2 = torch.randn(M, C, generator=g).to(dev).to(dt)
+    row = torch.randn(N, C, generator=g).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    mean = y.float().mean(0)
+    var = y.float().var(0, unbiased=False)
+    rstd = torch.rsqrt(var + 1e-5)
+    scale = gamma * rstd
+    shift = 0.1 - mean * scale
+    use_da, use_da2, use_row = "da+" in parts or parts.startswith("da+"), "da2" in parts, "row" in parts
+    use_da = parts.split("+")[0] == "da"
+    full = torch.zeros(M, C, device=dev)
+    if use_da:
+        full += da.float()
+    if use_da2:
+        full += da2.float()
+    if use_row:
+        full += (row / S).repeat_interleave(S, dim=0)
+    args = (gamma, mean, rstd, scale, shift, M, C, ACT_RELU)
+    # reference: float64 BatchNorm backward of the exact sum (what the kernels accumulate in float32 from the parts)
+    yd, fd = y.double(), full.double()
+    z = scale.double() * yd + shift.double()
+    dz = torch.where(z > 0, fd, torch.zeros_like(fd))
+    xhat = (yd - mean.double()) * rstd.double()
+    dbeta_ref, dgamma_ref = dz.sum(0), (dz * xhat).sum(0)
+    dy_ref = gamma.double() * rstd.double() * (dz - dbeta_ref / M - xhat * dgamma_ref / M)
+    a = da if use_da else None
+    b = da2 if use_da2 else None
+    if a is None:
+        a, b = b, None
+    dy, dgamma, dbeta = ops.bn_act_backward(a, y, *args, dt, row_g=row if use_row else None, da2=b)
+    _close(dy, dy_ref.cpu(), dt, "dy", f32_tol=2e-5, bf_tol=6e-3)
+    _close(dgamma, dgamma_ref.cpu(), torch.float32, "dgamma", f32_tol=1e-4)
+    _close(dbeta, dbeta_ref.cpu(), torch.float32, "dbeta", f32_tol=1e-4)
