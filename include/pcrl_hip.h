@@ -472,6 +472,25 @@ void pcrl_debug_set_wgrad_tr(int on);
 void pcrl_debug_set_conv2d_impl(int impl);
 
 /* ---------------------------------------------------------------------------------------
+ * 2D path, fused passes of the ResNet-18 encoder (csrc/encoder2d.hip): each replaces a chain of separate passes over one tensor and
+ * reproduces the chain's values bit for bit (intermediates the chain stored are rounded to `dtype` here too).
+ *   bn_add_relu_fwd      : out = relu(T(scale*y + shift) + i), i = r (identity) or T(rscale*r + rshift) (the downsample branch's
+ *                          BatchNorm2d; rscale / rshift both NULL or both given) -- torchvision BasicBlock.forward's
+ *                          `out = self.bn2(out); out += identity; out = self.relu(out)` (aten::native_batch_norm's apply half, add_, relu_)
+ *   relu_mask_sum_bwd    : g = T(da + db) where a > 0, else 0 -- the two gradients that reach a BasicBlock's output (next block's conv1
+ *                          branch and identity branch) summed and masked (aten::add + aten::threshold_backward)
+ *   bn_relu_maxpool2d_3s2_fwd : p, idx = MaxPool2d(3, 2, 1)(T(relu(scale*y + shift))) from one pass over the stem convolution's output
+ *                          (the full-resolution activation has no other consumer on the training path); idx as pcrl_maxpool2d_3s2_fwd
+ *   maxpool2d_3s2_bwd_sum: pcrl_maxpool2d_3s2_bwd of T(dy + dy2) (the pooled tensor feeds layer1.0's conv1 and its identity branch) */
+int pcrl_bn_add_relu_fwd(const void* y, const float* scale, const float* shift, const void* r, const float* rscale, const float* rshift,
+                         void* out, int64_t M, int C, int dtype, pcrl_stream_t stream);
+int pcrl_relu_mask_sum_bwd(const void* da, const void* db, const void* a, void* g, int64_t n, int dtype, pcrl_stream_t stream);
+int pcrl_bn_relu_maxpool2d_3s2_fwd(const void* y, const float* scale, const float* shift, void* p, uint8_t* idx, int N, int H, int W, int C,
+                                   int dtype, pcrl_stream_t stream);
+int pcrl_maxpool2d_3s2_bwd_sum(const void* dy, const void* dy2, const uint8_t* idx, void* dx, int N, int H, int W, int C, int dtype,
+                               pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * 2D path, the 3-channel ends of the step (csrc/heads2d.hip).
  * pcrl_mse2d_fwd / _bwd_pad -- nn.MSELoss()(masks, gt) at train_2d.py:165,167 with the prediction in NHWC memory (float32 [N][HW][C], what
  *   the segmentation / deep-supervision heads write) and the target as the loader delivers it (float32 NCHW [N][C][HW]): no layout copy of

@@ -502,7 +502,15 @@ __global__ void __launch_bounds__(256) wgrad2d_reduce_kernel(const float* __rest
     const int t = (int)(r % taps), co = (int)(r / taps);
     const float* src = ws + ((int64_t)co * taps + t) * CiP + ci;
     dst = ((int64_t)co * Ci_out + ci) * taps + t;
-    for (int z = zg; z < splits; z += ZG) a += (double)src[(int64_t)z * per];
+    // four independent partial sums per thread (a fixed tree: deterministic): the walk over the slabs is a chain of dependent round trips otherwise
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int z = zg;
+    for (; z + 3 * ZG < splits; z += 4 * ZG) {
+      const float v0 = src[(int64_t)z * per], v1 = src[(int64_t)(z + ZG) * per], v2 = src[(int64_t)(z + 2 * ZG) * per], v3 = src[(int64_t)(z + 3 * ZG) * per];
+      a += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+    }
+    for (; z < splits; z += ZG) a += (double)src[(int64_t)z * per];
+    a = (a + a1) + (a2 + a3);
   }
   part[zg][o] = a;
   __syncthreads();

@@ -9,7 +9,7 @@
 // x halo [10 x 34 px][CV] in LDS ONCE, and each wave multiplies two 32-pixel rows (the K dimension) for all nine taps:
 // CU/16 A fragments (dy, transpose reads) x 9 taps x CV/16 B fragments (x at the tap's shifted position, transpose reads).
 // Accumulators (CU/16 x 9 x CV/16 fragments) stay in registers over the block's whole patch range; every WAVE writes its own
-// partial slab, summed in fixed order by wgrad2d_reduce_kernel (conv_wgrad.hip).
+// partials in the block (fixed order) and the block writes one slab, summed in fixed order by wgrad2d_reduce_kernel (conv_wgrad.hip).
 #include "common.h"
 
 namespace {
@@ -20,7 +20,7 @@ constexpr int NPX = PH * PW, NHP = HPH * HPW;                // 256 patch pixels
 struct NarrowParams {
   const bf16* dy;   // [N][H][W][CU]
   const bf16* x;    // [N][Hs][Ws][CV]   (Hs = H, or H/2 when up)
-  float* ws;        // [blocks * 4][CU][9 * CV]
+  float* ws;        // [blocks][CU][9 * CV]
   int N, H, W, up;
   int npatch, per;
   int xpitch, cbase;   // x row pitch in channels (CiP) and the first of the CV input channels this launch handles (CiP = 64: two launches)
@@ -128,8 +128,42 @@ __global__ void __launch_bounds__(256) wgrad2d_narrow_kernel(const NarrowParams 
 #undef NW_LOAD
 #undef NW_STORE
 
+  // The four waves' accumulators are summed inside the block -- ((w0 + w1) + w2) + w3, through LDS one wave at a time (the staging tiles are
+  // free now) -- and the block leaves ONE partial slab: the second pass reads a quarter of the bytes (it was 54-138 us per full-resolution layer,
+  // latency-bound on 4 096 slabs).
+  constexpr int NACC = FA * 9 * FB * 4;
+  static_assert(NACC * 64 * 4 <= DY_BYTES + X_BYTES, "the wave-combine buffer must fit the staging tiles");
+  float* comb = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+  for (int src = 1; src < 4; ++src) {
+    if (wid == src) {
+      int e = 0;
+#pragma unroll
+      for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int b = 0; b < FB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r, ++e) comb[e * 64 + lane] = acc[a][t][b][r];
+    }
+    __syncthreads();
+    if (wid == 0) {
+      int e = 0;
+#pragma unroll
+      for (int a = 0; a < FA; ++a)
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int b = 0; b < FB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r, ++e) acc[a][t][b][r] += comb[e * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wid != 0) return;
   // D[i][j]: lane holds i = 16 a + 4 (lane >> 4) + r (co), j = 16 b + (lane & 15) (ci) of tap t
-  float* out = p.ws + ((int64_t)blockIdx.x * 4 + wid) * (CU * 9 * p.xpitch) + p.cbase;
+  float* out = p.ws + (int64_t)blockIdx.x * (CU * 9 * p.xpitch) + p.cbase;
 #pragma unroll
   for (int a = 0; a < FA; ++a)
 #pragma unroll
@@ -160,7 +194,7 @@ bool pcrl_wgrad2d_narrow_eligible(int N, int H, int W, int CiP, int CoP, int dty
   return dtype == PCRL_BF16 && (CiP == 16 || CiP == 32 || CiP == 64) && (CoP == 8 || CoP == 16 || CoP == 32) && H % PH == 0 && W % PW == 0 &&
          (int64_t)N * H * W * 32 < ((int64_t)1 << 40);
 }
-int pcrl_wgrad2d_narrow_slabs(int N, int H, int W) { return 4 * narrow_plan((int)((int64_t)N * (H / PH) * (W / PW))).blocks; }
+int pcrl_wgrad2d_narrow_slabs(int N, int H, int W) { return narrow_plan((int)((int64_t)N * (H / PH) * (W / PW))).blocks; }
 
 int pcrl_wgrad2d_narrow_launch(const void* x, const void* dy, float* ws, int N, int H, int W, int CiP, int CoP, int up, hipStream_t stream) {
   const int npatch = (int)((int64_t)N * (H / PH) * (W / PW));

@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from . import config, ops, ops2d
-from ._lib import ACT_RELU, dtype_code, lib, stream_handle
+from ._lib import ACT_NONE, ACT_RELU, dtype_code, lib, stream_handle
 from .functions import _park, mark_final
 
 
@@ -183,6 +183,116 @@ class ProjHeadFn(Function):
         grads[0], grads[1] = g_bng, g_bnb
         d_a = ops2d.gap_backward(d_g, ctx.a, ctx.dt)
         out = (d_a,) + tuple(_park(p, gr) for p, gr in zip(ctx.plist, grads)) + (None,)
+        mark_final(ctx, ctx.plist)
+        return out
+
+
+FUSED_ENCODER = __import__("os").environ.get("PCRL_FUSED_ENCODER_2D", "1") != "0"   # A/B switch (bit-identical results): 0 = one autograd node per unit
+
+
+class EncoderFn(Function):
+    """smp ResNetEncoder('resnet18').forward (torchvision ResNet-18 without fc; models/pcrlv2_model.py:200) down to its LAST feature map --
+    the only one the decoder reads (the skips are ignored, :115-117) -- as ONE autograd node.  As separate nodes every BasicBlock left
+    autograd a two-way sum at its input (conv1 branch + identity branch): 24 full-tensor aten::add launches per C5 step, next to 24 add+relu
+    and 24 mask passes.  Here: BatchNorm apply + identity add + ReLU in one pass (pcrl_bn_add_relu_fwd), the two gradients of a block's output
+    summed inside the mask pass (pcrl_relu_mask_sum_bwd) or inside the max-pool backward (pcrl_maxpool2d_3s2_bwd_sum), and the stem's
+    BatchNorm apply + ReLU + MaxPool2d(3, 2, 1) from one pass over the convolution output (the full-resolution stem activation is never
+    stored).  Values are those of the per-unit chain bit for bit (config switch PCRL_FUSED_ENCODER_2D; tests/test_model2d_gpu.py).
+
+    inputs : image (float32 NCHW), encoder module, then [conv.weight, bn.weight, bn.bias] of every unit in ResNetEncoder._units() order
+    output : layer4's output (activation)"""
+
+    @staticmethod
+    def forward(ctx, x, enc, *params):
+        units = enc._units()
+        dt = units[0].compute_dtype
+        L = lib()
+        P = [params[3 * i:3 * i + 3] for i in range(len(units))]
+        pi = {id(u): k for k, u in enumerate(units)}
+
+        def conv_bn(xin, u):
+            w, g, be = P[pi[id(u)]]
+            y, partial, rows = ops2d.conv2d_forward(xin, w, None, u._packed, u.stride, u.pad, 0, dt)
+            N, H, W, C = ops2d.dims2(y)
+            bn = u.bn_module
+            coef = ops.bn_finalize(partial, rows, C, N * H * W, g.detach(), be.detach(), bn.running_mean, bn.running_var)
+            u._count_batch()
+            return y, coef
+
+        img = ops2d.image_to_act(x, dt, 8)
+        y0, c0 = conv_bn(img, enc._stem)
+        N, H, W, C = ops2d.dims2(y0)
+        Ho, Wo = ops2d.out_size(H, 3, 2, 1), ops2d.out_size(W, 3, 2, 1)
+        h = ops2d.new_act2(N, Ho, Wo, C, dt, y0.device)
+        idx = torch.empty((N, Ho, Wo, C), dtype=torch.uint8, device=y0.device)
+        L.call("pcrl_bn_relu_maxpool2d_3s2_fwd", y0, c0[2], c0[3], h, idx, N, H, W, C, dtype_code(dt), stream_handle())
+        saved = []
+        for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
+            for blk in layer:
+                y1, c1 = conv_bn(h, blk._u1)
+                N, H, W, C = ops2d.dims2(y1)
+                M = N * H * W
+                a1 = ops.bn_act_apply(y1, c1[2], c1[3], M, C, ACT_RELU, dt)
+                y2, c2 = conv_bn(a1, blk._u2)
+                out = torch.empty_like(y2)
+                if blk._ud is not None:
+                    yd, cd = conv_bn(h, blk._ud)
+                    L.call("pcrl_bn_add_relu_fwd", y2, c2[2], c2[3], yd, cd[2], cd[3], out, M, C, dtype_code(dt), stream_handle())
+                else:
+                    yd = cd = None
+                    L.call("pcrl_bn_add_relu_fwd", y2, c2[2], c2[3], h, None, None, out, M, C, dtype_code(dt), stream_handle())
+                saved.append((blk, h, y1, c1, a1, y2, c2, yd, cd, M, C))
+                h = out
+        # the block outputs are needed by the mask passes: every one but the last is an intermediate (stashed as is); the last is this node's
+        # OUTPUT and goes through save_for_backward (an output on ctx is a reference cycle, see functions.UpStageFn)
+        ctx.outs = [s[1] for s in saved[1:]]
+        ctx.stem = (img, y0, c0, idx, ops2d.dims2(y0))
+        ctx.saved, ctx.units, ctx.P, ctx.pi, ctx.dt = saved, units, P, pi, dt
+        ctx.pass_idx = getattr(units[0], "_pass_idx", 1)
+        ctx.plist = tuple(params)
+        ctx.save_for_backward(h)
+        ctx.set_materialize_grads(False)
+        return h
+
+    @staticmethod
+    def backward(ctx, d_h):
+        n_in = 2 + len(ctx.plist)
+        if d_h is None:
+            return (None,) * n_in
+        dt, L, P, pi = ctx.dt, lib(), ctx.P, ctx.pi
+        (h_last,) = ctx.saved_tensors
+        outs = ctx.outs + [h_last]            # outs[k] = output of block k
+        grads = {}
+
+        def put(u, dw, dg, db):
+            k = pi[id(u)]
+            grads[3 * k], grads[3 * k + 1], grads[3 * k + 2] = dw, dg, db
+
+        def bn_conv_bwd(da, u, xin, y, c, M, C, act, need_dx=True):
+            w, g, _ = P[pi[id(u)]]
+            dy, dg, db = ops.bn_act_backward(da, y, g.detach(), c[0], c[1], c[2], c[3], M, C, act, dt)
+            dx, dw = ops2d.conv2d_backward(xin, dy, w, u._packed, u.stride, u.pad, 0, dt, need_dx=need_dx)
+            put(u, dw, dg, db)
+            return dx
+
+        g = ops2d.relu_mask_backward(ops2d.to_act2(d_h, dt), h_last, dt)
+        first, second = None, None
+        for k in range(len(ctx.saved) - 1, -1, -1):
+            blk, h_in, y1, c1, a1, y2, c2, yd, cd, M, C = ctx.saved[k]
+            d_a1 = bn_conv_bwd(g, blk._u2, a1, y2, c2, M, C, ACT_NONE)
+            Ci = h_in.shape[1]
+            Mi = h_in.numel() // Ci
+            first = bn_conv_bwd(d_a1, blk._u1, h_in, y1, c1, M, C, ACT_RELU)
+            second = bn_conv_bwd(g, blk._ud, h_in, yd, cd, M, C, ACT_NONE) if blk._ud is not None else g
+            if k > 0:
+                gp = torch.empty_like(first)
+                L.call("pcrl_relu_mask_sum_bwd", first, second, outs[k - 1], gp, first.numel(), dtype_code(dt), stream_handle())
+                g = gp
+        img, y0, c0, idx, (N, H, W, C) = ctx.stem
+        da0 = ops2d.new_act2(N, H, W, C, dt, y0.device)
+        L.call("pcrl_maxpool2d_3s2_bwd_sum", first, second, idx, da0, N, H, W, C, dtype_code(dt), stream_handle())
+        bn_conv_bwd(da0, ctx.units[0], img, y0, c0, N * H * W, C, ACT_RELU, need_dx=False)
+        out = (None, None) + tuple(_park(p, grads.get(i)) for i, p in enumerate(ctx.plist))
         mark_final(ctx, ctx.plist)
         return out
 

@@ -118,6 +118,16 @@ class ResNetEncoder(nn.Module):
             feats.append(h)
         return feats
 
+    def forward_last(self, x):
+        """The last feature map only -- all the decoder reads (pcrlv2_model.py:115-117 ignores the skips) -- through ONE autograd node
+        (functions2d.EncoderFn); with PCRL_FUSED_ENCODER_2D=0 the per-unit path above (same values, bit for bit)."""
+        if not Fn2.FUSED_ENCODER or x.dtype != torch.float32:
+            return self.forward(x)[-1]
+        params = []
+        for u in self._units():
+            params += [u.conv.weight, u.bn_module.weight, u.bn_module.bias]
+        return Fn2.EncoderFn.apply(x, self, *params)
+
 
 def initialize_decoder(module):
     """reference pcrlv2_model.py:23-38"""
@@ -318,7 +328,7 @@ class PCRLv2(nn.Module):
     def forward(self, x, local=False):
         """-> ([(pro, pre) x 5], masks [b,n_class,H,W] | None, [mask x 5])"""
         self._begin_pass(x)
-        features = self.model.encoder(x)
+        features = [None] * 5 + [self.model.encoder.forward_last(x)]      # the decoder reads the last feature map only
         decoder_outputs, h, middle_masks = self.model.decoder(features)
         masks = None
         if not local:
@@ -333,6 +343,6 @@ class PCRLv2(nn.Module):
         draws; None: no map at all -- the second view and the local views, whose maps the reference computes and never reads).
         -> ([(pro, pre) x 5], decoder output (activation), deep-supervision map of `mask_scale` at its own resolution | None)"""
         self._begin_pass(x)
-        features = self.model.encoder(x)
+        features = [None] * 5 + [self.model.encoder.forward_last(x)]
         decoder_outputs, h, low = self.model.decoder(features, _mask_scales=() if mask_scale is None else (mask_scale,), _upsample=False)
         return decoder_outputs, h, (low[mask_scale] if mask_scale is not None else None)

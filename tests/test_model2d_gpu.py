@@ -164,6 +164,79 @@ def test_second_view_on_its_own_stream_is_bit_identical_2d(dtype):
         assert torch.equal(x, y), what
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_as_one_autograd_node_is_bit_identical_2d(dtype):
+    """functions2d.EncoderFn (PCRL_FUSED_ENCODER_2D, default on): BatchNorm apply + identity add + ReLU in one pass, the two gradients of a block's
+    output summed inside the mask / max-pool backward passes, the stem's apply + ReLU + MaxPool2d in one pass -- against one autograd node per
+    unit with autograd's own adds: parameters, momentum buffers and running statistics after three steps are BIT-identical."""
+    import pcrlv2_2d_oracle as O
+    from pcrlv2_amd import functions2d as Fn2, train_2d
+    from pcrlv2_amd.optim import FusedSGD
+    from pcrlv2_amd.train_3d import CosineSimilarityMean
+    batches = [O.synthetic_batch(4, 64, 32, seed=21 + k) for k in range(3)]
+    keep, finals = Fn2.FUSED_ENCODER, []
+    try:
+        for on in (True, False):
+            Fn2.FUSED_ENCODER = on
+            model = _build(seed=6, dtype=dtype)
+            opt = FusedSGD(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+            random.seed(4)
+            for bt in batches:
+                out = train_2d.train_step(model, opt, bt, 0, train_2d.MSELoss2d(), CosineSimilarityMean())
+            torch.cuda.synchronize()
+            sd = model.state_dict()
+            rs = torch.cat([v.flatten().float() for k, v in sorted(sd.items()) if "running" in k or "num_batches" in k])
+            finals.append(([float(o) for o in out], opt.flat_p.clone(), opt.flat_buf.clone(), rs))
+    finally:
+        Fn2.FUSED_ENCODER = keep
+    a, b = finals
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y, what in zip(a[1:], b[1:], ("parameters", "momentum buffers", "running statistics")):
+        assert torch.equal(x, y), what
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_step_equals_the_reference_shaped_step_2d(dtype):
+    """train_2d.step_losses' engine form (scales drawn before the forwards, unread stateless outputs skipped, one launch for the 26 cosine
+    means, fused restoration terms; PCRL_FUSED_STEP_2D) against the reference-shaped loop over the public model API with the same draws:
+    the same five losses, the same gradients (float32: 1e-5 relative per tensor; bf16: 2e-2 -- the deep-supervision gradient takes a
+    float32 instead of a bf16 route into the 1x1 convolution's backward), the same None pattern, identical running statistics and
+    num_batches_tracked (the skipped work has no state)."""
+    import pcrlv2_2d_oracle as O
+    from pcrlv2_amd import train_2d
+    from pcrlv2_amd.train_3d import CosineSimilarityMean
+    batch = O.synthetic_batch(4, 64, 32, seed=31)
+    res = []
+    keep = train_2d.FUSED_STEP_2D
+    try:
+        for on in (True, False):
+            train_2d.FUSED_STEP_2D = on
+            model = _build(seed=8, dtype=dtype)
+            model.train()
+            random.seed(9)
+            losses = train_2d.step_losses(model, batch, 3, train_2d.MSELoss2d(), CosineSimilarityMean())
+            after = random.random()            # the global stream advanced by exactly the same 13 draws
+            losses[0].backward()
+            torch.cuda.synchronize()
+            sd = model.state_dict()
+            res.append(([float(l) for l in losses], {n: (None if p.grad is None else p.grad.double().cpu()) for n, p in model.named_parameters()},
+                        {k: v.clone() for k, v in sd.items() if "running" in k or "num_batches" in k}, after))
+    finally:
+        train_2d.FUSED_STEP_2D = keep
+    (la, ga, ba, ra), (lb, gb, bb, rb) = res
+    assert ra == rb
+    ltol = 1e-5 if dtype == torch.float32 else 2e-3
+    for x, y in zip(la, lb):
+        assert abs(x - y) < ltol * max(1.0, abs(y)), (la, lb)
+    gtol = 1e-5 if dtype == torch.float32 else 2e-2
+    for n in ga:
+        assert (ga[n] is None) == (gb[n] is None), n
+        if ga[n] is not None and float(gb[n].norm()) > 1e-6:      # (biases in front of a BatchNorm: identically zero, round-off either way)
+            assert float((ga[n] - gb[n]).norm()) <= gtol * float(gb[n].norm()), (n, float((ga[n] - gb[n]).norm()) / float(gb[n].norm()))
+    for k in ba:
+        assert torch.equal(ba[k], bb[k]), k
+
+
 def test_bf16_step_close_to_fp32():
     import pcrlv2_2d_oracle as O
     from pcrlv2_amd import train_2d
