@@ -306,9 +306,18 @@ int pcrl_prelu_bwd(const void* da, const void* z, const float* w, void* dz, floa
  *   wgrad : dw float32 [CoP][Ci_out][KH][KW]; ws: pcrl_conv2d_wgrad_ws_bytes */
 int64_t pcrl_conv2d_packed_elems(int rows, int taps, int CsP);
 int pcrl_conv2d_pack(const float* w_ref, void* out, int Co, int Ci, int KH, int KW, int CsP, int mode, int dtype, pcrl_stream_t stream);
-int64_t pcrl_conv2d_stats_rows(int N, int Ho, int Wo);
-int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, int N, int Hi, int Wi, int CiP,
-                    int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream);
+int64_t pcrl_conv2d_stats_rows(int N, int Ho, int Wo);     /* upper bound for any kernel: one row per 128 output pixels */
+/* rows of statistics pcrl_conv2d_fwd WRITES for this geometry (depends on the kernel its dispatcher picks): allocate that many, pass the
+ * count as `stats_rows` and to pcrl_bn_finalize; more rows may be passed -- the surplus is zero-filled */
+int64_t pcrl_conv2d_fwd_stats_rows(int N, int Hi, int Wi, int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype);
+int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, int64_t stats_rows, int N, int Hi, int Wi,
+                    int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream);
+/* data gradient of a 3x3 / stride 1 / pad 1 convolution that read its input through the nearest x2 upsample (decoder conv1,
+ * models/pcrlv2_model.py:114) INCLUDING the upsample's backward (aten::convolution_backward's input gradient + aten::upsample_nearest2d_backward):
+ * dx[N][Hc][Wc][Ci] = 2 x 2 block sums of the fine-resolution gradient, which is never stored.  dy: [N][2Hc][2Wc][CoP]; wp_dgrad as for
+ * pcrl_conv2d_dgrad.  Only where pcrl_conv2d_dgrad_up_ok() != 0 (both channel counts <= 32, bf16, fine extents multiples of 8 x 32). */
+int64_t pcrl_conv2d_dgrad_up_ok(int N, int Hc, int Wc, int Ci, int CoP, int dtype);
+int pcrl_conv2d_dgrad_up(const void* dy, const void* wp_dgrad, void* dx, int N, int Hc, int Wc, int Ci, int CoP, int dtype, pcrl_stream_t stream);
 int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH,
                       int KW, int stride, int pad, int dtype, pcrl_stream_t stream);
 /* Stride-2 data gradient without idle taps: the parity classes (a, b) = (ih & 1, iw & 1) of dx are four stride-1 gathers over dy

@@ -387,7 +387,7 @@ int pcrl_brick_conv2d_launch(const void* x, const void* wp, const float* bias, v
 bool pcrl_conv2d_narrow_eligible(int N, int H, int W, int Cs, int Nc, int ks, int dtype);
 int64_t pcrl_conv2d_narrow_rows(int N, int H, int W);
 int pcrl_conv2d_narrow_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Cs, int Nc, int ks,
-                              int up, int out_f32, hipStream_t stream);
+                              int up, int out_f32, int red2, hipStream_t stream);
 static std::atomic<int> g_conv2d_impl{0};   // 0 = auto (brick / narrow kernels where eligible), 1 = always the gather kernel
 extern "C" void pcrl_debug_set_conv2d_impl(int impl) { g_conv2d_impl = impl; }
 
@@ -413,28 +413,49 @@ extern "C" int pcrl_conv2d_pack(const float* w_ref, void* out, int Co, int Ci, i
 
 extern "C" int64_t pcrl_conv2d_stats_rows(int N, int Ho, int Wo) { return ((int64_t)N * Ho * Wo + PCRL_CONV_BM - 1) / PCRL_CONV_BM; }
 
-extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, int N, int Hi, int Wi, int CiP,
-                               int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream) {
+// which kernel the forward dispatcher picks: 0 gather, 1 LDS-halo brick, 2 right-sized narrow kernel
+static int conv2d_fwd_kind(int N, int Ho, int Wo, int CiP, int Co, int KH, int KW, int stride, int pad, int out_f32, int dtype) {
+  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !out_f32 && pcrl_brick_conv2d_eligible(N, Ho, Wo, CiP, Co, dtype)) return 1;
+  if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype))
+    return 2;
+  return 0;
+}
+// rows of [Co][2] statistics the forward WRITES for this geometry (the gather kernel: one per 128 output pixels; the brick kernel: one per
+// 256-pixel brick; the narrow kernel: one per block) -- what the caller hands to pcrl_bn_finalize
+extern "C" int64_t pcrl_conv2d_fwd_stats_rows(int N, int Hi, int Wi, int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype) {
   const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
   const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
-  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !out_f32 && x && wp && y &&
-      pcrl_brick_conv2d_eligible(N, Ho, Wo, CiP, Co, dtype)) {
-    if (stats_partial) {   // the caller sized the statistics for the gather kernel's 128-pixel tiles; a brick is 256 pixels: zero the rest
-      const int64_t rb = pcrl_brick_conv2d_rows(N, Ho, Wo), rg = pcrl_conv2d_stats_rows(N, Ho, Wo);
-      if (rg > rb) (void)hipMemsetAsync(stats_partial + rb * Co * 2, 0, (size_t)(rg - rb) * Co * 2 * sizeof(float), as_stream(stream));
-    }
-    return pcrl_brick_conv2d_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, up, as_stream(stream));
+  const int kind = conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype);
+  return kind == 1 ? pcrl_brick_conv2d_rows(N, Ho, Wo) : kind == 2 ? pcrl_conv2d_narrow_rows(N, Ho, Wo) : pcrl_conv2d_stats_rows(N, Ho, Wo);
+}
+
+// stats_rows: rows the caller allocated for stats_partial (>= pcrl_conv2d_fwd_stats_rows(...); rows beyond the written ones are zero-filled)
+extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, int64_t stats_rows, int N, int Hi, int Wi,
+                               int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream) {
+  const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
+  const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
+  const int kind = (x && wp && y) ? conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype) : 0;
+  if (stats_partial) {
+    const int64_t rw = kind == 1 ? pcrl_brick_conv2d_rows(N, Ho, Wo) : kind == 2 ? pcrl_conv2d_narrow_rows(N, Ho, Wo) : pcrl_conv2d_stats_rows(N, Ho, Wo);
+    PCRL_REQUIRE(stats_rows >= rw, "conv2d_fwd: %lld statistics rows allocated, %lld needed (pcrl_conv2d_fwd_stats_rows)", (long long)stats_rows, (long long)rw);
+    if (stats_rows > rw) (void)hipMemsetAsync(stats_partial + rw * Co * 2, 0, (size_t)(stats_rows - rw) * Co * 2 * sizeof(float), as_stream(stream));
   }
-  if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && x && wp && y &&
-      pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype)) {
-    if (stats_partial) {
-      const int64_t rb = pcrl_conv2d_narrow_rows(N, Ho, Wo), rg = pcrl_conv2d_stats_rows(N, Ho, Wo);
-      if (rg > rb) (void)hipMemsetAsync(stats_partial + rb * Co * 2, 0, (size_t)(rg - rb) * Co * 2 * sizeof(float), as_stream(stream));
-    }
-    return pcrl_conv2d_narrow_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, KH, up, out_f32, as_stream(stream));
-  }
+  if (kind == 1) return pcrl_brick_conv2d_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, up, as_stream(stream));
+  if (kind == 2) return pcrl_conv2d_narrow_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, KH, up, out_f32, 0, as_stream(stream));
   return conv2d_common("conv2d_fwd", C2_FWD, x, wp, bias, y, stats_partial, N, Hi, Wi, CiP, Ho, Wo, Co, KH, KW, stride, pad, up, out_f32, dtype,
                        as_stream(stream));
+}
+
+// Data gradient of a 3x3 / stride 1 / pad 1 convolution that read its input through the nearest x2 upsample (decoder conv1,
+// models/pcrlv2_model.py:114), WITH the upsample's backward: dx[N][Hc][Wc][Ci] = 2 x 2 block sums of the fine-resolution data gradient,
+// which is never stored.  Available (pcrl_conv2d_dgrad_up_ok) where the right-sized narrow kernel takes the fine-resolution problem.
+extern "C" int64_t pcrl_conv2d_dgrad_up_ok(int N, int Hc, int Wc, int Ci, int CoP, int dtype) {
+  return (g_conv2d_impl == 0 && pcrl_conv2d_narrow_eligible(N, 2 * Hc, 2 * Wc, CoP, Ci, 3, dtype)) ? 1 : 0;
+}
+extern "C" int pcrl_conv2d_dgrad_up(const void* dy, const void* wp_dgrad, void* dx, int N, int Hc, int Wc, int Ci, int CoP, int dtype, pcrl_stream_t stream) {
+  PCRL_REQUIRE(dy && wp_dgrad && dx, "conv2d_dgrad_up: null pointer");
+  PCRL_REQUIRE(pcrl_conv2d_dgrad_up_ok(N, Hc, Wc, Ci, CoP, dtype), "conv2d_dgrad_up: not available for this geometry (pcrl_conv2d_dgrad_up_ok)");
+  return pcrl_conv2d_narrow_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, 2 * Hc, 2 * Wc, CoP, Ci, 3, 0, 0, 1, as_stream(stream));
 }
 
 // dx[N][Hi][Wi][Ci] from dy[N][Ho][Wo][CoP]; (Ho, Wo) are the forward output dims of the (Hi, Wi) input.
@@ -445,7 +466,7 @@ extern "C" int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx,
     return pcrl_brick_conv2d_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, 0, as_stream(stream));
   if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
       pcrl_conv2d_narrow_eligible(N, Hi, Wi, CoP, Ci, KH, dtype))
-    return pcrl_conv2d_narrow_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, KH, 0, 0, as_stream(stream));
+    return pcrl_conv2d_narrow_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, KH, 0, 0, 0, as_stream(stream));
   return conv2d_common("conv2d_dgrad", C2_DGRAD, dy, wp_dgrad, nullptr, dx, nullptr, N, Ho, Wo, CoP, Hi, Wi, Ci, KH, KW, stride, pad, 0, 0, dtype,
                        as_stream(stream));
 }

@@ -109,9 +109,9 @@ def conv2d_forward(x, w, bias, packed: PackedConv2d, stride, pad, up, dtype, wan
     Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
     Ho, Wo = out_size(Hl, KH, stride, pad), out_size(Wl, KW, stride, pad)
     y = new_act2(N, Ho, Wo, Co, torch.float32 if out_f32 else dtype, x.device)
-    rows = L.call("pcrl_conv2d_stats_rows", N, Ho, Wo)
+    rows = L.call("pcrl_conv2d_fwd_stats_rows", N, Hi, Wi, CiP, Co, KH, KW, stride, pad, int(up), int(out_f32), dtype_code(dtype)) if want_stats else 0
     partial = ops._f32(rows * Co * 2, x.device) if want_stats else None
-    L.call("pcrl_conv2d_fwd", x, wf, None if bias is None else bias.detach(), y, partial, N, Hi, Wi, CiP, Co, KH, KW, stride, pad,
+    L.call("pcrl_conv2d_fwd", x, wf, None if bias is None else bias.detach(), y, partial, rows, N, Hi, Wi, CiP, Co, KH, KW, stride, pad,
            int(up), int(out_f32), dtype_code(dtype), s)
     return y, partial, rows
 
@@ -141,6 +141,11 @@ def conv2d_backward(x, dy, w, packed: PackedConv2d, stride, pad, up, dtype, need
             L.call("pcrl_conv2d_dgrad_s2", dy, wp, dx, N, Hi, Wi, Ci, Ho, Wo, CoP, KH, KW, a, b, dtype_code(dtype), s)
     elif need_dx:
         _, wd = packed.get(w, dtype, CiP)
+        if up and KH == 3 and stride == 1 and pad == 1 and L.call("pcrl_conv2d_dgrad_up_ok", N, Hi, Wi, Ci, CoP, dtype_code(dtype)):
+            # the narrow layers: data gradient and the nearest x2 upsample's backward in one kernel -- the fine-resolution gradient is never stored
+            dx = new_act2(N, Hi, Wi, Ci, dtype, x.device)
+            L.call("pcrl_conv2d_dgrad_up", dy, wd, dx, N, Hi, Wi, Ci, CoP, dtype_code(dtype), s)
+            return dx, dw
         Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
         dxl = new_act2(N, Hl, Wl, Ci, dtype, x.device)
         L.call("pcrl_conv2d_dgrad", dy, wd, dxl, N, Hl, Wl, Ci, Ho, Wo, CoP, KH, KW, stride, pad, dtype_code(dtype), s)
