@@ -481,6 +481,24 @@ void pcrl_debug_set_wgrad_tr(int on);
 void pcrl_debug_set_conv2d_impl(int impl);
 
 /* ---------------------------------------------------------------------------------------
+ * 2D path, the ResNet stem (csrc/stem2d.hip): conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False) of the ResNet-18 encoder
+ * smp.Unet('resnet18', in_channels=3) builds (models/pcrlv2_model.py:200) -- aten::convolution / convolution_backward (weight branch; the
+ * image needs no gradient) reading the float32 NCHW image as the loader delivers it (train_2d.py:139-141).  bf16 MFMA, float32 accumulation.
+ * Available where pcrl_stem7_ok() != 0: bf16, even H, W with H/2 a multiple of 8 and W/2 a multiple of 32 (else pcrl_conv2d_* on the image
+ * padded to 8 channels).
+ *   pack  : float32 [64][3][7][7] -> bf16 [64][7][32] (k = kw * 4 + c; zeros at c = 3 and kw = 7): pcrl_stem7_packed_elems() elements
+ *   fwd   : y bf16 NHWC [N][H/2][W/2][64]; stats: pcrl_stem7_stats_rows(N, H, W) rows of [64][2] (sum, sum^2) for bn1, or NULL
+ *   wgrad : dw_ref float32 [64][3][7][7] from dy bf16 [N][H/2][W/2][64]; ws: pcrl_stem7_wgrad_ws_bytes */
+int64_t pcrl_stem7_ok(int N, int H, int W, int dtype);
+int64_t pcrl_stem7_packed_elems(void);
+int64_t pcrl_stem7_stats_rows(int N, int H, int W);
+size_t pcrl_stem7_wgrad_ws_bytes(int N, int H, int W);
+int pcrl_stem7_pack(const float* w_ref, void* out, pcrl_stream_t stream);
+int pcrl_stem7_fwd(const float* x, const void* wp, void* y, float* stats, int N, int H, int W, int dtype, pcrl_stream_t stream);
+int pcrl_stem7_wgrad(const float* x, const void* dy, float* dw_ref, void* ws, size_t ws_bytes, int N, int H, int W, int dtype,
+                     pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * 2D path, fused passes of the ResNet-18 encoder (csrc/encoder2d.hip): each replaces a chain of separate passes over one tensor and
  * reproduces the chain's values bit for bit (intermediates the chain stored are rounded to `dtype` here too).
  *   bn_add_relu_fwd      : out = relu(T(scale*y + shift) + i), i = r (identity) or T(rscale*r + rshift) (the downsample branch's

@@ -188,6 +188,7 @@ class ProjHeadFn(Function):
 
 
 FUSED_ENCODER = __import__("os").environ.get("PCRL_FUSED_ENCODER_2D", "1") != "0"   # A/B switch (bit-identical results): 0 = one autograd node per unit
+STEM_KERNEL = __import__("os").environ.get("PCRL_STEM_KERNEL_2D", "1") != "0"       # A/B switch: 0 = the general gather kernel on the image padded to 8 channels
 
 
 class EncoderFn(Function):
@@ -219,8 +220,21 @@ class EncoderFn(Function):
             u._count_batch()
             return y, coef
 
-        img = ops2d.image_to_act(x, dt, 8)
-        y0, c0 = conv_bn(img, enc._stem)
+        stem = enc._stem
+        w0_, g0_, be0_ = P[0]
+        if STEM_KERNEL and ops2d.stem_ok(x, w0_, dt):
+            # the dedicated stem kernels read the loader's float32 NCHW image as it is (csrc/stem2d.hip): no padded bf16 copy of the image
+            if getattr(stem, "_packed_stem", None) is None:
+                stem._packed_stem = ops2d.PackedStem()
+            img = x
+            y0, partial, rows = ops2d.stem_forward(x, w0_, stem._packed_stem, dt)
+            N, H, W, C = ops2d.dims2(y0)
+            bn0 = stem.bn_module
+            c0 = ops.bn_finalize(partial, rows, C, N * H * W, g0_.detach(), be0_.detach(), bn0.running_mean, bn0.running_var)
+            stem._count_batch()
+        else:
+            img = ops2d.image_to_act(x, dt, 8)
+            y0, c0 = conv_bn(img, stem)
         N, H, W, C = ops2d.dims2(y0)
         Ho, Wo = ops2d.out_size(H, 3, 2, 1), ops2d.out_size(W, 3, 2, 1)
         h = ops2d.new_act2(N, Ho, Wo, C, dt, y0.device)
@@ -291,7 +305,13 @@ class EncoderFn(Function):
         img, y0, c0, idx, (N, H, W, C) = ctx.stem
         da0 = ops2d.new_act2(N, H, W, C, dt, y0.device)
         L.call("pcrl_maxpool2d_3s2_bwd_sum", first, second, idx, da0, N, H, W, C, dtype_code(dt), stream_handle())
-        bn_conv_bwd(da0, ctx.units[0], img, y0, c0, N * H * W, C, ACT_RELU, need_dx=False)
+        if img.dtype == torch.float32 and img.shape[1] == 3:      # the dedicated stem kernels ran forward: their weight gradient
+            u0 = ctx.units[0]
+            w0_, g0_, _ = P[0]
+            dy0, dg0, db0 = ops.bn_act_backward(da0, y0, g0_.detach(), c0[0], c0[1], c0[2], c0[3], N * H * W, C, ACT_RELU, dt)
+            put(u0, ops2d.stem_wgrad(img, dy0, w0_, dt), dg0, db0)
+        else:
+            bn_conv_bwd(da0, ctx.units[0], img, y0, c0, N * H * W, C, ACT_RELU, need_dx=False)
         out = (None, None) + tuple(_park(p, grads.get(i)) for i, p in enumerate(ctx.plist))
         mark_final(ctx, ctx.plist)
         return out

@@ -94,6 +94,55 @@ class PackedConv2d:
         return self.fwd, self.dgrad
 
 
+class PackedStem:
+    """bf16 [64][7][32] pack of the ResNet stem's 7x7 weight for csrc/stem2d.hip (k = kw * 4 + c), cached per parameter version."""
+
+    def __init__(self):
+        self.key, self.w = None, None
+        self._guard = ops._CacheGuard()
+
+    def get(self, w: torch.Tensor):
+        key = (ops._weights_epoch, w._version, w.data_ptr())
+        if key != self.key:
+            L = lib()
+            self.w = torch.empty(L.call("pcrl_stem7_packed_elems"), dtype=torch.bfloat16, device=w.device)
+            L.call("pcrl_stem7_pack", w.detach(), self.w, stream_handle())
+            self.key = key
+            self._guard._built(w.device)
+        else:
+            self._guard._reading(w.device)
+        return self.w
+
+
+def stem_ok(x, w, dtype) -> bool:
+    """The dedicated stem kernels take this image / weight (float32 NCHW [N,3,H,W] on the GPU, 64 x 3 x 7 x 7, bf16 compute, H/2 % 8 == W/2 % 32 == 0)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous() and tuple(w.shape) == (64, 3, 7, 7)):
+        return False
+    return bool(lib().call("pcrl_stem7_ok", x.shape[0], x.shape[2], x.shape[3], dtype_code(dtype)))
+
+
+def stem_forward(x, w, packed: PackedStem, dtype):
+    """conv1 of the ResNet stem on the float32 NCHW image.  -> (y bf16 NHWC [N,64,H/2,W/2], stats_partial, rows)"""
+    L = lib()
+    N, _, H, W = x.shape
+    y = new_act2(N, H // 2, W // 2, 64, dtype, x.device)
+    rows = L.call("pcrl_stem7_stats_rows", N, H, W)
+    partial = ops._f32(rows * 64 * 2, x.device)
+    L.call("pcrl_stem7_fwd", x, packed.get(w), y, partial, N, H, W, dtype_code(dtype), stream_handle())
+    return y, partial, rows
+
+
+def stem_wgrad(x, dy, w, dtype):
+    """float32 [64,3,7,7] weight gradient of the stem from the float32 NCHW image and dy (bf16 NHWC), on the weight-gradient side stream."""
+    L = lib()
+    N, _, H, W = x.shape
+    dw = torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format)
+    nb = L.call("pcrl_stem7_wgrad_ws_bytes", N, H, W)
+    with ops.side_wgrad(x.device, x, dy, path2d=True) as ws:
+        L.call("pcrl_stem7_wgrad", x, dy, dw, ws(nb), nb, N, H, W, dtype_code(dtype), stream_handle())
+    return dw
+
+
 def out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 

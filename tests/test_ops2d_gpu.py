@@ -302,3 +302,33 @@ def test_bn_backward_of_a_summed_gradient(C, N, S, parts, dt):
     _close(dy, dy_ref.cpu(), dt, "dy", f32_tol=2e-5, bf_tol=6e-3)
     _close(dgamma, dgamma_ref.cpu(), torch.float32, "dgamma", f32_tol=1e-4)
     _close(dbeta, dbeta_ref.cpu(), torch.float32, "dbeta", f32_tol=1e-4)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 32, 128), (3, 48, 64), (1, 16, 192)])
+def test_stem_kernels_against_torch(N, H, W):
+    """csrc/stem2d.hip: Conv2d(3, 64, 7, stride 2, padding 3) on the float32 NCHW image -- forward, BatchNorm statistics rows and the weight
+    gradient against float64 torch on the bf16-rounded operands; and against the general gather kernel on the padded image (same operands)."""
+    from pcrlv2_amd import ops2d
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(N, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 147 ** 0.5
+    xd, wd = x.to(_dev()), w.to(_dev())
+    assert ops2d.stem_ok(xd, wd, dt)
+    y, partial, rows = ops2d.stem_forward(xd, wd, ops2d.PackedStem(), dt)
+    xr, wr = _q(x, dt).requires_grad_(True), _q(w, dt).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, 2, 3)
+    _close(y, yr, dt, "stem fwd", bf_tol=4e-3)
+    st = partial.view(rows, 64, 2).double().sum(0).cpu()
+    _close(st[:, 0], yr.detach().sum((0, 2, 3)), torch.float32, "stem statistics: sums", f32_tol=1e-3)
+    _close(st[:, 1], (yr.detach() ** 2).sum((0, 2, 3)), torch.float32, "stem statistics: sums of squares", f32_tol=1e-4)
+    dy = torch.randn(yr.shape, generator=g)
+    dya = ops2d.to_act2(dy.to(_dev()), dt)
+    dw = ops2d.stem_wgrad(xd, dya, wd, dt)
+    torch.cuda.synchronize()
+    yr.backward(_q(dy, dt))
+    _close(dw, wr.grad, torch.float32, "stem wgrad", f32_tol=2e-4)
+    # the gather kernel on the image padded to 8 channels computes the same thing from the same rounded operands
+    packed = ops2d.PackedConv2d()
+    y2, _, _ = ops2d.conv2d_forward(ops2d.image_to_act(xd, dt, 8), wd, None, packed, 2, 3, 0, dt)
+    _close(y, y2.double().cpu(), dt, "stem fwd vs gather kernel", bf_tol=4e-3)
