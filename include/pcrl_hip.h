@@ -316,6 +316,9 @@ int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, f
  * models/pcrlv2_model.py:114) INCLUDING the upsample's backward (aten::convolution_backward's input gradient + aten::upsample_nearest2d_backward):
  * dx[N][Hc][Wc][Ci] = 2 x 2 block sums of the fine-resolution gradient, which is never stored.  dy: [N][2Hc][2Wc][CoP]; wp_dgrad as for
  * pcrl_conv2d_dgrad.  Only where pcrl_conv2d_dgrad_up_ok() != 0 (both channel counts <= 32, bf16, fine extents multiples of 8 x 32). */
+/* which kernel the dispatcher runs for a geometry (no launch): 0 gather implicit GEMM, 1 LDS-halo brick kernel, 2 right-sized narrow kernel */
+int64_t pcrl_conv2d_fwd_kind(int N, int Hi, int Wi, int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype);
+int64_t pcrl_conv2d_dgrad_kind(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH, int KW, int stride, int pad, int dtype);
 int64_t pcrl_conv2d_dgrad_up_ok(int N, int Hc, int Wc, int Ci, int CoP, int dtype);
 int pcrl_conv2d_dgrad_up(const void* dy, const void* wp_dgrad, void* dx, int N, int Hc, int Wc, int Ci, int CoP, int dtype, pcrl_stream_t stream);
 int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH,

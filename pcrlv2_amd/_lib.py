@@ -76,6 +76,7 @@ class _Lib:
             f.argtypes = [_ctype_of(t) for t, _ in args]
             self.fn[name] = (f, ret, args)
         self.profiler = None
+        self.counter = None
         self._kinds = {}
         self.debug_set_wgrad_tr = self.cdll.pcrl_debug_set_wgrad_tr
         self.debug_set_wgrad_tr.argtypes = [ctypes.c_int]
@@ -123,6 +124,8 @@ class _Lib:
                 add(float(a))
             else:
                 add(a)
+        if self.counter is not None and name in self.counter.watch:
+            self.counter.add(name, args)       # bench.py: algorithmic bytes / flops of the launches of a region (no events, no timing)
         if self.profiler is not None and name in self.profiler.watch:
             r = self.profiler.timed(name, args, f, conv)
         else:

@@ -429,6 +429,21 @@ extern "C" int64_t pcrl_conv2d_fwd_stats_rows(int N, int Hi, int Wi, int CiP, in
   return kind == 1 ? pcrl_brick_conv2d_rows(N, Ho, Wo) : kind == 2 ? pcrl_conv2d_narrow_rows(N, Ho, Wo) : pcrl_conv2d_stats_rows(N, Ho, Wo);
 }
 
+// which kernel pcrl_conv2d_fwd / pcrl_conv2d_dgrad run for a geometry: 0 gather implicit GEMM, 1 LDS-halo brick kernel, 2 right-sized narrow kernel
+// (bench.py's roofline classification; no launch)
+extern "C" int64_t pcrl_conv2d_fwd_kind(int N, int Hi, int Wi, int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype) {
+  const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
+  const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
+  return conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype);
+}
+extern "C" int64_t pcrl_conv2d_dgrad_kind(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH, int KW, int stride, int pad, int dtype) {
+  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo && pcrl_brick_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype)) return 1;
+  if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && Hi == Ho && Wi == Wo &&
+      pcrl_conv2d_narrow_eligible(N, Hi, Wi, CoP, Ci, KH, dtype))
+    return 2;
+  return 0;
+}
+
 // stats_rows: rows the caller allocated for stats_partial (>= pcrl_conv2d_fwd_stats_rows(...); rows beyond the written ones are zero-filled)
 extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, int64_t stats_rows, int N, int Hi, int Wi,
                                int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream) {

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 shift
 cd /tmp && export TMPDIR=/tmp
 export PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 PCRL_VIEW_STREAMS=0 PCRL_VIEW_STREAMS_2D=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -- python $R/tools/bench_2d.py --steps 3 --warmup 2 "$@" > $R/gpurun_out/$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG -- python $R/tools/bench_2d.py --steps 3 --warmup 2 --no-roofline "$@" > $R/gpurun_out/$TAG.log 2>&1
 cd $R
 export PROFILE_CMD="PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 PCRL_VIEW_STREAMS_2D=0 python tools/bench_2d.py --steps 3 --warmup 2 $* (C5 per-GPU workload: 512x512, b=64, bf16): one stream, every kernel alone on the chip"
 python tools/summarize_profiles.py $TAG $(find gpurun_out/$TAG -name "*kernel_stats.csv") 5 | head -60
