@@ -91,7 +91,42 @@ def make(tag, epoch=3, seed=0):
     print(f"[{tag}] losses { {k: float(r[k]) for k in LOSSES} }; wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)", flush=True)
 
 
+def make_curve(tag="e_curve_b8_32x32x16_12steps"):
+    """12 SGD steps of the rounding-aware comparator on the inputs of the reference's curve fixture (curve_b8_32x32x16_12steps.npz: same
+    batches, epoch, learning rate, draw seed): float32 master weights and momentum like the engine (the comparator's arithmetic runs in float64
+    on them, the update of torch.optim.SGD in float32), bf16 rounding points inside the step.  What the bf16 engine's loss curve is held to at
+    1e-3 where the float64 reference curve only allows 2.5e-2 (tests/test_model_gpu.py::test_bf16_loss_curve_vs_rounding_aware_comparator)."""
+    ref = np.load(os.path.join(OUT, "curve_b8_32x32x16_12steps.npz"))
+    b, dhw, nsteps = int(ref["b"]), tuple(int(v) for v in ref["dhw"]), int(ref["nsteps"])
+    epoch, seed, base_lr = int(ref["epoch"]), int(ref["seed"]), float(ref["base_lr"])
+    lr = O.lr_at(epoch, base_lr, 240)
+    torch.set_num_threads(8)
+    st = O.fill_state(torch.float32)
+    mom, rng, curve = {}, random.Random(seed), []
+    for s in range(nsteps):
+        batch = tuple(t.double() if torch.is_tensor(t) else [u.double() for u in t] for t in O.fill_batch(b, dhw, dtype=torch.float32, seed=int(ref["batch_seed0"]) + s))
+        st64 = OrderedDict((k, (v.double().requires_grad_(True) if not O.is_buffer(k) else v.double() if v.is_floating_point() else v)) for k, v in st.items())
+        nb = {}
+        with torch.backends.mkldnn.flags(enabled=False):
+            r = E.step_losses(st64, batch, epoch, rng, nb)
+            names = [k for k in st64 if not O.is_buffer(k)]
+            grads = torch.autograd.grad(r["loss"], [st64[k] for k in names], allow_unused=True)
+        g32 = {k: (None if g is None else g.float()) for k, g in zip(names, grads)}
+        st, mom = O.sgd_step(st, g32, mom, lr)                  # float32 masters, float32 momentum (FusedSGD's arithmetic)
+        for k, v in nb.items():
+            st[k] = v.float() if v.is_floating_point() else v
+        curve.append([float(r[k]) for k in LOSSES])
+        print(f"[{tag}] step {s}: " + "  ".join(f"{k} {v:+.6f}" for k, v in zip(LOSSES, curve[-1])) + "   reference: " + "  ".join(f"{v:+.6f}" for v in ref["curve"][s]), flush=True)
+    path = os.path.join(OUT, tag + ".npz")
+    np.savez_compressed(path, curve=np.array(curve), b=np.int64(b), dhw=np.array(dhw), nsteps=np.int64(nsteps), epoch=np.int64(epoch), seed=np.int64(seed),
+                        base_lr=np.float64(base_lr), batch_seed0=np.int64(int(ref["batch_seed0"])))
+    print(f"[{tag}] wrote {path}")
+
+
 if __name__ == "__main__":
     identity_check()
+    if "--curve" in sys.argv:
+        make_curve()
+        sys.exit(0)
     for t in (sys.argv[1:] or ["e_b16_32x32x16"]):
         make(t)

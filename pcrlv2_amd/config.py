@@ -146,10 +146,13 @@ PREPACK = os.environ.get("PCRL_PREPACK", "1") != "0"
 # and two multi-tensor adds (four ATen launches on the serial tail of backward).  PCRL_FUSED_GRAD_SUM=0: off (bit-identical).
 FUSED_GRAD_SUM = os.environ.get("PCRL_FUSED_GRAD_SUM", "1") != "0"
 
-# The reference returns the caching allocator's pools to the driver after every epoch (train_3d.py:83, "help release GPU memory").  It changes
-# no result; here it means releasing and re-reserving the provisioned pools (45 GB at C2) once per epoch, and about one such cycle in ten
-# stalls for ~3 s inside the driver (measured: `[provision] ... in 3.22 s`, PCRL_PROVISION_VERBOSE=1).  Off by default; =1: as the reference.
-EMPTY_CACHE_PER_EPOCH = os.environ.get("PCRL_EMPTY_CACHE_PER_EPOCH", "0") == "1"
+# The reference returns the caching allocator's cached memory to the driver after every epoch (train_3d.py:83, "help release GPU memory").  It
+# changes no result.  On by default (as the reference), through ops.empty_cache: the provisioned per-stream pools of the steady state are held
+# across the call (round 3 had to switch the call off: releasing and re-reserving 45 GB of pools stalled ~3 s one epoch in ten) -- everything
+# else the allocator caches goes back to the driver.  PCRL_EMPTY_CACHE_PER_EPOCH=0: no call; =raw: torch.cuda.empty_cache() itself.
+_ec = os.environ.get("PCRL_EMPTY_CACHE_PER_EPOCH", "1")
+EMPTY_CACHE_PER_EPOCH = _ec != "0"
+EMPTY_CACHE_RAW = _ec == "raw"
 
 # Experiment: a layer's weight gradient (side stream) is queued BEHIND its data gradient instead of in front of it.  Both need the same dy;
 # queued first, the weight gradient runs next to the data gradient (two matrix kernels sharing the chip) and the BatchNorm backward passes

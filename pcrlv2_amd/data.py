@@ -227,20 +227,185 @@ class GpuLunaAugment:
         return g(inp, 0), g(inp, 1), g(gt, 0), g(gt, 1), [loc[:, i].unsqueeze(1).contiguous() for i in range(nl)]
 
 
+class _SlotCrops(torch.utils.data.Dataset):
+    """LunaCropPairs whose workers write a sample STRAIGHT into a slot of two persistent shared, page-locked batch buffers (key = (slot, row,
+    file index)) and send back only (slot, row).  A DataLoader batch otherwise travels as freshly mapped shared memory: the consumer -- torch's
+    pin_memory thread or a staging copy -- takes a page fault on every 4 KB of the 36 MB of a b = 32 batch (measured 10 ms per batch on an idle
+    host, 22-38 ms next to a training loop that holds the GIL)."""
+
+    def __init__(self, files, pair_buf, local_buf):
+        self.files, self.pair, self.local = list(files), pair_buf, local_buf
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, key):
+        slot, row, i = key
+        name = self.files[i]
+        self.pair[slot, row] = torch.from_numpy(np.load(name).astype(np.float32, copy=False))
+        self.local[slot, row] = torch.from_numpy(np.load(name.replace("global", "local")).astype(np.float32, copy=False))     # lunaDataset.py:56
+        return slot, row
+
+
+class _SlotBatches(torch.utils.data.Sampler):
+    """Batches of (slot, row, index) keys: a fresh permutation per epoch (DataLoader(shuffle=True), data.py:90), slots handed out round-robin."""
+
+    def __init__(self, n, batch_size, shuffle, drop_last, nslots, seed):
+        self.n, self.b, self.shuffle, self.drop_last, self.nslots = n, batch_size, shuffle, drop_last, nslots
+        self.gen = torch.Generator().manual_seed(seed)
+        self.counter = 0
+
+    def __len__(self):
+        return self.n // self.b if self.drop_last else (self.n + self.b - 1) // self.b
+
+    def __iter__(self):
+        order = torch.randperm(self.n, generator=self.gen).tolist() if self.shuffle else list(range(self.n))
+        for k in range(len(self)):
+            idxs = order[k * self.b:(k + 1) * self.b]
+            slot = self.counter % self.nslots
+            self.counter += 1
+            yield [(slot, row, i) for row, i in enumerate(idxs)]
+
+
+def _pin_registered(t):
+    """Page-lock an existing (shared-memory) host tensor in place (hipHostRegister); -> True when the runtime accepted it."""
+    try:
+        rc = torch.cuda.cudart().cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)
+        return int(rc) == 0 and t.is_pinned()
+    except Exception:
+        return False
+
+
+AUG_STREAM = os.environ.get("PCRL_AUG_STREAM", "1") != "0"     # A/B switch: 0 = augment on the consumer's stream when the batch is asked for
+# how a batch gets into page-locked memory for the asynchronous host-to-device copy:
+#   slots  (default) workers write samples straight into persistent SHARED, page-locked batch slots (_SlotCrops): no copy at all in this process
+#   ring   the DataLoader hands over shared-memory tensors; THIS loader copies them into a small ring of persistent pinned buffers
+#   loader torch's pin_memory thread (a Python thread of the training process: it shares the GIL with the step's ~13 ms of enqueue work and
+#          allocates fresh pinned memory per batch -- measured 10 ms per batch on an idle host, 38 ms next to a training loop)
+#   none   pageable copies
+PIN_MODE = os.environ.get("PCRL_LOADER_PIN", "slots")
+LOADER_TIMING = os.environ.get("PCRL_LOADER_TIMING", "0") == "1"
+
+
 class AugmentedLoader:
-    """DataLoader over raw crops + GpuLunaAugment: iterates batches with the contract of datasets/lunaDataset.py:79-81."""
+    """DataLoader over raw crops + GpuLunaAugment: iterates batches with the contract of datasets/lunaDataset.py:79-81.
+
+    One batch ahead: the host-to-device copy and the augmentation kernels of batch k + 1 are enqueued on their OWN stream BEFORE batch k is handed
+    to the training loop, so they run under step k (~1.4 ms of HBM-bound kernels per b = 32 batch next to a ~31 ms step) instead of in
+    front of step k + 1 on its critical chain; the consumer's stream waits for the batch's event when it receives it.  The reference's
+    workers do the same job one batch ahead on the CPU (DataLoader prefetching, data.py:90-93)."""
 
     def __init__(self, files, batch_size, workers, device, shuffle=True, seed=0, drop_last=False):
-        self.loader = torch.utils.data.DataLoader(LunaCropPairs(files), batch_size=batch_size, shuffle=shuffle, num_workers=workers,
-                                                  pin_memory=torch.device(device).type == "cuda", drop_last=drop_last)
+        cuda = torch.device(device).type == "cuda"
+        self.slots = None
+        files = list(files)
+        if cuda and PIN_MODE == "slots" and AUG_STREAM and workers > 0 and len(files) > 0:
+            prefetch = 2
+            nslots = prefetch * workers + 6            # outstanding index batches + the batches this process still holds (see __iter__)
+            pshape = tuple(np.load(files[0], mmap_mode="r").shape)
+            lshape = tuple(np.load(files[0].replace("global", "local"), mmap_mode="r").shape)
+            pair_buf = torch.empty((nslots, batch_size) + pshape, dtype=torch.float32).share_memory_()
+            local_buf = torch.empty((nslots, batch_size) + lshape, dtype=torch.float32).share_memory_()
+            pinned = _pin_registered(pair_buf) and _pin_registered(local_buf)
+            self.slots = (pair_buf, local_buf, pinned)
+            self.loader = torch.utils.data.DataLoader(_SlotCrops(files, pair_buf, local_buf), num_workers=workers, collate_fn=lambda items: (items[0][0], len(items)),
+                                                      batch_sampler=_SlotBatches(len(files), batch_size, shuffle, drop_last, nslots, seed),
+                                                      persistent_workers=True, prefetch_factor=prefetch)
+        else:
+            self.loader = torch.utils.data.DataLoader(LunaCropPairs(files), batch_size=batch_size, shuffle=shuffle, num_workers=workers,
+                                                      pin_memory=cuda and PIN_MODE == "loader", drop_last=drop_last,
+                                                      persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
         self.augment = GpuLunaAugment(device, seed)
+        self._stream = None
+        self._ring, self._ring_pos = None, 0
+        self._events = []
+        self.timing = {"wait_loader_s": 0.0, "stage_s": 0.0, "enqueue_s": 0.0, "batches": 0}
 
     def __len__(self):
         return len(self.loader)
 
+    @staticmethod
+    def _tensors(batch):
+        for t in batch:
+            if torch.is_tensor(t):
+                yield t
+            elif t is not None:
+                yield from t
+
+    def _hand_over(self, batch, ev):
+        cur = torch.cuda.current_stream(self.augment.device)
+        cur.wait_event(ev)
+        for t in self._tensors(batch):
+            t.record_stream(cur)        # allocated on the augmentation stream, consumed on the training step's streams
+        return batch
+
+    def _stage(self, pair, local):
+        """Shared-memory batch -> a slot of the pinned ring (three slots: the copy out of a slot finished two batches ago)."""
+        if PIN_MODE != "ring" or pair.is_pinned():
+            return pair, local, None
+        if self._ring is None or self._ring[0][0].shape[1:] != pair.shape[1:] or self._ring[0][0].shape[0] < pair.shape[0]:
+            self._ring = [[torch.empty(pair.shape, dtype=pair.dtype).pin_memory(), torch.empty(local.shape, dtype=local.dtype).pin_memory(), None] for _ in range(3)]
+        slot = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        if slot[2] is not None:
+            slot[2].synchronize()
+        B = pair.shape[0]
+        slot[0][:B].copy_(pair)
+        slot[1][:B].copy_(local)
+        return slot[0][:B], slot[1][:B], slot
+
     def __iter__(self):
-        for pair, local in self.loader:
-            yield self.augment(pair, local)
+        import time
+        if not AUG_STREAM:
+            for pair, local in self.loader:
+                yield self.augment(pair, local)
+            return
+        dev = self.augment.device
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=dev)
+        ahead = None
+        it = iter(self.loader)
+        tm = self.timing
+        while True:
+            t0 = time.perf_counter()
+            try:
+                item = next(it)
+            except StopIteration:
+                break
+            t1 = time.perf_counter()
+            if self.slots is not None:
+                # (slot, rows): the batch already lies in the shared page-locked buffers.  Receiving it made the DataLoader hand out the index
+                # batch that will overwrite the slot of the batch six back: the copies out of that one are long done -- checked, not assumed
+                sl, rows = item
+                if len(self._events) >= 3:
+                    self._events[-3].synchronize()
+                pair, local, slot = self.slots[0][sl, :rows], self.slots[1][sl, :rows], None
+            else:
+                pair, local, slot = self._stage(*item)
+            t2 = time.perf_counter()
+            with torch.cuda.stream(self._stream):
+                batch = self.augment(pair, local)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+                if slot is not None:
+                    slot[2] = ev             # (behind the host-to-device copies of this slot)
+            self._events = (self._events + [ev])[-4:]
+            t3 = time.perf_counter()
+            tm["wait_loader_s"] += t1 - t0
+            tm["stage_s"] += t2 - t1
+            tm["enqueue_s"] += t3 - t2
+            tm["batches"] += 1
+            if ahead is not None:
+                yield self._hand_over(*ahead)
+            ahead = (batch, ev)
+        if ahead is not None:
+            yield self._hand_over(*ahead)
+        if LOADER_TIMING and tm["batches"]:
+            n = tm["batches"]
+            print("[loader] per batch: waiting for the DataLoader %.1f ms, staging into pinned memory %.1f ms, enqueue of copies + augmentation %.1f ms (pin mode %s, %d batches)"
+                  % (1e3 * tm["wait_loader_s"] / n, 1e3 * tm["stage_s"] / n, 1e3 * tm["enqueue_s"] / n, PIN_MODE, n), flush=True)
+            for k in ("wait_loader_s", "stage_s", "enqueue_s", "batches"):
+                tm[k] = 0
 
 
 def luna_pretask_loaders(args, device=None):

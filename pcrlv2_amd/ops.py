@@ -343,6 +343,41 @@ def provision_allocator(device, key=None):
         print("[provision] %d new segments x%d -> reserved %.1f GB in %.2f s" % (len(segs), f, _provisioned[(idx, key)] / 2**30, _time.perf_counter() - _t0), flush=True)
 
 
+def empty_cache(device=None):
+    """The reference's per-epoch `torch.cuda.empty_cache()` (train_3d.py:83, train_2d.py:108: "help release GPU memory") WITHOUT giving up the
+    engine's provisioned per-stream pools: every inactive block of the segments provision_allocator sized is occupied by a placeholder for
+    the duration of the call, so the allocator returns to the driver everything else it caches (other streams' and other shapes' leftovers:
+    what the call is for) and keeps the steady-state pools -- releasing and re-reserving those cost one device-wide stall of ~3 s in ten
+    epochs (round 3, which therefore switched the call off).  One device synchronisation per epoch, like the reference's own."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    mine = {e[1] for e in _provisioned_segments if e[0] == idx}
+    if not mine:
+        torch.cuda.empty_cache()
+        return
+    torch.cuda.synchronize(device)
+    streams = {}
+    for st in [torch.cuda.current_stream(device)] + list(_side_streams.values()) + list(_view_streams.values()):
+        streams[st.cuda_stream] = st
+    hold = []
+    by_stream = collections.defaultdict(list)
+    for seg in torch.cuda.memory_snapshot():
+        if seg["device"] == idx and seg["address"] in mine and seg["stream"] in streams:
+            for blk in seg["blocks"]:
+                if blk["state"] == "inactive" and blk["size"] >= 512:
+                    by_stream[seg["stream"]].append(blk["size"])
+    for sid, sizes in by_stream.items():
+        with torch.cuda.stream(streams[sid]):
+            for n in sorted(sizes, reverse=True):      # largest first: best fit then takes exactly the block the request was sized from
+                try:
+                    hold.append(torch.empty(n, dtype=torch.uint8, device=device))
+                except RuntimeError:
+                    break
+    torch.cuda.empty_cache()
+    del hold
+
+
 # ---- the second global view on its own stream (config.VIEW_STREAMS) ----
 _view_streams: dict = {}
 # "view2,local" with config.INTERLEAVE_VIEWS (every pass of the round-robin on its own stream), else "view2" (the local views' pass on the main stream)

@@ -153,8 +153,8 @@ def train_pcrlv2(args, data_loader, out_channel=3):
                 model.flush_counters()
                 state = {'opt': args, 'state_dict': model.model.encoder.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch}
                 torch.save(state, os.path.join(args.output, "{}_{}_{}_{}_{}.pt".format(args.model, args.n, args.phase, args.ratio, epoch)))
-        if _cfg.EMPTY_CACHE_PER_EPOCH:           # train_2d.py's per-epoch empty_cache; off by default (config.py)
-            torch.cuda.empty_cache()
+        if _cfg.EMPTY_CACHE_PER_EPOCH:           # the reference's per-epoch empty_cache (train_3d.py:83 / train_2d.py:108); the steady-state pools are kept (ops.empty_cache)
+            torch.cuda.empty_cache() if _cfg.EMPTY_CACHE_RAW else _ops.empty_cache()
     return model
 
 

@@ -289,8 +289,8 @@ def train_pcrlv2_3d(args, data_loader, out_channel=3):
                 print('==> Saving...')
                 torch.save({'opt': args, 'state_dict': model.state_dict(), 'optimizer': optimizer.state_dict(), 'epoch': epoch},
                            _checkpoint_name(args, epoch))
-        if _cfg.EMPTY_CACHE_PER_EPOCH:           # train_3d.py:83; off by default (config.py)
-            torch.cuda.empty_cache()
+        if _cfg.EMPTY_CACHE_PER_EPOCH:           # the reference's per-epoch empty_cache (train_3d.py:83 / train_2d.py:108); the steady-state pools are kept (ops.empty_cache)
+            torch.cuda.empty_cache() if _cfg.EMPTY_CACHE_RAW else _ops.empty_cache()
     return model
 
 

@@ -111,3 +111,38 @@ def test_loader_shards_have_equal_length(tmp_path, monkeypatch):
     monkeypatch.setenv("RANK", "0")
     files, drop = D.luna_pretask_loaders(types.SimpleNamespace(data=str(tmp_path), ratio=1.0, b=2, workers=0, seed=0), device="cpu")["train"]
     assert len(files) == 7 and drop is False                   # single process: the reference's loader (drop_last=False)
+
+
+def test_slot_loader_workers_write_the_right_samples_into_the_shared_buffers(tmp_path):
+    """data._SlotCrops / _SlotBatches (the default loader form on the GPU): worker processes write each sample into (slot, row) of the shared
+    batch buffers and send back (slot, rows).  Every batch read back from its slot holds exactly the files the sampler assigned, every file
+    is delivered once per epoch, slots rotate, the last batch is ragged (drop_last=False, data.py:90-93) -- over two epochs with two workers."""
+    _make_tree(tmp_path, series_per_fold=3, pairs=1)
+    files, _ = D.luna_file_lists(str(tmp_path), 1.0, str(tmp_path / "no_list.txt"))
+    assert len(files) == 21
+    b, nslots = 4, 2 * 2 + 6
+    pshape = tuple(np.load(files[0]).shape)
+    lshape = tuple(np.load(files[0].replace("global", "local")).shape)
+    pair_buf = torch.zeros((nslots, b) + pshape).share_memory_()
+    local_buf = torch.zeros((nslots, b) + lshape).share_memory_()
+    sampler = D._SlotBatches(len(files), b, True, False, nslots, seed=5)
+    loader = torch.utils.data.DataLoader(D._SlotCrops(files, pair_buf, local_buf), num_workers=2, collate_fn=lambda items: (items[0][0], len(items)),
+                                         batch_sampler=sampler, persistent_workers=True, prefetch_factor=2)
+    seen_slots = []
+    for epoch in range(2):
+        # the sampler's plan of this epoch, replayed from a copy of its generator state
+        g = torch.Generator()
+        g.set_state(sampler.gen.get_state())
+        order = torch.randperm(len(files), generator=g).tolist()
+        delivered = []
+        for k, (slot, rows) in enumerate(loader):
+            idxs = order[k * b:(k + 1) * b]
+            assert rows == len(idxs)
+            for r, i in enumerate(idxs):
+                assert torch.equal(pair_buf[slot, r], torch.from_numpy(np.load(files[i])))
+                assert torch.equal(local_buf[slot, r], torch.from_numpy(np.load(files[i].replace("global", "local"))))
+            delivered += idxs
+            seen_slots.append(slot)
+        assert sorted(delivered) == list(range(len(files)))
+    assert seen_slots == [k % nslots for k in range(len(seen_slots))]
+    assert len(seen_slots) == 2 * 6 and seen_slots[5] == 5      # 21 files, b = 4: five full batches and a ragged one per epoch
