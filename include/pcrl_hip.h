@@ -484,6 +484,20 @@ void pcrl_debug_set_wgrad_tr(int on);
 void pcrl_debug_set_conv2d_impl(int impl);
 
 /* ---------------------------------------------------------------------------------------
+ * Backward of one half of the projection / predictor heads (csrc/heads_fused.hip; models/pcrlv2_model_3d.py:55-59,67-70 and
+ * models/pcrlv2_model.py:108-111,124-127) in ONE launch: the data gradient of a Linear, the BatchNorm1d (+ReLU) backward of the tensor that
+ * gradient belongs to, and the Linear's weight / bias gradients -- aten::mm x 2 + sum (addmm backward), native_batch_norm_backward,
+ * threshold_backward.  All float32, row-major:
+ *   t[n][c] = add[n][c] + sum_k dy[n][k] * W[k][c]      dy [N][K] (NULL: t = add), W [K][C] (the Linear's weight [out][in]), add [N][C] or NULL
+ *   dx, dgamma, dbeta = BatchNorm1d backward of t through xbn [N][C] (the normalisation's input), gamma, mean, rstd [C];
+ *                       relu != 0: t is masked where ybn [N][C] (the normalisation's ReLU'd output) is <= 0 first
+ *   dW[k][c] = sum_n dy[n][k] * xin[n][c], db[k] = sum_n dy[n][k]      xin [N][C]: the Linear's input in forward
+ * N <= 512 rows, C % 4 == 0, K % 4 == 0. */
+int pcrl_head_bwd_stage(const float* dy, const float* W, const float* add, const float* xin, const float* xbn, const float* ybn,
+                        const float* gamma, const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta, float* dW,
+                        float* db, int N, int K, int C, int relu, pcrl_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * 2D path, the ResNet stem (csrc/stem2d.hip): conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False) of the ResNet-18 encoder
  * smp.Unet('resnet18', in_channels=3) builds (models/pcrlv2_model.py:200) -- aten::convolution / convolution_backward (weight branch; the
  * image needs no gradient) reading the float32 NCHW image as the loader delivers it (train_2d.py:139-141).  bf16 MFMA, float32 accumulation.

@@ -418,15 +418,11 @@ class UpStageFn(Function):
         d_a1 = _act_grad(d_out, dt) if d_out is not None else None
         # predictor / projection heads (train: pcrlv2_model_3d.py:55-59,69-70)
         if d_pre is not None or d_pro is not None:
-            d_xpro = d_pro.contiguous() if d_pro is not None else None
+            # ctx.plist[10:18] = bn.(weight, bias), predictor_head.0.(weight, bias), .1.(weight, bias), .3.(weight, bias)
+            d_g, hg = ops.heads_backward(d_pro, d_pre, ctx.heads, x_pro, ctx.plist[10:18])
+            grads[11], grads[12] = hg[0], hg[1]
             if d_pre is not None:
-                d_h1, g_p3w, g_p3b = ops.linear_backward(d_pre, h1, p3_w)
-                d_h0, g_p1g, g_p1b = ops.bn1d_backward(d_h1, h0, h1, p1_g, m_h, r_h, relu=True)
-                d_xp, g_p0w, g_p0b = ops.linear_backward(d_h0, x_pro, p0_w)
-                d_xpro = d_xp if d_xpro is None else ops.add2_small(d_xpro, d_xp)   # [N,C] float32: a few KB
-                grads[13], grads[14], grads[15], grads[16], grads[17], grads[18] = g_p0w, g_p0b, g_p1g, g_p1b, g_p3w, g_p3b
-            d_g, g_bng, g_bnb = ops.bn1d_backward(d_xpro, g, x_pro, bn_g, m_pro, r_pro, relu=False)
-            grads[11], grads[12] = g_bng, g_bnb
+                grads[13], grads[14], grads[15], grads[16], grads[17], grads[18] = hg[2], hg[3], hg[4], hg[5], hg[6], hg[7]
             if config.FOLD_GAP_GRAD and ctx.sv1.gn is None and ctx.sv1.prelu is None and ops.bn_rowadd_ok(a1.shape[1], dt):
                 row_g = d_g        # d a1 += d_g[n][c] / S: folded into the BatchNorm backward of ops.1, never materialised
             else:

@@ -318,21 +318,8 @@ class EncoderFn(Function):
 
 
 def _heads_backward(d_pro, d_pre, heads, x_pro, params):
-    """Backward of x_pro = bn(gap); x_pre = predictor_head(x_pro) (pcrlv2_model.py:124-127) down to the pooled vector.
-    -> (d_g float32 [N, C], [grads of bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b])"""
-    bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b = params
-    g, m_pro, r_pro, h0, h1, m_h, r_h = heads
-    grads = [None] * 8
-    d_xpro = d_pro.contiguous() if d_pro is not None else None
-    if d_pre is not None:
-        d_h1, g_p3w, g_p3b = ops.linear_backward(d_pre, h1, p3_w)
-        d_h0, g_p1g, g_p1b = ops.bn1d_backward(d_h1, h0, h1, p1_g, m_h, r_h, relu=True)
-        d_xp, g_p0w, g_p0b = ops.linear_backward(d_h0, x_pro, p0_w)
-        d_xpro = d_xp if d_xpro is None else ops.add2_small(d_xpro, d_xp)
-        grads[2:8] = [g_p0w, g_p0b, g_p1g, g_p1b, g_p3w, g_p3b]
-    d_g, g_bng, g_bnb = ops.bn1d_backward(d_xpro, g, x_pro, bn_g, m_pro, r_pro, relu=False)
-    grads[0], grads[1] = g_bng, g_bnb
-    return d_g, grads
+    """Backward of x_pro = bn(gap); x_pre = predictor_head(x_pro) (pcrlv2_model.py:124-127) down to the pooled vector (ops.heads_backward)."""
+    return ops.heads_backward(d_pro, d_pre, heads, x_pro, params)
 
 
 class DecoderBlockFn(Function):

@@ -1275,6 +1275,52 @@ def linear_forward(x, w, b):
     return y
 
 
+FUSED_HEAD_BWD = os.environ.get("PCRL_FUSED_HEAD_BWD", "1") != "0"     # A/B switch: 0 = nine launches (Linear backward x 2, BatchNorm1d backward x 2, add)
+
+
+def heads_backward(d_pro, d_pre, heads, x_pro, params):
+    """Backward of x_pro = bn(pooled); x_pre = predictor_head(x_pro) (pcrlv2_model_3d.py:55-59,67-70; pcrlv2_model.py:108-111,124-127) down to
+    the pooled vector.  heads = (pooled g, mean / rstd of bn, h0, h1, mean / rstd of predictor_head[1]); params = (bn.weight, bn.bias, ph0.weight,
+    ph0.bias, ph1.weight, ph1.bias, ph3.weight, ph3.bias).  -> (d_g float32 [N, C], [their 8 gradients]).
+    Two launches (pcrl_head_bwd_stage: Linear backward + the BatchNorm1d backward of what it produced, csrc/heads_fused.hip) where the rows fit
+    (N <= 512); else -- or with PCRL_FUSED_HEAD_BWD=0 -- the separate kernels."""
+    bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b = params
+    g, m_pro, r_pro, h0, h1, m_h, r_h = heads
+    N, C = g.shape
+    grads = [None] * 8
+    if FUSED_HEAD_BWD and N <= 512 and C % 4 == 0:
+        L, s, dev = lib(), stream_handle(), g.device
+        H = h0.shape[1]
+        d_h0 = None
+        if d_pre is not None:
+            d_pre = d_pre.contiguous()
+            d_h0 = _f32(N * H, dev).view(N, H)
+            v = _f32(2 * H + C, dev)
+            g_p3w = torch.empty_like(p3_w, dtype=torch.float32)
+            L.call("pcrl_head_bwd_stage", d_pre, p3_w.detach(), None, h1, h0, h1, p1_g.detach(), m_h, r_h, d_h0, v[:H], v[H:2 * H], g_p3w, v[2 * H:], N, C, H, 1, s)
+            grads[4], grads[5], grads[6], grads[7] = v[:H], v[H:2 * H], g_p3w, v[2 * H:]
+        d_g = _f32(N * C, dev).view(N, C)
+        v2 = _f32(2 * C + H, dev)
+        g_p0w = torch.empty_like(p0_w, dtype=torch.float32) if d_h0 is not None else None
+        L.call("pcrl_head_bwd_stage", d_h0, p0_w.detach() if d_h0 is not None else None, d_pro.contiguous() if d_pro is not None else None,
+               x_pro if d_h0 is not None else None, g, None, bn_g.detach(), m_pro, r_pro, d_g, v2[:C], v2[C:2 * C], g_p0w,
+               v2[2 * C:] if d_h0 is not None else None, N, H, C, 0, s)
+        grads[0], grads[1] = v2[:C], v2[C:2 * C]
+        if d_h0 is not None:
+            grads[2], grads[3] = g_p0w, v2[2 * C:]
+        return d_g, grads
+    d_xpro = d_pro.contiguous() if d_pro is not None else None
+    if d_pre is not None:
+        d_h1, g_p3w, g_p3b = linear_backward(d_pre, h1, p3_w)
+        d_h0, g_p1g, g_p1b = bn1d_backward(d_h1, h0, h1, p1_g, m_h, r_h, relu=True)
+        d_xp, g_p0w, g_p0b = linear_backward(d_h0, x_pro, p0_w)
+        d_xpro = d_xp if d_xpro is None else add2_small(d_xpro, d_xp)
+        grads[2:8] = [g_p0w, g_p0b, g_p1g, g_p1b, g_p3w, g_p3b]
+    d_g, g_bng, g_bnb = bn1d_backward(d_xpro, g, x_pro, bn_g, m_pro, r_pro, relu=False)
+    grads[0], grads[1] = g_bng, g_bnb
+    return d_g, grads
+
+
 def add2_small(a, b):
     """a + b for two float32 tensors of one shape (head-sized matrices), on the library's kernel instead of aten::add."""
     a, b = a.contiguous(), b.contiguous()

@@ -89,8 +89,22 @@ def golden(golden_dir):
     return fx, batches
 
 
-def _grad_report(model, fx, rel_tol, rel_tol_big, zero_tol):
-    worst, bad = 0.0, []
+# float32 gradient gates (5e-3 per-tensor rel-L2 against the float64 golden).  Measured on MI355X (tools/gates_probe.py, round 4):
+#   c_small_b4: 70 of 71 tensors <= 4.2e-3, up_tr128.ops.1.bn1.bias 5.2e-3;   c_b16: 55 of 71 <= 5e-3, the other 16 between 5.3e-3 and 8.2e-3 --
+#   every one of them an ENCODER tensor or a per-channel BatchNorm vector (down_tr64.ops.1.conv1.weight 8.2e-3, down_tr128.ops.1.bn1.bias 8.1e-3, ...).
+# Why those: a BatchNorm vector entry is a sum of dy * xhat over every voxel of the batch that cancels to a small remainder, and an encoder
+# tensor sits behind 9-16 batch-statistics backward passes, each of which subtracts two such sums from every element; float32 round-off is
+# amplified by the cancellation, and which tensor is worst moves with the summation order of any kernel (stock PyTorch float32 on the CPU is
+# 7.0e-3 away from the same golden).  So: 5e-3 for everything else -- decoder / up-conv / head WEIGHTS, the tensors a wrong tap or border class
+# shows up in -- 1.2e-2 for the two named classes, and at most a third of all tensors above 5e-3: a 2x regression of either class fails.
+LOOSE_GRAD_TENSORS = ("down_tr", ".bn1.weight", ".bn1.bias", ".bn.weight", ".bn.bias")
+
+
+def _grad_report(model, fx, rel_tol, rel_tol_big, zero_tol, tight=None):
+    """rel_tol / rel_tol_big: the gate for small / large tensors; tight: if given, the gate for every tensor OUTSIDE LOOSE_GRAD_TENSORS (which keep
+    rel_tol) and the count constraint above."""
+    worst, bad, above = 0.0, [], 0
+    total = 0
     for name, p in model.named_parameters():
         if f"grad/{name}/none" in fx.files:
             assert p.grad is None, f"{name}: reference has no gradient (unused head), HIP path produced one"
@@ -105,10 +119,16 @@ def _grad_report(model, fx, rel_tol, rel_tol_big, zero_tol):
         rel = np.linalg.norm(got_s - ref_s) / max(np.linalg.norm(ref_s), 1e-30)
         rel_n = abs(got_l2 - l2) / l2
         tol = rel_tol_big if p.numel() > 4096 else rel_tol
+        if tight is not None and not any(k in name for k in LOOSE_GRAD_TENSORS):
+            tol = tight
         worst = max(worst, rel)
+        total += 1
+        above += rel > 5e-3
         if rel > tol or rel_n > tol:
             bad.append((name, rel, rel_n))
     assert not bad, f"gradients outside rel-L2 tolerance: {bad[:8]} (+{max(0, len(bad) - 8)} more)"
+    if tight is not None:
+        assert above * 3 <= total, f"{above} of {total} tensors above 5e-3"
     return worst
 
 
@@ -127,7 +147,7 @@ def test_fp32_step_matches_reference_golden(golden):
     r["loss"].backward()
     # stock PyTorch float32 (CPU, oneDNN) lands at 7e-3 on this metric: backward through 17 batch-statistics normalisations
     # amplifies float32 round-off, and which tensor is worst moves with the summation order (measured here: 0.6e-2 .. 1.05e-2)
-    worst = _grad_report(model, fx, rel_tol=2e-2, rel_tol_big=2e-2, zero_tol=1e-5)
+    worst = _grad_report(model, fx, rel_tol=1.2e-2, rel_tol_big=1.2e-2, zero_tol=1e-5, tight=5e-3)
     print(f"fp32: worst gradient rel-L2 vs fp64 golden = {worst:.2e}")
     # BN running statistics after the three forwards of one step
     model.flush_counters()
@@ -213,9 +233,9 @@ def test_bf16_step_within_stated_tolerance_of_golden(golden):
 GOLDEN_STEPS = {
     # fp32: (map max, feature abs, (MSE-loss, other-loss) abs, gradient rel-L2)
     # bf16: (map max [mean = 1/4 of it], feature cosine, (MSE-loss, other-loss) abs, gradient-norm median, gradient-norm worst, gradient cosine min)
-    "c_b16_32x32x16": dict(fp32=(5e-5, 2e-4, (1e-5, 1e-5), 1.5e-2), bf16=(6e-2, 0.997, (5e-5, 2e-3), 0.02, 0.25, 0.8), grads=True),
+    "c_b16_32x32x16": dict(fp32=(5e-5, 2e-4, (1e-5, 1e-5), 1.2e-2), bf16=(6e-2, 0.997, (5e-5, 2e-3), 0.02, 0.25, 0.8), grads=True),
     # b = 8 rows in BatchNorm1d, 8x the voxels per crop: measured bf16 maps max 5.8e-2, cosine losses 1.5e-3, norms median 1.8 % / worst 10 %, direction 0.85
-    "c_luna_b8_64x64x32": dict(fp32=(5e-5, 2e-4, (1e-5, 1e-5), 1.5e-2), bf16=(9e-2, 0.996, (5e-5, 4e-3), 0.04, 0.25, 0.75), grads=True),
+    "c_luna_b8_64x64x32": dict(fp32=(5e-5, 2e-4, (1e-5, 1e-5), 1.2e-2), bf16=(9e-2, 0.996, (5e-5, 4e-3), 0.04, 0.25, 0.75), grads=True),
     "c_luna_b2_64x64x32": dict(fp32=(5e-5, 5e-4, (1e-5, 2e-5), None), bf16=(1e-1, 0.975, (5e-5, 2e-2), None, None, None), grads=False),
 }
 
@@ -256,7 +276,7 @@ def test_step_matches_reference_golden_large_batch(tag, dt, golden_dir):
         return
     r["loss"].backward()
     if f32:
-        worst = _grad_report(model, fx, rel_tol=tol[3], rel_tol_big=tol[3], zero_tol=1e-5)
+        worst = _grad_report(model, fx, rel_tol=tol[3], rel_tol_big=tol[3], zero_tol=1e-5, tight=5e-3)
         print(f"{tag} fp32: worst gradient rel-L2 vs fp64 golden = {worst:.2e}")
         return
     devs, coss, scalars = [], [], []
@@ -746,6 +766,45 @@ def test_bf16_loss_curve_vs_rounding_aware_comparator(golden_dir):
     for s in range(nsteps):
         assert abs(got[s][1] - ref[s][1]) < 1e-3, (s, "loss1", got[s][1], ref[s][1])
         assert abs(got[s][3] - ref[s][3]) < (1e-3 if s < 8 else 4e-3), (s, "loss4", got[s][3], ref[s][3])
+
+
+def test_bf16_rounding_points_census(golden_dir):
+    """A tripwire for the rounding-aware comparator (oracle/pcrlv2_bf16_emulation.py reproduces the engine's bf16 rounding points BY HAND, DESIGN
+    section 2): every bf16 store of the engine happens inside a C-ABI launch that is called with dtype = bf16, so the census of those calls
+    over one steady-state step (entry point -> number of calls) is frozen in tests/golden/bf16_call_census.json together with what each one
+    rounds.  A new bf16-typed launch on the training path, or one called a different number of times, fails here: add the rounding point to the
+    comparator (and to DESIGN section 2 and the fixture: tools/gates_probe.py --write-census) or show that it has none."""
+    import json
+    from pcrlv2_amd import _lib
+    fx = json.load(open(os.path.join(golden_dir, "bf16_call_census.json")))
+    L = _lib.lib()
+
+    class Census:
+        watch = {n for n, (_, args) in L.protos.items() if any(t == "pcrl_stream_t" for t, _ in args)}
+        calls = {}
+
+        def add(self, name, args):
+            a = {an: v for (_, an), v in zip(L.protos[name][1], args)}
+            if a.get("dtype") == _lib.PCRL_BF16:
+                self.calls[name] = self.calls.get(name, 0) + 1
+    model = build(torch.bfloat16)
+    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    batch = O.fill_batch(4, (32, 32, 16), dtype=torch.float32, seed=7)
+    random.seed(0)
+    train_step(model, opt, batch, 3, MSELoss(), CosineSimilarityMean())
+    torch.cuda.synchronize()
+    c = Census()
+    L.counter = c
+    try:
+        random.seed(0)
+        train_step(model, opt, batch, 3, MSELoss(), CosineSimilarityMean())
+        torch.cuda.synchronize()
+    finally:
+        L.counter = None
+    got = dict(sorted(c.calls.items()))
+    assert set(got) == set(fx["calls"]), ("bf16-typed launches changed", sorted(set(got) ^ set(fx["calls"])))
+    assert got == fx["calls"], {k: (got[k], fx["calls"][k]) for k in got if got[k] != fx["calls"][k]}
+    assert set(fx["rounding"]) == set(fx["calls"])        # every launch of the census says what it rounds
 
 
 def test_config_c4_large_crops_step_properties():
