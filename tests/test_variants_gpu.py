@@ -126,35 +126,48 @@ def test_padded_first_layer_follows_weight_updates_that_bypass_the_engine_optimi
     x = O.variant_input(3, (32, 32, 16), 3, torch.float32)
     name = "down_tr64.ops.0.conv1.weight"
 
-    def check(train):
+    def engine(train, keep=None):
         model.train(train)
-        out, _feats, _masks = model(x.to(DEV))
-        sd = {n: (v.detach().double().cpu() if v.is_floating_point() else v.detach().cpu()) for n, v in model.state_dict().items()}
-        return out, sd
+        out, feats, _masks = model(x.to(DEV))
+        if keep is not None:
+            keep.append(out)
+        return [out.detach().double().cpu()] + [f[0].detach().double().cpu() for f in feats]
 
-    def oracle_out(sd, train):
+    def snapshot():
+        return {n: (v.detach().double().cpu() if v.is_floating_point() else v.detach().cpu()) for n, v in model.state_dict().items()}
+
+    def oracle(sd, train):
         with torch.no_grad():
-            return O.forward(sd, x.double(), training=train, act=k["act"], norm=k["norm"])[0]
+            out, feats, _ = O.forward(sd, x.double(), training=train, act=k["act"], norm=k["norm"])
+        return [out] + [f[0] for f in feats]
+
+    def close(got, ref, what):
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert (a - b).abs().max() < (5e-5 if i == 0 else 3e-4), (what, i, float((a - b).abs().max()))
 
     train = how != "eval_between"
     model.train(train)
-    sd_before = {n: (v.detach().double().cpu() if v.is_floating_point() else v.detach().cpu()) for n, v in model.state_dict().items()}
-    out0, _ = check(train)
-    assert (out0.double().cpu() - oracle_out(sd_before, train)).abs().max() < 5e-5
+    sd_before = snapshot()
+    ref0 = oracle(sd_before, train)
+    kept = []
+    got0 = engine(train, kept)
+    close(got0, ref0, "before the update")
     w = dict(model.named_parameters())[name]
     if how == "torch_sgd":
         opt = torch.optim.SGD(model.parameters(), lr=0.5)
-        (out0 * out0).mean().backward()
+        (kept[0] * kept[0]).mean().backward()
         torch.cuda.synchronize()
         assert w.grad is not None and float(w.grad.abs().max()) > 0
         opt.step()
     else:
         with torch.no_grad():
-            w.copy_(w * -0.5 + 0.01)
+            w.copy_(w * -2.0 + 0.05)
     model.flush_counters()
-    sd_mid = {n: (v.detach().double().cpu() if v.is_floating_point() else v.detach().cpu()) for n, v in model.state_dict().items()}
+    sd_mid = snapshot()
     assert (sd_mid[name] - sd_before[name]).abs().max() > 1e-4      # the parameter really moved
-    out1, _ = check(train)
-    ref1 = oracle_out(sd_mid, train)
-    assert (out1.double().cpu() - ref1).abs().max() < 5e-5, "the first layer kept the packed weights of the previous forward"
-    assert (out1.double().cpu() - out0.double().cpu()).abs().max() > 1e-4
+    ref1 = oracle(sd_mid, train)
+    # the comparison below can only catch a stale pack if the update is visible in what is compared: the oracle's own outputs must have moved
+    moved = max(float((a - b).abs().max()) for a, b in zip(ref1, ref0))
+    assert moved > 1e-3, moved
+    got1 = engine(train)
+    close(got1, ref1, "after the update: the first layer kept the packed weights of the previous forward?")
