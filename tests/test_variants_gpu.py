@@ -120,6 +120,13 @@ def test_padded_first_layer_follows_weight_updates_that_bypass_the_engine_optimi
     kw = dict(in_channels=3)
     k = okw(kw)
     st = O.fill_state(torch.float32, **k)
+    if how == "eval_between":
+        # eval mode normalises with the RUNNING statistics: with the initial ones (variance 1 against activations of ~0.05) every layer shrinks its
+        # input and the outputs barely depend on the first layer (the oracle's own output moves by 1e-5 under the update below) -- statistics of
+        # the activations' real size make the comparison sensitive (asserted below)
+        for key in st:
+            if key.endswith("running_var"):
+                st[key] = torch.full_like(st[key], 2e-3)
     model = PCRLv23d(**kw).to(DEV)
     model.load_state_dict(st)
     model.set_compute_dtype(torch.float32)
