@@ -82,7 +82,7 @@ class Account2D:
                 2.0 * a["N"] * a["Ho"] * a["Wo"] * taps * a["Ci"] * a["CoP"])
 
     def _nparts(a, *names):
-        return sum(1 for n in names if a.get(n))
+        return sum(1 for n in names if a.get(n) is not None)
 
     RULES = {
         "pcrl_conv2d_fwd": _fwd,
