@@ -14,6 +14,10 @@
 // on the tap-flipped packed weights.
 #include "common.h"
 
+#ifndef NARROW_TRANSPOSED
+#define NARROW_TRANSPOSED 1
+#endif
+
 namespace {
 
 constexpr int PH = 8, PW = 32, HPH = PH + 2, HPW = PW + 2;
@@ -82,7 +86,9 @@ __global__ void __launch_bounds__(256) conv2d_narrow_kernel(const NarrowConvPara
     poff[mf] = (((px >> 5) * HPW) + (px & 31)) * CS * 2;
   }
   // channels of this lane's accumulator rows: c0 + r, c0 = nf * 16 + 4 * lg
-  float bv[NF][4], s1[NF][4], s2[NF][4];
+  float bv[NF][4], s1[NF][4], s2[NF][4], bvu[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) bvu[nf] = (p.bias && nf * 16 + lr < p.Nc) ? p.bias[nf * 16 + lr] : 0.f;
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
@@ -150,13 +156,16 @@ __global__ void __launch_bounds__(256) conv2d_narrow_kernel(const NarrowConvPara
 #pragma unroll
       for (int mf = 0; mf < 4; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nf][s], fa[mf], acc[mf][nf], 0, 0, 0);
+        for (int nf = 0; nf < NF; ++nf)
+          acc[mf][nf] = NARROW_TRANSPOSED ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nf][s], fa[mf], acc[mf][nf], 0, 0, 0)
+                                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mf], fb[nf][s], acc[mf][nf], 0, 0, 0);
     }
     // ---- epilogue: lane holds pixel wid*64 + mf*16 + lr, channels nf*16 + 4*lg + r ----
     int t_ = pb;
     const int w0 = (t_ % pw) * PW; t_ /= pw;
     const int h0 = (t_ % ph) * PH; t_ /= ph;
     const int n = t_;
+#if NARROW_TRANSPOSED
     if (RED2) {
       // rows 2*wid (mf 0, 1) and 2*wid + 1 (mf 2, 3) of the patch are one coarse row; columns lr, lr ^ 1 one coarse column
 #pragma unroll
@@ -213,6 +222,42 @@ __global__ void __launch_bounds__(256) conv2d_narrow_kernel(const NarrowConvPara
         }
       }
     }
+#else
+    // untransposed: lane holds pixels wid*64 + mf*16 + 4*lg + r (four consecutive pixels of a row), channel nf*16 + lr
+    if (RED2) {
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+          const int co = nf * 16 + lr;
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const float v = (acc[mf][nf][2 * q] + acc[mf + 2][nf][2 * q]) + (acc[mf][nf][2 * q + 1] + acc[mf + 2][nf][2 * q + 1]);
+            const int64_t row = ((int64_t)n * (p.H >> 1) + (h0 >> 1) + wid) * (p.W >> 1) + ((w0 + mf * 16 + 4 * lg) >> 1) + q;
+            if (co < p.Nc) Y[row * p.Nc + co] = (bf16)v;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int mf = 0; mf < 4; ++mf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = wid * 64 + mf * 16 + lg * 4 + r;
+          const int64_t row = ((int64_t)n * p.H + h0 + (px >> 5)) * p.W + w0 + (px & 31);
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf) {
+            const int co = nf * 16 + lr;
+            if (co < p.Nc) {
+              const float v = acc[mf][nf][r] + bvu[nf];
+              if (p.out_f32) Yf[row * p.Nc + co] = v;
+              else Y[row * p.Nc + co] = (bf16)v;
+              s1[nf][0] += v;
+              s2[nf][0] += v * v;
+            }
+          }
+        }
+    }
+#endif
     if (more) NC_STORE(cur ^ 1);
     __syncthreads();      // the other buffer is complete; everybody is done reading this one
     cur ^= 1;
@@ -220,6 +265,7 @@ __global__ void __launch_bounds__(256) conv2d_narrow_kernel(const NarrowConvPara
 #undef NC_LOAD
 #undef NC_STORE
   if (!RED2 && p.stats) {
+#if NARROW_TRANSPOSED
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
@@ -235,6 +281,20 @@ __global__ void __launch_bounds__(256) conv2d_narrow_kernel(const NarrowConvPara
           red[wid][nf * 16 + 4 * lg + r][1] = b;
         }
       }
+#else
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      float a = s1[nf][0], b = s2[nf][0];
+      a += __shfl_xor(a, 16, 64);
+      b += __shfl_xor(b, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      b += __shfl_xor(b, 32, 64);
+      if (lg == 0) {
+        red[wid][nf * 16 + lr][0] = a;
+        red[wid][nf * 16 + lr][1] = b;
+      }
+    }
+#endif
     __syncthreads();
     if (tid < NF * 16 && tid < p.Nc) {
       float* o = p.stats + ((int64_t)blockIdx.x * p.Nc + tid) * 2;

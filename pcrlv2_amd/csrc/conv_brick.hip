@@ -16,6 +16,15 @@
 //      the next chunk is prefetched into registers during the last tap row -- + one weight stage (3 taps x 64 x 64 B =
 //      12 KiB, next stage prefetched into registers) -> 72 KiB, two blocks per CU.
 #include "common.h"
+
+// BRICK_TRANSPOSED = 1: the MFMAs run transposed (D = W * X^T) so that a lane holds four consecutive channels of one voxel and the epilogue issues
+// 16 eight-byte stores per lane instead of 64 two-byte ones.  MEASURED SLOWER (round 4, same box, 2 x 2 interleaved runs of the C5 step: 44.7 ms
+// against 43.6 with the two-byte form): an eight-byte store instruction of this layout touches 16 different 32-byte segments (16 voxels), the
+// two-byte form 4 (16 consecutive channels of 4 voxels) -- the same number of segments in a quarter of the instructions is not what the
+// store path rewards, and the per-channel statistics need four shuffle steps instead of two.  Kept as a compile-time switch, default off.
+#ifndef BRICK_TRANSPOSED
+#define BRICK_TRANSPOSED 0
+#endif
 #include <atomic>
 #include <mutex>
 
@@ -237,7 +246,8 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   do {                                                                                                    \
     _Pragma("unroll") for (int fm = (F0_); fm < (F1_); ++fm)                                              \
       _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                      \
-        acc[fm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[B_][j], fa[B_][fm], acc[fm][j], 0, 0, 0); \
+        acc[fm][j] = BRICK_TRANSPOSED ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[B_][j], fa[B_][fm], acc[fm][j], 0, 0, 0) \
+                                      : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[B_][fm], fb[B_][j], acc[fm][j], 0, 0, 0); \
   } while (0)
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -357,6 +367,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #undef LOAD_W
 #undef STORE_W
 
+#if BRICK_TRANSPOSED
   // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick) ----
   // The MFMAs run TRANSPOSED (D = W * X^T: the weight fragment is the A operand), so a lane holds FOUR CONSECUTIVE CHANNELS (j * 16 + 4 lg + r)
   // of ONE voxel (fm * 16 + lr): 16 eight-byte stores per lane instead of 64 two-byte ones (round 4; with 9 taps per chunk in the 2D
@@ -429,6 +440,68 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
       o[1] = c2;
     }
   }
+#else   // the round-3 form: D = X * W^T, a lane holds 4 voxels of one channel, two-byte stores (A/B: tools/build_variant.sh ... -DBRICK_TRANSPOSED=0)
+  // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick) ----
+  float s1[FN], s2[FN], bv[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    s1[j] = 0.f;
+    s2[j] = 0.f;
+    bv[j] = (!UPCF && p.bias) ? p.bias[n0 + j * 16 + lr] : 0.f;
+  }
+  const int uch0 = UPCF ? n0 - uph * p.upc : n0;   // first channel of this tile (inside its phase)
+  const int ypitch = UPCF ? p.upc : p.Nc;
+#pragma unroll
+  for (int fm = 0; fm < 4; ++fm) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int v = wid * 64 + fm * 16 + lg * 4 + r;
+      int64_t row = (int64_t)n * p.D * p.H * p.W + (int64_t)(d0 + (v >> 6)) * p.sd + (h0 + ((v >> 3) & 7)) * p.sh + (w0 + (v & 7)) * p.sw;
+      if (UPCF) {   // the phase's fine voxel, and the bias of its border class (0 first, 1 inside, 2 last per axis; class number in memory order = tap strides)
+        const int fd = 2 * (d0 + (v >> 6)) + upd, fh = 2 * (h0 + ((v >> 3) & 7)) + uphh, fw = 2 * (w0 + (v & 7)) + upw;
+        row = (int64_t)n * (8 * p.D * p.H * p.W) + (int64_t)fd * p.fsd + fh * p.fsh + fw * p.fsw;
+        const int cd = fd == 0 ? 0 : (fd == 2 * p.D - 1 ? 2 : 1), ch = fh == 0 ? 0 : (fh == 2 * p.H - 1 ? 2 : 1), cw = fw == 0 ? 0 : (fw == 2 * p.W - 1 ? 2 : 1);
+        const int cls = cd * p.td + ch * p.th + cw * p.tw;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bv[j] = p.bias_tab[cls * p.upc + uch0 + j * 16 + lr];
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const float val = acc[fm][j][r] + bv[j];
+        p.y[row * ypitch + uch0 + j * 16 + lr] = (bf16)val;
+        s1[j] += val;
+        s2[j] += val * val;
+      }
+    }
+  }
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][64 ch][2]; the loop ended with a barrier
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float a = s1[j], c2 = s2[j];
+      a += __shfl_xor(a, 16, 64);
+      c2 += __shfl_xor(c2, 16, 64);
+      a += __shfl_xor(a, 32, 64);
+      c2 += __shfl_xor(c2, 32, 64);
+      if (lg == 0) {
+        red[(wid * 64 + j * 16 + lr) * 2 + 0] = a;
+        red[(wid * 64 + j * 16 + lr) * 2 + 1] = c2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      float a = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a += red[(q * 64 + tid) * 2 + 0];
+        c2 += red[(q * 64 + tid) * 2 + 1];
+      }
+      float* o = p.stats + ((int64_t)brick_id * p.Nc + n0 + tid) * 2;
+      o[0] = a;
+      o[1] = c2;
+    }
+  }
+#endif
 }
 
 }  // namespace
