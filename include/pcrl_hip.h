@@ -41,6 +41,8 @@ enum { PCRL_OK = 0, PCRL_EINVAL = -1, PCRL_ELAUNCH = -2, PCRL_EWORKSPACE = -3 };
 
 const char* pcrl_version(void);
 const char* pcrl_last_error(void);
+/* zero-fill `bytes` bytes at p on `stream` (hipMemsetAsync; aten::zero_ on a freshly allocated gradient tensor) */
+int pcrl_zero(void* p, size_t bytes, pcrl_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Weight packing (once per optimizer step).  Reference layouts: Conv3d weight [Co][Ci][3][3][3]

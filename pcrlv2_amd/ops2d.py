@@ -185,7 +185,7 @@ def conv2d_backward(x, dy, w, packed: PackedConv2d, stride, pad, up, dtype, need
         packs = packed.get_s2(w, dtype)
         dx = new_act2(N, Hi, Wi, Ci, dtype, x.device)
         if KH == 1:
-            dx.zero_()
+            L.call("pcrl_zero", dx, dx.numel() * dx.element_size(), s)      # 1x1 stride 2: three of the four parity classes receive nothing
         for (a, b), wp in packs.items():
             L.call("pcrl_conv2d_dgrad_s2", dy, wp, dx, N, Hi, Wi, Ci, Ho, Wo, CoP, KH, KW, a, b, dtype_code(dtype), s)
     elif need_dx:

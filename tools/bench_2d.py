@@ -207,11 +207,12 @@ def main():
     random.seed(0)
     model = PCRLv2().cuda().set_compute_dtype(a.dtype)
     opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
-    g = torch.Generator(device=dev).manual_seed(1234)
-    kw = dict(generator=g, device=dev)
+    g = torch.Generator().manual_seed(1234)          # synthetic inputs drawn on the host, resident on the device before the first step
+    kw = dict(generator=g)
     x1 = torch.randn(a.b, 3, a.size, a.size, **kw)
-    batch = (x1, x1 + 0.1 * torch.randn(a.b, 3, a.size, a.size, **kw), torch.rand(a.b, 3, a.size, a.size, **kw), None,
-             [torch.randn(a.b, 3, 96, 96, **kw) for _ in range(6)])
+    batch = tuple(t.to(dev) if torch.is_tensor(t) else ([u.to(dev) for u in t] if t is not None else None) for t in
+                  (x1, x1 + 0.1 * torch.randn(a.b, 3, a.size, a.size, **kw), torch.rand(a.b, 3, a.size, a.size, **kw), None,
+                   [torch.randn(a.b, 3, 96, 96, **kw) for _ in range(6)]))
     crit, cos = train_2d.MSELoss2d(), CosineSimilarityMean()
     dt, rep, out = c5_report(model, opt, batch, crit, cos, train_2d, steps=a.steps, warmup=a.warmup, roofline=not a.no_roofline)
     flop = 3 * a.b * (2 * conv_flops_fwd(a.size) + 6 * conv_flops_fwd(96))      # fwd + dgrad + wgrad ~ 3x forward
