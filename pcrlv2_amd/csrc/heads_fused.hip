@@ -15,19 +15,21 @@ namespace {
 
 constexpr int RMAX = 8;     // rows per lane: N <= 512
 
-// role A: wave = one column c; lanes own rows n = lane + 64 i
+// role A: BLOCK = one column c; the four waves split the K range of the product (a quarter each: the walk over K is the kernel's critical
+// chain -- with a whole column per wave a launch took 36 us), lanes own rows n = lane + 64 i; wave 0 combines through LDS (fixed order) and
+// runs the BatchNorm1d backward of the column.
 __device__ __forceinline__ void role_column(const float* __restrict__ dy, const float* __restrict__ W, const float* __restrict__ add,
                                             const float* __restrict__ xbn, const float* __restrict__ ybn, const float* __restrict__ gamma,
                                             const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
-                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int K, int C, int relu, int c, int lane) {
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int K, int C, int relu, int c, int lane, int wv,
+                                            float* __restrict__ sm) {
   float t[RMAX];
 #pragma unroll
-  for (int i = 0; i < RMAX; ++i) {
-    const int n = lane + 64 * i;
-    t[i] = (add && n < N) ? add[(int64_t)n * C + c] : 0.f;
-  }
+  for (int i = 0; i < RMAX; ++i) t[i] = 0.f;
   if (dy) {
-    for (int k = 0; k < K; k += 4) {
+    const int kq = ((K / 4 + 3) / 4) * 4;                 // a multiple of 4 per wave
+    const int k0 = wv * kq, k1 = min(K, k0 + kq);
+    for (int k = k0; k < k1; k += 4) {
       const float w0 = W[(int64_t)k * C + c], w1 = W[(int64_t)(k + 1) * C + c], w2 = W[(int64_t)(k + 2) * C + c], w3 = W[(int64_t)(k + 3) * C + c];   // wave-uniform
 #pragma unroll
       for (int i = 0; i < RMAX; ++i) {
@@ -38,6 +40,18 @@ __device__ __forceinline__ void role_column(const float* __restrict__ dy, const 
         }
       }
     }
+    if (wv > 0) {
+#pragma unroll
+      for (int i = 0; i < RMAX; ++i) sm[((wv - 1) * RMAX + i) * 64 + lane] = t[i];
+    }
+  }
+  __syncthreads();
+  if (wv != 0) return;
+#pragma unroll
+  for (int i = 0; i < RMAX; ++i) {
+    const int n = lane + 64 * i;
+    if (dy) t[i] = ((t[i] + sm[(0 * RMAX + i) * 64 + lane]) + sm[(1 * RMAX + i) * 64 + lane]) + sm[(2 * RMAX + i) * 64 + lane];
+    if (add && n < N) t[i] += add[(int64_t)n * C + c];
   }
   const double mu = mean[c], rs = rstd[c];
   double s1 = 0.0, s2 = 0.0;
@@ -74,11 +88,11 @@ __global__ void __launch_bounds__(256) head_bwd_stage_kernel(const float* __rest
                                                              const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ dW, float* __restrict__ db, int N, int K, int C,
                                                              int relu, int nA, int nBx) {
+  __shared__ float sm[3 * RMAX * 64];
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int b = blockIdx.x;
-  if (b < nA) {                                   // ---- role A: four columns of t and their BatchNorm1d backward
-    const int c = b * 4 + wv;
-    if (c < C) role_column(dy, W, add, xbn, ybn, gamma, mean, rstd, dx, dgamma, dbeta, N, K, C, relu, c, lane);
+  if (b < nA) {                                   // ---- role A: one column of t and its BatchNorm1d backward
+    role_column(dy, W, add, xbn, ybn, gamma, mean, rstd, dx, dgamma, dbeta, N, K, C, relu, b, lane, wv, sm);
     return;
   }
   b -= nA;
@@ -119,7 +133,7 @@ extern "C" int pcrl_head_bwd_stage(const float* dy, const float* W, const float*
   PCRL_REQUIRE(!dy || (W && xin && dW && db && K > 0 && K % 4 == 0), "head_bwd_stage: the Linear part needs W, xin, dW, db and K %% 4 == 0 (K=%d)", K);
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   PCRL_REQUIRE(!dy || (al(dy) && al(xin) && al(dW)), "head_bwd_stage: dy, xin and dW must be 16-byte aligned");
-  const int nA = (C + 3) / 4, nBx = (C + 255) / 256;
+  const int nA = C, nBx = (C + 255) / 256;
   const int nB = dy ? nBx * ((K + 3) / 4) : 0, nC = dy ? (K + 3) / 4 : 0;
   hipLaunchKernelGGL(head_bwd_stage_kernel, dim3(nA + nB + nC), dim3(256), 0, as_stream(stream), dy, W, add, xin, xbn, ybn, gamma, mean, rstd, dx, dgamma,
                      dbeta, dW, db, N, dy ? K : 0, C, relu, nA, nBx);

@@ -332,3 +332,64 @@ def test_stem_kernels_against_torch(N, H, W):
     packed = ops2d.PackedConv2d()
     y2, _, _ = ops2d.conv2d_forward(ops2d.image_to_act(xd, dt, 8), wd, None, packed, 2, 3, 0, dt)
     _close(y, y2.double().cpu(), dt, "stem fwd vs gather kernel", bf_tol=4e-3)
+
+
+@pytest.mark.parametrize("N,C", [(4, 16), (32, 128), (64, 256), (192, 64), (384, 32), (500, 16)])
+@pytest.mark.parametrize("parts", ["pro+pre", "pre", "pro"])
+def test_heads_backward_two_launches_equal_the_nine(N, C, parts):
+    """ops.heads_backward through pcrl_head_bwd_stage (Linear backward + the BatchNorm1d backward of what it produced, one launch per half of
+    the chain) against the separate kernels (PCRL_FUSED_HEAD_BWD=0) and against float64 autograd of the same chain."""
+    from pcrlv2_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + C)
+    H = 2 * C
+    pooled = torch.randn(N, C, generator=g)
+    P = dict(bn_g=torch.rand(C, generator=g) + 0.5, bn_b=torch.randn(C, generator=g) * 0.1, p0_w=torch.randn(H, C, generator=g) / C ** 0.5,
+             p0_b=torch.randn(H, generator=g) * 0.1, p1_g=torch.rand(H, generator=g) + 0.5, p1_b=torch.randn(H, generator=g) * 0.1,
+             p3_w=torch.randn(C, H, generator=g) / H ** 0.5, p3_b=torch.randn(C, generator=g) * 0.1)
+    d_pro = torch.randn(N, C, generator=g) if "pro" in parts else None
+    d_pre = torch.randn(N, C, generator=g) if "pre" in parts else None
+    # float64 reference
+    R = {k: v.double().requires_grad_(True) for k, v in P.items()}
+    gp = pooled.double().requires_grad_(True)
+    x_pro = F.batch_norm(gp, None, None, R["bn_g"], R["bn_b"], True, 0.1, 1e-5)
+    h0 = x_pro @ R["p0_w"].t() + R["p0_b"]
+    h1 = torch.relu(F.batch_norm(h0, None, None, R["p1_g"], R["p1_b"], True, 0.1, 1e-5))
+    x_pre = h1 @ R["p3_w"].t() + R["p3_b"]
+    loss = 0.0
+    if d_pro is not None:
+        loss = loss + (x_pro * d_pro.double()).sum()
+    if d_pre is not None:
+        loss = loss + (x_pre * d_pre.double()).sum()
+    loss.backward()
+    # engine forward pieces (the saved tensors of the stage Functions)
+    D = {k: v.to(dev) for k, v in P.items()}
+    pg = pooled.to(dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    xp, m_pro, r_pro = ops.bn1d_forward(pg, D["bn_g"], D["bn_b"], rm, rv, relu=False)
+    e_h0 = ops.linear_forward(xp, D["p0_w"], D["p0_b"])
+    e_h1, m_h, r_h = ops.bn1d_forward(e_h0, D["p1_g"], D["p1_b"], torch.zeros(H, device=dev), torch.ones(H, device=dev), relu=True)
+    heads = (pg, m_pro, r_pro, e_h0, e_h1, m_h, r_h)
+    params = tuple(D[k] for k in ("bn_g", "bn_b", "p0_w", "p0_b", "p1_g", "p1_b", "p3_w", "p3_b"))
+    dp = d_pro.to(dev) if d_pro is not None else None
+    dq = d_pre.to(dev) if d_pre is not None else None
+    outs = []
+    keep = ops.FUSED_HEAD_BWD
+    try:
+        for fused in (True, False):
+            ops.FUSED_HEAD_BWD = fused
+            outs.append(ops.heads_backward(dp, dq, heads, xp, params))
+    finally:
+        ops.FUSED_HEAD_BWD = keep
+    names = ("bn_g", "bn_b", "p0_w", "p0_b", "p1_g", "p1_b", "p3_w", "p3_b")
+    for d_g, grads in outs:
+        _close(d_g, gp.grad, torch.float32, "d pooled", f32_tol=2e-4)
+        for nm, gr in zip(names, grads):
+            if R[nm].grad is None or (d_pre is None and nm.startswith(("p0", "p1", "p3"))):
+                assert gr is None, nm
+                continue
+            ref = R[nm].grad
+            if float(ref.norm()) < 1e-9:        # a bias in front of a BatchNorm1d: identically zero
+                assert float(gr.abs().max()) < 1e-4, nm
+            else:
+                _close(gr, ref, torch.float32, nm, f32_tol=2e-4)
