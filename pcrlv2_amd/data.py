@@ -299,11 +299,21 @@ class AugmentedLoader:
         cuda = torch.device(device).type == "cuda"
         self.slots = None
         files = list(files)
-        if cuda and PIN_MODE == "slots" and AUG_STREAM and workers > 0 and len(files) > 0:
+        use_slots = cuda and PIN_MODE == "slots" and AUG_STREAM and workers > 0 and len(files) > 0
+        if use_slots:
             prefetch = 2
             nslots = prefetch * workers + 6            # outstanding index batches + the batches this process still holds (see __iter__)
             pshape = tuple(np.load(files[0], mmap_mode="r").shape)
             lshape = tuple(np.load(files[0].replace("global", "local"), mmap_mode="r").shape)
+            need = 4 * nslots * batch_size * (int(np.prod(pshape)) + int(np.prod(lshape)))
+            try:        # the slots live in /dev/shm: a container with a small shm mount would die with SIGBUS on the first write, not with an exception
+                vfs = os.statvfs("/dev/shm")
+                use_slots = vfs.f_bavail * vfs.f_frsize > 1.25 * need
+            except OSError:
+                use_slots = False
+            if not use_slots:
+                print(f"[pcrlv2_amd.data] /dev/shm has no room for {need / 2**20:.0f} MB of batch slots: falling back to torch's pin_memory thread (slower, see PCRL_LOADER_PIN)")
+        if use_slots:
             pair_buf = torch.empty((nslots, batch_size) + pshape, dtype=torch.float32).share_memory_()
             local_buf = torch.empty((nslots, batch_size) + lshape, dtype=torch.float32).share_memory_()
             pinned = _pin_registered(pair_buf) and _pin_registered(local_buf)
@@ -313,7 +323,7 @@ class AugmentedLoader:
                                                       persistent_workers=True, prefetch_factor=prefetch)
         else:
             self.loader = torch.utils.data.DataLoader(LunaCropPairs(files), batch_size=batch_size, shuffle=shuffle, num_workers=workers,
-                                                      pin_memory=cuda and PIN_MODE == "loader", drop_last=drop_last,
+                                                      pin_memory=cuda and PIN_MODE in ("loader", "slots"), drop_last=drop_last,
                                                       persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
         self.augment = GpuLunaAugment(device, seed)
         self._stream = None
