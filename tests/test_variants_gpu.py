@@ -126,7 +126,7 @@ def test_padded_first_layer_follows_weight_updates_that_bypass_the_engine_optimi
         # the activations' real size make the comparison sensitive (asserted below)
         for key in st:
             if key.endswith("running_var"):
-                st[key] = torch.full_like(st[key], 2e-3)
+                st[key] = torch.full_like(st[key], 0.25)
     model = PCRLv23d(**kw).to(DEV)
     model.load_state_dict(st)
     model.set_compute_dtype(torch.float32)
@@ -148,9 +148,9 @@ def test_padded_first_layer_follows_weight_updates_that_bypass_the_engine_optimi
             out, feats, _ = O.forward(sd, x.double(), training=train, act=k["act"], norm=k["norm"])
         return [out] + [f[0] for f in feats]
 
-    def close(got, ref, what):
+    def close(got, ref, what):       # absolute for O(1) tensors, relative to the tensor's size where the running statistics above blow the features up
         for i, (a, b) in enumerate(zip(got, ref)):
-            assert (a - b).abs().max() < (5e-5 if i == 0 else 3e-4), (what, i, float((a - b).abs().max()))
+            assert (a - b).abs().max() < (5e-5 if i == 0 else 3e-4) * max(1.0, float(b.abs().max())), (what, i, float((a - b).abs().max()), float(b.abs().max()))
 
     train = how != "eval_between"
     model.train(train)
@@ -174,7 +174,7 @@ def test_padded_first_layer_follows_weight_updates_that_bypass_the_engine_optimi
     assert (sd_mid[name] - sd_before[name]).abs().max() > 1e-4      # the parameter really moved
     ref1 = oracle(sd_mid, train)
     # the comparison below can only catch a stale pack if the update is visible in what is compared: the oracle's own outputs must have moved
-    moved = max(float((a - b).abs().max()) for a, b in zip(ref1, ref0))
+    moved = max(float((a - b).abs().max()) / max(1.0, float(b.abs().max())) for a, b in zip(ref1, ref0))
     assert moved > 1e-3, moved
     got1 = engine(train)
     close(got1, ref1, "after the update: the first layer kept the packed weights of the previous forward?")
