@@ -438,6 +438,9 @@ int pcrl_concat(const void* const* src, const int64_t* nbytes, int n, void* dst,
 /* loss = loss1 + loss2 + loss4 + local_loss with loss4 = beta * l4 (train_3d.py:136-138) from four device scalars in one launch:
  * out[0] = total (the reference's order of additions), out[1] = beta * l4. */
 int pcrl_loss_total(const float* l1, const float* l2, const float* l4, const float* l5, float beta, float* out, pcrl_stream_t stream);
+/* Its backward (autograd's mul / select_backward / add_ on four scalars, train_3d.py:138,144): out[0..3] = g, beta * g, g, g -- the gradients
+ * of loss1, l4 and of the (global, local) pair of cosine groups, which pcrl_cosine_terms_bwd takes as out + 2. */
+int pcrl_loss_total_bwd(const float* g, float beta, float* out, pcrl_stream_t stream);
 /* The divergence guard of train_3d.py:140-142 (`if loss > 1000 and epoch > 10: continue`) decided ON THE DEVICE, so that epochs 11..240 run
  * without a forward -> backward host synchronisation: pcrl_guard_flag writes out[0] = (loss[0] > threshold) ? 1 : 0 (under data parallelism
  * the caller MAX-all-reduces it: one process, one decision in the reference), pcrl_sgd_step_guarded is pcrl_sgd_step that does NOTHING when

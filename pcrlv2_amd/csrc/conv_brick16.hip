@@ -49,6 +49,7 @@
                     // bit 3 the first pass of the NEXT layer's BatchNorm backward in the data gradient's epilogue, its y tile through LDS-DMA into the
                     // free halo buffer (measured: 64->64 at 64x64x32 +77 us against the 171 us pass it would replace, neutral or worse on every
                     // smaller layer; ~200 spilled registers in the epilogue as written -- DESIGN 9, not built),
+                    // bit 5 only the kw = 0 fragments are read from LDS (upper bound of deriving the kw = 1, 2 fragments by lane shifts),
                     // bit 4 the output tile as coalesced 16-byte stores (upper bound of an LDS-transposed epilogue: -7 % on 32->64, <= 2.6 % elsewhere)
 #endif
 
@@ -324,24 +325,24 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \
     /* ht1: kw 0, half 1 */                                                                                \
-    LOADA(0, akw[1] + tap64, 0);                                                                           \
+    if (!(B16_ABL & 32)) LOADA(0, akw[1] + tap64, 0);                                                                           \
     LOADB((P_) ^ 1, wbuf + 1 * (BN * 64));                                                                 \
     MFMA_HALF(1, P_, 1, 0, 4);                                                                 \
     PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
     SB();                                                                                                  \
     /* ht2: kw 1, half 0 */                                                                                \
-    LOADA(1, akw[1] + tap64, 1);                                                                           \
+    if (!(B16_ABL & 32)) LOADA(1, akw[1] + tap64, 1);                                                                           \
     MFMA_HALF(0, (P_) ^ 1, 0, 0, 4);                                                                       \
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \
     /* ht3: kw 1, half 1 */                                                                                \
-    LOADA(0, akw[2] + tap64, 0);                                                                           \
+    if (!(B16_ABL & 32)) LOADA(0, akw[2] + tap64, 0);                                                                           \
     LOADB(P_, wbuf + 2 * (BN * 64));                                                                       \
     MFMA_HALF(1, (P_) ^ 1, 1, 0, 4);                                                                       \
     PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
     SB();                                                                                                  \
     /* ht4: kw 2, half 0 */                                                                                \
-    LOADA(1, akw[2] + tap64, 1);                                                                           \
+    if (!(B16_ABL & 32)) LOADA(1, akw[2] + tap64, 1);                                                                           \
     MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \

@@ -54,6 +54,11 @@ struct IgemmParams {
   // order): the 128 rows of a tile are a compact bd x bh x bw box of voxels instead of 128 consecutive ones, so the 8 / 64 gathered
   // neighbours of a tile's rows are mostly each other's.
   int nt, zdim, bd, bh, bw;
+  // GEOM_CONV3 only.  vmajor = 1: GEMM row m is (voxel v = m / N, sample n = m % N) instead of (n, v) -- a 128-row tile then holds ONE or two voxels
+  // of many samples, every row of it has (nearly) the same set of taps inside the volume, and the K loop walks only the taps some row of the
+  // tile uses: 8-12 of 27 on a 2^3 grid, 15.6 on average on 4^3 (the local views' deepest levels).  Skipped taps contributed
+  // exact zeros, so every output value is the one the full loop produces (split-K aside: the splits cut the shorter loop).
+  int vmajor;
 };
 
 
@@ -133,6 +138,14 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       row_voxel(m, n, d, h, w);
       if (GEOM == GEOM_CONV3) {
         abase[ps] = m;
+        if (p.vmajor) {
+          const int V = g.D * g.H * g.W, v = (int)(m / g.N);
+          n = (int)(m - (int64_t)v * g.N);
+          w = v % g.W;
+          h = (v / g.W) % g.H;
+          d = v / (g.W * g.H);
+          abase[ps] = (int64_t)n * V + v;
+        }
         amask[ps] = tap_mask27(d, h, w, g);
       } else if (GEOM == GEOM_UP2_FWD) {
         abase[ps] = m;
@@ -177,8 +190,24 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
 
   const int nchunk = K / 32;
   constexpr bool CAN_SPLIT = GEOM == GEOM_CONV3 || GEOM == GEOM_UPC_DGRAD;
-  const int s_off = (CAN_SPLIT && p.ws) ? blockIdx.z * p.steps_per_split : 0;   // first K-step of this split
-  const int S = (CAN_SPLIT && p.ws) ? min(p.steps_per_split, p.taps * nchunk - s_off) : p.taps * nchunk;
+  const bool vmaj = GEOM == GEOM_CONV3 && p.vmajor != 0;
+  // taps this tile walks (block-uniform): all of them, or (vmajor) the union of the tap masks of the tile's voxels
+  uint64_t tmask = p.taps >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << p.taps) - 1);
+  if (vmaj) {
+    const int64_t mlast = (m0 + BM - 1 < p.M ? m0 + BM - 1 : p.M - 1);
+    const int v0 = (int)(m0 / g.N), v1 = (int)(mlast / g.N);
+    uint32_t u = 0;
+    for (int v = v0; v <= v1; ++v) u |= tap_mask27(v / (g.W * g.H), (v / g.W) % g.H, v % g.W, g);
+    tmask = u;
+  }
+  const int total_steps = __popcll(tmask) * nchunk;
+  int s_off = 0, S = total_steps;
+  if (CAN_SPLIT && p.ws) {   // first K-step and step count of this split
+    const int per = vmaj ? (total_steps + (int)gridDim.z - 1) / (int)gridDim.z : p.steps_per_split;
+    s_off = blockIdx.z * per;
+    S = min(per, total_steps - s_off);
+    if (S < 0) S = 0;
+  }
   // Two staging register sets: the loads of K-step s+2 are issued while step s is multiplied and step s+1 waits in the
   // other set, so a load has two MFMA phases to land.
   u32x4 raA[AP], rbA[BP], raB[AP], rbB[BP];
@@ -234,12 +263,26 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
       _Pragma("unroll") for (int j = 0; j < FN; ++j) MM::mma(fa[i], fb[j], acc[i][j]);                  \
   } while (0)
 
-  // step -> (tap, chunk), clamped to the last step (the tail re-loads a valid step; its data is never used)
+  // K-steps in order: STEP_TC is called for s_ = 0, 1, 2, ... exactly once each and hands out (tap, chunk) of step s_off + min(s_, S - 1) (the
+  // tail re-loads the last step; its data is never used) from a running position: the lowest set bit of `tbits` is the current tap.
+  uint64_t tbits = tmask;
+  int it_c, it_n = 0;
+  {
+    const int so = s_off < total_steps ? s_off : 0;   // an empty split (S == 0) loads the first step and multiplies nothing
+    const int skip = so / nchunk;
+    it_c = so - skip * nchunk;
+    for (int q = 0; q < skip; ++q) tbits &= tbits - 1;
+  }
 #define STEP_TC(s_, t_, c_)                                                                             \
   do {                                                                                                  \
-    const int ss_ = s_off + ((s_) < S ? (s_) : S - 1);                                                  \
-    t_ = ss_ / nchunk;                                                                                  \
-    c_ = ss_ - t_ * nchunk;                                                                             \
+    t_ = __builtin_ctzll(tbits);                                                                        \
+    c_ = it_c;                                                                                          \
+    if (++it_n < S) {                                                                                   \
+      if (++it_c == nchunk) {                                                                           \
+        it_c = 0;                                                                                       \
+        tbits &= tbits - 1;                                                                             \
+      }                                                                                                 \
+    }                                                                                                   \
   } while (0)
 
   int t0_, c0_;
@@ -310,6 +353,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
             row_voxel(m, n, d, h, w);
             orow = (((int64_t)n * g.D + d) * g.H + h) * g.W + w;
           }
+          if (vmaj) orow = (m % g.N) * ((int64_t)g.D * g.H * g.W) + m / g.N;
 #pragma unroll
           for (int j = 0; j < FN; ++j) Z[orow * p.Nc + n0 + wn * (BN / 2) + j * 16 + lr] = acc[i][j][r];
         }
@@ -337,6 +381,7 @@ __global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
           row_voxel(m, n, d, h, w);
           orow = (((int64_t)n * g.D + d) * g.H + h) * g.W + w;
         }
+        if (vmaj) orow = (m % g.N) * ((int64_t)g.D * g.H * g.W) + m / g.N;
         if (GEOM == GEOM_UP2_FWD || GEOM == GEOM_UPC_FWD) {
           int n, d, h, w;
           row_voxel(m, n, d, h, w);
@@ -479,10 +524,11 @@ __global__ void __launch_bounds__(256) igemm_splitk_finish_kernel(const float* _
 struct SplitPlan {
   int splits, steps_per_split;
 };
-static SplitPlan splitk_plan(int64_t M, int Ci, int Co) {
+// taps: K-steps per 32-channel chunk a tile walks -- 27, or (voxel-major rows, conv3_vmajor) the average number of taps inside the volume
+static SplitPlan splitk_plan(int64_t M, int Ci, int Co, int taps = 27) {
   const int bn = Co % 128 == 0 ? 128 : (Co % 64 == 0 ? 64 : 32);
   const int64_t blocks = ((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM) * (Co / bn);
-  const int steps = 27 * (Ci / 32);
+  const int steps = taps * (Ci / 32);
   const bool shape_ok = Co == 32 || Co % 64 == 0;
   if (blocks >= 512 || !shape_ok) return SplitPlan{1, steps};
   int splits = (int)((768 + blocks - 1) / blocks);
@@ -537,6 +583,19 @@ extern "C" int64_t pcrl_conv3d_k3_fwd_kernel(int N, int D, int H, int W, int Ci,
   return 0;
 }
 
+// Voxel-major rows with per-tile tap skipping (IgemmParams::vmajor) for volumes of at most 8 voxels (the local views' 2^3 level: 8 of 27 taps per
+// voxel).  Measured (tools/conv_probe.py --b 192, same box): 2^3, 256 -> 256 / 256 -> 512 channels 51 -> 28 / 65 -> 43 us; on the 4^3 level (15.6 of
+// 27 taps) the same order is 5 % SLOWER (59 -> 64, 87 -> 92, 141 -> 146 us): a sample-major tile there gathers its 27 taps from the 64 voxels of two
+// samples (16 KB, cache resident), a voxel-major one from 128 samples -- that level is bound by the gather, not by K, and keeps sample-major rows.
+// PCRL_IGEMM_VMAJOR=0: off; =64: also the volumes of up to 64 voxels (A/B switch).  -> taps a tile walks on average, 0 = off.
+static int conv3_vmajor_taps(int N, int D, int H, int W) {
+  static const int vmax = [] { const char* e = getenv("PCRL_IGEMM_VMAJOR"); return e ? atoi(e) == 1 ? 8 : atoi(e) : 8; }();
+  const int64_t V = (int64_t)D * H * W;
+  if (V > vmax || (int64_t)N * V < PCRL_CONV_BM) return 0;
+  const double t = (3.0 * D - 2) * (3.0 * H - 2) * (3.0 * W - 2) / (double)V;
+  return t < 1 ? 1 : (int)(t + 0.5);
+}
+
 static int conv3d_k3_fwd_impl(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, void* ws, int64_t ws_bytes,
                              int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_dims("conv3d_k3_fwd", N, D, H, W, Ci, Co)) return e;
@@ -547,7 +606,9 @@ static int conv3d_k3_fwd_impl(const void* x, const void* wp, const float* bias, 
     return pcrl_brick_conv_launch(x, wp, bias, y, stats_partial, N, D, H, W, Ci, Co, as_stream(stream));
   const int64_t M = (int64_t)N * D * H * W;
   IgemmParams p{x, wp, bias, y, stats_partial, Dims{N, D, H, W}, M, Ci, Co, 27, nullptr, 0};
-  const SplitPlan sp = splitk_plan(M, Ci, Co);
+  const int vtaps = conv3_vmajor_taps(N, D, H, W);
+  p.vmajor = vtaps > 0;
+  const SplitPlan sp = splitk_plan(M, Ci, Co, vtaps ? vtaps : 27);
   if (ws && sp.splits > 1 && g_conv_impl != 2) {
     PCRL_REQUIRE(ws_bytes >= (int64_t)sp.splits * M * Co * 4, "conv3d_k3_fwd: workspace too small (%lld bytes)", (long long)ws_bytes);
     p.ws = static_cast<float*>(ws);
@@ -575,7 +636,8 @@ extern "C" int64_t pcrl_conv3d_k3_fwd_ws_bytes(int N, int D, int H, int W, int C
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0 || Ci % 32 != 0 || Co % 32 != 0) return 0;
   if (g_conv_impl == 0 && (pcrl_brick_conv_eligible(N, D, H, W, Ci, Co, dtype) || pcrl_brick16_conv_eligible(N, D, H, W, Ci, Co, dtype))) return 0;
   const int64_t M = (int64_t)N * D * H * W;
-  const SplitPlan sp = splitk_plan(M, Ci, Co);
+  const int vtaps = conv3_vmajor_taps(N, D, H, W);
+  const SplitPlan sp = splitk_plan(M, Ci, Co, vtaps ? vtaps : 27);
   return sp.splits > 1 ? (int64_t)sp.splits * M * Co * 4 : 0;
 }
 

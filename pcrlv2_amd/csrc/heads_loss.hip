@@ -1019,6 +1019,16 @@ extern "C" int pcrl_loss_total(const float* l1, const float* l2, const float* l4
   return pcrl_check_launch("loss_total");
 }
 
+// backward of pcrl_loss_total: out = (g, beta * g, g, g) -- the gradients of loss1, l4 and of the two cosine groups (global, local)
+__global__ void loss_total_bwd_kernel(const float* __restrict__ g, float beta, float* __restrict__ out) {
+  if (threadIdx.x < 4) out[threadIdx.x] = threadIdx.x == 1 ? beta * g[0] : g[0];
+}
+extern "C" int pcrl_loss_total_bwd(const float* g, float beta, float* out, pcrl_stream_t stream) {
+  PCRL_REQUIRE(g && out, "loss_total_bwd: null pointer");
+  hipLaunchKernelGGL(loss_total_bwd_kernel, dim3(1), dim3(64), 0, as_stream(stream), g, beta, out);
+  return pcrl_check_launch("loss_total_bwd");
+}
+
 static int sgd_launch(float* p, const float* g, float* buf, const int64_t* offsets, const int32_t* flags, int ntensors, int64_t total, float lr,
                       float momentum, float weight_decay, float grad_scale, const float* skip, pcrl_stream_t stream) {
   PCRL_REQUIRE(p && g && buf && offsets && flags && ntensors > 0 && total > 0, "sgd_step: bad arguments");

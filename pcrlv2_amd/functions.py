@@ -580,7 +580,8 @@ class CosineTermsFn(Function):
         used = sorted({s[0] for s in spec})
         holes = [i for i in used if ts[i].shape[0] != ctx.rows and len({r0 for (xi, r0) in seen if xi == i}) * ctx.rows != ts[i].shape[0]]
         if holes:
-            flat = torch.zeros(sum(ts[i].numel() for i in holes), dtype=torch.float32, device=ts[0].device)
+            flat = torch.empty(sum(ts[i].numel() for i in holes), dtype=torch.float32, device=ts[0].device)
+            ops.lib().call("pcrl_zero", flat, flat.numel() * 4, ops.stream_handle())
             o = 0
             for i in holes:
                 grads[i] = flat[o:o + ts[i].numel()].view_as(ts[i])
@@ -618,6 +619,48 @@ class LossTotalFn(Function):
 
 def loss_total(l1, l2, l4, l5, beta):
     return LossTotalFn.apply(l1, l2, l4, l5, beta)
+
+
+class LossTailFn(Function):
+    """LossTotalFn taking the two cosine groups as the [2] vector pcrl_cosine_terms_fwd wrote: (loss1, cos = [global, local], l4, beta) ->
+    (total, beta * l4, global, local).  No select / select_backward / add_ / mul nodes between the cosine launch and the total: the backward is
+    one launch (pcrl_loss_total_bwd) whose output is handed out as views -- g to loss1, beta * g to l4, [g, g] to the cosine terms."""
+
+    @staticmethod
+    def forward(ctx, l1, cos, l4, beta):
+        ctx.set_materialize_grads(False)
+        out = torch.empty(2, dtype=torch.float32, device=l1.device)
+        f = lambda t: t.detach().reshape(1).float()
+        c = cos.detach()
+        ops.lib().call("pcrl_loss_total", f(l1), c[0:1], f(l4), c[1:2], float(beta), out, ops.stream_handle())
+        ctx.beta = float(beta)
+        total, scaled, lg, ll = out[0], out[1], c[0], c[1]
+        ctx.mark_non_differentiable(scaled, lg, ll)
+        return total, scaled, lg, ll
+
+    @staticmethod
+    def backward(ctx, g, _gs, _gg, _gl):
+        if g is None:
+            return None, None, None, None
+        out = torch.empty(4, dtype=torch.float32, device=g.device)
+        ops.lib().call("pcrl_loss_total_bwd", g.reshape(1).float(), ctx.beta, out, ops.stream_handle())
+        return out[0], out[2:4], out[1], None
+
+
+def loss_tail(l1, cos, l4, beta):
+    return LossTailFn.apply(l1, cos, l4, beta)
+
+
+_root_grads: dict = {}
+
+
+def root_gradient(loss):
+    """d loss / d loss = 1 as a cached device scalar: `loss.backward(gradient=...)` with it skips autograd's ones_like fill launch."""
+    key = (str(loss.device), loss.dtype)
+    t = _root_grads.get(key)
+    if t is None:
+        t = _root_grads[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return t
 
 
 def cosine_terms(spec, rows, ngroups, tensors):

@@ -527,7 +527,11 @@ def zero_grad_vector(n, device):
     key = (n, str(device))
     t = _zero_cache.get(key)
     if t is None:
-        t = _zero_cache[key] = torch.zeros(n, dtype=torch.float32, device=device)
+        t = _zero_cache[key] = torch.empty(n, dtype=torch.float32, device=device)
+        if t.is_cuda:
+            lib().call("pcrl_zero", t, 4 * n, stream_handle())      # (first use of a size, from inside a backward: a runtime memset, no ATen launch)
+        else:
+            t.zero_()
         t._pcrl_shared_zero = True
     return t
 

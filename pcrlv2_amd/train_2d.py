@@ -68,12 +68,12 @@ def step_losses(model, batch, epoch, criterion, cosine):
         loc = _ops.concat_batch([_to_gpu(v) for v in local_views])
         feats_loc, _, _ = model.forward_engine(loc)
         _ops.join_side_stream()                    # the cosine terms read both views' features on the main stream
-        l_global, l_local, _ = _fused_cos_losses(feats1, feats2, feats_loc, n, nl, draws=draws)
+        cos2, _ = _fused_cos_losses(feats1, feats2, feats_loc, n, nl, draws=draws)
         seg = model.model.segmentation_head[0]
         l_restore = SegMSEFn.apply(h1, seg.weight, seg.bias, target, model._seg)
         l_deep_raw = MaskMSEFn.apply(low1, target, 2 ** (ns - 1 - scale))
         beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
-        total, l_deep = _fn.loss_total(l_restore, l_global, l_deep_raw, l_local, beta)
+        total, l_deep, l_global, l_local = _fn.loss_tail(l_restore, cos2, l_deep_raw, beta)
         return total, l_restore, l_global, l_deep, l_local
     feats1, mask1, masks1 = model(view1)
     with _ops.view_pass(view2.device, view2, path2d=True):
@@ -101,7 +101,7 @@ def train_step(model, optimizer, batch, epoch, criterion, cosine):
     _ops.throttle_host(dev)      # at most config.MAX_STEPS_AHEAD steps of host run-ahead (allocator footprint, see config.py)
     losses = step_losses(model, batch, epoch, criterion, cosine)
     optimizer.zero_grad()
-    losses[0].backward()
+    losses[0].backward(gradient=_fn.root_gradient(losses[0]))
     optimizer.step()
     _ops.throttle_host(dev, step_done=True)
     # first complete step of this batch shape: size the allocator's per-stream pools for the steady state, once (ops.provision_allocator)

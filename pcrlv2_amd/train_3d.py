@@ -95,7 +95,8 @@ def _to_gpu(t):
 def _fused_cos_losses(feats1, feats2, feats_loc, n, nlocal, draws=None):
     """The 13 cos_loss calls of train_3d.py:119-134 as ONE launch: the scales are drawn from python's `random` in the reference's
     order (global pair; then for every local view (view 1, local_i), (view 2, local_i)), the 26 cosine means and their weights
-    (-1/2 per call; /(2 * nlocal) for the local group) go to pcrl_cosine_terms_*.  -> (global term, local term, first drawn scale)."""
+    (-1/2 per call; /(2 * nlocal) for the local group) go to pcrl_cosine_terms_*.  -> ([global term, local term] as one float32[2], first drawn
+    scale): the pair goes to functions.loss_tail whole (selecting its elements here would cost select_backward's fills and adds)."""
     ns = len(feats1)
     tensors, idx = [], {}
     for name, fs in (("1", feats1), ("2", feats2), ("L", feats_loc)):
@@ -116,8 +117,7 @@ def _fused_cos_losses(feats1, feats2, feats_loc, n, nlocal, draws=None):
     for i in range(nlocal):
         add("1", 0, "L", n * i, nxt(), wl, 1)
         add("2", 0, "L", n * i, nxt(), wl, 1)
-    out = _fn.cosine_terms(spec, n, 2, tensors)
-    return out[0], out[1], k0
+    return _fn.cosine_terms(spec, n, 2, tensors), k0
 
 
 def step_losses(model, batch, epoch, criterion, cosine):
@@ -138,10 +138,10 @@ def step_losses(model, batch, epoch, criterion, cosine):
         with _ops.deferred_join():
             (out1, feats1, masks1), (_out2, feats2, _), (_, feats_loc, _) = model.forward_views(
                 [(view1, False, None), (view2, False, "view2"), (loc, True, "local")])
-        l_global, l_local, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
+        cos2, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
         l_restore = criterion(out1, target)
         beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
-        total, l_deep = _fn.loss_total(l_restore, l_global, criterion(masks1[scale], target), l_local, beta)
+        total, l_deep, l_global, l_local = _fn.loss_tail(l_restore, cos2, criterion(masks1[scale], target), beta)
         return total, l_restore, l_global, l_deep, l_local
     with _ops.deferred_join():     # the decoder stages' side branches (heads, deep-supervision maps) also run under the NEXT forward; joined on exit
         out1, feats1, masks1 = model(view1)
@@ -155,10 +155,10 @@ def step_losses(model, batch, epoch, criterion, cosine):
             with _ops.view_pass(loc.device, loc, name="local"):
                 _, feats_loc, _ = model(loc, local=True, **fo)
     if fused:
-        l_global, l_local, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
+        cos2, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
         l_restore = criterion(out1, target)
         beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
-        total, l_deep = _fn.loss_total(l_restore, l_global, criterion(masks1[scale], target), l_local, beta)   # one launch: the sum and beta * MSE
+        total, l_deep, l_global, l_local = _fn.loss_tail(l_restore, cos2, criterion(masks1[scale], target), beta)   # one launch: the sum and beta * MSE
         return total, l_restore, l_global, l_deep, l_local
     l_global, scale = cos_loss(cosine, feats1, feats2)
     _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True, **fo)
@@ -229,7 +229,7 @@ def train_step(model, optimizer, batch, epoch, criterion, cosine, guard=True):
             flag = None
     optimizer.zero_grad()
     with _ops.trace_range("backward"):
-        losses[0].backward()
+        losses[0].backward(gradient=_fn.root_gradient(losses[0]))
     optimizer.skip_flag = flag
     with _ops.trace_range("optimizer"):
         optimizer.step()

@@ -337,6 +337,32 @@ def test_fused_cosine_terms_equal_the_26_separate_launches():
             assert d < 1e-4 or float(gb[n].abs().max()) < 1e-7, (n, d)
 
 
+def test_loss_tail_equals_the_scalar_expression_and_its_autograd():
+    """functions.loss_tail (pcrl_loss_total + pcrl_loss_total_bwd, the [2] cosine vector taken whole) against the reference's scalar
+    expression loss1 + loss2 + beta * l4 + local_loss (train_3d.py:136-138) built from torch operators: same values, same gradients for
+    loss1, l4 and both cosine groups; a root gradient other than 1 scales them."""
+    from pcrlv2_amd import functions as F_
+    vals = torch.tensor([0.37, -0.81, 1.93, -0.42], device=DEV)
+    beta = 0.731
+    for root in (None, 2.5):
+        l1, l4 = vals[0].clone().requires_grad_(True), vals[2].clone().requires_grad_(True)
+        cos = torch.stack([vals[1], vals[3]]).clone().requires_grad_(True)
+        total, scaled, lg, ll = F_.loss_tail(l1, cos, l4, beta)
+        r1, r4, rc = vals[0].clone().requires_grad_(True), vals[2].clone().requires_grad_(True), torch.stack([vals[1], vals[3]]).clone().requires_grad_(True)
+        ref = r1 + rc[0] + beta * r4 + rc[1]
+        assert abs(float(total) - float(ref)) < 1e-6 and abs(float(scaled) - beta * float(vals[2])) < 1e-6
+        assert float(lg) == float(vals[1]) and float(ll) == float(vals[3])
+        assert not scaled.requires_grad and not lg.requires_grad and not ll.requires_grad
+        if root is None:
+            total.backward(gradient=F_.root_gradient(total))
+            ref.backward()
+        else:
+            total.backward(gradient=torch.tensor(root, device=DEV))
+            ref.backward(gradient=torch.tensor(root, device=DEV))
+        for a, b in ((l1.grad, r1.grad), (l4.grad, r4.grad), (cos.grad, rc.grad)):
+            assert torch.allclose(a, b, rtol=1e-6, atol=0), (a, b)
+
+
 @pytest.mark.parametrize("switch", ["COMPOSE_UPCONV", "FOLD_POOL_GRAD", "FOLD_GAP_GRAD", "FUSE_APPLY_CONSUMERS"])
 def test_round2_fusions_leave_the_step_unchanged_fp32(switch):
     """Each memory-pass fusion of round 2 (config.py) against the separate kernels it replaces, on a whole training step in the exact-fp32

@@ -64,6 +64,8 @@ SHAPES3 = [  # N, D, H, W, Ci, Co   (M deliberately not a multiple of 128 in the
     (3, 4, 16, 8, 64, 64), (1, 4, 32, 8, 64, 128), (2, 8, 16, 24, 32, 96), (1, 16, 16, 8, 128, 32),
     # brick kernels with the innermost extent as the 4-deep brick axis (the 8 x 8 x 4 bottleneck level; W = 12: three bricks along W)
     (2, 8, 8, 4, 64, 128), (3, 16, 8, 4, 32, 64), (1, 8, 16, 12, 64, 64),
+    # gather kernel with voxel-major rows and per-tile tap skipping (volumes of <= 8 voxels, M >= 128): tiles of one, two and many voxels
+    (40, 2, 2, 2, 64, 64), (48, 4, 4, 4, 32, 64), (200, 2, 2, 2, 32, 32), (33, 2, 2, 1, 64, 32), (130, 1, 1, 1, 32, 32), (70, 1, 2, 2, 32, 64),
 ]
 
 
@@ -165,7 +167,8 @@ def test_conv3d_fwd_stats_dgrad_wgrad(shape, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("shape", [(4, 8, 4, 4, 64, 128), (3, 2, 2, 2, 96, 64), (2, 4, 4, 4, 256, 32)])   # (8x8x4 runs on the brick kernel: axis permutation)
+@pytest.mark.parametrize("shape", [(4, 8, 4, 4, 64, 128), (3, 2, 2, 2, 96, 64), (2, 4, 4, 4, 256, 32),   # (8x8x4 runs on the brick kernel: axis permutation)
+                                   (40, 2, 2, 2, 128, 64), (24, 4, 4, 4, 128, 128), (192, 2, 2, 2, 256, 128)])  # voxel-major rows: the splits cut each tile's own tap list
 def test_conv3d_small_volume_split_k(shape, dt):
     """pcrl_conv3d_k3_fwd_ws: the K-split gather path of small volumes (8x8x4 bottleneck, 4^3 / 2^3 local-view levels) must give
     the one-pass result: output, bias, and the BatchNorm partial statistics (same row count)."""

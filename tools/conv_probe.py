@@ -24,6 +24,10 @@ LAYERS = [  # name, Ci, Co, (D, H, W) for 64x64x32 inputs
     ("up128.0", 256, 128, (32, 32, 16)), ("up128.1", 128, 128, (32, 32, 16)), ("up64.0", 128, 64, (64, 64, 32)),
     ("up64.1", 64, 64, (64, 64, 32)),
 ]
+LOCAL = [  # the local views' gather-kernel levels (16^3 crops, batch 6 b): --b 192 --layers loc256.0,...
+    ("loc256.0", 128, 128, (4, 4, 4)), ("loc256.1", 128, 256, (4, 4, 4)), ("loc512.0", 256, 256, (2, 2, 2)), ("loc512.1", 256, 512, (2, 2, 2)),
+    ("locup256.1", 256, 256, (4, 4, 4)),
+]
 
 
 def timed_ab(fns, rounds, inner=3):
@@ -66,8 +70,8 @@ def main():
     sel = set(args.layers.split(",")) if args.layers else None
     impls = [int(v) for v in args.impls.split(",")]
     tot = {}
-    for name, Ci, Co, (D, H, W) in LAYERS:
-        if sel and name not in sel:
+    for name, Ci, Co, (D, H, W) in LAYERS + LOCAL:
+        if (sel and name not in sel) or (not sel and name.startswith("loc")):
             continue
         N = args.b
         M = N * D * H * W
