@@ -6,6 +6,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+// Second argument of __launch_bounds__ for the kernels whose default allocation (no bound: the compiler assumes one wave per SIMD is acceptable)
+// came out at 150-218 VGPRs PLUS 40-144 AGPRs, i.e. ONE 256-thread block per CU: 2 = at most 256 registers per lane in all, two waves per SIMD
+// (found by rocprofv3 counters on the 2D stride-2 gather convolution: 0.23 waves per SIMD on average, 203 us for 38.7 GFLOP).  -DPCRL_OCC2=1
+// rebuilds the old allocation for A/B runs (tools/build_variant.sh).
+#ifndef PCRL_OCC2
+#define PCRL_OCC2 2
+#endif
+
 #include "../../include/pcrl_hip.h"
 
 typedef __bf16 bf16;

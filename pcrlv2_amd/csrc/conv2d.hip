@@ -21,6 +21,7 @@
 #include "common.h"
 #include "mma_tile.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace {
 
@@ -50,7 +51,7 @@ struct C2Params {
 // K-steps are loaded up front into NSM register sets, so a block waits for global memory once instead of once per step -- these
 // launches are 131 072 blocks of a few hundred MFMA cycles each and were bound by exactly that latency chain.
 template <typename T, int BN, int MODE, int NSM = 0>
-__global__ void __launch_bounds__(256) conv2d_kernel(const C2Params p) {
+__global__ void __launch_bounds__(256, PCRL_OCC2) conv2d_kernel(const C2Params p) {
   constexpr int BM = PCRL_CONV_BM;
   using TL = Tile<T>;
   using MM = Mma<T>;
@@ -335,7 +336,10 @@ int ilog2_exact(int v) {
 template <typename T, int MODE> int launch_bn(const C2Params& p, int NcP, hipStream_t stream) {
   using TL = Tile<T>;
   const unsigned gx = (unsigned)((p.M + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
-  if (NcP % 128 == 0) {
+  static const int bnmax = [] { const char* e = getenv("PCRL_GATHER_BN"); return e ? atoi(e) : 128; }();   // A/B switch: 64 = never the 128-column tile
+  // 128-column tiles (two waves per SIMD) unless the grid they give is small: below 512 blocks the 64-column tile (four waves per SIMD, twice the
+  // blocks) is faster -- measured on the local views' 12^2 / 6^2 / 3^2 maps (49 -> 45, 52 -> 48, 86 -> 69 us), slower on the large grids (90 -> 105 us)
+  if (NcP % 128 == 0 && bnmax >= 128 && (int64_t)gx * (NcP / 128) >= 512) {
     hipLaunchKernelGGL((conv2d_kernel<T, 128, MODE>), dim3(gx, NcP / 128), dim3(256), 2 * (size_t)(PCRL_CONV_BM + 128) * TL::ROWB, stream, p);
   } else if (NcP % 64 == 0) {
     hipLaunchKernelGGL((conv2d_kernel<T, 64, MODE>), dim3(gx, NcP / 64), dim3(256), 2 * (size_t)(PCRL_CONV_BM + 64) * TL::ROWB, stream, p);

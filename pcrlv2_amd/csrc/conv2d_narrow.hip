@@ -47,7 +47,7 @@ struct NarrowConvParams {
 //     sum of F.interpolate's backward is taken on the float accumulators (vertical pair = two fragments of the lane, horizontal pair = the
 //     neighbouring lane) and the COARSE tensor is stored -- the fine-resolution gradient (1 GB at block 4) is never written or read.
 template <int CS, int NF, int NS, bool RED2>   // source channels (8/16/32), output fragments (Nc <= 16 * NF), K-steps (Kpad / 32)
-__global__ void __launch_bounds__(256) conv2d_narrow_kernel(const NarrowConvParams p) {
+__global__ void __launch_bounds__(256, PCRL_OCC2) conv2d_narrow_kernel(const NarrowConvParams p) {
   constexpr int VPC = CS / 8;
   constexpr int XPIECES = NHP * VPC, XP = (XPIECES + 255) / 256;
   constexpr int CSH = CS == 8 ? 3 : (CS == 16 ? 4 : 5);

@@ -66,7 +66,7 @@ struct IgemmParams {
 // pointwise product z[t][m] = sum_c x[m][c] w[c][t]; the tile is written as float32, PLANE-major (z[col * M + m]), so the
 // shifted-sum pass that follows reads every plane contiguously.  No bias, no statistics.
 template <typename T, int BN, int GEOM, bool PLANES = false>
-__global__ void __launch_bounds__(256) igemm_kernel(const IgemmParams p) {
+__global__ void __launch_bounds__(256, PCRL_OCC2) igemm_kernel(const IgemmParams p) {
   constexpr int BM = PCRL_CONV_BM;
   using TL = Tile<T>;
   using MM = Mma<T>;
@@ -443,7 +443,8 @@ int launch_igemm(const IgemmParams& p, int zdim, hipStream_t stream) {
 }
 
 template <typename T, int GEOM> int dispatch_bn(const IgemmParams& p, int zdim, hipStream_t stream) {
-  if (p.Nc % 128 == 0) return launch_igemm<T, 128, GEOM>(p, zdim, stream);
+  static const int bnmax = [] { const char* e = getenv("PCRL_GATHER_BN"); return e ? atoi(e) : 128; }();   // A/B switch: 64 = never the 128-column tile
+  if (p.Nc % 128 == 0 && bnmax >= 128) return launch_igemm<T, 128, GEOM>(p, zdim, stream);
   if (p.Nc % 64 == 0) return launch_igemm<T, 64, GEOM>(p, zdim, stream);
   return launch_igemm<T, 32, GEOM>(p, zdim, stream);
 }

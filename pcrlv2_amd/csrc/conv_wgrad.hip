@@ -838,7 +838,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_up2_alltaps_kernel(const WgradPa
 // 16 MFMAs and ran at 150-190 TFLOP/s).  Block = 64 (co) x 64 (ci) tile of one phase and one voxel split; grid (tiles, 8 phases, splits);
 // slabs ws[split][p * 8 + q][Cu][Cv] as wgrad_kernel writes them.
 template <typename T, bool TR>
-__global__ void __launch_bounds__(256) wgrad_upc8_kernel(const WgradParams p) {
+__global__ void __launch_bounds__(256, sizeof(T) == 2 ? PCRL_OCC2 : 1) wgrad_upc8_kernel(const WgradParams p) {
   using WT = WTile<T>;
   using WF = WFrag<T, TR>;
   constexpr int KS = 32;

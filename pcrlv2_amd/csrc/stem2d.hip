@@ -73,7 +73,7 @@ __device__ __forceinline__ void patch_of(const StemParams& p, int pb, int& n, in
   n = pb / ph;
 }
 
-__global__ void __launch_bounds__(256) stem7_fwd_kernel(const StemParams p) {
+__global__ void __launch_bounds__(256, PCRL_OCC2) stem7_fwd_kernel(const StemParams p) {
   __shared__ __attribute__((aligned(16))) char win[2][WBYTES];
   __shared__ __attribute__((aligned(16))) bf16 wS[CO * KH * 32];    // 28 672 bytes
   __shared__ float red[4][CO][2];

@@ -38,7 +38,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base, int row0, int cb, in
 }
 
 template <int CU, int CV>
-__global__ void __launch_bounds__(256) wgrad2d_narrow_kernel(const NarrowParams p) {
+__global__ void __launch_bounds__(256, (CU == 32 && CV == 32) ? 1 : PCRL_OCC2) wgrad2d_narrow_kernel(const NarrowParams p) {   // (32 x 32: 61 spilled registers at two waves per SIMD)
   constexpr int UPC = CU / 8, VPC = CV / 8;                   // 16-byte pieces per pixel
   constexpr int DYP = NPX * UPC / 256;                        // dy pieces per thread: 2 / 4
   constexpr int XPIECES = NHP * VPC, XP = (XPIECES + 255) / 256;   // 680 / 1360 -> 3 / 6 per thread
