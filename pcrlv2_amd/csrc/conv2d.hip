@@ -418,7 +418,15 @@ extern "C" int pcrl_conv2d_pack(const float* w_ref, void* out, int Co, int Ci, i
 extern "C" int64_t pcrl_conv2d_stats_rows(int N, int Ho, int Wo) { return ((int64_t)N * Ho * Wo + PCRL_CONV_BM - 1) / PCRL_CONV_BM; }
 
 // which kernel the forward dispatcher picks: 0 gather, 1 LDS-halo brick, 2 right-sized narrow kernel
+// The 32 -> 32 channel layers (decoder block 3 at 256^2) go to the right-sized narrow kernel rather than the brick kernel: 204-219 -> 168 us per
+// launch on the same box once the narrow kernel runs two waves per SIMD (PCRL_OCC2).  PCRL_NARROW_FIRST=0: brick kernel first (A/B switch).
+static bool narrow_first(int Cs, int Nc) {
+  static const bool on = [] { const char* e = getenv("PCRL_NARROW_FIRST"); return !(e && e[0] == '0'); }();
+  return on && Cs <= 32 && Nc <= 32;
+}
 static int conv2d_fwd_kind(int N, int Ho, int Wo, int CiP, int Co, int KH, int KW, int stride, int pad, int out_f32, int dtype) {
+  if (g_conv2d_impl == 0 && narrow_first(CiP, Co) && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype))
+    return 2;
   if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !out_f32 && pcrl_brick_conv2d_eligible(N, Ho, Wo, CiP, Co, dtype)) return 1;
   if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype))
     return 2;
@@ -441,6 +449,9 @@ extern "C" int64_t pcrl_conv2d_fwd_kind(int N, int Hi, int Wi, int CiP, int Co, 
   return conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype);
 }
 extern "C" int64_t pcrl_conv2d_dgrad_kind(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH, int KW, int stride, int pad, int dtype) {
+  if (g_conv2d_impl == 0 && narrow_first(CoP, Ci) && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && Hi == Ho && Wi == Wo &&
+      pcrl_conv2d_narrow_eligible(N, Hi, Wi, CoP, Ci, KH, dtype))
+    return 2;
   if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo && pcrl_brick_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype)) return 1;
   if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && Hi == Ho && Wi == Wo &&
       pcrl_conv2d_narrow_eligible(N, Hi, Wi, CoP, Ci, KH, dtype))
@@ -481,7 +492,7 @@ extern "C" int pcrl_conv2d_dgrad_up(const void* dy, const void* wp_dgrad, void* 
 extern "C" int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH,
                                  int KW, int stride, int pad, int dtype, pcrl_stream_t stream) {
   if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
-      pcrl_brick_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype))
+      pcrl_brick_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype) && pcrl_conv2d_dgrad_kind(N, Hi, Wi, Ci, Ho, Wo, CoP, KH, KW, stride, pad, dtype) == 1)
     return pcrl_brick_conv2d_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, 0, as_stream(stream));
   if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
       pcrl_conv2d_narrow_eligible(N, Hi, Wi, CoP, Ci, KH, dtype))

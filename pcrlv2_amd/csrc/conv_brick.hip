@@ -25,6 +25,9 @@
 #ifndef BRICK_TRANSPOSED
 #define BRICK_TRANSPOSED 0
 #endif
+#ifndef BRICK_ABL
+#define BRICK_ABL 0   // timing ablations (wrong results): bit 0 no output stores, bit 1 no global loads in front of the first stage
+#endif
 #include <atomic>
 #include <mutex>
 
@@ -333,8 +336,15 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
     s9 = sn;                                                                                              \
   } while (0)
 
-  LOAD_HALO(0);
-  LOAD_W(0, SID(0, 0), KWB(0));
+  if (BRICK_ABL & 2) {   // timing ablation: no global latency in front of the first stage
+#pragma unroll
+    for (int i = 0; i < HPT; ++i) rh[i] = u32x4{1u, 2u, 3u, 4u};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) rw[j] = u32x4{1u, 2u, 3u, 4u};
+  } else {
+    LOAD_HALO(0);
+    LOAD_W(0, SID(0, 0), KWB(0));
+  }
   STORE_HALO();
   STORE_W();
   __syncthreads();
@@ -468,7 +478,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const float val = acc[fm][j][r] + bv[j];
-        p.y[row * ypitch + uch0 + j * 16 + lr] = (bf16)val;
+        if (!(BRICK_ABL & 1) || val == 12345.678f) p.y[row * ypitch + uch0 + j * 16 + lr] = (bf16)val;
         s1[j] += val;
         s2[j] += val * val;
       }
