@@ -1061,7 +1061,11 @@ EMULATED = {
     # gradient norms median 0.54 %; convolution / Linear weight tensors <= 3 % and direction >= 0.972; the per-channel BatchNorm vectors
     # (sums of dy * xhat over every voxel of the batch: cancellation) up to 8.5 % / 0.963; single-element tensors (the 1-channel heads'
     # BatchNorm parameters: one such sum) up to 25 %.  Against the float64 golden the same step is held to 25 % / 0.8 (GOLDEN_STEPS).
-    "e_b16_32x32x16": (8e-4, 4e-2, 4e-2, 0.03, 0.97, 0.10, 0.95, 0.01),
+    # The direction floor of the weight tensors sits on bf16 rounding noise, not on the kernels: the SAME step with the 2^3-level gather
+    # convolution walking its K steps in a different order (PCRL_IGEMM_VMAJOR=0 / 8: identical products, other float32 split points) moves the
+    # lowest tensor between 0.9713 (down_tr128.ops.0) and 0.9666 (up_tr64.ops.1) while its norm error IMPROVES (2.38 -> 2.25 %) and the median
+    # stays 0.65 %.  Gate 0.96: a wrong tap / phase / scale lands below 0.9 (the float64 golden's gate, GOLDEN_STEPS, is 0.8).
+    "e_b16_32x32x16": (8e-4, 4e-2, 4e-2, 0.03, 0.96, 0.10, 0.95, 0.01),
     # BASELINE crop size, b = 8: measured losses 8.5e-5, maps 9e-3 .. 2.5e-2, features 1.3e-2 .. 2.5e-2; weight-tensor norms <= 0.94 % (!),
     # BatchNorm vectors <= 7.1 %, median 0.41 %; DIRECTIONS 0.965 (weights) / 0.911 (up_tr64.ops.0.bn1.bias): the cosine terms reach the
     # decoder through BatchNorm1d over EIGHT rows of near-identical global averages, which turns the 2e-4 relative differences that rare
