@@ -659,7 +659,7 @@ def root_gradient(loss):
     key = (str(loss.device), loss.dtype)
     t = _root_grads.get(key)
     if t is None:
-        t = _root_grads[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        t = _root_grads[key] = torch.ones((), dtype=loss.dtype).to(loss.device)     # (built on the host: a copy, not a fill kernel)
     return t
 
 

@@ -39,9 +39,12 @@ class FusedSGD(torch.optim.SGD):
             offs.append(offs[-1] + n)
         self._offsets_host = offs
         self._total = offs[-1]
-        self.flat_p = torch.zeros(self._total, dtype=torch.float32, device=dev)
-        self.flat_g = torch.zeros(self._total, dtype=torch.float32, device=dev)
-        self.flat_buf = torch.zeros(self._total, dtype=torch.float32, device=dev)
+        arenas = []
+        for _ in range(3):         # zero-filled by the library's own entry point (a runtime memset): no ATen fill kernel even at set-up
+            a = torch.empty(self._total, dtype=torch.float32, device=dev)
+            lib().call("pcrl_zero", a, 4 * self._total, stream_handle())
+            arenas.append(a)
+        self.flat_p, self.flat_g, self.flat_buf = arenas
         with torch.no_grad():
             for p, o, n in zip(self._plist, offs, sizes):
                 if p.dtype != torch.float32:
