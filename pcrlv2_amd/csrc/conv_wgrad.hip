@@ -983,6 +983,146 @@ __global__ void __launch_bounds__(256, sizeof(T) == 2 ? PCRL_OCC2 : 1) wgrad_upc
   }
 }
 
+// 2D weight gradient of a 3 x 3 convolution (any stride, optional nearest x2 upsample in front) with ONE KERNEL ROW per block: the dy tile of a
+// K-step (64 output pixels x 64 output channels) is staged once and multiplied against the THREE x tiles of taps (kh, 0), (kh, 1), (kh, 2)
+// (64 pixels x 64 source channels each, gathered at (oh * s - pad + kh, ow * s - pad + kw); neighbouring pixels' kw taps overlap, so two of the three
+// gathers hit L1 / L2).  The flattened-tap form of wgrad_kernel gives every (tap, 64-channel) column tile its own block, which streams dy and x from
+// memory again: rocprofv3 counters on the stride-2 64 -> 128 layer at 128^2 showed 1.2 GB of L2 -> HBM requests per launch for 200 MB of operands
+// (TCC miss rate 87 %) and 18 VALU instructions per MFMA.  Here the operands cross the fabric three times instead of nine, the pixel coordinates are
+// carried (not decoded) from step to step, and a step is 24 MFMAs per wave between two barriers instead of 4.
+// grid (co tiles x ci tiles, 3 kernel rows, splits); slabs ws[split][Cu][9 * CiP] with column (kh * 3 + kw) * CiP + ci, as wgrad_kernel<WG_CONV2D> writes them.
+template <bool TR>
+__global__ void __launch_bounds__(256, PCRL_OCC2) wgrad2d_row3_kernel(const WgradParams p) {
+  using T = bf16;
+  using WT = WTile<T>;
+  using WF = WFrag<T, TR>;
+  constexpr int KS = 64, VEC = 8, CPR = 8, RPP = 32, NP = KS / RPP;
+  constexpr int TILE_BYTES = KS * WT::ROWB;   // 8 KiB
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][U, V0, V1, V2]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wi = wid >> 1, wj = wid & 1;
+  const int CiP = p.q.CiP, ntc = (CiP + 63) / 64;
+  const int i0 = (blockIdx.x / ntc) * 64, jc0 = (blockIdx.x % ntc) * 64;
+  const int kh = blockIdx.y;
+  const int64_t mbeg = (int64_t)blockIdx.z * p.chunk;
+  const int64_t mend = (mbeg + p.chunk < p.M) ? (mbeg + p.chunk) : p.M;
+  const T* __restrict__ U = reinterpret_cast<const T*>(p.u);
+  const T* __restrict__ V = reinterpret_cast<const T*>(p.v);
+  const Dims g = p.g;
+  const int chunk16 = tid % CPR, rowp = tid / CPR;
+  const int ucol = chunk16 * VEC;
+  const bool u_ok = (i0 + ucol) < p.Cu, v_ok = (jc0 + ucol) < CiP;
+  const int ucol_u = u_ok ? ucol : 0, vcol = jc0 + (v_ok ? ucol : 0);
+  const int Hl = p.q.up ? 2 * p.q.Hs : p.q.Hs, Wl = p.q.up ? 2 * p.q.Ws : p.q.Ws;
+
+  f32x4 acc[3][2][2];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[q][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int cn[NP], ch[NP], cw[NP];
+  int64_t cm[NP];
+  const int sw = KS % g.W, sh = (KS / g.W) % g.H, sn = KS / (g.W * g.H);
+#pragma unroll
+  for (int ps = 0; ps < NP; ++ps) {
+    cm[ps] = mbeg + ps * RPP + rowp;
+    const int64_t mc = cm[ps] < p.M ? cm[ps] : 0;
+    int dd;
+    decode_voxel(mc, g, cn[ps], dd, ch[ps], cw[ps]);
+  }
+  u32x4 ru[NP], rv[3][NP];
+  uint32_t uokb = 0, vokb = 0;   // vokb: bit q * NP + ps
+  // unconditional loads from clamped addresses; validity is applied at the LDS store (see wgrad_kernel)
+#define R3_LOAD()                                                                                 \
+  do {                                                                                            \
+    uokb = 0;                                                                                     \
+    vokb = 0;                                                                                     \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                           \
+      const bool live = cm[ps] < mend;                                                            \
+      const int64_t m = live ? cm[ps] : mbeg;                                                     \
+      ru[ps] = *reinterpret_cast<const u32x4*>(U + m * p.Cu + i0 + ucol_u);                       \
+      uokb |= (uint32_t)(live && u_ok) << ps;                                                     \
+      const int ih0 = ch[ps] * p.q.stride - p.q.pad + kh, iw0 = cw[ps] * p.q.stride - p.q.pad;    \
+      const bool rok = live && (unsigned)ih0 < (unsigned)Hl;                                      \
+      const int ihs = p.q.up ? (ih0 >> 1) : ih0;                                                  \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                             \
+        const int iw = iw0 + q;                                                                   \
+        const bool in = rok && (unsigned)iw < (unsigned)Wl;                                       \
+        const int iws = p.q.up ? (iw >> 1) : iw;                                                  \
+        const int64_t vrow = in ? ((int64_t)cn[ps] * p.q.Hs + ihs) * p.q.Ws + iws : (int64_t)0;   \
+        rv[q][ps] = *reinterpret_cast<const u32x4*>(V + vrow * CiP + vcol);                       \
+        vokb |= (uint32_t)(in && v_ok) << (q * NP + ps);                                          \
+      }                                                                                           \
+      cm[ps] += KS;                                                                               \
+      cw[ps] += sw;                                                                               \
+      if (cw[ps] >= g.W) { cw[ps] -= g.W; ch[ps] += 1; }                                          \
+      ch[ps] += sh;                                                                               \
+      if (ch[ps] >= g.H) { ch[ps] -= g.H; cn[ps] += 1; }                                          \
+      cn[ps] += sn;                                                                               \
+    }                                                                                             \
+  } while (0)
+#define R3_STORE(buf_)                                                                            \
+  do {                                                                                            \
+    char* base_ = smem + (buf_) * (4 * TILE_BYTES);                                               \
+    _Pragma("unroll") for (int ps = 0; ps < NP; ++ps) {                                           \
+      const int row = ps * RPP + rowp;                                                            \
+      *reinterpret_cast<u32x4*>(base_ + WT::off(row, ucol)) = keep_if((uokb >> ps) & 1u, ru[ps]); \
+      _Pragma("unroll") for (int q = 0; q < 3; ++q)                                               \
+        *reinterpret_cast<u32x4*>(base_ + (1 + q) * TILE_BYTES + WT::off(row, ucol)) = keep_if((vokb >> (q * NP + ps)) & 1u, rv[q][ps]); \
+    }                                                                                             \
+  } while (0)
+
+  const int64_t nsteps = (mend > mbeg) ? (mend - mbeg + KS - 1) / KS : 0;
+  if (nsteps > 0) {
+    R3_LOAD();
+    R3_STORE(0);
+  }
+  __syncthreads();
+  for (int64_t s = 0; s < nsteps; ++s) {
+    const int cur = (int)(s & 1);
+    R3_LOAD();   // the last iteration stages rows past `mend`: dead (the clamped pixel of row m = mbeg), zeroed at the LDS store
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < KS / 32; ++kk) {
+      const char* base = smem + cur * (4 * TILE_BYTES) + kk * 32 * WT::ROWB;
+      typename WF::Frag fa[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) fa[a] = WF::read(base, wi * 32 + a * 16, lane);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        typename WF::Frag fb[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) fb[b] = WF::read(base + (1 + q) * TILE_BYTES, wj * 32 + b * 16, lane);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) WF::mma(fa[a], fb[b], acc[q][a][b]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    R3_STORE(cur ^ 1);
+    __syncthreads();
+  }
+#undef R3_LOAD
+#undef R3_STORE
+  float* __restrict__ out = p.ws + (int64_t)blockIdx.z * (int64_t)p.Cu * p.Cv;
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = i0 + wi * 32 + a * 16 + (lane >> 4) * 4 + r;
+          const int jc = jc0 + wj * 32 + b * 16 + (lane & 15);
+          if (i < p.Cu && jc < CiP) out[(int64_t)i * p.Cv + (kh * 3 + q) * CiP + jc] = acc[q][a][b][r];
+        }
+}
+
 // split plan of the all-taps kernel: whole rounds of 512 blocks (2 per CU), at least 16 K-steps per block
 SplitPlanUp2 plan_up2(int64_t M, int Cu, int Cv) {
   const int64_t tiles = (int64_t)(Cu / 64) * (Cv / 64);
@@ -1349,6 +1489,23 @@ static SplitPlan plan_splits2d(int64_t M, int Cu, int Cv, int ks) {
   splits = (steps + per - 1) / per;
   return SplitPlan{(int)splits, per * ks};
 }
+// one-kernel-row-per-block form (wgrad2d_row3_kernel): K-steps of 64 pixels, whole rounds of ~1024 blocks, at least 8 steps per block.
+// PCRL_WGRAD2D_ROW3=0: the flattened-tap gather kernel instead (A/B switch)
+static bool wgrad2d_row3_ok(int CiP, int CoP, int KH, int KW, int dtype) {
+  static const bool on = [] { const char* e = getenv("PCRL_WGRAD2D_ROW3"); return !(e && e[0] == '0'); }();
+  return on && dtype == PCRL_BF16 && KH == 3 && KW == 3 && CiP >= 32 && CoP >= 32;
+}
+static SplitPlan plan_row3(int64_t M, int CoP, int CiP) {
+  const int64_t tiles = (int64_t)((CoP + 63) / 64) * ((CiP + 63) / 64) * 3;
+  const int64_t steps = (M + 63) / 64;
+  int64_t splits = 1024 / tiles;
+  const int64_t max_splits = (steps + 7) / 8;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  const int64_t per = (steps + splits - 1) / splits;
+  splits = (steps + per - 1) / per;
+  return SplitPlan{(int)splits, per * 64};
+}
 static int conv2d_wgrad_ks(int dtype) { return (dtype == PCRL_BF16 && g_wgrad_tr) ? 128 : 32; }   // 128 (template KS) measured slower: the loads, not the barriers, set the pace
 
 // LDS-halo brick kernel with the image index as depth (wgrad_brick.hip, nkd = 1)
@@ -1371,6 +1528,10 @@ extern "C" size_t pcrl_conv2d_wgrad_ws_bytes(int N, int Ho, int Wo, int CiP, int
   }
   if (KH == 3 && KW == 3 && pcrl_wgrad2d_narrow_eligible(N, Ho, Wo, CiP, CoP, PCRL_BF16)) {
     const int c = pcrl_wgrad2d_narrow_slabs(N, Ho, Wo);
+    if (c > splits) splits = c;
+  }
+  if (wgrad2d_row3_ok(CiP, CoP, KH, KW, PCRL_BF16)) {
+    const int c = plan_row3((int64_t)N * Ho * Wo, CoP, CiP).splits;
     if (c > splits) splits = c;
   }
   return (size_t)splits * KH * KW * CoP * CiP * sizeof(float);
@@ -1403,6 +1564,18 @@ extern "C" int pcrl_conv2d_wgrad(const void* x, const void* dy, float* dw_ref, v
   }
   const Dims g{N, 1, Ho, Wo};
   const int64_t M = (int64_t)N * Ho * Wo;
+  if (g_wgrad_impl == 0 && g_wgrad_tr && wgrad2d_row3_ok(CiP, CoP, KH, KW, dtype)) {
+    const SplitPlan sp = plan_row3(M, CoP, CiP);
+    const size_t need = (size_t)sp.splits * CoP * Cv * sizeof(float);
+    if (ws_bytes < need || !ws) return pcrl_fail(PCRL_EWORKSPACE, "conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+    WgradParams p{dy, x, (float*)ws, g, M, CoP, Cv, 1, sp.chunk, Wg2d{Hi, Wi, KW, stride, pad, up, CiP, taps}};
+    dim3 grid((unsigned)(((CoP + 63) / 64) * ((CiP + 63) / 64)), 3u, (unsigned)sp.splits);
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [] { hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad2d_row3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * 128); });
+    hipLaunchKernelGGL((wgrad2d_row3_kernel<true>), grid, dim3(256), 8 * 64 * 128, as_stream(stream), p);
+    if (int e = pcrl_check_launch("conv2d_wgrad (row3)")) return e;
+    return launch_wgrad2d_reduce((const float*)ws, dw_ref, sp.splits, taps, CoP, CiP, Ci_out, as_stream(stream));
+  }
   const int ks = conv2d_wgrad_ks(dtype);
   const SplitPlan sp = plan_splits2d(M, CoP, Cv, ks);
   const size_t need = (size_t)sp.splits * CoP * Cv * sizeof(float);

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--only", type=int, default=-1, help="index into the shape list")
     a = ap.parse_args()
     dev, dt = torch.device("cuda"), torch.bfloat16
+    from pcrlv2_amd import config as cfg
+    cfg.WGRAD_SIDE_STREAM_2D = False          # weight gradients on the timed stream
     shapes = GATHER if a.shapes == "gather" else (BRICK if a.shapes == "brick" else GATHER + BRICK)
     if a.only >= 0:
         shapes = shapes[a.only:a.only + 1]
