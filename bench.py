@@ -335,6 +335,7 @@ def main():
         torch.cuda.synchronize()
         L.profiler = None
         _cfg.WGRAD_SIDE_STREAM_3D, _cfg.FWD_BRANCH_STREAM = True, _branch
+    alg_bytes = dict(ALG_BYTES)       # of the launches `roofline.launches` counts (the secondary configurations below classify their own launches too)
 
     # BASELINE config C4 (128x128x64 crops, b = 8: the large-crop stress case) on the same model, after everything that feeds `value` and
     # `roofline`: 2 warm-up + 5 timed steps (~0.5 s), reported as `secondary` -- never part of `value`.
@@ -490,8 +491,8 @@ def main():
                                "PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 PCRL_VIEW_STREAMS=0 semantics)" % min(10, args.steps)})
     else:
         line["roofline"]["measured"] = "HIP events over the timed region"
-    if ALG_BYTES.get(dom) and line["roofline"]["launches"]:
-        ab = ALG_BYTES[dom] / line["roofline"]["launches"]
+    if alg_bytes.get(dom) and line["roofline"]["launches"]:
+        ab = alg_bytes[dom] / line["roofline"]["launches"]
         line["roofline"]["algorithmic_bytes_per_launch"] = round(ab)
         if line["roofline"]["traffic"]:
             line["roofline"]["traffic_over_algorithmic"] = round(line["roofline"]["traffic"] / ab, 3)

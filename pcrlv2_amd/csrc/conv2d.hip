@@ -26,6 +26,9 @@
 namespace {
 
 enum { C2_FWD = 0, C2_DGRAD = 1 };
+#ifndef C2_IDX
+#define C2_IDX int64_t   // element-offset type of the gather addresses (experiment: -DC2_IDX=int)
+#endif
 
 struct C2Params {
   const void* x;      // source rows [N*Hs*Ws][Cs]
@@ -81,7 +84,7 @@ __global__ void __launch_bounds__(256, PCRL_OCC2) conv2d_kernel(const C2Params p
   const int sshift = p.stride - 1;   // stride is 1 or 2
 
   // ---- per-thread A rows ----
-  int64_t nbase[AP];   // row of source pixel (n, 0, 0); -1 marks a dead row
+  C2_IDX nbase[AP];   // row of source pixel (n, 0, 0); -1 marks a dead row
   int oy[AP], ox[AP];
 #pragma unroll
   for (int ps = 0; ps < AP; ++ps) {
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(256, PCRL_OCC2) conv2d_kernel(const C2Params p
       const int ow = (int)(m % p.Wo);
       const int64_t t = m / p.Wo;
       const int oh = (int)(t % p.Ho), n = (int)(t / p.Ho);
-      nbase[ps] = (int64_t)n * p.Hs * p.Ws;
+      nbase[ps] = (C2_IDX)n * p.Hs * p.Ws;
       if (MODE == C2_FWD) {
         oy[ps] = oh * p.stride - p.pad;
         ox[ps] = ow * p.stride - p.pad;
@@ -103,13 +106,13 @@ __global__ void __launch_bounds__(256, PCRL_OCC2) conv2d_kernel(const C2Params p
     }
   }
   // ---- per-thread B rows ----
-  int64_t boff[BP];
+  C2_IDX boff[BP];
   bool bok[BP];
 #pragma unroll
   for (int ps = 0; ps < BP; ++ps) {
     const int brow = ps * RPP + rowp;
     bok[ps] = brow < BN;
-    boff[ps] = (int64_t)(n0 + (bok[ps] ? brow : 0)) * p.Kpad + slot * VEC;
+    boff[ps] = (C2_IDX)(n0 + (bok[ps] ? brow : 0)) * p.Kpad + slot * VEC;
   }
 
   f32x4 acc[FM][FN];
@@ -147,12 +150,12 @@ __global__ void __launch_bounds__(256, PCRL_OCC2) conv2d_kernel(const C2Params p
         iw_ = tw_ >> sshift;                                                                            \
         ok_ = ok_ && th_ >= 0 && tw_ >= 0 && (ih_ << sshift) == th_ && (iw_ << sshift) == tw_ && ih_ < p.Hs && iw_ < p.Ws; \
       }                                                                                                 \
-      const int64_t row_ = ok_ ? nbase[ps] + (int64_t)ih_ * p.Ws + iw_ : (int64_t)0;                    \
+      const C2_IDX row_ = ok_ ? nbase[ps] + (C2_IDX)ih_ * p.Ws + iw_ : (C2_IDX)0;                       \
       ra[ps] = *reinterpret_cast<const u32x4*>(X + row_ * Cs + (ok_ ? c_ : 0));                         \
       aok |= (uint32_t)ok_ << ps;                                                                       \
     }                                                                                                   \
     _Pragma("unroll") for (int ps = 0; ps < BP; ++ps)                                                   \
-      rb[ps] = *reinterpret_cast<const u32x4*>(Wp + boff[ps] + (int64_t)(s_)*32);                       \
+      rb[ps] = *reinterpret_cast<const u32x4*>(Wp + boff[ps] + (C2_IDX)(s_)*32);                        \
   } while (0)
 
 #define C2_STORE(buf_, ra, rb, aok)                                                                     \
