@@ -7,6 +7,7 @@
 // in the activation dtype, accessed as 16-byte channel vectors.  The weight gradients of these layers are MFMA GEMMs
 // (conv_wgrad.hip, via an im2col of the scalar operand).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -97,39 +98,42 @@ __global__ void c1_fwd_kernel(const float* __restrict__ x, const float* __restri
 // convolution in bf16 mode); bias, the bf16 store and the BatchNorm partials (one row per brick) come from the float sums.
 // six blocks per CU for the narrow forms (<= 80 registers): the kernel is a chain of latencies per block -- stage, im2col, MFMA, store -- (130 -> 116 us
 // at 64x64x32 with the batched halo loads; eight blocks per CU spill: 273 us)
+// Round 4: a block WALKS bricks (blockIdx.x, + gridDim.x, ...): the next brick's halo is requested before the current one is multiplied and stored
+// and lands under its MFMAs and stores (two LDS halo buffers), the weight fragments and tap offsets are built once per block -- the per-brick chain
+// stage -> im2col -> MFMA -> store becomes a pipeline.  Same arithmetic per brick, same statistics rows (one per brick): bit-identical.
 template <int CO>
-__global__ void __launch_bounds__(256, CO <= 32 ? 6 : 1) c1_brick_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_ref,
+__global__ void __launch_bounds__(256, CO <= 32 ? 4 : 2) c1_brick_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_ref,
                                                            const float* __restrict__ bias, bf16* __restrict__ y,
-                                                           float* __restrict__ stats, Dims g) {
+                                                           float* __restrict__ stats, Dims g, int nbricks) {
   constexpr int FN = CO / 16;
-  __shared__ float sh[600];
+  __shared__ float sh[2][600];
   __shared__ float red[4 * CO * 2];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int bw = g.W / 8, bh = g.H / 8, bd = g.D / 4;
-  int b = blockIdx.x;
-  const int w0 = (b % bw) * 8; b /= bw;
-  const int h0 = (b % bh) * 8; b /= bh;
-  const int d0 = (b % bd) * 4; b /= bd;
-  const int n = b;
-  const int64_t base0 = (((int64_t)n * g.D + d0) * g.H + h0) * g.W + w0;
-  // halo staging: the (up to) three loads of a thread are issued together, then stored (one global-memory latency per block instead of
-  // three: by ablation the staging was 59 of the kernel's 130 us at 64x64x32)
-  {
-    float hv[3];
-    bool hok[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int q = tid + 256 * i;
-      const int hd = q / 100, hh = (q / 10) % 10, hw = q % 10;
-      const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;
-      hok[i] = q < 600 && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-      hv[i] = x[hok[i] ? (((int64_t)n * g.D + d) * g.H + h) * g.W + w : base0];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      if (tid + 256 * i < 600) sh[tid + 256 * i] = hok[i] ? hv[i] : 0.f;
-  }
+  // halo staging: the (up to) three loads of a thread are issued together (one global-memory latency per brick instead of three)
+  float hv[3];
+  bool hok[3];
+#define C1_LOAD(b_)                                                                                       \
+  do {                                                                                                    \
+    int t_ = (b_);                                                                                        \
+    const int w0_ = (t_ % bw) * 8; t_ /= bw;                                                              \
+    const int h0_ = (t_ % bh) * 8; t_ /= bh;                                                              \
+    const int d0_ = (t_ % bd) * 4; t_ /= bd;                                                              \
+    const int64_t base_ = (((int64_t)t_ * g.D + d0_) * g.H + h0_) * g.W + w0_;                            \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                       \
+      const int q = tid + 256 * i;                                                                        \
+      const int hd = q / 100, hh = (q / 10) % 10, hw = q % 10;                                            \
+      const int d = d0_ + hd - 1, h = h0_ + hh - 1, w = w0_ + hw - 1;                                     \
+      hok[i] = q < 600 && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W; \
+      hv[i] = x[hok[i] ? (((int64_t)t_ * g.D + d) * g.H + h) * g.W + w : base_];                          \
+    }                                                                                                     \
+  } while (0)
+#define C1_STORE(buf_)                                                                                    \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                         \
+      if (tid + 256 * i < 600) sh[buf_][tid + 256 * i] = hok[i] ? hv[i] : 0.f;                            \
+  } while (0)
   // weights: fragment j, lane (lr = channel, lg = taps 8 lg .. 8 lg + 7)
   bf16x8 fb[FN];
 #pragma unroll
@@ -145,64 +149,85 @@ __global__ void __launch_bounds__(256, CO <= 32 ? 6 : 1) c1_brick_fwd_kernel(con
     const int t = 8 * lg + e;
     toff[e] = t < 27 ? ((t / 9) * 10 + (t / 3) % 3) * 10 + t % 3 : -1;
   }
+  float bv[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) bv[j] = bias ? bias[j * 16 + lr] : 0.f;
+  int b = blockIdx.x, cur = 0;
+  if (b < nbricks) {
+    C1_LOAD(b);
+    C1_STORE(0);
+  }
   __syncthreads();
-  f32x4 acc[4][FN];
+  for (; b < nbricks; b += gridDim.x, cur ^= 1) {
+    const bool more = b + (int)gridDim.x < nbricks;
+    if (more) C1_LOAD(b + (int)gridDim.x);
+    int t = b;
+    const int w0 = (t % bw) * 8; t /= bw;
+    const int h0 = (t % bh) * 8; t /= bh;
+    const int d0 = (t % bd) * 4; t /= bd;
+    const int64_t base0 = (((int64_t)t * g.D + d0) * g.H + h0) * g.W + w0;
+    const float* shc = sh[cur];
+    f32x4 acc[4][FN];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    const int hb = ((wid * 10 + 2 * f + (lr >> 3)) * 10) + (lr & 7);   // halo index of the lane's voxel (tap 0,0,0 corner)
-    bf16x8 fa;
+    for (int f = 0; f < 4; ++f) {
+      const int hb = ((wid * 10 + 2 * f + (lr >> 3)) * 10) + (lr & 7);   // halo index of the lane's voxel (tap 0,0,0 corner)
+      bf16x8 fa;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) fa[e] = toff[e] >= 0 ? (bf16)sh[hb + toff[e]] : (bf16)0.f;
+      for (int e = 0; e < 8; ++e) fa[e] = toff[e] >= 0 ? (bf16)shc[hb + toff[e]] : (bf16)0.f;
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
-      acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-  }
-  float s1[FN], s2[FN], bv[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    s1[j] = 0.f;
-    s2[j] = 0.f;
-    bv[j] = bias ? bias[j * 16 + lr] : 0.f;
-  }
-#pragma unroll
-  for (int f = 0; f < 4; ++f)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int v = f * 16 + lg * 4 + r;   // voxel of the wave's plane: h = v >> 3, w = v & 7
-      const int64_t row = base0 + ((int64_t)wid * g.H + (v >> 3)) * g.W + (v & 7);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const float val = acc[f][j][r] + bv[j];
-        y[row * CO + j * 16 + lr] = (bf16)val;
-        s1[j] += val;
-        s2[j] += val * val;
-      }
+      for (int j = 0; j < FN; ++j)
+        acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
-  if (stats) {
+    float s1[FN], s2[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      float a = s1[j], c2 = s2[j];
-      a += __shfl_xor(a, 16, 64);
-      c2 += __shfl_xor(c2, 16, 64);
-      a += __shfl_xor(a, 32, 64);
-      c2 += __shfl_xor(c2, 32, 64);
-      if (lg == 0) {
-        red[(wid * CO + j * 16 + lr) * 2 + 0] = a;
-        red[(wid * CO + j * 16 + lr) * 2 + 1] = c2;
-      }
+      s1[j] = 0.f;
+      s2[j] = 0.f;
     }
-    __syncthreads();
-    if (tid < CO) {
-      float a = 0.f, c2 = 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a += red[(q * CO + tid) * 2 + 0];
-        c2 += red[(q * CO + tid) * 2 + 1];
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int v = f * 16 + lg * 4 + r;   // voxel of the wave's plane: h = v >> 3, w = v & 7
+        const int64_t row = base0 + ((int64_t)wid * g.H + (v >> 3)) * g.W + (v & 7);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const float val = acc[f][j][r] + bv[j];
+          y[row * CO + j * 16 + lr] = (bf16)val;
+          s1[j] += val;
+          s2[j] += val * val;
+        }
       }
-      stats[((int64_t)blockIdx.x * CO + tid) * 2 + 0] = a;
-      stats[((int64_t)blockIdx.x * CO + tid) * 2 + 1] = c2;
+    if (stats) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        float a = s1[j], c2 = s2[j];
+        a += __shfl_xor(a, 16, 64);
+        c2 += __shfl_xor(c2, 16, 64);
+        a += __shfl_xor(a, 32, 64);
+        c2 += __shfl_xor(c2, 32, 64);
+        if (lg == 0) {
+          red[(wid * CO + j * 16 + lr) * 2 + 0] = a;
+          red[(wid * CO + j * 16 + lr) * 2 + 1] = c2;
+        }
+      }
+      __syncthreads();
+      if (tid < CO) {
+        float a = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          a += red[(q * CO + tid) * 2 + 0];
+          c2 += red[(q * CO + tid) * 2 + 1];
+        }
+        stats[((int64_t)b * CO + tid) * 2 + 0] = a;
+        stats[((int64_t)b * CO + tid) * 2 + 1] = c2;
+      }
     }
+    if (more) C1_STORE(cur ^ 1);
+    __syncthreads();   // the other halo buffer is complete; everybody has read this one and this brick's `red`
   }
+#undef C1_LOAD
+#undef C1_STORE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -387,10 +412,16 @@ extern "C" int pcrl_conv3d_k3_c1_fwd(const float* x, const float* w_ref, const f
   const Dims g{N, D, H, W};
   const int64_t M = (int64_t)N * D * H * W;
   if (c1_brick_ok(D, H, W, dtype)) {
-    const unsigned bricks = (unsigned)pcrl_conv3d_k3_c1_stats_rows(N, D, H, W, Co, dtype);
-    if (Co == 16) hipLaunchKernelGGL(c1_brick_fwd_kernel<16>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g);
-    else if (Co == 32) hipLaunchKernelGGL(c1_brick_fwd_kernel<32>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g);
-    else hipLaunchKernelGGL(c1_brick_fwd_kernel<64>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g);
+    const int64_t nb64 = pcrl_conv3d_k3_c1_stats_rows(N, D, H, W, Co, dtype);
+    PCRL_REQUIRE(nb64 < ((int64_t)1 << 31), "conv3d_k3_c1_fwd: too many bricks");
+    const int nbr = (int)nb64;
+    // persistent blocks: four per CU for the narrow forms (128 registers: the prefetch does not fit the 80 of six blocks per CU), two otherwise.  PCRL_C1_PERSIST=0: one brick per block (A/B switch)
+    static const bool persist = [] { const char* e = getenv("PCRL_C1_PERSIST"); return !(e && e[0] == '0'); }();
+    const int cap = persist ? 256 * (Co <= 32 ? 4 : 2) : nbr;
+    const unsigned bricks = (unsigned)(nbr < cap ? nbr : cap);
+    if (Co == 16) hipLaunchKernelGGL(c1_brick_fwd_kernel<16>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g, nbr);
+    else if (Co == 32) hipLaunchKernelGGL(c1_brick_fwd_kernel<32>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g, nbr);
+    else hipLaunchKernelGGL(c1_brick_fwd_kernel<64>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g, nbr);
     return pcrl_check_launch("c1_brick_fwd");
   }
   const unsigned blocks = (unsigned)((M + 127) / 128);
