@@ -354,6 +354,75 @@ def make_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, base_
     print(f"[{tag}] wrote fixture; oracle == reference over {nsteps} steps")
 
 
+def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, base_lr=1e-3, epochs=240, seed=5, ema=0.9):
+    """Long-horizon loss curve of the REAL reference (SURVEY App. C iv): `nsteps` SGD steps of train_3d.py:109-151 on
+    correlated synthetic views (fill_batch seeds 2000 + step), run TWICE from the same state and draws:
+      * float64, oneDNN off  -> the curve the engines are held to (per step: total, loss1, loss2, loss4, local_loss, index2, EMA(0.9) of the total);
+      * float32, stock PyTorch (oneDNN on: the reference's own CPU path) -> how far stock float32 itself drifts from float64 over the
+        same steps; its per-component maxima are stored as `stock_fp32_*` and are the yardstick for the tolerances the GPU test states.
+    The oracle is NOT re-run here over the whole horizon (make_curve pins it step for step over 12 steps; the restatement is the same code)."""
+    torch.set_num_threads(8)
+    names = ("loss", "loss1", "loss2", "loss4", "local_loss")
+
+    def run(dt, onednn):
+        st0 = O.fill_state(dt)
+        model = refmod.PCRLv23d().to(dt)
+        model.load_state_dict(st0, strict=True)
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=base_lr, momentum=0.9, weight_decay=1e-4)
+
+        class A:
+            pass
+        A.lr, A.epochs = base_lr, epochs
+        ref_utils.adjust_learning_rate(epoch, A, opt)
+        criterion, cosine = torch.nn.MSELoss(), torch.nn.CosineSimilarity()
+        random.seed(seed)
+        rows = []
+        with torch.backends.mkldnn.flags(enabled=onednn):
+            for s in range(nsteps):
+                batch = O.fill_batch(b, dhw, dtype=dt, seed=2000 + s)
+                r = reference_step(model, ref_train, batch, epoch, criterion, cosine)
+                opt.zero_grad()
+                r["loss"].backward()
+                opt.step()
+                rows.append([float(r[k].detach()) for k in names] + [float(r["index2"])])
+                if s % 20 == 0 or s == nsteps - 1:
+                    print(f"[{tag}] {dt} step {s}: {rows[-1]}", flush=True)
+        return np.array(rows)
+
+    def ema_of(v):
+        out, e = [], v[0]
+        for x in v:
+            e = ema * e + (1.0 - ema) * x
+            out.append(e)
+        return np.array(out)
+
+    def save(c64, c32):
+        ref = c64 if c64 is not None else c32
+        e_ref = ema_of(ref[:, 0])
+        extra = {}
+        if c64 is not None:
+            n = min(len(c64), len(c32))
+            d = np.abs(c32[:n, :5] - c64[:n, :5])
+            e32 = ema_of(c32[:, 0])
+            extra = dict(stock_fp32_max_abs=d.max(axis=0), stock_fp32_mean_abs=d.mean(axis=0),
+                         stock_fp32_ema_max_after20=np.float64(np.abs(e32[:n] - e_ref[:n])[20:].max()) if n > 21 else np.float64(0))
+            for i, k in enumerate(names):
+                print(f"[{tag}] stock fp32 vs fp64 over {n} steps, {k}: max {d[:, i].max():.3e} mean {d[:, i].mean():.3e}")
+            print(f"[{tag}] stock fp32 EMA(total) vs fp64 after step 20: max {float(extra['stock_fp32_ema_max_after20']):.3e}")
+        np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), curve=ref, ema_total=e_ref, ema=np.float64(ema), b=np.int64(b), dhw=np.array(dhw),
+                            nsteps=np.int64(len(ref)), epoch=np.int64(epoch), base_lr=np.float64(base_lr), seed=np.int64(seed), batch_seed0=np.int64(2000),
+                            reference_dtype="float64, oneDNN off" if c64 is not None else "float32, stock (oneDNN on)", stock_fp32_curve=c32, **extra)
+
+    # stock float32 first (minutes) so that a fixture exists early; the float64 run (~35 s per step on 8 cores: ATen's float64 convolutions
+    # take the native im2col path) then replaces `curve`; `reference_dtype` says which one a file holds
+    c32 = run(torch.float32, True)
+    save(None, c32)
+    c64 = run(torch.float64, False)
+    save(c64, c32)
+    print(f"[{tag}] wrote fixture ({nsteps} steps)")
+
+
 def make_eval(tag, b, dhw, refmod, ref_train, ref_utils):
     """Eval-mode forward of the REAL reference (model.eval(): running statistics) on a state whose buffers were moved by one oracle
     training step -- what a consumer of the checkpoint runs (README.md:48-55).  The tests rebuild the state with the oracle (it is
@@ -580,6 +649,9 @@ def main():
     if "--data-parallel" in sys.argv:
         # nn.DataParallel semantics (train_3d.py:54) on two replicas of b = 4
         make_dp("dp2_b4x2_32x32x16", 4, (32, 32, 16), 2, 2, refmod, ref_train, ref_utils)
+        return
+    if "--long-curve" in sys.argv:
+        make_long_curve("lc_b8_32x32x16_300steps", 8, (32, 32, 16), 300, refmod, ref_train, ref_utils)
         return
     if "--forward-only" in sys.argv:
         # the exact BASELINE batches (C2, C4), forward-only (float64 backward does not fit at these sizes)

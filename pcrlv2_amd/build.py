@@ -17,6 +17,10 @@ LIB = os.path.join(LIBDIR, "libpcrl_hip.so")
 OBJDIR = os.path.join(os.path.dirname(PKG), "build", "obj")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+# Per-file code generation flags.  conv_brick16.hip: the plain wide-brick instantiations sit at the 256-register budget of two waves per SIMD; the greedy
+# allocator's default assignment order spills 9-17 registers there (fragment addresses, reloaded behind s_waitcnt vmcnt(0) in the middle of a stage), the
+# reverse order fits all of them (profiles/r05_b16_isa_mix.txt).
+FILE_FLAGS = {"conv_brick16.hip": ["-mllvm", "-greedy-reverse-local-assignment"]}
 
 
 def hipcc() -> str:
@@ -40,7 +44,7 @@ def _compile(src: str, force: bool) -> str:
     obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _deps_mtime()):
         return obj
-    cmd = [hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [hipcc(), *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -39,20 +39,6 @@
 #include <atomic>
 #include <mutex>
 
-#ifndef B16_EARLY
-#define B16_EARLY 0   // 1: request the dead planes of the halo early (measured equal to 0, the whole halo at the end of the chunk: the co-resident block covers the latency)
-#endif
-#ifndef B16_ABL
-#define B16_ABL 0   // timing ablations (wrong results): bit 0 no weight staging after the first stage, bit 1 no halo requests after the first chunk,
-                    // bit 2 a BatchNorm + ReLU pass over the landed halo in LDS (what applying the PREVIOUS layer's normalisation inside this kernel
-                    // would cost: VERDICT r2 item 3; measured +9..17 % on the layers it would serve, see DESIGN 4.3 -- not built),
-                    // bit 3 the first pass of the NEXT layer's BatchNorm backward in the data gradient's epilogue, its y tile through LDS-DMA into the
-                    // free halo buffer (measured: 64->64 at 64x64x32 +77 us against the 171 us pass it would replace, neutral or worse on every
-                    // smaller layer; ~200 spilled registers in the epilogue as written -- DESIGN 9, not built),
-                    // bit 5 only the kw = 0 fragments are read from LDS (upper bound of deriving the kw = 1, 2 fragments by lane shifts),
-                    // bit 4 the output tile as coalesced 16-byte stores (upper bound of an LDS-transposed epilogue: -7 % on 32->64, <= 2.6 % elsewhere)
-#endif
-
 namespace {
 
 constexpr int TD = 4, TH = 8, TW = 16;
@@ -67,10 +53,8 @@ template <int NW> struct B16Geom {
   static constexpr int HALO_BYTES = NDMA * 1024;       // 69632 / 115712
   static constexpr int PPW = (NDMA + NW - 1) / NW;     // pieces per wave: 17 / 15
 };
-constexpr int HALO_BYTES = B16Geom<4>::HALO_BYTES;
 constexpr int NS = 9;                                  // stages per chunk: (kd, kh); a stage = three kw taps
 
-__device__ uint4 g_zero_page[4];                       // source of halo rows outside the volume (zero-initialised device memory)
 
 struct Brick16Params {
   const bf16* x;
@@ -103,17 +87,20 @@ __device__ __forceinline__ int woff(int row, int slot) {
   return row * 64 + ((slot ^ key) << 4);
 }
 
-// One LDS-DMA request: every lane's 16 bytes at `gsrc` land at LDS byte address `lds_dst` (wave-uniform) + 16 * lane.  M0 carries the
-// destination and is compiler-reserved: saved and restored inside the statement.  Issued from inline asm because hipcc waits
-// vmcnt(0) before the next barrier / LDS access behind the builtin (it cannot prove they do not touch the DMA's destination), which
-// would expose the latency of the requests that are issued early (see STAGE); completion is counted by hand (s_waitcnt vmcnt(0) at
-// the end of the chunk; the compiler's own counted waits for the weight loads can only over-wait, vmcnt retires in order).
-__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
+// One LDS-DMA request of the halo: the lanes whose bit 0 of `okmask` is set load 16 bytes from `base` + `voff` (SGPR base + 32-bit
+// unsigned lane offset) to LDS byte address `lds_dst` (wave-uniform) + 16 * lane; the other lanes request nothing (their LDS rows were
+// zeroed once per block).  EXEC is narrowed by v_cmpx and restored from `exec_all` inside the statement; M0 carries the destination.
+// Issued from inline asm because hipcc waits vmcnt(0) before the next barrier / LDS access behind the builtin (it cannot prove they do
+// not touch the DMA's destination), which would expose the latency of the requests; completion is counted by hand (s_waitcnt vmcnt(0)
+// at the end of the chunk; the compiler's own counted waits for the weight loads can only over-wait, vmcnt retires in order).
+// `okmask` and `chain` pass through as read-write operands: the address arithmetic of the NEXT piece (which starts from them) cannot be scheduled
+// in front of this request, so a wave never holds more than one piece's temporaries (17 pieces' worth spilled 47 registers).
+__device__ __forceinline__ void lds_dma16_masked(uint64_t base, uint32_t voff, uint32_t& okmask, uint32_t& chain, uint32_t lds_dst, uint64_t exec_all) {
+  uint32_t t;
+  asm volatile("v_and_b32 %0, 1, %1\n\tv_cmpx_ne_u32_e32 0, %0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\ts_mov_b64 exec, %6"
+               : "=&v"(t), "+v"(okmask), "+v"(chain)
+               : "v"(voff), "s"(lds_dst), "s"(base), "s"(exec_all)
+               : "memory", "vcc");
 }
 
 // MODE 0: 3x3x3 convolution; 1: composed up-conv forward; 2: composed up-conv data gradient (Brick16Params).
@@ -172,54 +159,105 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
   const int d0 = (b % bd) * NW; b /= bd;
   const int n = b;
 
-  // ---- halo DMA: wave `wid` issues pieces wid, wid + 4, ...; a piece = 16 rows, lane -> (row = piece * 16 + lane / 4, slot lane & 3).
-  //      The source voxel of a row is fixed for the block: element offsets are computed once (17 registers), -1 = outside. ----
+  // ---- halo DMA: wave `wid` issues pieces wid, wid + NW, ...; a piece = 16 rows (1 KiB), lane -> (row = piece * 16 + lane / 4, physical slot
+  //      lane & 3).  Round 5 (profiles/r05_b16_isa_mix.txt): the per-piece source address used to be recomputed from the row number at every
+  //      chunk boundary -- two divisions, three range checks, a 64-bit voxel index and a branch around it: ~65 instructions per piece with
+  //      ten quarter-rate multiplies, 17 pieces per wave, i.e. ~1 100 instructions (~6 000 cycles) per chunk in front of the chunk's 864 (plain)
+  //      or 256 (composed) MFMAs per wave.  Now the block's PLAN is made once: the source is (SGPR base of the halo's first voxel) + a 32-bit
+  //      lane offset that advances from piece to piece by C1 + wrap * C2 + plane * C3 (a piece stride is 16 * NW rows = QL lines + a few rows of
+  //      the 18-row line pitch: `wrap` = the lane's row crossed one more line end, `plane` = its line crossed a plane end), the two bits per
+  //      piece and lane, the swizzle key of the row and "row inside the volume" live in three mask registers, rows outside the volume are
+  //      zeroed ONCE and never requested (EXEC-masked request), and a chunk only adds its channel offset: ~14 instructions per piece. ----
   constexpr int PPW = G::PPW;
-  const char* xb = reinterpret_cast<const char*>(p.x);
-  const char* zp = reinterpret_cast<const char*>(g_zero_page);
-  // The source address of a piece is recomputed per request (a few dozen VALU operations per piece and chunk, nothing next to a chunk's
-  // 864 MFMAs): 17 precomputed addresses per lane do not fit beside 128 accumulators.  `lo` is made opaque so that the compiler does
-  // not hoist the 17 address computations out of the chunk loop (and spill them).
-#define DMA_HALO(c_, P0_, P1_) /* pieces [P0_, P1_) */                                                     \
-  do {                                                                                                     \
-    int lo = lane;                                                                                         \
-    asm volatile("" : "+v"(lo));                                                                           \
-    _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                      \
-      if (NW * i + NW - 1 < (P0_) || NW * i >= (P1_)) continue;    /* compile time */                        \
-      if (wid + NW * i < (P0_) || wid + NW * i >= (P1_)) continue; /* wave-uniform */                      \
-      const int row = (wid + NW * i) * 16 + (lo >> 2);                                                     \
-      const int hd = row / (HH * HP), rem = row % (HH * HP), hh = rem / HP, hw = rem % HP;                 \
-      const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                         \
-      const bool ok = row < ROWS && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W; \
-      const int ls = (lo & 3) ^ key_w(hw);                                                                 \
-      int64_t el;                                                                                          \
-      if (UPCD) { /* fine voxel 2 v + par of the coarse halo voxel, channel chunk inside the parity */     \
-        const int par = PARC(c_), co0 = ((c_) - (par << p.cshift)) * 32;                                   \
-        const int64_t fv = FVOX(n, 2 * d + BITD(par), 2 * h + BITH(par), 2 * w + BITW(par));               \
-        el = fv * p.upc + co0 + ls * 8;                                                                    \
-      } else {                                                                                             \
-        el = VOX(n, d, h, w) * K + (c_)*32 + ls * 8;                                                       \
-      }                                                                                                    \
-      const char* src = ok ? xb + (el << 1) : zp;                                                          \
-      lds_dma16(src, lds_base + (wid + NW * i) * 1024);                                                    \
-    }                                                                                                      \
-  } while (0)
-  // Rows of the halo die plane by plane: stage (kd, kh) reads planes kd .. kd + 3, so plane 0 is dead after the three kd = 0 stages and
-  // plane 1 after the kd = 1 stages.  The pieces that lie inside those planes (11 + 11 of 68) are requested at those points, two and one
-  // thirds of a chunk ahead of their use; the other 46 at the end of the chunk.
-  constexpr int PA = (HH * HP) / 16, PB = (2 * HH * HP) / 16;   // 11, 22: pieces wholly inside plane 0 / planes 0-1
+  constexpr int RSTEP = 16 * NW, QL = RSTEP / HP;                 // rows / whole lines between two pieces of a wave
+  static_assert(PPW <= 17 && RSTEP - QL * HP < HP, "plan masks hold 16 steps; at most one line wrap per step");
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // byte strides of the source along the brick's w (row), h (line), d (plane) axes; the byte offset of chunk c_
+  int RS, LS, PS;
+  if (UPCD) {   // the fine gradient read as its space-to-depth view on the coarse grid: coarse steps are two fine voxels
+    const int v2 = 4 * p.upc;
+    RS = PERM ? v2 * (2 * p.H) : v2;
+    LS = PERM ? v2 : v2 * (2 * p.W);
+    PS = v2 * (2 * p.H) * (2 * p.W);
+  } else {
+    RS = PERM ? 2 * K * p.H : 2 * K;
+    LS = PERM ? 2 * K : 2 * K * p.W;
+    PS = 2 * K * p.H * p.W;
+  }
+  const int C1 = QL * LS + (RSTEP - QL * HP) * RS, C2 = LS - HP * RS, C3 = PS - HH * LS;   // |C2|, |C3| < 2^23 (eligibility): 24-bit multiply-adds
+#define CHUNK_OFS(c_) (UPCD ? (uint32_t)(((BITD(PARC(c_)) * (2 * p.H) * (2 * p.W) + (PERM ? BITW(PARC(c_)) * (2 * p.H) + BITH(PARC(c_)) \
+                                                                                       : BITH(PARC(c_)) * (2 * p.W) + BITW(PARC(c_)))) * p.upc \
+                                          + ((c_) - (PARC(c_) << p.cshift)) * 32) * 2)                                               \
+                            : (uint32_t)(c_) * 64u)
+  // SGPR base: the halo's first voxel (d0 - 1, h0 - 1, w0 - 1) of sample n -- may lie in front of the tensor; only rows inside the volume are requested
+  const uint64_t hbase = (uint64_t)(uintptr_t)p.x + (UPCD ? (uint64_t)(FVOX(n, 2 * (d0 - 1), 2 * (h0 - 1), 2 * (w0 - 1)) * (int64_t)(2 * p.upc))
+                                                        : (uint64_t)(VOX(n, d0 - 1, h0 - 1, w0 - 1) * (int64_t)(2 * K)));
+  // the plan: hoff0 = piece 0's offset (bit 0: piece 0 inside the volume -- offsets are multiples of 16); m_step: bit i - 1 = wrap, bit 15 + i =
+  // plane of the step into piece i; m_ko: bit i - 1 = piece i inside the volume, bit 15 + i = key of piece i XOR key of piece 0
+  uint32_t hoff0 = 0, m_step = 0, m_ko = 0;
+  {
+    int prevL = 0, prevP = 0, key0 = 0;
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const int piece = wid + NW * i, row = piece * 16 + (lane >> 2);
+      const int L = row / HP, hw = row - L * HP, P = L / HH, hh = L - P * HH;
+      const int d = d0 + P - 1, h = h0 + hh - 1, w = w0 + hw - 1;
+      const bool ok = row < ROWS && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+      const int key = key_w(hw) >> 1;
+      if (i == 0) {
+        hoff0 = (uint32_t)(P * PS + hh * LS + hw * RS + (((lane & 3) ^ (key << 1)) << 4)) | (ok ? 1u : 0u);
+        key0 = key;
+      } else {
+        m_step |= (uint32_t)(L - prevL - QL) << (i - 1);
+        m_step |= (uint32_t)(P - prevP) << (15 + i);
+        m_ko |= (ok ? 1u : 0u) << (i - 1);
+        m_ko |= (uint32_t)(key ^ key0) << (15 + i);
+      }
+      prevL = L;
+      prevP = P;
+      // rows of the halo outside the volume: zero for the block's lifetime
+      if (!ok && piece < NDMA) *reinterpret_cast<u32x4*>(halo + piece * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+    }
+  }
+  // The two mask words depend on (wave, lane / 4) only and are needed once per chunk: they wait in LDS -- NW = 4: the 512 bytes behind the halo's
+  // last row (1080 rows of the 1088 its 68 pieces span: the request of rows 1080.. is masked off); NW = 8: behind the weight stage -- instead of
+  // occupying two registers across the stage loop (the allocator spilled fragment addresses for them: three scratch reloads per two stages).
+  uint2* plan_lds = reinterpret_cast<uint2*>(smem + (NW == 4 ? ROWS * 64 : HALO_BYTES + 3 * BN * 64)) + wid * 16 + (lane >> 2);
+  *plan_lds = uint2{m_step, m_ko};
+  asm volatile("" : "+v"(hoff0));   // nothing of the plan is re-derived inside the loop
+  const uint64_t exec_all = __builtin_amdgcn_read_exec();
+  // The pieces are a ROLLED loop (scalar counter, variable shifts): 17 unrolled copies per stage body made the stage one scheduling region of
+  // ~1 000 instructions, and the allocator spilled the fragment addresses of the stage loop for it.
+#define DMA_HALO(c_)                                                                                       \
+  do {                                                                                                     \
+    uint32_t hoff = (hoff0 & ~15u) + CHUNK_OFS(c_), m0keep;                                                \
+    const uint2 plan_ = *plan_lds;                                                                         \
+    uint32_t m_step = plan_.x, m_ko = plan_.y;   /* shifted right by one per piece: the bits of the next step sit at positions 0 and 16 */ \
+    asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep), "+v"(m_step), "+v"(m_ko));                             \
+    uint32_t dst = lds_base + wid * 1024;                                                                  \
+    lds_dma16_masked(hbase, hoff, hoff0, m_step, dst, exec_all);                                           \
+    _Pragma("unroll 1") for (int i = 1; i < PPW; ++i) {                                                    \
+      const int t1 = __builtin_amdgcn_sbfe(m_step, 0, 1), t2 = __builtin_amdgcn_sbfe(m_step, 16, 1);  /* 0 / -1 */ \
+      hoff += (uint32_t)((t1 & C2) + (t2 & C3) + C1);                                                      \
+      const uint32_t ha = hoff ^ ((m_ko >> 11) & 32u);                                                     \
+      dst += NW * 1024;                                                                                    \
+      lds_dma16_masked(hbase, ha, m_ko, m_step, dst, exec_all);                                            \
+      m_step >>= 1;                                                                                        \
+      m_ko >>= 1;                                                                                          \
+    }                                                                                                      \
+    asm volatile("s_mov_b32 m0, %0" ::"s"(m0keep));                                                        \
+  } while (0)
 
   // ---- weight staging through registers: 3 pieces per thread (taps kw = 0,1,2 of the stage), row co = tid >> 2, slot tid & 3 ----
   const bool wthread = NW * 16 <= BN || (tid >> 2) < BN;   // compile-time true for four waves x 64 channels: no exec mask around the weight stores
-  const bf16* wrow = p.w + ((int64_t)(n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8;
+  const uint32_t wlane = (uint32_t)(((n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8) * 2u;   // byte offset of the thread's weight row (weights < 4 GiB: eligibility)
   const int wdst = woff(tid >> 2, tid & 3);
   u32x4 rw[3];
   constexpr int NKW = MODE ? 2 : 3;   // kw taps per stage: the composed modes stage and multiply only the two taps their phase / parity uses
 #define LOAD_W(c_, s9_, kwb_) /* taps kwb_ .. kwb_ + NKW - 1 of stage (kd, kh) */                          \
   do {                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < NKW; ++j)                                                        \
-      rw[j] = *reinterpret_cast<const u32x4*>(wrow + (int64_t)WTAP(s9_, (kwb_) + j) * K + (c_)*32);        \
+      rw[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.w) + (int64_t)(WTAP(s9_, (kwb_) + j) * K + (c_)*32) * 2 + wlane); \
   } while (0)
 #define STORE_W()                                                                                          \
   do {                                                                                                     \
@@ -275,34 +313,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
   } while (0)
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
-  // B16_ABL bit 2 (timing only): a = max(y * scale[ci] + shift[ci], 0) over the 4 352 16-byte pieces of the landed halo, 17 per thread: the
-  // thread owns one LOGICAL 8-channel slot (one coefficient set) of rows tid / 4 + 64 i; rows outside the volume stay 0.
-#define HALO_XFORM(c_)                                                                                     \
-  do {                                                                                                     \
-    float sc[8], sh[8];                                                                                    \
-    const float* cf = reinterpret_cast<const float*>(p.w) + (((c_)*32 + (tid & 3) * 8) & 1016);            \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                        \
-      sc[e] = cf[e];                                                                                       \
-      sh[e] = cf[e + 8];                                                                                   \
-    }                                                                                                      \
-    _Pragma("unroll 1") for (int i = 0; i < NDMA / 4; ++i) {                                               \
-      const int row = (tid >> 2) + 64 * i;                                                                 \
-      const int hd = row / (HH * HP), rem = row % (HH * HP), hh = rem / HP, hw = rem % HP;                 \
-      const int d = d0 + hd - 1, h = h0 + hh - 1, w = w0 + hw - 1;                                         \
-      const bool ok = row < ROWS && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W; \
-      char* at = halo + row * 64 + (((tid & 3) ^ key_w(hw)) << 4);   /* the thread's LOGICAL slot is fixed: one coefficient set */ \
-      u32x4 v = *reinterpret_cast<const u32x4*>(at);                                                       \
-      u32x4 o;                                                                                             \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
-        const float lo = __uint_as_float(v[q] << 16), hi = __uint_as_float(v[q] & 0xffff0000u);            \
-        const float a0 = fmaxf(lo * sc[2 * q] + sh[2 * q], 0.f), a1 = fmaxf(hi * sc[2 * q + 1] + sh[2 * q + 1], 0.f); \
-        bf16 b0 = (bf16)a0, b1 = (bf16)a1;                                                                 \
-        o[q] = (uint32_t) * reinterpret_cast<uint16_t*>(&b0) | ((uint32_t) * reinterpret_cast<uint16_t*>(&b1) << 16); \
-      }                                                                                                    \
-      *reinterpret_cast<u32x4*>(at) = keep_if(ok, o);                                                      \
-    }                                                                                                      \
-  } while (0)
-
   // One stage = six half-taps (kw = 0,1,2 x voxel halves 0,1), 16 MFMAs each.  A sets alternate per half-tap (fa[0] = half 0,
   // fa[1] = half 1); B sets alternate per tap: P = the set that holds kw = 0 on entry (a stage has three taps, so P flips per stage).
   // The two barriers of a stage sit inside the LAST half-tap, whose operands are in registers: the next stage's weights are stored,
@@ -314,9 +324,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
     if (sn == NSK) { sn = 0; cn = c + 1; }                                                                 \
     const bool last = (cn == nchunk);                                                                      \
     if (last) { cn = c; sn = s9; }                                                                         \
-    if (!(B16_ABL & 1)) LOAD_W(cn, SID(cn, sn), 0);                                                        \
-    const bool halo_next = (s9 == NSK - 1) && !last && !(B16_ABL & 2); /* block-uniform */                 \
-    const bool more_chunks = c + 1 < nchunk && !(B16_ABL & 2);                                             \
+    LOAD_W(cn, SID(cn, sn), 0);                                                        \
+    const bool halo_next = (s9 == NSK - 1) && !last; /* block-uniform */                                   \
     const int tap64 = ((SID(c, s9) / 3) * HH + (SID(c, s9) % 3)) * (HP * 64);                              \
     const int ntap64 = ((SID(cn, sn) / 3) * HH + (SID(cn, sn) % 3)) * (HP * 64);                           \
     /* ht0: kw 0, half 0 */                                                                                \
@@ -325,42 +334,36 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \
     /* ht1: kw 0, half 1 */                                                                                \
-    if (!(B16_ABL & 32)) LOADA(0, akw[1] + tap64, 0);                                                                           \
+    LOADA(0, akw[1] + tap64, 0);                                                                           \
     LOADB((P_) ^ 1, wbuf + 1 * (BN * 64));                                                                 \
     MFMA_HALF(1, P_, 1, 0, 4);                                                                 \
     PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
     SB();                                                                                                  \
     /* ht2: kw 1, half 0 */                                                                                \
-    if (!(B16_ABL & 32)) LOADA(1, akw[1] + tap64, 1);                                                                           \
+    LOADA(1, akw[1] + tap64, 1);                                                                           \
     MFMA_HALF(0, (P_) ^ 1, 0, 0, 4);                                                                       \
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \
     /* ht3: kw 1, half 1 */                                                                                \
-    if (!(B16_ABL & 32)) LOADA(0, akw[2] + tap64, 0);                                                                           \
+    LOADA(0, akw[2] + tap64, 0);                                                                           \
     LOADB(P_, wbuf + 2 * (BN * 64));                                                                       \
     MFMA_HALF(1, (P_) ^ 1, 1, 0, 4);                                                                       \
     PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
     SB();                                                                                                  \
     /* ht4: kw 2, half 0 */                                                                                \
-    if (!(B16_ABL & 32)) LOADA(1, akw[2] + tap64, 1);                                                                           \
+    LOADA(1, akw[2] + tap64, 1);                                                                           \
     MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
     PIPE_READS(4, FN);                                                                                     \
     SB();                                                                                                  \
     /* ht5: kw 2, half 1 -- every LDS read of this stage (and, in a chunk's last stage, of this chunk's halo) is complete */ \
     __syncthreads();                                                                                       \
-    if (!(B16_ABL & 1)) STORE_W();                                                                         \
-    if (B16_EARLY && more_chunks && s9 == 2) DMA_HALO(c + 1, 0, PA);                                        \
-    if (B16_EARLY && more_chunks && s9 == 5) DMA_HALO(c + 1, PA, PB);                                       \
-    if (halo_next) DMA_HALO(c + 1, B16_EARLY ? PB : 0, NDMA);                                               \
+    STORE_W();                                                                         \
+    if (halo_next) DMA_HALO(c + 1);                                                                        \
     MFMA_HALF(1, P_, 1, 0, 2);                                                                 \
     PIPE_WRITES(3, FN / 2);                                                                                     \
     SB();                                                                                                  \
     if (halo_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
     __syncthreads();                                                                                       \
-    if ((B16_ABL & 4) && halo_next) {                                                                      \
-      HALO_XFORM(c + 1);                                                                                   \
-      __syncthreads();                                                                                     \
-    }                                                                                                      \
     LOADA(0, akw[0] + ntap64, 0);                                                                          \
     LOADB((P_) ^ 1, wbuf);                                                                                 \
     MFMA_HALF(1, P_, 1, 2, 4);                                                                 \
@@ -402,7 +405,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
     /* ht3: second tap, half 1 -- every LDS read of this stage (and, in a chunk's last stage, of this chunk's halo) is complete */ \
     __syncthreads();                                                                                       \
     STORE_W();                                                                                             \
-    if (halo_next) DMA_HALO(c + 1, 0, NDMA);                                                               \
+    if (halo_next) DMA_HALO(c + 1);                                                               \
     MFMA_HALF(1, 1, 1, 0, 2);                                                                              \
     PIPE_WRITES(2, FN / 2);                                                                                \
     SB();                                                                                                  \
@@ -417,7 +420,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
     s9 = sn;                                                                                               \
   } while (0)
 
-  DMA_HALO(0, 0, NDMA);
+  DMA_HALO(0);
   LOAD_W(0, SID(0, 0), KWB(0));
   STORE_W();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -449,35 +452,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
 #undef PIPE_READS
 #undef PIPE_WRITES
 #undef DMA_HALO
-#undef HALO_XFORM
+#undef CHUNK_OFS
 #undef LOAD_W
 #undef STORE_W
 
-#if B16_ABL & 8
-  // B16_ABL bit 3 (timing only, wrong statistics): what taking the FIRST PASS OF THE NEXT BatchNorm BACKWARD in this epilogue would cost
-  // (the data gradient's output tile is that layer's da; its y tile comes through LDS-DMA into the free halo buffer, one 16 KiB region
-  // per wave = its d-plane as [voxel][64 channels], and every lane reads its 128 (voxel, channel) elements back as 2-byte LDS reads).
-  int opq = 0;
-  asm volatile("" : "+v"(opq));   // everything below depends on a value defined AFTER the main loop: nothing is hoisted into it
-  if (MODE == 0 && BN == 64) {
-    const char* ysrc = reinterpret_cast<const char*>(p.y) + opq;   // any tensor of the output's shape will do for the timing
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int fmv = i >> 1, wv = ((i & 1) << 3) + (lane >> 3);
-      const int64_t rowv = VOX(n, d0 + wid, h0 + fmv, w0 + wv);
-      lds_dma16(ysrc + ((rowv * p.Nc + n0) << 1) + ((lane & 7) << 4), lds_base + wid * 16384 + i * 1024);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  }
-  float s3[FN], s4[FN], csc[FN], csh[FN], cmu[FN], crs[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    s3[j] = s4[j] = 0.f;
-    const float* cf = reinterpret_cast<const float*>(p.w) + ((n0 + j * 16 + lr + opq) & 255);
-    csc[j] = cf[0]; csh[j] = cf[256]; cmu[j] = cf[512]; crs[j] = cf[768];
-  }
-#endif
   // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick).  acc[fm][j][r]: voxel (d0 + wid, h0 + fm,
   //      w0 + 4 lg + r), channel n0 + 16 j + lr ----
   float s1[FN], s2[FN], bv[FN];
@@ -505,39 +483,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const float val = acc[fm][j][r] + bv[j];
-#if B16_ABL & 16
-        if (MODE != 0 || BN != 64)   // bit 4 (timing only, wrong output): the plain mode's 64-channel tile is stored below as 16-byte pieces instead
-#endif
         p.y[row * ypitch + (UPCF ? uch0 : n0) + j * 16 + lr] = (bf16)val;
         s1[j] += val;
         s2[j] += val * val;
-#if B16_ABL & 8
-        if (MODE == 0 && BN == 64) {
-          const bf16 yb = *reinterpret_cast<const bf16*>(smem + wid * 16384 + (fm * 16 + lg * 4 + r) * 128 + (j * 16 + lr) * 2);
-          const float yv = (float)yb, g = (csc[j] * yv + csh[j] > 0.f) ? (float)(bf16)val : 0.f;
-          s3[j] += g;
-          s4[j] += g * (yv - cmu[j]) * crs[j];
-        }
-#endif
       }
     }
-#if B16_ABL & 8
-    __builtin_amdgcn_sched_barrier(0);   // keep one h line's LDS reads in flight at a time (hoisting all 128 spills 170 registers)
-#endif
-#if B16_ABL & 16
-    // bit 4: the same bytes as 16-byte, fully coalesced stores (what an LDS-transposed epilogue would issue: 16 instead of 128 store
-    // instructions per lane), fed with accumulator bits so that nothing is optimised away -- the upper bound of what such an epilogue can gain
-    if (MODE == 0 && BN == 64) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int i = fm * 2 + q, wv = ((i & 1) << 3) + (lane >> 3);
-        const int64_t rowv = VOX(n, d0 + wid, h0 + fm, w0 + wv);
-        u32x4 o;
-        o.x = __float_as_uint(acc[fm][0][q]); o.y = __float_as_uint(acc[fm][1][q]); o.z = __float_as_uint(acc[fm][2][q + 2]); o.w = __float_as_uint(acc[fm][3][q + 2]);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(p.y) + ((rowv * p.Nc + n0) << 1) + ((lane & 7) << 4)) = o;
-      }
-    }
-#endif
   }
   if (p.stats) {
     // one statistics row per 4-plane half of the brick: row numbering and summation order are those of the 4 x 8 x 16 brick for either NW
@@ -549,10 +499,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
       c2 += __shfl_xor(c2, 16, 64);
       a += __shfl_xor(a, 32, 64);
       c2 += __shfl_xor(c2, 32, 64);
-#if B16_ABL & 8
-      a += s3[j] * 1e-30f;      // keep the ablation's sums alive
-      c2 += s4[j] * 1e-30f;
-#endif
       if (lg == 0) {
         red[(wid * 64 + j * 16 + lr) * 2 + 0] = a;
         red[(wid * 64 + j * 16 + lr) * 2 + 1] = c2;
@@ -597,14 +543,16 @@ int brick16_perm(int D, int H, int W) {
 void pcrl_brick16_set(int on) { g_brick16_on = on; }
 void pcrl_brick16_set_planes(int mode) { g_brick16_planes = mode; }
 bool pcrl_brick16_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  return g_brick16_on && dtype == PCRL_BF16 && brick16_perm(D, H, W) != 0 && Ci % 32 == 0 && Co % 32 == 0 && (int64_t)N * D * H * W < ((int64_t)1 << 29);
+  // the halo plan addresses a brick's source rows by 32-bit offsets from its first halo voxel (up to ten planes of 2 Ci H W bytes), a weight row by a 32-bit offset
+  return g_brick16_on && dtype == PCRL_BF16 && brick16_perm(D, H, W) != 0 && Ci % 32 == 0 && Co % 32 == 0 && (int64_t)N * D * H * W < ((int64_t)1 << 29) &&
+         (int64_t)20 * Ci * H * W < ((int64_t)1 << 31) && (int64_t)54 * Ci * Co < ((int64_t)1 << 32);
 }
 int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W) { return (int64_t)N * D * H * W / (TD * TH * TW); }
 
 // p.D / p.H / p.W arrive as the volume's extents; perm == 2: handed to the PERM instantiation as the extents along the brick axes (D, W, H)
 template <int BN, int MODE, int NW = 4>
 static int launch16(Brick16Params p, dim3 grid, hipStream_t stream, const char* what) {
-  constexpr size_t lds = B16Geom<NW>::HALO_BYTES + 3 * BN * 64;
+  constexpr size_t lds = B16Geom<NW>::HALO_BYTES + 3 * BN * 64 + (NW == 4 ? 0 : 1024);   // NW = 8: + the halo plan's mask words
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 0, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
