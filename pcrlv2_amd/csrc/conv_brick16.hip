@@ -1,542 +1,9 @@
-// Wide-brick LDS-halo implicit-GEMM 3x3x3 convolution for gfx950, bf16 -- the throughput path of pcrl_conv3d_k3_fwd (forward and
-// data gradient) for volumes with D % 4 == 0, H % 8 == 0, W % 16 == 0 (the 64x64x32 and 32x32x16 levels and the 16^3 local views:
-// 80 % of the convolution FLOPs of a step).  conv_brick.hip (4x8x8 bricks) keeps the narrower volumes and the 2D path.
-//
-// Replaces aten::convolution / convolution_backward(input) of LUConv.conv1 (models/pcrlv2_model_3d.py:9,33).
-//
-// Why a second brick kernel: conv_brick.hip sits against the chip's power cap with the matrix pipe ~55 % busy; what moves it
-// is bytes moved per FLOP.  Here a block owns a 4 x 8 x 16 brick (512 output voxels) and a wave owns one d-plane of it, 128 voxels x BN
-// output channels:
-//   * LDS fragment reads per MFMA: 12 x ds_read_b128 per 32 MFMAs (8 A + 4 B) instead of 8 per 16                      (x 0.75)
-//   * staged bytes per MFMA: the 27 weight tiles of a 32-channel chunk (108 KiB) serve 512 voxels instead of 256, the halo is
-//     6 x 10 x 18 rows for 512 voxels (2.1x) instead of 6 x 10 x 10 for 256 (2.3x)                                    (x 0.6)
-//   * the halo goes global -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write_b128 (the slowest LDS
-//     instruction, 13 cycles per wave), no staging registers -- which is what lets a 128-accumulator wave keep two fragment sets in
-//     ping-pong at two waves per SIMD.
-// A-fragment rows are 16 CONSECUTIVE w positions of one (d, h) line, so the halo keeps its natural w pitch of 18 rows; the 16-byte slot
-// of a row is XOR-ed with a key that depends only on the row's w position (the d, h tap offsets are multiples of the pitch, so a lane's
-// three kw addresses are computed once): key = 2 for w in {4,5,10..15}, else 0 -- found by exhaustive search over gfx950's
-// ds_read_b128 lane groups ({0-3,12-15,20-27}, ...) for both parities of the line index; conflict-free for every tap.  LDS-DMA writes
-// lane-linear, so the swizzle is applied to the SOURCE address (lane (row, physical slot s) loads logical slot s ^ key(row)).
-// Halo rows outside the volume are loaded from a 16-byte zero page.
-//
-// Measured (timing ablations, same box, 128 -> 64 channels at 64x64x32): without the halo requests after the first chunk -17 %, without the
-// weight staging -13 %, without both -22 % (1 560 TFLOP/s); requesting the dead planes early changes nothing.  What is left on the
-// table is bytes staged per MFMA, not latency.  (Also tried: weight fragments straight from global memory into registers, no weight stage
-// in LDS and no per-stage barriers -- 16 x 64-byte segments per load instruction, L1 / address-path bound: -30 %.)
-// The epilogue (128 two-byte stores per lane) costs 7 % (64 -> 64 channels) to 16 % (32 -> 64: one K chunk per block) by the same kind of
-// ablation; storing 4-byte channel pairs after a lane-pair exchange (64 stores, 2 DPP moves and 6 selects per fragment) measured equal
-// or 3 % worse, 8-byte quads through a transposed accumulator layout 4 % worse (spills): the stores stay as they are.
-// Composed modes: sourcing the halo planes a phase / parity never reads (one of T + 2 per axis, 30 % of the rows) from the zero page instead of
-// the tensor measured 4 % SLOWER (960 -> 915 TFLOP/s), and not requesting them at all (exec-masked lanes; rows outside the volume zeroed once per
-// block instead of read from the zero page) 1-2 % slower than the plain request, in every mode: what the halo request costs is its issue
-// (address arithmetic per piece at the chunk boundary), not the bytes -- the full halo is requested, branch-free.
-//
-// LDS: halo 68 KiB (single buffer: 1080 rows x 64 B, rounded up to whole 1 KiB DMA pieces) + one weight stage 12 KiB = 80 KiB -> two
-// blocks (eight waves) per CU.  The next chunk's halo is requested as soon as every wave holds the last fragments of the current one
-// (first barrier of the chunk's last stage) and lands under that stage's remaining MFMAs and the co-resident block's work.
-#include "common.h"
-#include <atomic>
-#include <mutex>
+// Plain 3x3x3 instantiations of the wide-brick convolution kernel (conv_brick16.h) and the dispatcher's interface to them.
+#include "conv_brick16.h"
 
 namespace {
-
-constexpr int TD = 4, TH = 8, TW = 16;
-constexpr int HH = TH + 2, HP = TW + 2;                // halo extents in h, w; w pitch = natural 18
-// NW = waves per block = d-planes per brick: 4 (4 x 8 x 16 bricks, two blocks per CU) or 8 (8 x 8 x 16 bricks, one block of eight waves per CU:
-// the 27 weight tiles of a chunk serve 1024 voxels and the halo is 10 / 8 instead of 6 / 4 planes per output plane -- 33 instead of 52 staged
-// bytes per MFMA; see pcrl_brick16_conv_launch for where it is used)
-template <int NW> struct B16Geom {
-  static constexpr int HD = NW + 2;
-  static constexpr int ROWS = HD * HH * HP;            // 1080 / 1800 rows of 64 B
-  static constexpr int NDMA = (ROWS + 15) / 16;        // 68 / 113 wave-instructions of 16 rows (1 KiB)
-  static constexpr int HALO_BYTES = NDMA * 1024;       // 69632 / 115712
-  static constexpr int PPW = (NDMA + NW - 1) / NW;     // pieces per wave: 17 / 15
-};
-constexpr int NS = 9;                                  // stages per chunk: (kd, kh); a stage = three kw taps
-
-
-struct Brick16Params {
-  const bf16* x;
-  const bf16* w;      // packed [Nc][27][K]
-  const float* bias;
-  bf16* y;
-  float* stats;       // [bricks][Nc][2] or null
-  int N, D, H, W;
-  int K, Nc;
-  int ny;             // > 0: 1-D grid of bricks x ny ids (channel tiles of a brick on one XCD, see conv_brick.hip); 0: 2-D grid
-  // UPCF instantiations only (forward of the composed ConvTranspose3d -> Conv3d operator, upconv_fused.hip): x is the COARSE tensor, the
-  // Nc = 8 * upc output channels are 8 phases x upc channels, w the zero-embedded 3x3x3 weights [8 * upc][27][K] in which a phase holds
-  // its 2 x 2 x 2 taps at (p + q) per axis.  A block (one 64-channel tile = one phase, or part of one) walks only the 4 of 9 (kd, kh) stages
-  // its phase uses, each with the two kw taps in use (STAGE2: the unused tap is neither staged nor read; 900 -> 960 TFLOP/s), writes its voxels to the phase's FINE positions of y [N][2D][2H][2W][upc]
-  // and adds bias_tab[border class of the fine voxel][channel]; the statistics rows are [bricks][8 * upc][2] = [bricks * 8][upc][2].
-  int upc;
-  const float* bias_tab;
-  // MODE 2 (data gradient of the composed operator): x is the FINE gradient dy0 [N][2D][2H][2W][upc] read as its space-to-depth view on the
-  // coarse grid, K = 8 * upc channels = 8 parities x upc (chunk c of 32 channels lies in parity c >> cshift, cshift = log2(upc / 32)); w the
-  // zero-embedded 3x3x3 weights [Nc = Ci][27][8 * upc] in which parity `par` holds the taps e = 2 k - 1 + par per axis (dx[v] = sum_e
-  // dy0[2 v + e - 1] wd[e]: parity 0 uses k in {1, 2}, parity 1 uses k in {0, 1}).  A chunk walks the 4 of 9 (kd, kh) stages and the two kw
-  // taps of ITS parity; the output is an ordinary coarse tensor [N][D][H][W][Nc].
-  int cshift;
-};
-
-__device__ __forceinline__ int key_w(int hw) { return ((0xFC30 >> hw) & 1) << 1; }   // hw in [0, 18)
-// weight tile [BN co][32 k]: fragment reads take 16 consecutive rows from a 16-aligned row (same swizzle as conv_brick.hip)
-__device__ __forceinline__ int woff(int row, int slot) {
-  const int key = (0x78 >> (((row >> 2) & 3) * 2)) & 3;
-  return row * 64 + ((slot ^ key) << 4);
-}
-
-// One LDS-DMA request of the halo: the lanes whose bit 0 of `okmask` is set load 16 bytes from `base` + `voff` (SGPR base + 32-bit
-// unsigned lane offset) to LDS byte address `lds_dst` (wave-uniform) + 16 * lane; the other lanes request nothing (their LDS rows were
-// zeroed once per block).  EXEC is narrowed by v_cmpx and restored from `exec_all` inside the statement; M0 carries the destination.
-// Issued from inline asm because hipcc waits vmcnt(0) before the next barrier / LDS access behind the builtin (it cannot prove they do
-// not touch the DMA's destination), which would expose the latency of the requests; completion is counted by hand (s_waitcnt vmcnt(0)
-// at the end of the chunk; the compiler's own counted waits for the weight loads can only over-wait, vmcnt retires in order).
-// `okmask` and `chain` pass through as read-write operands: the address arithmetic of the NEXT piece (which starts from them) cannot be scheduled
-// in front of this request, so a wave never holds more than one piece's temporaries (17 pieces' worth spilled 47 registers).
-__device__ __forceinline__ void lds_dma16_masked(uint64_t base, uint32_t voff, uint32_t& okmask, uint32_t& chain, uint32_t lds_dst, uint64_t exec_all) {
-  uint32_t t;
-  asm volatile("v_and_b32 %0, 1, %1\n\tv_cmpx_ne_u32_e32 0, %0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\ts_mov_b64 exec, %6"
-               : "=&v"(t), "+v"(okmask), "+v"(chain)
-               : "v"(voff), "s"(lds_dst), "s"(base), "s"(exec_all)
-               : "memory", "vcc");
-}
-
-// MODE 0: 3x3x3 convolution; 1: composed up-conv forward; 2: composed up-conv data gradient (Brick16Params).
-// PERM 1: the brick's (d, h, w) axes run along the volume's (D, W, H) -- p.D, p.H, p.W are then the extents along the BRICK axes (D, W, H of the
-// volume) -- for volumes whose H, not W, is a multiple of 16 (the 16 x 16 x 8 level).  A convolution commutes with a permutation of the axes
-// applied to volume, taps and phases alike: only the voxel index (VOX / FVOX), the tap number of a weight row (WTAP), the phase / parity bit of
-// an axis (BITH / BITW) and the border class (CLS) know the difference; rows still go through LDS one 64-byte slice per voxel.
-template <int BN, int MODE = 0, int PERM = 0, int NW = 4>
-__global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(const Brick16Params p) {
-  using G = B16Geom<NW>;
-  constexpr int ROWS = G::ROWS, NDMA = G::NDMA, HALO_BYTES = G::HALO_BYTES;
-  constexpr int FN = BN / 16;
-  constexpr bool UPCF = MODE == 1, UPCD = MODE == 2;
-  constexpr int NSK = MODE ? 4 : NS;   // stages per chunk
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* halo = smem;
-  char* wbuf = smem + HALO_BYTES;
-
-  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lr = lane & 15, lg = lane >> 4;
-  const int K = p.K, nchunk = K / 32;
-
-  // ---- brick origin (XCD-contiguous brick ranges; the channel tiles of a brick adjacent on one XCD) ----
-  const int bw = p.W / TW, bh = p.H / TH, bd = p.D / NW;
-  int b = blockIdx.x, ytile = blockIdx.y;
-  if (p.ny > 0) {
-    const int nbr = gridDim.x / p.ny;
-    if ((nbr & 7) == 0) {
-      const int slot = b >> 3;
-      ytile = slot % p.ny;
-      b = (b & 7) * (nbr >> 3) + slot / p.ny;
-    } else {
-      ytile = b % p.ny;
-      b = b / p.ny;
-    }
-  } else if ((gridDim.x & 7) == 0) {
-    b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
-  }
-  const int n0 = ytile * BN;
-#define BITD(x_) (((x_) >> 2) & 1)
-#define BITH(x_) (PERM ? ((x_)&1) : (((x_) >> 1) & 1))      /* bit of the volume axis the brick's h axis runs along */
-#define BITW(x_) (PERM ? (((x_) >> 1) & 1) : ((x_)&1))
-#define VOX(n_, d_, h_, w_) (PERM ? (((int64_t)(n_)*p.D + (d_)) * p.W + (w_)) * p.H + (h_) : (((int64_t)(n_)*p.D + (d_)) * p.H + (h_)) * p.W + (w_))
-#define FVOX(n_, d_, h_, w_) (PERM ? (((int64_t)(n_) * (2 * p.D) + (d_)) * (2 * p.W) + (w_)) * (2 * p.H) + (h_) \
-                                   : (((int64_t)(n_) * (2 * p.D) + (d_)) * (2 * p.H) + (h_)) * (2 * p.W) + (w_))
-#define WTAP(s9_, j_) (PERM ? ((s9_) / 3) * 9 + (j_)*3 + (s9_) % 3 : (s9_)*3 + (j_))   /* (kd, kh, kw) of the brick -> tap number of the volume */
-  const int uph = UPCF ? n0 / p.upc : 0, ukd0 = BITD(uph), ukh0 = BITH(uph);
-  // stage number -> (kd * 3 + kh).  UPCF: the block's phase uses k = p, p + 1 per axis; UPCD: chunk c's parity uses k = 1 - par, 2 - par.
-#define PARC(c_) ((c_) >> p.cshift)
-#define SID(c_, s_) (MODE == 0 ? (s_) : MODE == 1 ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) \
-                                                 : ((1 - BITD(PARC(c_)) + ((s_) >> 1)) * 3 + 1 - BITH(PARC(c_)) + ((s_)&1)))
-#define KWB(c_) (MODE == 0 ? 0 : MODE == 1 ? BITW(uph) : 1 - BITW(PARC(c_)))   /* first of the kw taps in use (composed modes: two, the third tap's weights are zero) */
-  const int brick_lin = b;   // NW == 4: the statistics row of this brick (kept instead of re-derived in the epilogue: seven fewer live scalars)
-  const int w0 = (b % bw) * TW; b /= bw;
-  const int h0 = (b % bh) * TH; b /= bh;
-  const int d0 = (b % bd) * NW; b /= bd;
-  const int n = b;
-
-  // ---- halo DMA: wave `wid` issues pieces wid, wid + NW, ...; a piece = 16 rows (1 KiB), lane -> (row = piece * 16 + lane / 4, physical slot
-  //      lane & 3).  Round 5 (profiles/r05_b16_isa_mix.txt): the per-piece source address used to be recomputed from the row number at every
-  //      chunk boundary -- two divisions, three range checks, a 64-bit voxel index and a branch around it: ~65 instructions per piece with
-  //      ten quarter-rate multiplies, 17 pieces per wave, i.e. ~1 100 instructions (~6 000 cycles) per chunk in front of the chunk's 864 (plain)
-  //      or 256 (composed) MFMAs per wave.  Now the block's PLAN is made once: the source is (SGPR base of the halo's first voxel) + a 32-bit
-  //      lane offset that advances from piece to piece by C1 + wrap * C2 + plane * C3 (a piece stride is 16 * NW rows = QL lines + a few rows of
-  //      the 18-row line pitch: `wrap` = the lane's row crossed one more line end, `plane` = its line crossed a plane end), the two bits per
-  //      piece and lane, the swizzle key of the row and "row inside the volume" live in three mask registers, rows outside the volume are
-  //      zeroed ONCE and never requested (EXEC-masked request), and a chunk only adds its channel offset: ~14 instructions per piece. ----
-  constexpr int PPW = G::PPW;
-  constexpr int RSTEP = 16 * NW, QL = RSTEP / HP;                 // rows / whole lines between two pieces of a wave
-  static_assert(PPW <= 17 && RSTEP - QL * HP < HP, "plan masks hold 16 steps; at most one line wrap per step");
-  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  // byte strides of the source along the brick's w (row), h (line), d (plane) axes; the byte offset of chunk c_
-  int RS, LS, PS;
-  if (UPCD) {   // the fine gradient read as its space-to-depth view on the coarse grid: coarse steps are two fine voxels
-    const int v2 = 4 * p.upc;
-    RS = PERM ? v2 * (2 * p.H) : v2;
-    LS = PERM ? v2 : v2 * (2 * p.W);
-    PS = v2 * (2 * p.H) * (2 * p.W);
-  } else {
-    RS = PERM ? 2 * K * p.H : 2 * K;
-    LS = PERM ? 2 * K : 2 * K * p.W;
-    PS = 2 * K * p.H * p.W;
-  }
-  const int C1 = QL * LS + (RSTEP - QL * HP) * RS, C2 = LS - HP * RS, C3 = PS - HH * LS;   // |C2|, |C3| < 2^23 (eligibility): 24-bit multiply-adds
-#define CHUNK_OFS(c_) (UPCD ? (uint32_t)(((BITD(PARC(c_)) * (2 * p.H) * (2 * p.W) + (PERM ? BITW(PARC(c_)) * (2 * p.H) + BITH(PARC(c_)) \
-                                                                                       : BITH(PARC(c_)) * (2 * p.W) + BITW(PARC(c_)))) * p.upc \
-                                          + ((c_) - (PARC(c_) << p.cshift)) * 32) * 2)                                               \
-                            : (uint32_t)(c_) * 64u)
-  // SGPR base: the halo's first voxel (d0 - 1, h0 - 1, w0 - 1) of sample n -- may lie in front of the tensor; only rows inside the volume are requested
-  const uint64_t hbase = (uint64_t)(uintptr_t)p.x + (UPCD ? (uint64_t)(FVOX(n, 2 * (d0 - 1), 2 * (h0 - 1), 2 * (w0 - 1)) * (int64_t)(2 * p.upc))
-                                                        : (uint64_t)(VOX(n, d0 - 1, h0 - 1, w0 - 1) * (int64_t)(2 * K)));
-  // the plan: hoff0 = piece 0's offset (bit 0: piece 0 inside the volume -- offsets are multiples of 16); m_step: bit i - 1 = wrap, bit 15 + i =
-  // plane of the step into piece i; m_ko: bit i - 1 = piece i inside the volume, bit 15 + i = key of piece i XOR key of piece 0
-  uint32_t hoff0 = 0, m_step = 0, m_ko = 0;
-  {
-    int prevL = 0, prevP = 0, key0 = 0;
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-      const int piece = wid + NW * i, row = piece * 16 + (lane >> 2);
-      const int L = row / HP, hw = row - L * HP, P = L / HH, hh = L - P * HH;
-      const int d = d0 + P - 1, h = h0 + hh - 1, w = w0 + hw - 1;
-      const bool ok = row < ROWS && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-      const int key = key_w(hw) >> 1;
-      if (i == 0) {
-        hoff0 = (uint32_t)(P * PS + hh * LS + hw * RS + (((lane & 3) ^ (key << 1)) << 4)) | (ok ? 1u : 0u);
-        key0 = key;
-      } else {
-        m_step |= (uint32_t)(L - prevL - QL) << (i - 1);
-        m_step |= (uint32_t)(P - prevP) << (15 + i);
-        m_ko |= (ok ? 1u : 0u) << (i - 1);
-        m_ko |= (uint32_t)(key ^ key0) << (15 + i);
-      }
-      prevL = L;
-      prevP = P;
-      // rows of the halo outside the volume: zero for the block's lifetime
-      if (!ok && piece < NDMA) *reinterpret_cast<u32x4*>(halo + piece * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
-    }
-  }
-  // The two mask words depend on (wave, lane / 4) only and are needed once per chunk: they wait in LDS -- NW = 4: the 512 bytes behind the halo's
-  // last row (1080 rows of the 1088 its 68 pieces span: the request of rows 1080.. is masked off); NW = 8: behind the weight stage -- instead of
-  // occupying two registers across the stage loop (the allocator spilled fragment addresses for them: three scratch reloads per two stages).
-  uint2* plan_lds = reinterpret_cast<uint2*>(smem + (NW == 4 ? ROWS * 64 : HALO_BYTES + 3 * BN * 64)) + wid * 16 + (lane >> 2);
-  *plan_lds = uint2{m_step, m_ko};
-  asm volatile("" : "+v"(hoff0));   // nothing of the plan is re-derived inside the loop
-  const uint64_t exec_all = __builtin_amdgcn_read_exec();
-  // The pieces are a ROLLED loop (scalar counter, variable shifts): 17 unrolled copies per stage body made the stage one scheduling region of
-  // ~1 000 instructions, and the allocator spilled the fragment addresses of the stage loop for it.
-#define DMA_HALO(c_)                                                                                       \
-  do {                                                                                                     \
-    uint32_t hoff = (hoff0 & ~15u) + CHUNK_OFS(c_), m0keep;                                                \
-    const uint2 plan_ = *plan_lds;                                                                         \
-    uint32_t m_step = plan_.x, m_ko = plan_.y;   /* shifted right by one per piece: the bits of the next step sit at positions 0 and 16 */ \
-    asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep), "+v"(m_step), "+v"(m_ko));                             \
-    uint32_t dst = lds_base + wid * 1024;                                                                  \
-    lds_dma16_masked(hbase, hoff, hoff0, m_step, dst, exec_all);                                           \
-    _Pragma("unroll 1") for (int i = 1; i < PPW; ++i) {                                                    \
-      const int t1 = __builtin_amdgcn_sbfe(m_step, 0, 1), t2 = __builtin_amdgcn_sbfe(m_step, 16, 1);  /* 0 / -1 */ \
-      hoff += (uint32_t)((t1 & C2) + (t2 & C3) + C1);                                                      \
-      const uint32_t ha = hoff ^ ((m_ko >> 11) & 32u);                                                     \
-      dst += NW * 1024;                                                                                    \
-      lds_dma16_masked(hbase, ha, m_ko, m_step, dst, exec_all);                                            \
-      m_step >>= 1;                                                                                        \
-      m_ko >>= 1;                                                                                          \
-    }                                                                                                      \
-    asm volatile("s_mov_b32 m0, %0" ::"s"(m0keep));                                                        \
-  } while (0)
-
-  // ---- weight staging through registers: 3 pieces per thread (taps kw = 0,1,2 of the stage), row co = tid >> 2, slot tid & 3 ----
-  const bool wthread = NW * 16 <= BN || (tid >> 2) < BN;   // compile-time true for four waves x 64 channels: no exec mask around the weight stores
-  const uint32_t wlane = (uint32_t)(((n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8) * 2u;   // byte offset of the thread's weight row (weights < 4 GiB: eligibility)
-  const int wdst = woff(tid >> 2, tid & 3);
-  u32x4 rw[3];
-  constexpr int NKW = MODE ? 2 : 3;   // kw taps per stage: the composed modes stage and multiply only the two taps their phase / parity uses
-#define LOAD_W(c_, s9_, kwb_) /* taps kwb_ .. kwb_ + NKW - 1 of stage (kd, kh) */                          \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < NKW; ++j)                                                        \
-      rw[j] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(p.w) + (int64_t)(WTAP(s9_, (kwb_) + j) * K + (c_)*32) * 2 + wlane); \
-  } while (0)
-#define STORE_W()                                                                                          \
-  do {                                                                                                     \
-    if (wthread) {                                                                                         \
-      _Pragma("unroll") for (int j = 0; j < NKW; ++j)                                                      \
-        *reinterpret_cast<u32x4*>(wbuf + j * (BN * 64) + wdst) = rw[j];                                    \
-    }                                                                                                      \
-  } while (0)
-
-  f32x4 acc[8][FN];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // Fragment addressing: wave = d-plane `wid`; fragment fm = h line fm, rows = 16 consecutive w.  Row of tap (kd,kh,kw):
-  // ((wid + kd) * HH + fm + kh) * HP + lr + kw; the key depends on lr + kw only -> three lane offsets, (kd,kh) and fm are adds.
-  int akw[3];
-#pragma unroll
-  for (int kw = 0; kw < 3; ++kw) akw[kw] = ((wid * HH) * HP + lr + kw) * 64 + ((lg ^ key_w(lr + kw)) << 4);
-  const int bofs = woff(lr, lg);
-
-  bf16x8 fa[2][4], fb[2][FN];
-#define LOADA(S_, aoff_, half_)                                                                            \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
-      fa[S_][q] = *reinterpret_cast<const bf16x8*>(halo + (aoff_) + ((half_)*4 + q) * (HP * 64));          \
-  } while (0)
-#define LOADB(S_, wt_)                                                                                     \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                         \
-      fb[S_][j] = *reinterpret_cast<const bf16x8*>((wt_) + bofs + j * 1024);                               \
-  } while (0)
-#define MFMA_HALF(SA_, SB_, half_, Q0_, Q1_)                                                               \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int q = (Q0_); q < (Q1_); ++q)                                                  \
-      _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                       \
-        acc[(half_)*4 + q][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[SA_][q], fb[SB_][j], acc[(half_)*4 + q][j], 0, 0, 0); \
-  } while (0)
-#define PIPE_READS(n_, m_)                                                                                 \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int q = 0; q < (n_); ++q) {                                                     \
-      __builtin_amdgcn_sched_group_barrier(0x008, (m_), 0);                                                \
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
-    }                                                                                                      \
-  } while (0)
-#define PIPE_WRITES(n_, m_)                                                                                \
-  do {                                                                                                     \
-    _Pragma("unroll") for (int q = 0; q < (n_); ++q) {                                                     \
-      __builtin_amdgcn_sched_group_barrier(0x008, (m_), 0);                                                \
-      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);                                                   \
-    }                                                                                                      \
-  } while (0)
-#define SB() __builtin_amdgcn_sched_barrier(0)
-
-  // One stage = six half-taps (kw = 0,1,2 x voxel halves 0,1), 16 MFMAs each.  A sets alternate per half-tap (fa[0] = half 0,
-  // fa[1] = half 1); B sets alternate per tap: P = the set that holds kw = 0 on entry (a stage has three taps, so P flips per stage).
-  // The two barriers of a stage sit inside the LAST half-tap, whose operands are in registers: the next stage's weights are stored,
-  // the next chunk's halo requested and the first fragments of the next stage read under its MFMAs.
-  int c = 0, s9 = 0;
-#define STAGE(P_)                                                                                          \
-  do {                                                                                                     \
-    int cn = c, sn = s9 + 1;                                                                               \
-    if (sn == NSK) { sn = 0; cn = c + 1; }                                                                 \
-    const bool last = (cn == nchunk);                                                                      \
-    if (last) { cn = c; sn = s9; }                                                                         \
-    LOAD_W(cn, SID(cn, sn), 0);                                                        \
-    const bool halo_next = (s9 == NSK - 1) && !last; /* block-uniform */                                   \
-    const int tap64 = ((SID(c, s9) / 3) * HH + (SID(c, s9) % 3)) * (HP * 64);                              \
-    const int ntap64 = ((SID(cn, sn) / 3) * HH + (SID(cn, sn) % 3)) * (HP * 64);                           \
-    /* ht0: kw 0, half 0 */                                                                                \
-    LOADA(1, akw[0] + tap64, 1);                                                                           \
-    MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
-    PIPE_READS(4, FN);                                                                                     \
-    SB();                                                                                                  \
-    /* ht1: kw 0, half 1 */                                                                                \
-    LOADA(0, akw[1] + tap64, 0);                                                                           \
-    LOADB((P_) ^ 1, wbuf + 1 * (BN * 64));                                                                 \
-    MFMA_HALF(1, P_, 1, 0, 4);                                                                 \
-    PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
-    SB();                                                                                                  \
-    /* ht2: kw 1, half 0 */                                                                                \
-    LOADA(1, akw[1] + tap64, 1);                                                                           \
-    MFMA_HALF(0, (P_) ^ 1, 0, 0, 4);                                                                       \
-    PIPE_READS(4, FN);                                                                                     \
-    SB();                                                                                                  \
-    /* ht3: kw 1, half 1 */                                                                                \
-    LOADA(0, akw[2] + tap64, 0);                                                                           \
-    LOADB(P_, wbuf + 2 * (BN * 64));                                                                       \
-    MFMA_HALF(1, (P_) ^ 1, 1, 0, 4);                                                                       \
-    PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                                     \
-    SB();                                                                                                  \
-    /* ht4: kw 2, half 0 */                                                                                \
-    LOADA(1, akw[2] + tap64, 1);                                                                           \
-    MFMA_HALF(0, P_, 0, 0, 4);                                                                 \
-    PIPE_READS(4, FN);                                                                                     \
-    SB();                                                                                                  \
-    /* ht5: kw 2, half 1 -- every LDS read of this stage (and, in a chunk's last stage, of this chunk's halo) is complete */ \
-    __syncthreads();                                                                                       \
-    STORE_W();                                                                         \
-    if (halo_next) DMA_HALO(c + 1);                                                                        \
-    MFMA_HALF(1, P_, 1, 0, 2);                                                                 \
-    PIPE_WRITES(3, FN / 2);                                                                                     \
-    SB();                                                                                                  \
-    if (halo_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
-    __syncthreads();                                                                                       \
-    LOADA(0, akw[0] + ntap64, 0);                                                                          \
-    LOADB((P_) ^ 1, wbuf);                                                                                 \
-    MFMA_HALF(1, P_, 1, 2, 4);                                                                 \
-    PIPE_READS(4 + FN, 1);                                                                                 \
-    SB();                                                                                                  \
-    c = cn;                                                                                                \
-    s9 = sn;                                                                                               \
-  } while (0)
-
-  // Composed modes: a stage = the TWO kw taps in use (four half-taps); same pipeline, the B sets no longer flip between stages.
-#define STAGE2()                                                                                           \
-  do {                                                                                                     \
-    int cn = c, sn = s9 + 1;                                                                               \
-    if (sn == NSK) { sn = 0; cn = c + 1; }                                                                 \
-    const bool last = (cn == nchunk);                                                                      \
-    if (last) { cn = c; sn = s9; }                                                                         \
-    const int kwb = KWB(c), kwbn = KWB(cn);                                                                \
-    LOAD_W(cn, SID(cn, sn), kwbn);                                                                         \
-    const bool halo_next = (s9 == NSK - 1) && !last; /* block-uniform */                                   \
-    const int tap64 = ((SID(c, s9) / 3) * HH + (SID(c, s9) % 3)) * (HP * 64);                              \
-    const int ntap64 = ((SID(cn, sn) / 3) * HH + (SID(cn, sn) % 3)) * (HP * 64);                           \
-    const int a0 = kwb ? akw[1] : akw[0], a1 = kwb ? akw[2] : akw[1], an0 = kwbn ? akw[1] : akw[0];        \
-    /* ht0: first tap, half 0 */                                                                           \
-    LOADA(1, a0 + tap64, 1);                                                                               \
-    MFMA_HALF(0, 0, 0, 0, 4);                                                                              \
-    PIPE_READS(4, FN);                                                                                     \
-    SB();                                                                                                  \
-    /* ht1: first tap, half 1 */                                                                           \
-    LOADA(0, a1 + tap64, 0);                                                                               \
-    LOADB(1, wbuf + 1 * (BN * 64));                                                                        \
-    MFMA_HALF(1, 0, 1, 0, 4);                                                                              \
-    PIPE_READS(4 + FN, (4 * FN) / (4 + FN));                                                               \
-    SB();                                                                                                  \
-    /* ht2: second tap, half 0 */                                                                          \
-    LOADA(1, a1 + tap64, 1);                                                                               \
-    MFMA_HALF(0, 1, 0, 0, 4);                                                                              \
-    PIPE_READS(4, FN);                                                                                     \
-    SB();                                                                                                  \
-    /* ht3: second tap, half 1 -- every LDS read of this stage (and, in a chunk's last stage, of this chunk's halo) is complete */ \
-    __syncthreads();                                                                                       \
-    STORE_W();                                                                                             \
-    if (halo_next) DMA_HALO(c + 1);                                                               \
-    MFMA_HALF(1, 1, 1, 0, 2);                                                                              \
-    PIPE_WRITES(2, FN / 2);                                                                                \
-    SB();                                                                                                  \
-    if (halo_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                        \
-    __syncthreads();                                                                                       \
-    LOADA(0, an0 + ntap64, 0);                                                                             \
-    LOADB(0, wbuf);                                                                                        \
-    MFMA_HALF(1, 1, 1, 2, 4);                                                                              \
-    PIPE_READS(4 + FN, 1);                                                                                 \
-    SB();                                                                                                  \
-    c = cn;                                                                                                \
-    s9 = sn;                                                                                               \
-  } while (0)
-
-  DMA_HALO(0);
-  LOAD_W(0, SID(0, 0), KWB(0));
-  STORE_W();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  LOADA(0, (KWB(0) ? akw[1] : akw[0]) + ((SID(0, 0) / 3) * HH + (SID(0, 0) % 3)) * (HP * 64), 0);
-  LOADB(0, wbuf);
-
-  const int nstage = NSK * nchunk;
-  if constexpr (MODE == 0) {
-    for (int S = 0; S + 1 < nstage; S += 2) {
-      STAGE(0);
-      STAGE(1);
-    }
-    if (nstage & 1) STAGE(0);
-  } else {
-    for (int S = 0; S < nstage; ++S) STAGE2();
-  }
-  __syncthreads();   // the epilogue reuses the LDS
-#undef STAGE
-#undef STAGE2
-#undef SID
-#undef PARC
-#undef KWB
-#undef WTAP
-#undef SB
-#undef MFMA_HALF
-#undef LOADA
-#undef LOADB
-#undef PIPE_READS
-#undef PIPE_WRITES
-#undef DMA_HALO
-#undef CHUNK_OFS
-#undef LOAD_W
-#undef STORE_W
-
-  // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick).  acc[fm][j][r]: voxel (d0 + wid, h0 + fm,
-  //      w0 + 4 lg + r), channel n0 + 16 j + lr ----
-  float s1[FN], s2[FN], bv[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    s1[j] = 0.f;
-    s2[j] = 0.f;
-    bv[j] = (!UPCF && p.bias) ? p.bias[n0 + j * 16 + lr] : 0.f;
-  }
-  const int uch0 = UPCF ? n0 - uph * p.upc : 0;                       // first channel of this tile inside its phase
-  const int ypitch = UPCF ? p.upc : p.Nc;
-#pragma unroll
-  for (int fm = 0; fm < 8; ++fm) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      int64_t row = VOX(n, d0 + wid, h0 + fm, w0 + lg * 4 + r);
-      if (UPCF) {   // the phase's fine voxel, and the bias of its border class (0 first, 1 inside, 2 last per axis; class number in volume order)
-        const int fd = 2 * (d0 + wid) + BITD(uph), fh = 2 * (h0 + fm) + BITH(uph), fw = 2 * (w0 + lg * 4 + r) + BITW(uph);
-        row = FVOX(n, fd, fh, fw);
-        const int cd = fd == 0 ? 0 : (fd == 2 * p.D - 1 ? 2 : 1), ch = fh == 0 ? 0 : (fh == 2 * p.H - 1 ? 2 : 1), cw = fw == 0 ? 0 : (fw == 2 * p.W - 1 ? 2 : 1);
-        const int cls = PERM ? (cd * 3 + cw) * 3 + ch : (cd * 3 + ch) * 3 + cw;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bv[j] = p.bias_tab[cls * p.upc + uch0 + j * 16 + lr];
-      }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const float val = acc[fm][j][r] + bv[j];
-        p.y[row * ypitch + (UPCF ? uch0 : n0) + j * 16 + lr] = (bf16)val;
-        s1[j] += val;
-        s2[j] += val * val;
-      }
-    }
-  }
-  if (p.stats) {
-    // one statistics row per 4-plane half of the brick: row numbering and summation order are those of the 4 x 8 x 16 brick for either NW
-    float* red = reinterpret_cast<float*>(smem);  // [NW waves][64 ch][2]; the loop ended with a barrier
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      float a = s1[j], c2 = s2[j];
-      a += __shfl_xor(a, 16, 64);
-      c2 += __shfl_xor(c2, 16, 64);
-      a += __shfl_xor(a, 32, 64);
-      c2 += __shfl_xor(c2, 32, 64);
-      if (lg == 0) {
-        red[(wid * 64 + j * 16 + lr) * 2 + 0] = a;
-        red[(wid * 64 + j * 16 + lr) * 2 + 1] = c2;
-      }
-    }
-    __syncthreads();
-    const int half = tid >> 6, ch = tid & 63;
-    if (half < NW / 4 && ch < BN) {
-      float a = 0.f, c2 = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a += red[((half * 4 + q) * 64 + ch) * 2 + 0];
-        c2 += red[((half * 4 + q) * 64 + ch) * 2 + 1];
-      }
-      const int64_t brick_id = NW == 4 ? (int64_t)brick_lin : (((int64_t)n * (p.D / 4) + (d0 >> 2) + half) * bh + h0 / TH) * bw + w0 / TW;
-      float* o = p.stats + (brick_id * p.Nc + n0 + ch) * 2;
-      o[0] = a;
-      o[1] = c2;
-    }
-  }
-}
-
-#undef BITD
-#undef BITH
-#undef BITW
-#undef VOX
-#undef FVOX
-
 std::atomic<int> g_brick16_on{1};
 std::atomic<int> g_brick16_planes{-1};   // -1: PCRL_B16_NW8 / the default rule; 0: 4-plane bricks only; 2: 8-plane bricks wherever they tile
-// 0: no brick tiling; 1: (4, 8, 16) bricks along (D, H, W); 2: along (D, W, H) (PERM instantiations)
-int brick16_perm(int D, int H, int W) {
-  if (D % TD == 0 && H % TH == 0 && W % TW == 0) return 1;
-  static const bool perm_on = [] { const char* e = getenv("PCRL_B16_PERM"); return !(e && e[0] == '0'); }();   // A/B switch
-  if (perm_on && D % TD == 0 && W % TH == 0 && H % TW == 0) return 2;
-  return 0;
-}
-
 }  // namespace
 
 // ---- internal interface used by conv_igemm.hip's dispatcher -------------------------------------------------------
@@ -548,24 +15,6 @@ bool pcrl_brick16_conv_eligible(int N, int D, int H, int W, int Ci, int Co, int 
          (int64_t)20 * Ci * H * W < ((int64_t)1 << 31) && (int64_t)54 * Ci * Co < ((int64_t)1 << 32);
 }
 int64_t pcrl_brick16_conv_rows(int N, int D, int H, int W) { return (int64_t)N * D * H * W / (TD * TH * TW); }
-
-// p.D / p.H / p.W arrive as the volume's extents; perm == 2: handed to the PERM instantiation as the extents along the brick axes (D, W, H)
-template <int BN, int MODE, int NW = 4>
-static int launch16(Brick16Params p, dim3 grid, hipStream_t stream, const char* what) {
-  constexpr size_t lds = B16Geom<NW>::HALO_BYTES + 3 * BN * 64 + (NW == 4 ? 0 : 1024);   // NW = 8: + the halo plan's mask words
-  static std::once_flag attr_once;
-  std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 0, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 1, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  });
-  if (brick16_perm(p.D, p.H, p.W) == 2) {
-    std::swap(p.H, p.W);
-    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 1, NW>), grid, dim3(NW * 64), lds, stream, p);
-  } else {
-    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 0, NW>), grid, dim3(NW * 64), lds, stream, p);
-  }
-  return pcrl_check_launch(what);
-}
 
 int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, void* y, float* stats,
                              int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
@@ -590,45 +39,3 @@ int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, v
   return BN == 64 ? launch16<64, 0>(p, grid, stream, "brick16_conv") : launch16<32, 0>(p, grid, stream, "brick16_conv");
 }
 
-// composed modes on 8 x 8 x 16 bricks (PCRL_B16_UPC_NW8=1; the test hook of the plain mode applies): D % 8 == 0 and a block for every CU
-static bool upc_planes8(int D, int64_t bricks, int ny) {
-  static const int env = [] { const char* e = getenv("PCRL_B16_UPC_NW8"); return e ? atoi(e) : 0; }();
-  const int mode = g_brick16_planes >= 0 ? (int)g_brick16_planes : env;
-  return mode > 0 && D % 8 == 0 && (mode == 2 || (bricks / 2) * ny >= 256);
-}
-
-// ---- forward of the composed ConvTranspose3d -> Conv3d operator on the wide-brick kernel (see Brick16Params::upc) ----
-// x: coarse [N][D][H][W][Ci]; w3: zero-embedded weights [8 * Co][27][Ci]; y0: fine [N][2D][2H][2W][Co]; stats [bricks * 8][Co][2]
-bool pcrl_brick16_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  return pcrl_brick16_conv_eligible(N, D, H, W, Ci, 8 * Co, dtype) && Co % 64 == 0 && (int64_t)N * D * H * W * 8 < ((int64_t)1 << 29);
-}
-int pcrl_brick16_upc_fwd_launch(const void* x, const void* w3, const float* bias_tab, void* y0, float* stats, int N, int D, int H, int W, int Ci, int Co,
-                                hipStream_t stream) {
-  Brick16Params p{(const bf16*)x, (const bf16*)w3, nullptr, (bf16*)y0, stats, N, D, H, W, Ci, 8 * Co, 0, Co, bias_tab, 0};
-  const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
-  const int ny = 8 * Co / 64;
-  if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16 (composed up-conv): grid too large");
-  p.ny = ny;
-  if (upc_planes8(D, bricks, ny)) return launch16<64, 1, 8>(p, dim3((unsigned)(bricks / 2 * ny)), stream, "brick16_conv (composed up-conv forward, 8 planes)");
-  return launch16<64, 1>(p, dim3((unsigned)(bricks * ny)), stream, "brick16_conv (composed up-conv forward)");
-}
-
-// ---- data gradient of the composed operator on the wide-brick kernel (see Brick16Params::cshift) ----
-// dy0: fine [N][2D][2H][2W][Co]; wd3: zero-embedded weights [Ci][27][8 * Co]; dx: coarse [N][D][H][W][Ci]
-static int upc_cshift(int Co) {
-  for (int k = 0; k < 8; ++k)
-    if (Co == (32 << k)) return k;
-  return -1;
-}
-bool pcrl_brick16_upc_dgrad_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  return upc_cshift(Co) >= 0 && Ci % 64 == 0 && pcrl_brick16_conv_eligible(N, D, H, W, 8 * Co, Ci, dtype) && (int64_t)N * D * H * W * 8 < ((int64_t)1 << 29);
-}
-int pcrl_brick16_upc_dgrad_launch(const void* dy0, const void* wd3, void* dx, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream) {
-  Brick16Params p{(const bf16*)dy0, (const bf16*)wd3, nullptr, (bf16*)dx, nullptr, N, D, H, W, 8 * Co, Ci, 0, Co, nullptr, upc_cshift(Co)};
-  const int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
-  const int ny = Ci / 64;
-  if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16 (composed up-conv data gradient): grid too large");
-  p.ny = ny;
-  if (upc_planes8(D, bricks, ny)) return launch16<64, 2, 8>(p, dim3((unsigned)(bricks / 2 * ny)), stream, "brick16_conv (composed up-conv data gradient, 8 planes)");
-  return launch16<64, 2>(p, dim3((unsigned)(bricks * ny)), stream, "brick16_conv (composed up-conv data gradient)");
-}
