@@ -132,7 +132,7 @@ def main():
     labels = {t: i for i, (k, t) in enumerate(body) if k == "label"}
     loops = []
     for i, (k, t) in enumerate(body):
-        if k == "ins" and t.startswith("s_cbranch"):
+        if k == "ins" and t.startswith(("s_cbranch", "s_branch")):
             tgt = t.split()[-1]
             if tgt in labels and labels[tgt] < i:
                 loops.append((labels[tgt], i, tgt))
