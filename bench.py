@@ -28,6 +28,7 @@ import os
 import random
 import sys
 import time
+from types import SimpleNamespace as types_ns
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -110,10 +111,10 @@ def synthetic_batch(b, dhw, local, device, seed, nlocal=6):
     return to(x1), to(x2), to(gt), None, [to(t) for t in loc]
 
 
-def cpu_baseline(b=8, budget_s=35.0, threads=None):
+def cpu_baseline(b=4, budget_s=15.0, threads=None):
     """Time the oracle port of the reference step on the host cores (fp32, default oneDNN) on a BOUNDED sample, following
-    BASELINE.md section 3: b = 8 full-size (64x64x32 + 6 x 16^3) crops, one warm-up step (at 32x32x16: it only pages the code in), then
-    up to 3 timed steps or ~budget_s of CPU work, whichever comes first (>= 1 step).
+    BASELINE.md section 3: b = 4 full-size (64x64x32 + 6 x 16^3) crops, one warm-up step (at 32x32x16: it only pages the code in), then
+    up to 3 timed steps or ~budget_s (15 s: VERDICT r4 -- it was 80 % of the driver's run at 35 s) of CPU work, whichever comes first (>= 1 step).
     Threads: min(32, cores) -- with all 256 hardware threads of the GPU box a step is >10x SLOWER (oversubscribed oneDNN / ATen
     threading: measured 279 s for b = 2), so "all cores" of the plan is not a fair baseline on that host; the count used is reported."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -140,6 +141,76 @@ def cpu_baseline(b=8, budget_s=35.0, threads=None):
     return {"value": round(b * steps / dt, 4), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle port of train_3d.py:109-151 (oracle/pcrlv2_oracle.py), fp32 oneDNN, b={b}, 64x64x32 + 6x16^3, "
                       f"{steps} timed step(s) in {dt:.1f} s on {torch.get_num_threads()} of {cores} host threads ({model_name})"}
+
+
+
+# ---- PCRL_BENCH_DRYRUN=1: the N-rank code path of this file on CPU (tests/test_host_cpu.py, world 4 over gloo) ------------------------------
+# Everything that is bench.py's OWN -- the self-spawn of `--gpus N`, rank / device table, the four-setting bucket A/B, the barrier-bracketed
+# timed region with MAX over ranks, the JSON line and its `distributed` block -- runs as it does on a node; only the step itself is replaced by a
+# stub that parks KNOWN gradients through the engine's own parking / flush / bucket machinery (pcrlv2_amd.functions, ddp.DataParallel) and
+# checks the all-reduced arena after every optimizer step.  No GPU, no library call.
+class _DryEvent:
+    def __init__(self, enable_timing=True):
+        self.t = 0.0
+
+    def record(self):
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return 1e3 * (other.t - self.t)
+
+
+def _dryrun_parts(rank, world):
+    import types
+    from pcrlv2_amd import functions as Fn
+    torch.manual_seed(0)
+    shapes = [(300,), (7, 5), (2000,), (3,), (64, 8), (5000,)]
+    params = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    sizes = [p.numel() for p in params]
+    offs = [0]
+    for n in sizes:
+        offs.append(offs[-1] + n)
+    flat_g = torch.full((offs[-1],), 123.0)
+    opt = types.SimpleNamespace(_plist=params, flat_g=flat_g, flat_p=torch.cat([p.detach().reshape(-1) for p in params]).clone(),
+                                _gviews=[flat_g[o:o + n].view(p.shape) for p, o, n in zip(params, offs, sizes)], grad_scale=1.0, pre_step=None,
+                                steps=0, checked=0)
+    opt.gather_grads = lambda: None
+    model = torch.nn.Module()
+
+    class Dot(torch.autograd.Function):      # stand-in for a stage Function: parks its parameter gradient, final when it ran in pass 0
+        @staticmethod
+        def forward(ctx, p, x, pass_idx):
+            ctx.p, ctx.x, ctx.pass_idx = p, x, pass_idx
+            return (p.detach() * x).sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            out = Fn._park(ctx.p, g * ctx.x)
+            Fn.mark_final(ctx, [ctx.p])
+            return out, None, None
+
+    def train_step(model_, opt_, batch, epoch, crit, cosine, guard=False):
+        k = opt_.steps
+        for p in params:
+            p.grad = None
+        x = [torch.full(s_, float(rank + 1 + (k % 3))) for s_ in shapes]
+        l0 = sum(Dot.apply(params[i], x[i], 0) for i in (0, 2, 4, 5))      # pass 0 (final); parameter 3 never gets a gradient, parameter 1 only a non-final one
+        l1 = sum(Dot.apply(params[i], x[i], 1) for i in (0, 1, 2, 4, 5))
+        (l0 + l1).backward()
+        if opt_.pre_step is None:
+            Fn.flush_param_grads()
+        has = opt_.pre_step(opt_, None) if opt_.pre_step is not None else [p.grad is not None for p in params]
+        assert has == [True, True, True, False, True, True], has
+        tot = sum(r + 1 + (k % 3) for r in range(world))
+        for i, v in enumerate(opt_._gviews):
+            mult = {0: 2, 1: 1, 2: 2, 3: 0, 4: 2, 5: 2}[i]
+            if has[i]:
+                assert torch.allclose(v, torch.full_like(v, float(mult * tot))), ("dry-run gradient check", k, i, float(v.flatten()[0]), mult * tot)
+        opt_.steps += 1
+        opt_.checked += 1
+        z = torch.zeros(())
+        return torch.tensor(float(k)), z, z, z, z
+    return model, opt, train_step
 
 
 def main():
@@ -171,29 +242,35 @@ def main():
             print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr)
         raise SystemExit(r.returncode)
 
-    from pcrlv2_amd import _lib, ddp
-    from pcrlv2_amd.models import PCRLv23d
-    from pcrlv2_amd.optim import FusedSGD
-    from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step
+    dry = os.environ.get("PCRL_BENCH_DRYRUN", "0") == "1"
+    from pcrlv2_amd import ddp
+    if not dry:
+        from pcrlv2_amd import _lib
+        from pcrlv2_amd.models import PCRLv23d
+        from pcrlv2_amd.optim import FusedSGD
+        from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank, local_rank = 0, 0
     if world > 1:
         # "nccl" IS RCCL on ROCm; PCRL_DIST_BACKEND=gloo lets the multi-rank code path be exercised with several ranks on ONE GPU
-        rank, world, local_rank = ddp.init_process_group_from_env(os.environ.get("PCRL_DIST_BACKEND", "nccl"))
+        rank, world, local_rank = ddp.init_process_group_from_env("gloo" if dry else os.environ.get("PCRL_DIST_BACKEND", "nccl"))
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
     # several ranks on fewer GPUs (PCRL_DIST_BACKEND=gloo on a one-GPU box): ranks share devices round-robin
-    ndev = torch.cuda.device_count()
-    local_rank = local_rank % max(ndev, 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = 0 if dry else torch.cuda.device_count()
+    if dry:
+        dev = torch.device("cpu")
+    else:
+        local_rank = local_rank % max(ndev, 1)
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist_info = None
     if world > 1:
         import torch.distributed as dist
         backend = dist.get_backend()
         # every rank reports its device; rank 0 keeps the table (proof that N ranks on N devices took part in the timed region)
-        mine = {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank)}
+        mine = {"rank": rank, "device": local_rank, "name": "cpu (dry run)" if dry else torch.cuda.get_device_name(local_rank)}
         table = [None] * world
         dist.all_gather_object(table, mine)
         ver = None
@@ -204,14 +281,17 @@ def main():
                 ver = "unknown"
         dist_info = {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": ver, "world_size": dist.get_world_size(),
                      "visible_devices": ndev, "ranks": table}
-        print(f"[bench] rank {rank}/{world} on cuda:{local_rank} backend={backend}", file=sys.stderr)
+        print(f"[bench] rank {rank}/{world} on {'cpu' if dry else 'cuda'}:{local_rank} backend={backend}", file=sys.stderr)
     dhw = tuple(int(v) for v in args.dhw.split(","))
 
     torch.manual_seed(0)
     random.seed(0)          # same scale draws on every rank (see ddp.DataParallel)
-    model = PCRLv23d().to(dev).train()
-    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    if dry:
+        model, opt, train_step = _dryrun_parts(rank, world)
+    else:
+        model = PCRLv23d().to(dev).train()
+        model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+        opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
     dp = ddp.DataParallel(model, opt) if world > 1 else None  # noqa: F841
     if world == 1 and os.environ.get("PCRL_FORCE_DDP", "0") == "2":     # bisect probe: the process group alone, no wrapper
         import torch.distributed as dist
@@ -228,16 +308,18 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1)
         dp = ddp.DataParallel(model, opt, force_collectives=True)  # noqa: F841
         dist_info = {"backend": "nccl (RCCL)", "world_size": 1, "forced_one_rank_probe": True}
-    crit, cosine = MSELoss(), CosineSimilarityMean()
-    batch = synthetic_batch(args.b, dhw, 16, dev, 1234 + rank, args.nlocal)
+    crit, cosine = (None, None) if dry else (MSELoss(), CosineSimilarityMean())
+    batch = None if dry else synthetic_batch(args.b, dhw, 16, dev, 1234 + rank, args.nlocal)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    Event = _DryEvent if dry else torch.cuda.Event
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    L = _lib.lib()
+    L = types_ns() if dry else _lib.lib()
     # same-box A/B of launch variants (tools/conv_probe.py documents the codes); not used by the default run
     if os.environ.get("PCRL_DEBUG_CONV_IMPL"):
         L.debug_set_conv_impl(int(os.environ["PCRL_DEBUG_CONV_IMPL"]))
@@ -250,7 +332,8 @@ def main():
     # fastest (max over ranks) is used for the timed region and all four are reported (distributed.ab).  Results do not depend on the setting.
     ddp_ab = None
     if dp is not None and getattr(dp, "_active", False) and os.environ.get("PCRL_BENCH_DDP_AB", "1") != "0":
-        settings = collections.OrderedDict([("from_step_buckets24MB", (False, 24.0)), ("overlap_buckets24MB", (True, 24.0)),
+        mb = 0.004 if dry else 24.0      # the dry run's stand-in parameters are ~30 KB: ~1000-float buckets there, so that several go out
+        settings = collections.OrderedDict([("from_step_buckets24MB", (False, mb)), ("overlap_buckets24MB", (True, mb)),
                                             ("from_step_1bucket", (False, 1e6)), ("overlap_1bucket", (True, 1e6))])
         st0 = random.getstate()
         ddp_ab = {}
@@ -275,8 +358,9 @@ def main():
             train_step(model, opt, batch, 0, crit, cosine, guard=False)
         random.setstate(st0)
         ddp_ab = {"settings": ddp_ab, "used_for_timed_region": best, "steps_each": 6}
-    prof = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad",
-                               "pcrl_upconv_wgrad_accum"}, keyfn)
+    prof = types_ns(results=lambda: {"brick16_conv_kernel": (1, 1.0, 1.0)}) if dry else \
+        _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad",
+                            "pcrl_upconv_wgrad_accum"}, keyfn)
     import gc
     gc.collect()
     if os.environ.get("PCRL_BENCH_NOGC", "0") == "1":
@@ -285,8 +369,8 @@ def main():
     ALG_BYTES.clear()
     if os.environ.get("PCRL_BENCH_NO_INREGION", "0") != "1":     # A/B probe of what the event pairs inside the timed region cost
         L.profiler = prof
-    ms0 = torch.cuda.memory_stats(dev)
-    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    ms0 = {} if dry else torch.cuda.memory_stats(dev)
+    step_marks = [Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     step_marks[0].record()
     draw_states = []
@@ -297,7 +381,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     L.profiler = None
-    ms1 = torch.cuda.memory_stats(dev)
+    ms1 = {} if dry else torch.cuda.memory_stats(dev)
     per_step = [round(step_marks[i].elapsed_time(step_marks[i + 1]), 1) for i in range(args.steps)]
     # the step's 13 scale draws (train_3d.py:87: global pair, then (view 1, local i), (view 2, local i) for the six local views) decide which
     # stages run a backward: view 2's full-resolution decoder stage (up_tr64, ~3.4 ms of kernels) only if a term with view 2 drew scale 2
@@ -321,12 +405,15 @@ def main():
     # the roofline figure (the one-stream rocprofv3 summary agrees with it), never `value`; the timed region's share stays in roofline.in_timed_region.
     from pcrlv2_amd import config as _cfg
     alone = None
+    if dry:
+        args.no_alone = args.no_secondary = args.no_cpu_baseline = True
     if _cfg.WGRAD_SIDE_STREAM_3D and not args.no_alone:      # every rank runs them (the optimizer step holds a collective)
         _cfg.WGRAD_SIDE_STREAM_3D = False     # also turns the second view's stream off (it needs the side stream)
         _branch, _cfg.FWD_BRANCH_STREAM = _cfg.FWD_BRANCH_STREAM, False
         for _ in range(2):
             train_step(model, opt, batch, 0, crit, cosine, guard=False)
-        alone = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_upconv_fwd"}, keyfn)
+        alone = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad",
+                                    "pcrl_upconv_wgrad_accum"}, keyfn)   # every matrix kernel: roofline.weighted_matrix_frac
         ALG_BYTES.clear()
         torch.cuda.synchronize()
         L.profiler = alone
@@ -450,6 +537,8 @@ def main():
     cfg_name = {((64, 64, 32), 32): "C2", ((128, 128, 64), 8): "C4"}.get((dhw, args.b), "custom (not a BASELINE config)")
     if args.nlocal != 6:
         cfg_name = "custom (not a BASELINE config: %d local views)" % args.nlocal
+    if dry:
+        cfg_name = "DRY RUN on CPU (PCRL_BENCH_DRYRUN=1: stub step with known gradients; `value` is NOT a measurement)"
     flop_per_crop = {"C2": FLOP_PER_CROP, "C4": 9.42e12}.get(cfg_name)
     line = {
         "metric": "3D crops/sec (64x64x32, b=32) pretrain step" if cfg_name == "C2" else f"3D crops/sec ({dhw[0]}x{dhw[1]}x{dhw[2]}, b={args.b}) pretrain step", "value": round(crops, 2), "unit": "crops/s",
@@ -486,6 +575,17 @@ def main():
         rf = line["roofline"]
         rf["in_timed_region"] = {"achieved": rf["achieved"], "frac": rf["frac"], "avg_launch_ms": rf["avg_launch_ms"], "launches": rf["launches"],
                                  "note": "three streams share the chip (second view; weight gradients + side branches): the kernel's share, not its rate"}
+        # every matrix kernel of the one-stream steps, weighted by its time: executed FLOPs / summed kernel time / peak (the dominant
+        # kernel's `frac` alone flatters the step: the composed, weight-gradient and small-grid kernels run below it)
+        mk = alone.results()
+        mk_ms, mk_work = sum(v[1] for v in mk.values()), sum(v[2] for v in mk.values())
+        if mk_ms > 0:
+            nst = min(10, args.steps)
+            rf["weighted_matrix_frac"] = round(mk_work / (mk_ms * 1e-3) / 1e12 / rf["peak"], 4)
+            rf["weighted_matrix"] = {"executed_tflop_per_step": round(mk_work / nst / 1e12, 2), "kernel_ms_per_step": round(mk_ms / nst, 3),
+                                     "kernels": {k: {"ms_per_step": round(v[1] / nst, 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(mk.items())},
+                                     "note": "all convolution / composed up-conv forward, data-gradient and weight-gradient launches (with their second passes) of the "
+                                             "one-stream steps: executed FLOPs / summed HIP-event time / dense bf16 peak"}
         rf.update({"achieved": round(a1, 1), "frac": round(a1 / rf["peak"], 4), "avg_launch_ms": round(ms1_ / n1, 4), "launches": n1,
                    "measured": "HIP events over %d one-stream steps run right after the timed region (same process, model and batch; "
                                "PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 PCRL_VIEW_STREAMS=0 semantics)" % min(10, args.steps)})
@@ -496,6 +596,8 @@ def main():
         line["roofline"]["algorithmic_bytes_per_launch"] = round(ab)
         if line["roofline"]["traffic"]:
             line["roofline"]["traffic_over_algorithmic"] = round(line["roofline"]["traffic"] / ab, 3)
+    if dry:
+        line["dry_run"] = {"gradient_checks_passed": opt.checked, "note": "every optimizer step of every rank checked the all-reduced arena against the known sums"}
     if secondary is not None:
         line["secondary"] = secondary
     if dist_info is not None:

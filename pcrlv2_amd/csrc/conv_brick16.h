@@ -223,7 +223,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
       prevL = L;
       prevP = P;
       // rows of the halo outside the volume: zero for the block's lifetime
-      if (!inside && piece < NDMA) *reinterpret_cast<u32x4*>(halo + piece * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
+      // (rows >= ROWS of the last piece are never read -- and, for NW = 4, that tail of the buffer holds every wave's plan words: not touched)
+      if (!inside && row < ROWS) *reinterpret_cast<u32x4*>(halo + piece * 1024 + lane * 16) = u32x4{0u, 0u, 0u, 0u};
     }
   }
   // The two mask words depend on (wave, lane / 4) only and are needed once per chunk: they wait in LDS -- NW = 4: the 512 bytes behind the halo's

@@ -287,6 +287,21 @@ PIN_MODE = os.environ.get("PCRL_LOADER_PIN", "slots")
 LOADER_TIMING = os.environ.get("PCRL_LOADER_TIMING", "0") == "1"
 
 
+def worker_affinity_init(worker_id: int):
+    """DataLoader worker_init_fn: a worker forked from a rank whose launcher thread ddp.bind_rank_to_numa pinned inherits that narrow mask; the
+    binding left the CPUs meant for the workers in $PCRL_WORKER_CPUS -- move there (worker i prefers CPU i of the list when there is one per
+    worker, otherwise all of them share the list).  No variable, or a refusal: nothing happens."""
+    cpus = [int(c) for c in os.environ.get("PCRL_WORKER_CPUS", "").split(",") if c.strip().isdigit()]
+    if not cpus or not hasattr(os, "sched_setaffinity"):
+        return
+    try:
+        info = torch.utils.data.get_worker_info()
+        n = info.num_workers if info is not None else 0
+        os.sched_setaffinity(0, [cpus[worker_id % len(cpus)]] if 0 < n <= len(cpus) else cpus)
+    except OSError:
+        pass
+
+
 class AugmentedLoader:
     """DataLoader over raw crops + GpuLunaAugment: iterates batches with the contract of datasets/lunaDataset.py:79-81.
 
@@ -320,11 +335,12 @@ class AugmentedLoader:
             self.slots = (pair_buf, local_buf, pinned)
             self.loader = torch.utils.data.DataLoader(_SlotCrops(files, pair_buf, local_buf), num_workers=workers, collate_fn=lambda items: (items[0][0], len(items)),
                                                       batch_sampler=_SlotBatches(len(files), batch_size, shuffle, drop_last, nslots, seed),
-                                                      persistent_workers=True, prefetch_factor=prefetch)
+                                                      persistent_workers=True, prefetch_factor=prefetch, worker_init_fn=worker_affinity_init)
         else:
             self.loader = torch.utils.data.DataLoader(LunaCropPairs(files), batch_size=batch_size, shuffle=shuffle, num_workers=workers,
                                                       pin_memory=cuda and PIN_MODE in ("loader", "slots"), drop_last=drop_last,
-                                                      persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None)
+                                                      persistent_workers=workers > 0, prefetch_factor=4 if workers > 0 else None,
+                                                      worker_init_fn=worker_affinity_init if workers > 0 else None)
         self.augment = GpuLunaAugment(device, seed)
         self._stream = None
         self._ring, self._ring_pos = None, 0

@@ -39,8 +39,22 @@ def init_process_group_from_env(backend: str | None = None):
         torch.cuda.set_device(local)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if world > 1:
-        bind_rank_to_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), verbose=os.environ.get("PCRL_BIND_VERBOSE", "0") == "1",
-                          exchange=True)
+        # The (host, NUMA node, rank) exchange is a COLLECTIVE: every rank reaches it, whatever its own PCRL_BIND_CPUS says and whether or not it
+        # can read its node (a rank that opted out, or raised before the gather, left its peers blocked inside an optional optimisation).
+        table = None
+        try:
+            import socket
+            node = _gpu_numa_node(torch.cuda.current_device()) if torch.cuda.is_available() else -1
+        except Exception:
+            node = -1
+        try:
+            table = [None] * world
+            dist.all_gather_object(table, (socket.gethostname(), node, rank))
+        except Exception as e:      # a failing collective is a broken group, not a binding problem: say so and carry on unbound
+            print(f"[pcrlv2_amd.ddp] rank table exchange failed ({e}); CPU binding skipped", flush=True)
+            table = None
+        if table is not None:
+            bind_rank_to_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), verbose=os.environ.get("PCRL_BIND_VERBOSE", "0") == "1", table=table)
     return rank, world, local
 
 
@@ -74,15 +88,33 @@ def _gpu_numa_node(index: int):
         return -1
 
 
-def bind_rank_to_numa(local_rank: int, local_world: int, verbose: bool = False, exchange: bool = False):
+WORKER_CPUS = None      # set by bind_rank_to_numa: the CPUs this rank's DataLoader workers should run on (data.worker_affinity_init applies it)
+
+
+def split_share(mine, workers: int):
+    """A rank's CPU share -> (launcher CPUs, loader-worker CPUs).  The launcher thread (it enqueues ~1 000 kernel launches per step: SURVEY 8e, the
+    >= 6x target is bounded by its jitter) keeps CPUs of its own; the `workers` DataLoader processes get the rest, one CPU each where the share
+    allows.  A share too small for that (fewer than workers + 2 CPUs) is not split: everything runs on all of it (and the log says so)."""
+    mine = list(mine)
+    if workers <= 0 or len(mine) < workers + 2:
+        return mine, mine
+    k = max(2, len(mine) - workers)
+    return mine[:k], mine[k:]
+
+
+def bind_rank_to_numa(local_rank: int, local_world: int, verbose: bool = False, exchange: bool = False, table=None, workers=None):
     """Pin this rank's host threads to CPUs of its GPU's NUMA node (at < 1 ms of communication per ~33 ms step the >= 6x target
     at 8 GPUs is bounded by host-side launch jitter, not by xGMI: eight launcher threads migrating across two sockets is that jitter).
     The node is that of the device this process has made CURRENT (`torch.cuda.current_device()` after `set_device`: correct under
-    HIP_VISIBLE_DEVICES remapping, where local device index != local rank); with `exchange` (a process group is up) the ranks tell each
-    other (host, node) so that ranks sharing a node split its CPUs -- without it the split assumes device i belongs to local rank i.
-    Side effects, logged ONCE on rank 0 (stderr): the process-wide affinity mask is narrowed -- DataLoader workers forked later inherit it
-    (a rank's share is node CPUs / ranks on the node, e.g. 32 of 128: `--workers` beyond that share time-slice) -- and
-    `torch.set_num_threads(<= 8)`.  PCRL_BIND_CPUS=0 turns the binding off.  -> the CPU list, or None when nothing was done."""
+    HIP_VISIBLE_DEVICES remapping, where local device index != local rank); `table` = the [(host, node, rank)] list every rank contributed to
+    (init_process_group_from_env gathers it unconditionally) lets ranks that share a node split its CPUs -- without it the split assumes device i
+    belongs to local rank i.  (`exchange=True` without a table gathers it here: kept for callers that build their own group.)
+    The rank's share is split again (split_share): the LAUNCHER thread is pinned to the first part, the DataLoader workers (`workers`, default
+    $PCRL_LOADER_WORKERS or main.py's --workers) are told to run on the rest through ddp.WORKER_CPUS / $PCRL_WORKER_CPUS, which
+    data.worker_affinity_init applies in each worker (a forked worker inherits the launcher's narrow mask; it widens itself) -- round 4 left the
+    workers inside the launcher's mask, time-slicing with it.  Logged ONCE on rank 0 (stderr), with the split.  Also `torch.set_num_threads(<= 8)`.
+    PCRL_BIND_CPUS=0 turns the binding off (after the exchange).  -> the launcher's CPU list, or None when nothing was done."""
+    global WORKER_CPUS
     if os.environ.get("PCRL_BIND_CPUS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
     try:
@@ -91,11 +123,13 @@ def bind_rank_to_numa(local_rank: int, local_world: int, verbose: bool = False, 
         cuda = torch.cuda.is_available()
         node = _gpu_numa_node(torch.cuda.current_device()) if cuda else -1
         how = "current device"
-        if exchange and dist.is_available() and dist.is_initialized():
+        if table is None and exchange and dist.is_available() and dist.is_initialized():
             table = [None] * dist.get_world_size()
             dist.all_gather_object(table, (socket.gethostname(), node, dist.get_rank()))
+        if table is not None:
+            me = dist.get_rank() if dist.is_available() and dist.is_initialized() else local_rank
             mates = sorted(r for (h, n, r) in table if h == socket.gethostname() and n == node)
-            peers, slot = len(mates), mates.index(dist.get_rank())
+            peers, slot = len(mates), mates.index(me)
         else:
             nodes = [_gpu_numa_node(i) for i in range(local_world)] if cuda and torch.cuda.device_count() >= local_world else [-1] * local_world
             if not cuda:
@@ -108,14 +142,22 @@ def bind_rank_to_numa(local_rank: int, local_world: int, verbose: bool = False, 
             with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
                 node_cpus = parse_cpulist(f.read())
         mine = cpu_share(node_cpus, allowed, peers, slot)
-        os.sched_setaffinity(0, mine)
-        torch.set_num_threads(max(1, min(8, len(mine))))
+        if workers is None:
+            workers = int(os.environ.get("PCRL_LOADER_WORKERS", "0") or 0)
+        launcher, wcpus = split_share(mine, workers)
+        os.sched_setaffinity(0, launcher)
+        WORKER_CPUS = list(wcpus)
+        os.environ["PCRL_WORKER_CPUS"] = ",".join(str(c) for c in wcpus)
+        torch.set_num_threads(max(1, min(8, len(launcher))))
         if verbose or (dist.is_available() and dist.is_initialized() and dist.get_rank() == 0):
             import sys
-            print(f"[pcrlv2_amd.ddp] rank binding on ({how}): local rank {local_rank} -> GPU NUMA node {node}, {len(mine)} CPUs "
-                  f"({mine[0]}..{mine[-1]}), {torch.get_num_threads()} torch threads; DataLoader workers inherit this mask; PCRL_BIND_CPUS=0 disables",
-                  file=sys.stderr, flush=True)
-        return mine
+            split = (f"launcher thread on {len(launcher)} ({launcher[0]}..{launcher[-1]}), {workers} loader workers on {len(wcpus)} ({wcpus[0]}..{wcpus[-1]})"
+                     if wcpus is not launcher and wcpus != launcher else
+                     f"NOT split: {workers} loader workers share the launcher's {len(mine)} CPUs ({mine[0]}..{mine[-1]})" if workers > 0 else
+                     f"launcher on all {len(mine)} ({mine[0]}..{mine[-1]}); no loader workers announced (PCRL_LOADER_WORKERS)")
+            print(f"[pcrlv2_amd.ddp] rank binding on ({how}): local rank {local_rank} -> GPU NUMA node {node}, share {len(mine)} CPUs: {split}; "
+                  f"{torch.get_num_threads()} torch threads; PCRL_BIND_CPUS=0 disables", file=sys.stderr, flush=True)
+        return launcher
     except Exception as e:      # binding is an optimisation, never a reason to fail a run
         if verbose:
             print(f"[pcrlv2_amd.ddp] CPU binding skipped: {e}", flush=True)
@@ -305,10 +347,26 @@ class DataParallel:
             with (torch.cuda.stream(cs) if cs is not None else contextlib.nullcontext()):
                 miss = [i for i in idxs if opt._plist[i].grad is None]
                 copy = [i for i in idxs if opt._plist[i].grad is not None and opt._plist[i].grad.data_ptr() != opt._gviews[i].data_ptr()]
-                if copy:
-                    torch._foreach_copy_([opt._gviews[i] for i in copy], [opt._plist[i].grad for i in copy])
-                if miss:
-                    torch._foreach_zero_([opt._gviews[i] for i in miss])
+                if seg.is_cuda:
+                    # no ATen launch on the step path: grad-less parameters are zeroed by pcrl_zero (a runtime memset) --
+                    # consecutive ones (the unused deep-supervision heads sit next to each other in the arena) as ONE range
+                    L, sh = ops.lib(), ops.stream_handle()
+                    for i in copy:      # never on the training step's path (its gradients are parked and summed straight into the arena by flush_param_grads)
+                        opt._gviews[i].copy_(opt._plist[i].grad)
+                    offs = opt._offsets_host
+                    k = 0
+                    while k < len(miss):
+                        j = k
+                        while j + 1 < len(miss) and miss[j + 1] == miss[j] + 1:
+                            j += 1
+                        lo, hi = offs[miss[k]], offs[miss[j] + 1]
+                        L.call("pcrl_zero", opt.flat_g[lo:hi], 4 * (hi - lo), sh)
+                        k = j + 1
+                else:       # CPU tensors (the gloo tests of this logic)
+                    if copy:
+                        torch._foreach_copy_([opt._gviews[i] for i in copy], [opt._plist[i].grad for i in copy])
+                    if miss:
+                        torch._foreach_zero_([opt._gviews[i] for i in miss])
                 if not _PROBE_SKIP_COLLECTIVE:
                     self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for i in idxs:

@@ -122,6 +122,7 @@ def main(argv=None):
         raise SystemExit(subprocess.call(cmd, env=env))
     if "WORLD_SIZE" not in os.environ:
         os.environ["HIP_VISIBLE_DEVICES"] = args.gpus
+    os.environ.setdefault("PCRL_LOADER_WORKERS", str(args.workers))     # ddp.bind_rank_to_numa keeps this many CPUs of the rank's share for the loader workers
     print(args)
     data_loader = get_dataloader(args)
     if args.model == 'pcrlv2' and args.phase == 'pretask' and args.d == 3:

@@ -419,6 +419,31 @@ def test_divergence_guard_decision_is_collective_gloo_world2(tmp_path):
     assert all("OK" in o for o in outs)
 
 
+def test_bench_gpus4_code_path_dry_run_gloo_world4():
+    """`python bench.py --gpus 4` end to end on CPU (PCRL_BENCH_DRYRUN=1): the self-spawn through torch.distributed.run, four gloo
+    ranks, the rank / device table, the four-setting bucket A/B, the barrier-bracketed timed region, the JSON line -- with the step replaced by a
+    stub whose KNOWN gradients go through the engine's parking / bucket / all-reduce machinery and are checked after every optimizer step."""
+    import json
+    env = dict(os.environ, PCRL_BENCH_DRYRUN="1", PCRL_BIND_CPUS="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "4", "--warmup", "1"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert lines and lines[-1].startswith("{"), r.stdout[-500:]        # the JSON line is the LAST line of stdout
+    assert sum(ln.startswith("{") for ln in lines) == 1                 # ... and the only one
+    d = json.loads(lines[-1])
+    assert d["n_gpus"] == 4 and d["config"]["parallelism"] == "dp4" and d["scaling"] == "weak"
+    ranks = d["distributed"]["ranks"]
+    assert sorted(x["rank"] for x in ranks) == [0, 1, 2, 3] and len({x["device"] for x in ranks}) == 4
+    ab = d["distributed"]["ab"]
+    assert set(ab["settings"]) == {"from_step_buckets24MB", "overlap_buckets24MB", "from_step_1bucket", "overlap_1bucket"}
+    assert ab["used_for_timed_region"] in ab["settings"] and ab["settings"]["overlap_buckets24MB"]["buckets"] >= 3
+    assert abs(d["per_gpu_value"] * 4 - d["value"]) < 0.02 * d["value"]
+    assert d["dry_run"]["gradient_checks_passed"] >= 4 + 1 + 4 * 8 and "DRY RUN" in d["config"]["workload"]
+    assert d["steps"] == 4 and d["warmup"] == 1 and d["ms_per_step"] > 0
+
+
 def test_rank_cpu_binding_helpers():
     """ddp.bind_rank_to_numa's pure parts: sysfs cpulist parsing and the even split of a NUMA node's CPUs among the ranks on it."""
     from pcrlv2_amd.ddp import cpu_share, parse_cpulist
@@ -430,6 +455,32 @@ def test_rank_cpu_binding_helpers():
     assert all(len(s) == 32 for s in shares) and len(set(c for s in shares for c in s)) == 128      # disjoint, whole node
     assert cpu_share(node, {1, 2, 3}, 4, 3) == [1, 2, 3]        # fewer CPUs than ranks: share the pool rather than starve a rank
     assert cpu_share([], {4, 5, 6, 7}, 2, 1) == [6, 7]          # unknown node: even split of what is allowed
+    # the rank's share is split again: the launcher thread keeps CPUs of its own, the loader workers get the rest
+    from pcrlv2_amd.ddp import split_share
+    launcher, workers = split_share(shares[1], 8)
+    assert len(launcher) == 24 and len(workers) == 8 and not set(launcher) & set(workers) and sorted(launcher + workers) == shares[1]
+    assert split_share(shares[0], 0) == (shares[0], shares[0])                    # no workers announced: nothing to split
+    small = list(range(6))
+    assert split_share(small, 8) == (small, small)                              # share too small: not split (everything time-slices, and the log says so)
+    la, wo = split_share(list(range(10)), 8)
+    assert la == [0, 1] and wo == list(range(2, 10))                            # the launcher never gets fewer than two CPUs
+
+
+def test_loader_worker_moves_to_the_cpus_the_binding_left_for_it(monkeypatch):
+    """data.worker_affinity_init: a forked worker leaves the launcher's mask for $PCRL_WORKER_CPUS."""
+    from pcrlv2_amd import data
+    if not hasattr(os, "sched_setaffinity"):
+        return
+    allowed = sorted(os.sched_getaffinity(0))
+    try:
+        monkeypatch.setenv("PCRL_WORKER_CPUS", ",".join(str(c) for c in allowed[-2:]))
+        data.worker_affinity_init(0)
+        assert sorted(os.sched_getaffinity(0)) == allowed[-2:]                  # outside a DataLoader (no worker info): the whole list
+        monkeypatch.setenv("PCRL_WORKER_CPUS", "")
+        data.worker_affinity_init(0)                                            # no variable: nothing happens
+        assert sorted(os.sched_getaffinity(0)) == allowed[-2:]
+    finally:
+        os.sched_setaffinity(0, allowed)
 
 
 def test_header_is_plain_c_and_links_from_c(tmp_path):
