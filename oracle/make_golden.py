@@ -423,6 +423,60 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
     print(f"[{tag}] wrote fixture ({nsteps} steps)")
 
 
+def make_loss2d(tag, b=4, nlocal=6, epoch=3, seed=11):
+    """Pin of what CAN be pinned on the 2D path: the reference's `train_2d.cos_loss` (train_2d.py:111-117, imported) and its
+    loss assembly (train_2d.py:139-168, restated around the imported function: the loop itself sits inside train_pcrlv2_inner behind .cuda()
+    calls) on closed-form five-scale feature lists (pcrlv2_2d_oracle.fill_loss_inputs).  The 2D MODEL stays unpinned (smp / torchvision absent).
+    Stores the five losses, the scale the first draw picked, and all 1 + 2 * nlocal draws in order."""
+    import math
+    _stub_modules()
+    sys.path.insert(0, REF)
+    try:
+        import train_2d as ref2d
+    finally:
+        sys.path.remove(REF)
+    import pcrlv2_2d_oracle as O2
+    feats1, feats2, feats_loc, mask1, masks1, gt = O2.fill_loss_inputs(b, nlocal, dtype=torch.float64)
+    cosine, criterion = torch.nn.CosineSimilarity(), torch.nn.MSELoss()
+    draws = []
+    real_randint = random.randint
+
+    def spy(a_, b_):
+        v = real_randint(a_, b_)
+        draws.append(v)
+        return v
+    random.seed(seed)
+    ref2d.random.randint = spy          # the module's own `random` is the global one: record the draws cos_loss takes
+    try:
+        # train_2d.py:139-168 (decoder_outputs1 = feats1, ...; local_views_outputs = the model's output for the concatenated local views)
+        bsz = b
+        loss2, index2 = ref2d.cos_loss(cosine, feats1, feats2)
+        local_loss = 0.0
+        local_views_outputs = [torch.stack(t) for t in feats_loc]
+        for i in range(nlocal):
+            tmp = [t[:, bsz * i: bsz * (i + 1)] for t in local_views_outputs]
+            l1, _ = ref2d.cos_loss(cosine, feats1, tmp)
+            l2, _ = ref2d.cos_loss(cosine, feats2, tmp)
+            local_loss += l1
+            local_loss += l2
+        local_loss = local_loss / (2 * nlocal)
+        loss1 = criterion(mask1, gt)
+        beta = 0.5 * (1. + math.cos(math.pi * epoch / 240))
+        loss4 = beta * criterion(masks1[index2], gt)
+        loss = loss1 + loss2 + local_loss + loss4
+    finally:
+        ref2d.random.randint = real_randint
+    assert len(draws) == 1 + 2 * nlocal and draws[0] == index2
+    # the 2D oracle's restatement of cos_loss must agree (it is what the GPU tests of the 2D step use)
+    random.seed(seed)
+    l2o, k2o = O2.cos_loss(feats1, feats2)
+    assert k2o == index2 and abs(float(l2o) - float(loss2)) < 1e-12
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), loss=np.float64(loss), loss1=np.float64(loss1), loss2=np.float64(loss2), loss4=np.float64(loss4),
+                        local_loss=np.float64(local_loss), index2=np.int64(index2), draws=np.array(draws, dtype=np.int64), b=np.int64(b), nlocal=np.int64(nlocal),
+                        epoch=np.int64(epoch), seed=np.int64(seed))
+    print(f"[{tag}] loss {float(loss):+.6f} loss1 {float(loss1):.6f} loss2 {float(loss2):+.6f} loss4 {float(loss4):.6f} local {float(local_loss):+.6f} draws {draws}")
+
+
 def make_eval(tag, b, dhw, refmod, ref_train, ref_utils):
     """Eval-mode forward of the REAL reference (model.eval(): running statistics) on a state whose buffers were moved by one oracle
     training step -- what a consumer of the checkpoint runs (README.md:48-55).  The tests rebuild the state with the oracle (it is
@@ -649,6 +703,10 @@ def main():
     if "--data-parallel" in sys.argv:
         # nn.DataParallel semantics (train_3d.py:54) on two replicas of b = 4
         make_dp("dp2_b4x2_32x32x16", 4, (32, 32, 16), 2, 2, refmod, ref_train, ref_utils)
+        return
+    if "--loss2d" in sys.argv:
+        make_loss2d("loss2d_b4_5scales")
+        make_loss2d("loss2d_b2_nl3", b=2, nlocal=3, epoch=120, seed=4)
         return
     if "--long-curve" in sys.argv:
         make_long_curve("lc_b8_32x32x16_300steps", 8, (32, 32, 16), 300, refmod, ref_train, ref_utils)

@@ -133,3 +133,33 @@ def synthetic_batch(b, size, local_size, seed, dtype=torch.float32):
     gt = torch.rand(b, 3, size, size, generator=g, dtype=dtype)
     locs = [torch.randn(b, 3, local_size, local_size, generator=g, dtype=dtype) for _ in range(6)]
     return x1, x2, gt, gt.clone(), locs
+
+
+def fill_loss_inputs(b=4, nlocal=6, size=32, seed=31, dtype=torch.float64, channels=(256, 128, 64, 32, 16)):
+    """Closed-form stand-ins for what the three forwards of train_2d.py:139-147 hand to the loss assembly (the MODEL is not part of this pin:
+    smp / torchvision are absent, 'parity unpinned' -- only train_2d.py:111-117,139-168 is): five scales of [projection, prediction] features for
+    view 1 / view 2 ([b, C_k]) and the concatenated local views ([nlocal * b, C_k]), the reconstruction, the five deep-supervision maps and the
+    target ([b, 3, size, size]).  View 2 and the local features are correlated with view 1 (cosine terms away from 0)."""
+    import sys as _sys
+    import os as _os
+    _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+    import pcrlv2_oracle as O3
+    import numpy as np
+
+    def u(n, sd):
+        return torch.from_numpy(np.ascontiguousarray(O3._hash_uniform(n, sd))).to(dtype)
+    feats1, feats2, feats_loc = [], [], []
+    for k, c in enumerate(channels):
+        pro1, pre1 = u(b * c, seed + 10 * k).reshape(b, c), u(b * c, seed + 10 * k + 1).reshape(b, c)
+        pro2 = 0.6 * pre1 + 0.4 * u(b * c, seed + 10 * k + 2).reshape(b, c)
+        pre2 = 0.6 * pro1 + 0.4 * u(b * c, seed + 10 * k + 3).reshape(b, c)
+        prol = 0.5 * pre1.repeat(nlocal, 1) + 0.5 * u(nlocal * b * c, seed + 10 * k + 4).reshape(nlocal * b, c)
+        prel = 0.5 * pro2.repeat(nlocal, 1) + 0.5 * u(nlocal * b * c, seed + 10 * k + 5).reshape(nlocal * b, c)
+        feats1.append([pro1, pre1])
+        feats2.append([pro2, pre2])
+        feats_loc.append([prol, prel])
+    n = b * 3 * size * size
+    target = (0.5 + 0.5 * u(n, seed + 100)).reshape(b, 3, size, size)
+    mask1 = (0.5 + 0.4 * u(n, seed + 101)).reshape(b, 3, size, size)
+    masks1 = [(0.5 + 0.45 * u(n, seed + 110 + k)).reshape(b, 3, size, size) for k in range(len(channels))]
+    return feats1, feats2, feats_loc, mask1, masks1, target

@@ -81,13 +81,24 @@ def step_losses(model, batch, epoch, criterion, cosine):
     _ops.join_side_stream()                        # the cosine term below reads both views' features on the main stream
     l_global, scale = cos_loss(cosine, feats1, feats2)
     feats_loc, _, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True)
+    return assemble_losses(feats1, feats2, feats_loc, mask1, masks1, target, n, len(local_views), epoch, criterion, cosine, first=(l_global, scale))
+
+
+def assemble_losses(feats1, feats2, feats_loc, mask1, masks1, target, n, nlocal, epoch, criterion, cosine, first=None):
+    """train_2d.py:139-168 from the three forwards' outputs on: the global cosine term (its scale draw also picks the deep-supervision map), the
+    2 * nlocal local terms in the reference's order -- (view 1, local_i), (view 2, local_i) for every local view i --, the restoration term,
+    beta * the deep-supervision term, the sum.  Pure torch on whatever device the tensors live on: pinned on the CPU against the reference's own
+    `cos_loss` and a restatement of its loop body (tests/golden/loss2d_*.npz, oracle/make_golden.py --loss2d).
+    `first`: the (global term, scale) pair when the caller has already drawn it (step_losses draws it before the local views' forward, as the
+    reference does).  -> (total, restoration, global-cosine, deep-supervision, local-cosine)"""
+    l_global, scale = first if first is not None else cos_loss(cosine, feats1, feats2)
     stacked = [torch.stack(pair) for pair in feats_loc]                 # [2, 6n, C] per scale
     l_local = 0.0
-    for i in range(len(local_views)):
+    for i in range(nlocal):
         crop_i = [s[:, n * i: n * (i + 1)] for s in stacked]
         l_local = l_local + cos_loss(cosine, feats1, crop_i)[0]
         l_local = l_local + cos_loss(cosine, feats2, crop_i)[0]
-    l_local = l_local / (2 * len(local_views))
+    l_local = l_local / (2 * nlocal)
     l_restore = criterion(mask1, target)
     beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
     l_deep = beta * criterion(masks1[scale], target)

@@ -1,6 +1,7 @@
 """CPU: host logic, the C-ABI surface and the drop-in API (no GPU compute)."""
 import ctypes
 import math
+import random
 import os
 import subprocess
 import sys
@@ -442,6 +443,29 @@ def test_bench_gpus4_code_path_dry_run_gloo_world4():
     assert abs(d["per_gpu_value"] * 4 - d["value"]) < 0.02 * d["value"]
     assert d["dry_run"]["gradient_checks_passed"] >= 4 + 1 + 4 * 8 and "DRY RUN" in d["config"]["workload"]
     assert d["steps"] == 4 and d["warmup"] == 1 and d["ms_per_step"] > 0
+
+
+@pytest.mark.parametrize("tag", ["loss2d_b4_5scales", "loss2d_b2_nl3"])
+def test_2d_loss_assembly_and_draw_order_match_the_reference(tag, golden_dir, monkeypatch):
+    """What can be pinned of the 2D path without smp / torchvision: pcrlv2_amd.train_2d's `cos_loss` and loss assembly against
+    fixtures the REFERENCE's own train_2d.cos_loss produced (oracle/make_golden.py --loss2d: train_2d.py:111-117 imported, :139-168 restated around
+    it) on closed-form five-scale feature lists: all five losses to float64 round-off, the deep-supervision scale, and the 1 + 2 * nlocal scale draws
+    in the reference's order.  The 2D MODEL remains 'parity unpinned'."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pcrlv2_2d_oracle as O2
+    from pcrlv2_amd import train_2d, train_3d
+    fx = np.load(os.path.join(golden_dir, tag + ".npz"))
+    b, nl, epoch = int(fx["b"]), int(fx["nlocal"]), int(fx["epoch"])
+    f1, f2, fl, mask1, masks1, gt = O2.fill_loss_inputs(b, nl, dtype=torch.float64)
+    draws = []
+    real = random.randint
+    monkeypatch.setattr(train_3d.random, "randint", lambda a_, b_: (draws.append(real(a_, b_)) or draws[-1]))
+    random.seed(int(fx["seed"]))
+    total, l1, l2, l4, ll = train_2d.assemble_losses(f1, f2, fl, mask1, masks1, gt, b, nl, epoch, torch.nn.MSELoss(), torch.nn.CosineSimilarity())
+    assert draws == [int(v) for v in fx["draws"]] and draws[0] == int(fx["index2"])
+    for name, got in (("loss", total), ("loss1", l1), ("loss2", l2), ("loss4", l4), ("local_loss", ll)):
+        assert abs(float(got) - float(fx[name])) < 1e-12, (name, float(got), float(fx[name]))
+    assert train_2d.cos_loss is train_3d.cos_loss       # one implementation serves both loops (train_2d.py:111-117 == train_3d.py:86-92)
 
 
 def test_rank_cpu_binding_helpers():

@@ -399,3 +399,50 @@ def test_full_size_step_properties_2d_bf16():
         torch.cuda.empty_cache()
     assert results[0][0] == results[1][0], "losses differ between identical runs (non-deterministic reduction?)"
     assert torch.equal(results[0][1], results[1][1]), "parameters differ between identical runs"
+
+
+@pytest.mark.parametrize("tag", ["loss2d_b4_5scales", "loss2d_b2_nl3"])
+def test_fused_cosine_terms_and_loss_tail_match_the_reference_cos_loss_2d(tag):
+    """The ENGINE form of the 2D step's loss assembly -- the 1 + 2 * nlocal draws taken up front, all cosine means in one launch
+    (pcrl_cosine_terms_*), the total in one (pcrl_loss_total) -- against the fixture the REFERENCE's own train_2d.cos_loss produced
+    (oracle/make_golden.py --loss2d; the CPU test of the same fixture holds train_2d.assemble_losses): float32 kernels vs float64 numbers,
+    1e-6 on every component; the gradient of the total w.r.t. the prediction features against float64 autograd of the restated assembly."""
+    import math
+    import numpy as np
+    import pcrlv2_2d_oracle as O2
+    from pcrlv2_amd import functions as Fn, train_2d
+    from pcrlv2_amd.train_3d import _fused_cos_losses
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", tag + ".npz"))
+    b, nl, epoch = int(fx["b"]), int(fx["nlocal"]), int(fx["epoch"])
+    f1, f2, fl, mask1, masks1, gt = O2.fill_loss_inputs(b, nl, dtype=torch.float64)
+    # float64 autograd of the reference-shaped assembly (the CPU test pins ITS values to the reference): gradients for the comparison below
+    leaves = [t.clone().requires_grad_(True) for pair in f1 for t in pair]
+    f1g = [[leaves[2 * k], leaves[2 * k + 1]] for k in range(len(f1))]
+    random.seed(int(fx["seed"]))
+    tot64 = train_2d.assemble_losses(f1g, f2, fl, mask1, masks1, gt, b, nl, epoch, torch.nn.MSELoss(), torch.nn.CosineSimilarity())[0]
+    tot64.backward()
+
+    dev = lambda t: t.float().cuda()
+    g1 = [[dev(a).requires_grad_(True), dev(p).requires_grad_(True)] for a, p in f1]
+    g2, gl = [[dev(a), dev(p)] for a, p in f2], [[dev(a), dev(p)] for a, p in fl]
+    random.seed(int(fx["seed"]))
+    draws = [random.randint(0, len(f1) - 1) for _ in range(1 + 2 * nl)]
+    assert draws == [int(v) for v in fx["draws"]]
+    cos2, k0 = _fused_cos_losses(g1, g2, gl, b, nl, draws=draws)
+    assert k0 == int(fx["index2"])
+    l1 = Fn.mse_loss(dev(mask1), dev(gt))
+    l4raw = Fn.mse_loss(dev(masks1[k0]), dev(gt))
+    beta = 0.5 * (1.0 + math.cos(math.pi * epoch / 240))
+    total, l4, lg, ll = Fn.loss_tail(l1, cos2, l4raw, beta)
+    for name, got in (("loss", total), ("loss1", l1), ("loss2", lg), ("loss4", l4), ("local_loss", ll)):
+        assert abs(float(got) - float(fx[name])) < 1e-6, (name, float(got), float(fx[name]))
+    total.backward()
+    for k in range(len(f1)):
+        for j in range(2):
+            ref = leaves[2 * k + j].grad
+            got = g1[k][j].grad
+            if ref is None or float(ref.abs().max()) == 0.0:
+                assert got is None or float(got.abs().max()) == 0.0, (k, j)
+            else:
+                err = float((got.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+                assert err < 1e-5, (k, j, err)
