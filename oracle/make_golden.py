@@ -477,6 +477,61 @@ def make_loss2d(tag, b=4, nlocal=6, epoch=3, seed=11):
     print(f"[{tag}] loss {float(loss):+.6f} loss1 {float(loss1):.6f} loss2 {float(loss2):+.6f} loss4 {float(loss4):.6f} local {float(local_loss):+.6f} draws {draws}")
 
 
+def make_mfma_pin(tag, refmod):
+    """Tight pin of the bf16 MFMA kernels.  The REAL reference modules -- `LUConv(Ci, Co, 'relu', 'bn')` and
+    `UpTransition(C, C, 0, 'relu', 'bn')` of models/pcrlv2_model_3d.py -- evaluated in float64 (oneDNN off) on operands that are exactly
+    representable in bfloat16 (pcrlv2_oracle.mfma_pin_*_case), so that a bf16 MFMA kernel differs from these numbers by float32 accumulation
+    order only.  Per convolution case: samples of conv1's output, the BatchNorm3d running statistics the module holds after ONE training-mode
+    forward (= 0.1 x the batch statistics of conv1's output: the observable the kernels' (sum, sum^2) rows are held to), and from autograd of
+    the module's own conv1 on a bf16-exact upstream gradient: samples of the data gradient, samples + norm of the weight gradient, the bias
+    gradient.  Per composed case: the same for `ops[0].conv1(up_conv(x))` (its output, ops[0].bn1's running statistics, the data gradient)."""
+    torch.set_num_threads(8)
+    out = {}
+    K = 4096
+    with torch.backends.mkldnn.flags(enabled=False):
+        for name in O.MFMA_PIN_CONV:
+            N, dhw, Ci, Co = O.MFMA_PIN_CONV[name]
+            c = O.mfma_pin_conv_case(name)
+            m = refmod.LUConv(Ci, Co, 'relu', 'bn').double().train()
+            with torch.no_grad():
+                m.conv1.weight.copy_(c["w"]); m.conv1.bias.copy_(c["b"]); m.bn1.weight.copy_(c["gamma"]); m.bn1.bias.copy_(c["beta"])
+            keep = {}
+            h = m.conv1.register_forward_hook(lambda mod, i, o: keep.__setitem__("y", o.detach()))
+            m(c["x"])
+            h.remove()
+            y = keep["y"]
+            xr = c["x"].clone().requires_grad_(True)
+            m.zero_grad()
+            m.conv1(xr).backward(c["dy"])
+            fy, fdx, fdw = y.reshape(-1), xr.grad.reshape(-1), m.conv1.weight.grad.reshape(-1)
+            out.update({f"{name}.y": fy[sample_idx(fy.numel(), K, 3)].numpy(), f"{name}.running_mean": m.bn1.running_mean.numpy().copy(),
+                        f"{name}.running_var": m.bn1.running_var.numpy().copy(), f"{name}.dx": fdx[sample_idx(fdx.numel(), K, 4)].numpy(),
+                        f"{name}.dw": fdw[sample_idx(fdw.numel(), K, 5)].numpy(), f"{name}.dw_l2": np.float64(fdw.norm()), f"{name}.dw_max": np.float64(fdw.abs().max()),
+                        f"{name}.db": m.conv1.bias.grad.numpy().copy(), f"{name}.y_max": np.float64(fy.abs().max()), f"{name}.dx_max": np.float64(fdx.abs().max())})
+            print(f"[{tag}] {name}: |y| max {float(fy.abs().max()):.3f}  |dx| max {float(fdx.abs().max()):.3f}  |dw| l2 {float(fdw.norm()):.3f}")
+        for name in O.MFMA_PIN_UP:
+            N, dhw, C = O.MFMA_PIN_UP[name]
+            c = O.mfma_pin_up_case(name)
+            m = refmod.UpTransition(C, C, 0, 'relu', 'bn').double().train()
+            with torch.no_grad():
+                m.up_conv.weight.copy_(c["w_up"]); m.up_conv.bias.copy_(c["b_up"]); m.ops[0].conv1.weight.copy_(c["w0"]); m.ops[0].conv1.bias.copy_(c["b0"])
+            keep = {}
+            h = m.ops[0].conv1.register_forward_hook(lambda mod, i, o: keep.__setitem__("y", o.detach()))
+            m.ops[0](m.up_conv(c["x"]))     # UpTransition.forward's `self.ops(self.up_conv(x))` down to ops[0] (pcrlv2_model_3d.py:61-64; the heads' BatchNorm1d needs b >= 2)
+            h.remove()
+            y0 = keep["y"]
+            xr = c["x"].clone().requires_grad_(True)
+            m.zero_grad()
+            m.ops[0].conv1(m.up_conv(xr)).backward(c["dy0"])
+            fy, fdx = y0.reshape(-1), xr.grad.reshape(-1)
+            out.update({f"{name}.y": fy[sample_idx(fy.numel(), K, 3)].numpy(), f"{name}.running_mean": m.ops[0].bn1.running_mean.numpy().copy(),
+                        f"{name}.running_var": m.ops[0].bn1.running_var.numpy().copy(), f"{name}.dx": fdx[sample_idx(fdx.numel(), K, 4)].numpy(),
+                        f"{name}.y_max": np.float64(fy.abs().max()), f"{name}.dx_max": np.float64(fdx.abs().max())})
+            print(f"[{tag}] {name}: |y0| max {float(fy.abs().max()):.3f}  |dx| max {float(fdx.abs().max()):.3f}")
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out)
+    print(f"[{tag}] wrote fixture")
+
+
 def make_eval(tag, b, dhw, refmod, ref_train, ref_utils):
     """Eval-mode forward of the REAL reference (model.eval(): running statistics) on a state whose buffers were moved by one oracle
     training step -- what a consumer of the checkpoint runs (README.md:48-55).  The tests rebuild the state with the oracle (it is
@@ -703,6 +758,9 @@ def main():
     if "--data-parallel" in sys.argv:
         # nn.DataParallel semantics (train_3d.py:54) on two replicas of b = 4
         make_dp("dp2_b4x2_32x32x16", 4, (32, 32, 16), 2, 2, refmod, ref_train, ref_utils)
+        return
+    if "--mfma-pin" in sys.argv:
+        make_mfma_pin("mfma_pin", refmod)
         return
     if "--loss2d" in sys.argv:
         make_loss2d("loss2d_b4_5scales")

@@ -28,8 +28,16 @@ DECODER_CHANNELS = (256, 128, 64, 32, 16)          # pcrlv2_model.py:137
 BETA_PERIOD = 240                                  # train_2d.py:166
 
 
+EVAL = False      # True (set by model_forward(..., training=False)): nn.Module.eval() -- every BatchNorm uses its running statistics, nothing is updated
+
+
 def _bn(x, sd, prefix, state_out=None):
-    """nn.BatchNorm{1,2}d in training mode: batch statistics (biased variance) + running-stat update (unbiased)."""
+    """nn.BatchNorm{1,2}d in training mode: batch statistics (biased variance) + running-stat update (unbiased); in eval mode (EVAL) the running
+    statistics, no update."""
+    if EVAL:
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        rm, rv = sd[prefix + ".running_mean"].to(x.dtype), sd[prefix + ".running_var"].to(x.dtype)
+        return (x - rm.view(shape)) / torch.sqrt(rv.view(shape) + BN_EPS) * sd[prefix + ".weight"].view(shape) + sd[prefix + ".bias"].view(shape)
     dims = [0] + list(range(2, x.dim()))
     mean = x.mean(dims)
     var = x.var(dims, unbiased=False)
@@ -81,8 +89,16 @@ def decoder_block(x, sd, p, so=None):
     return x, x_pro, x_pre, x_mask
 
 
-def model_forward(x, sd, local=False, so=None):
-    """PCRLv2.forward, pcrlv2_model.py:203-209 (the decoder is always called with local=False there: quirk kept)."""
+def model_forward(x, sd, local=False, so=None, training=True):
+    """PCRLv2.forward, pcrlv2_model.py:203-209 (the decoder is always called with local=False there: quirk kept).
+    training=False: the same forward under nn.Module.eval() (running statistics, no buffer updates)."""
+    global EVAL
+    if not training:
+        EVAL = True
+        try:
+            return model_forward(x, sd, local, None, True)
+        finally:
+            EVAL = False
     feats = encoder_forward(x, sd, so)
     h = feats[1:][::-1][0]                                                                                      # :177-180
     outs, masks_mid = [], []

@@ -169,6 +169,64 @@ def fill_batch(b: int, dhw=(32, 32, 16), local=16, dtype=torch.float64, seed: in
 
 
 # ----------------------------------------------------------------------------------------
+# bf16-EXACT operator cases for the tight pin of the MFMA kernels (oracle/make_golden.py --mfma-pin,
+# tests/test_mfma_pin_gpu.py).  Every operand is exactly representable in bfloat16, so a bf16 MFMA kernel forms exact products and
+# differs from a float64 evaluation only by float32 accumulation order: its float32 outputs (BatchNorm partial statistics, weight
+# gradients) can be held at float32-class tolerance, its bf16 outputs at "equal to the correctly rounded reference, up to one ulp on
+# the rare round-off ties".
+# ----------------------------------------------------------------------------------------
+MFMA_PIN_CONV = {      # name -> (N, (D, H, W), Ci, Co): all tile into 4 x 8 x 16 bricks (the last: along (D, W, H) -- the PERM instantiations)
+    "lu_32_64": (2, (8, 16, 32), 32, 64),
+    "lu_128_64": (1, (4, 8, 16), 128, 64),
+    "lu_64_128": (1, (8, 16, 16), 64, 128),
+    "lu_64_64_perm": (1, (8, 32, 8), 64, 64),
+}
+MFMA_PIN_UP = {        # name -> (N, coarse (D, H, W), C of UpTransition(C, C, 0): ConvTranspose3d(C -> C) into LUConv(C -> 64))
+    "up_128": (1, (4, 8, 16), 128),
+    "up_64_perm": (2, (4, 16, 8), 64),
+}
+
+
+def _bf16_exact(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16).double()
+
+
+def mfma_pin_conv_case(name: str):
+    """-> dict of float64 tensors, all bf16-representable: x [N,Ci,D,H,W], w [Co,Ci,3,3,3], dy [N,Co,D,H,W]; plus float64 b, gamma, beta [Co]."""
+    N, (D, H, W), Ci, Co = MFMA_PIN_CONV[name]
+    sd = _name_seed(name) % 100000
+    x = _bf16_exact(_hash_uniform(N * Ci * D * H * W, sd).reshape(N, Ci, D, H, W) * 1.5)
+    w = _bf16_exact(_hash_uniform(Co * Ci * 27, sd + 1).reshape(Co, Ci, 3, 3, 3) * (1.2 / math.sqrt(27 * Ci)))
+    dy = _bf16_exact(_hash_uniform(N * Co * D * H * W, sd + 2).reshape(N, Co, D, H, W))
+    f = lambda n, k, lo, sc: torch.from_numpy(lo + sc * _hash_uniform(n, sd + k)).double()
+    return dict(x=x, w=w, dy=dy, b=f(Co, 3, 0.0, 0.2), gamma=f(Co, 4, 1.0, 0.3), beta=f(Co, 5, 0.0, 0.3))
+
+
+def mfma_pin_up_case(name: str):
+    """Weights of ConvTranspose3d(C -> C, k2 s2) and Conv3d(C -> 64, 3x3x3) whose COMPOSED 8-tap phase weights are exactly
+    representable in bf16: the transposed convolution is sparse (two non-zero intermediate channels per (input channel, position), values
+    +-1/4, +-1/2), the 3x3x3 weights are small integers / 32 -- every composed entry is k / 128 with |k| <= 64.
+    -> x [N,C,D,H,W] (bf16-exact), w_up [C,C,2,2,2], b_up [C], w0 [64,C,3,3,3], b0 [64], dy0 [N,64,2D,2H,2W] (bf16-exact)."""
+    N, (D, H, W), C = MFMA_PIN_UP[name]
+    Co = 64
+    sd = _name_seed(name) % 100000
+    x = _bf16_exact(_hash_uniform(N * C * D * H * W, sd).reshape(N, C, D, H, W) * 1.5)
+    u = _hash_uniform(C * 8 * 4, sd + 1).reshape(C, 8, 4)
+    w_up = np.zeros((C, C, 8))
+    for ci in range(C):
+        for s in range(8):
+            c0 = int((u[ci, s, 0] * 0.5 + 0.5) * C) % C
+            c1 = (c0 + 1 + int((u[ci, s, 1] * 0.5 + 0.5) * (C - 1))) % C
+            w_up[ci, c0, s] = (0.25 if u[ci, s, 2] < 0 else 0.5) * (1 if u[ci, s, 3] < 0 else -1)
+            w_up[ci, c1, s] = (0.5 if u[ci, s, 2] < 0.3 else 0.25) * (-1 if u[ci, s, 3] < 0.2 else 1)
+    w_up = torch.from_numpy(w_up.reshape(C, C, 2, 2, 2)).double()
+    w0 = torch.from_numpy(np.round(_hash_uniform(Co * C * 27, sd + 2).reshape(Co, C, 3, 3, 3) * 2.49) / 32.0).double()
+    dy0 = _bf16_exact(_hash_uniform(N * Co * 8 * D * H * W, sd + 3).reshape(N, Co, 2 * D, 2 * H, 2 * W))
+    f = lambda n, k, sc: torch.from_numpy(sc * _hash_uniform(n, sd + k)).double()
+    return dict(x=x, w_up=w_up, b_up=f(C, 4, 0.3), w0=w0, b0=f(Co, 5, 0.2), dy0=dy0)
+
+
+# ----------------------------------------------------------------------------------------
 # Forward pass
 # ----------------------------------------------------------------------------------------
 _CFG = {"act": "relu", "norm": "bn"}   # constructor variant in force (forward(act=, norm=)); the default is what train_3d.py:45 instantiates

@@ -314,9 +314,47 @@ class PCRLv2(nn.Module):
         ops.bump_weights_epoch()
         return out
 
+    # ---- model.eval(): what a consumer of the saved encoder / model runs (README.md:31-45) -- the same convolution / normalisation kernels on
+    #      the RUNNING statistics, nothing updated, no autograd graph (the 2D model raised outside train mode) ----
+    @staticmethod
+    def _unit_eval(u, x, dt, out_f32=False):
+        c, n = u.conv, u.bn_module
+        if n is None:
+            return ops2d.conv2d_forward(x, c.weight, c.bias, u._packed, u.stride, u.pad, 0, dt, want_stats=False, out_f32=True)[0]
+        y = ops2d.conv2d_forward(x, c.weight, c.bias, u._packed, u.stride, u.pad, u.up, dt, want_stats=False)[0]
+        N, H, W, C = ops2d.dims2(y)
+        scale, shift = ops.bn_eval_coef(n.weight, n.bias, n.running_mean, n.running_var)
+        return ops.bn_act_apply(y, scale, shift, N * H * W, C, u.act, dt)
+
+    @torch.no_grad()
+    def _forward_eval(self, x, local=False):
+        if not x.is_cuda:
+            raise RuntimeError("PCRLv2 (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
+        dt, ue = self.compute_dtype, self._unit_eval
+        enc = self.model.encoder
+        h = ue(enc._stem, ops2d.image_to_act(x.float(), dt, 8), dt)
+        h = ops2d.maxpool_forward(h, dt)[0]
+        for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
+            for blk in layer:
+                t = ue(blk._u2, ue(blk._u1, h, dt), dt)
+                idn = h if blk._ud is None else ue(blk._ud, h, dt)
+                h = ops2d.add_relu_forward(t, ops2d.to_act2(idn, dt), dt)
+        decoder_outputs, middle_masks = [], []
+        for i, blk in enumerate(self.model.decoder.blocks):
+            h = ue(blk._u2, ue(blk._u1, h, dt), dt)
+            ph = blk.predictor_head
+            g = ops2d.gap_forward(h, dt)
+            x_pro = ops.bn1d_eval(g, blk.bn.weight, blk.bn.bias, blk.bn.running_mean, blk.bn.running_var, relu=False)
+            hid = ops.bn1d_eval(ops.linear_forward(x_pro, ph[0].weight, ph[0].bias), ph[1].weight, ph[1].bias, ph[1].running_mean, ph[1].running_var, relu=True)
+            x_pre = ops.linear_forward(hid, ph[3].weight, ph[3].bias)
+            decoder_outputs.append((x_pro, x_pre))
+            x_mask = ue(blk._ud3, ue(blk._ud0, h, dt), dt)
+            # (reference quirk, kept: PCRLv2.forward never hands `local` to the decoder -- the maps are upsampled for the local views too)
+            middle_masks.append(ops2d.bilinear_forward(ops2d.to_act2(x_mask, torch.float32), 2 ** (4 - i)))
+        masks = None if local else ue(self._seg, h, dt)
+        return decoder_outputs, masks, middle_masks
+
     def _begin_pass(self, x):
-        if not self.training:
-            raise NotImplementedError("PCRLv2 on the MI355X engine implements the pre-training (train-mode) path only")
         if not x.is_cuda:
             raise RuntimeError("PCRLv2 (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
         pass_idx = ops.next_pass()
@@ -327,6 +365,8 @@ class PCRLv2(nn.Module):
 
     def forward(self, x, local=False):
         """-> ([(pro, pre) x 5], masks [b,n_class,H,W] | None, [mask x 5])"""
+        if not self.training:
+            return self._forward_eval(x, local)
         self._begin_pass(x)
         features = [None] * 5 + [self.model.encoder.forward_last(x)]      # the decoder reads the last feature map only
         decoder_outputs, h, middle_masks = self.model.decoder(features)
@@ -342,6 +382,8 @@ class PCRLv2(nn.Module):
         output), the bilinear upsampling, and the deep-supervision maps of every scale but `mask_scale` (the scale the first cos_loss
         draws; None: no map at all -- the second view and the local views, whose maps the reference computes and never reads).
         -> ([(pro, pre) x 5], decoder output (activation), deep-supervision map of `mask_scale` at its own resolution | None)"""
+        if not self.training:
+            raise RuntimeError("PCRLv2.forward_engine is the TRAINING step's forward; in eval mode call the model (forward)")
         self._begin_pass(x)
         features = [None] * 5 + [self.model.encoder.forward_last(x)]
         decoder_outputs, h, low = self.model.decoder(features, _mask_scales=() if mask_scale is None else (mask_scale,), _upsample=False)

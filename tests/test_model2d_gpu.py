@@ -1,5 +1,6 @@
 """2D path: PCRLv2 (ResNet-18 U-Net) forward / losses / gradients / SGD on the HIP engine against the CPU oracle
 (oracle/pcrlv2_2d_oracle.py, PARITY UNPINNED: a restatement, the reference's 2D model cannot be imported in this image)."""
+import math
 import os
 import random
 import sys
@@ -446,3 +447,56 @@ def test_fused_cosine_terms_and_loss_tail_match_the_reference_cos_loss_2d(tag):
             else:
                 err = float((got.double().cpu() - ref).abs().max()) / float(ref.abs().max())
                 assert err < 1e-5, (k, j, err)
+
+
+@pytest.mark.parametrize("dtype,local", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, False)])
+def test_eval_mode_forward_uses_the_running_statistics_2d(dtype, local):
+    """PCRLv2.eval() (what a consumer of the saved model runs, README.md:31-45; VERDICT r4: it raised NotImplementedError): two training steps move the
+    running statistics away from their initial values, then `model.eval()` forward against the 2D oracle in eval mode (running statistics, nothing
+    updated): float32 features / maps / reconstruction at 2e-4 relative to the largest entry, bf16 at 4e-2; the state_dict is bit-unchanged by the eval
+    forward, and train() afterwards is the training path again.  (2D parity unpinned: the oracle is a restatement.)"""
+    import pcrlv2_2d_oracle as O2
+    from pcrlv2_amd import train_2d
+    from pcrlv2_amd.optim import FusedSGD
+    from pcrlv2_amd.train_3d import CosineSimilarityMean
+    model = _build(seed=5, dtype=dtype)
+    model.train()
+    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    random.seed(1)
+    for s in range(2):
+        train_2d.train_step(model, opt, O2.synthetic_batch(4, 64, 32, seed=40 + s), 0, train_2d.MSELoss2d(), CosineSimilarityMean())
+    torch.cuda.synchronize()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    assert float((before["model.encoder.bn1.running_mean"]).abs().max()) > 0          # the statistics have moved
+    model.eval()
+    x = O2.synthetic_batch(3, 64, 32, seed=77)[0]
+    with torch.no_grad():
+        outs, masks, mids = model(x.cuda(), local=local)
+    torch.cuda.synchronize()
+    after = model.state_dict()
+    for k in before:
+        assert torch.equal(before[k], after[k]), k                                      # eval forward updates nothing
+    sd = {k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in before.items()}
+    with torch.no_grad():
+        r_outs, r_masks, r_mids = O2.model_forward(x.double(), sd, local=local, training=False)
+    tol = 2e-4 if dtype == torch.float32 else 4e-2
+
+    def close(got, ref, what):
+        got = got.detach().float().cpu().double()
+        if got.dim() == 4 and got.shape != ref.shape:
+            got = got.permute(0, 3, 1, 2) if got.shape[-1] == ref.shape[1] else got
+        err = float((got.reshape(ref.shape) - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+        assert err < tol, (what, err)
+    for i, ((pro, pre), (rpro, rpre)) in enumerate(zip(outs, r_outs)):
+        close(pro, rpro, f"x_pro[{i}]")
+        close(pre, rpre, f"x_pre[{i}]")
+    assert (masks is None) == (r_masks is None) == local
+    if not local:
+        close(masks, r_masks, "reconstruction")
+    assert len(mids) == 5
+    for i, (m, rm) in enumerate(zip(mids, r_mids)):
+        close(m, rm, f"deep-supervision map {i}")
+    model.train()
+    random.seed(2)
+    out = train_2d.train_step(model, opt, O2.synthetic_batch(4, 64, 32, seed=50), 0, train_2d.MSELoss2d(), CosineSimilarityMean())
+    assert all(math.isfinite(float(v)) for v in out)
