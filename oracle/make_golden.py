@@ -364,7 +364,7 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
     torch.set_num_threads(8)
     names = ("loss", "loss1", "loss2", "loss4", "local_loss")
 
-    def run(dt, onednn):
+    def run(dt, onednn, partial=None):
         st0 = O.fill_state(dt)
         model = refmod.PCRLv23d().to(dt)
         model.load_state_dict(st0, strict=True)
@@ -388,6 +388,8 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
                 rows.append([float(r[k].detach()) for k in names] + [float(r["index2"])])
                 if s % 20 == 0 or s == nsteps - 1:
                     print(f"[{tag}] {dt} step {s}: {rows[-1]}", flush=True)
+                if partial is not None and (s + 1) % 25 == 0:
+                    partial(np.array(rows))       # the float64 run takes hours: a usable (shorter) fixture exists from step 25 on
         return np.array(rows)
 
     def ema_of(v):
@@ -397,7 +399,8 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
             out.append(e)
         return np.array(out)
 
-    def save(c64, c32):
+    def save(c64, c32, name=None):
+        name = name or tag
         ref = c64 if c64 is not None else c32
         e_ref = ema_of(ref[:, 0])
         extra = {}
@@ -410,15 +413,19 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
             for i, k in enumerate(names):
                 print(f"[{tag}] stock fp32 vs fp64 over {n} steps, {k}: max {d[:, i].max():.3e} mean {d[:, i].mean():.3e}")
             print(f"[{tag}] stock fp32 EMA(total) vs fp64 after step 20: max {float(extra['stock_fp32_ema_max_after20']):.3e}")
-        np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), curve=ref, ema_total=e_ref, ema=np.float64(ema), b=np.int64(b), dhw=np.array(dhw),
+        np.savez_compressed(os.path.join(OUT if name == tag else "/tmp", f"{name}.npz"), curve=ref, ema_total=e_ref, ema=np.float64(ema), b=np.int64(b), dhw=np.array(dhw),
                             nsteps=np.int64(len(ref)), epoch=np.int64(epoch), base_lr=np.float64(base_lr), seed=np.int64(seed), batch_seed0=np.int64(2000),
                             reference_dtype="float64, oneDNN off" if c64 is not None else "float32, stock (oneDNN on)", stock_fp32_curve=c32, **extra)
 
     # stock float32 first (minutes) so that a fixture exists early; the float64 run (~35 s per step on 8 cores: ATen's float64 convolutions
     # take the native im2col path) then replaces `curve`; `reference_dtype` says which one a file holds
-    c32 = run(torch.float32, True)
-    save(None, c32)
-    c64 = run(torch.float64, False)
+    cache = os.path.join(OUT, f"{tag}.npz")
+    if "--reuse-fp32" in sys.argv and os.path.exists(cache):
+        c32 = np.load(cache, allow_pickle=True)["stock_fp32_curve"]
+    else:
+        c32 = run(torch.float32, True)
+        save(None, c32)
+    c64 = run(torch.float64, False, partial=lambda rows: save(rows, c32, tag + "_partial_fp64"))     # partial float64 curves go to /tmp; the fixture is replaced when complete
     save(c64, c32)
     print(f"[{tag}] wrote fixture ({nsteps} steps)")
 

@@ -76,7 +76,13 @@ class SyntheticLunaLoader:
             x1 = torch.randn(self.b, 1, 64, 64, 32, **kw)
             x2 = x1 + 0.1 * torch.randn(self.b, 1, 64, 64, 32, **kw)
             gt = torch.rand(self.b, 1, 64, 64, 32, **kw)
-            loc = [torch.randn(self.b, 1, 16, 16, 16, **kw) for _ in range(6)]
+            # local views = 16^3 crops of the first global view + noise, as the real loader's are crops of the same volume (lunaDataset.py:60-78) and as
+            # SURVEY 8(d) prescribes for loss-curve runs: with i.i.d. noise locals the local cosine term has no signal and its trajectory is chaotic
+            # (round 5: bf16 and float32 runs of 2 000 steps ended 0.27 apart in that term alone, profiles/r05_long_run_compare_iid_locals.txt)
+            loc = []
+            for i in range(6):
+                d0, h0, w0 = (i * 9) % 49, (i * 11) % 49, (i * 3) % 17
+                loc.append(x1[:, :, d0:d0 + 16, h0:h0 + 16, w0:w0 + 16] + 0.1 * torch.randn(self.b, 1, 16, 16, 16, **kw))
             yield x1, x2, gt, gt, loc
 
 
