@@ -451,7 +451,11 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
     }
   }
 #else   // the round-3 form: D = X * W^T, a lane holds 4 voxels of one channel, two-byte stores (A/B: tools/build_variant.sh ... -DBRICK_TRANSPOSED=0)
-  // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick) ----
+  // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick).  Voxel of (fm, r) in the wave's 64: d offset = wave, h offset =
+  //      2 fm + (lg >> 1), w offset = 4 (lg & 1) + r.  Addresses (round 5, as in conv_brick16.h): a SCALAR base per (fm, r) -- the wave's first voxel +
+  //      2 fm h-steps + r w-steps -- plus ONE lane offset and the store's immediate (32 j bytes): the 64-bit voxel index per (fm, r) that was rebuilt
+  //      on the vector unit (34 quarter-rate multiplies + 17 64-bit multiply-adds per lane; with 9 taps per chunk in the 2D geometry the epilogue and
+  //      prologue were MORE instructions than the stage loop) is gone. ----
   float s1[FN], s2[FN], bv[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
@@ -461,24 +465,30 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   }
   const int uch0 = UPCF ? n0 - uph * p.upc : n0;   // first channel of this tile (inside its phase)
   const int ypitch = UPCF ? p.upc : p.Nc;
+  // byte steps of the output along the brick's h and w axes (composed forward: a coarse step is two fine voxels)
+  const int64_t HS = (int64_t)(UPCF ? 2 * p.fsh : p.sh) * ypitch * 2, WS = (int64_t)(UPCF ? 2 * p.fsw : p.sw) * ypitch * 2;
+  const int64_t row0 = UPCF ? (int64_t)n * (8 * p.D * p.H * p.W) + (int64_t)(2 * (d0 + wid) + upd) * p.fsd + (int64_t)(2 * h0 + uphh) * p.fsh + (int64_t)(2 * w0 + upw) * p.fsw
+                            : (int64_t)n * p.D * p.H * p.W + (int64_t)(d0 + wid) * p.sd + (int64_t)h0 * p.sh + (int64_t)w0 * p.sw;
+  char* const ybase = reinterpret_cast<char*>(p.y) + (row0 * ypitch + uch0) * 2;      // wave-uniform
+  const uint32_t yl = (uint32_t)((lg >> 1) * HS + (lg & 1) * 4 * WS + lr * 2);
+  const int fd_ = 2 * (d0 + wid) + upd;
+  const int cd = fd_ == 0 ? 0 : (fd_ == 2 * p.D - 1 ? 2 : 1);
 #pragma unroll
   for (int fm = 0; fm < 4; ++fm) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int v = wid * 64 + fm * 16 + lg * 4 + r;
-      int64_t row = (int64_t)n * p.D * p.H * p.W + (int64_t)(d0 + (v >> 6)) * p.sd + (h0 + ((v >> 3) & 7)) * p.sh + (w0 + (v & 7)) * p.sw;
-      if (UPCF) {   // the phase's fine voxel, and the bias of its border class (0 first, 1 inside, 2 last per axis; class number in memory order = tap strides)
-        const int fd = 2 * (d0 + (v >> 6)) + upd, fh = 2 * (h0 + ((v >> 3) & 7)) + uphh, fw = 2 * (w0 + (v & 7)) + upw;
-        row = (int64_t)n * (8 * p.D * p.H * p.W) + (int64_t)fd * p.fsd + fh * p.fsh + fw * p.fsw;
-        const int cd = fd == 0 ? 0 : (fd == 2 * p.D - 1 ? 2 : 1), ch = fh == 0 ? 0 : (fh == 2 * p.H - 1 ? 2 : 1), cw = fw == 0 ? 0 : (fw == 2 * p.W - 1 ? 2 : 1);
+      if (UPCF) {   // bias of the fine voxel's border class (0 first, 1 inside, 2 last per axis; class number in memory order = tap strides)
+        const int fh = 2 * (h0 + 2 * fm + (lg >> 1)) + uphh, fw = 2 * (w0 + 4 * (lg & 1) + r) + upw;
+        const int ch = fh == 0 ? 0 : (fh == 2 * p.H - 1 ? 2 : 1), cw = fw == 0 ? 0 : (fw == 2 * p.W - 1 ? 2 : 1);
         const int cls = cd * p.td + ch * p.th + cw * p.tw;
 #pragma unroll
         for (int j = 0; j < FN; ++j) bv[j] = p.bias_tab[cls * p.upc + uch0 + j * 16 + lr];
       }
+      char* const yrow = ybase + (int64_t)(2 * fm) * HS + (int64_t)r * WS;   // scalar
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const float val = acc[fm][j][r] + bv[j];
-        if (!(BRICK_ABL & 1) || val == 12345.678f) p.y[row * ypitch + uch0 + j * 16 + lr] = (bf16)val;
+        if (!(BRICK_ABL & 1) || val == 12345.678f) *reinterpret_cast<bf16*>(yrow + yl + j * 32) = (bf16)val;
         s1[j] += val;
         s2[j] += val * val;
       }
