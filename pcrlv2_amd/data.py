@@ -329,9 +329,15 @@ class AugmentedLoader:
             if not use_slots:
                 print(f"[pcrlv2_amd.data] /dev/shm has no room for {need / 2**20:.0f} MB of batch slots: falling back to torch's pin_memory thread (slower, see PCRL_LOADER_PIN)")
         if use_slots:
-            pair_buf = torch.empty((nslots, batch_size) + pshape, dtype=torch.float32).share_memory_()
-            local_buf = torch.empty((nslots, batch_size) + lshape, dtype=torch.float32).share_memory_()
+            # zero-filled right after share_memory_(): the pages are COMMITTED now, so the /dev/shm room check of the next loader / rank sees real
+            # usage instead of passing on sparse files and dying with SIGBUS later
+            pair_buf = torch.empty((nslots, batch_size) + pshape, dtype=torch.float32).share_memory_().zero_()
+            local_buf = torch.empty((nslots, batch_size) + lshape, dtype=torch.float32).share_memory_().zero_()
             pinned = _pin_registered(pair_buf) and _pin_registered(local_buf)
+            if not pinned:
+                # the copies out of pageable shared memory would be synchronous staged copies: the 841 -> 1015 crops/s of the slot loader is gone
+                print("[pcrlv2_amd.data] warning: hipHostRegister refused the shared batch slots (locked-memory limit?): host-to-device copies are "
+                      "staged and synchronous -- expect the loader to fall behind the step (PCRL_LOADER_PIN=ring copies into pinned buffers instead)", flush=True)
             self.slots = (pair_buf, local_buf, pinned)
             self.loader = torch.utils.data.DataLoader(_SlotCrops(files, pair_buf, local_buf), num_workers=workers, collate_fn=lambda items: (items[0][0], len(items)),
                                                       batch_sampler=_SlotBatches(len(files), batch_size, shuffle, drop_last, nslots, seed),
@@ -380,6 +386,22 @@ class AugmentedLoader:
         slot[1][:B].copy_(local)
         return slot[0][:B], slot[1][:B], slot
 
+    def close(self):
+        """Release the page-lock on the shared batch slots (hipHostUnregister); the loader is unusable afterwards."""
+        if self.slots is not None and self.slots[2]:
+            for t in self.slots[:2]:
+                try:
+                    torch.cuda.cudart().cudaHostUnregister(t.data_ptr())
+                except Exception:
+                    pass
+        self.slots = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def __iter__(self):
         import time
         if not AUG_STREAM:
@@ -390,6 +412,10 @@ class AugmentedLoader:
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=dev)
         ahead = None
+        # A consumer that left the previous epoch early (a fixed step count with persistent workers) leaves index batches dispatched and slots
+        # whose copies were never event-checked: drain this loader's stream and forget the old events before slots are handed out again
+        self._stream.synchronize()
+        self._events = []
         it = iter(self.loader)
         tm = self.timing
         while True:

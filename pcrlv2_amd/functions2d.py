@@ -227,12 +227,14 @@ class EncoderFn(Function):
             if getattr(stem, "_packed_stem", None) is None:
                 stem._packed_stem = ops2d.PackedStem()
             img = x
+            ctx.stem_kernel = True
             y0, partial, rows = ops2d.stem_forward(x, w0_, stem._packed_stem, dt)
             N, H, W, C = ops2d.dims2(y0)
             bn0 = stem.bn_module
             c0 = ops.bn_finalize(partial, rows, C, N * H * W, g0_.detach(), be0_.detach(), bn0.running_mean, bn0.running_var)
             stem._count_batch()
         else:
+            ctx.stem_kernel = False
             img = ops2d.image_to_act(x, dt, 8)
             y0, c0 = conv_bn(img, stem)
         N, H, W, C = ops2d.dims2(y0)
@@ -294,8 +296,6 @@ class EncoderFn(Function):
         for k in range(len(ctx.saved) - 1, -1, -1):
             blk, h_in, y1, c1, a1, y2, c2, yd, cd, M, C = ctx.saved[k]
             d_a1 = bn_conv_bwd(g, blk._u2, a1, y2, c2, M, C, ACT_NONE)
-            Ci = h_in.shape[1]
-            Mi = h_in.numel() // Ci
             first = bn_conv_bwd(d_a1, blk._u1, h_in, y1, c1, M, C, ACT_RELU)
             second = bn_conv_bwd(g, blk._ud, h_in, yd, cd, M, C, ACT_NONE) if blk._ud is not None else g
             if k > 0:
@@ -305,7 +305,7 @@ class EncoderFn(Function):
         img, y0, c0, idx, (N, H, W, C) = ctx.stem
         da0 = ops2d.new_act2(N, H, W, C, dt, y0.device)
         L.call("pcrl_maxpool2d_3s2_bwd_sum", first, second, idx, da0, N, H, W, C, dtype_code(dt), stream_handle())
-        if img.dtype == torch.float32 and img.shape[1] == 3:      # the dedicated stem kernels ran forward: their weight gradient
+        if ctx.stem_kernel:      # the dedicated stem kernels ran forward (recorded there, not inferred from the saved tensor): their weight gradient
             u0 = ctx.units[0]
             w0_, g0_, _ = P[0]
             dy0, dg0, db0 = ops.bn_act_backward(da0, y0, g0_.detach(), c0[0], c0[1], c0[2], c0[3], N * H * W, C, ACT_RELU, dt)
@@ -314,6 +314,7 @@ class EncoderFn(Function):
             bn_conv_bwd(da0, ctx.units[0], img, y0, c0, N * H * W, C, ACT_RELU, need_dx=False)
         out = (None, None) + tuple(_park(p, grads.get(i)) for i, p in enumerate(ctx.plist))
         mark_final(ctx, ctx.plist)
+        ctx.saved = ctx.outs = ctx.stem = None      # intermediates held on ctx (not saved tensors): released with the backward, not with the graph
         return out
 
 
@@ -426,6 +427,7 @@ class DecoderBlockFn(Function):
             pg[0], pg[1], pg[2], pg[3], pg[4], pg[5] = g_w1, g_g1, g_be1, g_w2, g_g2, g_be2
         out = (dx,) + tuple(_park(p, g) for p, g in zip(ctx.plist, pg)) + (None, None)
         mark_final(ctx, ctx.plist)
+        ctx.x = ctx.l1 = ctx.l2 = ctx.ld = ctx.heads = None      # per-block activations held on ctx: released with the backward
         return out
 
 

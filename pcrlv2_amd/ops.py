@@ -365,7 +365,9 @@ def empty_cache(device=None):
     for seg in torch.cuda.memory_snapshot():
         if seg["device"] == idx and seg["address"] in mine and seg["stream"] in streams:
             for blk in seg["blocks"]:
-                if blk["state"] == "inactive" and blk["size"] >= 512:
+                # placeholders only for blocks of 1 MiB and more: a smaller request is served from the allocator's SMALL pool -- it cannot occupy a
+                # sub-MiB hole inside a provisioned large-pool segment and would open fresh 2 MiB segments that then stay cached
+                if blk["state"] == "inactive" and blk["size"] >= (1 << 20):
                     by_stream[seg["stream"]].append(blk["size"])
     for sid, sizes in by_stream.items():
         with torch.cuda.stream(streams[sid]):
@@ -376,6 +378,22 @@ def empty_cache(device=None):
                     break
     torch.cuda.empty_cache()
     del hold
+    # best fit may have put a placeholder into a segment that was NOT provisioned and left a provisioned one wholly free (released above): say so
+    # once -- the next step re-reserves it (a device-wide stall), which is what this function exists to avoid
+    left = {seg["address"] for seg in torch.cuda.memory_snapshot() if seg["device"] == idx}
+    lost = [a for a in mine if a not in left]
+    if lost:
+        for e in list(_provisioned_segments):
+            if e[0] == idx and e[1] in lost:
+                _provisioned_segments.discard(e)
+        global _empty_cache_warned
+        if not _empty_cache_warned:
+            _empty_cache_warned = True
+            print(f"[pcrlv2_amd.ops] empty_cache: {len(lost)} of {len(mine)} provisioned segments were released with the cache "
+                  "(a placeholder landed elsewhere); they are re-reserved on demand", flush=True)
+
+
+_empty_cache_warned = False
 
 
 # ---- the second global view on its own stream (config.VIEW_STREAMS) ----
