@@ -97,21 +97,8 @@ COMPOSE_UPCONV = os.environ.get("PCRL_COMPOSE_UPCONV", "1") != "0"
 # mallocs in the timed region, 28.8 GB reserved instead of 44.7 for the 13 GB peak of a C2 step (sized to what the pools need).
 PROVISION_FACTOR = int(os.environ.get("PCRL_PROVISION_FACTOR", "2"))
 
-# EXPERIMENT, measured and NOT kept (default off; kept as switches because the result is instructive -- DESIGN.md section 5).
-# Idea: two streams that run the SAME layer sequence from the same start fall into lockstep -- both convolutions side by side, then both
-# BatchNorm passes side by side -- so HBM-bound passes never run under the other pass's matrix work (rocprofv3 timeline: 7.6 ms per step with
-# only HBM-bound kernels in flight).  INTERLEAVE_VIEWS: the three forwards are enqueued stage by stage in rotation (PCRLv23d.forward_views:
-# view 1, view 2, local views, each on its own stream), so the backward replays in the same rotation.  MFMA_TOKEN: every large matrix kernel
-# (>= MFMA_TOKEN_MIN_GF GFLOP) waits for the previous large matrix kernel of another stream (ops.mfma_turn): one matrix kernel at a time, in
-# enqueue order, HBM-bound passes under it.  Results bit-identical (tests).  Same-box A/B, 15 steps x 2 rounds: baseline 33.53 ms; interleave
-# alone 34.39; interleave + token 37.13; token alone 38.54; token only >= 60 GFLOP 35.59.  Why: (a) a cross-stream event wait in front of
-# ~150 kernels per step exposes the queue-to-queue signalling latency each time; (b) two matrix kernels side by side are ~10 % FASTER than
-# back to back (the co-scheduled blocks fill each other's barrier / staging stalls: one kernel alone keeps the MFMA pipe 56 % busy), so
-# serialising them gives up more than the hidden BatchNorm passes return; (c) step time tracks the SUM of kernel time (a step whose
-# draws leave view 2's 64-channel scale without a gradient skips 3.4 ms of kernels and is 3 ms shorter), i.e. the chip is throughput-bound.
-INTERLEAVE_VIEWS = os.environ.get("PCRL_INTERLEAVE", "0") == "1"
-MFMA_TOKEN = os.environ.get("PCRL_MFMA_TOKEN", "0") == "1"
-MFMA_TOKEN_MIN_GF = float(os.environ.get("PCRL_MFMA_TOKEN_MIN_GF", "20"))
+# (Round 3's experiment -- the three forwards enqueued stage by stage in rotation, each on its own stream, with one large matrix kernel at a time
+# across streams -- measured slower in every combination, 33.5 -> 34.4 / 37.1 / 38.5 ms, and is gone from the code; DESIGN section 5.4 keeps the result.)
 
 # Weight gradients of the second view's backward on the view stream itself (ops.side_wgrad) instead of the side stream.  Measured without a
 # profiler (tools/stream_balance_probe.py: events at the tail of every stream): the view stream ran dry 24.2 ms into a 31.6 ms step -- it
@@ -121,20 +108,8 @@ MFMA_TOKEN_MIN_GF = float(os.environ.get("PCRL_MFMA_TOKEN_MIN_GF", "20"))
 # 32.36 -> 31.84 ms (same box, three interleaved runs each).  PCRL_VIEW_WGRAD_INLINE=0: off (A/B switch; results are bit-identical).
 VIEW_WGRAD_INLINE = os.environ.get("PCRL_VIEW_WGRAD_INLINE", "1") != "0"
 
-# EXPERIMENT: the second view's forward side branches (heads, deep-supervision map) on the view stream itself instead of the side stream
-# (the view stream is idle for the last 2 ms of the forward phase).  PCRL_VIEW_BRANCH_INLINE=1: on.
-VIEW_BRANCH_INLINE = os.environ.get("PCRL_VIEW_BRANCH_INLINE", "0") == "1"
-
-# Experiment: the second view's forward starts only when the first view's forward has passed its VIEW_SKEW-th stage stop (1..11; 0: off --
-# both views start together and run their identical layer sequences in lockstep, convolution next to convolution and BatchNorm next to
-# BatchNorm).  One event wait per step, nothing else changes; results bit-identical.
-VIEW_SKEW = int(os.environ.get("PCRL_VIEW_SKEW", "0"))
-
-# Experiment: HIP stream priorities (0 = normal, -1 = high).  When two streams hold ready kernels the dispatcher takes the higher-priority
-# queue's workgroups first, so a favoured view finishes its convolution earlier and its BatchNorm passes run under the other view's
-# convolution instead of next to its BatchNorm passes (the two views run identical layer sequences).  Results bit-identical.
-VIEW_STREAM_PRIORITY = int(os.environ.get("PCRL_VIEW_PRIO", "0"))
-SIDE_STREAM_PRIORITY = int(os.environ.get("PCRL_SIDE_PRIO", "0"))
+# (Measured, not kept, removed in round 5: the second view's side branches on its own stream; a start skew between the two views' forwards; HIP stream
+# priorities for the view / side streams -- 31.80 / 31.81 / 31.82 / 31.80 ms, they do nothing.)
 
 # Weight packing off the forward's critical chain: the packed / composed weight forms a step needs (10 pack launches, 3 x the composed
 # operator's prep + GEMM + pack + bias: ~25 small kernels, 0.5 ms back to back) are rebuilt on the SIDE stream at the start of the step, in
@@ -154,14 +129,3 @@ FUSED_GRAD_SUM = os.environ.get("PCRL_FUSED_GRAD_SUM", "1") != "0"
 _ec = os.environ.get("PCRL_EMPTY_CACHE_PER_EPOCH", "1")
 EMPTY_CACHE_PER_EPOCH = _ec != "0"
 EMPTY_CACHE_RAW = _ec == "raw"
-
-# Experiment: a layer's weight gradient (side stream) is queued BEHIND its data gradient instead of in front of it.  Both need the same dy;
-# queued first, the weight gradient runs next to the data gradient (two matrix kernels sharing the chip) and the BatchNorm backward passes
-# of the layer below then run with nothing beside them; queued second, the side stream's wait covers the data gradient, and the weight
-# gradient runs next to those HBM-bound passes.  Same kernels, same results (bit-identical).  PCRL_WGRAD_AFTER_DGRAD=1: on.
-WGRAD_AFTER_DGRAD = os.environ.get("PCRL_WGRAD_AFTER_DGRAD", "0") == "1"
-
-# Experiment (measured, no gain, default off): weight gradients of the 1-output-channel layers (OutputTransition, the deep-supervision heads) on
-# the side stream like every other weight gradient instead of inline on the data-gradient chain, at whose head OutputTransition's column sums
-# are ~100 us.  Same box, 4 interleaved runs: 31.70 (inline) vs 31.80 ms.  PCRL_TO1_WGRAD_SIDE=1: on (bit-identical).
-TO1_WGRAD_SIDE = os.environ.get("PCRL_TO1_WGRAD_SIDE", "0") == "1"

@@ -17,14 +17,9 @@
 //      12 KiB, next stage prefetched into registers) -> 72 KiB, two blocks per CU.
 #include "common.h"
 
-// BRICK_TRANSPOSED = 1: the MFMAs run transposed (D = W * X^T) so that a lane holds four consecutive channels of one voxel and the epilogue issues
-// 16 eight-byte stores per lane instead of 64 two-byte ones.  MEASURED SLOWER (round 4, same box, 2 x 2 interleaved runs of the C5 step: 44.7 ms
-// against 43.6 with the two-byte form): an eight-byte store instruction of this layout touches 16 different 32-byte segments (16 voxels), the
-// two-byte form 4 (16 consecutive channels of 4 voxels) -- the same number of segments in a quarter of the instructions is not what the
-// store path rewards, and the per-channel statistics need four shuffle steps instead of two.  Kept as a compile-time switch, default off.
-#ifndef BRICK_TRANSPOSED
-#define BRICK_TRANSPOSED 0
-#endif
+// (Measured in round 4, not kept, removed: transposed MFMAs (D = W * X^T) so that a lane holds four consecutive channels of one voxel and the epilogue
+// issues 16 eight-byte stores instead of 64 two-byte ones -- 44.7 ms against 43.6 on the C5 step: an eight-byte store of that layout touches 16
+// different 32-byte segments, the two-byte form 4, and the per-channel statistics need four shuffle steps instead of two.)
 #ifndef BRICK_ABL
 #define BRICK_ABL 0   // timing ablations (wrong results): bit 0 no output stores, bit 1 no global loads in front of the first stage
 #endif
@@ -249,8 +244,7 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
   do {                                                                                                    \
     _Pragma("unroll") for (int fm = (F0_); fm < (F1_); ++fm)                                              \
       _Pragma("unroll") for (int j = 0; j < FN; ++j)                                                      \
-        acc[fm][j] = BRICK_TRANSPOSED ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[B_][j], fa[B_][fm], acc[fm][j], 0, 0, 0) \
-                                      : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[B_][fm], fb[B_][j], acc[fm][j], 0, 0, 0); \
+        acc[fm][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[B_][fm], fb[B_][j], acc[fm][j], 0, 0, 0);   \
   } while (0)
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
@@ -377,80 +371,6 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
 #undef LOAD_W
 #undef STORE_W
 
-#if BRICK_TRANSPOSED
-  // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick) ----
-  // The MFMAs run TRANSPOSED (D = W * X^T: the weight fragment is the A operand), so a lane holds FOUR CONSECUTIVE CHANNELS (j * 16 + 4 lg + r)
-  // of ONE voxel (fm * 16 + lr): 16 eight-byte stores per lane instead of 64 two-byte ones (round 4; with 9 taps per chunk in the 2D
-  // geometry the epilogue is a large share of the kernel).
-  float s1[FN][4], s2[FN][4], bv[FN][4];
-#pragma unroll
-  for (int j = 0; j < FN; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      s1[j][r] = 0.f;
-      s2[j][r] = 0.f;
-      bv[j][r] = (!UPCF && p.bias) ? p.bias[n0 + j * 16 + 4 * lg + r] : 0.f;
-    }
-  const int uch0 = UPCF ? n0 - uph * p.upc : n0;   // first channel of this tile (inside its phase)
-  const int ypitch = UPCF ? p.upc : p.Nc;
-#pragma unroll
-  for (int fm = 0; fm < 4; ++fm) {
-    const int v = wid * 64 + fm * 16 + lr;
-    int64_t row = (int64_t)n * p.D * p.H * p.W + (int64_t)(d0 + (v >> 6)) * p.sd + (h0 + ((v >> 3) & 7)) * p.sh + (w0 + (v & 7)) * p.sw;
-    if (UPCF) {   // the phase's fine voxel, and the bias of its border class (0 first, 1 inside, 2 last per axis; class number in memory order = tap strides)
-      const int fd = 2 * (d0 + (v >> 6)) + upd, fh = 2 * (h0 + ((v >> 3) & 7)) + uphh, fw = 2 * (w0 + (v & 7)) + upw;
-      row = (int64_t)n * (8 * p.D * p.H * p.W) + (int64_t)fd * p.fsd + fh * p.fsh + fw * p.fsw;
-      const int cd = fd == 0 ? 0 : (fd == 2 * p.D - 1 ? 2 : 1), ch = fh == 0 ? 0 : (fh == 2 * p.H - 1 ? 2 : 1), cw = fw == 0 ? 0 : (fw == 2 * p.W - 1 ? 2 : 1);
-      const int cls = cd * p.td + ch * p.th + cw * p.tw;
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias_tab + cls * p.upc + uch0 + j * 16 + 4 * lg);
-        bv[j][0] = b4[0]; bv[j][1] = b4[1]; bv[j][2] = b4[2]; bv[j][3] = b4[3];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      float val[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        val[r] = acc[fm][j][r] + bv[j][r];
-        s1[j][r] += val[r];
-        s2[j][r] += val[r] * val[r];
-      }
-      *reinterpret_cast<bf16x4*>(p.y + row * ypitch + uch0 + j * 16 + 4 * lg) = bf16x4{(bf16)val[0], (bf16)val[1], (bf16)val[2], (bf16)val[3]};
-    }
-  }
-  if (p.stats) {
-    float* red = reinterpret_cast<float*>(smem);  // [4 waves][64 ch][2]; the loop ended with a barrier
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float a = s1[j][r], c2 = s2[j][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o, 64);
-          c2 += __shfl_xor(c2, o, 64);
-        }
-        if (lr == 0) {
-          red[(wid * 64 + j * 16 + 4 * lg + r) * 2 + 0] = a;
-          red[(wid * 64 + j * 16 + 4 * lg + r) * 2 + 1] = c2;
-        }
-      }
-    __syncthreads();
-    if (tid < BN) {
-      float a = 0.f, c2 = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a += red[(q * 64 + tid) * 2 + 0];
-        c2 += red[(q * 64 + tid) * 2 + 1];
-      }
-      float* o = p.stats + ((int64_t)brick_id * p.Nc + n0 + tid) * 2;
-      o[0] = a;
-      o[1] = c2;
-    }
-  }
-#else   // the round-3 form: D = X * W^T, a lane holds 4 voxels of one channel, two-byte stores (A/B: tools/build_variant.sh ... -DBRICK_TRANSPOSED=0)
   // ---- epilogue: bias, store, BatchNorm partial statistics (one row per brick).  Voxel of (fm, r) in the wave's 64: d offset = wave, h offset =
   //      2 fm + (lg >> 1), w offset = 4 (lg & 1) + r.  Addresses (round 5, as in conv_brick16.h): a SCALAR base per (fm, r) -- the wave's first voxel +
   //      2 fm h-steps + r w-steps -- plus ONE lane offset and the store's immediate (32 j bytes): the 64-bit voxel index per (fm, r) that was rebuilt
@@ -521,7 +441,6 @@ __global__ void __launch_bounds__(256, 2) brick_conv_kernel(const BrickParams p)
       o[1] = c2;
     }
   }
-#endif
 }
 
 }  // namespace

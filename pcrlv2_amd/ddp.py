@@ -18,10 +18,6 @@ import torch
 import torch.distributed as dist
 
 
-_PROBE_SKIP_COLLECTIVE = os.environ.get("PCRL_DDP_PROBE_SKIP_COLLECTIVE", "0") == "1"   # tools/ddp_overlap_probe.sh only: everything but the collective itself
-_PROBE_DEFER = os.environ.get("PCRL_DDP_PROBE_DEFER", "0") == "1"                       # ... callbacks on, bucket launches left to optimizer.step()
-_PROBE_SKIP_FLUSH = os.environ.get("PCRL_DDP_PROBE_SKIP_FLUSH", "0") == "1"             # ... only the callbacks' bookkeeping (wrong results)
-
 
 def init_process_group_from_env(backend: str | None = None):
     """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT)."""
@@ -299,7 +295,7 @@ class DataParallel:
         self._final[i] = True
         bi = self._param_bucket[i]
         self._ready[bi] += 1
-        if self._ready[bi] == len(self._bucket_params[bi]) and not self._launched[bi] and not _PROBE_DEFER:
+        if self._ready[bi] == len(self._bucket_params[bi]) and not self._launched[bi]:
             self._launch_bucket(bi)
 
     @torch.no_grad()
@@ -336,11 +332,6 @@ class DataParallel:
             # On the GPU everything a bucket needs -- summing its parked gradients into the arena, zero-filling parameters without a gradient,
             # the collective -- runs on the COMMUNICATION stream, which waits for the producers; the main stream is never joined here, so the
             # weight gradients queued on the side stream keep overlapping the data-gradient chain while buckets go out.
-            if _PROBE_SKIP_FLUSH:
-                for i in idxs:
-                    self._gathered[i] = True
-                self._launched[bi] = True
-                return
             self._fn.flush_param_grads([opt._plist[i] for i in idxs], on_stream=cs)
             if cs is not None:
                 cs.wait_stream(torch.cuda.current_stream())
@@ -367,8 +358,7 @@ class DataParallel:
                         torch._foreach_copy_([opt._gviews[i] for i in copy], [opt._plist[i].grad for i in copy])
                     if miss:
                         torch._foreach_zero_([opt._gviews[i] for i in miss])
-                if not _PROBE_SKIP_COLLECTIVE:
-                    self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for i in idxs:
             self._gathered[i] = True
         self._launched[bi] = True

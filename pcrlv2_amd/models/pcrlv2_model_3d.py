@@ -257,8 +257,8 @@ class PCRLv23d(nn.Module):
         return ops.conv1x1_to1_forward(ops.to_act(h, dt), self.out_tr.final_conv.weight, self.out_tr.final_conv.bias, dt), feats, masks
 
     def _train_stages(self, x, local, pass_idx, features_only=False):
-        """The training-mode forward as a generator: yields after every stage's kernels are enqueued (eleven stops), returns the forward's
-        result.  `forward` runs it to the end; `forward_views` advances several of them in rotation, each under its own stream.
+        """The training-mode forward.  (Rounds 3-4 had this as a generator so that several passes could be advanced stage by stage in rotation,
+        each on its own stream, with one matrix kernel at a time -- measured slower, 33.5 -> 34.4 / 37.1 ms, DESIGN section 5 -- removed.)
         features_only: the caller discards the reconstruction and the deep-supervision maps (the second view and the local views of a
         training step, train_3d.py:117,123 -- SURVEY Q3): `out_tr` (no state) and the trilinear upsampling are skipped and None / [] are
         returned in their place; everything that has STATE -- the deep-supervision heads' BatchNorm running statistics -- still runs."""
@@ -267,13 +267,6 @@ class PCRLv23d(nn.Module):
         def mine():          # the stage Functions read the pass number off their module at forward time
             for m in mods:
                 m._pass_idx = pass_idx
-
-        stops = [0]
-
-        def stop():          # config.VIEW_SKEW: the second view's stream starts when the first view has enqueued this many stages
-            stops[0] += 1
-            if pass_idx == 0 and stops[0] == config.VIEW_SKEW:
-                ops.skew_mark(x.device)
 
         h, pooled = x, None
         for i, ((name, _, _), attr) in enumerate(zip(_ENCODER, _SKIPS)):
@@ -284,15 +277,10 @@ class PCRLv23d(nn.Module):
             if config.FOLD_POOL_GRAD and i + 1 < len(_ENCODER) and not last._gn_groups:
                 # stage output and `self.maxpool` of it (:115-117) as one node: the pool's backward folds into the BatchNorm backward
                 a = stage.ops[0](h)
-                stop()
-                yield
-                mine()
                 h, pooled = last.forward_pooled(a)
             else:
                 h, pooled = stage(h), None
             setattr(self, attr, h)          # the reference keeps these alive as attributes; the skips are never consumed (D6)
-            stop()
-            yield
         middle_features, middle_masks = [], []
         for (name, _, _), factor in zip(_DECODER, _UPSAMPLE):
             mine()
@@ -300,8 +288,6 @@ class PCRLv23d(nn.Module):
             middle_features.append([pro, pre])
             if not local and not features_only:
                 middle_masks.append(mask if factor == 1 else Fn.TrilinearFn.apply(mask, factor))
-            stop()
-            yield
         if features_only:
             return None, middle_features, middle_masks
         mine()
@@ -315,45 +301,6 @@ class PCRLv23d(nn.Module):
             raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
         if not self.training:
             return self._forward_eval(x, local)
-        gen = self._train_stages(x, local, ops.next_pass(), features_only)     # pass 0 = first forward since the last optimizer step (its backward runs last)
-        try:
-            while True:
-                next(gen)
-        except StopIteration as done:
-            result = done.value
+        result = self._train_stages(x, local, ops.next_pass(), features_only)     # pass 0 = first forward since the last optimizer step (its backward runs last)
         ops.end_of_forward_join()           # the stages' side branches (config.FWD_BRANCH_STREAM) are complete when the outputs are handed out
         return result
-
-    def forward_views(self, views):
-        """Several training-mode forwards enqueued stage by stage in rotation (engine API, not in the reference; an experiment that is off by
-        default, config.INTERLEAVE_VIEWS): `views` = [(x, local, stream name | None), ...] -> [forward(x, local) for the first,
-        forward(x, local, features_only=True) for the others], as if called one after the other in that order -- same kernels, same results, same
-        order of the running-statistics updates (ops.order_rmw) -- but the autograd graphs interleave, so the backward replays the passes in
-        rotation too, and each pass runs on the view stream of its name (ops.fork_views must have been called; None = the current stream).
-        With config.MFMA_TOKEN the HBM-bound passes of one view then run under the convolutions of the others (config.py)."""
-        if not self.training:
-            return [self.forward(x, local) for x, local, _ in views]
-        runs = []
-        for k, (x, local, name) in enumerate(views):
-            if not x.is_cuda:
-                raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
-            st = ops.view_stream(x.device, name) if name else None
-            if st is not None:
-                x.record_stream(st)
-            runs.append([self._train_stages(x, local, ops.next_pass(), features_only=k > 0), st, None, False])   # only the first view's maps are used
-        alive = len(runs)
-        while alive:
-            for r in runs:
-                if r[3]:
-                    continue
-                try:
-                    if r[1] is not None:
-                        with torch.cuda.stream(r[1]):
-                            next(r[0])
-                    else:
-                        next(r[0])
-                except StopIteration as done:
-                    r[2], r[3] = done.value, True
-                    alive -= 1
-        ops.end_of_forward_join()
-        return [r[2] for r in runs]

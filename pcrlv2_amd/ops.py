@@ -116,7 +116,7 @@ class side_wgrad:
         key = (self.device.type, self.device.index)
         side = _side_streams.get(key)
         if side is None:
-            side = _side_streams[key] = torch.cuda.Stream(device=self.device, priority=config.SIDE_STREAM_PRIORITY)
+            side = _side_streams[key] = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         for t in self.operands:
             t.record_stream(side)
@@ -138,10 +138,6 @@ class side_branch(side_wgrad):
     def __init__(self, device, *operands):
         self.device, self.operands = device, operands
         self.active = config.FWD_BRANCH_STREAM and device.type == "cuda"
-        if self.active and config.VIEW_BRANCH_INLINE and _views_active:
-            cur = torch.cuda.current_stream(device).cuda_stream
-            if any(cur == vs.cuda_stream for vs in _view_streams.values()):
-                self.active = False       # the second view's side branches stay on its own stream (config.VIEW_BRANCH_INLINE)
 
 
 _defer_join = 0
@@ -197,7 +193,7 @@ def side_stream(device):
     key = (device.type, device.index)
     side = _side_streams.get(key)
     if side is None:
-        side = _side_streams[key] = torch.cuda.Stream(device=device, priority=config.SIDE_STREAM_PRIORITY)
+        side = _side_streams[key] = torch.cuda.Stream(device=device)
     return side
 
 
@@ -232,37 +228,6 @@ def throttle_host(device, step_done=False):
     else:
         while len(q) >= lag:
             q.popleft().synchronize()
-
-
-# ---- one large matrix kernel at a time (config.MFMA_TOKEN) ----
-_mfma_last: dict = {}      # device index -> (event recorded behind the last large matrix kernel, stream it ran on)
-
-
-class mfma_turn:
-    """`with mfma_turn(device, flops):` around the launch of a matrix kernel on the CURRENT stream.  If the kernel is large it first waits
-    for the previous large matrix kernel launched on another stream (an event wait on the device, nothing on the host) and leaves its own
-    event behind: large matrix kernels of all streams run one at a time, in enqueue order (config.MFMA_TOKEN explains why)."""
-    __slots__ = ("dev", "on")
-
-    def __init__(self, device, flops):
-        self.dev = device
-        self.on = config.MFMA_TOKEN and _views_active and device.type == "cuda" and flops >= config.MFMA_TOKEN_MIN_GF * 1e9
-
-    def __enter__(self):
-        if self.on:
-            last = _mfma_last.get(self.dev.index)
-            if last is not None:
-                cur = torch.cuda.current_stream(self.dev)
-                if last[1] != cur.cuda_stream:
-                    cur.wait_event(last[0])
-
-    def __exit__(self, *exc):
-        if self.on:
-            cur = torch.cuda.current_stream(self.dev)
-            ev = torch.cuda.Event()
-            ev.record(cur)
-            _mfma_last[self.dev.index] = (ev, cur.cuda_stream)
-        return False
 
 
 # ---- allocator provisioning (config.PROVISION_FACTOR) ----
@@ -398,21 +363,11 @@ _empty_cache_warned = False
 
 # ---- the second global view on its own stream (config.VIEW_STREAMS) ----
 _view_streams: dict = {}
-# "view2,local" with config.INTERLEAVE_VIEWS (every pass of the round-robin on its own stream), else "view2" (the local views' pass on the main stream)
-VIEW_STREAM_NAMES = tuple(n for n in os.environ.get("PCRL_VIEW_STREAM_NAMES", "view2,local" if config.INTERLEAVE_VIEWS else "view2").split(",") if n)
+# the passes that get a stream of their own: the second global view (the local views' pass stays on the main stream -- a third view stream was
+# measured and is slower: 31.64 -> 32.02 ms)
+VIEW_STREAM_NAMES = ("view2",)
 _views_active = False        # set while a step uses the view stream: the cross-stream guards below are then live
 _rmw_events: dict = {}
-
-
-_skew_event = None
-
-
-def skew_mark(device):
-    """config.VIEW_SKEW: the first view's forward has enqueued the stage the second view waits for."""
-    global _skew_event
-    if _views_active and _skew_event is None:
-        _skew_event = torch.cuda.Event()
-        _skew_event.record(torch.cuda.current_stream(device))
 
 
 def view_streams_on(device, path2d=False) -> bool:
@@ -430,7 +385,7 @@ def fork_views(device, path2d=False):
         key = (device.type, device.index, name)
         vs = _view_streams.get(key)
         if vs is None:
-            vs = _view_streams[key] = torch.cuda.Stream(device=device, priority=config.VIEW_STREAM_PRIORITY)
+            vs = _view_streams[key] = torch.cuda.Stream(device=device)
         vs.wait_stream(torch.cuda.current_stream(device))
     _views_active = True
 
@@ -455,8 +410,6 @@ class view_pass:
             vs = _view_streams[key]
             for t in self.operands:
                 t.record_stream(vs)
-            if _skew_event is not None and self.name == "view2":
-                vs.wait_event(_skew_event)
             self._cm = torch.cuda.stream(vs)
             self._cm.__enter__()
 
@@ -578,10 +531,9 @@ _pass_index = 0
 
 
 def begin_step():
-    global _pass_index, _views_active, _skew_event, _pack_recording
+    global _pass_index, _views_active, _pack_recording
     _pass_index = 0
     _views_active = False
-    _skew_event = None
     _pack_recording = None
     drop_pending_composed()
 
@@ -897,9 +849,8 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
         y = new_act(N, D, H, W, Co, dtype, dev)
         partial = _f32(rows * Co * 2, dev) if training else None
         nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
-        with mfma_turn(dev, 54.0 * M * Ci * Co):
-            L.call("pcrl_conv3d_k3_fwd_ws", x, wf, conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb, N, D, H, W, Ci, Co,
-                   dtype_code(dtype), s)
+        L.call("pcrl_conv3d_k3_fwd_ws", x, wf, conv_b.detach(), y, partial, workspace(nb, dev) if nb else None, nb, N, D, H, W, Ci, Co,
+               dtype_code(dtype), s)
         mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, training)
         if pooled and prelu is None and config.FUSE_APPLY_CONSUMERS and bn_pool_ok(D, H, W, Co, dtype):
             a, p = torch.empty_like(y), new_act(N, D // 2, H // 2, W // 2, Co, dtype, dev)
@@ -958,11 +909,8 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
             dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, 1, sv.act, torch.float32)
         nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, Ci, 27)
         dbias_unused = _f32(1, dev)
-        if config.TO1_WGRAD_SIDE:      # like every other weight gradient: off the data-gradient chain (the side stream is idle this early in the backward)
-            with side_wgrad(dev, sv.x, dy) as ws:
-                L.call("pcrl_conv3d_to1_wgrad", sv.x, dy, dw, dbias_unused, ws(nb), nb, N, D, H, W, Ci, 27, dtype_code(dtype), stream_handle())
-        else:
-            L.call("pcrl_conv3d_to1_wgrad", sv.x, dy, dw, dbias_unused, workspace(nb, dev), nb, N, D, H, W, Ci, 27, dtype_code(dtype), s)
+        # (inline on the data-gradient chain; on the side stream like the other weight gradients it measured 31.80 vs 31.70 ms: not kept)
+        L.call("pcrl_conv3d_to1_wgrad", sv.x, dy, dw, dbias_unused, workspace(nb, dev), nb, N, D, H, W, Ci, 27, dtype_code(dtype), s)
         dx = None
         if need_dx:
             dx = new_act(N, D, H, W, Ci, dtype, dev)
@@ -985,14 +933,11 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
     def weight_gradient():
         nbw = L.call("pcrl_conv3d_k3_wgrad_ws_bytes", N, D, H, W, Ci, Co)
         with side_wgrad(dev, sv.x, dy) as ws:
-            with mfma_turn(dev, 54.0 * M * Ci * Co):
-                L.call("pcrl_conv3d_k3_wgrad", sv.x, dy, dw, ws(nbw), nbw, N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
+            L.call("pcrl_conv3d_k3_wgrad", sv.x, dy, dw, ws(nbw), nbw, N, D, H, W, Ci, Co, dtype_code(dtype), stream_handle())
 
-    # config.WGRAD_AFTER_DGRAD: the data gradient is queued first, so the side stream's wait for this stream covers it and the weight
-    # gradient runs behind it, next to the BatchNorm backward passes of the layer below, instead of next to the data gradient
-    late = config.WGRAD_AFTER_DGRAD and need_dx
-    if not late:
-        weight_gradient()
+    # queued IN FRONT of the data gradient: both need dy, the two matrix kernels then share the chip (queued behind it -- next to the BatchNorm
+    # backward of the layer below -- was an experiment of round 3, bit-identical, no gain: removed)
+    weight_gradient()
     dx = None
     if need_dx:
         _, wd = packed.get(conv_w, dtype)
@@ -1002,15 +947,12 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
         if dx_colsum is not None:
             rows = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Co, Ci, dtype_code(dtype))
             part = _f32(rows * Ci * 2, dev)
-        with mfma_turn(dev, 54.0 * M * Ci * Co):
-            L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, part, workspace(nb, dev) if nb else None, nb, N, D, H, W, Co, Ci, dtype_code(dtype), s)
+        L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, part, workspace(nb, dev) if nb else None, nb, N, D, H, W, Co, Ci, dtype_code(dtype), s)
         if part is not None:   # [rows][Ci][2] -> column sums; the (sum) entries are the even columns
             both = _f32(Ci * 2, dev)
             nb2 = L.call("pcrl_colsum_ws_bytes", rows, Ci * 2)
             L.call("pcrl_colsum", part, both, workspace(nb2, dev), nb2, rows, Ci * 2, dtype_code(torch.float32), s)
             dx_colsum.copy_(both.view(Ci, 2)[:, 0])
-    if late:
-        weight_gradient()
     return dx, dw, db, dgamma, dbeta
 
 
@@ -1129,9 +1071,8 @@ class ComposedUpConv(_CacheGuard):
             _pending_composed.append(self)
         nb = L.call("pcrl_upconv_wgrad_accum_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))
         with side_wgrad(dev, x, dy, shared_accumulator=True) as ws:
-            with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
-                L.call("pcrl_upconv_wgrad_accum", x, dy, self.dweff, self.box, (1 if first else 0) | (2 if zero_sum else 0), ws(nb), nb, N, D, H, W, Ci, Co,
-                       dtype_code(dtype), stream_handle())
+            L.call("pcrl_upconv_wgrad_accum", x, dy, self.dweff, self.box, (1 if first else 0) | (2 if zero_sum else 0), ws(nb), nb, N, D, H, W, Ci, Co,
+                   dtype_code(dtype), stream_handle())
 
     def finish(self):
         """-> (w_up, b_up, w0, dw_up, db_up, dw0) for everything accumulated since the last delivery."""
@@ -1199,8 +1140,7 @@ def upconv_luconv_forward(x, w_up, b_up, conv_w, conv_b, gamma, beta, running_me
     rows = L.call("pcrl_upconv_stats_rows", N, D, H, W, Ci, Co, dtype_code(dtype))
     y = new_act(N, 2 * D, 2 * H, 2 * W, Co, dtype, dev)
     partial = _f32(rows * Co * 2, dev)
-    with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
-        L.call("pcrl_upconv_fwd", x, wf, composed.w3f, bias_tab, y, partial, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+    L.call("pcrl_upconv_fwd", x, wf, composed.w3f, bias_tab, y, partial, N, D, H, W, Ci, Co, dtype_code(dtype), s)
     mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, True)
     a = bn_act_apply(y, scale, shift, M, Co, act, dtype)
     sv = LUConvSaved()
@@ -1218,26 +1158,22 @@ def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamm
     N, D, H, W, Ci, Co = sv.geom
     M = N * D * H * W * 8
     dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype)
-    late = config.WGRAD_AFTER_DGRAD and need_dx and defer      # see luconv_backward
     dx = None
 
     def data_gradient():
         _, wd, _ = composed.get(w_up, b_up, conv_w, conv_b, dtype)
         dxx = new_act(N, D, H, W, Ci, dtype, dev)
         nbd = L.call("pcrl_upconv_dgrad_ws_bytes", N, D, H, W, Ci, Co, dtype_code(dtype))      # split-K scratch on the small coarse grids
-        with mfma_turn(dev, 128.0 * N * D * H * W * Ci * Co):
-            L.call("pcrl_upconv_dgrad_ws", dy, wd, composed.wd3, dxx, workspace(nbd, dev) if nbd else None, nbd, N, D, H, W, Ci, Co, dtype_code(dtype), s)
+        L.call("pcrl_upconv_dgrad_ws", dy, wd, composed.wd3, dxx, workspace(nbd, dev) if nbd else None, nbd, N, D, H, W, Ci, Co, dtype_code(dtype), s)
         return dxx
 
-    if late:
-        dx = data_gradient()
     composed.accumulate(sv.x, dy, sv.geom, w_up, b_up, conv_w, dtype, zero_sum=config.UPC_ZERO_SUM)   # dy: output of the BatchNorm backward just above
     dw_up = db_up = dw0 = None
     if not defer:
         join_side_stream()
         _pending_composed.remove(composed)
         _, _, _, dw_up, db_up, dw0 = composed.finish()
-    if need_dx and not late:
+    if need_dx:
         dx = data_gradient()
     return dx, dw_up, db_up, dw0, zero_grad_vector(Co, dev), dgamma, dbeta
 
@@ -1426,11 +1362,7 @@ def conv1x1_to1_backward(x, out, dout, w, dtype, need_dx=True):
     dw = torch.empty_like(w, dtype=torch.float32, memory_format=torch.contiguous_format)
     db = _f32(1, dev)
     nb = L.call("pcrl_conv3d_to1_wgrad_ws_bytes", N, D, H, W, C, 1)
-    if config.TO1_WGRAD_SIDE:          # 145 us of column sums over the full-resolution activation, at the very head of the backward's chain
-        with side_wgrad(dev, x, dpre) as ws:
-            L.call("pcrl_conv3d_to1_wgrad", x, dpre, dw, db, ws(nb), nb, N, D, H, W, C, 1, dtype_code(dtype), stream_handle())
-    else:
-        L.call("pcrl_conv3d_to1_wgrad", x, dpre, dw, db, workspace(nb, dev), nb, N, D, H, W, C, 1, dtype_code(dtype), s)
+    L.call("pcrl_conv3d_to1_wgrad", x, dpre, dw, db, workspace(nb, dev), nb, N, D, H, W, C, 1, dtype_code(dtype), s)
     dx = None
     if need_dx:
         dx = torch.empty_like(x)

@@ -132,17 +132,6 @@ def step_losses(model, batch, epoch, criterion, cosine):
     view1, view2 = _to_gpu(view1), _to_gpu(view2)
     _ops.fork_views(view1.device)  # config.VIEW_STREAMS: the second view's forward (and backward) on its own stream, next to the first's
     _ops.prepack(model, view1.device)   # config.PREPACK: this step's packed / composed weight forms on the side stream, ahead of their use
-    if fused and _cfg.INTERLEAVE_VIEWS and hasattr(model, "forward_views") and _ops.view_streams_on(view1.device):
-        # the three forwards enqueued stage by stage in rotation, each pass on its own stream (config.INTERLEAVE_VIEWS / MFMA_TOKEN)
-        loc = _ops.concat_batch([_to_gpu(v) for v in local_views])
-        with _ops.deferred_join():
-            (out1, feats1, masks1), (_out2, feats2, _), (_, feats_loc, _) = model.forward_views(
-                [(view1, False, None), (view2, False, "view2"), (loc, True, "local")])
-        cos2, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
-        l_restore = criterion(out1, target)
-        beta = 0.5 * (1.0 + math.cos(math.pi * epoch / BETA_PERIOD))
-        total, l_deep, l_global, l_local = _fn.loss_tail(l_restore, cos2, criterion(masks1[scale], target), beta)
-        return total, l_restore, l_global, l_deep, l_local
     with _ops.deferred_join():     # the decoder stages' side branches (heads, deep-supervision maps) also run under the NEXT forward; joined on exit
         out1, feats1, masks1 = model(view1)
         # mask2, the local views' reconstruction and their deep-supervision maps are never used (train_3d.py:117,123): the engine's
