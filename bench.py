@@ -82,8 +82,8 @@ def upconv_key(name, args):
         # the wide-brick kernel's composed instantiations are separate kernels (template arguments <64, 1> forward, <64, 2> data gradient)
         brick = L.call("pcrl_upconv_fwd_uses_brick", N, D, H, W, Ci, Co, dt)
         key = "brick16_conv_kernel<upconv_fwd>" if brick else "igemm_kernel<%s,upconv_fwd>" % ("bf16" if dt == 1 else "f32")
-    elif name == "pcrl_upconv_dgrad":   # (dy0, wd, wd3, dx, N, D, H, W, Ci, Co, dtype, stream)
-        N, D, H, W, Ci, Co, dt = args[4:11]
+    elif name in ("pcrl_upconv_dgrad", "pcrl_upconv_dgrad_ws"):   # (dy0, wd, wd3, dx, [ws, ws_bytes,] N, D, H, W, Ci, Co, dtype, stream)
+        N, D, H, W, Ci, Co, dt = args[6:13] if name.endswith("_ws") else args[4:11]
         brick = L.call("pcrl_upconv_dgrad_uses_brick", N, D, H, W, Ci, Co, dt)
         key = "brick16_conv_kernel<upconv_dgrad>" if brick else "igemm_kernel<%s,upconv_dgrad>" % ("bf16" if dt == 1 else "f32")
     else:                               # pcrl_upconv_wgrad_accum(x, dy0, dweff, box, first, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)
@@ -353,7 +353,7 @@ def main():
         random.setstate(st0)
         ddp_ab = {"settings": ddp_ab, "used_for_timed_region": best, "steps_each": 6}
     prof = types_ns(results=lambda: {"brick16_conv_kernel": (1, 1.0, 1.0)}) if dry else \
-        _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad",
+        _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad", "pcrl_upconv_dgrad_ws",
                             "pcrl_upconv_wgrad_accum"}, keyfn)
     import gc
     gc.collect()
@@ -403,7 +403,7 @@ def main():
         _branch, _cfg.FWD_BRANCH_STREAM = _cfg.FWD_BRANCH_STREAM, False
         for _ in range(2):
             train_step(model, opt, batch, 0, crit, cosine, guard=False)
-        alone = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad",
+        alone = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad", "pcrl_upconv_dgrad_ws",
                                     "pcrl_upconv_wgrad_accum"}, keyfn)   # every matrix kernel: roofline.weighted_matrix_frac
         ALG_BYTES.clear()
         torch.cuda.synchronize()
