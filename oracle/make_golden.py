@@ -219,13 +219,15 @@ def make_case(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=3, base_l
     print(f"[{tag}] wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB, {len(fx)} arrays)")
 
 
-def make_dp(tag, b_rank, dhw, nsteps, world, refmod, ref_train, ref_utils, epoch=3, base_lr=1e-3, epochs=240, seed=0):
+def make_dp(tag, b_rank, dhw, nsteps, world, refmod, ref_train, ref_utils, epoch=3, base_lr=1e-3, epochs=240, seed=0, partition="sample"):
     """The reference's multi-GPU semantics -- `nn.DataParallel(model)` (train_3d.py:54) -- run on the REAL model, on CPU: replica 0 is
     the module itself (its BatchNorm buffers persist), replicas r >= 1 are `torch.func.functional_call`s of the same module with the SAME
     parameter tensors and throw-away copies of the buffers (what `replicate` builds on every forward call); every replica normalises with
     its own batch statistics; the losses of train_3d.py:119-138 are means over the gathered batch (= the mean of the replicas' losses for
     equal chunks) with ONE scale draw per cos_loss call; one backward sums the replicas' gradients into the shared parameters; one SGD step.
-    The local views are partitioned by sample (see oracle.train_steps_data_parallel).  Asserts the oracle's restatement equal, writes
+    partition="sample": the local views are partitioned by sample (see oracle.train_steps_data_parallel); partition="chunk": the literal
+    scatter of train_3d.py:121-123 -- the [6B] view-major tensor of the GLOBAL batch cut into `world` chunks, each replica's local forward (and its
+    BatchNorm statistics) over ITS chunk, outputs gathered, losses over the gathered batch.  Asserts the oracle's restatement equal, writes
     tests/golden/<tag>.npz: per-replica losses of every step, the gradient of step 0, the parameters and replica 0's buffers after `nsteps`."""
     from torch.func import functional_call
     torch.set_num_threads(8)
@@ -258,7 +260,36 @@ def make_dp(tag, b_rank, dhw, nsteps, world, refmod, ref_train, ref_utils, epoch
         for s in range(nsteps):
             draws = random.getstate()
             total, entry = 0.0, []
-            for r in range(world):
+            if partition == "chunk":
+                import math
+                per_rank = rank_batches[s]
+                B, nl = world * b_rank, len(per_rank[0][4])
+                fw = [list(replica(r)(per_rank[r][0])) for r in range(world)]               # (mask1, dec1, mid1) of every replica: view 1 ...
+                dec2 = [replica(r)(per_rank[r][1])[1] for r in range(world)]                # ... then view 2 ...
+                local_input = torch.cat([torch.cat([per_rank[r][4][v] for r in range(world)], dim=0) for v in range(nl)], dim=0)   # train_3d.py:121 on the global batch
+                rows = nl * B // world
+                louts = [replica(r)(local_input[r * rows:(r + 1) * rows], local=True)[1] for r in range(world)]       # ... then DataParallel's scatter of :123
+                gathered = [[torch.cat([louts[r][k][j] for r in range(world)], dim=0) for j in range(2)] for k in range(len(louts[0]))]
+                lvo = [torch.stack(t) for t in gathered]                                      # train_3d.py:125 on the gathered outputs
+                for r in range(world):
+                    random.setstate(draws)
+                    mask1, d1, mid1 = fw[r]
+                    loss2, index2 = ref_train.cos_loss(cosine, d1, dec2[r])
+                    local_loss = 0.0
+                    for i in range(nl):
+                        tmp = [t[:, B * i + r * b_rank: B * i + (r + 1) * b_rank] for t in lvo]    # rows of replica r's samples in `t[:, bsz * i: bsz * (i + 1)]`
+                        l1, _ = ref_train.cos_loss(cosine, d1, tmp)
+                        l2, _ = ref_train.cos_loss(cosine, dec2[r], tmp)
+                        local_loss += l1
+                        local_loss += l2
+                    local_loss = local_loss / (2 * nl)
+                    loss1 = criterion(mask1, per_rank[r][2])
+                    beta = 0.5 * (1. + math.cos(math.pi * epoch / 240))
+                    loss4 = beta * criterion(mid1[index2], per_rank[r][2])
+                    res = dict(loss=loss1 + loss2 + loss4 + local_loss, loss1=loss1, loss2=loss2, loss4=loss4, local_loss=local_loss, index2=index2)
+                    total = total + res["loss"] / world
+                    entry.append({k: float(res[k].detach()) for k in ("loss", "loss1", "loss2", "loss4", "local_loss")} | {"index2": res["index2"]})
+            for r in range(world if partition != "chunk" else 0):
                 random.setstate(draws)               # one draw per cos_loss call, for the whole gathered batch
                 res = reference_step(replica(r), ref_train, rank_batches[s][r], epoch, criterion, cosine)
                 total = total + res["loss"] / world
@@ -272,7 +303,7 @@ def make_dp(tag, b_rank, dhw, nsteps, world, refmod, ref_train, ref_utils, epoch
     ref_final = {k: v.detach().clone() for k, v in model.state_dict().items()}
 
     with torch.backends.mkldnn.flags(enabled=False):
-        st_fin, _mom, log, g0 = O.train_steps_data_parallel(st0, rank_batches, epoch, base_lr, epochs, seed)
+        st_fin, _mom, log, g0 = O.train_steps_data_parallel(st0, rank_batches, epoch, base_lr, epochs, seed, partition=partition)
     for s in range(nsteps):
         for r in range(world):
             for k in ("loss", "loss1", "loss2", "loss4", "local_loss"):
@@ -295,6 +326,7 @@ def make_dp(tag, b_rank, dhw, nsteps, world, refmod, ref_train, ref_utils, epoch
     fx["meta/b_rank"], fx["meta/dhw"], fx["meta/nsteps"], fx["meta/world"] = np.int64(b_rank), np.array(dhw), np.int64(nsteps), np.int64(world)
     fx["meta/epoch"], fx["meta/base_lr"], fx["meta/epochs"], fx["meta/seed"] = np.int64(epoch), np.float64(base_lr), np.int64(epochs), np.int64(seed)
     fx["meta/lr"] = np.float64(opt.param_groups[0]["lr"])
+    fx["meta/partition"] = np.array(partition)
     for s, entry in enumerate(ref_log):
         for r, l in enumerate(entry):
             for k, v in l.items():
@@ -764,7 +796,10 @@ def main():
         return
     if "--data-parallel" in sys.argv:
         # nn.DataParallel semantics (train_3d.py:54) on two replicas of b = 4
-        make_dp("dp2_b4x2_32x32x16", 4, (32, 32, 16), 2, 2, refmod, ref_train, ref_utils)
+        if "--chunk-only" not in sys.argv:
+            make_dp("dp2_b4x2_32x32x16", 4, (32, 32, 16), 2, 2, refmod, ref_train, ref_utils)
+        # the same two replicas with nn.DataParallel's LITERAL scatter of the [6B] local-view tensor (train_3d.py:121-123; PCRL_DP_LOCAL_PARTITION=chunk)
+        make_dp("dp2chunk_b4x2_32x32x16", 4, (32, 32, 16), 2, 2, refmod, ref_train, ref_utils, partition="chunk")
         return
     if "--mfma-pin" in sys.argv:
         make_mfma_pin("mfma_pin", refmod)

@@ -454,7 +454,53 @@ def train_steps(st, batches, epoch=0, base_lr=1e-3, epochs=240, seed=0, momentum
     return st, mom, log, first_grads
 
 
-def train_steps_data_parallel(st, rank_batches, epoch=0, base_lr=1e-3, epochs=240, seed=0, momentum=0.9, weight_decay=1e-4):
+def step_losses_data_parallel_chunked(st, per_rank, epoch: int, rng: random.Random):
+    """One iteration of train_3d.py:109-138 under nn.DataParallel with the LITERAL scatter of the local views (train_3d.py:121-123): the
+    six local views of the GLOBAL batch are concatenated view-major into one [6B] tensor and `model(local_input, local=True)` scatters THAT
+    along dim 0 -- replica r runs rows [r * 6B / W, (r + 1) * 6B / W), i.e. with two replicas replica 0 sees local views 0-2 of ALL samples
+    (its BatchNorm statistics of the local pass are over those rows), the outputs are gathered back into [6B] order and the losses are
+    taken over the gathered batch.  per_rank[r] = replica r's share of the global batch (global sample order = replica 0's samples, then
+    replica 1's, ...).  -> (list of per-replica result dicts with the loss restricted to the replica's own samples -- their mean is the
+    reference's loss over the gathered batch --, replica 0's new buffers)."""
+    W = len(per_rank)
+    b = per_rank[0][0].size(0)
+    B = W * b
+    nl = len(per_rank[0][4])
+    draws = rng.getstate()
+    bufs = [dict() for _ in range(W)]
+    fw = []
+    for r, batch in enumerate(per_rank):            # every replica: view 1, then view 2 (the order replica 0's running statistics see)
+        mask1, dec1, mid1 = forward(st, batch[0], new_bufs=bufs[r])
+        fw.append([mask1, dec1, mid1, None])
+    for r, batch in enumerate(per_rank):
+        fw[r][3] = forward(st, batch[1], new_bufs=bufs[r])[1]
+    local_global = torch.cat([torch.cat([per_rank[r][4][v] for r in range(W)], dim=0) for v in range(nl)], dim=0)     # [6B]: view-major, samples in global order
+    rows = nl * B // W
+    louts = []
+    for r in range(W):
+        _, lo, _ = forward(st, local_global[r * rows:(r + 1) * rows], local=True, new_bufs=bufs[r])
+        louts.append(lo)
+    lout = [torch.stack([torch.cat([louts[r][k][j] for r in range(W)], dim=0) for j in range(2)]) for k in range(len(louts[0]))]   # gathered: [2, 6B, C] per scale
+    out = []
+    for r, batch in enumerate(per_rank):
+        rng.setstate(draws)                          # ONE draw per cos_loss call for the whole gathered batch
+        mask1, dec1, mid1, dec2 = fw[r]
+        loss2, index2 = cos_loss(dec1, dec2, rng)
+        local_loss = 0.0
+        for i in range(nl):
+            tmp = [t[:, B * i + r * b: B * i + (r + 1) * b] for t in lout]      # this replica's samples of local view i
+            l1, _ = cos_loss(dec1, tmp, rng)
+            l2, _ = cos_loss(dec2, tmp, rng)
+            local_loss = local_loss + l1 + l2
+        local_loss = local_loss / (2 * nl)
+        loss1 = F.mse_loss(mask1, batch[2])
+        beta = 0.5 * (1.0 + math.cos(math.pi * epoch / 240))
+        loss4 = beta * F.mse_loss(mid1[index2], batch[2])
+        out.append(dict(loss=loss1 + loss2 + loss4 + local_loss, loss1=loss1, loss2=loss2, loss4=loss4, local_loss=local_loss, index2=index2))
+    return out, bufs[0]
+
+
+def train_steps_data_parallel(st, rank_batches, epoch=0, base_lr=1e-3, epochs=240, seed=0, momentum=0.9, weight_decay=1e-4, partition="sample"):
     """k iterations under the reference's `nn.DataParallel` (train_3d.py:54), restated for `world` replicas.
 
     rank_batches[s][r] = the batch of replica r in iteration s (DataParallel scatters the global batch along dim 0, one chunk per
@@ -466,8 +512,9 @@ def train_steps_data_parallel(st, rank_batches, epoch=0, base_lr=1e-3, epochs=24
         the mean of the replicas' losses; the scales are drawn ONCE per cos_loss call for the whole batch (every replica sees the
         same draw);
       * one backward, gradients of all replicas summed into the one parameter set, one SGD step (train_3d.py:143-151).
-    One deliberate difference, stated in DESIGN.md: the local views are partitioned BY SAMPLE (each replica holds all six local
-    views of its own crops, as one-process-per-GPU loaders deliver them), not by chunks of the concatenated [6b] tensor.
+    partition="sample" (the engine's default, one deliberate difference stated in DESIGN.md): the local views are partitioned BY SAMPLE (each
+    replica holds all six local views of its own crops, as one-process-per-GPU loaders deliver them); partition="chunk": by chunks of the
+    concatenated [6B] tensor, as nn.DataParallel literally does (PCRL_DP_LOCAL_PARTITION=chunk in the engine).
     Returns (final state with replica 0's buffers, momentum, per-step list of per-replica loss dicts, gradients of the first step)."""
     rng = random.Random(seed)
     st = OrderedDict((k, v.clone()) for k, v in st.items())
@@ -479,7 +526,12 @@ def train_steps_data_parallel(st, rank_batches, epoch=0, base_lr=1e-3, epochs=24
             st[k] = st[k].detach().requires_grad_(True)
         draws = rng.getstate()
         total, bufs0, entry = 0.0, None, []
-        for r, batch in enumerate(per_rank):
+        if partition == "chunk":        # the reference's literal scatter of the concatenated local views (step_losses_data_parallel_chunked)
+            results, bufs0 = step_losses_data_parallel_chunked(st, per_rank, epoch, rng)
+            for res in results:
+                total = total + res["loss"] / len(per_rank)
+                entry.append({k: float(res[k].detach()) for k in ("loss", "loss1", "loss2", "loss4", "local_loss")} | {"index2": res["index2"]})
+        for r, batch in enumerate(per_rank if partition != "chunk" else []):
             rng.setstate(draws)                     # one draw per cos_loss call for the whole gathered batch
             new_bufs = {}
             res = step_losses(st, batch, epoch, rng, new_bufs)

@@ -160,6 +160,70 @@ def bind_rank_to_numa(local_rank: int, local_world: int, verbose: bool = False, 
         return None
 
 
+# ---- opt-in: nn.DataParallel's LITERAL partition of the local views (PCRL_DP_LOCAL_PARTITION=chunk) -------------------------------------------
+# The reference concatenates the six local views of the GLOBAL batch view-major into one [6B] tensor and lets DataParallel scatter THAT along dim 0
+# (train_3d.py:121-123): replica r runs rows [r * 6B / W, (r + 1) * 6B / W) -- with two replicas, replica 0 sees local views 0-2 of ALL samples -- so the
+# BatchNorm statistics of the local pass group rows differently than when every rank keeps the six views of its own crops (this engine's default and
+# one stated deviation).  This mode reproduces the reference's grouping at the price of two small exchanges on the data path per step: the local
+# views' inputs (6 b x 16 KiB per rank) before the local forward and their pooled features ([6 b, 896] floats) after it, plus the features' gradient
+# in backward -- all-gathers / one all-reduce (gloo has no all-to-all), nothing a pre-training run would want by choice.  Pinned by
+# tests/golden/dp2chunk_b4x2_32x32x16.npz (the REAL model under the literal scatter; oracle/make_golden.py --data-parallel).
+def chunk_partition_on() -> bool:
+    return os.environ.get("PCRL_DP_LOCAL_PARTITION", "sample") == "chunk" and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def chunk_local_inputs(loc: torch.Tensor, b: int, nl: int) -> torch.Tensor:
+    """loc = this rank's local views, view-major [nl * b, ...] -> this rank's chunk of the GLOBAL view-major tensor (same number of rows)."""
+    W, r = dist.get_world_size(), dist.get_rank()
+    loc = loc.contiguous()
+    parts = [torch.empty_like(loc) for _ in range(W)]
+    dist.all_gather(parts, loc)
+    G = torch.stack(parts).view(W, nl, b, *loc.shape[1:]).transpose(0, 1).reshape(nl * W * b, *loc.shape[1:])     # row v * B + rank * b + i
+    rows = nl * b
+    return G[r * rows:(r + 1) * rows].contiguous()
+
+
+class _OwnRowsOfGathered(torch.autograd.Function):
+    """x = the features this rank computed for ITS chunk of the global local-view tensor ([nl * b, C]) -> the features of this rank's OWN samples,
+    view-major ([nl * b, C]: DataParallel's gather followed by `t[:, bsz * i: bsz * (i + 1)]` restricted to the rank's samples).  Backward: the
+    gradient rows go back to the ranks that computed them (all-reduce of the scattered gradient, then this rank's chunk)."""
+
+    @staticmethod
+    def forward(ctx, x, b, nl):
+        W, r = dist.get_world_size(), dist.get_rank()
+        x = x.contiguous()
+        parts = [torch.empty_like(x) for _ in range(W)]
+        dist.all_gather(parts, x)
+        G = torch.cat(parts, dim=0).view(nl, W, b, x.shape[1])          # the chunks in rank order ARE the global row order
+        ctx.geom = (W, r, b, nl, x.shape[1])
+        return G[:, r].reshape(nl * b, x.shape[1]).contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        W, r, b, nl, C = ctx.geom
+        full = torch.zeros(nl, W, b, C, dtype=g.dtype, device=g.device)
+        full[:, r] = g.reshape(nl, b, C)
+        dist.all_reduce(full, op=dist.ReduceOp.SUM)
+        rows = nl * b
+        return full.view(nl * W * b, C)[r * rows:(r + 1) * rows].contiguous(), None, None
+
+
+def chunk_local_features(feats_loc, b: int, nl: int):
+    """feats_loc = [[projection, prediction] per scale] of the rank's CHUNK -> the same structure for the rank's OWN samples (one exchange for all six)."""
+    flat = [t for pair in feats_loc for t in pair]
+    widths = [t.shape[1] for t in flat]
+    own = _OwnRowsOfGathered.apply(torch.cat([t.float() for t in flat], dim=1), b, nl)
+    out, o = [], 0
+    for k in range(len(feats_loc)):
+        pair = []
+        for _ in range(2):
+            w = widths[len(out) * 2 + len(pair)]
+            pair.append(own[:, o:o + w].contiguous())
+            o += w
+        out.append(pair)
+    return out
+
+
 def plan_buckets(sizes, bucket_elems: int):
     """Contiguous element ranges [(begin, end)] over the flat arena, built from the LAST parameter backwards
     (gradients become final in reverse execution order), each at most `bucket_elems` unless one tensor is larger."""

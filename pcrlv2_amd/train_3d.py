@@ -141,8 +141,13 @@ def step_losses(model, batch, epoch, criterion, cosine):
             _out2, feats2, _ = model(view2, **fo)
         if fused:
             loc = _ops.concat_batch([_to_gpu(v) for v in local_views])
+            chunked = _ddp.chunk_partition_on()       # opt-in: nn.DataParallel's literal scatter of the [6B] local-view tensor (ddp.py)
+            if chunked:
+                loc = _ddp.chunk_local_inputs(loc, n, len(local_views))
             with _ops.view_pass(loc.device, loc, name="local"):
                 _, feats_loc, _ = model(loc, local=True, **fo)
+            if chunked:
+                feats_loc = _ddp.chunk_local_features(feats_loc, n, len(local_views))
     if fused:
         cos2, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))
         l_restore = criterion(out1, target)
@@ -150,7 +155,12 @@ def step_losses(model, batch, epoch, criterion, cosine):
         total, l_deep, l_global, l_local = _fn.loss_tail(l_restore, cos2, criterion(masks1[scale], target), beta)   # one launch: the sum and beta * MSE
         return total, l_restore, l_global, l_deep, l_local
     l_global, scale = cos_loss(cosine, feats1, feats2)
-    _, feats_loc, _ = model(torch.cat([_to_gpu(v) for v in local_views], dim=0), local=True, **fo)
+    loc = torch.cat([_to_gpu(v) for v in local_views], dim=0)
+    if _ddp.chunk_partition_on():
+        loc = _ddp.chunk_local_inputs(loc, n, len(local_views))
+    _, feats_loc, _ = model(loc, local=True, **fo)
+    if _ddp.chunk_partition_on():
+        feats_loc = _ddp.chunk_local_features(feats_loc, n, len(local_views))
     stacked = [torch.stack(pair) for pair in feats_loc]                 # [2, 6n, C] per scale
     l_local = 0.0
     for i in range(len(local_views)):

@@ -1049,9 +1049,10 @@ from pcrlv2_amd.optim import FusedSGD
 from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step
 rank, world, _ = ddp.init_process_group_from_env("gloo")     # two processes, ONE GPU: gloo moves the CUDA buffers
 torch.cuda.set_device(0)
-fx = np.load(os.path.join(root, "tests", "golden", "dp2_b4x2_32x32x16.npz"))
+fx = np.load(os.path.join(root, "tests", "golden", os.environ.get("TEST_DP_FIXTURE", "dp2_b4x2_32x32x16") + ".npz"))
 b, dhw, nsteps = int(fx["meta/b_rank"]), tuple(int(v) for v in fx["meta/dhw"]), int(fx["meta/nsteps"])
 assert world == int(fx["meta/world"])
+assert ddp.chunk_partition_on() == (str(fx["meta/partition"]) == "chunk" if "meta/partition" in fx.files else False)
 overlap = os.environ.get("TEST_OVERLAP", "0") == "1"
 random.seed(int(fx["meta/seed"]))        # every rank draws the scales of the ONE global cos_loss call sequence
 model = PCRLv23d().cuda()
@@ -1087,6 +1088,32 @@ dist.barrier()
 print("OK", rank, "worst parameter |d| after %d data-parallel steps = %.2e" % (nsteps, worst), flush=True)
 dist.destroy_process_group()
 """
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_data_parallel_literal_chunk_partition_of_the_local_views(tmp_path, overlap):
+    """PCRL_DP_LOCAL_PARTITION=chunk (opt-in; VERDICT r4 "missing" 5): nn.DataParallel's literal scatter of the concatenated [6B] local-view tensor
+    (train_3d.py:121-123: with two replicas, replica 0 runs local views 0-2 of ALL samples, so the local pass's BatchNorm statistics group rows
+    differently than the engine's by-sample default) -- two gloo ranks on one GPU against tests/golden/dp2chunk_b4x2_32x32x16.npz, which the REAL
+    model produced under that scatter (oracle/make_golden.py --data-parallel): every rank's losses of both iterations, every parameter after the
+    second update, rank 0's running statistics -- the same bounds as the by-sample test below.  The two fixtures differ (local_loss of step 0:
+    -5.07e-3 / +3.07e-3 here, other values there), so passing this one with the default partition is impossible."""
+    import subprocess
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fa, fb = (np.load(os.path.join(root, "tests", "golden", t + ".npz")) for t in ("dp2chunk_b4x2_32x32x16", "dp2_b4x2_32x32x16"))
+    assert abs(float(fa["step0/rank0/local_loss"]) - float(fb["step0/rank0/local_loss"])) > 1e-4        # the partition changes the result
+    script = tmp_path / "ddp_chunk.py"
+    script.write_text(DDP_ORACLE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29775" if overlap else "29773", WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TEST_OVERLAP="1" if overlap else "0", TEST_DP_FIXTURE="dp2chunk_b4x2_32x32x16", PCRL_DP_LOCAL_PARTITION="chunk")
+    procs = [subprocess.Popen([sys.executable, str(script), root], env=dict(env, RANK=str(r), LOCAL_RANK="0"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert all("OK" in o for o in outs)
+    print("\n".join(l for o in outs for l in o.splitlines() if l.startswith("OK")))
 
 
 @pytest.mark.parametrize("overlap", [False, True])

@@ -152,10 +152,12 @@ def test_constructor_variants_match_reference(tag, golden_dir):
             np.testing.assert_allclose(nb[key[5:]].double().numpy(), fx[key], rtol=0, atol=1e-10, err_msg=key)
 
 
-def test_data_parallel_semantics_match_reference(golden_dir):
+@pytest.mark.parametrize("tag", ["dp2_b4x2_32x32x16", "dp2chunk_b4x2_32x32x16"])
+def test_data_parallel_semantics_match_reference(golden_dir, tag):
     """`oracle.train_steps_data_parallel` (nn.DataParallel, train_3d.py:54: per-replica statistics, replica 0's buffers persist, losses over
     the gathered batch, summed gradients, one SGD step) against the fixture `make_golden.py --data-parallel` produced with the REAL model."""
-    fx = _load(golden_dir, "dp2_b4x2_32x32x16")
+    fx = _load(golden_dir, tag)       # by-sample partition of the local views (the engine's default) / nn.DataParallel's literal [6B]-chunk scatter
+    part = str(fx["meta/partition"]) if "meta/partition" in fx.files else "sample"
     b, dhw, nsteps, world = int(fx["meta/b_rank"]), tuple(int(v) for v in fx["meta/dhw"]), int(fx["meta/nsteps"]), int(fx["meta/world"])
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     st0 = O.fill_state(torch.float64)
@@ -164,7 +166,7 @@ def test_data_parallel_semantics_match_reference(golden_dir):
         # the first iteration only (the CPU suite's time budget): losses and the summed gradient; the state after both iterations is asserted
         # equal when the fixture is generated (make_golden.make_dp) and is what the two-rank GPU test is held to
         st, _mom, log, g0 = O.train_steps_data_parallel(st0, rb[:1], int(fx["meta/epoch"]), float(fx["meta/base_lr"]), int(fx["meta/epochs"]),
-                                                        int(fx["meta/seed"]))
+                                                        int(fx["meta/seed"]), partition=part)
     for s in range(1):
         for r in range(world):
             for k in ("loss", "loss1", "loss2", "loss4", "local_loss"):
