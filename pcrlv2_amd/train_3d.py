@@ -147,6 +147,7 @@ def step_losses(model, batch, epoch, criterion, cosine):
             with _ops.view_pass(loc.device, loc, name="local"):
                 _, feats_loc, _ = model(loc, local=True, **fo)
             if chunked:
+                _ops.join_side_stream()        # the heads ran on the side stream (config.FWD_BRANCH_STREAM): the exchange reads their outputs on this one
                 feats_loc = _ddp.chunk_local_features(feats_loc, n, len(local_views))
     if fused:
         cos2, scale = _fused_cos_losses(feats1, feats2, feats_loc, n, len(local_views))

