@@ -24,7 +24,10 @@ int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, v
   // every CU a block.  Measured per layer (tools/conv_probe.py, same box): 512->256 at 16x16x8 1445 -> 1544 TFLOP/s, 256->256 1433 -> 1495,
   // 256->128 at 32x32x16 1320 -> 1383, 128->128 1365 -> 1403; the 64-output-channel layers (one tile per brick) do not gain (128->64 at
   // 64x64x32: 1330 -> 1300) and small grids lose (128->128 at 16x16x8, 64 blocks: 1105 -> 805).  PCRL_B16_NW8=0: off; =2: every eligible shape.
-  static const int nw8_env = [] { const char* e = getenv("PCRL_B16_NW8"); return e ? atoi(e) : 1; }();
+  // Round 5: with the halo plan (conv_brick16.h) the 4-plane form is as fast or faster on EVERY layer (same box, tools/conv_probe.py: 64->128 at 32x32x16
+  // 1 363 vs 1 225 TFLOP/s, 256->128 1 537 vs 1 480, 128->128 1 492 vs 1 435, the 16x16x8 decoder layers within 1 %; one pass over the model's layers 4.28 vs
+  // 4.35 ms) -- what the 8-plane brick saved was halo REQUEST ISSUE, which the plan made cheap.  Default off now; PCRL_B16_NW8=1: the round-4 rule, =2: everywhere.
+  static const int nw8_env = [] { const char* e = getenv("PCRL_B16_NW8"); return e ? atoi(e) : 0; }();
   const int nw8_mode = g_brick16_planes >= 0 ? (int)g_brick16_planes : nw8_env;   // test hook (pcrl_debug_set_conv_impl 5 / 6) over the environment
   int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
   const bool nw8 = nw8_mode > 0 && BN == 64 && D % 8 == 0 && (nw8_mode == 2 || (ny >= 2 && (bricks / 2) * ny >= 256));
