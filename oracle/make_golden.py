@@ -410,8 +410,14 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
         criterion, cosine = torch.nn.MSELoss(), torch.nn.CosineSimilarity()
         random.seed(seed)
         rows = []
+        # the float64 run takes hours: its state (model, momentum, draws, rows so far) is checkpointed every 25 steps and picked up again
+        ck = f"/tmp/{tag}_{str(dt).split('.')[-1]}.ckpt"
+        if partial is not None and os.path.exists(ck):
+            st_ = torch.load(ck, weights_only=False)
+            model.load_state_dict(st_["model"]); opt.load_state_dict(st_["opt"]); random.setstate(st_["random"]); rows = st_["rows"]
+            print(f"[{tag}] resumed {dt} at step {len(rows)} from {ck}", flush=True)
         with torch.backends.mkldnn.flags(enabled=onednn):
-            for s in range(nsteps):
+            for s in range(len(rows), nsteps):
                 batch = O.fill_batch(b, dhw, dtype=dt, seed=2000 + s)
                 r = reference_step(model, ref_train, batch, epoch, criterion, cosine)
                 opt.zero_grad()
@@ -421,7 +427,8 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
                 if s % 20 == 0 or s == nsteps - 1:
                     print(f"[{tag}] {dt} step {s}: {rows[-1]}", flush=True)
                 if partial is not None and (s + 1) % 25 == 0:
-                    partial(np.array(rows))       # the float64 run takes hours: a usable (shorter) fixture exists from step 25 on
+                    partial(np.array(rows))
+                    torch.save({"model": model.state_dict(), "opt": opt.state_dict(), "random": random.getstate(), "rows": rows}, ck)       # the float64 run takes hours: a usable (shorter) fixture exists from step 25 on
         return np.array(rows)
 
     def ema_of(v):

@@ -390,12 +390,17 @@ bool pcrl_brick_conv2d_eligible(int N, int H, int W, int Ci, int Co, int dtype);
 int64_t pcrl_brick_conv2d_rows(int N, int H, int W);
 int pcrl_brick_conv2d_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Ci, int Co, int up,
                              hipStream_t stream);
+// wide-brick LDS-DMA kernel (conv_brick16.h, MODE 3): 4 images x 8 x 16 pixels per block, no upsampled source
+bool pcrl_brick16_conv2d_eligible(int N, int H, int W, int Ci, int Co, int dtype);
+int64_t pcrl_brick16_conv2d_rows(int N, int H, int W);
+int pcrl_brick16_conv2d_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Ci, int Co, hipStream_t stream);
 // right-sized kernel for layers with <= 32 channels on both sides (conv2d_narrow.hip)
 bool pcrl_conv2d_narrow_eligible(int N, int H, int W, int Cs, int Nc, int ks, int dtype);
 int64_t pcrl_conv2d_narrow_rows(int N, int H, int W);
 int pcrl_conv2d_narrow_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Cs, int Nc, int ks,
                               int up, int out_f32, int red2, hipStream_t stream);
-static std::atomic<int> g_conv2d_impl{0};   // 0 = auto (brick / narrow kernels where eligible), 1 = always the gather kernel
+static std::atomic<int> g_conv2d_impl{0};   // 0 = auto (wide brick / brick / narrow kernels where eligible), 1 = always the gather kernel, 2 = auto without the wide brick (tests, A/B)
+static inline bool auto_impl() { return g_conv2d_impl == 0 || g_conv2d_impl == 2; }
 extern "C" void pcrl_debug_set_conv2d_impl(int impl) { g_conv2d_impl = impl; }
 
 extern "C" int64_t pcrl_conv2d_packed_elems(int rows, int taps, int Cs) {
@@ -420,18 +425,19 @@ extern "C" int pcrl_conv2d_pack(const float* w_ref, void* out, int Co, int Ci, i
 
 extern "C" int64_t pcrl_conv2d_stats_rows(int N, int Ho, int Wo) { return ((int64_t)N * Ho * Wo + PCRL_CONV_BM - 1) / PCRL_CONV_BM; }
 
-// which kernel the forward dispatcher picks: 0 gather, 1 LDS-halo brick, 2 right-sized narrow kernel
+// which kernel the forward dispatcher picks: 0 gather, 1 LDS-halo brick (4 x 8 x 8), 2 right-sized narrow kernel, 3 wide brick (4 x 8 x 16, LDS-DMA)
 // The 32 -> 32 channel layers (decoder block 3 at 256^2) go to the right-sized narrow kernel rather than the brick kernel: 204-219 -> 168 us per
 // launch on the same box once the narrow kernel runs two waves per SIMD (PCRL_OCC2).  PCRL_NARROW_FIRST=0: brick kernel first (A/B switch).
 static bool narrow_first(int Cs, int Nc) {
   static const bool on = [] { const char* e = getenv("PCRL_NARROW_FIRST"); return !(e && e[0] == '0'); }();
   return on && Cs <= 32 && Nc <= 32;
 }
-static int conv2d_fwd_kind(int N, int Ho, int Wo, int CiP, int Co, int KH, int KW, int stride, int pad, int out_f32, int dtype) {
-  if (g_conv2d_impl == 0 && narrow_first(CiP, Co) && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype))
+static int conv2d_fwd_kind(int N, int Ho, int Wo, int CiP, int Co, int KH, int KW, int stride, int pad, int out_f32, int dtype, int up) {
+  if (auto_impl() && narrow_first(CiP, Co) && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype))
     return 2;
-  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !out_f32 && pcrl_brick_conv2d_eligible(N, Ho, Wo, CiP, Co, dtype)) return 1;
-  if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype))
+  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !out_f32 && !up && pcrl_brick16_conv2d_eligible(N, Ho, Wo, CiP, Co, dtype)) return 3;
+  if (auto_impl() && KH == 3 && KW == 3 && stride == 1 && pad == 1 && !out_f32 && pcrl_brick_conv2d_eligible(N, Ho, Wo, CiP, Co, dtype)) return 1;
+  if (auto_impl() && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype))
     return 2;
   return 0;
 }
@@ -440,8 +446,8 @@ static int conv2d_fwd_kind(int N, int Ho, int Wo, int CiP, int Co, int KH, int K
 extern "C" int64_t pcrl_conv2d_fwd_stats_rows(int N, int Hi, int Wi, int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype) {
   const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
   const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
-  const int kind = conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype);
-  return kind == 1 ? pcrl_brick_conv2d_rows(N, Ho, Wo) : kind == 2 ? pcrl_conv2d_narrow_rows(N, Ho, Wo) : pcrl_conv2d_stats_rows(N, Ho, Wo);
+  const int kind = conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype, up);
+  return kind == 3 ? pcrl_brick16_conv2d_rows(N, Ho, Wo) : kind == 1 ? pcrl_brick_conv2d_rows(N, Ho, Wo) : kind == 2 ? pcrl_conv2d_narrow_rows(N, Ho, Wo) : pcrl_conv2d_stats_rows(N, Ho, Wo);
 }
 
 // which kernel pcrl_conv2d_fwd / pcrl_conv2d_dgrad run for a geometry: 0 gather implicit GEMM, 1 LDS-halo brick kernel, 2 right-sized narrow kernel
@@ -449,14 +455,15 @@ extern "C" int64_t pcrl_conv2d_fwd_stats_rows(int N, int Hi, int Wi, int CiP, in
 extern "C" int64_t pcrl_conv2d_fwd_kind(int N, int Hi, int Wi, int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype) {
   const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
   const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
-  return conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype);
+  return conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype, up);
 }
 extern "C" int64_t pcrl_conv2d_dgrad_kind(int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH, int KW, int stride, int pad, int dtype) {
-  if (g_conv2d_impl == 0 && narrow_first(CoP, Ci) && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && Hi == Ho && Wi == Wo &&
+  if (auto_impl() && narrow_first(CoP, Ci) && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && Hi == Ho && Wi == Wo &&
       pcrl_conv2d_narrow_eligible(N, Hi, Wi, CoP, Ci, KH, dtype))
     return 2;
-  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo && pcrl_brick_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype)) return 1;
-  if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && Hi == Ho && Wi == Wo &&
+  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo && pcrl_brick16_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype)) return 3;
+  if (auto_impl() && KH == 3 && KW == 3 && stride == 1 && pad == 1 && Hi == Ho && Wi == Wo && pcrl_brick_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype)) return 1;
+  if (auto_impl() && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && Hi == Ho && Wi == Wo &&
       pcrl_conv2d_narrow_eligible(N, Hi, Wi, CoP, Ci, KH, dtype))
     return 2;
   return 0;
@@ -467,12 +474,13 @@ extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias,
                                int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream) {
   const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
   const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
-  const int kind = (x && wp && y) ? conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype) : 0;
+  const int kind = (x && wp && y) ? conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype, up) : 0;
   if (stats_partial) {
-    const int64_t rw = kind == 1 ? pcrl_brick_conv2d_rows(N, Ho, Wo) : kind == 2 ? pcrl_conv2d_narrow_rows(N, Ho, Wo) : pcrl_conv2d_stats_rows(N, Ho, Wo);
+    const int64_t rw = kind == 3 ? pcrl_brick16_conv2d_rows(N, Ho, Wo) : kind == 1 ? pcrl_brick_conv2d_rows(N, Ho, Wo) : kind == 2 ? pcrl_conv2d_narrow_rows(N, Ho, Wo) : pcrl_conv2d_stats_rows(N, Ho, Wo);
     PCRL_REQUIRE(stats_rows >= rw, "conv2d_fwd: %lld statistics rows allocated, %lld needed (pcrl_conv2d_fwd_stats_rows)", (long long)stats_rows, (long long)rw);
     if (stats_rows > rw) (void)hipMemsetAsync(stats_partial + rw * Co * 2, 0, (size_t)(stats_rows - rw) * Co * 2 * sizeof(float), as_stream(stream));
   }
+  if (kind == 3) return pcrl_brick16_conv2d_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, as_stream(stream));
   if (kind == 1) return pcrl_brick_conv2d_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, up, as_stream(stream));
   if (kind == 2) return pcrl_conv2d_narrow_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, KH, up, out_f32, 0, as_stream(stream));
   return conv2d_common("conv2d_fwd", C2_FWD, x, wp, bias, y, stats_partial, N, Hi, Wi, CiP, Ho, Wo, Co, KH, KW, stride, pad, up, out_f32, dtype,
@@ -483,7 +491,7 @@ extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias,
 // models/pcrlv2_model.py:114), WITH the upsample's backward: dx[N][Hc][Wc][Ci] = 2 x 2 block sums of the fine-resolution data gradient,
 // which is never stored.  Available (pcrl_conv2d_dgrad_up_ok) where the right-sized narrow kernel takes the fine-resolution problem.
 extern "C" int64_t pcrl_conv2d_dgrad_up_ok(int N, int Hc, int Wc, int Ci, int CoP, int dtype) {
-  return (g_conv2d_impl == 0 && pcrl_conv2d_narrow_eligible(N, 2 * Hc, 2 * Wc, CoP, Ci, 3, dtype)) ? 1 : 0;
+  return (auto_impl() && pcrl_conv2d_narrow_eligible(N, 2 * Hc, 2 * Wc, CoP, Ci, 3, dtype)) ? 1 : 0;
 }
 extern "C" int pcrl_conv2d_dgrad_up(const void* dy, const void* wp_dgrad, void* dx, int N, int Hc, int Wc, int Ci, int CoP, int dtype, pcrl_stream_t stream) {
   PCRL_REQUIRE(dy && wp_dgrad && dx, "conv2d_dgrad_up: null pointer");
@@ -494,10 +502,12 @@ extern "C" int pcrl_conv2d_dgrad_up(const void* dy, const void* wp_dgrad, void* 
 // dx[N][Hi][Wi][Ci] from dy[N][Ho][Wo][CoP]; (Ho, Wo) are the forward output dims of the (Hi, Wi) input.
 extern "C" int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH,
                                  int KW, int stride, int pad, int dtype, pcrl_stream_t stream) {
-  if (g_conv2d_impl == 0 && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
+  if (g_conv2d_impl == 0 && dy && wp_dgrad && dx && pcrl_conv2d_dgrad_kind(N, Hi, Wi, Ci, Ho, Wo, CoP, KH, KW, stride, pad, dtype) == 3)
+    return pcrl_brick16_conv2d_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, as_stream(stream));
+  if (auto_impl() && KH == 3 && KW == 3 && stride == 1 && pad == 1 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
       pcrl_brick_conv2d_eligible(N, Hi, Wi, CoP, Ci, dtype) && pcrl_conv2d_dgrad_kind(N, Hi, Wi, Ci, Ho, Wo, CoP, KH, KW, stride, pad, dtype) == 1)
     return pcrl_brick_conv2d_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, 0, as_stream(stream));
-  if (g_conv2d_impl == 0 && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
+  if (auto_impl() && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && dy && wp_dgrad && dx && Hi == Ho && Wi == Wo &&
       pcrl_conv2d_narrow_eligible(N, Hi, Wi, CoP, Ci, KH, dtype))
     return pcrl_conv2d_narrow_launch(dy, wp_dgrad, nullptr, dx, nullptr, N, Hi, Wi, CoP, Ci, KH, 0, 0, 0, as_stream(stream));
   return conv2d_common("conv2d_dgrad", C2_DGRAD, dy, wp_dgrad, nullptr, dx, nullptr, N, Ho, Wo, CoP, Hi, Wi, Ci, KH, KW, stride, pad, 0, 0, dtype,

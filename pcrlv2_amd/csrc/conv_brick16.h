@@ -106,7 +106,9 @@ __device__ __forceinline__ void lds_dma16_masked(uint64_t base, uint32_t voff, u
                : "memory", "vcc");
 }
 
-// MODE 0: 3x3x3 convolution; 1: composed up-conv forward; 2: composed up-conv data gradient (Brick16Params).
+// MODE 0: 3x3x3 convolution; 1: composed up-conv forward; 2: composed up-conv data gradient (Brick16Params); 3: 3x3 convolution of the 2D path -- the image
+// index plays the role of depth (a brick = 4 images x 8 x 16 pixels), only the three kd = 1 stages are walked, the two d planes of the halo no tap reads
+// are not requested, weights are packed [Nc][9][K] (round 5: the 2D step's stride-1 layers on the LDS-DMA kernel instead of conv_brick.hip's register staging).
 // PERM 1: the brick's (d, h, w) axes run along the volume's (D, W, H) -- p.D, p.H, p.W are then the extents along the BRICK axes (D, W, H of the
 // volume) -- for volumes whose H, not W, is a multiple of 16 (the 16 x 16 x 8 level).  A convolution commutes with a permutation of the axes
 // applied to volume, taps and phases alike: only the voxel index (VOX / FVOX), the tap number of a weight row (WTAP), the phase / parity bit of
@@ -116,8 +118,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
   using G = B16Geom<NW>;
   constexpr int ROWS = G::ROWS, NDMA = G::NDMA, HALO_BYTES = G::HALO_BYTES, HD = G::HD;
   constexpr int FN = BN / 16;
-  constexpr bool UPCF = MODE == 1, UPCD = MODE == 2;
-  constexpr int NSK = MODE ? 4 : NS;   // stages per chunk
+  constexpr bool UPCF = MODE == 1, UPCD = MODE == 2, P2D = MODE == 3;
+  constexpr int NSK = P2D ? 3 : (MODE ? 4 : NS);   // stages per chunk
+  constexpr int TAPS = P2D ? 9 : 27;               // taps per packed weight row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* halo = smem;
   char* wbuf = smem + HALO_BYTES;
@@ -149,13 +152,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
 #define VOX(n_, d_, h_, w_) (PERM ? (((int64_t)(n_)*p.D + (d_)) * p.W + (w_)) * p.H + (h_) : (((int64_t)(n_)*p.D + (d_)) * p.H + (h_)) * p.W + (w_))
 #define FVOX(n_, d_, h_, w_) (PERM ? (((int64_t)(n_) * (2 * p.D) + (d_)) * (2 * p.W) + (w_)) * (2 * p.H) + (h_) \
                                    : (((int64_t)(n_) * (2 * p.D) + (d_)) * (2 * p.H) + (h_)) * (2 * p.W) + (w_))
-#define WTAP(s9_, j_) (PERM ? ((s9_) / 3) * 9 + (j_)*3 + (s9_) % 3 : (s9_)*3 + (j_))   /* (kd, kh, kw) of the brick -> tap number of the volume */
+#define WTAP(s9_, j_) ((PERM ? ((s9_) / 3) * 9 + (j_)*3 + (s9_) % 3 : (s9_)*3 + (j_)) - (MODE == 3 ? 9 : 0))   /* (kd, kh, kw) of the brick -> tap number of the volume (2D: kd = 1, 9-tap rows) */
   const int uph = UPCF ? n0 / p.upc : 0, ukd0 = BITD(uph), ukh0 = BITH(uph);
   // stage number -> (kd * 3 + kh).  UPCF: the block's phase uses k = p, p + 1 per axis; UPCD: chunk c's parity uses k = 1 - par, 2 - par.
 #define PARC(c_) ((c_) >> p.cshift)
-#define SID(c_, s_) (MODE == 0 ? (s_) : MODE == 1 ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) \
+#define SID(c_, s_) (MODE == 0 ? (s_) : MODE == 3 ? 3 + (s_) : MODE == 1 ? ((ukd0 + ((s_) >> 1)) * 3 + ukh0 + ((s_)&1)) \
                                                  : ((1 - BITD(PARC(c_)) + ((s_) >> 1)) * 3 + 1 - BITH(PARC(c_)) + ((s_)&1)))
-#define KWB(c_) (MODE == 0 ? 0 : MODE == 1 ? BITW(uph) : 1 - BITW(PARC(c_)))   /* first of the kw taps in use (composed modes: two, the third tap's weights are zero) */
+#define KWB(c_) (MODE == 0 || MODE == 3 ? 0 : MODE == 1 ? BITW(uph) : 1 - BITW(PARC(c_)))   /* first of the kw taps in use (composed modes: two, the third tap's weights are zero) */
   const int brick_lin = b;   // NW == 4: the statistics row of this brick (kept instead of re-derived in the epilogue: seven fewer live scalars)
   const int w0 = (b % bw) * TW; b /= bw;
   const int h0 = (b % bh) * TH; b /= bh;
@@ -208,7 +211,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
       const bool inside = row < ROWS && (unsigned)d < (unsigned)p.D && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
       // composed forward: the block's phase reads taps k = bit, bit + 1 per axis -- one of the T + 2 planes / lines / columns of the halo is never read
       // (29 % of the rows): not requested.  (Round 4 measured this 1-2 % SLOWER -- with the old per-piece address arithmetic; with the plan it is a mask bit.)
-      const bool used = !UPCF || (P != (ukd0 ? 0 : HD - 1) && hh != (ukh0 ? 0 : HH - 1) && hw != (BITW(uph) ? 0 : HP - 1));
+      const bool used = P2D ? (P != 0 && P != HD - 1)      /* 2D: no tap reaches into the neighbouring images */
+                            : (!UPCF || (P != (ukd0 ? 0 : HD - 1) && hh != (ukh0 ? 0 : HH - 1) && hw != (BITW(uph) ? 0 : HP - 1)));
       const bool ok = inside && used;
       const int key = key_w(hw) >> 1;
       if (i == 0) {
@@ -258,10 +262,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
 
   // ---- weight staging through registers: 3 pieces per thread (taps kw = 0,1,2 of the stage), row co = tid >> 2, slot tid & 3 ----
   const bool wthread = NW * 16 <= BN || (tid >> 2) < BN;   // compile-time true for four waves x 64 channels: no exec mask around the weight stores
-  const uint32_t wlane = (uint32_t)(((n0 + (wthread ? (tid >> 2) : 0)) * 27) * K + (tid & 3) * 8) * 2u;   // byte offset of the thread's weight row (weights < 4 GiB: eligibility)
+  const uint32_t wlane = (uint32_t)(((n0 + (wthread ? (tid >> 2) : 0)) * TAPS) * K + (tid & 3) * 8) * 2u;   // byte offset of the thread's weight row (weights < 4 GiB: eligibility)
   const int wdst = woff(tid >> 2, tid & 3);
   u32x4 rw[3];
-  constexpr int NKW = MODE ? 2 : 3;   // kw taps per stage: the composed modes stage and multiply only the two taps their phase / parity uses
+  constexpr int NKW = (UPCF || UPCD) ? 2 : 3;   // kw taps per stage: the composed modes stage and multiply only the two taps their phase / parity uses
 #define LOAD_W(c_, s9_, kwb_) /* taps kwb_ .. kwb_ + NKW - 1 of stage (kd, kh) */                          \
   do {                                                                                                     \
     _Pragma("unroll") for (int j = 0; j < NKW; ++j)                                                        \
@@ -435,7 +439,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
   LOADB(0, wbuf);
 
   const int nstage = NSK * nchunk;
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 0 || MODE == 3) {
     for (int S = 0; S + 1 < nstage; S += 2) {
       STAGE(0);
       STAGE(1);

@@ -42,3 +42,24 @@ int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, v
   return BN == 64 ? launch16<64, 0>(p, grid, stream, "brick16_conv") : launch16<32, 0>(p, grid, stream, "brick16_conv");
 }
 
+
+// ---- 2D path (MODE 3): 3x3 / stride 1 / pad 1 convolution of [N][H][W][Ci] images, forward or data gradient (conv2d.hip's dispatcher) ----
+// The image index is the brick's d axis (4 images per brick); wp: packed [Co][9][Ci] (pcrl_conv2d_pack); stats [bricks][Co][2] or null.
+bool pcrl_brick16_conv2d_eligible(int N, int H, int W, int Ci, int Co, int dtype) {
+  static const bool on = [] { const char* e = getenv("PCRL_B16_2D"); return !(e && e[0] == '0'); }();     // A/B switch: 0 = the 4 x 8 x 8-brick kernel (round 4)
+  return on && g_brick16_on && dtype == PCRL_BF16 && N % TD == 0 && brick16_perm(N, H, W) != 0 && Ci % 32 == 0 && Co % 32 == 0 &&
+         (int64_t)N * H * W < ((int64_t)1 << 29) && (int64_t)20 * Ci * H * W < ((int64_t)1 << 31) && (int64_t)18 * Ci * Co < ((int64_t)1 << 32);
+}
+int64_t pcrl_brick16_conv2d_rows(int N, int H, int W) { return (int64_t)N * H * W / (TD * TH * TW); }
+int pcrl_brick16_conv2d_launch(const void* x, const void* wp, const float* bias, void* y, float* stats, int N, int H, int W, int Ci, int Co, hipStream_t stream) {
+  Brick16Params p{(const bf16*)x, (const bf16*)wp, bias, (bf16*)y, stats, 1, N, H, W, Ci, Co, 0, 0, nullptr, 0};
+  const int BN = Co % 64 == 0 ? 64 : 32, ny = Co / BN;
+  const int64_t bricks = pcrl_brick16_conv2d_rows(N, H, W);
+  if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16_conv2d: grid too large");
+  dim3 grid((unsigned)bricks, ny);
+  if (ny > 1) {
+    p.ny = ny;
+    grid = dim3((unsigned)(bricks * ny));
+  }
+  return BN == 64 ? launch16<64, 3>(p, grid, stream, "brick16_conv2d") : launch16<32, 3>(p, grid, stream, "brick16_conv2d");
+}

@@ -158,10 +158,15 @@ def test_add_relu_and_mask(dt):
     assert torch.equal(gk.cpu(), torch.where(ref > 0, da, torch.zeros_like(da)))
 
 
-@pytest.mark.parametrize("Ci,Co,up,H,W,N", [(64, 64, 0, 16, 24, 4), (64, 32, 0, 8, 16, 8), (128, 64, 1, 8, 8, 4), (32, 128, 0, 24, 8, 4)])
+@pytest.mark.parametrize("Ci,Co,up,H,W,N", [(64, 64, 0, 16, 24, 4), (64, 32, 0, 8, 16, 8), (128, 64, 1, 8, 8, 4), (32, 128, 0, 24, 8, 4),
+                                            # the wide-brick LDS-DMA kernel (conv_brick16.h MODE 3; W % 16 == 0, or H % 16 == 0 on its permuted axes): edge bricks in every
+                                            # direction, one and several bricks, 64- and 32-channel tiles, several channel tiles, two chunks and more
+                                            (64, 64, 0, 16, 32, 4), (32, 64, 0, 24, 48, 8), (128, 128, 0, 8, 16, 4), (64, 128, 0, 32, 8, 4), (128, 32, 0, 16, 16, 12),
+                                            (64, 64, 1, 8, 16, 4)])     # upsampled source: stays on the 4 x 8 x 8-brick kernel
 def test_conv2d_brick_path(Ci, Co, up, H, W, N):
-    """3x3 / stride 1 bf16 convolutions with N % 4 == H % 8 == W % 8 == 0 and channels % 32 == 0 run on the LDS-halo brick kernel
-    (conv_brick.hip, KD = 1), forward (optionally behind the nearest x2 upsample) and data gradient; statistics rows included."""
+    """3x3 / stride 1 bf16 convolutions with N % 4 == H % 8 == W % 8 == 0 and channels % 32 == 0 run on the LDS-halo brick kernels -- the wide brick
+    (4 images x 8 x 16 pixels, LDS-DMA; round 5) where it tiles and the source is not upsampled, else conv_brick.hip's 4 x 8 x 8 brick -- forward
+    (optionally behind the nearest x2 upsample) and data gradient; statistics rows included.  impl 0 = auto, 2 = auto without the wide brick, 1 = gather."""
     from pcrlv2_amd import ops2d
     from pcrlv2_amd._lib import lib
     dt = torch.bfloat16
@@ -176,9 +181,13 @@ def test_conv2d_brick_path(Ci, Co, up, H, W, N):
     dy = torch.randn(yr.shape, generator=g)
     yr.backward(_q(dy, dt))
     outs = {}
-    for impl in (0, 1):            # 0 = auto (brick), 1 = gather kernel
+    Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+    wide = (not up) and (Wo % 16 == 0 or (Ho % 16 == 0 and Wo % 8 == 0))
+    from pcrlv2_amd._lib import dtype_code
+    assert lib().call("pcrl_conv2d_fwd_kind", N, H, W, Ci, Co, 3, 3, 1, 1, up, 0, dtype_code(dt)) == (3 if wide else 1)
+    for impl in (0, 2, 1):         # 0 = auto (wide brick where it tiles), 2 = auto without the wide brick, 1 = gather kernel
         lib().debug_set_conv2d_impl(impl)
-        lib().debug_set_wgrad_impl(impl)     # weight gradient: brick kernel (wgrad_brick.hip, nkd = 1) where Co % 64 == 0 and no upsample
+        lib().debug_set_wgrad_impl(1 if impl == 1 else 0)     # weight gradient: brick kernel (wgrad_brick.hip, nkd = 1) where Co % 64 == 0 and no upsample
         try:
             packed = ops2d.PackedConv2d()
             y, partial, rows = ops2d.conv2d_forward(xa, wd, None, packed, 1, 1, up, dt)
@@ -195,6 +204,7 @@ def test_conv2d_brick_path(Ci, Co, up, H, W, N):
         outs[impl] = (y.float().cpu(), dx.float().cpu())
     # same operands, same fp32 accumulation: the two kernels differ only in summation order
     assert (outs[0][0] - outs[1][0]).abs().max() <= 0.02 * outs[1][0].abs().max()
+    assert (outs[0][0] - outs[2][0]).abs().max() <= 0.02 * outs[1][0].abs().max() and (outs[0][1] - outs[2][1]).abs().max() <= 0.02 * outs[1][1].abs().max()
 
 
 # ---- round 4: the 3-channel ends of the step (csrc/heads2d.hip) and the summed-gradient BatchNorm backward ----------------------------

@@ -140,7 +140,7 @@ def brick2d_keyfn(lib):
         else:
             kind = lib.call("pcrl_conv2d_dgrad_kind", a["N"], a["Hi"], a["Wi"], a["Ci"], a["Ho"], a["Wo"], a["CoP"], a["KH"], a["KW"], a["stride"], a["pad"], a["dtype"])
             b, f = Account2D.RULES["pcrl_conv2d_dgrad"](a, 2)
-        return ("brick_conv_kernel<2D>", "conv2d_narrow_kernel", "conv2d_kernel(gather)")[1 if kind == 2 else (0 if kind == 1 else 2)], f
+        return {1: "brick_conv_kernel<2D>", 2: "conv2d_narrow_kernel", 3: "brick16_conv_kernel<2D>"}.get(kind, "conv2d_kernel(gather)"), f
     return key
 
 
