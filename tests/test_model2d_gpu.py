@@ -360,6 +360,7 @@ def test_full_size_conv2d_adjoint_identities_bf16(layer):
     dy = torch.empty_like(y)
     dy.normal_(generator=g)
     dx, dw = ops2d.conv2d_backward(x, dy, w, packed, stride, pad, up, dt, need_dx=True)
+    ops2d.ops.join_side_stream()      # dw is produced on the weight-gradient side stream (ops.side_wgrad): the engine joins it before the gradients are summed
     wq = w.to(dt).double()
     a = float((y.double() * dy.double()).sum())
     b_ = float((x[:, :dx.shape[1]].double() * dx.double()).sum())

@@ -13,6 +13,7 @@ def _dev():
 
 
 def _close(got, ref, dt, what, f32_tol=2e-5, bf_tol=2e-2):
+    torch.cuda.synchronize()      # operator-level tests read results of EVERY engine stream (weight gradients are produced on the side stream, ops.side_wgrad)
     got = got.detach().double().cpu()
     ref = ref.detach().double()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
@@ -75,6 +76,7 @@ def test_conv2d_fwd_dgrad_wgrad(geom, dt):
     dy = torch.randn(yr.shape, generator=g)
     dya = ops2d.to_act2(dy.to(_dev()), dt)
     dx, dw = ops2d.conv2d_backward(xa, dya, wd, packed, stride, pad, up, dt, need_dx=True)
+    ops2d.ops.join_side_stream()      # dw is produced on the weight-gradient side stream (ops.side_wgrad): the engine joins it before the gradients are summed
     yr.backward(_q(dy, dt))
     _close(dx[:, :Ci], xr.grad, dt, "conv2d dgrad", bf_tol=6e-3)
     _close(dw, wr.grad, torch.float32, "conv2d wgrad", f32_tol=3e-5 if dt == torch.float32 else 1e-4)
@@ -101,6 +103,7 @@ def test_conv2d_to3_float_output(K, Ci, W, dt):
     dy = torch.randn(yr.shape, generator=g)
     dyp = ops2d.to_act2(dy.to(_dev()), dt, pad_to=8)
     dx, dw = ops2d.conv2d_backward(xa, dyp, w.to(_dev()), packed, 1, K // 2, 0, dt)
+    ops2d.ops.join_side_stream()      # dw is produced on the weight-gradient side stream (ops.side_wgrad): the engine joins it before the gradients are summed
     yr.backward(_q(dy, dt))
     _close(dx, xr.grad, dt, "conv -> 3 dgrad", bf_tol=6e-3)
     _close(dw, wr.grad, torch.float32, "conv -> 3 wgrad", f32_tol=1e-4)
@@ -192,6 +195,7 @@ def test_conv2d_brick_path(Ci, Co, up, H, W, N):
             packed = ops2d.PackedConv2d()
             y, partial, rows = ops2d.conv2d_forward(xa, wd, None, packed, 1, 1, up, dt)
             dx, dw = ops2d.conv2d_backward(xa, ops2d.to_act2(dy.to(_dev()), dt), wd, packed, 1, 1, up, dt)
+            ops2d.ops.join_side_stream()      # dw is produced on the weight-gradient side stream (ops.side_wgrad): the engine joins it before the gradients are summed
         finally:
             lib().debug_set_conv2d_impl(0)
             lib().debug_set_wgrad_impl(0)

@@ -37,6 +37,7 @@ def act_dev(t, dt):
 
 
 def back(t):
+    torch.cuda.synchronize()      # operator-level tests read results of EVERY engine stream (weight gradients are produced on the side stream, ops.side_wgrad)
     return t.detach().double().cpu().contiguous()
 
 

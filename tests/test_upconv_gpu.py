@@ -24,6 +24,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 def back(t):
+    torch.cuda.synchronize()      # operator-level tests read results of EVERY engine stream (weight gradients are produced on the side stream, ops.side_wgrad)
     return t.detach().double().cpu().contiguous()
 
 
