@@ -1,11 +1,16 @@
 # Every launch of ONE one-stream step in issue order, with grid and duration, plus a per-(kernel, grid) summary:
 #   gpurun -- 'bash tools/step_launch_table.sh [tag] [bench args...]'     -> gpurun_out/<tag>_launches.txt, <tag>_launch_groups.txt
+#   STEP2D=1: the 2D step (tools/bench_2d.py) instead of bench.py
 TAG=${1:-launches}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 export PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 PCRL_VIEW_STREAMS=0
 rm -rf $R/gpurun_out/slt
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/slt -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alone --no-secondary "$@" > $R/gpurun_out/slt.log 2>&1
+if [ "$STEP2D" = 1 ]; then
+  rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/slt -- python $R/tools/bench_2d.py --steps 4 --warmup 2 "$@" > $R/gpurun_out/slt.log 2>&1
+else
+  rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/slt -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-alone --no-secondary "$@" > $R/gpurun_out/slt.log 2>&1
+fi
 python - $R/gpurun_out/${TAG} $(find $R/gpurun_out/slt -name "*kernel_trace.csv") <<'PY'
 import csv, sys, re, collections
 out, f = sys.argv[1:3]
