@@ -22,7 +22,10 @@ def timed(fn, n=9):
     return ts[len(ts) // 2]
 
 
-for M, C in ((4194304, 64), (4194304, 32), (524288, 128), (524288, 64), (65536, 256)):
+SHAPES = ((4194304, 64), (4194304, 32), (524288, 128), (524288, 64), (65536, 256))
+if len(sys.argv) > 1:      # "M,C;M,C;..."  (2D decoder: 16777216,16;16777216,32;4194304,64)
+    SHAPES = tuple(tuple(int(v) for v in t.split(",")) for t in sys.argv[1].split(";"))
+for M, C in SHAPES:
     da = torch.randn(M, C, device=dev).to(dt)
     y = torch.randn(M, C, device=dev).to(dt)
     dy = torch.empty_like(y)
