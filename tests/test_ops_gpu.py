@@ -309,7 +309,7 @@ def test_one_channel_wgrad_brick_kernel(case):
     assert (dw - dw2).abs().max().item() <= 2e-3 * max(1.0, dw2.abs().max().item())
 
 
-@pytest.mark.parametrize("C", [64, 128, 256])
+@pytest.mark.parametrize("C", [32, 64, 96, 128, 256])
 def test_conv_to_one_channel_brick_kernel(C):
     """bf16 deep-supervision head forward on a brick-eligible volume (several bricks per axis: interior and boundary halos):
     the LDS-halo kernel against F.conv3d with bf16-rounded operands, the per-brick BatchNorm partials, and the two-pass kernel."""
@@ -330,6 +330,14 @@ def test_conv_to_one_channel_brick_kernel(C):
     st = back(part).view(-1, 2).sum(0)
     assert abs(st[0].item() - ref.sum().item()) <= 1e-4 * max(1.0, ref.abs().sum().item())
     assert abs(st[1].item() - (ref * ref).sum().item()) <= 1e-4 * max(1.0, (ref * ref).sum().item())
+    # with a workspace the weight tiles are packed once per call and (C <= 128) the halo is staged by LDS-DMA into two chunk buffers
+    # (to1_brick_dma_kernel): the same MFMAs in the same order -- bit-identical output and statistics rows
+    nbf = L.call("pcrl_conv3d_to1_fwd_ws_bytes", N, D, H, W, C, 27)
+    yw = torch.zeros(M, dtype=torch.float32, device=DEV)
+    partw = torch.zeros(rows * 2, dtype=torch.float32, device=DEV)
+    L.call("pcrl_conv3d_to1_fwd", xa, wdev, bdev, yw, partw, ops.workspace(nbf, xa.device), nbf, N, D, H, W, C, 27, dtype_code(dt), s)
+    torch.cuda.synchronize()
+    assert torch.equal(yw, y) and torch.equal(partw, part)
     # the two-pass kernel (debug switch) rounds at the same points: float32 sums of bf16 products, different order only
     L.debug_set_conv_impl(1)
     try:
