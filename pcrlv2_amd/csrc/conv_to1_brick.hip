@@ -31,8 +31,15 @@ constexpr int HROWS = NFRAG * 16;                     // 608 rows of 64 B
 constexpr int HALO_BYTES = HROWS * 64;                // 38 912
 constexpr int HPT = (HROWS * 4 + 255) / 256;          // 10 staging pieces (16 B) per thread and chunk
 constexpr int FPW = (NFRAG + 3) / 4;                  // 10 fragments per wave (wave w: fragments w, w + 4, ...)
-constexpr int ZA = 17, ZB = 13;                       // row pitches (floats) of the two z phases: odd, conflict-free for the writes and the gather
-constexpr int Z_BYTES = ZROWS * ZA * 4;               // 40 800
+constexpr int ZA = 17, ZB = 13;                       // TO1_ZT = 0: row pitches (floats) of the two z phases: odd, conflict-free for the writes and the gather
+// TO1_ZT = 1 (round 5): z tap-major, zl[tap][row] with a plane pitch of ZP floats.  The four accumulator elements of a lane are four CONSECUTIVE rows of one
+// tap: one ds_write_b128 instead of four ds_write_b32 -- 20 instead of 80 LDS writes per lane and brick.  (profiles/r05y_to1_dma_ab.txt, r05z_to1_ab.txt: 203 -> 191 us at 64 x 64 x 32 x 32, 64 channels.)  ZP = 612: 16-byte aligned planes, and the eight lanes of a write phase (taps lr .. lr + 7) land 144 bytes
+// apart mod 256 -- distinct bank quads.  Same sums in the same order: bit-identical.
+#ifndef TO1_ZT
+#define TO1_ZT 1
+#endif
+constexpr int ZP = 612;
+constexpr int Z_BYTES = TO1_ZT ? 16 * ZP * 4 : ZROWS * ZA * 4;   // 39 168 / 40 800
 
 struct To1Params {
   const bf16* x;        // [M][C]
@@ -157,6 +164,28 @@ __global__ void __launch_bounds__(256, 3) to1_brick_fwd_kernel(const To1Params p
   const int vrow = (vd * HH + vh) * HWU + vw;            // halo row of tap (0, 0, 0)
   float out = p.bias ? p.bias[0] : 0.f;
   // phase A: taps 0 .. 15 (C layout of the 16x16 MFMA: acc[f][j][r] = row 16 (wid + 4 f) + 4 lg + r, tap 16 j + lr)
+#if TO1_ZT
+#pragma unroll
+  for (int f = 0; f < FPW; ++f)
+    if (wid + 4 * f < NFRAG) *reinterpret_cast<f32x4*>(zl + lr * ZP + (wid + 4 * f) * 16 + 4 * lg) = acc[f][0];   // rows 600 .. 607 of the last fragment: inside the plane, never read
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    out += zl[t * ZP + vrow + (kd * HH + kh) * HWU + kw];
+  }
+  __syncthreads();
+  // phase B: taps 16 .. 26
+#pragma unroll
+  for (int f = 0; f < FPW; ++f)
+    if (wid + 4 * f < NFRAG && lr < 11) *reinterpret_cast<f32x4*>(zl + lr * ZP + (wid + 4 * f) * 16 + 4 * lg) = acc[f][1];
+  __syncthreads();
+#pragma unroll
+  for (int t = 16; t < 27; ++t) {
+    const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    out += zl[(t - 16) * ZP + vrow + (kd * HH + kh) * HWU + kw];
+  }
+#else
 #pragma unroll
   for (int f = 0; f < FPW; ++f)
 #pragma unroll
@@ -185,6 +214,7 @@ __global__ void __launch_bounds__(256, 3) to1_brick_fwd_kernel(const To1Params p
     const int kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
     out += zl[(vrow + (kd * HH + kh) * HWU + kw) * ZB + (t - 16)];
   }
+#endif
   p.y[(((int64_t)n * p.D + d0 + vd) * p.H + h0 + vh) * p.W + w0 + vw] = out;
   if (p.stats) {
     __shared__ float red[8];

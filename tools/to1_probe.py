@@ -1,6 +1,6 @@
 """Probe of the 1-channel layers: C -> 1 brick forward (deep-supervision heads) and 1 -> Co first layer, HIP-event timing at the C2 shapes."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pcrlv2_amd._lib import dtype_code, lib, stream_handle
 L, dev, dt = lib(), torch.device("cuda"), torch.bfloat16
