@@ -108,25 +108,39 @@ __global__ void __launch_bounds__(256, CO <= 32 ? 4 : 2) c1_brick_fwd_kernel(con
   constexpr int FN = CO / 16;
   __shared__ float sh[2][600];
   __shared__ float red[4 * CO * 2];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lg = lane >> 4;
   const int bw = g.W / 8, bh = g.H / 8, bd = g.D / 4;
+  const uint32_t yl = (uint32_t)((((lg >> 1) * g.W + (lg & 1) * 4) * CO + lr) * 2);   // lane part of every store address of the epilogue
   // halo staging: the (up to) three loads of a thread are issued together (one global-memory latency per brick instead of three)
   float hv[3];
   bool hok[3];
+  // Per piece, ONCE per thread: the halo voxel's offset from the brick's first voxel and the faces of the halo it lies on (bit: d-, d+, h-, h+, w-, w+;
+  // bit 6 = not a halo voxel).  Per brick a block-uniform mask of the faces that stick out of the volume decides validity with one AND, and the load is
+  // a block-uniform base pointer + a 32-bit offset (was: per piece and brick two divisions of the piece number by constants, three range checks and a
+  // 64-bit voxel index -- 12 quarter-rate multiplies and 6 64-bit multiply-adds per lane and brick on a vector unit that is the kernel's limiter).
+  int hrel[3];
+  uint32_t hedge[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int q = tid + 256 * i;
+    const int hd = q / 100, hh = (q / 10) % 10, hw = q % 10;
+    hrel[i] = ((hd - 1) * g.H + (hh - 1)) * g.W + (hw - 1);
+    hedge[i] = (hd == 0 ? 1u : 0u) | (hd == 5 ? 2u : 0u) | (hh == 0 ? 4u : 0u) | (hh == 9 ? 8u : 0u) | (hw == 0 ? 16u : 0u) | (hw == 9 ? 32u : 0u) |
+               (q < 600 ? 0u : 64u);
+  }
 #define C1_LOAD(b_)                                                                                       \
   do {                                                                                                    \
     int t_ = (b_);                                                                                        \
     const int w0_ = (t_ % bw) * 8; t_ /= bw;                                                              \
     const int h0_ = (t_ % bh) * 8; t_ /= bh;                                                              \
     const int d0_ = (t_ % bd) * 4; t_ /= bd;                                                              \
-    const int64_t base_ = (((int64_t)t_ * g.D + d0_) * g.H + h0_) * g.W + w0_;                            \
+    const float* const xb_ = x + ((((int64_t)t_ * g.D + d0_) * g.H + h0_) * g.W + w0_);                   \
+    const uint32_t out_ = (d0_ == 0 ? 1u : 0u) | (d0_ + 4 == g.D ? 2u : 0u) | (h0_ == 0 ? 4u : 0u) | (h0_ + 8 == g.H ? 8u : 0u) |   \
+                          (w0_ == 0 ? 16u : 0u) | (w0_ + 8 == g.W ? 32u : 0u) | 64u;                       \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                                       \
-      const int q = tid + 256 * i;                                                                        \
-      const int hd = q / 100, hh = (q / 10) % 10, hw = q % 10;                                            \
-      const int d = d0_ + hd - 1, h = h0_ + hh - 1, w = w0_ + hw - 1;                                     \
-      hok[i] = q < 600 && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W; \
-      hv[i] = x[hok[i] ? (((int64_t)t_ * g.D + d) * g.H + h) * g.W + w : base_];                          \
+      hok[i] = (hedge[i] & out_) == 0;                                                                    \
+      hv[i] = xb_[hok[i] ? hrel[i] : 0];                                                                  \
     }                                                                                                     \
   } while (0)
 #define C1_STORE(buf_)                                                                                    \
@@ -147,7 +161,7 @@ __global__ void __launch_bounds__(256, CO <= 32 ? 4 : 2) c1_brick_fwd_kernel(con
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int t = 8 * lg + e;
-    toff[e] = t < 27 ? ((t / 9) * 10 + (t / 3) % 3) * 10 + t % 3 : -1;
+    toff[e] = t < 27 ? ((t / 9) * 10 + (t / 3) % 3) * 10 + t % 3 : 0;   // K slots 27 .. 31: any tap of the voxel's own window -- their weight rows are zero
   }
   float bv[FN];
 #pragma unroll
@@ -173,7 +187,7 @@ __global__ void __launch_bounds__(256, CO <= 32 ? 4 : 2) c1_brick_fwd_kernel(con
       const int hb = ((wid * 10 + 2 * f + (lr >> 3)) * 10) + (lr & 7);   // halo index of the lane's voxel (tap 0,0,0 corner)
       bf16x8 fa;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) fa[e] = toff[e] >= 0 ? (bf16)shc[hb + toff[e]] : (bf16)0.f;
+      for (int e = 0; e < 8; ++e) fa[e] = (bf16)shc[hb + toff[e]];
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -184,16 +198,21 @@ __global__ void __launch_bounds__(256, CO <= 32 ? 4 : 2) c1_brick_fwd_kernel(con
       s1[j] = 0.f;
       s2[j] = 0.f;
     }
+    // Store addresses (round 5, as in conv_brick16.h): voxel v = 16 f + 4 lg + r of the wave's plane sits at h = 2 f + (lg >> 1), w = 4 (lg & 1) + r, so a row
+    // is a wave-uniform SCALAR base (brick origin + the wave's plane + 2 f lines + r voxels) + one loop-invariant lane offset + the store's immediate
+    // (32 j bytes).  The 64-bit voxel index per (f, r) on the vector unit (22 quarter-rate 32-bit multiplies, 11 64-bit multiply-adds and ~60 shifts /
+    // adds per lane and brick: ~40 % of the loop's vector issue time, with the SIMDs 65 % busy on vector instructions -- rocprofv3 counters +
+    // tools/isa_mix.py, profiles/r05z_c1_addr_ab.txt) is gone.
+    char* const ybase = reinterpret_cast<char*>(y) + (base0 + (int64_t)wid * g.H * g.W) * (CO * 2);
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int v = f * 16 + lg * 4 + r;   // voxel of the wave's plane: h = v >> 3, w = v & 7
-        const int64_t row = base0 + ((int64_t)wid * g.H + (v >> 3)) * g.W + (v & 7);
+        char* const yrow = ybase + ((int64_t)(2 * f) * g.W + r) * (CO * 2);   // scalar
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const float val = acc[f][j][r] + bv[j];
-          y[row * CO + j * 16 + lr] = (bf16)val;
+          *reinterpret_cast<bf16*>(yrow + yl + j * 32) = (bf16)val;
           s1[j] += val;
           s2[j] += val * val;
         }
@@ -224,7 +243,7 @@ __global__ void __launch_bounds__(256, CO <= 32 ? 4 : 2) c1_brick_fwd_kernel(con
       }
     }
     if (more) C1_STORE(cur ^ 1);
-    __syncthreads();   // the other halo buffer is complete; everybody has read this one and this brick's `red`
+    __syncthreads();   // the other halo buffer is complete; everybody has read this one and this brick's `red` (one barrier with a double-buffered `red`: measured equal, profiles/r05z_c1_addr_ab.txt)
   }
 #undef C1_LOAD
 #undef C1_STORE
