@@ -273,6 +273,39 @@ __global__ void __launch_bounds__(256) to1_fwd_kernel(const T* __restrict__ x, c
   const float b0 = bias ? bias[0] : 0.f;
   float s1 = 0.f, s2 = 0.f;
   const int64_t mbeg = (int64_t)blockIdx.x * TO1_VOX;
+  if (taps == 1 && nvec == lpv) {
+    // Pointwise head (out_tr: 1x1x1, 64 -> 1) with one channel vector per lane: no voxel decode (two 64-bit divisions per voxel), the lane's weights in
+    // registers, four voxels' loads in flight.  The general loop below ran the SIMDs' vector issue 85 % busy at 4.2 TB/s (profiles/r05z_3d_valu_table.txt:
+    // 4 120 vector instructions per wave); same products in the same order.
+    float wreg[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) wreg[j] = wl[sub * VEC + j];
+    constexpr int U = 4;
+    for (int it = 0; it < TO1_VOX / vpp; it += U) {
+      Vec16<T> xv[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t m = mbeg + (it + u) * vpp + vslot;
+        ok[u] = m < M;
+        xv[u] = ld16(x + (ok[u] ? m : mbeg) * C + sub * VEC);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc += to_f(xv[u].v[j]) * wreg[j];
+        if (!ok[u]) acc = 0.f;
+        for (int o = lpv >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (ok[u] && sub == 0) {
+          const float v = acc + b0;
+          y[mbeg + (it + u) * vpp + vslot] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+  } else
   for (int it = 0; it < TO1_VOX / vpp; ++it) {
     const int64_t m = mbeg + it * vpp + vslot;
     float acc = 0.f;
