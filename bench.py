@@ -48,6 +48,13 @@ def conv_key(name, args):
     """Classify a pcrl_conv3d_k3_fwd launch the way the library's dispatcher does (conv_igemm.hip / conv_brick.hip) and
     return its algorithmic FLOPs (2 * voxels * 27 * Ci * Co)."""
     # pcrl_conv3d_k3_fwd_ws(x, wp, bias, y, stats, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream)   [_fwd: without ws, ws_bytes]
+    if name == "pcrl_conv3d_k3_dgrad_bnred":
+        # (dy, wp, dx, bn_y, scale, shift, mean, rstd, partial, N, D, H, W, Ci, Co, act, dtype, stream): the wide-brick data gradient with the first pass of
+        # the BatchNorm backward of the layer below in its epilogue -- its own instantiation (conv_brick16_bnr.hip), its own row; it also reads bn_y
+        N, D, H, W, Ci, Co = args[9:15]
+        key = "brick16_conv_kernel<dgrad+bn_reduce>"
+        ALG_BYTES[key] += 2.0 * (N * D * H * W * (Ci + 2 * Co) + 27 * Ci * Co)
+        return key, 2.0 * N * D * H * W * 27 * Ci * Co
     N, D, H, W, Ci, Co, dt = args[7:14] if name == "pcrl_conv3d_k3_fwd_ws" else args[5:12]
     from pcrlv2_amd import _lib
     kid = _lib.lib().call("pcrl_conv3d_k3_fwd_kernel", N, D, H, W, Ci, Co, dt)
@@ -96,7 +103,7 @@ def upconv_key(name, args):
 def keyfn(name, args):
     if name.startswith("pcrl_upconv"):
         return upconv_key(name, args)
-    return conv_key(name, args) if name.startswith("pcrl_conv3d_k3_fwd") else wgrad_key(name, args)
+    return conv_key(name, args) if name.startswith(("pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_dgrad")) else wgrad_key(name, args)
 
 
 def synthetic_batch(b, dhw, local, device, seed, nlocal=6):
@@ -353,7 +360,7 @@ def main():
         random.setstate(st0)
         ddp_ab = {"settings": ddp_ab, "used_for_timed_region": best, "steps_each": 6}
     prof = types_ns(results=lambda: {"brick16_conv_kernel": (1, 1.0, 1.0)}) if dry else \
-        _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad", "pcrl_upconv_dgrad_ws",
+        _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_dgrad_bnred", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad", "pcrl_upconv_dgrad_ws",
                             "pcrl_upconv_wgrad_accum"}, keyfn)
     import gc
     gc.collect()
@@ -403,7 +410,7 @@ def main():
         _branch, _cfg.FWD_BRANCH_STREAM = _cfg.FWD_BRANCH_STREAM, False
         for _ in range(2):
             train_step(model, opt, batch, 0, crit, cosine, guard=False)
-        alone = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad", "pcrl_upconv_dgrad_ws",
+        alone = _lib.EventProfiler({"pcrl_conv3d_k3_fwd", "pcrl_conv3d_k3_fwd_ws", "pcrl_conv3d_k3_dgrad_bnred", "pcrl_conv3d_k3_wgrad", "pcrl_upconv_fwd", "pcrl_upconv_dgrad", "pcrl_upconv_dgrad_ws",
                                     "pcrl_upconv_wgrad_accum"}, keyfn)   # every matrix kernel: roofline.weighted_matrix_frac
         ALG_BYTES.clear()
         torch.cuda.synchronize()

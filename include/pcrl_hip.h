@@ -79,6 +79,20 @@ int64_t pcrl_conv3d_k3_fwd_ws_bytes(int N, int D, int H, int W, int Ci, int Co, 
 int pcrl_conv3d_k3_fwd_ws(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, void* ws, int64_t ws_bytes,
                           int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream);
 
+/* Data gradient of a 3x3x3 convolution (convolution_backward(input) of LUConv.conv1, models/pcrlv2_model_3d.py:9,33) WITH the first pass of the
+ * BatchNorm backward of the layer BELOW in its epilogue -- for the case that layer's activation has this convolution as its only consumer
+ * (ops.0 -> ops.1 inside nn.Sequential(LUConv, LUConv), :37-45): dx IS the gradient of a = relu(scale * bn_y + shift), and rows of
+ * (sum dz, sum dz * xhat), dz = [scale * bn_y + shift > 0] * dx (as stored), xhat = (bn_y - mean) * rstd, come out of the convolution's tiles
+ * instead of a separate pass over dx and bn_y (pcrl_bn_act_bwd_reduce; aten::threshold_backward + native_batch_norm_backward's reduction).
+ * dy: [N][D][H][W][Ci]; wp_dgrad: the packed data-gradient weights of pcrl_conv3d_k3_fwd; dx, bn_y: [N][D][H][W][Co]; scale .. rstd: Co floats
+ * (pcrl_bn_finalize's outputs for the layer below); partial: [rows][Co][2] float for pcrl_bn_bwd_finalize(partial, rows, Co, count = N D H W, ...).
+ * `pcrl_conv3d_k3_dgrad_bnred_rows` returns the row count, or 0 when the shape / activation / dtype has no such kernel (wide-brick bf16 shapes
+ * behind ReLU only): the caller then runs pcrl_conv3d_k3_fwd_ws and pcrl_bn_act_bwd_reduce as two passes. */
+int64_t pcrl_conv3d_k3_dgrad_bnred_rows(int N, int D, int H, int W, int Ci, int Co, int act, int dtype);
+int pcrl_conv3d_k3_dgrad_bnred(const void* dy, const void* wp_dgrad, void* dx, const void* bn_y, const float* scale, const float* shift,
+                               const float* mean, const float* rstd, float* partial, int N, int D, int H, int W, int Ci, int Co, int act,
+                               int dtype, pcrl_stream_t stream);
+
 /* Weight gradient (aten::convolution_backward, weight half).  dw_ref[co][ci][27] float32, reference layout.
  * Split-K over voxels with a fixed-order second pass.  ws: pcrl_conv3d_k3_wgrad_ws_bytes(). */
 size_t pcrl_conv3d_k3_wgrad_ws_bytes(int N, int D, int H, int W, int Ci, int Co);

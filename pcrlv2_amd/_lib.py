@@ -7,6 +7,7 @@ error.  There is NO fallback: if the library is absent or a call fails, a Runtim
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import re
@@ -96,6 +97,22 @@ class _Lib:
 
     def last_error(self) -> str:
         return self.fn["pcrl_last_error"][0]().decode()
+
+    @contextlib.contextmanager
+    def count_calls(self, *names):
+        """Counts the calls of the named entry points inside the block (tests: which kernels a step really used) -> {name: calls}."""
+        class _Counter:
+            def __init__(self, watch):
+                self.watch, self.n = set(watch), {}
+
+            def add(self, name, args):
+                self.n[name] = self.n.get(name, 0) + 1
+
+        prev, self.counter = self.counter, _Counter(names)
+        try:
+            yield self.counter.n
+        finally:
+            self.counter = prev
 
     def call(self, name: str, *args):
         """Call an `int pcrl_*` entry point; tensors -> device pointers, None -> NULL; raises on error."""

@@ -20,7 +20,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-gpu-rdc",
 # Per-file code generation flags.  conv_brick16.hip: the plain wide-brick instantiations sit at the 256-register budget of two waves per SIMD; the greedy
 # allocator's default assignment order spills 9-17 registers there (fragment addresses, reloaded behind s_waitcnt vmcnt(0) in the middle of a stage), the
 # reverse order fits all of them (profiles/r05_b16_isa_mix.txt).
-FILE_FLAGS = {"conv_brick16.hip": ["-mllvm", "-greedy-reverse-local-assignment"]}
+FILE_FLAGS = {"conv_brick16.hip": ["-mllvm", "-greedy-reverse-local-assignment"], "conv_brick16_bnr.hip": ["-mllvm", "-greedy-reverse-local-assignment"]}
 
 
 def hipcc() -> str:

@@ -84,6 +84,9 @@ FOLD_POOL_GRAD = os.environ.get("PCRL_FOLD_POOL_GRAD", "1") != "0"
 # stage end) or its global average pool (UpTransition) -- instead of a second kernel re-reading the activation it just wrote
 # (pcrl_bn_act_apply_pool / pcrl_bn_act_apply_gap).  PCRL_FUSE_APPLY_CONSUMERS=0: separate kernels (A/B switch; results are bit-identical).
 FUSE_APPLY_CONSUMERS = os.environ.get("PCRL_FUSE_APPLY_CONSUMERS", "1") != "0"
+# The data gradient of ops.1 takes the first pass of ops.0's BatchNorm backward from its own output tiles (pcrl_conv3d_k3_dgrad_bnred: wide-brick bf16 shapes
+# behind ReLU; ops.luconv_backward's `bnred`).  PCRL_DGRAD_BNRED=0: the separate reduce pass (A/B switch; same arithmetic per element, different summation order).
+DGRAD_BNRED = os.environ.get("PCRL_DGRAD_BNRED", "1") != "0"
 
 # UpTransition: up_conv (ConvTranspose3d k2 s2) and ops.0.conv1 (3x3x3) are applied back to back (pcrlv2_model_3d.py:64) -- composed into
 # one 8-tap operator on the coarse grid (csrc/upconv_fused.hip): 0.30 of the multiply-adds of the 27-tap convolution over the upsampled

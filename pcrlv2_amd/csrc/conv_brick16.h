@@ -81,6 +81,12 @@ struct Brick16Params {
   // dy0[2 v + e - 1] wd[e]: parity 0 uses k in {1, 2}, parity 1 uses k in {0, 1}).  A chunk walks the 4 of 9 (kd, kh) stages and the two kw
   // taps of ITS parity; the output is an ordinary coarse tensor [N][D][H][W][Nc].
   int cshift;
+  // BNR instantiations only (data gradient with the BatchNorm backward's first pass in the epilogue, conv_brick16_bnr.hip): the output is the gradient
+  // of the activation a = relu(scale * bn_y + shift) of the layer below; `stats` rows receive (sum dz, sum dz * xhat) with dz = [scale * bn_y + shift > 0]
+  // * (this output, rounded to bf16 as stored), xhat = (bn_y - mean) * rstd -- what bn_bwd_reduce_kernel (norm_pool.hip) computes from a second read of
+  // the stored gradient.  bn_y: [N][D][H][W][Nc] bf16, the layout of y; bn_scale / bn_shift / bn_mean / bn_rstd: Nc floats each (pcrl_bn_finalize's outputs).
+  const bf16* bn_y;
+  const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd;
 };
 
 __device__ __forceinline__ int key_w(int hw) { return ((0xFC30 >> hw) & 1) << 1; }   // hw in [0, 18)
@@ -113,8 +119,9 @@ __device__ __forceinline__ void lds_dma16_masked(uint64_t base, uint32_t voff, u
 // volume) -- for volumes whose H, not W, is a multiple of 16 (the 16 x 16 x 8 level).  A convolution commutes with a permutation of the axes
 // applied to volume, taps and phases alike: only the voxel index (VOX / FVOX), the tap number of a weight row (WTAP), the phase / parity bit of
 // an axis (BITH / BITW) and the border class (CLS) know the difference; rows still go through LDS one 64-byte slice per voxel.
-template <int BN, int MODE = 0, int PERM = 0, int NW = 4>
+template <int BN, int MODE = 0, int PERM = 0, int NW = 4, bool BNR = false>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(const Brick16Params p) {
+  static_assert(!BNR || (MODE == 0 && NW == 4), "the BatchNorm-reduce epilogue exists for the plain 4-plane data gradient only");
   using G = B16Geom<NW>;
   constexpr int ROWS = G::ROWS, NDMA = G::NDMA, HALO_BYTES = G::HALO_BYTES, HD = G::HD;
   constexpr int FN = BN / 16;
@@ -478,12 +485,20 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
   //      forward: the bias of a fine voxel's border class is a per-(fm) scalar class plus, in bricks on the phase's w border, one lane column
   //      (r = 0 of lanes lg = 0 for the phases with an even fine w, r = 3 of lg = 3 for the odd ones): 8-16 bias loads per lane, not 128. ----
   float s1[FN], s2[FN], bv[FN], bvE[FN];
+  float bsc[FN], bsh[FN], bmu[FN], brs[FN];   // BNR: the layer below's BatchNorm coefficients of this lane's FN channels
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     s1[j] = 0.f;
     s2[j] = 0.f;
     bv[j] = (!UPCF && p.bias) ? p.bias[n0 + j * 16 + lr] : 0.f;
     bvE[j] = 0.f;
+    if (BNR) {
+      const int c = n0 + j * 16 + lr;
+      bsc[j] = p.bn_scale[c];
+      bsh[j] = p.bn_shift[c];
+      bmu[j] = p.bn_mean[c];
+      brs[j] = p.bn_rstd[c];
+    }
   }
   const int uch0 = UPCF ? n0 - uph * p.upc : 0;                       // first channel of this tile inside its phase
   const int ypitch = UPCF ? p.upc : p.Nc;
@@ -493,6 +508,29 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
   const int WS = UPCF ? 2 * fineW : fineW, HS = UPCF ? 2 * fineH : fineH;
   const int64_t row0 = UPCF ? FVOX(n, 2 * (d0 + wid) + BITD(uph), 2 * h0 + BITH(uph), 2 * w0 + BITW(uph)) : VOX(n, d0 + wid, h0, w0);
   char* const ybase = reinterpret_cast<char*>(p.y) + (row0 * ypitch + (UPCF ? uch0 : n0)) * 2;   // wave-uniform
+  // BNR: the wave's plane of the layer below's pre-normalisation tensor (128 voxels x BN channels, the geometry of the output tile) goes to LDS by DMA
+  // now -- the halo is dead -- and lands under the stores below: 16 (BN = 64) / 8 (BN = 32) one-KiB pieces per wave, a piece = 64 / SL consecutive w
+  // voxels of one h line x SL 16-byte slots.  The epilogue reads it back two bytes per lane (channel 16 j + lr of voxel 4 lg + r): the four lg groups of
+  // a wave sit 4 voxels = a multiple of 256 bytes apart -- the same banks -- so a voxel's slots are XOR-ed with 2 lg on the SOURCE side (BN = 64:
+  // conflict-free; BN = 32, four slots per voxel: two-way).  Bytes [0, BNR_LDS0) stay free for the statistics rows' block reduction.
+  constexpr int BNR_LDS0 = 4096;
+  if (BNR) {
+    constexpr int SL = BN / 8, VP = 64 / SL, PPL = 16 / VP, NPW = 8 * PPL;
+    static_assert(!BNR || BNR_LDS0 + NW * 128 * BN * 2 <= HALO_BYTES, "the y tile reuses the halo buffer");
+    const uint64_t bnbase = (uint64_t)(uintptr_t)p.bn_y + (uint64_t)((row0 * ypitch + n0) * 2);   // wave-uniform
+    const uint32_t ydst = lds_base + BNR_LDS0 + wid * (128 * BN * 2);
+    const int vl = lane / SL, sl = lane % SL;
+    uint32_t m0keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(m0keep));
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) {
+      const int w = (q % PPL) * VP + vl;
+      const int lsl = sl ^ (BN == 64 ? ((w >> 2) & 3) * 2 : ((w >> 2) & 1) * 2);
+      const uint32_t voff = (uint32_t)((q / PPL) * HS + w * WS + lsl * 16);
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(ydst + q * 1024), "s"(bnbase) : "memory");
+    }
+    asm volatile("s_mov_b32 m0, %0" ::"s"(m0keep));
+  }
   const uint32_t yl = (uint32_t)(lg * 4 * WS + lr * 2);
   // composed forward: border classes (0 first, 1 inside, 2 last per axis; class number in volume order)
   const int fd_ = 2 * (d0 + wid) + BITD(uph);
@@ -525,10 +563,34 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
         float bias = bv[j];
         if (UPCF && (r == 0 || r == 3)) bias = (elane && r == (pwb ? 3 : 0)) ? bvE[j] : bv[j];
         const float val = acc[fm][j][r] + bias;
-        *reinterpret_cast<bf16*>(yrow + yl + j * 32) = (bf16)val;
-        s1[j] += val;
-        s2[j] += val * val;
+        const bf16 vb = (bf16)val;
+        *reinterpret_cast<bf16*>(yrow + yl + j * 32) = vb;
+        if (BNR) {
+          acc[fm][j][r] = (float)vb;   // the value as stored: what the separate reduce pass would read back
+        } else {
+          s1[j] += val;
+          s2[j] += val * val;
+        }
       }
+    }
+  }
+  if (BNR) {
+    // bn_bwd_reduce_kernel's arithmetic (ReLU) on the stored values against the y tile staged above
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own DMA pieces (a wave reads only the plane it requested: no barrier)
+    const char* ytile = smem + BNR_LDS0 + wid * (128 * BN * 2) + (4 * lg) * (BN * 2) + (lr >> 3) * 16 + (lr & 7) * 2;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {   // one channel fragment at a time (32 LDS reads in flight; all 128 at once spilled)
+      const int jx = j ^ (BN == 64 ? lg : (lg & 1));   // the staging swizzle (source side of the DMA)
+#pragma unroll
+      for (int fm = 0; fm < 8; ++fm)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float yv = (float)*reinterpret_cast<const bf16*>(ytile + (fm * 16 + r) * (BN * 2) + jx * 32);
+          const float dz = bsc[j] * yv + bsh[j] > 0.f ? acc[fm][j][r] : 0.f;
+          s1[j] += dz;
+          s2[j] += dz * (yv - bmu[j]) * brs[j];
+        }
+      asm volatile("" : "+v"(s1[j]), "+v"(s2[j])::"memory");   // this fragment's sums are complete here, the next fragment's reads start here
     }
   }
   if (p.stats) {
@@ -579,19 +641,19 @@ inline int brick16_perm(int D, int H, int W) {
 
 
 // p.D / p.H / p.W arrive as the volume's extents; perm == 2: handed to the PERM instantiation as the extents along the brick axes (D, W, H)
-template <int BN, int MODE, int NW = 4>
+template <int BN, int MODE, int NW = 4, bool BNR = false>
 inline int launch16(Brick16Params p, dim3 grid, hipStream_t stream, const char* what) {
   constexpr size_t lds = B16Geom<NW>::HALO_BYTES + 3 * BN * 64 + (NW == 4 ? 0 : 1024);   // NW = 8: + the halo plan's mask words
   static std::once_flag attr_once;
   std::call_once(attr_once, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 0, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 1, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 0, NW, BNR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(brick16_conv_kernel<BN, MODE, 1, NW, BNR>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   if (brick16_perm(p.D, p.H, p.W) == 2) {
     std::swap(p.H, p.W);
-    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 1, NW>), grid, dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 1, NW, BNR>), grid, dim3(NW * 64), lds, stream, p);
   } else {
-    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 0, NW>), grid, dim3(NW * 64), lds, stream, p);
+    hipLaunchKernelGGL((brick16_conv_kernel<BN, MODE, 0, NW, BNR>), grid, dim3(NW * 64), lds, stream, p);
   }
   return pcrl_check_launch(what);
 }

@@ -647,6 +647,25 @@ extern "C" int pcrl_conv3d_k3_fwd_ws(const void* x, const void* wp, const float*
   return conv3d_k3_fwd_impl(x, wp, bias, y, stats_partial, ws, ws_bytes, N, D, H, W, Ci, Co, dtype, stream);
 }
 
+// ---- data gradient + first pass of the BatchNorm backward of the layer below (conv_brick16_bnr.hip) ----
+int pcrl_brick16_dgrad_bnred_launch(const void* dy, const void* wp, void* dx, const void* bn_y, const float* scale, const float* shift, const float* mean,
+                                    const float* rstd, float* partial, int N, int D, int H, int W, int Ci, int Co, hipStream_t stream);
+extern "C" int64_t pcrl_conv3d_k3_dgrad_bnred_rows(int N, int D, int H, int W, int Ci, int Co, int act, int dtype) {
+  static const bool off = [] { const char* e = getenv("PCRL_DGRAD_BNRED"); return e && e[0] == '0'; }();   // A/B switch
+  if (off || act != PCRL_ACT_RELU || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Co <= 0) return 0;
+  if (g_conv_impl == 0 && pcrl_brick16_conv_eligible(N, D, H, W, Ci, Co, dtype)) return pcrl_brick16_conv_rows(N, D, H, W);
+  return 0;
+}
+extern "C" int pcrl_conv3d_k3_dgrad_bnred(const void* dy, const void* wp_dgrad, void* dx, const void* bn_y, const float* scale, const float* shift,
+                                          const float* mean, const float* rstd, float* partial, int N, int D, int H, int W, int Ci, int Co, int act,
+                                          int dtype, pcrl_stream_t stream) {
+  if (int e = check_dims("conv3d_k3_dgrad_bnred", N, D, H, W, Ci, Co)) return e;
+  PCRL_REQUIRE(dy && wp_dgrad && dx && bn_y && scale && shift && mean && rstd && partial, "conv3d_k3_dgrad_bnred: null pointer");
+  PCRL_REQUIRE(pcrl_conv3d_k3_dgrad_bnred_rows(N, D, H, W, Ci, Co, act, dtype) > 0,
+               "conv3d_k3_dgrad_bnred: no fused kernel for this shape / activation / dtype (pcrl_conv3d_k3_dgrad_bnred_rows == 0)");
+  return pcrl_brick16_dgrad_bnred_launch(dy, wp_dgrad, dx, bn_y, scale, shift, mean, rstd, partial, N, D, H, W, Ci, Co, as_stream(stream));
+}
+
 extern "C" int pcrl_convt3d_k2s2_fwd(const void* x, const void* wp_fwd, const float* bias, void* y,
                                      int N, int D, int H, int W, int Ci, int Co, int dtype, pcrl_stream_t stream) {
   if (int e = check_dims("convt3d_k2s2_fwd", N, D, H, W, Ci, Co)) return e;

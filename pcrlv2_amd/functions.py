@@ -8,6 +8,8 @@ reference's autograd does for the never-used `mask2` / view-2 deep-supervision h
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -244,6 +246,26 @@ def _park_slope(mod, sv):
     sv.dslope = None
 
 
+def _remember_output(mod, sv, a):
+    """ops.0 of an nn.Sequential(LUConv, LUConv) (models/pcrlv2_model_3d.py:37-45) remembers -- weakly -- what it just produced, so that ops.1's
+    forward, which runs next, can recognise its input as that activation (LUConv._below, _below_saved)."""
+    mod._last_out = (weakref.ref(sv), a.data_ptr(), tuple(a.shape))
+
+
+def _below_saved(mod, x):
+    """-> the saved state of the LUConv whose activation `x` is, if `mod` is the ops.1 of a pair and x is exactly what ops.0 returned in this
+    pass; else None.  That activation then has this convolution as its only consumer by construction of the model, and backward double-checks:
+    the fused first pass is used only if the gradient that reaches ops.0 is the very tensor this layer's data gradient wrote (ops.take_pre_partial)."""
+    below = getattr(mod, "_below", None)
+    last = getattr(below, "_last_out", None) if below is not None else None
+    if last is None or not config.DGRAD_BNRED:
+        return None
+    sv = last[0]()
+    if sv is None or x.data_ptr() != last[1] or tuple(x.shape) != last[2]:
+        return None
+    return sv
+
+
 class LUConvFn(Function):
     """act(bn1(conv1(x)))  --  models/pcrlv2_model_3d.py:32-34."""
 
@@ -259,6 +281,8 @@ class LUConvFn(Function):
                                    mod._packed, mod._act, dt, gn_groups=gn, prelu=_slope(mod), inorm=getattr(mod, "_inorm", False))
         mod._count_batch()
         ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
+        ctx.below = _below_saved(mod, x)
+        _remember_output(mod, sv, a)
         ctx.wref, ctx.gref = w_eff, gamma
         ctx.pass_idx = getattr(mod, "_pass_idx", 1)
         ctx.plist = (w, b, gamma, beta)
@@ -272,7 +296,7 @@ class LUConvFn(Function):
         sv = ctx.sv
         da = da.contiguous() if sv.kind == "to1" else _act_grad(da, ctx.dt)
         dx, dw, db, dg, dbeta = ops.luconv_backward(sv, da, ctx.wref, ctx.gref, ctx.mod._packed, ctx.dt,
-                                                    need_dx=ctx.needs_input_grad[0] and sv.kind != "c1")
+                                                    need_dx=ctx.needs_input_grad[0] and sv.kind != "c1", bnred=ctx.below)
         if ctx.ci:                              # padded first layer: the real input channels' share
             ops.join_side_stream()              # the weight gradient was produced on the side stream; the slice below runs on this one
             dw = dw[:, :ctx.ci].contiguous()
@@ -297,6 +321,7 @@ class LUConvPoolFn(Function):
                                         prelu=_slope(mod))
         mod._count_batch()
         ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
+        ctx.below = _below_saved(mod, x)
         ctx.wref, ctx.gref = w, gamma
         ctx.pass_idx = getattr(mod, "_pass_idx", 1)
         ctx.plist = (w, b, gamma, beta)
@@ -321,7 +346,7 @@ class LUConvPoolFn(Function):
         elif da is not None:
             da = _act_grad(da, dt)
         dx, dw, db, dg, dbeta = ops.luconv_backward(sv, da, ctx.wref, ctx.gref, ctx.mod._packed, dt, need_dx=ctx.needs_input_grad[0],
-                                                    pool_dp=pool_dp)
+                                                    pool_dp=pool_dp, bnred=ctx.below)
         _park_slope(ctx.mod, sv)
         w, b, gamma, beta = ctx.plist
         out = dx, _park(w, dw), _park(b, db), _park(gamma, dg), _park(beta, dbeta), None
@@ -433,7 +458,8 @@ class UpStageFn(Function):
             d_a1 = dx_ds
             grads[19], grads[20], grads[21], grads[22] = g_dw, g_db, g_dg, g_dbe
         # ---- ops.1, ops.0 ----
-        d_a0, gw1, gb1, gg1, gbe1 = ops.luconv_backward(ctx.sv1, d_a1, w1, g1, l1._packed, dt, need_dx=True, da_row_g=row_g)
+        # ops.0's activation has ops.1 as its only consumer: ops.1's data gradient takes the first pass of ops.0's BatchNorm backward (`bnred`)
+        d_a0, gw1, gb1, gg1, gbe1 = ops.luconv_backward(ctx.sv1, d_a1, w1, g1, l1._packed, dt, need_dx=True, da_row_g=row_g, bnred=ctx.sv0)
         _park_slope(l1, ctx.sv1)
         grads[7], grads[8], grads[9], grads[10] = gw1, gb1, gg1, gbe1
         deferred = ()

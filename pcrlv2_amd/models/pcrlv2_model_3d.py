@@ -95,7 +95,11 @@ def _make_nConv(in_channel, depth, act, norm, double_chnnel=False):
     """Two LUConvs.  Encoder stage d: in -> 32*2^d -> 64*2^d; decoder stage (double_chnnel): in -> 64*2^d -> 64*2^d   [:37-45]"""
     wide = 64 << depth
     mid = wide if double_chnnel else wide // 2
-    return nn.Sequential(LUConv(in_channel, mid, act, norm), LUConv(mid, wide, act, norm))
+    first, second = LUConv(in_channel, mid, act, norm), LUConv(mid, wide, act, norm)
+    # engine hint, not a submodule (no state_dict entry): `first`'s activation has `second` as its only consumer, so `second`'s data gradient may take
+    # the first pass of `first`'s BatchNorm backward from its own output tiles (functions.LUConvFn / ops.luconv_backward `bnred`)
+    object.__setattr__(second, "_below", first)
+    return nn.Sequential(first, second)
 
 
 class UpTransition(nn.Module, _Counted):

@@ -654,15 +654,21 @@ def bn_pool_ok(D, H, W, C, dtype) -> bool:
     return bool(lib().call("pcrl_bn_act_bwd_pool_ok", D, H, W, C, dtype_code(dtype)))
 
 
-def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, row_g=None, pool_dp=None, da2=None):
+def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, row_g=None, pool_dp=None, da2=None, pre_partial=None):
     """-> (dy, dgamma, dbeta): gradient w.r.t. the pre-normalisation tensor and the affine parameters.
     `row_g` (float32 [N, C]): the incoming gradient is da + row_g[n] / S broadcast over the S = M / N voxels of a sample (the
     global-average-pool branch, folded into both passes instead of materialised by gap_backward); `da` may then be None.
     `pool_dp` (activation [N, C, D/2, H/2, W/2]): the activation was consumed through MaxPool3d(2) only and THIS is the gradient of
     the pooled tensor (da must be None): max_pool3d_backward happens inside the two passes.
-    `da2`: a second gradient tensor of da's shape added to it inside both passes (two consumers of the activation; pcrl_bn_act_bwd_*_sum)."""
+    `da2`: a second gradient tensor of da's shape added to it inside both passes (two consumers of the activation; pcrl_bn_act_bwd_*_sum).
+    `pre_partial` = (partial, rows): the first pass was already taken -- by the data-gradient kernel that PRODUCED da, from its output
+    tiles (pcrl_conv3d_k3_dgrad_bnred, luconv_backward's `bnred`); plain da only."""
     L, s, dev = lib(), stream_handle(), y.device
-    if pool_dp is not None:
+    if pre_partial is not None:
+        if row_g is not None or pool_dp is not None or da2 is not None:
+            raise PcrlError("bn_act_backward: a precomputed first pass covers the plain gradient tensor only")
+        partial, rows = pre_partial
+    elif pool_dp is not None:
         N, D, H, W, _ = dims(y)
         rows = L.call("pcrl_bn_act_bwd_pool_partial_rows", N, D, H, W)
         partial = _f32(rows * C * 2, dev)
@@ -698,7 +704,7 @@ def bn_act_backward(da, y, gamma, mean, rstd, scale, shift, M, C, act, dtype, ro
 # LUConv = conv3x3x3 + BatchNorm3d(train) + activation      (models/pcrlv2_model_3d.py:6-34)
 # ----------------------------------------------------------------------------------------------
 class LUConvSaved:
-    __slots__ = ("kind", "x", "y", "mean", "rstd", "scale", "shift", "geom", "act", "gn", "prelu", "z", "dslope", "in_head")
+    __slots__ = ("kind", "x", "y", "mean", "rstd", "scale", "shift", "geom", "act", "gn", "prelu", "z", "dslope", "in_head", "pre_partial", "__weakref__")
 
 
 def prelu_forward(z, slope, dtype):
@@ -875,8 +881,18 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
     return a, sv
 
 
+def take_pre_partial(sv: LUConvSaved, da):
+    """The first BatchNorm-backward pass of `sv`'s layer if the data gradient above it already took it for exactly this gradient tensor
+    (luconv_backward's `bnred`), else None.  One-shot."""
+    pre = getattr(sv, "pre_partial", None)
+    sv.pre_partial = None
+    if pre is None or da is None or pre[2].data_ptr() != da.data_ptr() or pre[2].shape != da.shape:
+        return None
+    return pre[0], pre[1]
+
+
 def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, dtype, need_dx=True, dx_add=None, dx_colsum=None, da_row_g=None,
-                    pool_dp=None):
+                    pool_dp=None, bnred: LUConvSaved = None):
     """-> (dx | None, dw, db, dgamma, dbeta).  `dx_add`: optional activation folded into dx (to1 kind only).
     `da_row_g`: optional float32 [N, Co] -- the gradient of this LUConv's output is da + da_row_g[n] / (D*H*W) (bn_act_backward; da may
     be None then).  Only for BatchNorm layers with bn_rowadd_ok(Co, dtype).
@@ -888,6 +904,11 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
 
     db is exactly zero: a bias that is followed by a batch-statistics normalisation has an identically
     zero gradient (the reference's autograd yields round-off noise ~1e-8 there).
+
+    `bnred`: the saved state of the LUConv BELOW whose activation is this convolution's input and has NO other consumer (ops.0 under ops.1
+    in nn.Sequential(LUConv, LUConv), models/pcrlv2_model_3d.py:37-45): where the library has the kernel
+    (pcrl_conv3d_k3_dgrad_bnred_rows) the data gradient takes the first pass of that layer's BatchNorm backward from its output tiles
+    and leaves it on `bnred.pre_partial` for that layer's backward (take_pre_partial); otherwise nothing changes.
     """
     L, s = lib(), stream_handle()
     N, D, H, W, Ci, Co = sv.geom
@@ -924,8 +945,9 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
         nbc = L.call("pcrl_colsum_ws_bytes", M, Co)
         L.call("pcrl_colsum", dy, db, workspace(nbc, dev), nbc, M, Co, dtype_code(dtype), s)
     else:
+        pre = take_pre_partial(sv, da) if (da_row_g is None and pool_dp is None) else None
         dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype,
-                                            row_g=da_row_g, pool_dp=pool_dp)
+                                            row_g=da_row_g, pool_dp=pool_dp, pre_partial=pre)
     if sv.kind == "c1":
         nb = L.call("pcrl_conv3d_k3_c1_wgrad_ws_bytes", N, D, H, W, Co)
         L.call("pcrl_conv3d_k3_c1_wgrad", sv.x, dy, dw, workspace(nb, dev), nb, N, D, H, W, Co, dtype_code(dtype), s)
@@ -947,7 +969,17 @@ def luconv_backward(sv: LUConvSaved, da, conv_w, gamma, packed: PackedWeights, d
         if dx_colsum is not None:
             rows = L.call("pcrl_conv3d_k3_stats_rows", N, D, H, W, Co, Ci, dtype_code(dtype))
             part = _f32(rows * Ci * 2, dev)
-        L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, part, workspace(nb, dev) if nb else None, nb, N, D, H, W, Co, Ci, dtype_code(dtype), s)
+        brows = 0
+        if (bnred is not None and part is None and config.DGRAD_BNRED and bnred.gn is None and getattr(bnred, "prelu", None) is None and bnred.mean is not None
+                and bnred.y.dtype == dtype and bnred.y.numel() == M * Ci):
+            brows = L.call("pcrl_conv3d_k3_dgrad_bnred_rows", N, D, H, W, Co, Ci, bnred.act, dtype_code(dtype))
+        if brows:
+            bpart = _f32(brows * Ci * 2, dev)
+            L.call("pcrl_conv3d_k3_dgrad_bnred", dy, wd, dx, bnred.y, bnred.scale, bnred.shift, bnred.mean, bnred.rstd, bpart,
+                   N, D, H, W, Co, Ci, bnred.act, dtype_code(dtype), s)
+            bnred.pre_partial = (bpart, brows, dx)
+        else:
+            L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx, part, workspace(nb, dev) if nb else None, nb, N, D, H, W, Co, Ci, dtype_code(dtype), s)
         if part is not None:   # [rows][Ci][2] -> column sums; the (sum) entries are the even columns
             both = _f32(Ci * 2, dev)
             nb2 = L.call("pcrl_colsum_ws_bytes", rows, Ci * 2)
@@ -1157,7 +1189,8 @@ def upconv_luconv_backward(sv: LUConvSaved, da, w_up, b_up, conv_w, conv_b, gamm
     L, s, dev = lib(), stream_handle(), sv.y.device
     N, D, H, W, Ci, Co = sv.geom
     M = N * D * H * W * 8
-    dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype)
+    dy, dgamma, dbeta = bn_act_backward(da, sv.y, gamma.detach(), sv.mean, sv.rstd, sv.scale, sv.shift, M, Co, sv.act, dtype,
+                                        pre_partial=take_pre_partial(sv, da))
     dx = None
 
     def data_gradient():

@@ -1,0 +1,148 @@
+"""The data gradient that takes the first pass of the BatchNorm backward of the layer below from its own output tiles
+(pcrl_conv3d_k3_dgrad_bnred, csrc/conv_brick16_bnr.hip; ops.luconv_backward `bnred`) -- for ops.0 -> ops.1 inside nn.Sequential(LUConv, LUConv),
+models/pcrlv2_model_3d.py:37-45, where the activation of ops.0 has exactly one consumer.
+
+Operator level: dx is BIT-identical to the plain data gradient (same kernel, same accumulators); the two sums per channel, after
+pcrl_bn_bwd_finalize, equal those of the separate reduce pass (pcrl_bn_act_bwd_reduce over the stored dx) up to float32 summation order, and a float64
+torch evaluation of the same definition.  Model level: a training step with the switch on and off lands on the same losses / parameters to
+summation-order noise, and the fused kernel really ran (call counter of the library)."""
+import os
+import random
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+import pcrlv2_oracle as O  # noqa: E402
+from pcrlv2_amd import config, ops  # noqa: E402
+from pcrlv2_amd._lib import ACT_RELU, dtype_code, lib, stream_handle  # noqa: E402
+from pcrlv2_amd.models import PCRLv23d  # noqa: E402
+from pcrlv2_amd.optim import FusedSGD  # noqa: E402
+from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1
+
+
+# N, D, H, W, channels of dy (this layer's output), channels of dx (= the layer below's output): natural bricks, edge bricks in every direction,
+# the (D, W, H) brick orientation (H % 16 == 0, W % 8 == 0), one and several 64-channel tiles, the 32-channel tile (first layer below)
+SHAPES = [(2, 4, 8, 16, 64, 64), (1, 8, 16, 32, 64, 32), (1, 12, 24, 16, 32, 64), (2, 8, 8, 32, 128, 128), (3, 4, 16, 8, 64, 64), (1, 16, 16, 8, 256, 128),
+          (1, 4, 32, 8, 64, 32), (2, 16, 16, 16, 64, 64)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_fused_first_pass_equals_the_separate_reduce(shape):
+    N, D, H, W, Cy, Cx = shape
+    L, s = lib(), stream_handle()
+    rows = L.call("pcrl_conv3d_k3_dgrad_bnred_rows", N, D, H, W, Cy, Cx, ACT_RELU, dtype_code(BF))
+    assert rows == N * D * H * W // 512, (shape, rows)
+    M = N * D * H * W
+    dy = ops.to_act(rnd(N, Cy, D, H, W, seed=1).to(BF).to(DEV), BF)
+    w = (rnd(Cy, Cx, 3, 3, 3, seed=2) * 0.1).float().to(DEV)           # the layer's weight [Co = Cy][Ci = Cx]
+    y_below = ops.to_act((rnd(N, Cx, D, H, W, seed=3) * 2).to(BF).to(DEV), BF)
+    # BatchNorm coefficients of the layer below: scale / shift decide the ReLU mask, mean / rstd the normalised value
+    gamma = (rnd(Cx, seed=4) * 0.5 + 1.0).float().to(DEV)
+    mean = (rnd(Cx, seed=5) * 0.3).float().to(DEV)
+    rstd = (rnd(Cx, seed=6) * 0.2 + 0.8).float().to(DEV)
+    beta = (rnd(Cx, seed=7) * 0.2).float().to(DEV)
+    scale = (gamma * rstd).contiguous()
+    shift = (beta - mean * scale).contiguous()
+    packed = ops.PackedWeights("conv3")
+    _, wd = packed.get(w, BF)
+    # plain data gradient + separate reduce
+    dx0 = ops.new_act(N, D, H, W, Cx, BF, dy.device)
+    nb = L.call("pcrl_conv3d_k3_fwd_ws_bytes", N, D, H, W, Cy, Cx, dtype_code(BF))
+    assert nb == 0
+    L.call("pcrl_conv3d_k3_fwd_ws", dy, wd, None, dx0, None, None, 0, N, D, H, W, Cy, Cx, dtype_code(BF), s)
+    rows0 = L.call("pcrl_bn_bwd_partial_rows", M)
+    part0 = torch.empty(rows0 * Cx * 2, dtype=torch.float32, device=DEV)
+    L.call("pcrl_bn_act_bwd_reduce", dx0, y_below, scale, shift, mean, rstd, part0, M, Cx, ACT_RELU, dtype_code(BF), s)
+    # fused
+    dx1 = ops.new_act(N, D, H, W, Cx, BF, dy.device)
+    part1 = torch.full((rows * Cx * 2,), float("nan"), dtype=torch.float32, device=DEV)
+    L.call("pcrl_conv3d_k3_dgrad_bnred", dy, wd, dx1, y_below, scale, shift, mean, rstd, part1, N, D, H, W, Cy, Cx, ACT_RELU, dtype_code(BF), s)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1), "the data gradient itself must not change"
+    assert torch.isfinite(part1).all(), "every statistics row written"
+
+    def finalize(part, r):
+        out = torch.empty(5 * Cx, dtype=torch.float32, device=DEV)
+        o = [out[i * Cx:(i + 1) * Cx] for i in range(5)]
+        L.call("pcrl_bn_bwd_finalize", part, r, Cx, float(M), gamma, mean, rstd, o[0], o[1], o[2], o[3], o[4], s)
+        torch.cuda.synchronize()
+        return [t.double().cpu() for t in o]
+
+    f0, f1 = finalize(part0, rows0), finalize(part1, rows)
+    # float64 definition on the stored values
+    dxv = dx1.permute(0, 2, 3, 4, 1).reshape(M, Cx).double().cpu()
+    yv = y_below.permute(0, 2, 3, 4, 1).reshape(M, Cx).double().cpu()
+    z = scale.float().cpu().double() * yv + shift.float().cpu().double()
+    # the kernels evaluate the mask in float32: take it from a float32 evaluation of the same expression, the sums in float64
+    zf = (scale.cpu() * yv.float() + shift.cpu())
+    dz = torch.where(zf > 0, dxv, torch.zeros_like(dxv))
+    xhat = (yv - mean.cpu().double()) * rstd.cpu().double()
+    ref_dbeta, ref_dgamma = dz.sum(0), (dz * xhat).sum(0)
+    del z
+    for k, (a, b, name) in enumerate(zip(f0, f1, ("dgamma", "dbeta", "k1", "kB", "kA"))):
+        sc = max(a.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 2e-5 * sc + 1e-6, (shape, name, (a - b).abs().max().item(), sc)
+    sc = max(ref_dgamma.abs().max().item(), ref_dbeta.abs().max().item(), 1e-6)
+    assert (f1[0] - ref_dgamma).abs().max().item() <= 2e-5 * sc, (shape, "dgamma vs float64")
+    assert (f1[1] - ref_dbeta).abs().max().item() <= 2e-5 * sc, (shape, "dbeta vs float64")
+
+
+def test_no_fused_kernel_outside_its_shapes():
+    L = lib()
+    bf = dtype_code(BF)
+    assert L.call("pcrl_conv3d_k3_dgrad_bnred_rows", 2, 8, 8, 4, 64, 64, ACT_RELU, bf) == 0          # 8 x 8 x 4: not a wide-brick volume
+    assert L.call("pcrl_conv3d_k3_dgrad_bnred_rows", 2, 4, 8, 16, 64, 64, ACT_RELU, dtype_code(torch.float32)) == 0
+    assert L.call("pcrl_conv3d_k3_dgrad_bnred_rows", 2, 4, 8, 16, 64, 64, 0, bf) == 0                  # no activation / other activations: two passes
+    assert L.call("pcrl_conv3d_k3_dgrad_bnred_rows", 2, 4, 8, 16, 64, 64, ACT_RELU, bf) == 2
+
+
+def test_training_step_with_and_without_the_fused_first_pass():
+    """Two SGD steps at b = 4, 32 x 32 x 16 (+ six 16^3 local views per sample) with config.DGRAD_BNRED on and off.  The only difference is the order in
+    which float32 partial sums of two per-channel reductions are added: the FIRST step's five losses are identical (the forward does not change) and
+    the parameters after it agree to summation-order noise; on the second step the two restoration terms (MSE) agree to 1e-4, the cosine terms --
+    which reach the loss through BatchNorm1d over four rows and amplify any last-bit change ("Long horizon") -- to 2e-2.  And the fused
+    kernel really ran for the layer pairs the wide-brick kernel serves (call counter), replacing exactly as many reduce passes."""
+    batches = [O.fill_batch(4, (32, 32, 16), dtype=torch.float32, seed=31 + k) for k in range(2)]
+    L = lib()
+    finals = []
+    keep = config.DGRAD_BNRED
+    try:
+        for on in (True, False):
+            config.DGRAD_BNRED = on
+            model = PCRLv23d().to(DEV)
+            model.load_state_dict(O.fill_state(torch.float32))
+            model.train().set_compute_dtype(BF)
+            opt = FusedSGD(model.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+            random.seed(5)
+            per_step, params = [], []
+            with L.count_calls("pcrl_conv3d_k3_dgrad_bnred", "pcrl_bn_act_bwd_reduce") as counts:
+                for bt in batches:
+                    losses = train_step(model, opt, bt, 3, MSELoss(), CosineSimilarityMean())
+                    torch.cuda.synchronize()
+                    per_step.append([float(l) for l in losses])
+                    params.append(opt.flat_p.clone())
+            finals.append((per_step, params, dict(counts)))
+    finally:
+        config.DGRAD_BNRED = keep
+    (la, pa, ca), (lb, pb, cb) = finals
+    assert cb.get("pcrl_conv3d_k3_dgrad_bnred", 0) == 0
+    # per step: the 32x32x16 global views' down_tr64 / down_tr128 (16x16x8) / up_tr128 / up_tr64 pairs, twice (two views), and the local 16^3 views' first-level pairs
+    assert ca.get("pcrl_conv3d_k3_dgrad_bnred", 0) >= 2 * (2 * 4 + 2), ca
+    assert ca["pcrl_bn_act_bwd_reduce"] == cb["pcrl_bn_act_bwd_reduce"] - ca["pcrl_conv3d_k3_dgrad_bnred"], (ca, cb)
+    assert la[0] == lb[0], (la[0], lb[0])                                   # same forward
+    d0 = float((pa[0] - pb[0]).abs().max())
+    assert d0 <= 2e-5 * float(pb[0].abs().max()), d0                        # one SGD step apart by summation order only
+    for i, tol in enumerate((2e-2, 1e-4, 2e-2, 1e-4, 2e-2)):                # loss, loss1 (MSE), loss2, loss4 (MSE), local_loss
+        assert abs(la[1][i] - lb[1][i]) <= tol, (i, la[1], lb[1])
