@@ -501,6 +501,9 @@ void pcrl_debug_set_conv_impl(int impl);
 void pcrl_debug_set_wgrad_impl(int impl);
 void pcrl_debug_set_wgrad_tr(int on);
 void pcrl_debug_set_conv2d_impl(int impl);
+/* Timing ablation (tools/double_ablation.py): the non-accumulating fixed-order second passes of the weight gradients are launched n times (idempotent);
+ * the step-time difference between n = 2 and n = 1 is what those launches cost inside the multi-stream step.  Default 1. */
+void pcrl_debug_set_reduce_repeat(int n);
 
 /* ---------------------------------------------------------------------------------------
  * Backward of one half of the projection / predictor heads (csrc/heads_fused.hip; models/pcrlv2_model_3d.py:55-59,67-70 and

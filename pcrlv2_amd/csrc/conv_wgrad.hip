@@ -473,11 +473,17 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
     if (base + k < lim) out[base + k] = accumulate ? out[base + k] + tile[k] : tile[k];
 }
 
+// Timing ablation (tools/double_ablation.py): the non-accumulating second passes are launched this many times (idempotent: same slabs, same output) --
+// what a set of launches costs INSIDE the three-stream step is the step-time difference between 2 and 1.  Default 1.
+static std::atomic<int> g_reduce_repeat{1};
+extern "C" void pcrl_debug_set_reduce_repeat(int n) { g_reduce_repeat = n < 1 ? 1 : n; }
+
 // every weight-gradient path ends here (`accumulate`: out += the sum, for gradients gathered over several passes)
 int launch_wgrad_reduce(const float* ws, float* out, int splits, int taps, int Cu, int Cv, int Cv_out, hipStream_t stream, bool accumulate = false) {
   if (taps < 1 || taps > 64) return pcrl_fail(PCRL_EINVAL, "wgrad_reduce: %d taps", taps);
   const int blocks = (int)(((int64_t)Cu * Cv_out + RED_IJ - 1) / RED_IJ);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, out, splits, taps, Cu, Cv, Cv_out, accumulate);
+  for (int rep = accumulate ? 1 : (int)g_reduce_repeat; rep > 0; --rep)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, out, splits, taps, Cu, Cv, Cv_out, accumulate);
   return pcrl_check_launch("wgrad_reduce");
 }
 

@@ -1,0 +1,104 @@
+"""What a SET of launches costs inside the three-stream C2 step: run them twice (they are idempotent) and take the step-time difference.
+
+One-stream kernel sums overstate what removing a launch set would buy: in the three-stream step HBM- and latency-bound kernels run under other streams'
+matrix kernels.  This probe measures the set's cost where it counts, without building the fused form first: blocks of K steps alternate between the
+plain step and the step with the set doubled, same process, same box, same draws.
+
+    python tools/double_ablation.py [--steps 12] [--rounds 3]
+Sets: finalize (pcrl_bn_finalize + pcrl_bn_bwd_finalize: 94 launches), bn_reduce (every pcrl_bn_act_bwd_reduce*: the HBM-bound first pass),
+small_conv (forward / data gradient convolutions of the 4^3 / 2^3 local-view levels), wgrad_reduce (the fixed-order second passes of the
+weight gradients, through pcrl_debug_set_reduce_repeat)."""
+import argparse
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from bench import synthetic_batch  # noqa: E402
+from pcrlv2_amd import _lib  # noqa: E402
+from pcrlv2_amd.models import PCRLv23d  # noqa: E402
+from pcrlv2_amd.optim import FusedSGD  # noqa: E402
+from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--rounds", type=int, default=3)
+a = ap.parse_args()
+dev = torch.device("cuda")
+L = _lib.lib()
+L.cdll.pcrl_debug_set_reduce_repeat.argtypes = [__import__("ctypes").c_int]
+L.cdll.pcrl_debug_set_reduce_repeat.restype = None
+
+
+def small(name, args):   # convolution launches on volumes of <= 64 voxels
+    if name in ("pcrl_conv3d_k3_fwd_ws",):
+        return args[8] * args[9] * args[10] <= 64
+    if name == "pcrl_upconv_fwd":
+        return args[7] * args[8] * args[9] <= 64
+    if name == "pcrl_upconv_dgrad_ws":
+        return args[7] * args[8] * args[9] <= 64
+    return False
+
+
+SETS = {
+    "finalize": lambda n, ar: n in ("pcrl_bn_finalize", "pcrl_bn_bwd_finalize"),
+    "bn_reduce": lambda n, ar: n.startswith("pcrl_bn_act_bwd_reduce"),
+    "small_conv": small,
+    "wgrad_reduce": None,
+}
+active = [None]
+orig_call = _lib._Lib.call
+
+
+def call(self, name, *args):
+    r = orig_call(self, name, *args)
+    f = active[0]
+    if f is not None and f(name, args):
+        orig_call(self, name, *args)
+    return r
+
+
+_lib._Lib.call = call
+torch.manual_seed(0)
+model = PCRLv23d().to(dev).train().set_compute_dtype(torch.bfloat16)
+opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+batch = synthetic_batch(32, (64, 64, 32), 16, dev, 1234)
+crit, cosine = MSELoss(), CosineSimilarityMean()
+random.seed(0)
+for _ in range(8):
+    train_step(model, opt, batch, 0, crit, cosine, guard=False)
+st0 = random.getstate()
+
+
+def block(which):
+    if which == "wgrad_reduce":
+        L.cdll.pcrl_debug_set_reduce_repeat(2)
+    elif which is not None:
+        active[0] = SETS[which]
+    random.setstate(st0)
+    for _ in range(2):
+        train_step(model, opt, batch, 0, crit, cosine, guard=False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(a.steps):
+        train_step(model, opt, batch, 0, crit, cosine, guard=False)
+    e1.record()
+    torch.cuda.synchronize()
+    active[0] = None
+    L.cdll.pcrl_debug_set_reduce_repeat(1)
+    return e0.elapsed_time(e1) / a.steps
+
+
+res = {k: [] for k in [None, *SETS]}
+for _ in range(a.rounds):
+    for k in res:
+        res[k].append(block(k))
+base = sum(res[None]) / a.rounds
+print(f"plain step            : {['%.3f' % v for v in res[None]]}  mean {base:.3f} ms")
+for k in SETS:
+    m = sum(res[k]) / a.rounds
+    print(f"{k:12s} doubled  : {['%.3f' % v for v in res[k]]}  mean {m:.3f} ms  -> the set costs {m - base:+.3f} ms inside the step")
