@@ -490,15 +490,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
   for (int j = 0; j < FN; ++j) {
     s1[j] = 0.f;
     s2[j] = 0.f;
-    bv[j] = (!UPCF && p.bias) ? p.bias[n0 + j * 16 + lr] : 0.f;
+    bv[j] = (!UPCF && !BNR && p.bias) ? p.bias[n0 + j * 16 + lr] : 0.f;   // BNR: a data gradient, no bias
     bvE[j] = 0.f;
-    if (BNR) {
-      const int c = n0 + j * 16 + lr;
-      bsc[j] = p.bn_scale[c];
-      bsh[j] = p.bn_shift[c];
-      bmu[j] = p.bn_mean[c];
-      brs[j] = p.bn_rstd[c];
-    }
   }
   const int uch0 = UPCF ? n0 - uph * p.upc : 0;                       // first channel of this tile inside its phase
   const int ypitch = UPCF ? p.upc : p.Nc;
@@ -513,10 +506,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
   // voxels of one h line x SL 16-byte slots.  The epilogue reads it back two bytes per lane (channel 16 j + lr of voxel 4 lg + r): the four lg groups of
   // a wave sit 4 voxels = a multiple of 256 bytes apart -- the same banks -- so a voxel's slots are XOR-ed with 2 lg on the SOURCE side (BN = 64:
   // conflict-free; BN = 32, four slots per voxel: two-way).  Bytes [0, BNR_LDS0) stay free for the statistics rows' block reduction.
-  constexpr int BNR_LDS0 = 4096;
+  constexpr int BNR_LDS0 = 4096, BNR_COEF = 2048;   // every wave loads its own copy of the coefficient piece to the same place (identical bytes)
   if (BNR) {
     constexpr int SL = BN / 8, VP = 64 / SL, PPL = 16 / VP, NPW = 8 * PPL;
     static_assert(!BNR || BNR_LDS0 + NW * 128 * BN * 2 <= HALO_BYTES, "the y tile reuses the halo buffer");
+    // every vector-memory load of the main loop has long returned; saying so where the compiler sees it (the builtin, not asm) keeps its own counted
+    // waits -- it protects registers of the loop's last weight loads when the epilogue reuses them -- from landing behind the requests below,
+    // where vmcnt's in-order retirement would turn them into waits for the DMA
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) only
     const uint64_t bnbase = (uint64_t)(uintptr_t)p.bn_y + (uint64_t)((row0 * ypitch + n0) * 2);   // wave-uniform
     const uint32_t ydst = lds_base + BNR_LDS0 + wid * (128 * BN * 2);
     const int vl = lane / SL, sl = lane % SL;
@@ -528,6 +525,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
       const int lsl = sl ^ (BN == 64 ? ((w >> 2) & 3) * 2 : ((w >> 2) & 1) * 2);
       const uint32_t voff = (uint32_t)((q / PPL) * HS + w * WS + lsl * 16);
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" ::"v"(voff), "s"(ydst + q * 1024), "s"(bnbase) : "memory");
+    }
+    // ... and the four coefficient vectors of this channel tile as one more piece, [scale | shift | mean | rstd][BN] floats at BNR_COEF: loaded into
+    // registers they would be ordinary vector-memory loads among the stores below, and the compiler's counted waits for them (it does not see the
+    // asm's requests) would wait for the DMA pieces -- or, placed behind the stores, for the stores
+    {
+      constexpr int LPA = BN / 4;   // lanes per array (16 bytes each)
+      const int arr = (lane / LPA) & 3;
+      const float* src = arr == 0 ? p.bn_scale : arr == 1 ? p.bn_shift : arr == 2 ? p.bn_mean : p.bn_rstd;
+      const float* lsrc = src + n0 + (lane % LPA) * 4;
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(lsrc), "s"(lds_base + BNR_COEF) : "memory");
     }
     asm volatile("s_mov_b32 m0, %0" ::"s"(m0keep));
   }
@@ -573,11 +580,25 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
         }
       }
     }
+    // BNR: the wave's DMA pieces (a wave reads only the plane it requested: no barrier) are the OLDEST vector-memory operations in flight; behind them
+    // three lines of stores (12 FN <= 48).  vmcnt retires in order on gfx9, so "at most 12 FN outstanding" means the pieces have landed -- without waiting
+    // for any store to complete (s_waitcnt vmcnt(0) here cost the 64-channel form 7 %: a store's completion is microseconds away).
+    if (BNR && fm == 2) {
+      if (FN == 4) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    }
   }
   if (BNR) {
     // bn_bwd_reduce_kernel's arithmetic (ReLU) on the stored values against the y tile staged above
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own DMA pieces (a wave reads only the plane it requested: no barrier)
     const char* ytile = smem + BNR_LDS0 + wid * (128 * BN * 2) + (4 * lg) * (BN * 2) + (lr >> 3) * 16 + (lr & 7) * 2;
+    const float* coef = reinterpret_cast<const float*>(smem + BNR_COEF);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      bsc[j] = coef[j * 16 + lr];
+      bsh[j] = coef[BN + j * 16 + lr];
+      bmu[j] = coef[2 * BN + j * 16 + lr];
+      brs[j] = coef[3 * BN + j * 16 + lr];
+    }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {   // one channel fragment at a time (32 LDS reads in flight; all 128 at once spilled)
       const int jx = j ^ (BN == 64 ? lg : (lg & 1));   // the staging swizzle (source side of the DMA)

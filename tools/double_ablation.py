@@ -43,12 +43,28 @@ def small(name, args):   # convolution launches on volumes of <= 64 voxels
     return False
 
 
+def big_conv(name, args):   # plain forward / data gradient convolutions on volumes of > 64 voxels (the brick kernels)
+    if name == "pcrl_conv3d_k3_fwd_ws":
+        return args[8] * args[9] * args[10] > 64
+    return name == "pcrl_conv3d_k3_dgrad_bnred"
+
+
 SETS = {
     "finalize": lambda n, ar: n in ("pcrl_bn_finalize", "pcrl_bn_bwd_finalize"),
     "bn_reduce": lambda n, ar: n.startswith("pcrl_bn_act_bwd_reduce"),
+    "bn_bwd_apply": lambda n, ar: n.startswith("pcrl_bn_act_bwd_apply"),
+    "bn_apply": lambda n, ar: n in ("pcrl_bn_act_apply", "pcrl_bn_act_apply_pool", "pcrl_bn_act_apply_gap"),
     "small_conv": small,
+    "big_conv": big_conv,
+    "upconv_fwd_dgrad": lambda n, ar: n in ("pcrl_upconv_fwd", "pcrl_upconv_dgrad_ws") and not small(n, ar),
+    "wgrad": lambda n, ar: n == "pcrl_conv3d_k3_wgrad",
+    "to1_heads": lambda n, ar: n in ("pcrl_conv3d_to1_fwd", "pcrl_conv3d_to1_dgrad", "pcrl_conv3d_to1_wgrad"),
+    "first_layer": lambda n, ar: n in ("pcrl_conv3d_k3_c1_fwd", "pcrl_conv3d_k3_c1_wgrad"),
     "wgrad_reduce": None,
+    "no_bnred": None,
 }
+if os.environ.get("ABL_SETS"):
+    SETS = {k: v for k, v in SETS.items() if k in os.environ["ABL_SETS"].split(",")}
 active = [None]
 orig_call = _lib._Lib.call
 
@@ -74,7 +90,10 @@ st0 = random.getstate()
 
 
 def block(which):
-    if which == "wgrad_reduce":
+    from pcrlv2_amd import config
+    if which == "no_bnred":           # not a doubling: the separate first BatchNorm-backward pass instead of the data gradient's fused one (config.DGRAD_BNRED)
+        config.DGRAD_BNRED = False
+    elif which == "wgrad_reduce":
         L.cdll.pcrl_debug_set_reduce_repeat(2)
     elif which is not None:
         active[0] = SETS[which]
@@ -89,6 +108,7 @@ def block(which):
     e1.record()
     torch.cuda.synchronize()
     active[0] = None
+    config.DGRAD_BNRED = True
     L.cdll.pcrl_debug_set_reduce_repeat(1)
     return e0.elapsed_time(e1) / a.steps
 
