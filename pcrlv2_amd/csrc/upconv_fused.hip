@@ -139,6 +139,57 @@ __global__ void __launch_bounds__(256) upc_pack_kernel(const float* __restrict__
   }
 }
 
+// The same for Ci % 32 == 0 and Co % 32 == 0 (every layer of the model), tiled: block = (32 ci, one e, 32 co).  The two forms with co innermost
+// (wd, wd3) are written straight from the co-fastest thread order the sums are read in; the two with ci innermost (wf, w3 -- the forward
+// kernels' K-contiguous rows) go through a 32 x 32 LDS tile and leave as 64-byte runs.  (The untiled kernel above writes them as single two-byte
+// stores 8 Ci / 27 Ci elements apart: 103 us for up_tr256's 8.4 M composed weights, 79 us at up_tr128 -- most of pcrl_upconv_compose.)
+template <typename T>
+__global__ void __launch_bounds__(256) upc_pack_tiled_kernel(const float* __restrict__ P, T* __restrict__ wf, T* __restrict__ wd, T* __restrict__ w3,
+                                                             T* __restrict__ wd3, int Ci, int Co) {
+  __shared__ T tile[32][33];
+  const int64_t M27 = (int64_t)27 * Co;
+  const int e = blockIdx.y, ci0 = blockIdx.x * 32, co0 = blockIdx.z * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  int pd, qd, ph, qh, pw, qw;
+  pq_of_e(e >> 4, pd, qd);
+  pq_of_e((e >> 2) & 3, ph, qh);
+  pq_of_e(e & 3, pw, qw);
+  int td, sd, th, sh, tw, sw;
+  const int nd = ts_axis(pd, qd, 0, td, sd), nh = ts_axis(ph, qh, 0, th, sh), nw = ts_axis(pw, qw, 0, tw, sw);
+  const int p = pd * 4 + ph * 2 + pw, q = qd * 4 + qh * 2 + qw;
+  const int ed = e >> 4, eh = (e >> 2) & 3, ew = e & 3;
+  const int k3 = ((ed + 1) >> 1) * 9 + ((eh + 1) >> 1) * 3 + ((ew + 1) >> 1), par = (((ed + 1) & 1) << 2) | (((eh + 1) & 1) << 1) | ((ew + 1) & 1);
+  const int co = co0 + tx;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ci = ci0 + ty + 8 * r;
+    float acc = 0.f;
+    for (int a = 0; a < nd; ++a) {      // the same summation order as upc_pack_kernel: bit-identical weights
+      ts_axis(pd, qd, a, td, sd);
+      for (int b = 0; b < nh; ++b) {
+        ts_axis(ph, qh, b, th, sh);
+        for (int c = 0; c < nw; ++c) {
+          ts_axis(pw, qw, c, tw, sw);
+          const int t = td * 9 + th * 3 + tw, s_ = sd * 4 + sh * 2 + sw;
+          acc += P[((int64_t)s_ * Ci + ci) * M27 + (int64_t)t * Co + co];
+        }
+      }
+    }
+    const T v = cvt<T>(acc);
+    wd[((int64_t)ci * 64 + e) * Co + co] = v;
+    if (wd3) wd3[(((int64_t)ci * 27 + k3) * 8 + par) * Co + co] = v;
+    tile[ty + 8 * r][tx] = v;            // [ci][co]
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co2 = co0 + ty + 8 * r;   // thread = (co2 row, ci = tx): 32 consecutive ci per row
+    const T v = tile[tx][ty + 8 * r];
+    wf[(((int64_t)p * Co + co2) * 8 + q) * Ci + ci0 + tx] = v;
+    if (w3) w3[(((int64_t)p * Co + co2) * 27 + (pd + qd) * 9 + (ph + qh) * 3 + (pw + qw)) * Ci + ci0 + tx] = v;
+  }
+}
+
 // bias_tab[cls][co] = b0[co] + sum over the taps t inside the grid for class cls of wb[co][t],  wb[co][t] = sum_cm w0[co][cm][t] * b_up[cm].
 // Block = one co: lane t < 27 of the eight 32-lane groups walks cm (the 27 taps of a (co, cm) are contiguous: coalesced), LDS combine.
 __global__ void __launch_bounds__(256) upc_bias_kernel(const float* __restrict__ w0, const float* __restrict__ b_up, const float* __restrict__ b0,
@@ -450,7 +501,12 @@ extern "C" int pcrl_upconv_compose(const float* w_up, const float* b_up, const f
   const unsigned gp = blocks_for((int64_t)64 * Ci * Co);
   if (w3f) (void)hipMemsetAsync(w3f, 0, (size_t)216 * Ci * Co * esz(dtype), st);   // 19 of a phase's 27 taps stay zero
   if (wd3) (void)hipMemsetAsync(wd3, 0, (size_t)216 * Ci * Co * esz(dtype), st);   // a parity holds 8 of the 27 taps
-  if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_pack_kernel<bf16>, dim3(gp), dim3(256), 0, st, (const float*)P, (bf16*)wf, (bf16*)wd, (bf16*)w3f, (bf16*)wd3, Ci, Co);
+  static const bool tiled_on = [] { const char* e = getenv("PCRL_UPC_PACK_TILED"); return !(e && e[0] == '0'); }();   // A/B switch (bit-identical outputs)
+  if (tiled_on && Ci % 32 == 0 && Co % 32 == 0 && Co / 32 <= 65535) {
+    const dim3 gt((unsigned)(Ci / 32), 64, (unsigned)(Co / 32));
+    if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_pack_tiled_kernel<bf16>, gt, dim3(256), 0, st, (const float*)P, (bf16*)wf, (bf16*)wd, (bf16*)w3f, (bf16*)wd3, Ci, Co);
+    else hipLaunchKernelGGL(upc_pack_tiled_kernel<float>, gt, dim3(256), 0, st, (const float*)P, (float*)wf, (float*)wd, (float*)w3f, (float*)wd3, Ci, Co);
+  } else if (dtype == PCRL_BF16) hipLaunchKernelGGL(upc_pack_kernel<bf16>, dim3(gp), dim3(256), 0, st, (const float*)P, (bf16*)wf, (bf16*)wd, (bf16*)w3f, (bf16*)wd3, Ci, Co);
   else hipLaunchKernelGGL(upc_pack_kernel<float>, dim3(gp), dim3(256), 0, st, (const float*)P, (float*)wf, (float*)wd, (float*)w3f, (float*)wd3, Ci, Co);
   if (int e = pcrl_check_launch("upconv_compose (pack)")) return e;
   hipLaunchKernelGGL(upc_bias_kernel, dim3(Co), dim3(256), 0, st, w0, b_up, b0, bias_tab, Cm, Co);

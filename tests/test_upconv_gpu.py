@@ -304,3 +304,43 @@ def test_border_class_sums_from_the_border_when_dy_sums_to_zero(geom, dt):
         ref[t] = dq[:, :, sl(td, FD), sl(th, FH), sl(tw, FW)].sum(dim=(0, 2, 3, 4))
     for got, what in ((ba, "all voxels"), (bb, "border voxels")):
         assert float((got.view(27, Co) - ref).abs().max()) <= noise, what
+
+
+def test_tiled_weight_pack_is_bit_identical_to_the_untiled_one(tmp_path):
+    """pcrl_upconv_compose writes the composed weights in four layouts; for Ci % 32 == Co % 32 == 0 the pack runs tiled (the two K-contiguous forms
+    through an LDS transposition, upc_pack_tiled_kernel).  PCRL_UPC_PACK_TILED=0 selects the untiled kernel (read once per process): two
+    subprocesses, the same closed-form weights, all four forms and the bias table byte for byte -- bf16 and float32."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    prog = r'''
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+from pcrlv2_amd._lib import dtype_code, lib, stream_handle
+L = lib()
+out = []
+for dt in (torch.bfloat16, torch.float32):
+    for Ci, Cm, Co in ((64, 64, 32), (128, 128, 64), (32, 96, 160)):
+        g = torch.Generator().manual_seed(Ci + Co)
+        w_up = (torch.rand(Ci, Cm, 2, 2, 2, generator=g) - 0.5).cuda(); b_up = (torch.rand(Cm, generator=g) - 0.5).cuda()
+        w0 = (torch.rand(Co, Cm, 3, 3, 3, generator=g) - 0.5).cuda(); b0 = (torch.rand(Co, generator=g) - 0.5).cuda()
+        wf = torch.empty(64 * Ci * Co, dtype=dt, device="cuda"); wd = torch.empty_like(wf)
+        w3 = torch.empty(216 * Ci * Co, dtype=dt, device="cuda"); wd3 = torch.empty_like(w3)
+        tab = torch.empty(27 * Co, device="cuda")
+        nb = L.call("pcrl_upconv_compose_ws_bytes", Ci, Cm, Co, dtype_code(dt))
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        L.call("pcrl_upconv_compose", w_up, b_up, w0, b0, wf, wd, w3, wd3, tab, ws, nb, Ci, Cm, Co, dtype_code(dt), stream_handle())
+        torch.cuda.synchronize()
+        for t in (wf, wd, w3, wd3, tab):
+            out.append(hashlib.sha256(t.view(torch.uint8).cpu().numpy().tobytes()).hexdigest()[:16])
+print("HASHES", " ".join(out))
+''' % root
+    res = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, PCRL_UPC_PACK_TILED=flag)
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append([ln for ln in r.stdout.splitlines() if ln.startswith("HASHES")][0])
+    assert res[0] == res[1], (res[0], res[1])
+    assert len(res[0].split()) == 1 + 2 * 3 * 5

@@ -60,6 +60,9 @@ SETS = {
     "wgrad": lambda n, ar: n == "pcrl_conv3d_k3_wgrad",
     "to1_heads": lambda n, ar: n in ("pcrl_conv3d_to1_fwd", "pcrl_conv3d_to1_dgrad", "pcrl_conv3d_to1_wgrad"),
     "first_layer": lambda n, ar: n in ("pcrl_conv3d_k3_c1_fwd", "pcrl_conv3d_k3_c1_wgrad"),
+    "upc_compose": lambda n, ar: n == "pcrl_upconv_compose",
+    "upc_wgrad_accum": lambda n, ar: n == "pcrl_upconv_wgrad_accum",      # (accumulates: the values double, the timing is what is measured)
+    "upc_wgrad_finish": lambda n, ar: n == "pcrl_upconv_wgrad_finish",
     "wgrad_reduce": None,
     "no_bnred": None,
 }
