@@ -21,6 +21,8 @@ def short(name):
                 import re
                 m = re.search(r"brick16_conv_kernel(?:ILi\d+ELi(\d)E|<\d+, (\d)[,>])", name)     # <BN, MODE, PERM>
                 mode = (m.group(1) or m.group(2)) if m else "0"
+                if re.search(r"brick16_conv_kernel(?:ILi\d+ELi\d+ELi\d+ELi\d+ELb1E|<[^>]*true>)", name):
+                    return key + "<dgrad+bn_reduce>"       # BNR instantiations (conv_brick16_bnr.hip): the data gradient with the BatchNorm backward's first pass
                 return key + {"1": "<upconv_fwd>", "2": "<upconv_dgrad>"}.get(mode, "")
             if key == "igemm_kernel":
                 import re
@@ -75,7 +77,7 @@ def main():
                 "# SQ counters are sampled on ONE XCD (SQ_BUSY_CU_CYCLES / GRBM_GUI_ACTIVE ~ 30 of its 32 CUs): MFMA busy fraction =\n"
                 "# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 32 CUs * 4 SIMDs).\n")
         traffic = {}
-        mfma_kernels = ["brick16_conv_kernel", "brick16_conv_kernel<upconv_fwd>", "brick16_conv_kernel<upconv_dgrad>", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_brick27_kernel", "wgrad_brick_upc2_kernel", "wgrad_upc8_kernel"] + sorted(k for k in fd if k.startswith("igemm_kernel<") and "upconv" in k)
+        mfma_kernels = ["brick16_conv_kernel", "brick16_conv_kernel<dgrad+bn_reduce>", "brick16_conv_kernel<upconv_fwd>", "brick16_conv_kernel<upconv_dgrad>", "brick_conv_kernel", "wgrad_brick_kernel", "wgrad_brick27_kernel", "wgrad_brick_upc2_kernel", "wgrad_upc8_kernel"] + sorted(k for k in fd if k.startswith("igemm_kernel<") and "upconv" in k)
         for k in mfma_kernels:
             if k not in fd or k not in wd or k not in md:
                 continue
