@@ -339,6 +339,14 @@ int64_t pcrl_conv2d_dgrad_up_ok(int N, int Hc, int Wc, int Ci, int CoP, int dtyp
 int pcrl_conv2d_dgrad_up(const void* dy, const void* wp_dgrad, void* dx, int N, int Hc, int Wc, int Ci, int CoP, int dtype, pcrl_stream_t stream);
 int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx, int N, int Hi, int Wi, int Ci, int Ho, int Wo, int CoP, int KH,
                       int KW, int stride, int pad, int dtype, pcrl_stream_t stream);
+/* 3x3 / stride 1 / pad 1 data gradient WITH the first pass of the BatchNorm backward of the layer below (the 2D counterpart of
+ * pcrl_conv3d_k3_dgrad_bnred): conv2 of a torchvision BasicBlock under relu(bn1(conv1(x))), conv2 of a DecoderBlock under conv1's
+ * BatchNorm + ReLU (models/pcrlv2_model.py:113-128) -- activations with one consumer.  dy: [N][H][W][CoP]; dx, bn_y: [N][H][W][Ci];
+ * partial: [rows][Ci][2] for pcrl_bn_bwd_finalize(partial, rows, Ci, count = N H W, ...).  _rows == 0: no fused kernel for the shape (two passes). */
+int64_t pcrl_conv2d_dgrad_bnred_rows(int N, int H, int W, int Ci, int CoP, int act, int dtype);
+int pcrl_conv2d_dgrad_bnred(const void* dy, const void* wp_dgrad, void* dx, const void* bn_y, const float* scale, const float* shift,
+                            const float* mean, const float* rstd, float* partial, int N, int H, int W, int Ci, int CoP, int act, int dtype,
+                            pcrl_stream_t stream);
 /* Stride-2 data gradient without idle taps: the parity classes (a, b) = (ih & 1, iw & 1) of dx are four stride-1 gathers over dy
  * (3x3/pad 1: 1, 2, 2, 4 taps; 1x1/pad 0: class (0,0) only, the caller zero-fills dx).  Hi, Wi even.  pack_s2: rows round32(Ci),
  * K = taps(a) * taps(b) * CoP -> pcrl_conv2d_packed_elems(Ci, taps(a) * taps(b), CoP) elements, taps(0) = 1, taps(1) = 2 (3x3). */

@@ -514,6 +514,23 @@ extern "C" int pcrl_conv2d_dgrad(const void* dy, const void* wp_dgrad, void* dx,
                        as_stream(stream));
 }
 
+// ---- 3x3 / stride 1 / pad 1 data gradient + first pass of the BatchNorm backward of the layer below (conv_brick16_bnr.hip) ----
+int pcrl_brick16_dgrad2d_bnred_launch(const void* dy, const void* wp, void* dx, const void* bn_y, const float* scale, const float* shift, const float* mean,
+                                      const float* rstd, float* partial, int N, int H, int W, int Ci, int Co, hipStream_t stream);
+extern "C" int64_t pcrl_conv2d_dgrad_bnred_rows(int N, int H, int W, int Ci, int CoP, int act, int dtype) {
+  static const bool off = [] { const char* e = getenv("PCRL_DGRAD_BNRED"); return e && e[0] == '0'; }();   // A/B switch (shared with the 3D path)
+  if (off || act != PCRL_ACT_RELU || N <= 0 || H <= 0 || W <= 0 || Ci <= 0 || CoP <= 0) return 0;
+  return pcrl_conv2d_dgrad_kind(N, H, W, Ci, H, W, CoP, 3, 3, 1, 1, dtype) == 3 ? pcrl_brick16_conv2d_rows(N, H, W) : 0;
+}
+extern "C" int pcrl_conv2d_dgrad_bnred(const void* dy, const void* wp_dgrad, void* dx, const void* bn_y, const float* scale, const float* shift,
+                                       const float* mean, const float* rstd, float* partial, int N, int H, int W, int Ci, int CoP, int act, int dtype,
+                                       pcrl_stream_t stream) {
+  PCRL_REQUIRE(dy && wp_dgrad && dx && bn_y && scale && shift && mean && rstd && partial, "conv2d_dgrad_bnred: null pointer");
+  PCRL_REQUIRE(pcrl_conv2d_dgrad_bnred_rows(N, H, W, Ci, CoP, act, dtype) > 0,
+               "conv2d_dgrad_bnred: no fused kernel for this shape / activation / dtype (pcrl_conv2d_dgrad_bnred_rows == 0)");
+  return pcrl_brick16_dgrad2d_bnred_launch(dy, wp_dgrad, dx, bn_y, scale, shift, mean, rstd, partial, N, H, W, CoP, Ci, as_stream(stream));
+}
+
 // ---- stride-2 data gradient by parity classes ------------------------------------------------------------------------------------
 // dx[ih][iw] of a stride-2 convolution only receives taps whose parity matches (ih + pad - kh even): run as ONE gather over all
 // taps, 3 of 4 taps are idle (conv2d_dgrad above).  Here the four parity classes (a, b) = (ih & 1, iw & 1) are four small stride-1

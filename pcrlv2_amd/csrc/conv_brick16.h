@@ -121,7 +121,7 @@ __device__ __forceinline__ void lds_dma16_masked(uint64_t base, uint32_t voff, u
 // an axis (BITH / BITW) and the border class (CLS) know the difference; rows still go through LDS one 64-byte slice per voxel.
 template <int BN, int MODE = 0, int PERM = 0, int NW = 4, bool BNR = false>
 __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(const Brick16Params p) {
-  static_assert(!BNR || (MODE == 0 && NW == 4), "the BatchNorm-reduce epilogue exists for the plain 4-plane data gradient only");
+  static_assert(!BNR || ((MODE == 0 || MODE == 3) && NW == 4), "the BatchNorm-reduce epilogue exists for the plain 4-plane data gradient only (3D, and the 2D path's 3x3 form)");
   using G = B16Geom<NW>;
   constexpr int ROWS = G::ROWS, NDMA = G::NDMA, HALO_BYTES = G::HALO_BYTES, HD = G::HD;
   constexpr int FN = BN / 16;

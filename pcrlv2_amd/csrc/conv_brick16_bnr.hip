@@ -26,3 +26,20 @@ int pcrl_brick16_dgrad_bnred_launch(const void* dy, const void* wp, void* dx, co
   }
   return BN == 64 ? launch16<64, 0, 4, true>(p, grid, stream, "brick16_dgrad_bnred") : launch16<32, 0, 4, true>(p, grid, stream, "brick16_dgrad_bnred");
 }
+
+// The 2D path's 3x3 / stride 1 / pad 1 data gradient (MODE 3: the image index is the brick's d axis) with the same epilogue: conv2 -> bn1 inside a
+// BasicBlock (torchvision ResNet-18: relu(bn1(conv1(x))) feeds conv2 only) and conv2 -> conv1's BatchNorm inside a DecoderBlock (models/pcrlv2_model.py:113-128).
+// dy: [N][H][W][Ci]; dx, bn_y: [N][H][W][Co]; partial: [N H W / 512][Co][2].
+int pcrl_brick16_dgrad2d_bnred_launch(const void* dy, const void* wp, void* dx, const void* bn_y, const float* scale, const float* shift, const float* mean,
+                                      const float* rstd, float* partial, int N, int H, int W, int Ci, int Co, hipStream_t stream) {
+  Brick16Params p{(const bf16*)dy, (const bf16*)wp, nullptr, (bf16*)dx, partial, 1, N, H, W, Ci, Co, 0, 0, nullptr, 0, (const bf16*)bn_y, scale, shift, mean, rstd};
+  const int BN = Co % 64 == 0 ? 64 : 32, ny = Co / BN;
+  const int64_t bricks = (int64_t)N * H * W / (TD * TH * TW);
+  if (bricks * ny >= ((int64_t)1 << 31)) return pcrl_fail(PCRL_EINVAL, "brick16_dgrad2d_bnred: grid too large");
+  dim3 grid((unsigned)bricks, ny);
+  if (ny > 1) {
+    p.ny = ny;
+    grid = dim3((unsigned)(bricks * ny));
+  }
+  return BN == 64 ? launch16<64, 3, 4, true>(p, grid, stream, "brick16_dgrad2d_bnred") : launch16<32, 3, 4, true>(p, grid, stream, "brick16_dgrad2d_bnred");
+}

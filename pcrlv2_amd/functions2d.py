@@ -284,10 +284,12 @@ class EncoderFn(Function):
             k = pi[id(u)]
             grads[3 * k], grads[3 * k + 1], grads[3 * k + 2] = dw, dg, db
 
-        def bn_conv_bwd(da, u, xin, y, c, M, C, act, need_dx=True):
+        def bn_conv_bwd(da, u, xin, y, c, M, C, act, need_dx=True, below=None, pre=None):
+            # below: {"y", "c"} of the BatchNorm + ReLU layer whose activation xin is and which has no other consumer -- this layer's data gradient
+            # may take that layer's first backward pass with it (ops2d.conv2d_backward); pre: such a pass already taken for `da`
             w, g, _ = P[pi[id(u)]]
-            dy, dg, db = ops.bn_act_backward(da, y, g.detach(), c[0], c[1], c[2], c[3], M, C, act, dt)
-            dx, dw = ops2d.conv2d_backward(xin, dy, w, u._packed, u.stride, u.pad, 0, dt, need_dx=need_dx)
+            dy, dg, db = ops.bn_act_backward(da, y, g.detach(), c[0], c[1], c[2], c[3], M, C, act, dt, pre_partial=pre)
+            dx, dw = ops2d.conv2d_backward(xin, dy, w, u._packed, u.stride, u.pad, 0, dt, need_dx=need_dx, below=below)
             put(u, dw, dg, db)
             return dx
 
@@ -295,8 +297,9 @@ class EncoderFn(Function):
         first, second = None, None
         for k in range(len(ctx.saved) - 1, -1, -1):
             blk, h_in, y1, c1, a1, y2, c2, yd, cd, M, C = ctx.saved[k]
-            d_a1 = bn_conv_bwd(g, blk._u2, a1, y2, c2, M, C, ACT_NONE)
-            first = bn_conv_bwd(d_a1, blk._u1, h_in, y1, c1, M, C, ACT_RELU)
+            below = {"y": y1, "c": c1}       # a1 = relu(bn1(conv1(h_in))) feeds conv2 only (torchvision BasicBlock)
+            d_a1 = bn_conv_bwd(g, blk._u2, a1, y2, c2, M, C, ACT_NONE, below=below)
+            first = bn_conv_bwd(d_a1, blk._u1, h_in, y1, c1, M, C, ACT_RELU, pre=below.get("pre"))
             second = bn_conv_bwd(g, blk._ud, h_in, yd, cd, M, C, ACT_NONE) if blk._ud is not None else g
             if k > 0:
                 gp = torch.empty_like(first)
@@ -421,8 +424,9 @@ class DecoderBlockFn(Function):
             if da2 is not None and not ops.bn_rowadd_ok(C, dt):
                 da, da2 = da + da2, None
             dy2, g_g2, g_be2 = ops.bn_act_backward(da, y2, g2.detach(), c2[0], c2[1], c2[2], c2[3], M, C, ACT_RELU, dt, row_g=row_g, da2=da2)
-            d_a1, g_w2 = ops2d.conv2d_backward(a1, dy2, w2, u2._packed, 1, 1, 0, dt, need_dx=True)
-            dy1, g_g1, g_be1 = ops.bn_act_backward(d_a1, y1, g1.detach(), c1[0], c1[1], c1[2], c1[3], M, C, ACT_RELU, dt)
+            below = {"y": y1, "c": c1}       # a1 = relu(bn(conv1(up(x)))) feeds conv2 only (models/pcrlv2_model.py:115-118)
+            d_a1, g_w2 = ops2d.conv2d_backward(a1, dy2, w2, u2._packed, 1, 1, 0, dt, need_dx=True, below=below)
+            dy1, g_g1, g_be1 = ops.bn_act_backward(d_a1, y1, g1.detach(), c1[0], c1[1], c1[2], c1[3], M, C, ACT_RELU, dt, pre_partial=below.get("pre"))
             dx, g_w1 = ops2d.conv2d_backward(ctx.x, dy1, w1, u1._packed, 1, 1, 1, dt, need_dx=ctx.needs_input_grad[0])
             pg[0], pg[1], pg[2], pg[3], pg[4], pg[5] = g_w1, g_g1, g_be1, g_w2, g_g2, g_be2
         out = (dx,) + tuple(_park(p, g) for p, g in zip(ctx.plist, pg)) + (None, None)

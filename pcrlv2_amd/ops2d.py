@@ -7,8 +7,8 @@ from __future__ import annotations
 
 import torch
 
-from . import ops
-from ._lib import PcrlError, dtype_code, lib, stream_handle
+from . import config, ops
+from ._lib import ACT_RELU, PcrlError, dtype_code, lib, stream_handle
 
 
 def new_act2(N, H, W, C, dtype, device) -> torch.Tensor:
@@ -165,9 +165,13 @@ def conv2d_forward(x, w, bias, packed: PackedConv2d, stride, pad, up, dtype, wan
     return y, partial, rows
 
 
-def conv2d_backward(x, dy, w, packed: PackedConv2d, stride, pad, up, dtype, need_dx=True):
+def conv2d_backward(x, dy, w, packed: PackedConv2d, stride, pad, up, dtype, need_dx=True, below=None):
     """x: the forward input (NHWC, CiP channels); dy: NHWC gradient of the forward output in `dtype` with CoP = pow2 >= 8 channels
-    (zero-padded by the caller when Co = 3).  -> (dx | None, dw float32 [Co][Ci][KH][KW])"""
+    (zero-padded by the caller when Co = 3).  -> (dx | None, dw float32 [Co][Ci][KH][KW])
+    `below` = {"y": pre-normalisation tensor, "c": (mean, rstd, scale, shift)} of the BatchNorm + ReLU layer whose activation x is, when this
+    convolution is that activation's ONLY consumer (conv2 over relu(bn1(conv1)) in a BasicBlock / DecoderBlock): where the library has the kernel
+    (pcrl_conv2d_dgrad_bnred_rows) the data gradient takes the first pass of that layer's BatchNorm backward from its output tiles and leaves
+    below["pre"] = (partial, rows) for ops.bn_act_backward(pre_partial=...)."""
     L, s = lib(), stream_handle()
     N, Hi, Wi, CiP = dims2(x)
     _, Ho, Wo, CoP = dims2(dy)
@@ -197,6 +201,16 @@ def conv2d_backward(x, dy, w, packed: PackedConv2d, stride, pad, up, dtype, need
             return dx, dw
         Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
         dxl = new_act2(N, Hl, Wl, Ci, dtype, x.device)
+        brows = 0
+        if (below is not None and config.DGRAD_BNRED and not up and KH == 3 and KW == 3 and stride == 1 and pad == 1 and (Ho, Wo) == (Hi, Wi)
+                and below["y"].dtype == dtype and tuple(below["y"].shape) == tuple(dxl.shape)):
+            brows = L.call("pcrl_conv2d_dgrad_bnred_rows", N, Hi, Wi, Ci, CoP, ACT_RELU, dtype_code(dtype))
+        if brows:
+            mean, rstd, scale, shift = below["c"]
+            bpart = ops._f32(brows * Ci * 2, x.device)
+            L.call("pcrl_conv2d_dgrad_bnred", dy, wd, dxl, below["y"], scale, shift, mean, rstd, bpart, N, Hi, Wi, Ci, CoP, ACT_RELU, dtype_code(dtype), s)
+            below["pre"] = (bpart, brows)
+            return dxl, dw
         L.call("pcrl_conv2d_dgrad", dy, wd, dxl, N, Hl, Wl, Ci, Ho, Wo, CoP, KH, KW, stride, pad, dtype_code(dtype), s)
         if up:
             dx = new_act2(N, Hi, Wi, Ci, dtype, x.device)
