@@ -284,7 +284,16 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
   constexpr int VEC = 16 / (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [slots][C]
   const int tid = threadIdx.x, nvec = C / VEC, cv = tid % nvec, slot = tid / nvec, nslots = 256 / nvec;
-  const T* base = dy + (int64_t)blockIdx.x * FH * FW * C + cv * VEC;
+  // Plane order: the 2 N border planes (fd = 0, FD - 1: every voxel of them is read) take the FIRST block ids, the planes inside the volume (a ninth of the
+  // work each under zsum) follow -- in plane order the last border plane started in the last round of blocks and alone set the kernel's duration.
+  const int nsamp = gridDim.x / FD;
+  int plane;
+  if ((int)blockIdx.x < 2 * nsamp) plane = (blockIdx.x >> 1) * FD + ((blockIdx.x & 1) ? FD - 1 : 0);
+  else {
+    const int kk = blockIdx.x - 2 * nsamp;
+    plane = (kk / (FD - 2)) * FD + 1 + kk % (FD - 2);
+  }
+  const T* base = dy + (int64_t)plane * FH * FW * C + cv * VEC;
   float acc[9][VEC];
 #pragma unroll
   for (int k = 0; k < 9; ++k)
@@ -339,7 +348,7 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
   // zsum: dy sums to zero over all voxels per channel (it is the output of a training-mode BatchNorm backward over exactly these voxels), so the
   // fully interior class is minus the sum of the other 26 (upc_box_kernel) and a plane inside the volume only contributes its border: two
   // rows and two columns instead of FH x FW voxels (9 % at 64 x 32) -- and the result is the exact-arithmetic one, free of the rounding of dy.
-  const int fd = blockIdx.x % FD;
+  const int fd = plane % FD;
   if (zsum && fd > 0 && fd < FD - 1) {
     ROWS(0, 1, 0)
     ROWS(FH - 1, FH, 2)
@@ -374,7 +383,7 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
     __syncthreads();
     for (int i = tid; i < 9 * C; i += 256) {
       const int q = i / C, c = i - q * C;
-      part[((int64_t)blockIdx.x * 9 + q) * C + c] = (sm[q * C + c] + sm[(9 + q) * C + c]) + (sm[(18 + q) * C + c] + sm[(27 + q) * C + c]);
+      part[((int64_t)plane * 9 + q) * C + c] = (sm[q * C + c] + sm[(9 + q) * C + c]) + (sm[(18 + q) * C + c] + sm[(27 + q) * C + c]);
     }
     return;
   }
@@ -387,7 +396,7 @@ __global__ void __launch_bounds__(256) upc_class_sums_kernel(const T* __restrict
     for (int c = tid; c < C; c += 256) {
       float a = 0.f;
       for (int s2 = 0; s2 < nslots; ++s2) a += sm[s2 * C + c];
-      part[((int64_t)blockIdx.x * 9 + q) * C + c] = a;
+      part[((int64_t)plane * 9 + q) * C + c] = a;
     }
   }
 }
