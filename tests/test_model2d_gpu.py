@@ -174,10 +174,14 @@ def test_encoder_as_one_autograd_node_is_bit_identical_2d(dtype):
     from pcrlv2_amd import functions2d as Fn2, train_2d
     from pcrlv2_amd.optim import FusedSGD
     from pcrlv2_amd.train_3d import CosineSimilarityMean
+    from pcrlv2_amd import config
     batches = [O.synthetic_batch(4, 64, 32, seed=21 + k) for k in range(3)]
-    keep, keep_stem, finals = Fn2.FUSED_ENCODER, Fn2.STEM_KERNEL, []
+    keep, keep_stem, keep_bnred, finals = Fn2.FUSED_ENCODER, Fn2.STEM_KERNEL, config.DGRAD_BNRED, []
     try:
         Fn2.STEM_KERNEL = False      # the dedicated stem kernels (another summation order) exist on the one-node path only: compared separately below
+        # likewise the data gradient that takes bn1's first backward pass with it (another summation order of two per-channel sums; it knows a BasicBlock's
+        # structure, so it lives on the one-node path only): held to the separate pass in tests/test_dgrad_bnred_gpu.py
+        config.DGRAD_BNRED = False
         for on in (True, False):
             Fn2.FUSED_ENCODER = on
             model = _build(seed=6, dtype=dtype)
@@ -190,7 +194,7 @@ def test_encoder_as_one_autograd_node_is_bit_identical_2d(dtype):
             rs = torch.cat([v.flatten().float() for k, v in sorted(sd.items()) if "running" in k or "num_batches" in k])
             finals.append(([float(o) for o in out], opt.flat_p.clone(), opt.flat_buf.clone(), rs))
     finally:
-        Fn2.FUSED_ENCODER, Fn2.STEM_KERNEL = keep, keep_stem
+        Fn2.FUSED_ENCODER, Fn2.STEM_KERNEL, config.DGRAD_BNRED = keep, keep_stem, keep_bnred
     a, b = finals
     assert a[0] == b[0], (a[0], b[0])
     for x, y, what in zip(a[1:], b[1:], ("parameters", "momentum buffers", "running statistics")):
