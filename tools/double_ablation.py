@@ -26,6 +26,7 @@ from pcrlv2_amd.train_3d import CosineSimilarityMean, MSELoss, train_step  # noq
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--d", type=int, default=3, choices=[2, 3], help="2: the C5 per-GPU 2D step (512 x 512, b = 64) with its own launch sets")
 a = ap.parse_args()
 dev = torch.device("cuda")
 L = _lib.lib()
@@ -82,12 +83,43 @@ def call(self, name, *args):
 
 _lib._Lib.call = call
 torch.manual_seed(0)
-model = PCRLv23d().to(dev).train().set_compute_dtype(torch.bfloat16)
-opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
-batch = synthetic_batch(32, (64, 64, 32), 16, dev, 1234)
-crit, cosine = MSELoss(), CosineSimilarityMean()
+if a.d == 3:
+    model = PCRLv23d().to(dev).train().set_compute_dtype(torch.bfloat16)
+    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    batch = synthetic_batch(32, (64, 64, 32), 16, dev, 1234)
+    crit, cosine = MSELoss(), CosineSimilarityMean()
+else:
+    from pcrlv2_amd import train_2d
+    from pcrlv2_amd.models import PCRLv2
+    model = PCRLv2().cuda().set_compute_dtype("bf16")
+    opt = FusedSGD(model.parameters(), lr=1e-3, momentum=0.9, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    x1 = torch.randn(64, 3, 512, 512, generator=g)
+    batch = (x1.to(dev), (x1 + 0.1 * torch.randn(64, 3, 512, 512, generator=g)).to(dev), torch.rand(64, 3, 512, 512, generator=g).to(dev), None,
+             [torch.randn(64, 3, 96, 96, generator=g).to(dev) for _ in range(6)])
+    crit, cosine = train_2d.MSELoss2d(), CosineSimilarityMean()
+    _step2d = train_2d.train_step
+
+    def train_step(model, opt, batch, epoch, crit, cosine, guard=False):   # noqa: F811  (the 2D step behind the 3D step's name)
+        return _step2d(model, opt, batch, epoch, crit, cosine)
+
+    SETS = {
+        "finalize": lambda n, ar: n in ("pcrl_bn_finalize", "pcrl_bn_bwd_finalize"),
+        "bn_reduce": lambda n, ar: n.startswith("pcrl_bn_act_bwd_reduce"),
+        "bn_bwd_apply": lambda n, ar: n.startswith("pcrl_bn_act_bwd_apply"),
+        "bn_apply": lambda n, ar: n in ("pcrl_bn_act_apply", "pcrl_bn_act_apply_gap", "pcrl_bn_add_relu_fwd", "pcrl_bn_relu_maxpool2d_3s2_fwd"),
+        "conv_fwd": lambda n, ar: n == "pcrl_conv2d_fwd",
+        "conv_dgrad": lambda n, ar: n in ("pcrl_conv2d_dgrad", "pcrl_conv2d_dgrad_bnred", "pcrl_conv2d_dgrad_up", "pcrl_conv2d_dgrad_s2"),
+        "conv_wgrad": lambda n, ar: n == "pcrl_conv2d_wgrad",
+        "weight_packs": lambda n, ar: n in ("pcrl_conv2d_pack", "pcrl_conv2d_pack_s2", "pcrl_stem7_pack"),
+        "stem": lambda n, ar: n in ("pcrl_stem7_fwd", "pcrl_stem7_wgrad"),
+        "masks_pools": lambda n, ar: n in ("pcrl_relu_mask_sum_bwd", "pcrl_relu_mask_bwd", "pcrl_maxpool2d_3s2_bwd_sum", "pcrl_upsample2d_nearest2_bwd"),
+        "no_bnred": None,
+    }
+    if os.environ.get("ABL_SETS"):
+        SETS = {k: v for k, v in SETS.items() if k in os.environ["ABL_SETS"].split(",")}
 random.seed(0)
-for _ in range(8):
+for _ in range(8 if a.d == 3 else 4):
     train_step(model, opt, batch, 0, crit, cosine, guard=False)
 st0 = random.getstate()
 
