@@ -249,6 +249,19 @@ def main():
             print(ln, file=sys.stdout if ln.startswith("{") else sys.stderr)
         raise SystemExit(r.returncode)
 
+    # Every rank leaves through ddp.shutdown(): a barrier, then destroy_process_group().  A rank that falls off main() with the group alive
+    # aborts now and then at interpreter exit ("terminate called without an active exception": gloo's / RCCL's threads are still running when
+    # their statics go away) -- AFTER the JSON line, but torchrun then reports rc = 1 for the whole run (reproduced 1 in 4).
+    from pcrlv2_amd import ddp
+    ok = False
+    try:
+        _run(args)
+        ok = True
+    finally:
+        ddp.shutdown(ok)
+
+
+def _run(args):
     dry = os.environ.get("PCRL_BENCH_DRYRUN", "0") == "1"
     from pcrlv2_amd import ddp
     if not dry:

@@ -29,8 +29,8 @@ def init_process_group_from_env(backend: str | None = None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"  # "nccl" IS RCCL on ROCm
+    if backend is None:     # PCRL_DIST_BACKEND=gloo: several ranks on ONE GPU (tests of the N-rank entry points on a one-GPU box)
+        backend = os.environ.get("PCRL_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")  # "nccl" IS RCCL on ROCm
     if backend == "nccl":
         torch.cuda.set_device(local)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -52,6 +52,28 @@ def init_process_group_from_env(backend: str | None = None):
         if table is not None:
             bind_rank_to_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), verbose=os.environ.get("PCRL_BIND_VERBOSE", "0") == "1", table=table)
     return rank, world, local
+
+
+def shutdown(ok: bool = True):
+    """Leave the process group the way every N-rank entry point must (bench.py, main.py -> train_3d / train_2d): a barrier so that no rank tears
+    its transport down under a peer's last collective, then `destroy_process_group()`.  The reference's nn.DataParallel (train_3d.py:54) lives
+    in one process and needs none of this; one process per GPU does -- a rank that returns from main() with the group alive leaves gloo's /
+    RCCL's worker threads running into interpreter teardown, which now and then ends in `terminate called without an active exception`
+    (SIGABRT, torchrun reports rc = 1 although every result was already printed).  `ok=False` (an exception is propagating): no barrier --
+    the peers may never reach it -- only the teardown.  A no-op without a group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if ok:
+        try:
+            if torch.cuda.is_available() and dist.get_backend() == "nccl":
+                torch.cuda.synchronize()
+            dist.barrier()
+        except Exception as e:      # a broken group must not turn a finished run into a failed one
+            print(f"[pcrlv2_amd.ddp] barrier before shutdown failed ({e})", flush=True)
+    try:
+        dist.destroy_process_group()
+    except Exception as e:
+        print(f"[pcrlv2_amd.ddp] destroy_process_group failed ({e})", flush=True)
 
 
 def parse_cpulist(text: str):

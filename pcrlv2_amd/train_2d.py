@@ -122,6 +122,19 @@ def train_step(model, optimizer, batch, epoch, criterion, cosine):
 
 def train_pcrlv2(args, data_loader, out_channel=3):
     distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    # a group this call creates is this call's to take down (see train_3d.train_pcrlv2_3d)
+    owns_group = distributed and not (torch.distributed.is_available() and torch.distributed.is_initialized())
+    ok = False
+    try:
+        model = _train_pcrlv2(args, data_loader, distributed)
+        ok = True
+        return model
+    finally:
+        if owns_group:
+            _ddp.shutdown(ok)
+
+
+def _train_pcrlv2(args, data_loader, distributed):
     rank = 0
     if distributed:
         rank, _, local_rank = _ddp.init_process_group_from_env()

@@ -258,6 +258,20 @@ def load_checkpoint(path, model, optimizer=None):
 
 def train_pcrlv2_3d(args, data_loader, out_channel=3):
     distributed = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    # a group this call creates is this call's to take down (ddp.shutdown: barrier + destroy_process_group, also when an exception propagates):
+    # nn.DataParallel (train_3d.py:54) needs no teardown, one process per GPU does -- ranks that return with the group alive abort now and then
+    owns_group = distributed and not (torch.distributed.is_available() and torch.distributed.is_initialized())
+    ok = False
+    try:
+        model = _train_pcrlv2_3d(args, data_loader, distributed)
+        ok = True
+        return model
+    finally:
+        if owns_group:
+            _ddp.shutdown(ok)
+
+
+def _train_pcrlv2_3d(args, data_loader, distributed):
     rank = 0
     if distributed:
         rank, _, local_rank = _ddp.init_process_group_from_env()

@@ -171,3 +171,45 @@ def test_guard_is_collective_two_ranks_one_gpu_gloo(tmp_path, mode):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
     assert all("OK" in o for o in outs)
+
+
+# ---- every N-rank entry point exits clean (reference: train_3d.py:54's nn.DataParallel needs no teardown, one process per GPU does) ----
+_ABORT_MARKS = ("terminate called", "destroy_process_group() was not called", "ChildFailedError", "Aborted", "SIGABRT")
+
+
+def test_bench_one_rank_rccl_group_is_destroyed_before_exit():
+    """`PCRL_FORCE_DDP=1 python bench.py`: the data-parallel wrapper on a ONE-rank RCCL group (real collectives on the communication stream).  The
+    process must end rc = 0 with its JSON line and WITHOUT ProcessGroupNCCL's "destroy_process_group() was not called before program exit" warning
+    -- bench.py leaves through ddp.shutdown() on every rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCRL_FORCE_DDP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--b", "4", "--dhw", "32,32,16", "--no-cpu-baseline",
+                        "--no-secondary", "--no-alone"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert not any(m in r.stderr for m in _ABORT_MARKS), r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["distributed"]["forced_one_rank_probe"] is True and d["value"] > 0
+
+
+@pytest.mark.parametrize("d", [3, 2])
+def test_main_py_two_ranks_one_gpu_exits_clean(tmp_path, d):
+    """`main.py --data synthetic` as two ranks (gloo, both on cuda:0 -- PCRL_DIST_BACKEND): real model, real steps, the product's own
+    train_pcrlv2_3d / train_pcrlv2 creates the process group and destroys it in its `finally`.  Both ranks rc = 0, no abort message."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29781 + d), WORLD_SIZE="2", PCRL_DIST_BACKEND="gloo", PCRL_BIND_CPUS="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "main.py"), "--data", "synthetic", "--d", str(d), "--b", "4", "--epochs", "0", "--steps_per_epoch", "2",
+           "--output", str(tmp_path), "--gpus", "0", "--amp"] + (["--size2d", "64"] if d == 2 else [])
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    assert not any(m in o for o in outs for m in _ABORT_MARKS), "\n".join(o[-3000:] for o in outs)
+    assert "==> Saving..." in outs[0] and "total time" in outs[0]

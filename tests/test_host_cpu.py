@@ -445,6 +445,138 @@ def test_bench_gpus4_code_path_dry_run_gloo_world4():
     assert d["steps"] == 4 and d["warmup"] == 1 and d["ms_per_step"] > 0
 
 
+class _BusyLoops:
+    """`n` busy-loop processes beside a test (the rc = 1 exits of the N-rank entry points showed up under CPU load, when a
+    rank's teardown was slow enough for its peers' threads to outlive it).  Killed by their exact PIDs."""
+
+    def __init__(self, n):
+        self.n, self.procs = n, []
+
+    def __enter__(self):
+        self.procs = [subprocess.Popen([sys.executable, "-c", "while True: pass"]) for _ in range(self.n)]
+        return self
+
+    def __exit__(self, *exc):
+        for p in self.procs:
+            p.kill()
+        for p in self.procs:
+            p.wait()
+
+
+_ABORT_MARKS = ("terminate called", "destroy_process_group() was not called", "ChildFailedError", "Aborted", "SIGABRT")
+
+
+def test_bench_gpus4_dry_run_exits_clean_10_times_under_cpu_load():
+    """Every rank of `bench.py --gpus N` leaves through ddp.shutdown() (barrier + destroy_process_group).  Round 5's bench.py returned from main()
+    with the group alive: one dry run in four ended `terminate called without an active exception` on some rank AFTER the JSON line and torchrun
+    reported rc = 1 -- on the day the driver runs `--gpus 8` that voids the record.  Ten spawns with eight busy loops beside them: rc = 0 and no
+    abort / missing-teardown message every time."""
+    env = dict(os.environ, PCRL_BENCH_DRYRUN="1", PCRL_BIND_CPUS="0")
+    env.pop("WORLD_SIZE", None)
+    with _BusyLoops(8):
+        for i in range(10):
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "1"], env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+            assert r.returncode == 0, (i, r.stderr[-3000:])
+            assert not any(m in r.stderr for m in _ABORT_MARKS), (i, r.stderr[-3000:])
+            assert sum(ln.startswith("{") for ln in r.stdout.splitlines()) == 1, (i, r.stdout[-300:])
+
+
+MAIN_STUB_WORKER = r'''
+# `main.py --data synthetic --d 3` on CPU, two gloo ranks: main.main -> train_3d.train_pcrlv2_3d -> (group created) -> epochs -> ddp.shutdown.
+# The model / optimizer / step are stand-ins (no GPU here); everything that decides how the process ENDS is the product's own code.
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from pcrlv2_amd import main as M, train_3d as T, ddp, config
+torch.cuda.set_device = lambda *_a, **_k: None
+config.EMPTY_CACHE_PER_EPOCH = False
+
+
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(1000))
+
+    def cuda(self, *a, **k):
+        return self
+
+    def set_compute_dtype(self, dt):
+        return self
+
+
+class Opt(torch.optim.SGD):
+    def __init__(self, params, lr, momentum, weight_decay):
+        super().__init__(params, lr=lr, momentum=momentum, weight_decay=weight_decay)
+
+
+class Crit(torch.nn.Module):
+    def cuda(self):
+        return self
+
+
+def dp(model, opt):
+    assert dist.is_initialized() and dist.get_world_size() == 2
+    opt.collective = True
+
+
+def step(model, opt, batch, epoch, crit, cosine, guard=True):
+    g = torch.full((1000,), float(dist.get_rank() + 1))
+    dist.all_reduce(g)                       # the step's exchange
+    assert float(g[0]) == 3.0
+    z = torch.zeros(())
+    out = T.StepLosses((z, z, z, z, z)) if hasattr(T, "StepLosses") else None
+    return out
+
+
+T.PCRLv23d, T.FusedSGD, T.MSELoss, T.CosineSimilarityMean = Net, Opt, Crit, Crit
+T._ddp.DataParallel = dp
+T.train_pcrlv2_inner = lambda args, epoch, loader, model, opt, crit, cos, verbose=True: [step(model, opt, b, epoch, crit, cos) for b in loader]
+M.SyntheticLunaLoader.__init__ = lambda self, b, steps, seed=0, device=None: setattr(self, "steps", steps)
+M.SyntheticLunaLoader.__iter__ = lambda self: iter(range(self.steps))
+mode = sys.argv[3]
+if mode == "raise" and os.environ["RANK"] == "1":
+    def boom(*a, **k):
+        raise RuntimeError("rank 1 fails inside the epoch")
+    T.train_pcrlv2_inner = boom
+try:
+    M.main(["--data", "synthetic", "--d", "3", "--b", "4", "--epochs", "1", "--steps_per_epoch", "3", "--output", sys.argv[2], "--gpus", "0,1"])
+except RuntimeError as e:
+    assert mode == "raise" and "rank 1 fails" in str(e), e
+    assert not dist.is_initialized(), "the group must be torn down when an exception propagates"
+    print("OK-raised", flush=True)
+    raise SystemExit(0)
+assert not dist.is_initialized(), "train_pcrlv2_3d created the group and must have destroyed it"
+print("OK", os.environ["RANK"], flush=True)
+'''
+
+
+def test_main_py_two_ranks_cpu_stub_exits_clean_10_times_under_cpu_load(tmp_path):
+    """`main.py --gpus 0,1` (one process per GPU instead of train_3d.py:54's nn.DataParallel) tears its process group down in a `finally`
+    (train_3d.train_pcrlv2_3d -> ddp.shutdown): ten 2-rank gloo runs of main.main with stand-in model / step on CPU, eight busy loops beside
+    them, every rank rc = 0 with the group gone; and once with rank 1 raising inside the epoch -- its group is destroyed on the way out
+    (rank 0, left alone in the all-reduce, is killed by the test: only rank 1's exit is asserted there)."""
+    script = tmp_path / "m.py"
+    script.write_text(MAIN_STUB_WORKER)
+
+    def spawn(port, mode):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", PCRL_BIND_CPUS="0")
+        return [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path), mode], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                 stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    with _BusyLoops(8):
+        for i in range(10):
+            procs = spawn(29741 + i, "ok")
+            outs = [p.communicate(timeout=180)[0] for p in procs]
+            assert all(p.returncode == 0 for p in procs), (i, outs)
+            assert all("OK" in o for o in outs) and not any(m in o for o in outs for m in _ABORT_MARKS), (i, outs)
+    procs = spawn(29761, "raise")
+    out1 = procs[1].communicate(timeout=180)[0]
+    procs[0].kill()
+    procs[0].communicate()
+    assert procs[1].returncode == 0 and "OK-raised" in out1 and not any(m in out1 for m in _ABORT_MARKS), out1
+
+
 @pytest.mark.parametrize("tag", ["loss2d_b4_5scales", "loss2d_b2_nl3"])
 def test_2d_loss_assembly_and_draw_order_match_the_reference(tag, golden_dir, monkeypatch):
     """What can be pinned of the 2D path without smp / torchvision (VERDICT r4 item 7): pcrlv2_amd.train_2d's `cos_loss` and loss assembly against
