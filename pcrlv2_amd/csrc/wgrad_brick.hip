@@ -31,7 +31,14 @@
 #define WB_PF 1
 #endif
 #ifndef WB_ABL
-#define WB_ABL 0   // timing ablations (wrong results): 1 no staging requests, 2 no x-fragment reads after the first brick, 3 no per-brick wait + barrier
+#define WB_ABL 0   // timing ablations (wrong results): 1 no staging requests, 2 no x-fragment reads after the first brick, 3 no per-brick wait + barrier,
+#endif             // 4 every brick's pieces from the FIRST brick's addresses (same staging traffic, all of it L2 hits)
+#ifndef WB_PRIO
+#define WB_PRIO 1  // 1: a wave's issue priority falls with the step inside a brick (s_setprio 3 .. 0 per quarter): of the two waves of a SIMD the one
+#endif             // that is BEHIND wins the arbitration.  0: equal priorities -- the hardware then favours the older wave (waves 0-3), which reaches
+                   // every end-of-brick barrier 28-37 % of a brick early (s_memtime accounting, profiles/r06_wgrad_trace.txt)
+#ifndef WB_TRACE
+#define WB_TRACE 0 // 1 (probe builds only, tools/wgrad_trace.py): s_memtime accounting per block, summed into g_wb_trace
 #endif
 
 namespace {
@@ -91,6 +98,40 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_void;
 __device__ uint4 g_wb_zero[4];   // source of halo rows outside the volume (zero-initialised device memory)
+#if WB_TRACE
+// [0] block cycles, [1] cycles between the last step and the end of the barrier (wave 0), [2] cycles of the steps that issue staging requests (wave 0),
+// [3] bricks, [4] blocks; [8 + 2 w] / [9 + 2 w]: wave w's cycles in the vmcnt wait / in the barrier behind it
+__device__ unsigned long long g_wb_trace[32];
+#define WB_T_DECL() unsigned long long t_all_ = __builtin_amdgcn_s_memtime(), t_wait_ = 0, t_issue_ = 0, t_b0_ = 0, t_w0_ = 0, t_vm_ = 0; int t_n_ = 0; (void)t_b0_; (void)t_w0_
+#define WB_T_BRICK() do { __builtin_amdgcn_sched_barrier(0); t_b0_ = __builtin_amdgcn_s_memtime(); ++t_n_; } while (0)
+#define WB_T_ISSUED() do { __builtin_amdgcn_sched_barrier(0); t_issue_ += __builtin_amdgcn_s_memtime() - t_b0_; } while (0)
+#define WB_T_WAIT0() do { __builtin_amdgcn_sched_barrier(0); t_w0_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define WB_T_MID() do { __builtin_amdgcn_sched_barrier(0); t_vm_ += __builtin_amdgcn_s_memtime() - t_w0_; } while (0)
+#define WB_T_WAIT1() do { __builtin_amdgcn_sched_barrier(0); t_wait_ += __builtin_amdgcn_s_memtime() - t_w0_; } while (0)
+#define WB_T_END() do { if ((threadIdx.x & 63) == 0) { atomicAdd(&g_wb_trace[8 + 2 * (threadIdx.x >> 6)], t_vm_); atomicAdd(&g_wb_trace[9 + 2 * (threadIdx.x >> 6)], t_wait_ - t_vm_); } \
+  if (threadIdx.x == 0) { atomicAdd(&g_wb_trace[0], __builtin_amdgcn_s_memtime() - t_all_); atomicAdd(&g_wb_trace[1], t_wait_); \
+    atomicAdd(&g_wb_trace[2], t_issue_); atomicAdd(&g_wb_trace[3], (unsigned long long)t_n_); atomicAdd(&g_wb_trace[4], 1ull); } } while (0)
+#else
+#define WB_T_DECL() do {} while (0)
+#define WB_T_BRICK() do {} while (0)
+#define WB_T_ISSUED() do {} while (0)
+#define WB_T_WAIT0() do {} while (0)
+#define WB_T_MID() do {} while (0)
+#define WB_T_WAIT1() do {} while (0)
+#define WB_T_END() do {} while (0)
+#endif
+// the quarter-of-the-brick priority (WB_PRIO): call with the compile-time step index and the steps per brick
+#if WB_PRIO
+#define WB_SETPRIO(st_, n_)                                          \
+  do {                                                               \
+    if ((st_) == 0) __builtin_amdgcn_s_setprio(3);                   \
+    else if ((st_) == (n_) / 4) __builtin_amdgcn_s_setprio(2);       \
+    else if ((st_) == (n_) / 2) __builtin_amdgcn_s_setprio(1);       \
+    else if ((st_) == 3 * (n_) / 4) __builtin_amdgcn_s_setprio(0);   \
+  } while (0)
+#else
+#define WB_SETPRIO(st_, n_) do {} while (0)
+#endif
 
 // One LDS-DMA request: every lane's 16 bytes at `gsrc` land at LDS byte address `lds_dst` (wave-uniform) + 16 * lane.  M0 carries the
 // destination and is compiler-reserved: saved and restored inside the statement.  Not counted by hipcc: wait with s_waitcnt vmcnt.
@@ -216,45 +257,57 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     }
     on = t_;
   }
+  // Byte offsets of the brick being loaded are CARRIED as well (round 6): dyo = its first voxel in dy, xo = its first halo voxel in x; a step
+  // along an axis and the wrap at its end are precomputed 64-bit constants.  Rebuilding them from (n, d0, h0, w0) took ~50 scalar instructions
+  // with eight 64-bit multiplies per brick, executed by all eight waves at once right behind the barrier -- with the matrix pipe idle.
+  const int64_t evx = p.up ? 1 : p.sw, ehx = p.up ? Ws : p.sh, edx = p.up ? (int64_t)Hs * Ws : p.sd;   // x strides (voxels) of the brick axes
+  const int64_t cub = 2 * (int64_t)p.Cu, cvb = 2 * (int64_t)p.Cv;
+  const int64_t dsW = BW * p.sw * cub, dsH = BH * p.sh * cub, dsD = BD * p.sd * cub;                      // dy: one brick along w / h / d
+  const int64_t dwW = (int64_t)p.W * p.sw * cub, dwH = (int64_t)p.H * p.sh * cub, dwD = (int64_t)p.D * p.sd * cub;   // ... and a whole axis
+  const int64_t dsN = (int64_t)p.D * p.H * p.W * cub;
+  const int64_t xsW = (p.up ? BW / 2 : BW) * evx * cvb, xsH = (p.up ? BH / 2 : BH) * ehx * cvb, xsD = BD * edx * cvb;
+  const int64_t xwW = (p.up ? p.W / 2 : p.W) * evx * cvb, xwH = (p.up ? p.H / 2 : p.H) * ehx * cvb, xwD = (int64_t)p.D * edx * cvb;
+  const int64_t xsN = (p.up ? (int64_t)p.D * Hs * Ws : (int64_t)p.D * p.H * p.W) * cvb;
+  int64_t dyo = ((int64_t)on * p.D * p.H * p.W + (int64_t)od0 * p.sd + (int64_t)oh0 * p.sh + (int64_t)ow0 * p.sw) * cub + 2 * (int64_t)i0;
+  // first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then
+  int64_t xo = p.up ? ((((int64_t)on * p.D + od0 + (kd - 1)) * Hs + (oh0 >> 1)) * Ws + (ow0 >> 1) - Ws - 1) * cvb
+                    : ((int64_t)on * p.D * p.H * p.W + (int64_t)(od0 + kd - 1) * p.sd + (int64_t)(oh0 - 1) * p.sh + (int64_t)(ow0 - 1) * p.sw) * cvb;
 #define WB_ORIGIN_NEXT()                                                                                     \
   do {                                                                                                       \
-    const int w0 = ow0, h0 = oh0, d0 = od0, n = on;                                                          \
-    if (ob + 1 < b_end) { /* advance to the next brick; the last one is repeated (its loads are unused) */   \
+    const int w0 = ow0, h0 = oh0, d0 = od0;                                                                  \
+    dyb = reinterpret_cast<const char*>(p.dy) + dyo;                                                         \
+    xb = reinterpret_cast<const char*>(p.x) + xo;                                                            \
+    /* faces of this brick's halo that stick out of the volume (BD = 2: the d faces are the two planes) */    \
+    xout = (d0 + kd - 1 < 0 ? 1u : 0u) | (d0 + kd - 1 + BD - 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |      \
+           (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;            \
+    if (WB_ABL != 4 && ob + 1 < b_end) { /* advance to the next brick; the last one is repeated (its loads are unused) */ \
       ++ob;                                                                                                  \
-      ow0 += BW;                                                                                             \
+      ow0 += BW; dyo += dsW; xo += xsW;                                                                      \
       if (ow0 == p.W) {                                                                                      \
-        ow0 = 0;                                                                                             \
+        ow0 = 0; dyo -= dwW; xo -= xwW;                                                                      \
         if (p.order) {                                                                                       \
-          od0 += BD;                                                                                         \
+          od0 += BD; dyo += dsD; xo += xsD;                                                                  \
           if (od0 == p.D) {                                                                                  \
-            od0 = 0;                                                                                         \
-            oh0 += BH;                                                                                       \
+            od0 = 0; dyo -= dwD; xo -= xwD;                                                                  \
+            oh0 += BH; dyo += dsH; xo += xsH;                                                                \
             if (oh0 == p.H) {                                                                                \
-              oh0 = 0;                                                                                       \
-              ++on;                                                                                          \
+              oh0 = 0; dyo -= dwH; xo -= xwH;                                                                \
+              ++on; dyo += dsN; xo += xsN;                                                                   \
             }                                                                                                \
           }                                                                                                  \
         } else {                                                                                             \
-          oh0 += BH;                                                                                         \
+          oh0 += BH; dyo += dsH; xo += xsH;                                                                  \
           if (oh0 == p.H) {                                                                                  \
-            oh0 = 0;                                                                                         \
-            od0 += BD;                                                                                       \
+            oh0 = 0; dyo -= dwH; xo -= xwH;                                                                  \
+            od0 += BD; dyo += dsD; xo += xsD;                                                                \
             if (od0 == p.D) {                                                                                \
-              od0 = 0;                                                                                       \
-              ++on;                                                                                          \
+              od0 = 0; dyo -= dwD; xo -= xwD;                                                                \
+              ++on; dyo += dsN; xo += xsN;                                                                   \
             }                                                                                                \
           }                                                                                                  \
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
-    const int64_t base0 = (int64_t)n * p.D * p.H * p.W + (int64_t)d0 * p.sd + h0 * p.sh + w0 * p.sw;          \
-    dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                           \
-    /* first halo voxel (d0 + kd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
-    const int64_t xbase0 = p.up ? (((int64_t)n * p.D + d0) * Hs + (h0 >> 1)) * Ws + (w0 >> 1) : base0;       \
-    xb = reinterpret_cast<const char*>(p.x + (xbase0 + (p.up ? ((int64_t)(kd - 1) * Hs - 1) * Ws - 1 : (int64_t)(kd - 1) * p.sd - p.sh - p.sw)) * p.Cv); \
-    /* faces of this brick's halo that stick out of the volume (BD = 2: the d faces are the two planes) */    \
-    xout = (d0 + kd - 1 < 0 ? 1u : 0u) | (d0 + kd - 1 + BD - 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |      \
-           (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;            \
   } while (0)
   // The request is issued from inline asm: behind the builtin hipcc waits vmcnt(0) in front of the next ds_read (it cannot prove
   // that the read does not alias the DMA's LDS destination), which would expose every request's latency.  Completion is counted
@@ -286,6 +339,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     xbase[ci] = lrow * 128 + ((((col >> 4) ^ ((c + lrow) >> 1)) & 3) << 5) + ((col & 15) << 1);
   }
 
+  WB_T_DECL();
   if (b_beg < b_end) {
     WB_ORIGIN_NEXT();                                     // brick b_beg
 #pragma unroll
@@ -302,6 +356,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
     const bool more = b + 1 < b_end;                      // block-uniform
     WB_ORIGIN_NEXT();                                     // brick b + 1: its pieces are requested during this one
     __builtin_amdgcn_sched_barrier(0);
+    WB_T_BRICK();
 
     // 36 steps = 4 K-chunks x 9 taps, fully unrolled and SOFTWARE-PIPELINED: the x fragment of step s+1 (and the dy
     // fragments of the next K-chunk) are fetched two steps before the MFMAs that use them.  With one wave per SIMD nothing else hides
@@ -325,6 +380,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
       const int kc = st / 9, t = st % 9;
+      WB_SETPRIO(st, NSTEP);
       if (st < NPIECE) {   // piece st of brick b+1 -> the other LDS buffer
 #if WB_ABL != 1
         if (more) WB_DMA_PIECE(st < NPIECE ? st : 0, nxt);
@@ -343,6 +399,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #pragma unroll
       for (int f = 0; f < FA; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st % (PF + 1)], acc[t][f], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (st == NPIECE - 1) WB_T_ISSUED();
     }
 #undef WB_A
 #undef WB_XR
@@ -350,11 +407,15 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_kernel(const WBrickParams p
 #undef WB_B
 
     __builtin_amdgcn_sched_barrier(0);
+    WB_T_WAIT0();
 #if WB_ABL != 3
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WB_T_MID();
     __syncthreads();   // this brick's reads and the next brick's pieces are complete
 #endif
+    WB_T_WAIT1();
   }
+  WB_T_END();
 #undef WB_ORIGIN_NEXT
 #undef WB_DMA_PIECE
 
@@ -499,29 +560,44 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_upc2_kernel(const WBrick2Pa
     }
     on = t_;
   }
+  // carried byte offsets of the brick being loaded (see wgrad_brick_kernel): phase 0's first fine voxel in dy, the first halo voxel in x
+  const int64_t cob = 2 * (int64_t)p.Co, cvb = 2 * (int64_t)p.Cv;
+  const int64_t dsW = BW * p.dsw * cob, dsH = BH * p.dsh * cob, dsD = BD * p.dsd * cob;
+  const int64_t dwW = (int64_t)p.W * p.dsw * cob, dwH = (int64_t)p.H * p.dsh * cob, dwD = (int64_t)p.D * p.dsd * cob, dsN = p.dyn * cob;
+  const int64_t xsW = BW * p.sw * cvb, xsH = BH * p.sh * cvb, xsD = BD * p.sd * cvb;
+  const int64_t xwW = (int64_t)p.W * p.sw * cvb, xwH = (int64_t)p.H * p.sh * cvb, xwD = (int64_t)p.D * p.sd * cvb, xsN = (int64_t)p.D * p.H * p.W * cvb;
+  int64_t dyo = ((int64_t)on * p.dyn + (int64_t)od0 * p.dsd + (int64_t)oh0 * p.dsh + (int64_t)ow0 * p.dsw + p.phoff[uph0]) * cob + 2 * (int64_t)uco;
+  // first halo voxel (d0 + pbd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then
+  int64_t xo = ((int64_t)on * p.D * p.H * p.W + (int64_t)(od0 + pbd - 1) * p.sd + (int64_t)(oh0 - 1) * p.sh + (int64_t)(ow0 - 1) * p.sw) * cvb;
 #define W2_ORIGIN_NEXT()                                                                                     \
   do {                                                                                                       \
-    const int w0 = ow0, h0 = oh0, d0 = od0, n = on;                                                          \
-    if (ob + 1 < b_end) {                                                                                    \
+    const int w0 = ow0, h0 = oh0, d0 = od0;                                                                  \
+    dyb = reinterpret_cast<const char*>(p.dy) + dyo;                                                         \
+    xb = reinterpret_cast<const char*>(p.x) + xo;                                                            \
+    xout = (d0 + pbd - 1 < 0 ? 1u : 0u) | (d0 + pbd + 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |            \
+           (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;            \
+    if (WB_ABL != 4 && ob + 1 < b_end) {                                                                     \
       ++ob;                                                                                                  \
-      ow0 += BW;                                                                                             \
+      ow0 += BW; dyo += dsW; xo += xsW;                                                                      \
       if (ow0 == p.W) {                                                                                      \
-        ow0 = 0;                                                                                             \
+        ow0 = 0; dyo -= dwW; xo -= xwW;                                                                      \
         if (p.order) {                                                                                       \
-          od0 += BD;                                                                                         \
-          if (od0 == p.D) { od0 = 0; oh0 += BH; if (oh0 == p.H) { oh0 = 0; ++on; } }                         \
+          od0 += BD; dyo += dsD; xo += xsD;                                                                  \
+          if (od0 == p.D) {                                                                                  \
+            od0 = 0; dyo -= dwD; xo -= xwD;                                                                  \
+            oh0 += BH; dyo += dsH; xo += xsH;                                                                \
+            if (oh0 == p.H) { oh0 = 0; dyo -= dwH; xo -= xwH; ++on; dyo += dsN; xo += xsN; }                 \
+          }                                                                                                  \
         } else {                                                                                             \
-          oh0 += BH;                                                                                         \
-          if (oh0 == p.H) { oh0 = 0; od0 += BD; if (od0 == p.D) { od0 = 0; ++on; } }                         \
+          oh0 += BH; dyo += dsH; xo += xsH;                                                                  \
+          if (oh0 == p.H) {                                                                                  \
+            oh0 = 0; dyo -= dwH; xo -= xwH;                                                                  \
+            od0 += BD; dyo += dsD; xo += xsD;                                                                \
+            if (od0 == p.D) { od0 = 0; dyo -= dwD; xo -= xwD; ++on; dyo += dsN; xo += xsN; }                 \
+          }                                                                                                  \
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
-    const int64_t base0 = (int64_t)n * p.D * p.H * p.W + (int64_t)d0 * p.sd + h0 * p.sh + w0 * p.sw;          \
-    dyb = reinterpret_cast<const char*>(p.dy + ((int64_t)n * p.dyn + (int64_t)d0 * p.dsd + h0 * p.dsh + w0 * p.dsw + p.phoff[uph0]) * p.Co + uco); \
-    /* first halo voxel (d0 + pbd - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */ \
-    xb = reinterpret_cast<const char*>(p.x + (base0 + (int64_t)(pbd - 1) * p.sd - p.sh - p.sw) * p.Cv);      \
-    xout = (d0 + pbd - 1 < 0 ? 1u : 0u) | (d0 + pbd + 1 >= p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) |            \
-           (h0 + BH == p.H ? 8u : 0u) | (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;            \
   } while (0)
 #define W2_DMA_PIECE(i_, buf_)                                                                               \
   do {                                                                                                       \
@@ -549,6 +625,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_upc2_kernel(const WBrick2Pa
     xbase[ci] = lrow * 128 + ((((col >> 4) ^ ((c + lrow) >> 1)) & 3) << 5) + ((col & 15) << 1);
   }
 
+  WB_T_DECL();
   if (b_beg < b_end) {
     W2_ORIGIN_NEXT();
 #pragma unroll
@@ -564,6 +641,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_upc2_kernel(const WBrick2Pa
     const bool more = b + 1 < b_end;
     W2_ORIGIN_NEXT();
     __builtin_amdgcn_sched_barrier(0);
+    WB_T_BRICK();
     // K chunk kc = brick d plane kc >> 1, h half kc & 1 (32 voxels); tap t8 = (kd, kh, kw) offsets from the phase's origin
 #define W2_A(kc_, f_) tr_frag(dys + abase[f_] + (kc_)*4096, dys + abase[f_] + (kc_)*4096 + 512)
 #define W2_XR(kc_, t_) (((((kc_) >> 1) + ((t_) >> 2)) * XH + ((kc_)&1) * 4 + (((t_) >> 1) & 1)) * XW + ((t_)&1))
@@ -576,6 +654,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_upc2_kernel(const WBrick2Pa
 #pragma unroll
     for (int st = 0; st < NSTEP2; ++st) {
       const int kc = st / 8, t = st % 8;
+      WB_SETPRIO(st, NSTEP2);
       if (st < NPIECE2) {
         if (more) W2_DMA_PIECE(st < NPIECE2 ? st : 0, nxt);
       }
@@ -588,15 +667,20 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick_upc2_kernel(const WBrick2Pa
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc[t][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st & 1], acc[t][f], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (st == NPIECE2 - 1) WB_T_ISSUED();
     }
 #undef W2_A
 #undef W2_XR
 #undef W2_XADDR
 #undef W2_B
     __builtin_amdgcn_sched_barrier(0);
+    WB_T_WAIT0();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WB_T_MID();
     __syncthreads();
+    WB_T_WAIT1();
   }
+  WB_T_END();
 #undef W2_ORIGIN_NEXT
 #undef W2_DMA_PIECE
 
@@ -712,29 +796,35 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick27_kernel(const WBrick27Para
     }
     on = t_;
   }
+  // carried byte offsets of the brick being loaded (see wgrad_brick_kernel)
+  const int64_t cub = 2 * (int64_t)p.Cu, cvb = 2 * (int64_t)p.Cv;
+  const int64_t vsW = BW * p.sw, vsH = BH * p.sh, vsD = BD * p.sd, vwW = (int64_t)p.W * p.sw, vwH = (int64_t)p.H * p.sh, vwD = (int64_t)p.D * p.sd;
+  const int64_t vsN = (int64_t)p.D * p.H * p.W;
+  int64_t vo = (int64_t)on * p.D * p.H * p.W + (int64_t)od0 * p.sd + (int64_t)oh0 * p.sh + (int64_t)ow0 * p.sw;   // first voxel of the brick
+  const char* const dy0_ = reinterpret_cast<const char*>(p.dy + i0);
+  // first halo voxel (d0 - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then
+  const char* const x0_ = reinterpret_cast<const char*>(p.x) - ((int64_t)p.sd + p.sh + p.sw) * cvb;
 #define W27_ORIGIN_NEXT()                                                                                    \
   do {                                                                                                       \
-    const int w0 = ow0, h0 = oh0, d0 = od0, n = on;                                                          \
-    if (ob + 1 < b_end) {                                                                                    \
+    const int w0 = ow0, h0 = oh0, d0 = od0;                                                                  \
+    dyb = dy0_ + vo * cub;                                                                                   \
+    xb = x0_ + vo * cvb;                                                                                     \
+    xout = (d0 == 0 ? 1u : 0u) | (d0 + BD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + BH == p.H ? 8u : 0u) | \
+           (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;                                         \
+    if (WB_ABL != 4 && ob + 1 < b_end) {                                                                     \
       ++ob;                                                                                                  \
-      ow0 += BW;                                                                                             \
+      ow0 += BW; vo += vsW;                                                                                  \
       if (ow0 == p.W) {                                                                                      \
-        ow0 = 0;                                                                                             \
+        ow0 = 0; vo -= vwW;                                                                                  \
         if (p.order) {                                                                                       \
-          od0 += BD;                                                                                         \
-          if (od0 == p.D) { od0 = 0; oh0 += BH; if (oh0 == p.H) { oh0 = 0; ++on; } }                         \
+          od0 += BD; vo += vsD;                                                                              \
+          if (od0 == p.D) { od0 = 0; vo -= vwD; oh0 += BH; vo += vsH; if (oh0 == p.H) { oh0 = 0; vo -= vwH; ++on; vo += vsN; } } \
         } else {                                                                                             \
-          oh0 += BH;                                                                                         \
-          if (oh0 == p.H) { oh0 = 0; od0 += BD; if (od0 == p.D) { od0 = 0; ++on; } }                         \
+          oh0 += BH; vo += vsH;                                                                              \
+          if (oh0 == p.H) { oh0 = 0; vo -= vwH; od0 += BD; vo += vsD; if (od0 == p.D) { od0 = 0; vo -= vwD; ++on; vo += vsN; } } \
         }                                                                                                    \
       }                                                                                                      \
     }                                                                                                        \
-    const int64_t base0 = (int64_t)n * p.D * p.H * p.W + (int64_t)d0 * p.sd + h0 * p.sh + w0 * p.sw;          \
-    dyb = reinterpret_cast<const char*>(p.dy + base0 * p.Cu + i0);                                           \
-    /* first halo voxel (d0 - 1, h0 - 1, w0 - 1): may lie outside the volume, never dereferenced then */      \
-    xb = reinterpret_cast<const char*>(p.x + (base0 - (int64_t)p.sd - p.sh - p.sw) * p.Cv);                  \
-    xout = (d0 == 0 ? 1u : 0u) | (d0 + BD == p.D ? 2u : 0u) | (h0 == 0 ? 4u : 0u) | (h0 + BH == p.H ? 8u : 0u) | \
-           (w0 == 0 ? 16u : 0u) | (w0 + BW == p.W ? 32u : 0u) | 64u;                                         \
   } while (0)
 #define W27_DMA_PIECE(i_, buf_)                                                                              \
   do {                                                                                                       \
@@ -771,6 +861,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick27_kernel(const WBrick27Para
   // (group 3's seventh slot multiplies tap 26 once more into an accumulator that is never written: 4 of 112 MFMAs per K chunk of two of
   // the eight waves, cheaper than a branch around them -- a conditional MFMA cost 30 spilled registers)
 
+  WB_T_DECL();
   if (b_beg < b_end) {
     W27_ORIGIN_NEXT();
 #pragma unroll
@@ -791,6 +882,7 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick27_kernel(const WBrick27Para
     const bool more = b + 1 < b_end;
     W27_ORIGIN_NEXT();
     __builtin_amdgcn_sched_barrier(0);
+    WB_T_BRICK();
     bf16x8 fa[2][4], fbr[2];
 #pragma unroll
     for (int f = 0; f < 4; ++f) fa[0][f] = W27_A(0, f);
@@ -798,8 +890,11 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick27_kernel(const WBrick27Para
 #pragma unroll
     for (int st = 0; st < NSTEP27; ++st) {
       const int kc = st / 7, k = st % 7;
+      WB_SETPRIO(st, NSTEP27);
       if (st < NPIECE27) {
+#if WB_ABL != 1
         if (more) W27_DMA_PIECE(st < NPIECE27 ? st : 0, nxt);
+#endif
       }
       if (st + 1 < NSTEP27) fbr[(st + 1) & 1] = W27_B((st + 1) / 7, (st + 1) % 7);
       if (k == 3 && kc < 3) {
@@ -810,11 +905,18 @@ __global__ void __launch_bounds__(NT, 1) wgrad_brick27_kernel(const WBrick27Para
 #pragma unroll
       for (int f = 0; f < 4; ++f) acc[k][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kc & 1][f], fbr[st & 1], acc[k][f], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      if (st == NPIECE27 - 1) WB_T_ISSUED();
     }
     __builtin_amdgcn_sched_barrier(0);
+    WB_T_WAIT0();
+#if WB_ABL != 3
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WB_T_MID();
     __syncthreads();
+#endif
+    WB_T_WAIT1();
   }
+  WB_T_END();
 #undef W27_A
 #undef W27_B
 #undef W27_ORIGIN_NEXT
@@ -1077,3 +1179,14 @@ int pcrl_wgrad_brick2d_launch(const void* x, const void* dy, float* ws, int N, i
   launch_cfg<64, 64>(grid, stream, p);
   return pcrl_check_launch("wgrad_brick2d");
 }
+
+#if WB_TRACE
+// probe builds only (tools/wgrad_trace.py): the 32 accounting words, read and cleared
+extern "C" int pcrl_debug_wb_trace(unsigned long long* out32) {
+  unsigned long long z[32] = {0};
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_wb_trace), sizeof(z)) != hipSuccess) return -2;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_wb_trace), z, sizeof(z)) != hipSuccess) return -3;
+  return 0;
+}
+#endif

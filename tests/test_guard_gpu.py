@@ -206,7 +206,7 @@ def test_main_py_two_ranks_one_gpu_exits_clean(tmp_path, d):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29781 + d), WORLD_SIZE="2", PCRL_DIST_BACKEND="gloo", PCRL_BIND_CPUS="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.join(root, "main.py"), "--data", "synthetic", "--d", str(d), "--b", "4", "--epochs", "0", "--steps_per_epoch", "2",
+    cmd = [sys.executable, os.path.join(root, "main.py"), "--data", "synthetic", "--d", str(d), "--b", "4", "--epochs", "1", "--steps_per_epoch", "2",
            "--output", str(tmp_path), "--gpus", "0", "--amp"] + (["--size2d", "64"] if d == 2 else [])
     procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK="0"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=900)[0] for p in procs]
