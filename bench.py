@@ -15,7 +15,7 @@
              per-launch time inside the timed region is kept as roofline.in_timed_region (profiles/*_overlap_* is the three-stream trace).
              `value` is always the three-stream timed region.  With --no-alone the roofline is the timed region's.
   cpu_baseline : the CPU oracle (a port of the reference step, oracle/pcrlv2_oracle.py) timed on this box's host cores on
-             a bounded sample (b=8, <= 3 steps or ~35 s), rank 0, N=1 only.
+             a bounded sample (b=4, 2-3 timed steps, ~16-25 s), rank 0, N=1 only.
 
 Launch: python bench.py [--gpus 1 --steps K --warmup W]   or, for N>1,
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -118,7 +118,7 @@ def synthetic_batch(b, dhw, local, device, seed, nlocal=6):
     return to(x1), to(x2), to(gt), None, [to(t) for t in loc]
 
 
-def cpu_baseline(b=4, budget_s=15.0, threads=None):
+def cpu_baseline(b=4, budget_s=18.0, threads=None):
     """Time the oracle port of the reference step on the host cores (fp32, default oneDNN) on a BOUNDED sample, following
     BASELINE.md section 3: b = 4 full-size (64x64x32 + 6 x 16^3) crops, one warm-up step (at 32x32x16: it only pages the code in), then
     up to 3 timed steps or ~budget_s (15 s: VERDICT r4 -- it was 80 % of the driver's run at 35 s) of CPU work, whichever comes first (>= 1 step).
@@ -138,16 +138,21 @@ def cpu_baseline(b=4, budget_s=15.0, threads=None):
         pass
     st = O.fill_state(torch.float32)
     O.train_steps(st, [O.fill_batch(2, (32, 32, 16), local=16, dtype=torch.float32, seed=3)])   # warm-up
-    steps, t0 = 0, time.time()
+    per, t0 = [], time.time()
     while True:
-        O.train_steps(st, [O.fill_batch(b, (64, 64, 32), local=16, dtype=torch.float32, seed=7 + steps)])
-        steps += 1
+        t1 = time.time()
+        O.train_steps(st, [O.fill_batch(b, (64, 64, 32), local=16, dtype=torch.float32, seed=7 + len(per))])
+        per.append(time.time() - t1)
         dt = time.time() - t0
-        if dt + dt / steps > budget_s or steps >= 3:
+        # at least TWO timed steps (one step is a sample of one), then up to 3 or ~budget_s
+        if len(per) >= 2 and (dt + dt / len(per) > budget_s or len(per) >= 3):
             break
+    steps = len(per)
     return {"value": round(b * steps / dt, 4), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "n_timed_steps": steps, "s_per_step": [round(v, 2) for v in per], "value_best_step": round(b / min(per), 4),
             "sample": f"oracle port of train_3d.py:109-151 (oracle/pcrlv2_oracle.py), fp32 oneDNN, b={b}, 64x64x32 + 6x16^3, "
-                      f"{steps} timed step(s) in {dt:.1f} s on {torch.get_num_threads()} of {cores} host threads ({model_name})"}
+                      f"n = {steps} timed steps in {dt:.1f} s (value = mean rate, value_best_step = the fastest step's) on "
+                      f"{torch.get_num_threads()} of {cores} host threads ({model_name})"}
 
 
 
@@ -472,6 +477,16 @@ def _run(args):
                                                    "unit": "TFLOP/s", "frac": round(w4 / (ms4 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                                                    "avg_launch_ms": round(ms4 / n4, 4), "launches": n4, "ms_per_step": round(ms4 / 3, 3),
                                                    "measured": "HIP events over 3 one-stream steps", "traffic": None}
+                    try:        # HBM bytes per launch of the same kernel in the C4 step: profiles/LATEST_PMC_C4.txt names the committed PMC summary
+                        l4 = os.path.join(ROOT, "profiles", "LATEST_PMC_C4.txt")
+                        if os.path.exists(l4):
+                            n4f = open(l4).read().strip()
+                            j4 = json.load(open(os.path.join(ROOT, "profiles", n4f)))
+                            if d4 in j4:
+                                secondary["C4"]["roofline"]["traffic"] = round(j4[d4]["hbm_bytes_per_launch"])
+                                secondary["C4"]["roofline"]["traffic_source"] = "profiles/" + n4f
+                    except Exception:
+                        pass
                 finally:
                     L.profiler = None
                     _cfg.WGRAD_SIDE_STREAM_3D, _cfg.FWD_BRANCH_STREAM = True, _b4
@@ -595,6 +610,20 @@ def _run(args):
                                      "kernels": {k: {"ms_per_step": round(v[1] / nst, 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)} for k, v in sorted(mk.items())},
                                      "note": "all convolution / composed up-conv forward, data-gradient and weight-gradient launches (with their second passes) of the "
                                              "one-stream steps: executed FLOPs / summed HIP-event time / dense bf16 peak"}
+        # the FAMILY next to the dominant instantiation: every brick16_conv_kernel* row -- plain, <dgrad+bn_reduce>, the composed
+        # <upconv_fwd> / <upconv_dgrad> -- so that a re-keying of the instantiations cannot move the headline fraction
+        fam = {k: v for k, v in mk.items() if k.startswith("brick16_conv_kernel")}
+        if fam:
+            f_ms, f_work = sum(v[1] for v in fam.values()), sum(v[2] for v in fam.values())
+            rf["family"] = {"kernels": sorted(fam), "achieved": round(f_work / (f_ms * 1e-3) / 1e12, 1), "frac": round(f_work / (f_ms * 1e-3) / 1e12 / rf["peak"], 4),
+                            "ms_per_step": round(f_ms / min(10, args.steps), 3), "launches_per_step": round(sum(v[0] for v in fam.values()) / min(10, args.steps), 1),
+                            "note": "all instantiations of the wide-brick convolution kernel in the one-stream steps: executed FLOPs / summed HIP-event time / peak"}
+            plain = {k: v for k, v in fam.items() if "upconv" not in k}
+            if plain:
+                p_ms, p_work = sum(v[1] for v in plain.values()), sum(v[2] for v in plain.values())
+                rf["family"]["frac_3x3x3_only"] = round(p_work / (p_ms * 1e-3) / 1e12 / rf["peak"], 4)
+        rf["power_note"] = ("the matrix kernels run at the board's 1 400 W cap (rocm-smi 1 390-1 397 W, shader clock 1.90-1.94 GHz of 2.4 nominal while they loop: "
+                            "profiles/r06_wgrad_trace.txt section 11); `peak` is the nominal-clock figure")
         rf.update({"achieved": round(a1, 1), "frac": round(a1 / rf["peak"], 4), "avg_launch_ms": round(ms1_ / n1, 4), "launches": n1,
                    "measured": "HIP events over %d one-stream steps run right after the timed region (same process, model and batch; "
                                "PCRL_WGRAD_STREAM=0 PCRL_BRANCH_STREAM=0 PCRL_VIEW_STREAMS=0 semantics)" % min(10, args.steps)})

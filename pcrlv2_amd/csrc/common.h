@@ -83,8 +83,7 @@ template <bool NT, typename T> __device__ __forceinline__ void st16_sel(T* p, co
   else st16(p, v);
 }
 inline bool pcrl_streaming(int64_t bytes) {
-  static const int64_t min_mb = [] { const char* e = getenv("PCRL_NT_MIN_MB"); return e ? (int64_t)atoll(e) : (int64_t)192; }();
-  return bytes >= (min_mb << 20);
+  return bytes >= ((int64_t)192 << 20);   // non-temporal accesses from 192 MB per tensor on (tools/bn_probe.py, round 3)
 }
 
 // ---- wave / block reductions (wave = 64) ------------------------------------------------

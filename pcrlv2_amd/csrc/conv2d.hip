@@ -339,10 +339,9 @@ int ilog2_exact(int v) {
 template <typename T, int MODE> int launch_bn(const C2Params& p, int NcP, hipStream_t stream) {
   using TL = Tile<T>;
   const unsigned gx = (unsigned)((p.M + PCRL_CONV_BM - 1) / PCRL_CONV_BM);
-  static const int bnmax = [] { const char* e = getenv("PCRL_GATHER_BN"); return e ? atoi(e) : 128; }();   // A/B switch: 64 = never the 128-column tile
   // 128-column tiles (two waves per SIMD) unless the grid they give is small: below 512 blocks the 64-column tile (four waves per SIMD, twice the
   // blocks) is faster -- measured on the local views' 12^2 / 6^2 / 3^2 maps (49 -> 45, 52 -> 48, 86 -> 69 us), slower on the large grids (90 -> 105 us)
-  if (NcP % 128 == 0 && bnmax >= 128 && (int64_t)gx * (NcP / 128) >= 512) {
+  if (NcP % 128 == 0 && (int64_t)gx * (NcP / 128) >= 512) {
     hipLaunchKernelGGL((conv2d_kernel<T, 128, MODE>), dim3(gx, NcP / 128), dim3(256), 2 * (size_t)(PCRL_CONV_BM + 128) * TL::ROWB, stream, p);
   } else if (NcP % 64 == 0) {
     hipLaunchKernelGGL((conv2d_kernel<T, 64, MODE>), dim3(gx, NcP / 64), dim3(256), 2 * (size_t)(PCRL_CONV_BM + 64) * TL::ROWB, stream, p);
@@ -427,11 +426,8 @@ extern "C" int64_t pcrl_conv2d_stats_rows(int N, int Ho, int Wo) { return ((int6
 
 // which kernel the forward dispatcher picks: 0 gather, 1 LDS-halo brick (4 x 8 x 8), 2 right-sized narrow kernel, 3 wide brick (4 x 8 x 16, LDS-DMA)
 // The 32 -> 32 channel layers (decoder block 3 at 256^2) go to the right-sized narrow kernel rather than the brick kernel: 204-219 -> 168 us per
-// launch on the same box once the narrow kernel runs two waves per SIMD (PCRL_OCC2).  PCRL_NARROW_FIRST=0: brick kernel first (A/B switch).
-static bool narrow_first(int Cs, int Nc) {
-  static const bool on = [] { const char* e = getenv("PCRL_NARROW_FIRST"); return !(e && e[0] == '0'); }();
-  return on && Cs <= 32 && Nc <= 32;
-}
+// launch on the same box once the narrow kernel runs two waves per SIMD (PCRL_OCC2).
+static bool narrow_first(int Cs, int Nc) { return Cs <= 32 && Nc <= 32; }
 static int conv2d_fwd_kind(int N, int Ho, int Wo, int CiP, int Co, int KH, int KW, int stride, int pad, int out_f32, int dtype, int up) {
   if (auto_impl() && narrow_first(CiP, Co) && KH == KW && (KH == 1 || KH == 3) && stride == 1 && pad == (KH - 1) / 2 && pcrl_conv2d_narrow_eligible(N, Ho, Wo, CiP, Co, KH, dtype))
     return 2;

@@ -655,8 +655,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) brick16_conv_kernel(
 // 0: no brick tiling; 1: (4, 8, 16) bricks along (D, H, W); 2: along (D, W, H) (PERM instantiations)
 inline int brick16_perm(int D, int H, int W) {
   if (D % TD == 0 && H % TH == 0 && W % TW == 0) return 1;
-  static const bool perm_on = [] { const char* e = getenv("PCRL_B16_PERM"); return !(e && e[0] == '0'); }();   // A/B switch
-  if (perm_on && D % TD == 0 && W % TH == 0 && H % TW == 0) return 2;
+  if (D % TD == 0 && W % TH == 0 && H % TW == 0) return 2;
   return 0;
 }
 

@@ -3,7 +3,7 @@
 
 namespace {
 std::atomic<int> g_brick16_on{1};
-std::atomic<int> g_brick16_planes{-1};   // -1: PCRL_B16_NW8 / the default rule; 0: 4-plane bricks only; 2: 8-plane bricks wherever they tile
+std::atomic<int> g_brick16_planes{-1};   // -1: the default rule (4-plane bricks); 0: 4-plane bricks only; 2: 8-plane bricks wherever they tile
 }  // namespace
 
 // ---- internal interface used by conv_igemm.hip's dispatcher -------------------------------------------------------
@@ -23,12 +23,12 @@ int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, v
   // 8 x 8 x 16 bricks (one eight-wave block per CU) where there are two or more 64-channel tiles per brick, D % 8 == 0 and the grid still gives
   // every CU a block.  Measured per layer (tools/conv_probe.py, same box): 512->256 at 16x16x8 1445 -> 1544 TFLOP/s, 256->256 1433 -> 1495,
   // 256->128 at 32x32x16 1320 -> 1383, 128->128 1365 -> 1403; the 64-output-channel layers (one tile per brick) do not gain (128->64 at
-  // 64x64x32: 1330 -> 1300) and small grids lose (128->128 at 16x16x8, 64 blocks: 1105 -> 805).  PCRL_B16_NW8=0: off; =2: every eligible shape.
+  // 64x64x32: 1330 -> 1300) and small grids lose (128->128 at 16x16x8, 64 blocks: 1105 -> 805).
   // Round 5: with the halo plan (conv_brick16.h) the 4-plane form is as fast or faster on EVERY layer (same box, tools/conv_probe.py: 64->128 at 32x32x16
   // 1 363 vs 1 225 TFLOP/s, 256->128 1 537 vs 1 480, 128->128 1 492 vs 1 435, the 16x16x8 decoder layers within 1 %; one pass over the model's layers 4.28 vs
-  // 4.35 ms) -- what the 8-plane brick saved was halo REQUEST ISSUE, which the plan made cheap.  Default off now; PCRL_B16_NW8=1: the round-4 rule, =2: everywhere.
-  static const int nw8_env = [] { const char* e = getenv("PCRL_B16_NW8"); return e ? atoi(e) : 0; }();
-  const int nw8_mode = g_brick16_planes >= 0 ? (int)g_brick16_planes : nw8_env;   // test hook (pcrl_debug_set_conv_impl 5 / 6) over the environment
+  // 4.35 ms) -- what the 8-plane brick saved was halo REQUEST ISSUE, which the plan made cheap.  Off; the instantiation stays behind the test hook
+  // (pcrl_debug_set_conv_impl 5: the round-4 rule, 6: every eligible shape), bit-identical to the 4-plane form.
+  const int nw8_mode = g_brick16_planes >= 0 ? (int)g_brick16_planes : 0;
   int64_t bricks = pcrl_brick16_conv_rows(N, D, H, W);
   const bool nw8 = nw8_mode > 0 && BN == 64 && D % 8 == 0 && (nw8_mode == 2 || (ny >= 2 && (bricks / 2) * ny >= 256));
   if (nw8) bricks /= 2;
@@ -46,8 +46,7 @@ int pcrl_brick16_conv_launch(const void* x, const void* wp, const float* bias, v
 // ---- 2D path (MODE 3): 3x3 / stride 1 / pad 1 convolution of [N][H][W][Ci] images, forward or data gradient (conv2d.hip's dispatcher) ----
 // The image index is the brick's d axis (4 images per brick); wp: packed [Co][9][Ci] (pcrl_conv2d_pack); stats [bricks][Co][2] or null.
 bool pcrl_brick16_conv2d_eligible(int N, int H, int W, int Ci, int Co, int dtype) {
-  static const bool on = [] { const char* e = getenv("PCRL_B16_2D"); return !(e && e[0] == '0'); }();     // A/B switch: 0 = the 4 x 8 x 8-brick kernel (round 4)
-  return on && g_brick16_on && dtype == PCRL_BF16 && N % TD == 0 && brick16_perm(N, H, W) != 0 && Ci % 32 == 0 && Co % 32 == 0 &&
+  return g_brick16_on && dtype == PCRL_BF16 && N % TD == 0 && brick16_perm(N, H, W) != 0 && Ci % 32 == 0 && Co % 32 == 0 &&
          (int64_t)N * H * W < ((int64_t)1 << 29) && (int64_t)20 * Ci * H * W < ((int64_t)1 << 31) && (int64_t)18 * Ci * Co < ((int64_t)1 << 32);
 }
 int64_t pcrl_brick16_conv2d_rows(int N, int H, int W) { return (int64_t)N * H * W / (TD * TH * TW); }

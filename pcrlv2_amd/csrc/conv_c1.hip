@@ -467,9 +467,8 @@ extern "C" int pcrl_conv3d_k3_c1_fwd(const float* x, const float* w_ref, const f
     const int64_t nb64 = pcrl_conv3d_k3_c1_stats_rows(N, D, H, W, Co, dtype);
     PCRL_REQUIRE(nb64 < ((int64_t)1 << 31), "conv3d_k3_c1_fwd: too many bricks");
     const int nbr = (int)nb64;
-    // persistent blocks: four per CU for the narrow forms (128 registers: the prefetch does not fit the 80 of six blocks per CU), two otherwise.  PCRL_C1_PERSIST=0: one brick per block (A/B switch)
-    static const bool persist = [] { const char* e = getenv("PCRL_C1_PERSIST"); return !(e && e[0] == '0'); }();
-    const int cap = persist ? 256 * (Co <= 32 ? 4 : 2) : nbr;
+    // persistent blocks: four per CU for the narrow forms (128 registers: the prefetch does not fit the 80 of six blocks per CU), two otherwise
+    const int cap = 256 * (Co <= 32 ? 4 : 2);
     const unsigned bricks = (unsigned)(nbr < cap ? nbr : cap);
     if (Co == 16) hipLaunchKernelGGL(c1_brick_fwd_kernel<16>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g, nbr);
     else if (Co == 32) hipLaunchKernelGGL(c1_brick_fwd_kernel<32>, dim3(bricks), dim3(256), 0, as_stream(stream), x, w_ref, bias, (bf16*)y, stats_partial, g, nbr);

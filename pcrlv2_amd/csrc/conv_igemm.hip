@@ -443,8 +443,7 @@ int launch_igemm(const IgemmParams& p, int zdim, hipStream_t stream) {
 }
 
 template <typename T, int GEOM> int dispatch_bn(const IgemmParams& p, int zdim, hipStream_t stream) {
-  static const int bnmax = [] { const char* e = getenv("PCRL_GATHER_BN"); return e ? atoi(e) : 128; }();   // A/B switch: 64 = never the 128-column tile
-  if (p.Nc % 128 == 0 && bnmax >= 128) return launch_igemm<T, 128, GEOM>(p, zdim, stream);
+  if (p.Nc % 128 == 0) return launch_igemm<T, 128, GEOM>(p, zdim, stream);
   if (p.Nc % 64 == 0) return launch_igemm<T, 64, GEOM>(p, zdim, stream);
   return launch_igemm<T, 32, GEOM>(p, zdim, stream);
 }
@@ -710,26 +709,19 @@ int pcrl_upc_fwd_launch(const void* x, const void* wf, const float* bias_tab, vo
 }
 bool pcrl_brick16_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_brick16.hip
 bool pcrl_brick8_upc_fwd_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);    // conv_brick.hip
-// PCRL_UPC_BRICK8=0: the coarse grids only the 4 x 8 x 8 brick tiles (8 x 8 x 4 of up_tr256, 8^3 of the local views' up_tr64) stay on the gather kernel (A/B switch)
-static bool upc_brick8_on() {
-  static const bool on = [] { const char* e = getenv("PCRL_UPC_BRICK8"); return !(e && e[0] == '0'); }();
-  return on;
-}
 // 0: gather kernel; 1: wide-brick kernel (conv_brick16.hip); 2: 4 x 8 x 8-brick kernel (conv_brick.hip)
 int pcrl_upc_fwd_impl(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  static const bool gather_only = [] { const char* e = getenv("PCRL_UPC_FWD_GATHER"); return e && e[0] == '1'; }();   // A/B switch
-  if (g_conv_impl != 0 || gather_only) return 0;
+  if (g_conv_impl != 0) return 0;
   if (pcrl_brick16_upc_fwd_eligible(N, D, H, W, Ci, Co, dtype)) return 1;
-  return upc_brick8_on() && pcrl_brick8_upc_fwd_eligible(N, D, H, W, Ci, Co, dtype) ? 2 : 0;
+  return pcrl_brick8_upc_fwd_eligible(N, D, H, W, Ci, Co, dtype) ? 2 : 0;
 }
 bool pcrl_upc_fwd_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) { return pcrl_upc_fwd_impl(N, D, H, W, Ci, Co, dtype) != 0; }
 bool pcrl_brick16_upc_dgrad_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);   // conv_brick16.hip
 bool pcrl_brick8_upc_dgrad_eligible(int N, int D, int H, int W, int Ci, int Co, int dtype);    // conv_brick.hip
 int pcrl_upc_dgrad_impl(int N, int D, int H, int W, int Ci, int Co, int dtype) {
-  static const bool gather_only = [] { const char* e = getenv("PCRL_UPC_DGRAD_GATHER"); return e && e[0] == '1'; }();   // A/B switch
-  if (g_conv_impl != 0 || gather_only) return 0;
+  if (g_conv_impl != 0) return 0;
   if (pcrl_brick16_upc_dgrad_eligible(N, D, H, W, Ci, Co, dtype)) return 1;
-  return upc_brick8_on() && pcrl_brick8_upc_dgrad_eligible(N, D, H, W, Ci, Co, dtype) ? 2 : 0;
+  return pcrl_brick8_upc_dgrad_eligible(N, D, H, W, Ci, Co, dtype) ? 2 : 0;
 }
 bool pcrl_upc_dgrad_uses_brick(int N, int D, int H, int W, int Ci, int Co, int dtype) { return pcrl_upc_dgrad_impl(N, D, H, W, Ci, Co, dtype) != 0; }
 // Split-K plan of the composed data gradient on the gather kernel: K = 64 taps x Co / 32 chunks (512 steps at up_tr256) over row tiles that
@@ -739,8 +731,7 @@ static SplitPlan upc_dgrad_plan(int64_t M, int Ci, int Co) {
   const int bn = Ci % 128 == 0 ? 128 : (Ci % 64 == 0 ? 64 : 32);
   const int64_t blocks = ((M + PCRL_CONV_BM - 1) / PCRL_CONV_BM) * (Ci / bn);
   const int steps = 64 * (Co / 32);
-  static const bool off = [] { const char* e = getenv("PCRL_UPC_DGRAD_SPLITK"); return e && e[0] == '0'; }();   // A/B switch
-  if (off || blocks >= 512) return SplitPlan{1, steps};
+  if (blocks >= 512) return SplitPlan{1, steps};
   int splits = (int)((1024 + blocks - 1) / blocks);
   if (splits > 16) splits = 16;
   if (splits > steps / 16) splits = steps / 16;   // at least 16 K-steps per split

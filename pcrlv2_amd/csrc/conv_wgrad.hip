@@ -1496,10 +1496,8 @@ static SplitPlan plan_splits2d(int64_t M, int Cu, int Cv, int ks) {
   return SplitPlan{(int)splits, per * ks};
 }
 // one-kernel-row-per-block form (wgrad2d_row3_kernel): K-steps of 64 pixels, whole rounds of ~1024 blocks, at least 8 steps per block.
-// PCRL_WGRAD2D_ROW3=0: the flattened-tap gather kernel instead (A/B switch)
 static bool wgrad2d_row3_ok(int CiP, int CoP, int KH, int KW, int dtype) {
-  static const bool on = [] { const char* e = getenv("PCRL_WGRAD2D_ROW3"); return !(e && e[0] == '0'); }();
-  return on && dtype == PCRL_BF16 && KH == 3 && KW == 3 && CiP >= 32 && CoP >= 32;
+  return dtype == PCRL_BF16 && KH == 3 && KW == 3 && CiP >= 32 && CoP >= 32;
 }
 static SplitPlan plan_row3(int64_t M, int CoP, int CiP) {
   const int64_t tiles = (int64_t)((CoP + 63) / 64) * ((CiP + 63) / 64) * 3;

@@ -801,8 +801,7 @@ extern "C" int pcrl_upsample_trilinear_bwd(const float* dy, float* dx, int N, in
   PCRL_REQUIRE(dy && dx && scale >= 1 && scale <= 4, "upsample_trilinear_bwd: scale must be 1..4 (got %d)", scale);
   const int64_t total = (int64_t)N * D * H * W;
   const size_t lds = ((size_t)H * scale * W * scale + (size_t)H * W * scale) * sizeof(float);
-  static const bool planes_on = [] { const char* e = getenv("PCRL_TRI_BWD_PLANES"); return !(e && e[0] == '0'); }();   // A/B switch
-  if (planes_on && scale > 1 && lds <= 60 * 1024 && (int64_t)N * D < ((int64_t)1 << 30)) {
+  if (scale > 1 && lds <= 60 * 1024 && (int64_t)N * D < ((int64_t)1 << 30)) {
     hipLaunchKernelGGL(tri_bwd_planes_kernel, dim3((unsigned)(N * D)), dim3(256), lds, as_stream(stream), dy, dx, Dims{N, D, H, W}, scale);
     return pcrl_check_launch("tri_bwd (planes)");
   }

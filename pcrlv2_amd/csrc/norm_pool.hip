@@ -196,7 +196,7 @@ template <typename T, int ACT, bool NT>
 __device__ __forceinline__ void bn_bwd_apply_rc_kernel_body(const T* __restrict__ da, const T* __restrict__ y, T* __restrict__ dy,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ k1, const float* __restrict__ kB,
-                                                              const float* __restrict__ kA, int64_t M, int C, RowAdd ra, bool rev) {
+                                                              const float* __restrict__ kA, int64_t M, int C, RowAdd ra) {
   constexpr int VEC = 16 / (int)sizeof(T);
   const int nvec = C / VEC, cv = threadIdx.x % nvec, slot = threadIdx.x / nvec, nslots = 256 / nvec;
   float sc[VEC], sh[VEC], c1[VEC], cB[VEC], cA[VEC], add[VEC];
@@ -214,22 +214,14 @@ __device__ __forceinline__ void bn_bwd_apply_rc_kernel_body(const T* __restrict_
   if (ra.g) { n = r0 / ra.S; rem = r0 % ra.S; }
 #pragma unroll 4
   for (int64_t r = r0; r < M; r += stride) {
-    // rev: the rows are walked from the END of the tensor -- the pass that ran just before this one (bn_bwd_reduce) read da and y front to
-    // back, so their tails are what the Infinity Cache still holds
-    const int64_t rr = rev ? M - 1 - r : r;
-    const int64_t off = (rr * nvec + cv) * VEC;
+    // (walking the rows from the END of the tensor, where the reduce pass that ran just before left the Infinity Cache, was measured in round 4:
+    // 464.8 -> 460.5 us per pair at 537 MB -- these passes run at the fabric's rate, cache residency does not help; removed in round 6)
+    const int64_t off = (r * nvec + cv) * VEC;
     Vec16<T> g, g2;
     if (da) g = ld16_sel<NT>(da + off);
     if (ra.da2) g2 = ld16_sel<NT>(reinterpret_cast<const T*>(ra.da2) + off);
     const Vec16<T> v = ld16_sel<NT>(y + off);
-    if (ra.g && rev) {
-      n = rr / ra.S;
-      if (n != n_have) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) add[j] = ra.g[n * C + cv * VEC + j] * ra.inv_s;
-        n_have = n;
-      }
-    } else if (ra.g) {
+    if (ra.g) {
       if (n != n_have) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) add[j] = ra.g[n * C + cv * VEC + j] * ra.inv_s;
@@ -255,8 +247,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_rc_kernel(const T* __restric
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               const float* __restrict__ k1, const float* __restrict__ kB,
                                                               const float* __restrict__ kA, int64_t M, int C, int nt, RowAdd ra) {
-  if (nt & 1) bn_bwd_apply_rc_kernel_body<T, ACT, true>(da, y, dy, scale, shift, k1, kB, kA, M, C, ra, (nt & 2) != 0);
-  else bn_bwd_apply_rc_kernel_body<T, ACT, false>(da, y, dy, scale, shift, k1, kB, kA, M, C, ra, (nt & 2) != 0);
+  if (nt & 1) bn_bwd_apply_rc_kernel_body<T, ACT, true>(da, y, dy, scale, shift, k1, kB, kA, M, C, ra);
+  else bn_bwd_apply_rc_kernel_body<T, ACT, false>(da, y, dy, scale, shift, k1, kB, kA, M, C, ra);
 }
 
 #ifndef BN_RED_U
@@ -900,11 +892,6 @@ extern "C" int pcrl_bn_bwd_finalize(const float* partial, int rows, int C, doubl
   return pcrl_check_launch("bn_bwd_finalize");
 }
 
-// bit 1 of the kernels' mode word: walk the rows back to front (PCRL_BN_REV=1)
-static int bn_rev_mode() {
-  static const int m = [] { const char* e = getenv("PCRL_BN_REV"); return (e && e[0] == '1') ? 2 : 0; }();
-  return m;
-}
 static int bn_bwd_apply_impl(const void* da, const void* y, void* dy, const float* scale, const float* shift,
                              const float* k1, const float* kB, const float* kA,
                              int64_t M, int C, int act, int dtype, RowAdd ra, pcrl_stream_t stream) {
@@ -919,11 +906,11 @@ static int bn_bwd_apply_impl(const void* da, const void* y, void* dy, const floa
   const dim3 grid_rc(rc_grid(M, C / (C % vec == 0 ? vec : 1)));
   if (dtype == PCRL_BF16) {
     using T = bf16;
-    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, (int)pcrl_streaming(M * C * (int64_t)sizeof(T)) | bn_rev_mode(), ra);
+    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, (int)pcrl_streaming(M * C * (int64_t)sizeof(T)), ra);
     else DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
   } else {
     using T = float;
-    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, (int)pcrl_streaming(M * C * (int64_t)sizeof(T)) | bn_rev_mode(), ra);
+    if (rc) DISPATCH_ACT_T(bn_bwd_apply_rc_kernel, grid_rc, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, M, C, (int)pcrl_streaming(M * C * (int64_t)sizeof(T)), ra);
     else DISPATCH_ACT_T(bn_bwd_apply_kernel, grid, 0, (const T*)da, (const T*)y, (T*)dy, scale, shift, k1, kB, kA, nvec, C);
   }
   return pcrl_check_launch("bn_act_bwd_apply");

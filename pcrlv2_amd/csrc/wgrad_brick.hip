@@ -1034,14 +1034,13 @@ bool pcrl_wgrad_brick_eligible(int N, int D, int H, int W, int Ci, int Co, int d
   return dtype == PCRL_BF16 && (wb_natural(D, H, W) || wb_permuted(D, H, W)) && Co % 64 == 0 && Ci % 32 == 0 &&
          (int64_t)N * D * H * W / BV < (1 << 30) && (int64_t)N * D * H * W * (Ci > Co ? Ci : Co) < ((int64_t)1 << 31);
 }
-// 27-taps-per-block kernel (wgrad_brick27_kernel): layers with 64 output channels and 32 or 64 input channels.  PCRL_WGRAD27=0: off (A/B switch).
+// 27-taps-per-block kernel (wgrad_brick27_kernel): layers with 64 output channels and 32 or 64 input channels.
 // Measured (same box, isolated, b = 32): 32 -> 64 at 64x64x32  752 -> 965 TFLOP/s (0.617 -> 0.480 ms: the 64 x 32 tile of the one-plane kernel
 // staged a half-empty x image for 9 taps); 64 -> 64 at 64x64x32  1 162 -> 1 198; 64 -> 64 at 32x32x16 (4 096 bricks)  895 -> 851: with Ci = 64
 // the one-plane kernel is no longer bound by its staging (both forms sit at ~0.8 transpose reads per MFMA), and on small volumes the
 // larger tile count of the one-plane form fills the chip better -- so: Ci = 32 always, Ci = 64 from 8 192 bricks on.
 static bool wb27_on(int Ci, int Co, int nbricks) {
-  static const bool off = [] { const char* e = getenv("PCRL_WGRAD27"); return e && e[0] == '0'; }();
-  return !off && g_wb_tiles && Co == 64 && (Ci == 32 || (Ci == 64 && nbricks >= 8192));
+  return g_wb_tiles && Co == 64 && (Ci == 32 || (Ci == 64 && nbricks >= 8192));
 }
 static void wb27_plan(int nbricks, int Ci, int Co, int& splits, int& per) {
   const int ntile = (Co / 64) * (Ci / 32);

@@ -289,15 +289,18 @@ LOADER_TIMING = os.environ.get("PCRL_LOADER_TIMING", "0") == "1"
 
 def worker_affinity_init(worker_id: int):
     """DataLoader worker_init_fn: a worker forked from a rank whose launcher thread ddp.bind_rank_to_numa pinned inherits that narrow mask; the
-    binding left the CPUs meant for the workers in $PCRL_WORKER_CPUS -- move there (worker i prefers CPU i of the list when there is one per
-    worker, otherwise all of them share the list).  No variable, or a refusal: nothing happens."""
+    binding left the CPUs meant for the workers in $PCRL_WORKER_CPUS -- move there.  One CPU per worker ONLY where the rank's share was really
+    split into launcher CPUs and worker CPUs ($PCRL_WORKER_CPUS_SPLIT=1, set by the binding) and there is a CPU per worker; an unsplit share
+    (ddp.split_share returned the same list twice: too few CPUs) is the launcher's own CPUs -- the workers float over all of it, as they did
+    before the split existed, instead of being hard-pinned onto the launcher thread's cores.  No variable, or a refusal: nothing happens."""
     cpus = [int(c) for c in os.environ.get("PCRL_WORKER_CPUS", "").split(",") if c.strip().isdigit()]
     if not cpus or not hasattr(os, "sched_setaffinity"):
         return
+    split = os.environ.get("PCRL_WORKER_CPUS_SPLIT", "0") == "1"
     try:
         info = torch.utils.data.get_worker_info()
         n = info.num_workers if info is not None else 0
-        os.sched_setaffinity(0, [cpus[worker_id % len(cpus)]] if 0 < n <= len(cpus) else cpus)
+        os.sched_setaffinity(0, [cpus[worker_id % len(cpus)]] if split and 0 < n <= len(cpus) else cpus)
     except OSError:
         pass
 
@@ -387,7 +390,17 @@ class AugmentedLoader:
         return slot[0][:B], slot[1][:B], slot
 
     def close(self):
-        """Release the page-lock on the shared batch slots (hipHostUnregister); the loader is unusable afterwards."""
+        """Release the page-lock on the shared batch slots (hipHostUnregister); the loader is unusable afterwards.  Host-to-device copies out of a
+        slot may still be in flight (a consumer that broke out of the epoch; garbage collection): the loader's stream is drained first, and the
+        DataLoader -- whose persistent workers still write into the slots -- is dropped before the buffers lose their page-lock."""
+        if getattr(self, "_stream", None) is not None:
+            try:
+                self._stream.synchronize()
+            except Exception:
+                pass
+        self._events = []
+        if self.slots is not None:
+            self.loader = None          # the iterator and its persistent workers go first
         if self.slots is not None and self.slots[2]:
             for t in self.slots[:2]:
                 try:

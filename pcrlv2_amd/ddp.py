@@ -166,6 +166,7 @@ def bind_rank_to_numa(local_rank: int, local_world: int, verbose: bool = False, 
         os.sched_setaffinity(0, launcher)
         WORKER_CPUS = list(wcpus)
         os.environ["PCRL_WORKER_CPUS"] = ",".join(str(c) for c in wcpus)
+        os.environ["PCRL_WORKER_CPUS_SPLIT"] = "1" if list(wcpus) != list(launcher) else "0"   # unsplit share: the workers share it, unpinned
         torch.set_num_threads(max(1, min(8, len(launcher))))
         if verbose or (dist.is_available() and dist.is_initialized() and dist.get_rank() == 0):
             import sys

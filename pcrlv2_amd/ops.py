@@ -329,11 +329,27 @@ def empty_cache(device=None):
     by_stream = collections.defaultdict(list)
     for seg in torch.cuda.memory_snapshot():
         if seg["device"] == idx and seg["address"] in mine and seg["stream"] in streams:
+            # A request lands in the pool its SIZE selects (torch's caching allocator: <= 1 MiB -> the small pool of 2 MiB segments, above -> the large
+            # pool), whatever segment the hole it was sized from belongs to.  So a placeholder can only pin a hole of its own pool (filtering
+            # by block size alone let a >= 1 MiB hole of a small-pool segment ask the LARGE pool for a block -- taking one meant for another
+            # placeholder or opening a fresh 20 MiB segment, and the "segments were released" warning fired in normal runs):
+            #   large-pool segment: holes above 1 MiB (smaller holes cannot be held: a request of that size is a small-pool request)
+            #   small-pool segment: holes of at most 1 MiB, held by a request of that size; a larger hole (a 2 MiB segment that is mostly free) by
+            #                       1 MiB requests -- best fit places them in it
+            large = seg.get("segment_type", "large") == "large"
             for blk in seg["blocks"]:
-                # placeholders only for blocks of 1 MiB and more: a smaller request is served from the allocator's SMALL pool -- it cannot occupy a
-                # sub-MiB hole inside a provisioned large-pool segment and would open fresh 2 MiB segments that then stay cached
-                if blk["state"] == "inactive" and blk["size"] >= (1 << 20):
+                if blk["state"] != "inactive":
+                    continue
+                if large and blk["size"] > (1 << 20):
                     by_stream[seg["stream"]].append(blk["size"])
+                elif not large and blk["size"] >= 512:
+                    n_, left_ = blk["size"], []
+                    while n_ > (1 << 20):
+                        left_.append(1 << 20)
+                        n_ -= 1 << 20
+                    if n_ >= 512:
+                        left_.append(n_)
+                    by_stream[seg["stream"]].extend(left_)
     for sid, sizes in by_stream.items():
         with torch.cuda.stream(streams[sid]):
             for n in sorted(sizes, reverse=True):      # largest first: best fit then takes exactly the block the request was sized from
@@ -1266,7 +1282,7 @@ def linear_forward(x, w, b):
     return y
 
 
-FUSED_HEAD_BWD = os.environ.get("PCRL_FUSED_HEAD_BWD", "1") != "0"     # A/B switch: 0 = nine launches (Linear backward x 2, BatchNorm1d backward x 2, add)
+FUSED_HEAD_BWD = True     # A/B switch: 0 = nine launches (Linear backward x 2, BatchNorm1d backward x 2, add)
 
 
 def heads_backward(d_pro, d_pre, heads, x_pro, params):
@@ -1274,7 +1290,7 @@ def heads_backward(d_pro, d_pre, heads, x_pro, params):
     the pooled vector.  heads = (pooled g, mean / rstd of bn, h0, h1, mean / rstd of predictor_head[1]); params = (bn.weight, bn.bias, ph0.weight,
     ph0.bias, ph1.weight, ph1.bias, ph3.weight, ph3.bias).  -> (d_g float32 [N, C], [their 8 gradients]).
     Two launches (pcrl_head_bwd_stage: Linear backward + the BatchNorm1d backward of what it produced, csrc/heads_fused.hip) where the rows fit
-    (N <= 512); else -- or with PCRL_FUSED_HEAD_BWD=0 -- the separate kernels."""
+    (N <= 512); else -- or with ops.FUSED_HEAD_BWD = False (the test's handle) -- the separate kernels."""
     bn_g, bn_b, p0_w, p0_b, p1_g, p1_b, p3_w, p3_b = params
     g, m_pro, r_pro, h0, h1, m_h, r_h = heads
     N, C = g.shape

@@ -54,7 +54,7 @@ class MSELoss:
         return mse_loss(pred, target)
 
 
-SKIP_UNUSED_OUTPUTS = os.environ.get("PCRL_SKIP_UNUSED_OUTPUTS", "1") != "0"   # A/B switch (results are bit-identical)
+SKIP_UNUSED_OUTPUTS = True   # module attribute, flipped by the bit-identity test (no environment switch since round 6)
 COS_MAX_TERMS = 32   # csrc/heads_loss.hip
 FUSED_COS_LOSSES = os.environ.get("PCRL_FUSED_COS", "1") != "0"   # all 26 cosine means of a step in one launch (0: one launch per mean)
 

@@ -445,6 +445,37 @@ def test_bench_gpus4_code_path_dry_run_gloo_world4():
     assert d["steps"] == 4 and d["warmup"] == 1 and d["ms_per_step"] > 0
 
 
+def test_bnr_counted_wait_matches_the_stores_behind_the_dma_pieces(tmp_path):
+    """the fused data-gradient + BatchNorm-reduce epilogue (csrc/conv_brick16.h, BNR instantiations) knows that its LDS-DMA pieces have
+    landed from a COUNTED wait -- `s_waitcnt vmcnt(12 FN)`: the pieces are the oldest vector-memory operations in flight and exactly 12 FN stores (three
+    lines of the output tile) were issued behind them.  If a compiler ever merges, drops or reorders those stores the count is wrong and the partial
+    sums read a half-landed tile.  Build-time check on the ISA hipcc emits for every BNR instantiation (gfx950 cross-compile, ~5 s): between the last
+    `global_load_lds` request and the counted wait there are exactly N vector-memory instructions, all stores, N = the wait's count, straight-line."""
+    import re
+    import shutil
+    from pcrlv2_amd import build as B
+    hipcc = B.hipcc()
+    src = os.path.join(ROOT, "pcrlv2_amd", "csrc", "conv_brick16_bnr.hip")
+    out = tmp_path / "bnr.s"
+    flags = [f for f in B.FLAGS if f not in ("-fPIC",)] + B.FILE_FLAGS.get("conv_brick16_bnr.hip", [])
+    r = subprocess.run([hipcc, *flags, "--cuda-device-only", "-S", src, "-o", str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = out.read_text().split("\n")
+    waits = [i for i, ln in enumerate(lines) if re.search(r"s_waitcnt vmcnt\((48|24)\)", ln)]
+    assert len(waits) == 8, ("one counted wait per BNR instantiation (2 widths x 2 axis orders x 3D / 2D)", len(waits))
+    for w in waits:
+        want = int(re.search(r"vmcnt\((\d+)\)", lines[w]).group(1))
+        j, vm = w - 1, []
+        while j > 0 and "global_load_lds" not in lines[j]:
+            ln = lines[j].strip()
+            assert not (ln.endswith(":") and not ln.startswith(";")), ("a label (control flow) between the DMA requests and the counted wait", w, ln)
+            if re.match(r"(global|buffer|flat|scratch)_", ln):
+                vm.append(ln.split()[0])
+            j -= 1
+        assert j > 0, "no LDS-DMA request in front of the counted wait"
+        assert len(vm) == want and all(v.startswith("global_store") for v in vm), (w, want, len(vm), sorted(set(vm)))
+
+
 class _BusyLoops:
     """`n` busy-loop processes beside a test (the rc = 1 exits of the N-rank entry points showed up under CPU load, when a
     rank's teardown was slow enough for its peers' threads to outlive it).  Killed by their exact PIDs."""
@@ -635,6 +666,18 @@ def test_loader_worker_moves_to_the_cpus_the_binding_left_for_it(monkeypatch):
         monkeypatch.setenv("PCRL_WORKER_CPUS", "")
         data.worker_affinity_init(0)                                            # no variable: nothing happens
         assert sorted(os.sched_getaffinity(0)) == allowed[-2:]
+        # one CPU per worker only where the rank's share was really split: inside a DataLoader worker (worker info present) ...
+        import types
+        monkeypatch.setattr(torch.utils.data, "get_worker_info", lambda: types.SimpleNamespace(num_workers=2, id=1))
+        monkeypatch.setenv("PCRL_WORKER_CPUS", ",".join(str(c) for c in allowed[-2:]))
+        monkeypatch.setenv("PCRL_WORKER_CPUS_SPLIT", "0")                       # ... an UNSPLIT share is shared: the workers float over all of it
+        os.sched_setaffinity(0, allowed)
+        data.worker_affinity_init(1)
+        assert sorted(os.sched_getaffinity(0)) == allowed[-2:]
+        monkeypatch.setenv("PCRL_WORKER_CPUS_SPLIT", "1")                       # ... a split share: worker i on CPU i of the list
+        os.sched_setaffinity(0, allowed)
+        data.worker_affinity_init(1)
+        assert sorted(os.sched_getaffinity(0)) == [allowed[-1]]
     finally:
         os.sched_setaffinity(0, allowed)
 

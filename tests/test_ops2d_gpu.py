@@ -352,7 +352,7 @@ def test_stem_kernels_against_torch(N, H, W):
 @pytest.mark.parametrize("parts", ["pro+pre", "pre", "pro"])
 def test_heads_backward_two_launches_equal_the_nine(N, C, parts):
     """ops.heads_backward through pcrl_head_bwd_stage (Linear backward + the BatchNorm1d backward of what it produced, one launch per half of
-    the chain) against the separate kernels (PCRL_FUSED_HEAD_BWD=0) and against float64 autograd of the same chain."""
+    the chain) against the separate kernels (ops.FUSED_HEAD_BWD = False) and against float64 autograd of the same chain."""
     from pcrlv2_amd import ops
     dev = _dev()
     g = torch.Generator().manual_seed(N + C)

@@ -1,4 +1,4 @@
-"""Trilinear upsample backward at the two shapes of a C2 step (x4 of the 16x16x8 map, x2 of the 32x32x16 map); PCRL_TRI_BWD_PLANES=0: the gather form."""
+"""Trilinear upsample backward at the two shapes of a C2 step (x4 of the 16x16x8 map, x2 of the 32x32x16 map) (the per-plane LDS form; the gather form it replaced was removed with its switch in round 6)."""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch
