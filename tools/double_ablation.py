@@ -50,7 +50,17 @@ def big_conv(name, args):   # plain forward / data gradient convolutions on volu
     return name == "pcrl_conv3d_k3_dgrad_bnred"
 
 
+def level_8x8x4(name, args):   # plain forward / data gradient convolutions of the GLOBAL views' 8 x 8 x 4 level (down_tr512, up_tr256.ops): VERDICT r5 item 6
+    if name == "pcrl_conv3d_k3_fwd_ws":
+        return args[8] * args[9] * args[10] == 256 and args[7] <= 64
+    if name == "pcrl_conv3d_k3_dgrad_bnred":
+        return args[10] * args[11] * args[12] == 256 and args[9] <= 64
+    return False
+
+
 SETS = {
+    "level_8x8x4": level_8x8x4,
+    "level_8x8x4_all": lambda n, ar: level_8x8x4(n, ar) or (n in ("pcrl_upconv_fwd", "pcrl_upconv_dgrad_ws") and ar[7] * ar[8] * ar[9] == 256),
     "finalize": lambda n, ar: n in ("pcrl_bn_finalize", "pcrl_bn_bwd_finalize"),
     "bn_reduce": lambda n, ar: n.startswith("pcrl_bn_act_bwd_reduce"),
     "bn_bwd_apply": lambda n, ar: n.startswith("pcrl_bn_act_bwd_apply"),
