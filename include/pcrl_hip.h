@@ -176,7 +176,9 @@ int pcrl_bn_act_bwd_reduce(const void* da, const void* y, const float* scale, co
  * pcrl_bn_act_bwd_rowadd_ok(C, dtype)); partial: [pcrl_bn_act_bwd_pool_partial_rows(N, D, H, W)][C][2] -> pcrl_bn_bwd_finalize with
  * count = N*D*H*W. */
 int64_t pcrl_bn_act_bwd_pool_ok(int D, int H, int W, int C, int dtype);   /* 1 / 0 */
-/* forward of the same pair: a = act(scale*y + shift) and p = MaxPool3d(2)(a) in one pass (same availability) */
+/* forward of the same pair: a = act(scale*y + shift) and p = MaxPool3d(2)(a) in one pass (same availability).  a may be NULL: only p is stored --
+   the encoder stages' unpooled outputs have no reader in a training step (models/pcrlv2_model_3d.py:114-117 stashes them as attributes, nothing
+   consumes them), and the backward of the pair reads y, not a: 47 % of the pass's bytes */
 int pcrl_bn_act_apply_pool(const void* y, void* a, void* p, const float* scale, const float* shift, int N, int D, int H, int W, int C,
                            int act, int dtype, pcrl_stream_t stream);
 int64_t pcrl_bn_act_bwd_pool_partial_rows(int N, int D, int H, int W);

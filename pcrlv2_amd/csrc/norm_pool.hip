@@ -635,7 +635,7 @@ __device__ __forceinline__ void bn_apply_pool_body(const T* __restrict__ y, T* _
         const float f = to_f(o.v[j]);
         if (f > m[j] || f != f) m[j] = f;
       }
-      st16_sel<NT>(a + rows[t] * C + cv * VEC, o);
+      if (a) st16_sel<NT>(a + rows[t] * C + cv * VEC, o);      // a == nullptr (kernel argument: uniform): only the pooled tensor is wanted
     }
     Vec16<T> o;
 #pragma unroll
@@ -973,7 +973,7 @@ extern "C" int64_t pcrl_bn_act_bwd_pool_partial_rows(int N, int D, int H, int W)
 }
 extern "C" int pcrl_bn_act_apply_pool(const void* y, void* a, void* p, const float* scale, const float* shift, int N, int D, int H, int W, int C,
                                       int act, int dtype, pcrl_stream_t stream) {
-  PCRL_REQUIRE(y && a && p && scale && shift && N > 0, "bn_act_apply_pool: bad arguments");
+  PCRL_REQUIRE(y && p && scale && shift && N > 0, "bn_act_apply_pool: bad arguments");   // a may be null: the full-resolution activation is not stored
   PCRL_REQUIRE(pcrl_bn_act_bwd_pool_ok(D, H, W, C, dtype), "bn_act_apply_pool: not available for %dx%dx%d, C=%d (pcrl_bn_act_bwd_pool_ok)", D, H, W, C);
   const int64_t Mp = (int64_t)N * (D / 2) * (H / 2) * (W / 2);
   const int vec = dtype == PCRL_BF16 ? 8 : 4;

@@ -315,10 +315,10 @@ class LUConvPoolFn(Function):
     the full-resolution gradient of `a` is never written or read."""
 
     @staticmethod
-    def forward(ctx, x, w, b, gamma, beta, mod):
+    def forward(ctx, x, w, b, gamma, beta, mod, pool_only=False):
         dt = mod.compute_dtype
         (a, p), sv = ops.luconv_forward(x, w, b, gamma, beta, mod.bn1.running_mean, mod.bn1.running_var, mod._packed, mod._act, dt, pooled=True,
-                                        prelu=_slope(mod))
+                                        prelu=_slope(mod), pool_only=pool_only)
         mod._count_batch()
         ctx.sv, ctx.mod, ctx.dt = sv, mod, dt
         ctx.below = _below_saved(mod, x)
@@ -326,12 +326,15 @@ class LUConvPoolFn(Function):
         ctx.pass_idx = getattr(mod, "_pass_idx", 1)
         ctx.plist = (w, b, gamma, beta)
         ctx.set_materialize_grads(False)
-        return a, p
+        ctx.pool_only = a is None
+        mod._last_saved = sv            # for PCRLv23d's lazily materialised skip attribute (pool_only: `a` was not stored)
+        return p if a is None else (a, p)
 
     @staticmethod
-    def backward(ctx, da, dp):
+    def backward(ctx, *grads):
+        da, dp = (None, grads[0]) if ctx.pool_only else grads
         if da is None and dp is None:
-            return (None,) * 6
+            return (None,) * 7
         sv, dt = ctx.sv, ctx.dt
         N, D, H, W, _, Co = sv.geom
         pool_dp = None
@@ -349,7 +352,7 @@ class LUConvPoolFn(Function):
                                                     pool_dp=pool_dp, bnred=ctx.below)
         _park_slope(ctx.mod, sv)
         w, b, gamma, beta = ctx.plist
-        out = dx, _park(w, dw), _park(b, db), _park(gamma, dg), _park(beta, dbeta), None
+        out = dx, _park(w, dw), _park(b, db), _park(gamma, dg), _park(beta, dbeta), None, None
         mark_final(ctx, ctx.plist)
         return out
 

@@ -84,11 +84,33 @@ class LUConv(nn.Module, _Counted):
         c, n = self.conv1, self.bn1
         return Fn.LUConvFn.apply(x, c.weight, c.bias, n.weight, n.bias, self)
 
-    def forward_pooled(self, x):
+    def forward_pooled(self, x, pool_only=False):
         """-> (act(bn1(conv1(x))), MaxPool3d(2) of it) as one autograd node (Fn.LUConvPoolFn): what PCRLv23d.forward asks of the second
-        LUConv of an encoder stage.  BatchNorm layers with more than one input channel only."""
+        LUConv of an encoder stage.  BatchNorm layers with more than one input channel only.  pool_only (the engine's training step): the unpooled
+        activation is not stored -- (a _LazySkip that builds it from the saved pre-normalisation tensor on demand, the pooled tensor)."""
         c, n = self.conv1, self.bn1
-        return Fn.LUConvPoolFn.apply(ops.to_act(x, self.compute_dtype), c.weight, c.bias, n.weight, n.bias, self)
+        out = Fn.LUConvPoolFn.apply(ops.to_act(x, self.compute_dtype), c.weight, c.bias, n.weight, n.bias, self, pool_only)
+        if isinstance(out, tuple):
+            return out
+        return _LazySkip(self._last_saved, self.compute_dtype), out
+
+
+class _LazySkip:
+    """The unpooled output of an encoder stage when the training step did not store it: `PCRLv23d.skip_out64` (etc.) hands out
+    act(scale * y + shift) computed from the stage's saved pre-normalisation tensor the first time somebody reads the attribute -- the values the
+    stored tensor would have held, detached (the reference's attribute is a graph node; nothing in train_3d.py reads it)."""
+
+    def __init__(self, sv, dt):
+        self.sv, self.dt, self.value = sv, dt, None
+
+    def materialize(self):
+        if self.value is None:
+            sv = self.sv
+            N, D, H, W, _, Co = sv.geom
+            with torch.no_grad():
+                self.value = ops.bn_act_apply(sv.y, sv.scale, sv.shift, N * D * H * W, Co, sv.act, self.dt)
+            self.sv = None
+        return self.value
 
 
 def _make_nConv(in_channel, depth, act, norm, double_chnnel=False):
@@ -260,7 +282,7 @@ class PCRLv23d(nn.Module):
                 masks.append(mask if factor == 1 else ops.upsample_forward(mask, factor))
         return ops.conv1x1_to1_forward(ops.to_act(h, dt), self.out_tr.final_conv.weight, self.out_tr.final_conv.bias, dt), feats, masks
 
-    def _train_stages(self, x, local, pass_idx, features_only=False):
+    def _train_stages(self, x, local, pass_idx, features_only=False, lazy_skips=False):
         """The training-mode forward.  (Rounds 3-4 had this as a generator so that several passes could be advanced stage by stage in rotation,
         each on its own stream, with one matrix kernel at a time -- measured slower, 33.5 -> 34.4 / 37.1 ms, DESIGN section 5 -- removed.)
         features_only: the caller discards the reconstruction and the deep-supervision maps (the second view and the local views of a
@@ -281,7 +303,7 @@ class PCRLv23d(nn.Module):
             if config.FOLD_POOL_GRAD and i + 1 < len(_ENCODER) and not last._gn_groups:
                 # stage output and `self.maxpool` of it (:115-117) as one node: the pool's backward folds into the BatchNorm backward
                 a = stage.ops[0](h)
-                h, pooled = last.forward_pooled(a)
+                h, pooled = last.forward_pooled(a, pool_only=lazy_skips)     # lazy_skips: h is a _LazySkip (the stage output is not stored)
             else:
                 h, pooled = stage(h), None
             setattr(self, attr, h)          # the reference keeps these alive as attributes; the skips are never consumed (D6)
@@ -298,13 +320,37 @@ class PCRLv23d(nn.Module):
         out = self.out_tr(h)
         return out, middle_features, middle_masks
 
-    def forward(self, x, local=False, *, features_only=False):
+    def forward(self, x, local=False, *, features_only=False, lazy_skips=False):
         """-> (out [b,1,D,H,W], [[pro, pre] x 3 scales], [mask x 3] or [] when local).  `features_only` (engine extension, keyword only):
-        (None, features, []) -- see _train_stages."""
+        (None, features, []) -- see _train_stages.  `lazy_skips` (engine extension, keyword only; train_3d.step_losses sets it): the encoder stages'
+        unpooled outputs -- which the reference stashes as `self.skip_out64 / 128 / 256` (:114-117) and never reads -- are not written to HBM; the
+        attributes still answer, computing the tensor from the stage's saved pre-normalisation values when read (detached)."""
         if not x.is_cuda:
             raise RuntimeError("PCRLv23d (pcrlv2_amd) runs on the GPU only: input is on %s and there is no CPU fallback" % x.device)
         if not self.training:
             return self._forward_eval(x, local)
-        result = self._train_stages(x, local, ops.next_pass(), features_only)     # pass 0 = first forward since the last optimizer step (its backward runs last)
+        result = self._train_stages(x, local, ops.next_pass(), features_only, lazy_skips)     # pass 0 = first forward since the last optimizer step (its backward runs last)
         ops.end_of_forward_join()           # the stages' side branches (config.FWD_BRANCH_STREAM) are complete when the outputs are handed out
         return result
+
+
+def _skip_attribute(name):
+    """`model.skip_out64` etc.: plain attributes as in the reference (:114-117), except that a _LazySkip stored by the engine's training step is
+    turned into its tensor when read."""
+    def get(self):
+        store = self.__dict__.get("_skip_store")
+        if store is None or name not in store:
+            raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}' (set by forward())")
+        v = store[name]
+        if isinstance(v, _LazySkip):
+            v = store[name] = v.materialize()
+        return v
+
+    def put(self, v):
+        self.__dict__.setdefault("_skip_store", {})[name] = v
+    return property(get, put)
+
+
+for _n in _SKIPS[:3]:
+    setattr(PCRLv23d, _n, _skip_attribute(_n))
+

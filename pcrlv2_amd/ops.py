@@ -776,7 +776,7 @@ def pad_first_layer(x, conv_w, ci_pad, dtype):
 
 
 def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, packed: PackedWeights, act: int, dtype, training=True, gn_groups=0,
-                   pooled=False, gap=False, prelu=None, inorm=False):
+                   pooled=False, gap=False, prelu=None, inorm=False, pool_only=False):
     """x: activation (or float32 [N,1,D,H,W] for the first layer).  Returns (a, saved); with `pooled` ((a, MaxPool3d(2)(a)), saved) --
     one pass where bn_pool_ok (BatchNorm layers of the MFMA path), else the separate pool; with `gap` ((a, global average pool [N, C]
     float32 of a), saved), likewise in one pass where bn_rowadd_ok.
@@ -875,7 +875,9 @@ def luconv_forward(x, conv_w, conv_b, gamma, beta, running_mean, running_var, pa
                dtype_code(dtype), s)
         mean, rstd, scale, shift = bn_finalize(partial, rows, Co, M, gamma.detach(), beta.detach(), running_mean, running_var, training)
         if pooled and prelu is None and config.FUSE_APPLY_CONSUMERS and bn_pool_ok(D, H, W, Co, dtype):
-            a, p = torch.empty_like(y), new_act(N, D // 2, H // 2, W // 2, Co, dtype, dev)
+            # pool_only (the engine's training step): the unpooled activation is not stored at all -- nothing reads it (the backward of this pair
+            # reads y; PCRLv23d hands the stashed attribute out lazily, from y, if somebody asks)
+            a, p = None if pool_only else torch.empty_like(y), new_act(N, D // 2, H // 2, W // 2, Co, dtype, dev)
             L.call("pcrl_bn_act_apply_pool", y, a, p, scale, shift, N, D, H, W, Co, act, dtype_code(dtype), s)
             a, pooled = (a, p), False
         elif gap and prelu is None and config.FUSE_APPLY_CONSUMERS and bn_rowadd_ok(Co, dtype):

@@ -54,6 +54,7 @@ class MSELoss:
         return mse_loss(pred, target)
 
 
+LAZY_SKIPS = True            # module attribute (tests / tools/step_ab.py flip it): the encoder stages' unpooled outputs are not stored by the step (PCRLv23d.forward lazy_skips)
 SKIP_UNUSED_OUTPUTS = True   # module attribute, flipped by the bit-identity test (no environment switch since round 6)
 COS_MAX_TERMS = 32   # csrc/heads_loss.hip
 FUSED_COS_LOSSES = os.environ.get("PCRL_FUSED_COS", "1") != "0"   # all 26 cosine means of a step in one launch (0: one launch per mean)
@@ -133,10 +134,11 @@ def step_losses(model, batch, epoch, criterion, cosine):
     _ops.fork_views(view1.device)  # config.VIEW_STREAMS: the second view's forward (and backward) on its own stream, next to the first's
     _ops.prepack(model, view1.device)   # config.PREPACK: this step's packed / composed weight forms on the side stream, ahead of their use
     with _ops.deferred_join():     # the decoder stages' side branches (heads, deep-supervision maps) also run under the NEXT forward; joined on exit
-        out1, feats1, masks1 = model(view1)
+        lz = dict(lazy_skips=True) if LAZY_SKIPS and isinstance(model, PCRLv23d) else {}      # the encoder stages' unpooled outputs have no reader in this step: not stored
+        out1, feats1, masks1 = model(view1, **lz)
         # mask2, the local views' reconstruction and their deep-supervision maps are never used (train_3d.py:117,123): the engine's
         # model skips what has no state (out_tr, the trilinear upsampling) when asked for the features only; a plain nn.Module computes them
-        fo = dict(features_only=True) if SKIP_UNUSED_OUTPUTS and isinstance(model, PCRLv23d) else {}
+        fo = dict(features_only=True, **lz) if SKIP_UNUSED_OUTPUTS and isinstance(model, PCRLv23d) else dict(lz)
         with _ops.view_pass(view2.device, view2):
             _out2, feats2, _ = model(view2, **fo)
         if fused:

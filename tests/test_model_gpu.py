@@ -1289,3 +1289,52 @@ def test_no_device_malloc_after_the_first_step_at_the_bench_size():
     grown = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - n0
     # without the provisioning: 21-23 in a run of this length; a step whose draws need a block size the first step never used may still add one
     assert grown <= 3, f"{grown} device mallocs in 15 steps after the pools were provisioned"
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_lazy_skip_attributes_are_the_stored_tensors_and_leave_the_step_bit_identical(dt):
+    """The reference stashes the encoder stages' unpooled outputs as `self.skip_out64 / 128 / 256` (pcrlv2_model_3d.py:114-117) and never reads them
+    (UpTransition takes no skip input).  The engine's training step does not store them (forward(..., lazy_skips=True): the fused normalise + pool
+    pass writes the pooled tensor only -- 47 % of that pass's HBM bytes); the attribute still answers, built from the stage's saved
+    pre-normalisation tensor when read.  Held: (i) every lazily built attribute is bit-equal to the tensor the plain forward stores, same shape,
+    dtype and NDHWC layout, and `out512` (a stage output that IS consumed) is unchanged; (ii) outputs, features and maps of the two forwards are
+    bit-equal; (iii) two training steps give bit-identical losses, parameters, momentum and BatchNorm buffers whether train_3d passes
+    lazy_skips or not."""
+    from pcrlv2_amd import train_3d
+    from pcrlv2_amd.models import pcrlv2_model_3d as M3
+    batch = O.fill_batch(4, (32, 32, 16), dtype=torch.float32, seed=77)
+    x = batch[0].to(DEV)
+    model = build(dt)
+    with torch.no_grad():
+        out_a, feats_a, masks_a = model(x)
+        stored = {n: getattr(model, n).clone() for n in ("skip_out64", "skip_out128", "skip_out256", "out512")}
+        model.load_state_dict(O.fill_state(torch.float32))
+        out_b, feats_b, masks_b = model(x, lazy_skips=True)
+        assert all(isinstance(model.__dict__["_skip_store"][n], M3._LazySkip) for n in ("skip_out64", "skip_out128", "skip_out256"))
+        for n, want in stored.items():
+            got = getattr(model, n)
+            assert torch.is_tensor(got) and got.shape == want.shape and got.dtype == want.dtype and got.stride() == want.stride(), n
+            assert torch.equal(got, want), n
+            assert getattr(model, n) is got             # materialised once
+    assert torch.equal(out_a, out_b) and all(torch.equal(a, b) for a, b in zip(masks_a, masks_b))
+    for (a, b), (c, d) in zip(feats_a, feats_b):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    batches = [O.fill_batch(4, (32, 32, 16), dtype=torch.float32, seed=41 + s) for s in range(2)]
+    finals = []
+    keep = train_3d.LAZY_SKIPS
+    for lazy in (True, False):
+        train_3d.LAZY_SKIPS = lazy
+        try:
+            m = build(dt)
+            opt = FusedSGD(m.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-4)
+            random.seed(9)
+            for bt in batches:
+                losses = train_step(m, opt, bt, 3, MSELoss(), CosineSimilarityMean())
+            torch.cuda.synchronize()
+            finals.append(([float(v) for v in losses], opt.flat_p.clone(), opt.flat_buf.clone(), {k: v.clone() for k, v in m.state_dict().items() if O.is_buffer(k)}))
+        finally:
+            train_3d.LAZY_SKIPS = keep
+    (la, pa, ma, ba), (lb, pb, mb, bb) = finals
+    assert la == lb and torch.equal(pa, pb) and torch.equal(ma, mb)
+    for k in ba:
+        assert torch.equal(ba[k], bb[k]), k
