@@ -391,7 +391,9 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
     correlated synthetic views (fill_batch seeds 2000 + step), run TWICE from the same state and draws:
       * float64, oneDNN off  -> the curve the engines are held to (per step: total, loss1, loss2, loss4, local_loss, index2, EMA(0.9) of the total);
       * float32, stock PyTorch (oneDNN on: the reference's own CPU path) -> how far stock float32 itself drifts from float64 over the
-        same steps; its per-component maxima are stored as `stock_fp32_*` and are the yardstick for the tolerances the GPU test states.
+        same steps; its per-component maxima are stored as `stock_fp32_*` and are the yardstick for the tolerances the GPU test states;
+      * float32 with oneDNN off (ATen's native convolutions: the same arithmetic width in another summation order) -> `fp32_nodnn_*`: a second
+        draw of that drift (the cosine terms are chaotic: one float32 run's distance from the float64 run is a sample, not a bound).
     The oracle is NOT re-run here over the whole horizon (make_curve pins it step for step over 12 steps; the restatement is the same code)."""
     torch.set_num_threads(8)
     names = ("loss", "loss1", "loss2", "loss4", "local_loss")
@@ -438,7 +440,7 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
             out.append(e)
         return np.array(out)
 
-    def save(c64, c32, name=None):
+    def save(c64, c32, name=None, c32n=None):
         name = name or tag
         ref = c64 if c64 is not None else c32
         e_ref = ema_of(ref[:, 0])
@@ -452,6 +454,16 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
             for i, k in enumerate(names):
                 print(f"[{tag}] stock fp32 vs fp64 over {n} steps, {k}: max {d[:, i].max():.3e} mean {d[:, i].mean():.3e}")
             print(f"[{tag}] stock fp32 EMA(total) vs fp64 after step 20: max {float(extra['stock_fp32_ema_max_after20']):.3e}")
+            if c32n is not None:
+                # a SECOND float32 realisation of the reference (oneDNN off: ATen's native convolutions, another summation order): the quantities behind
+                # BatchNorm1d over eight rows are chaotic, and one float32 run's distance from the float64 run is one draw of that distance, not a bound
+                dn = np.abs(c32n[:n, :5] - c64[:n, :5])
+                en = ema_of(c32n[:, 0])
+                extra.update(fp32_nodnn_curve=c32n, fp32_nodnn_max_abs=dn.max(axis=0),
+                             fp32_nodnn_ema_max_after20=np.float64(np.abs(en[:n] - e_ref[:n])[20:].max()) if n > 21 else np.float64(0))
+                for i, k in enumerate(names):
+                    print(f"[{tag}] fp32 (oneDNN off) vs fp64 over {n} steps, {k}: max {dn[:, i].max():.3e} mean {dn[:, i].mean():.3e}")
+                print(f"[{tag}] fp32 (oneDNN off) EMA(total) vs fp64 after step 20: max {float(extra['fp32_nodnn_ema_max_after20']):.3e}")
         np.savez_compressed(os.path.join(OUT if name == tag else "/tmp", f"{name}.npz"), curve=ref, ema_total=e_ref, ema=np.float64(ema), b=np.int64(b), dhw=np.array(dhw),
                             nsteps=np.int64(len(ref)), epoch=np.int64(epoch), base_lr=np.float64(base_lr), seed=np.int64(seed), batch_seed0=np.int64(2000),
                             reference_dtype="float64, oneDNN off" if c64 is not None else "float32, stock (oneDNN on)", stock_fp32_curve=c32, **extra)
@@ -464,8 +476,16 @@ def make_long_curve(tag, b, dhw, nsteps, refmod, ref_train, ref_utils, epoch=0, 
     else:
         c32 = run(torch.float32, True)
         save(None, c32)
-    c64 = run(torch.float64, False, partial=lambda rows: save(rows, c32, tag + "_partial_fp64"))     # partial float64 curves go to /tmp; the fixture is replaced when complete
-    save(c64, c32)
+    c64 = None
+    if "--reuse-fp64" in sys.argv and os.path.exists(cache):        # the float64 run takes ~3 h: adding a float32 realisation must not repeat it
+        fx_ = np.load(cache, allow_pickle=True)
+        if str(fx_["reference_dtype"]).startswith("float64") and len(fx_["curve"]) == nsteps:
+            c64 = fx_["curve"]
+    if c64 is None:
+        c64 = run(torch.float64, False, partial=lambda rows: save(rows, c32, tag + "_partial_fp64"))     # partial float64 curves go to /tmp; the fixture is replaced when complete
+        save(c64, c32)
+    c32n = run(torch.float32, False)       # float32 with oneDNN off: a second float32 realisation of the reference (minutes)
+    save(c64, c32, c32n=c32n)
     print(f"[{tag}] wrote fixture ({nsteps} steps)")
 
 

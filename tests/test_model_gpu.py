@@ -771,18 +771,21 @@ LONG_CURVE = {}      # dtype -> the engine's 300-step curve (computed once per s
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_long_horizon_loss_curve_300_steps_vs_reference(dt, golden_dir):
-    """Row LC of VERDICT r4 / SURVEY App. C (iv): 300 SGD steps (b = 8, 32x32x16 + 6 local 16^3, correlated synthetic views, lr 1e-3) of the
-    float32 AND the bfloat16 engine against the curve of the REAL reference over the same 300 steps, same state, same draws
-    (tests/golden/lc_b8_32x32x16_300steps.npz, oracle/make_golden.py --long-curve; `reference_dtype` says whether the file holds the float64
-    run or, until that has finished, the stock float32 one; `stock_fp32_*` = how far stock PyTorch float32 drifts from float64 on this horizon).
-    Held:
-      * restoration loss `loss1` at EVERY one of the 300 steps,
-      * deep-supervision loss `loss4` at every step,
-      * the EMA(0.9) of the total loss after step 20 and the mean of the total over steps 100-299 --
-    the total itself swings by +-0.5 from step to step (the 13 cosine terms through BatchNorm1d over eight rows: SURVEY App. C), which is why the
-    smoothed curve is what a loss-curve comparison can mean.  Tolerances below; measured values are printed."""
+    """Row LC (north_star: "loss curve matching reference to 1e-3"; SURVEY App. C iv): 300 SGD steps (b = 8, 32x32x16 + 6 local 16^3, correlated
+    synthetic views, lr 1e-3) of the float32 AND the bfloat16 engine against the curve of the REAL reference in FLOAT64 (oneDNN off) over the same
+    steps, same state, same draws (tests/golden/lc_b8_32x32x16_300steps.npz, oracle/make_golden.py --long-curve, train_3d.py:109-151).  The fixture also
+    holds the reference's own STOCK FLOAT32 run (oneDNN on: its CPU path) and how far THAT drifts from its float64 run -- `stock_fp32_max_abs` per
+    component, `stock_fp32_ema_max_after20` -- which is the yardstick: the total swings by +-0.5 from step to step (13 cosine terms through
+    BatchNorm1d over eight rows), two float32 runs one ulp apart drift as far as bf16 does (profiles/r05bg_long_run_compare.txt).
+    Held, per engine dtype:
+      * restoration loss `loss1`: within 1e-3 of the float64 reference at EVERY step (north_star's bound, absolute);
+      * deep-supervision loss `loss4`, EMA(0.9) of the total after step 20, mean of the total over steps 100..end: within LC_FACTOR x the drift of
+        the reference's own float32 run from its float64 run on the same quantity (no free-standing tolerance).
+    Measured values are printed (profiles/r06_long_curve.txt)."""
     fx = np.load(os.path.join(golden_dir, "lc_b8_32x32x16_300steps.npz"), allow_pickle=True)
+    assert str(fx["reference_dtype"]).startswith("float64"), "the fixture must hold the float64 reference curve (oracle/make_golden.py --long-curve)"
     ref, b, dhw, nsteps, ema = fx["curve"], int(fx["b"]), tuple(int(v) for v in fx["dhw"]), int(fx["nsteps"]), float(fx["ema"])
+    c32 = fx["stock_fp32_curve"][:nsteps]
     model = build(dt)
     opt = FusedSGD(model.parameters(), lr=float(fx["base_lr"]), momentum=0.9, weight_decay=1e-4)
     random.seed(int(fx["seed"]))
@@ -800,31 +803,32 @@ def test_long_horizon_loss_curve_300_steps_vs_reference(dt, golden_dir):
             e = ema * e + (1.0 - ema) * x
             out.append(e)
         return np.array(out)
-    d1, d4 = np.abs(got[:, 1] - ref[:, 1]), np.abs(got[:, 3] - ref[:, 3])
+
+    def drift(c):      # of a curve from the float64 reference: loss1 max, loss4 max, EMA(total) max after step 20, |mean of the total over steps 100..|
+        t0 = min(100, nsteps // 3)
+        return (np.abs(c[:, 1] - ref[:, 1]).max(), np.abs(c[:, 3] - ref[:, 3]).max(), np.abs(ema_of(c[:, 0]) - ema_of(ref[:, 0]))[20:].max(),
+                abs(c[t0:, 0].mean() - ref[t0:, 0].mean()))
+    e1, e4, ee, et = drift(got)
+    s1, s4, se, st_ = drift(c32)
+    assert abs(s1 - float(fx["stock_fp32_max_abs"][1])) < 1e-12 and abs(se - float(fx["stock_fp32_ema_max_after20"])) < 1e-12     # the yardstick IS the fixture's
+    print(f"  {dt} vs the float64 reference over {nsteps} steps: loss1 max {e1:.2e}  loss4 max {e4:.2e}  EMA(total) max after step 20 {ee:.2e}  "
+          f"|mean total, steps 100..| {et:.2e}   [stock float32 reference vs its float64 run: {s1:.2e}  {s4:.2e}  {se:.2e}  {st_:.2e}]")
     e_got, e_ref = ema_of(got[:, 0]), ema_of(ref[:, 0])
-    de = np.abs(e_got - e_ref)
-    tail = abs(got[100:, 0].mean() - ref[100:, 0].mean())
-    print(f"  {dt} vs reference ({fx['reference_dtype']}): loss1 max {d1.max():.2e} (step {d1.argmax()})  loss4 max {d4.max():.2e} (step {d4.argmax()})  "
-          f"EMA(total) max after step 20: {de[20:].max():.2e} (step {20 + de[20:].argmax()}), at 299: {de[-1]:.2e}  mean total steps 100-299: engine {got[100:, 0].mean():+.4f} "
-          f"reference {ref[100:, 0].mean():+.4f} (|d| {tail:.2e})  final total EMA {e_got[-1]:+.4f} vs {e_ref[-1]:+.4f}")
     for s in (0, 1, 2, 5, 10, 20, 50, 100, 150, 200, 250, 299):
-        print(f"    step {s:3d}: total {got[s, 0]:+.4f} ({got[s, 0] - ref[s, 0]:+.1e})  loss1 {got[s, 1]:.5f} ({got[s, 1] - ref[s, 1]:+.1e})  loss4 {got[s, 3]:.5f} ({got[s, 3] - ref[s, 3]:+.1e})  "
-              f"EMA {e_got[s]:+.4f} ({e_got[s] - e_ref[s]:+.1e})")
-    if "stock_fp32_max_abs" in fx.files:
-        print("    stock PyTorch float32 vs float64 on the same horizon: max |d| per component", fx["stock_fp32_max_abs"], " EMA after 20:", float(fx["stock_fp32_ema_max_after20"]))
-    bf = dt == torch.bfloat16
-    assert d1.max() < (LC_TOL["loss1_bf16"] if bf else LC_TOL["loss1_fp32"]), ("loss1", d1.max(), int(d1.argmax()))
-    assert d4.max() < (LC_TOL["loss4_bf16"] if bf else LC_TOL["loss4_fp32"]), ("loss4", d4.max(), int(d4.argmax()))
-    assert de[20:].max() < (LC_TOL["ema_bf16"] if bf else LC_TOL["ema_fp32"]), ("EMA(total)", de[20:].max())
-    assert tail < (LC_TOL["tail_bf16"] if bf else LC_TOL["tail_fp32"]), ("mean total, steps 100-299", tail)
+        if s < nsteps:
+            print(f"    step {s:3d}: total {got[s, 0]:+.4f} ({got[s, 0] - ref[s, 0]:+.1e}; stock fp32 {c32[s, 0] - ref[s, 0]:+.1e})  loss1 {got[s, 1]:.5f} ({got[s, 1] - ref[s, 1]:+.1e})  "
+                  f"loss4 {got[s, 3]:.5f} ({got[s, 3] - ref[s, 3]:+.1e})  EMA {e_got[s]:+.4f} ({e_got[s] - e_ref[s]:+.1e})")
+    assert e1 <= 1e-3, ("loss1 vs the float64 reference", e1)
+    assert e4 <= LC_FACTOR * s4, ("loss4", e4, s4)
+    assert ee <= LC_FACTOR * se, ("EMA(total) after step 20", ee, se)
+    assert et <= LC_FACTOR * max(st_, LC_TAIL_FLOOR), ("mean of the total, steps 100..", et, st_)
 
 
-# calibrated on MI355X (profiles/r05_long_curve.txt); see the docstring above for what each bounds
-# Measured (profiles/r05_long_curve.txt) against the stock-float32 reference curve: loss1 9.8e-4 (fp32) / 6.8e-4 (bf16), loss4 5.0e-3 / 4.0e-3, EMA(total) 0.16 / 0.11,
-# mean of the total over steps 100-299 4.2e-2 / 1.3e-2 -- the bfloat16 engine tracks the reference as closely as the float32 one does: what separates two runs on
-# this horizon is the chaotic cosine trajectory (two float32 runs differing in the LAST BIT of one summation drift as far: profiles/r05j_long_run_compare.txt),
-# not the arithmetic width.  The 1e-3 of north_star holds for the restoration loss at every step (2e-3 asserted), not for terms that pass through BatchNorm1d.
-LC_TOL = dict(loss1_fp32=2e-3, loss1_bf16=2e-3, loss4_fp32=9e-3, loss4_bf16=9e-3, ema_fp32=0.3, ema_bf16=0.3, tail_fp32=8e-2, tail_bf16=8e-2)
+# engine drift <= LC_FACTOR x the drift of the reference's own stock-float32 run, both measured against the reference's float64 run.
+# LC_TAIL_FLOOR: the difference of two 200-step means of a chaotic +-0.5 signal can come out arbitrarily small for ONE pair of runs (the stock run's is
+# its realisation, not a bound): the yardstick for the mean is at least the standard error of such a mean, 0.5 / sqrt(200) / 3.
+LC_FACTOR = 1.5
+LC_TAIL_FLOOR = 0.012
 
 
 def test_bf16_loss_curve_vs_rounding_aware_comparator(golden_dir):
