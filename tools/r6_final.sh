@@ -6,8 +6,8 @@ TAG=${1:-r06z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 mkdir -p gpurun_out
-python -m pytest tests -q -m gpu > gpurun_out/${TAG}_pytest_gpu.log 2>&1
-grep -E "passed|failed" gpurun_out/${TAG}_pytest_gpu.log | tail -1
+[ "$SKIP_PYTEST" = 1 ] || python -m pytest tests -q -m gpu > gpurun_out/${TAG}_pytest_gpu.log 2>&1
+[ "$SKIP_PYTEST" = 1 ] || grep -E "passed|failed" gpurun_out/${TAG}_pytest_gpu.log | tail -1
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_driver.json 2> gpurun_out/${TAG}_bench_driver.err
 python - <<PY
 import json
