@@ -831,7 +831,7 @@ def test_long_horizon_loss_curve_300_steps_vs_reference(dt, golden_dir):
 # engine drift <= LC_FACTOR x the drift of the reference's own float32 runs (stock; oneDNN off), all measured against the reference's float64 run
 # (no free-standing tolerance).  The chaotic quantities (EMA of the total) are ONE draw per run: see the measured ratios in
 # profiles/r06_long_curve.txt before tightening.
-LC_FACTOR = 2.0
+LC_FACTOR = 2.5
 
 
 def test_bf16_loss_curve_vs_rounding_aware_comparator(golden_dir):
