@@ -805,18 +805,23 @@ def test_long_horizon_loss_curve_300_steps_vs_reference(dt, golden_dir):
             out.append(e)
         return np.array(out)
 
-    def drift(c):      # of a curve from the float64 reference: loss1 max, loss4 max, EMA(total) after step 20: max and mean of |difference|
-        de = np.abs(ema_of(c[:, 0]) - ema_of(ref[:, 0]))[20:]
-        return np.abs(c[:, 1] - ref[:, 1]).max(), np.abs(c[:, 3] - ref[:, 3]).max(), de.max(), de.mean()
+    def drift(c, base=None):      # of curve c from `base` (default: the float64 reference): loss1 max, loss4 max, EMA(total) after step 20: max and mean of |difference|
+        base = ref if base is None else base
+        de = np.abs(ema_of(c[:, 0]) - ema_of(base[:, 0]))[20:]
+        return np.abs(c[:, 1] - base[:, 1]).max(), np.abs(c[:, 3] - base[:, 3]).max(), de.max(), de.mean()
     e1, e4, ee, em = drift(got)
     s1, s4, se, sm = drift(c32)
     assert abs(s1 - float(fx["stock_fp32_max_abs"][1])) < 1e-12 and abs(se - float(fx["stock_fp32_ema_max_after20"])) < 1e-12     # the yardstick IS the fixture's
-    yard = [(s1, s4, se, sm)]
-    if "fp32_nodnn_curve" in fx.files:      # the reference's second float32 realisation (oneDNN off): the yardstick is the larger of the two draws
-        yard.append(drift(fx["fp32_nodnn_curve"][:nsteps]))
-    y4, ye, ym = (max(y[i] for y in yard) for i in (1, 2, 3))
+    yard = {"stock float32 vs float64": (s1, s4, se, sm)}
+    if "fp32_nodnn_curve" in fx.files:
+        # the reference's second float32 realisation (oneDNN off).  The yardstick is the LARGEST distance between two of the reference's own runs:
+        # each float32 run against the float64 run, and the two float32 runs against each other
+        cn = fx["fp32_nodnn_curve"][:nsteps]
+        yard["float32 (oneDNN off) vs float64"] = drift(cn)
+        yard["stock float32 vs float32 (oneDNN off)"] = drift(c32, cn)
+    y4, ye, ym = (max(y[i] for y in yard.values()) for i in (1, 2, 3))
     print(f"  {dt} vs the float64 reference over {nsteps} steps: loss1 max {e1:.2e}  loss4 max {e4:.2e}  EMA(total) after step 20: max {ee:.2e} mean {em:.2e}   "
-          + "   ".join(f"[reference float32 run {k} vs its float64 run: {y[0]:.2e}  {y[1]:.2e}  {y[2]:.2e}  {y[3]:.2e}]" for k, y in enumerate(yard)))
+          + "   ".join(f"[reference, {k}: {y[0]:.2e}  {y[1]:.2e}  {y[2]:.2e}  {y[3]:.2e}]" for k, y in yard.items()))
     e_got, e_ref = ema_of(got[:, 0]), ema_of(ref[:, 0])
     for s in (0, 1, 2, 5, 10, 20, 50, 100, 150, 200, 250, 299):
         if s < nsteps:
@@ -831,7 +836,7 @@ def test_long_horizon_loss_curve_300_steps_vs_reference(dt, golden_dir):
 # engine drift <= LC_FACTOR x the drift of the reference's own float32 runs (stock; oneDNN off), all measured against the reference's float64 run
 # (no free-standing tolerance).  The chaotic quantities (EMA of the total) are ONE draw per run: see the measured ratios in
 # profiles/r06_long_curve.txt before tightening.
-LC_FACTOR = 2.5
+LC_FACTOR = 2.0
 
 
 def test_bf16_loss_curve_vs_rounding_aware_comparator(golden_dir):
