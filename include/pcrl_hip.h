@@ -330,6 +330,10 @@ int64_t pcrl_conv2d_stats_rows(int N, int Ho, int Wo);     /* upper bound for an
 int64_t pcrl_conv2d_fwd_stats_rows(int N, int Hi, int Wi, int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype);
 int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias, void* y, float* stats_partial, int64_t stats_rows, int N, int Hi, int Wi,
                     int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream);
+/* y may be NULL where pcrl_conv2d_fwd_stats_only_ok(...) == 1: the statistics rows only -- the 3x3 convolution of a deep-supervision head whose map
+ * nothing reads (14 of the 15 heads of a step, pcrlv2_model.py:103-106 / train_2d.py:143-168) runs for its BatchNorm's running statistics alone; its
+ * output (537 MB at 512 x 512 x 16 channels, b = 64) is not written.  The statistics are taken from the float32 accumulators either way. */
+int64_t pcrl_conv2d_fwd_stats_only_ok(int N, int Hi, int Wi, int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype);
 /* data gradient of a 3x3 / stride 1 / pad 1 convolution that read its input through the nearest x2 upsample (decoder conv1,
  * models/pcrlv2_model.py:114) INCLUDING the upsample's backward (aten::convolution_backward's input gradient + aten::upsample_nearest2d_backward):
  * dx[N][Hc][Wc][Ci] = 2 x 2 block sums of the fine-resolution gradient, which is never stored.  dy: [N][2Hc][2Wc][CoP]; wp_dgrad as for

@@ -470,7 +470,12 @@ extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias,
                                int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype, pcrl_stream_t stream) {
   const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
   const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
-  const int kind = (x && wp && y) ? conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype, up) : 0;
+  int kind = (x && wp) ? conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype, up) : 0;
+  if (!y) {
+    // y = NULL: the per-row statistics only -- a deep-supervision head's convolution whose map nothing reads runs for its BatchNorm's running
+    // statistics alone (pcrlv2_model.py:103-106 / train_2d.py:143-168).  Served by the narrow kernel (pcrl_conv2d_fwd_stats_only_ok).
+    PCRL_REQUIRE(x && wp && stats_partial && kind == 2, "conv2d_fwd: y = NULL (statistics only) is not available for this geometry (pcrl_conv2d_fwd_stats_only_ok)");
+  }
   if (stats_partial) {
     const int64_t rw = kind == 3 ? pcrl_brick16_conv2d_rows(N, Ho, Wo) : kind == 1 ? pcrl_brick_conv2d_rows(N, Ho, Wo) : kind == 2 ? pcrl_conv2d_narrow_rows(N, Ho, Wo) : pcrl_conv2d_stats_rows(N, Ho, Wo);
     PCRL_REQUIRE(stats_rows >= rw, "conv2d_fwd: %lld statistics rows allocated, %lld needed (pcrl_conv2d_fwd_stats_rows)", (long long)stats_rows, (long long)rw);
@@ -481,6 +486,12 @@ extern "C" int pcrl_conv2d_fwd(const void* x, const void* wp, const float* bias,
   if (kind == 2) return pcrl_conv2d_narrow_launch(x, wp, bias, y, stats_partial, N, Ho, Wo, CiP, Co, KH, up, out_f32, 0, as_stream(stream));
   return conv2d_common("conv2d_fwd", C2_FWD, x, wp, bias, y, stats_partial, N, Hi, Wi, CiP, Ho, Wo, Co, KH, KW, stride, pad, up, out_f32, dtype,
                        as_stream(stream));
+}
+
+extern "C" int64_t pcrl_conv2d_fwd_stats_only_ok(int N, int Hi, int Wi, int CiP, int Co, int KH, int KW, int stride, int pad, int up, int out_f32, int dtype) {
+  const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
+  const int Ho = (Hl + 2 * pad - KH) / stride + 1, Wo = (Wl + 2 * pad - KW) / stride + 1;
+  return conv2d_fwd_kind(N, Ho, Wo, CiP, Co, KH, KW, stride, pad, out_f32, dtype, up) == 2 ? 1 : 0;
 }
 
 // Data gradient of a 3x3 / stride 1 / pad 1 convolution that read its input through the nearest x2 upsample (decoder conv1,

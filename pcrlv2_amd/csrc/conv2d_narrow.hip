@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256, PCRL_OCC2) conv2d_narrow_kernel(const Nar
             s1[nf][r] += v[r];
             s2[nf][r] += v[r] * v[r];
           }
-          if (c0 < p.Nc) {
+          if (c0 < p.Nc && p.y) {      // p.y == nullptr (kernel argument: uniform): statistics only, the output has no reader (pcrl_conv2d_fwd with y = NULL)
             const int64_t o = row * p.Nc + c0;
             if (vec_ok) {
               if (p.out_f32) *reinterpret_cast<f32x4*>(Yf + o) = f32x4{v[0], v[1], v[2], v[3]};
@@ -249,7 +249,8 @@ __global__ void __launch_bounds__(256, PCRL_OCC2) conv2d_narrow_kernel(const Nar
             const int co = nf * 16 + lr;
             if (co < p.Nc) {
               const float v = acc[mf][nf][r] + bvu[nf];
-              if (p.out_f32) Yf[row * p.Nc + co] = v;
+              if (!p.y) {
+              } else if (p.out_f32) Yf[row * p.Nc + co] = v;
               else Y[row * p.Nc + co] = (bf16)v;
               s1[nf][0] += v;
               s2[nf][0] += v * v;

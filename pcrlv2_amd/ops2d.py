@@ -147,8 +147,10 @@ def out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
-def conv2d_forward(x, w, bias, packed: PackedConv2d, stride, pad, up, dtype, want_stats=True, out_f32=False):
-    """x: NHWC activation with CiP >= w.shape[1] channels.  -> (y, stats_partial | None, rows)"""
+def conv2d_forward(x, w, bias, packed: PackedConv2d, stride, pad, up, dtype, want_stats=True, out_f32=False, stats_only=False):
+    """x: NHWC activation with CiP >= w.shape[1] channels.  -> (y, stats_partial | None, rows).  stats_only: the statistics rows are all the caller
+    wants (a deep-supervision head's convolution whose map nothing reads): where the library can (pcrl_conv2d_fwd_stats_only_ok) y is not written and
+    None is returned in its place."""
     L, s = lib(), stream_handle()
     N, Hi, Wi, CiP = dims2(x)
     Co, Ci, KH, KW = w.shape
@@ -157,7 +159,10 @@ def conv2d_forward(x, w, bias, packed: PackedConv2d, stride, pad, up, dtype, wan
     wf, _ = packed.get(w, dtype, CiP)
     Hl, Wl = (2 * Hi, 2 * Wi) if up else (Hi, Wi)
     Ho, Wo = out_size(Hl, KH, stride, pad), out_size(Wl, KW, stride, pad)
-    y = new_act2(N, Ho, Wo, Co, torch.float32 if out_f32 else dtype, x.device)
+    if stats_only and want_stats and L.call("pcrl_conv2d_fwd_stats_only_ok", N, Hi, Wi, CiP, Co, KH, KW, stride, pad, int(up), int(out_f32), dtype_code(dtype)):
+        y = None
+    else:
+        y = new_act2(N, Ho, Wo, Co, torch.float32 if out_f32 else dtype, x.device)
     rows = L.call("pcrl_conv2d_fwd_stats_rows", N, Hi, Wi, CiP, Co, KH, KW, stride, pad, int(up), int(out_f32), dtype_code(dtype)) if want_stats else 0
     partial = ops._f32(rows * Co * 2, x.device) if want_stats else None
     L.call("pcrl_conv2d_fwd", x, wf, None if bias is None else bias.detach(), y, partial, rows, N, Hi, Wi, CiP, Co, KH, KW, stride, pad,

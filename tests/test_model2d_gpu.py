@@ -509,3 +509,51 @@ def test_eval_mode_forward_uses_the_running_statistics_2d(dtype, local):
     random.seed(2)
     out = train_2d.train_step(model, opt, O2.synthetic_batch(4, 64, 32, seed=50), 0, train_2d.MSELoss2d(), CosineSimilarityMean())
     assert all(math.isfinite(float(v)) for v in out)
+
+
+def test_unread_deep_supervision_convolutions_write_nothing_2d():
+    """functions2d.HEAD_STATS_ONLY (default on): 14 of the 15 deep-supervision heads of a step have no reader (train_2d.py:143-168: the second view's,
+    the local views', and the four scales the first cos_loss did not draw) -- their 3x3 convolution runs for the statistics update of its
+    BatchNorm2d only (pcrlv2_model.py:103-105), so where the kernel can leave the output out (pcrl_conv2d_fwd with y = NULL: the narrow kernel,
+    <= 32 channels: the two full-resolution heads) it is not written.  The statistics come from the float32 accumulators either way: losses,
+    parameters, momentum buffers and every BatchNorm buffer after three steps are BIT-identical to writing the outputs; and the stats-only
+    launches are really taken (counted through the C ABI)."""
+    import pcrlv2_2d_oracle as O
+    from pcrlv2_amd import functions2d, train_2d
+    from pcrlv2_amd._lib import lib
+    from pcrlv2_amd.optim import FusedSGD
+    from pcrlv2_amd.train_3d import CosineSimilarityMean
+    batches = [O.synthetic_batch(4, 64, 32, seed=21 + k) for k in range(3)]
+    keep, finals, nulls = functions2d.HEAD_STATS_ONLY, [], []
+    L = lib()
+
+    class Count:
+        watch = {"pcrl_conv2d_fwd"}
+        n = 0
+
+        def add(self, name, args):
+            self.n += args[3] is None       # y
+    try:
+        for on in (True, False):
+            functions2d.HEAD_STATS_ONLY = on
+            model = _build(seed=5, dtype=torch.bfloat16)
+            opt = FusedSGD(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4)
+            random.seed(2)
+            c = Count()
+            L.counter = c
+            try:
+                for bt in batches:
+                    out = train_2d.train_step(model, opt, bt, 0, train_2d.MSELoss2d(), CosineSimilarityMean())
+                torch.cuda.synchronize()
+            finally:
+                L.counter = None
+            nulls.append(c.n)
+            bufs = torch.cat([v.flatten().float() for k, v in sorted(model.state_dict().items()) if "running" in k or "num_batches" in k])
+            finals.append(([float(o) for o in out], opt.flat_p.clone(), opt.flat_buf.clone(), bufs))
+    finally:
+        functions2d.HEAD_STATS_ONLY = keep
+    assert nulls[0] > 0 and nulls[1] == 0, nulls
+    a, b = finals
+    assert a[0] == b[0], (a[0], b[0])
+    for x, y, what in zip(a[1:], b[1:], ("parameters", "momentum buffers", "BatchNorm buffers")):
+        assert torch.equal(x, y), what
