@@ -391,7 +391,8 @@ def _run(args):
     step_marks[0].record()
     draw_states = []
     for i in range(args.steps):
-        draw_states.append(random.getstate())
+        if i < 256:     # (diagnostics only; a state is a 625-int tuple: keeping thousands of them made the cyclic GC's full collections pause 100-300 ms each in a 1 500-step run)
+            draw_states.append(random.getstate())
         out = train_step(model, opt, batch, 0, crit, cosine, guard=False)
         step_marks[i + 1].record()
     barrier()
