@@ -325,10 +325,26 @@ def empty_cache(device=None):
     streams = {}
     for st in [torch.cuda.current_stream(device)] + list(_side_streams.values()) + list(_view_streams.values()):
         streams[st.cuda_stream] = st
+    # blocks freed while another stream still used them (record_stream) sit in the allocator as "active_pending_free" until it processes their
+    # events -- which it does at the start of the NEXT malloc, not at the synchronize above.  One throw-away allocation per stream settles them into
+    # "inactive" before the snapshot is read (left pending, they turned free under the placeholders and took one meant for a provisioned segment)
+    for st_ in streams.values():
+        with torch.cuda.stream(st_):
+            torch.empty(1, dtype=torch.uint8, device=device)
     hold = []
     by_stream = collections.defaultdict(list)
+    seen = {}
     for seg in torch.cuda.memory_snapshot():
-        if seg["device"] == idx and seg["address"] in mine and seg["stream"] in streams:
+        if seg["device"] == idx and seg["address"] in mine:
+            seen[seg["address"]] = (seg.get("segment_type", "?"), seg["total_size"], seg["stream"] in streams,
+                                    [(b_["state"], b_["size"]) for b_ in seg["blocks"]][:6])
+        if seg["device"] == idx and seg["stream"] in streams:
+            # EVERY inactive block of the step's streams gets a placeholder, whichever segment it sits in: best fit gives a request the smallest free
+            # block that holds it, so with the requests issued largest first each one takes a block of exactly its size -- but WHICH of several equal
+            # (or larger, unclaimed) blocks is the allocator's choice, and a placeholder sized from a provisioned segment's hole that lands in a hole
+            # of another segment leaves the provisioned one to be released (seen in normal runs: one wholly free 16 MiB segment per call).  With every
+            # hole claimed, the placeholders are sorted by where they LANDED: those outside the provisioned segments are dropped before the cache is
+            # emptied (that memory goes back to the driver, as the reference's empty_cache wants), those inside are held across it.
             # A request lands in the pool its SIZE selects (torch's caching allocator: <= 1 MiB -> the small pool of 2 MiB segments, above -> the large
             # pool), whatever segment the hole it was sized from belongs to.  So a placeholder can only pin a hole of its own pool (filtering
             # by block size alone let a >= 1 MiB hole of a small-pool segment ask the LARGE pool for a block -- taking one meant for another
@@ -357,10 +373,19 @@ def empty_cache(device=None):
                     hold.append(torch.empty(n, dtype=torch.uint8, device=device))
                 except RuntimeError:
                     break
+    ranges = sorted((a_, a_ + v_[1]) for a_, v_ in seen.items())
+    import bisect
+    starts = [r_[0] for r_ in ranges]
+
+    def inside(t):
+        q = t.data_ptr()
+        k = bisect.bisect_right(starts, q) - 1
+        return k >= 0 and q < ranges[k][1]
+    hold = [t for t in hold if inside(t)]          # the others are freed here: their (non-provisioned) segments may go
     torch.cuda.empty_cache()
     del hold
-    # best fit may have put a placeholder into a segment that was NOT provisioned and left a provisioned one wholly free (released above): say so
-    # once -- the next step re-reserves it (a device-wide stall), which is what this function exists to avoid
+    # a provisioned segment can still be lost (a hole nothing could hold: under 512 bytes, or under 1 MiB in a large-pool segment): say so once --
+    # the next step re-reserves it (a device-wide stall), which is what this function exists to avoid
     left = {seg["address"] for seg in torch.cuda.memory_snapshot() if seg["device"] == idx}
     lost = [a for a in mine if a not in left]
     if lost:
@@ -372,6 +397,9 @@ def empty_cache(device=None):
             _empty_cache_warned = True
             print(f"[pcrlv2_amd.ops] empty_cache: {len(lost)} of {len(mine)} provisioned segments were released with the cache "
                   "(a placeholder landed elsewhere); they are re-reserved on demand", flush=True)
+            if os.environ.get("PCRL_PROVISION_VERBOSE", "0") == "1":
+                for a_ in lost:
+                    print("    lost segment (type, bytes, on a known stream, first blocks):", seen.get(a_), flush=True)
 
 
 _empty_cache_warned = False
